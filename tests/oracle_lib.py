@@ -1,0 +1,130 @@
+"""ctypes binding of the CPU oracle (oracle/liboracle.so).  TEST INFRASTRUCTURE ONLY."""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_SO = os.path.join(ROOT, "oracle", "liboracle.so")
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "liboracle.so"])
+
+
+def _load():
+    if not os.path.exists(_SO):
+        build()
+    lib = C.CDLL(_SO)
+    u8p = C.POINTER(C.c_uint8)
+    lib.oracle_update.restype = C.c_uint8
+    lib.oracle_update.argtypes = [C.c_void_p, C.c_uint8, C.c_uint8, C.c_void_p]
+    lib.oracle_choices.restype = C.c_uint8
+    lib.oracle_choices.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t]
+    lib.oracle_options_set.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.oracle_init_battle.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
+    lib.oracle_result_from_state.restype = C.c_uint8
+    lib.oracle_result_from_state.argtypes = [C.c_void_p]
+    lib.oracle_randomize_hidden_variables.argtypes = [C.c_void_p, C.c_void_p]
+    lib.oracle_mt19937_seed.argtypes = [C.c_void_p, C.c_uint32]
+    lib.oracle_mt19937_uniform_64.restype = C.c_uint64
+    lib.oracle_mt19937_uniform_64.argtypes = [C.c_void_p]
+    lib.oracle_fast_prng_seed.argtypes = [C.c_void_p, C.c_uint64]
+    lib.oracle_fast_prng_next32.restype = C.c_uint32
+    lib.oracle_fast_prng_next32.argtypes = [C.c_void_p]
+    lib.oracle_fast_prng_uniform_64.restype = C.c_uint64
+    lib.oracle_fast_prng_uniform_64.argtypes = [C.c_void_p]
+    lib.oracle_rollout_fast.restype = C.c_uint8
+    lib.oracle_rollout_fast.argtypes = [C.c_void_p, C.c_void_p, C.c_uint8, C.c_void_p, C.c_uint32, C.c_void_p]
+    lib.oracle_rollout_mt.restype = C.c_uint8
+    lib.oracle_rollout_mt.argtypes = [C.c_void_p, C.c_void_p, C.c_uint8, C.c_void_p, C.c_uint32, C.c_void_p]
+    lib.oracle_rollout_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32,
+                                         C.c_uint32, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+    lib.oracle_set_ou_pools.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    lib.oracle_make_random_ou_battle.restype = C.c_uint8
+    lib.oracle_make_random_ou_battle.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
+    lib.oracle_hash64.restype = C.c_uint64
+    lib.oracle_hash64.argtypes = [C.c_void_p, C.c_size_t]
+    return lib
+
+
+LIB = _load()
+OPTIONS_SIZE = 40
+
+
+def ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Options:
+    def __init__(self, durations=None):
+        self.buf = np.zeros(OPTIONS_SIZE, dtype=np.uint8)
+        if durations is not None:
+            self.buf[16:24] = durations
+
+    @property
+    def actions(self):
+        return self.buf[0:16]
+
+    @property
+    def durations(self):
+        return self.buf[16:24]
+
+    def set(self, durations=None, overrides=None):
+        d = None if durations is None else ptr(np.ascontiguousarray(durations, dtype=np.uint8))
+        o = None if overrides is None else ptr(np.ascontiguousarray(overrides, dtype=np.uint8))
+        LIB.oracle_options_set(ptr(self.buf), d, o)
+
+
+def update(battle, c1, c2, options):
+    return LIB.oracle_update(ptr(battle), c1, c2, ptr(options.buf))
+
+
+def choices(battle, player, request):
+    out = np.zeros(9, dtype=np.uint8)
+    n = LIB.oracle_choices(ptr(battle), player, request, ptr(out), 9)
+    return out[:n].copy()
+
+
+def init_battle(teams, seed):
+    """teams: array-like [2][6][5] (species, 4 moves)."""
+    t = np.ascontiguousarray(np.array(teams, dtype=np.uint8).reshape(60))
+    b = np.zeros(384, dtype=np.uint8)
+    LIB.oracle_init_battle(ptr(b), ptr(t), C.c_uint64(seed))
+    return b
+
+
+_pools_set = False
+
+
+def ensure_pools():
+    global _pools_set
+    if _pools_set:
+        return
+    import sys
+    sys.path.insert(0, ROOT)
+    from oak_amd import gamedata
+    legal, pools, sizes = gamedata.ou_pools()
+    LIB.oracle_set_ou_pools(ptr(legal), len(legal), ptr(np.ascontiguousarray(pools)), ptr(sizes))
+    _pools_set = True
+
+
+def make_random_ou_batch(n, seed0=0x0A4B00000000):
+    """SURVEY 8(d) config 2 inputs: (battles[n,384], durations[n,8], prng[n,8], results[n])."""
+    ensure_pools()
+    battles = np.zeros((n, 384), dtype=np.uint8)
+    durs = np.zeros((n, 8), dtype=np.uint8)
+    prng = np.zeros((n, 8), dtype=np.uint8)
+    res = np.zeros(n, dtype=np.uint8)
+    for i in range(n):
+        res[i] = LIB.oracle_make_random_ou_battle(ptr(battles[i]), ptr(durs[i]), ptr(prng[i]), C.c_uint64(seed0 + i))
+    return battles, durs, prng, res
+
+
+def rollout_batch(battles, durs, results, prng, max_steps=1000, prep=False, threads=1):
+    n = battles.shape[0]
+    out = np.zeros(n, dtype=np.uint8)
+    steps = np.zeros(n, dtype=np.uint32)
+    LIB.oracle_rollout_batch(ptr(battles), ptr(durs), ptr(np.ascontiguousarray(results)), ptr(prng), n,
+                             max_steps, 1 if prep else 0, ptr(out), ptr(steps), threads)
+    return out, steps
