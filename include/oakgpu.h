@@ -1,0 +1,103 @@
+/* include/oakgpu.h -- C ABI of liboakgpu.so (MI355X / gfx950).
+ *
+ * Drop-in boundary for ONE hot path of lab-oak/oak: batched random-playout turn stepping
+ * and MLP leaf evaluation.  Every entry point is plain C (pointers + sizes, no torch / C++
+ * types) so the reference's own FFI layers (C++ headers, pybind11) can bind it directly.
+ * Each function cites the reference interface it replaces; INTEGRATION.md shows the
+ * reference-side glue.
+ *
+ * Conventions
+ *   - `*_dev` functions take DEVICE pointers and enqueue on the context's HIP stream
+ *     without synchronising; the un-suffixed forms take HOST pointers, copy, run, copy
+ *     back and synchronise (PCIe-inclusive; never the benchmarked path).
+ *   - Battles are the reference's 384-byte POD (cpp/include/libpkmn/layout.h:5-31), AoS,
+ *     n x 384 bytes; durations n x 8 bytes (data.h:270-311); choices / results one byte.
+ *   - Return value 0 = success; otherwise a hipError_t-compatible code (or -1 for
+ *     argument errors) and oakgpu_last_error() describes it.  There is NO CPU fallback:
+ *     without a usable HIP device every call fails.
+ */
+#ifndef OAKGPU_H
+#define OAKGPU_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OAKGPU_BATTLE_SIZE 384
+#define OAKGPU_DURATIONS_SIZE 8
+#define OAKGPU_ACTIONS_SIZE 16
+#define OAKGPU_MAX_CHOICES 9
+#define OAKGPU_TEAMS_SIZE 60 /* 2 sides x 6 sets x {species, move x4} */
+
+typedef struct oakgpu_ctx oakgpu_ctx;
+
+int oakgpu_create(oakgpu_ctx **out, int device);
+void oakgpu_destroy(oakgpu_ctx *ctx);
+const char *oakgpu_last_error(void);
+/* Use an existing hipStream_t (e.g. torch's current stream) for all *_dev launches. */
+int oakgpu_set_stream(oakgpu_ctx *ctx, void *hip_stream);
+int oakgpu_synchronize(oakgpu_ctx *ctx);
+int oakgpu_device_count(void);
+
+/* ---- rollout: replaces MCTS::Search::init_stats_and_rollout (search/mcts.h:448-496) and,
+ * with prep != 0, the per-iteration prep of run_root_iteration (mcts.h:250-263:
+ * battle.rng = device.uniform_64(); randomize_hidden_variables (search/durations.h:25-97)).
+ * Device RNG = the reference's fast_prng (util/random.h:67-133), 8 bytes of state per lane,
+ * advanced in place.  Per lane: play uniformly random legal joint choices
+ * (c1 = p1_choices[seed % m]; c2 = p2_choices[(seed >> 32) % n]) until the result type is
+ * non-zero or max_steps turn-steps were made.
+ *   results_out[i] : final pkmn_result byte (type 0 = hit the step cap)
+ *   steps_out[i]   : number of pkmn_gen1_battle_update-equivalent turn-steps executed
+ *   values_out[i]  : 1 / 0 / 0.5 for win / lose / (tie or capped)  (mcts.h:481-495)
+ *   battles_out / durations_out (nullable): final state bytes, for parity checks. */
+int oakgpu_rollout_dev(oakgpu_ctx *ctx, const uint8_t *battles, const uint8_t *durations,
+                       const uint8_t *results_in, uint8_t *prng_state, uint32_t n, uint32_t max_steps,
+                       int prep, uint8_t *results_out, uint32_t *steps_out, float *values_out,
+                       uint8_t *battles_out, uint8_t *durations_out);
+int oakgpu_rollout(oakgpu_ctx *ctx, const uint8_t *battles, const uint8_t *durations,
+                   const uint8_t *results_in, uint8_t *prng_state, uint32_t n, uint32_t max_steps, int prep,
+                   uint8_t *results_out, uint32_t *steps_out, float *values_out, uint8_t *battles_out,
+                   uint8_t *durations_out);
+
+/* ---- batched pkmn_gen1_battle_update (call sites mcts.h:278,350,463,479; wrapper
+ * libpkmn/pkmn.h:106-139).  In place on battles; durations in/out (chance options);
+ * actions (nullable) receives the 16-byte chance-actions key of each update (mcts.h:93-98);
+ * overrides (nullable, n x 16) are the calc damage-roll overrides (mcts.h:575-588). */
+int oakgpu_update_dev(oakgpu_ctx *ctx, uint8_t *battles, const uint8_t *c1, const uint8_t *c2,
+                      uint8_t *durations, uint8_t *actions, const uint8_t *overrides, uint32_t n,
+                      uint8_t *results);
+int oakgpu_update(oakgpu_ctx *ctx, uint8_t *battles, const uint8_t *c1, const uint8_t *c2, uint8_t *durations,
+                  uint8_t *actions, const uint8_t *overrides, uint32_t n, uint8_t *results);
+
+/* ---- batched pkmn_gen1_battle_choices (mcts.h:161-166,337-342; pkmn.h:141-156).
+ * requests come from the per-lane result byte (p1: bits 4-5, p2: bits 6-7).
+ * out: n x 9 bytes, counts: n bytes. */
+int oakgpu_choices_dev(oakgpu_ctx *ctx, const uint8_t *battles, const uint8_t *results, int player,
+                       uint8_t *out, uint8_t *counts, uint32_t n);
+int oakgpu_choices(oakgpu_ctx *ctx, const uint8_t *battles, const uint8_t *results, int player, uint8_t *out,
+                   uint8_t *counts, uint32_t n);
+
+/* ---- batched PKMN::battle(p1, p2, seed) (pkmn.h:50-57, init.h:90-154), level 100 sets.
+ * teams: n x 60 bytes; seeds: n x u64; with first_update != 0 also performs the opening
+ * update(battle, 0, 0) (benchmark.cc:29) and writes its result byte. */
+int oakgpu_init_battles_dev(oakgpu_ctx *ctx, const uint8_t *teams, const uint64_t *seeds, uint32_t n,
+                            int first_update, uint8_t *battles, uint8_t *durations, uint8_t *results);
+int oakgpu_init_battles(oakgpu_ctx *ctx, const uint8_t *teams, const uint64_t *seeds, uint32_t n,
+                        int first_update, uint8_t *battles, uint8_t *durations, uint8_t *results);
+
+/* ---- SURVEY 8(d) config-2 synthetic input: n random OU team pairs generated ON DEVICE.
+ * Lane i: fast_prng::seed(state, seed0 + i); 2 x 6 distinct legal species, min(4, pool)
+ * distinct moves each (legal[next32 % 149], pool[next32 % size], rejection on duplicates);
+ * battle.rng = uniform_64(); opening update(0,0).  prng_state receives the continuing
+ * stream.  ou_legal: 149 species ids; ou_pools: 152 x 48 move ids; ou_sizes: 152. */
+int oakgpu_set_ou_pools(oakgpu_ctx *ctx, const uint8_t *ou_legal, int n_legal, const uint8_t *ou_pools,
+                        const uint8_t *ou_sizes);
+int oakgpu_random_ou_battles_dev(oakgpu_ctx *ctx, uint64_t seed0, uint32_t n, uint8_t *battles,
+                                 uint8_t *durations, uint8_t *prng_state, uint8_t *results);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,55 @@
+"""ctypes loader for liboakgpu.so (the HIP product library).  Fails loudly: there is no CPU
+fallback anywhere in oak_amd -- if the library is missing or no HIP device is usable, calls raise."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liboakgpu.so")
+
+# every symbol include/oakgpu.h declares (checked by tests/test_abi.py)
+SYMBOLS = [
+    "oakgpu_create", "oakgpu_destroy", "oakgpu_last_error", "oakgpu_set_stream", "oakgpu_synchronize",
+    "oakgpu_device_count", "oakgpu_rollout_dev", "oakgpu_rollout", "oakgpu_update_dev", "oakgpu_update",
+    "oakgpu_choices_dev", "oakgpu_choices", "oakgpu_init_battles_dev", "oakgpu_init_battles",
+    "oakgpu_set_ou_pools", "oakgpu_random_ou_battles_dev",
+]
+
+_lib = None
+
+
+class OakGpuError(RuntimeError):
+    pass
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise OakGpuError("liboakgpu.so not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+    lib = C.CDLL(LIB_PATH)
+    vp, u32, u64, i32 = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int
+    lib.oakgpu_create.argtypes = [C.POINTER(vp), i32]
+    lib.oakgpu_destroy.argtypes = [vp]
+    lib.oakgpu_destroy.restype = None
+    lib.oakgpu_last_error.restype = C.c_char_p
+    lib.oakgpu_set_stream.argtypes = [vp, vp]
+    lib.oakgpu_synchronize.argtypes = [vp]
+    lib.oakgpu_rollout_dev.argtypes = [vp, vp, vp, vp, vp, u32, u32, i32, vp, vp, vp, vp, vp]
+    lib.oakgpu_rollout.argtypes = [vp, vp, vp, vp, vp, u32, u32, i32, vp, vp, vp, vp, vp]
+    lib.oakgpu_update_dev.argtypes = [vp, vp, vp, vp, vp, vp, vp, u32, vp]
+    lib.oakgpu_update.argtypes = [vp, vp, vp, vp, vp, vp, vp, u32, vp]
+    lib.oakgpu_choices_dev.argtypes = [vp, vp, vp, i32, vp, vp, u32]
+    lib.oakgpu_choices.argtypes = [vp, vp, vp, i32, vp, vp, u32]
+    lib.oakgpu_init_battles_dev.argtypes = [vp, vp, vp, u32, i32, vp, vp, vp]
+    lib.oakgpu_init_battles.argtypes = [vp, vp, vp, u32, i32, vp, vp, vp]
+    lib.oakgpu_set_ou_pools.argtypes = [vp, vp, i32, vp, vp]
+    lib.oakgpu_random_ou_battles_dev.argtypes = [vp, u64, u32, vp, vp, vp, vp]
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != 0:
+        raise OakGpuError("liboakgpu: %s (code %d)" % (load().oakgpu_last_error().decode(), rc))

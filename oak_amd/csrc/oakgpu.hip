@@ -1,0 +1,645 @@
+// oak_amd/csrc/oakgpu.hip -- HIP kernels (gfx950) + the C ABI of include/oakgpu.h.
+//
+// K1  k_rollout   : batched random playouts (replaces cpp/include/search/mcts.h:448-496 and
+//                   the per-iteration prep of mcts.h:250-263): one lane per playout, the
+//                   384-byte battle resident in LDS (lane-interleaved) for the whole playout,
+//                   tables in LDS, choice RNG (fast_prng) and durations in registers.
+//     k_update    : batched pkmn_gen1_battle_update (+ chance durations / actions / calc).
+//     k_choices   : batched pkmn_gen1_battle_choices.
+//     k_init      : batched PKMN::battle (cpp/include/libpkmn/init.h:90-154) + opening update.
+//     k_random_ou : SURVEY 8(d) config-2 input generator (teams drawn on device).
+// There is no CPU fallback in this library.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <string>
+
+#include "../../include/oakgpu.h"
+#include "gen1_device.hpp"
+
+namespace oak {
+
+constexpr int BLOCK = 256;      // 4 waves: one per SIMD of a CU
+constexpr int STATE_WORDS = 96; // 384-byte battle
+constexpr int STATE_LDS_BYTES = STATE_WORDS * BLOCK * 4;
+constexpr int TABLE_LDS_PAD = (TABLE_LDS_BYTES + 15) & ~15;
+constexpr int ENGINE_LDS_BYTES = STATE_LDS_BYTES + TABLE_LDS_PAD;
+
+__device__ __forceinline__ Tables stage_default_tables(uint8_t *lds) {
+  return stage_tables(lds, OAK_MOVE_WORDS, OAK_MOVE_MAXPP, OAK_SPECIES_W0, OAK_SPECIES_W1, OAK_TYPE_CHART, OAK_BOOSTS);
+}
+
+// AoS (n x 384 B, 4-byte aligned) <-> lane-interleaved LDS, whole workgroup cooperating.
+__device__ __forceinline__ void load_state(uint32_t *state, const uint8_t *battles, uint32_t base, uint32_t count) {
+  const uint32_t *src = (const uint32_t *)battles + (size_t)base * STATE_WORDS;
+  for (uint32_t i = threadIdx.x; i < count * STATE_WORDS; i += BLOCK) {
+    uint32_t b = i / STATE_WORDS, w = i - b * STATE_WORDS;
+    state[w * BLOCK + b] = src[i];
+  }
+}
+__device__ __forceinline__ void store_state(const uint32_t *state, uint8_t *battles, uint32_t base, uint32_t count) {
+  uint32_t *dst = (uint32_t *)battles + (size_t)base * STATE_WORDS;
+  for (uint32_t i = threadIdx.x; i < count * STATE_WORDS; i += BLOCK) {
+    uint32_t b = i / STATE_WORDS, w = i - b * STATE_WORDS;
+    dst[i] = state[w * BLOCK + b];
+  }
+}
+
+// ---- fast_prng (cpp/include/util/random.h:67-133): 2 x u32 of state per lane ---------------
+struct FastPrng {
+  uint32_t s0, s1;
+  __device__ __forceinline__ static uint32_t rotl(uint32_t x, int k) { return (x << k) | (x >> (32 - k)); }
+  __device__ __forceinline__ uint32_t next32() {
+    uint32_t result = rotl(s0 + s1, 9) + s0;
+    s1 ^= s0;
+    s0 = rotl(s0, 13) ^ s1 ^ (s1 << 5);
+    s1 = rotl(s1, 28);
+    return result;
+  }
+  // std::seed_seq{lo32, hi32}.generate(2 words), random.h:99-105
+  __device__ void seed(uint64_t seed) {
+    const uint32_t v[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+    uint32_t b0 = 0x8b8b8b8bu, b1 = 0x8b8b8b8bu;
+    // n = 2, s = 2, t = 0, p = q = 1, m = 3; indices alternate between the two words
+#pragma unroll
+    for (uint32_t k = 0; k < 3; ++k) {
+      uint32_t &bk = (k & 1) ? b1 : b0, &bo = (k & 1) ? b0 : b1; // bk = b[k%2], bo = b[(k+1)%2] = b[(k-1)%2]
+      uint32_t arg = bk ^ bo ^ bo;
+      uint32_t r1 = 1664525u * (arg ^ (arg >> 27));
+      uint32_t r2 = r1 + (k == 0 ? 2u : (k & 1) + v[k - 1 < 2 ? k - 1 : 0]);
+      bo += r1;
+      bo += r2;
+      bk = r2;
+    }
+#pragma unroll
+    for (uint32_t k = 3; k < 5; ++k) {
+      uint32_t &bk = (k & 1) ? b1 : b0, &bo = (k & 1) ? b0 : b1;
+      uint32_t arg = bk + bo + bo;
+      uint32_t r3 = 1566083941u * (arg ^ (arg >> 27));
+      uint32_t r4 = r3 - (k & 1);
+      bo ^= r3;
+      bo ^= r4;
+      bk = r4;
+    }
+    s0 = b0;
+    s1 = b1;
+  }
+};
+
+__device__ __forceinline__ uint32_t mod64_small(uint32_t hi, uint32_t lo, uint32_t m) {
+  // (hi * 2^32 + lo) % m for small m, 32-bit ops only
+  uint32_t two32 = (0xFFFFFFFFu % m + 1) % m;
+  return ((hi % m) * two32 + (lo % m)) % m;
+}
+
+// ---- MCTS::randomize_hidden_variables (cpp/include/search/durations.h:25-97) ---------------
+template <class E>
+__device__ void randomize_hidden(E &e) {
+  // rows of the reference's 4 x 40 binding table as run lengths: {15,15,6,4} {24,8,8} {20,20} {40}
+  const uint32_t hi = e.r32(B_RNG + 4), lo = e.r32(B_RNG);
+  for (int s = 0; s < 2; ++s) {
+    const int so = s * SIDE_SZ;
+    const uint32_t d = e.dur[s];
+    const uint32_t confusion = (d >> 18) & 7, disable = (d >> 21) & 15, attacking = (d >> 25) & 7, binding = (d >> 28) & 7;
+    if (confusion) {
+      uint32_t one = confusion == 1;
+      uint32_t max = (6 - (confusion + one)) & 0xFF;
+      e.set_conf_left(so, (mod64_small(hi, lo, max) + 1 + one) & 0xFF);
+    }
+    if (disable) e.set_disable_left(so, (mod64_small(hi, lo, (9 - disable) & 0xFF) + 1) & 0xFF);
+    if (attacking && (e.vlo(so) & (V_BIDE | V_THRASHING)))
+      e.set_attacks(so, attacking == 3 ? 1u : 4u - (attacking + mod64_small(hi, lo, 2)));
+    if (binding) {
+      uint32_t idx = mod64_small(hi, lo, 40), a;
+      if (binding == 1) a = idx < 15 ? 1 : idx < 30 ? 2 : idx < 36 ? 3 : 4;
+      else if (binding == 2) a = idx < 24 ? 1 : idx < 32 ? 2 : 3;
+      else if (binding == 3) a = idx < 20 ? 1 : 2;
+      else a = 1;
+      e.set_attacks(so, a);
+    }
+    for (int i = 0; i < 6; ++i) {
+      uint32_t sleep = (d >> (3 * i)) & 7;
+      if (!sleep) continue;
+      int pk = so + PK_SZ * ((int)e.r8(so + O_ORDER + i) - 1);
+      uint32_t st = e.r8(pk + P_STATUS);
+      if ((st & 7) && !(st & 0x80)) e.w8(pk + P_STATUS, (st & 0xF8) | ((mod64_small(hi, lo, (8 - sleep) & 0xFF) + 1) & 0xFF));
+    }
+  }
+}
+
+// ---- K1: random playouts -------------------------------------------------------------------
+struct RolloutArgs {
+  const uint8_t *battles;
+  const uint8_t *durations;
+  const uint8_t *results_in;
+  uint8_t *prng;
+  uint32_t n, max_steps;
+  int prep;
+  uint8_t *results_out;
+  uint32_t *steps_out;
+  float *values_out;
+  uint8_t *battles_out;
+  uint8_t *durations_out;
+};
+
+__global__ __launch_bounds__(BLOCK) void k_rollout(RolloutArgs a) {
+  extern __shared__ __align__(16) uint8_t smem[];
+  uint32_t *state = (uint32_t *)smem;
+  Tables T = stage_default_tables(smem + STATE_LDS_BYTES);
+  const uint32_t base = blockIdx.x * BLOCK;
+  const uint32_t count = min((uint32_t)BLOCK, a.n - base);
+  load_state(state, a.battles, base, count);
+  __syncthreads();
+  const uint32_t tid = threadIdx.x, lane = base + tid;
+  if (tid < count) {
+    Engine<BLOCK, false> e;
+    e.m = state + tid;
+    e.T = T;
+    const uint32_t *dsrc = (const uint32_t *)a.durations + 2 * (size_t)lane;
+    e.dur[0] = dsrc[0];
+    e.dur[1] = dsrc[1];
+    e.over[0] = e.over[1] = 0;
+    FastPrng g;
+    const uint32_t *psrc = (const uint32_t *)a.prng + 2 * (size_t)lane;
+    g.s0 = psrc[0];
+    g.s1 = psrc[1];
+    if (a.prep) { // mcts.h:254-259
+      uint32_t hi = g.next32(), lo = g.next32();
+      e.w32(B_RNG, lo);
+      e.w32(B_RNG + 4, hi);
+      randomize_hidden(e);
+    }
+    uint32_t result = a.results_in[lane];
+    uint32_t steps = 0;
+    while ((result & 15) == 0 && steps < a.max_steps) {
+      const uint32_t hi = g.next32(), lo = g.next32(); // uniform_64 = hi << 32 | lo
+      auto c1s = e.choices(0, (result >> 4) & 3);
+      const uint32_t c1 = c1s.get(mod64_small(hi, lo, c1s.n));
+      auto c2s = e.choices(1, (result >> 6) & 3);
+      const uint32_t c2 = c2s.get(hi % c2s.n);
+      result = e.update(c1, c2);
+      ++steps;
+    }
+    a.results_out[lane] = (uint8_t)result;
+    a.steps_out[lane] = steps;
+    const uint32_t t = result & 15;
+    a.values_out[lane] = t == R_WIN ? 1.0f : t == R_LOSE ? 0.0f : 0.5f;
+    uint32_t *pdst = (uint32_t *)a.prng + 2 * (size_t)lane;
+    pdst[0] = g.s0;
+    pdst[1] = g.s1;
+    if (a.durations_out) {
+      uint32_t *ddst = (uint32_t *)a.durations_out + 2 * (size_t)lane;
+      ddst[0] = e.dur[0];
+      ddst[1] = e.dur[1];
+    }
+  }
+  if (a.battles_out) {
+    __syncthreads();
+    store_state(state, a.battles_out, base, count);
+  }
+}
+
+// ---- batched single update -------------------------------------------------------------------
+__global__ __launch_bounds__(BLOCK) void k_update(uint8_t *battles, const uint8_t *c1, const uint8_t *c2,
+                                                  uint8_t *durations, uint8_t *actions, const uint8_t *overrides,
+                                                  uint32_t n, uint8_t *results) {
+  extern __shared__ __align__(16) uint8_t smem[];
+  uint32_t *state = (uint32_t *)smem;
+  Tables T = stage_default_tables(smem + STATE_LDS_BYTES);
+  const uint32_t base = blockIdx.x * BLOCK;
+  const uint32_t count = min((uint32_t)BLOCK, n - base);
+  load_state(state, battles, base, count);
+  __syncthreads();
+  const uint32_t tid = threadIdx.x, lane = base + tid;
+  if (tid < count) {
+    Engine<BLOCK, true> e;
+    e.m = state + tid;
+    e.T = T;
+    uint32_t *d = (uint32_t *)durations + 2 * (size_t)lane;
+    e.dur[0] = d[0];
+    e.dur[1] = d[1];
+    e.over[0] = overrides ? overrides[(size_t)lane * 16] : 0;
+    e.over[1] = overrides ? overrides[(size_t)lane * 16 + 8] : 0;
+    e.act[0] = e.act[1] = 0;
+    results[lane] = (uint8_t)e.update(c1[lane], c2[lane]);
+    d[0] = e.dur[0];
+    d[1] = e.dur[1];
+    if (actions) {
+      uint64_t *ad = (uint64_t *)actions + 2 * (size_t)lane;
+      ad[0] = e.act[0];
+      ad[1] = e.act[1];
+    }
+  }
+  __syncthreads();
+  store_state(state, battles, base, count);
+}
+
+__global__ __launch_bounds__(BLOCK) void k_choices(const uint8_t *battles, const uint8_t *results, int player,
+                                                   uint8_t *out, uint8_t *counts, uint32_t n) {
+  extern __shared__ __align__(16) uint8_t smem[];
+  uint32_t *state = (uint32_t *)smem;
+  const uint32_t base = blockIdx.x * BLOCK;
+  const uint32_t count = min((uint32_t)BLOCK, n - base);
+  load_state(state, battles, base, count);
+  __syncthreads();
+  const uint32_t tid = threadIdx.x, lane = base + tid;
+  if (tid < count) {
+    Engine<BLOCK, false> e;
+    e.m = state + tid;
+    const uint32_t r = results[lane];
+    auto c = e.choices(player, player == 0 ? (r >> 4) & 3 : (r >> 6) & 3);
+    counts[lane] = (uint8_t)c.n;
+    for (uint32_t i = 0; i < OAKGPU_MAX_CHOICES; ++i) out[(size_t)lane * OAKGPU_MAX_CHOICES + i] = i < c.n ? (uint8_t)c.get(i) : 0;
+  }
+}
+
+// ---- PKMN::battle / Init::init_side (cpp/include/libpkmn/init.h:35-40,90-154) ---------------
+template <class E>
+__device__ void init_from_teams(E &e, const uint8_t *teams /* 60 B, this lane */, uint32_t seed_lo, uint32_t seed_hi) {
+  for (int w = 0; w < STATE_WORDS; ++w) e.w32(4 * w, 0);
+  for (int s = 0; s < 2; ++s) {
+    const int so = s * SIDE_SZ;
+    for (int i = 0; i < 6; ++i) {
+      const uint8_t *set = teams + (s * 6 + i) * 5;
+      const int pk = so + PK_SZ * i;
+      const uint32_t sp = set[0];
+      e.w8(pk + P_SPECIES, sp);
+      if (sp == 0) { if (i == 0) e.w8(so + O_ORDER, 1); continue; }
+      const uint32_t w0 = e.T.sp0[sp], w1 = e.T.sp1[sp];
+      const uint32_t level = 100;
+      auto stat = [&](uint32_t base, bool hp) { return (2 * (base + 15) + 63) * level / 100 + (hp ? level + 10 : 5); };
+      const uint32_t hp = stat(w0 & 0xFF, true);
+      e.w16(pk + P_HP_MAX, hp);
+      e.w16(pk + P_ATK, stat((w0 >> 8) & 0xFF, false));
+      e.w16(pk + P_DEF, stat((w0 >> 16) & 0xFF, false));
+      e.w16(pk + P_SPE, stat(w0 >> 24, false));
+      e.w16(pk + P_SPC, stat(w1 & 0xFF, false));
+      for (int mi = 0; mi < 4; ++mi) {
+        const uint32_t id = set[1 + mi];
+        e.w8(pk + P_MOVES + 2 * mi, id);
+        e.w8(pk + P_MOVES + 2 * mi + 1, id ? e.T.maxpp[id] : 0);
+      }
+      e.w16(pk + P_HP, hp);
+      e.w8(pk + P_TYPES, ((w1 >> 8) & 0xFF) | (((w1 >> 16) & 0xFF) << 4));
+      e.w8(pk + P_LEVEL, level);
+      e.w8(so + O_ORDER + i, i + 1);
+    }
+  }
+  e.w32(B_RNG, seed_lo);
+  e.w32(B_RNG + 4, seed_hi);
+}
+
+__global__ __launch_bounds__(BLOCK) void k_init(const uint8_t *teams, const uint64_t *seeds, uint32_t n, int first_update,
+                                                uint8_t *battles, uint8_t *durations, uint8_t *results) {
+  extern __shared__ __align__(16) uint8_t smem[];
+  uint32_t *state = (uint32_t *)smem;
+  Tables T = stage_default_tables(smem + STATE_LDS_BYTES);
+  __syncthreads();
+  const uint32_t base = blockIdx.x * BLOCK;
+  const uint32_t count = min((uint32_t)BLOCK, n - base);
+  const uint32_t tid = threadIdx.x, lane = base + tid;
+  if (tid < count) {
+    Engine<BLOCK, false> e;
+    e.m = state + tid;
+    e.T = T;
+    e.dur[0] = e.dur[1] = 0;
+    e.over[0] = e.over[1] = 0;
+    const uint64_t sd = seeds[lane];
+    init_from_teams(e, teams + (size_t)lane * OAKGPU_TEAMS_SIZE, (uint32_t)sd, (uint32_t)(sd >> 32));
+    uint32_t r = mk_result(0, C_MOVE, C_MOVE);
+    if (first_update) r = e.update(0, 0);
+    if (results) results[lane] = (uint8_t)r;
+    if (durations) {
+      uint32_t *d = (uint32_t *)durations + 2 * (size_t)lane;
+      d[0] = e.dur[0];
+      d[1] = e.dur[1];
+    }
+  }
+  __syncthreads();
+  store_state(state, battles, base, count);
+}
+
+__global__ __launch_bounds__(BLOCK) void k_random_ou(uint64_t seed0, uint32_t n, const uint8_t *legal, int n_legal,
+                                                     const uint8_t *pools, const uint8_t *sizes, uint8_t *battles,
+                                                     uint8_t *durations, uint8_t *prng, uint8_t *results) {
+  extern __shared__ __align__(16) uint8_t smem[];
+  uint32_t *state = (uint32_t *)smem;
+  Tables T = stage_default_tables(smem + STATE_LDS_BYTES);
+  __syncthreads();
+  const uint32_t base = blockIdx.x * BLOCK;
+  const uint32_t count = min((uint32_t)BLOCK, n - base);
+  const uint32_t tid = threadIdx.x, lane = base + tid;
+  if (tid < count) {
+    Engine<BLOCK, false> e;
+    e.m = state + tid;
+    e.T = T;
+    e.dur[0] = e.dur[1] = 0;
+    e.over[0] = e.over[1] = 0;
+    FastPrng g;
+    g.seed(seed0 + lane);
+    uint8_t teams[OAKGPU_TEAMS_SIZE];
+    for (int i = 0; i < OAKGPU_TEAMS_SIZE; ++i) teams[i] = 0;
+    for (int s = 0; s < 2; ++s)
+      for (int k = 0; k < 6; ++k) {
+        uint32_t sp;
+        for (;;) {
+          sp = legal[g.next32() % (uint32_t)n_legal];
+          bool dup = false;
+          for (int j = 0; j < k; ++j) dup |= teams[(s * 6 + j) * 5] == sp;
+          if (!dup) break;
+        }
+        uint8_t *set = teams + (s * 6 + k) * 5;
+        set[0] = (uint8_t)sp;
+        const uint32_t psz = sizes[sp];
+        const uint32_t want = psz < 4 ? psz : 4;
+        for (uint32_t mi = 0; mi < want; ++mi) {
+          for (;;) {
+            uint32_t mvid = pools[sp * 48 + g.next32() % psz];
+            bool dup = false;
+            for (uint32_t j = 0; j < mi; ++j) dup |= set[1 + j] == mvid;
+            if (!dup) { set[1 + mi] = (uint8_t)mvid; break; }
+          }
+        }
+      }
+    const uint32_t hi = g.next32(), lo = g.next32();
+    init_from_teams(e, teams, lo, hi);
+    const uint32_t r = e.update(0, 0);
+    results[lane] = (uint8_t)r;
+    uint32_t *d = (uint32_t *)durations + 2 * (size_t)lane;
+    d[0] = e.dur[0];
+    d[1] = e.dur[1];
+    uint32_t *pd = (uint32_t *)prng + 2 * (size_t)lane;
+    pd[0] = g.s0;
+    pd[1] = g.s1;
+  }
+  __syncthreads();
+  store_state(state, battles, base, count);
+}
+
+} // namespace oak
+
+// =================================== C ABI ==================================================
+struct oakgpu_ctx {
+  int device;
+  hipStream_t stream;
+  bool own_stream;
+  uint8_t *d_legal, *d_pools, *d_sizes;
+  int n_legal;
+};
+
+static thread_local std::string g_err;
+static int fail(hipError_t e, const char *what) {
+  g_err = std::string(what) + ": " + hipGetErrorString(e);
+  return (int)e;
+}
+static int bad(const char *what) {
+  g_err = what;
+  return -1;
+}
+#define HIPCHK(x) do { hipError_t _e = (x); if (_e != hipSuccess) return fail(_e, #x); } while (0)
+
+extern "C" {
+
+const char *oakgpu_last_error(void) { return g_err.c_str(); }
+
+int oakgpu_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+static int set_lds_limits() {
+  HIPCHK(hipFuncSetAttribute((const void *)oak::k_rollout, hipFuncAttributeMaxDynamicSharedMemorySize, oak::ENGINE_LDS_BYTES));
+  HIPCHK(hipFuncSetAttribute((const void *)oak::k_update, hipFuncAttributeMaxDynamicSharedMemorySize, oak::ENGINE_LDS_BYTES));
+  HIPCHK(hipFuncSetAttribute((const void *)oak::k_choices, hipFuncAttributeMaxDynamicSharedMemorySize, oak::ENGINE_LDS_BYTES));
+  HIPCHK(hipFuncSetAttribute((const void *)oak::k_init, hipFuncAttributeMaxDynamicSharedMemorySize, oak::ENGINE_LDS_BYTES));
+  HIPCHK(hipFuncSetAttribute((const void *)oak::k_random_ou, hipFuncAttributeMaxDynamicSharedMemorySize, oak::ENGINE_LDS_BYTES));
+  return 0;
+}
+
+int oakgpu_create(oakgpu_ctx **out, int device) {
+  if (!out) return bad("oakgpu_create: null out");
+  int n = 0;
+  HIPCHK(hipGetDeviceCount(&n));
+  if (n <= 0) return bad("oakgpu_create: no HIP device (this library has no CPU fallback)");
+  if (device < 0 || device >= n) return bad("oakgpu_create: device index out of range");
+  HIPCHK(hipSetDevice(device));
+  if (int r = set_lds_limits()) return r;
+  oakgpu_ctx *c = new oakgpu_ctx();
+  c->device = device;
+  c->own_stream = true;
+  c->d_legal = c->d_pools = c->d_sizes = nullptr;
+  c->n_legal = 0;
+  hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+  if (e != hipSuccess) { delete c; return fail(e, "hipStreamCreate"); }
+  *out = c;
+  return 0;
+}
+
+void oakgpu_destroy(oakgpu_ctx *c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  if (c->own_stream) (void)hipStreamDestroy(c->stream);
+  if (c->d_legal) (void)hipFree(c->d_legal);
+  if (c->d_pools) (void)hipFree(c->d_pools);
+  if (c->d_sizes) (void)hipFree(c->d_sizes);
+  delete c;
+}
+
+int oakgpu_set_stream(oakgpu_ctx *c, void *hip_stream) {
+  if (!c) return bad("null ctx");
+  if (c->own_stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
+  c->stream = (hipStream_t)hip_stream;
+  c->own_stream = false;
+  return 0;
+}
+
+int oakgpu_synchronize(oakgpu_ctx *c) {
+  if (!c) return bad("null ctx");
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+static inline uint32_t grid_for(uint32_t n) { return (n + oak::BLOCK - 1) / oak::BLOCK; }
+
+int oakgpu_rollout_dev(oakgpu_ctx *c, const uint8_t *battles, const uint8_t *durations, const uint8_t *results_in,
+                       uint8_t *prng_state, uint32_t n, uint32_t max_steps, int prep, uint8_t *results_out,
+                       uint32_t *steps_out, float *values_out, uint8_t *battles_out, uint8_t *durations_out) {
+  if (!c) return bad("null ctx");
+  if (n == 0) return 0;
+  if (!battles || !durations || !results_in || !prng_state || !results_out || !steps_out || !values_out)
+    return bad("oakgpu_rollout_dev: null required pointer");
+  oak::RolloutArgs a{battles, durations, results_in, prng_state, n, max_steps, prep, results_out, steps_out, values_out,
+                     battles_out, durations_out};
+  hipLaunchKernelGGL(oak::k_rollout, dim3(grid_for(n)), dim3(oak::BLOCK), oak::ENGINE_LDS_BYTES, c->stream, a);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int oakgpu_update_dev(oakgpu_ctx *c, uint8_t *battles, const uint8_t *c1, const uint8_t *c2, uint8_t *durations,
+                      uint8_t *actions, const uint8_t *overrides, uint32_t n, uint8_t *results) {
+  if (!c) return bad("null ctx");
+  if (n == 0) return 0;
+  if (!battles || !c1 || !c2 || !durations || !results) return bad("oakgpu_update_dev: null required pointer");
+  hipLaunchKernelGGL(oak::k_update, dim3(grid_for(n)), dim3(oak::BLOCK), oak::ENGINE_LDS_BYTES, c->stream, battles, c1, c2,
+                     durations, actions, overrides, n, results);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int oakgpu_choices_dev(oakgpu_ctx *c, const uint8_t *battles, const uint8_t *results, int player, uint8_t *out,
+                       uint8_t *counts, uint32_t n) {
+  if (!c) return bad("null ctx");
+  if (n == 0) return 0;
+  if (!battles || !results || !out || !counts || player < 0 || player > 1) return bad("oakgpu_choices_dev: bad argument");
+  hipLaunchKernelGGL(oak::k_choices, dim3(grid_for(n)), dim3(oak::BLOCK), oak::ENGINE_LDS_BYTES, c->stream, battles, results,
+                     player, out, counts, n);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int oakgpu_init_battles_dev(oakgpu_ctx *c, const uint8_t *teams, const uint64_t *seeds, uint32_t n, int first_update,
+                            uint8_t *battles, uint8_t *durations, uint8_t *results) {
+  if (!c) return bad("null ctx");
+  if (n == 0) return 0;
+  if (!teams || !seeds || !battles) return bad("oakgpu_init_battles_dev: null required pointer");
+  hipLaunchKernelGGL(oak::k_init, dim3(grid_for(n)), dim3(oak::BLOCK), oak::ENGINE_LDS_BYTES, c->stream, teams, seeds, n,
+                     first_update, battles, durations, results);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int oakgpu_set_ou_pools(oakgpu_ctx *c, const uint8_t *legal, int n_legal, const uint8_t *pools, const uint8_t *sizes) {
+  if (!c || !legal || !pools || !sizes || n_legal <= 0 || n_legal > 152) return bad("oakgpu_set_ou_pools: bad argument");
+  HIPCHK(hipSetDevice(c->device));
+  if (!c->d_legal) {
+    HIPCHK(hipMalloc((void **)&c->d_legal, 152));
+    HIPCHK(hipMalloc((void **)&c->d_pools, 152 * 48));
+    HIPCHK(hipMalloc((void **)&c->d_sizes, 152));
+  }
+  HIPCHK(hipMemcpy(c->d_legal, legal, (size_t)n_legal, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(c->d_pools, pools, 152 * 48, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(c->d_sizes, sizes, 152, hipMemcpyHostToDevice));
+  c->n_legal = n_legal;
+  return 0;
+}
+
+int oakgpu_random_ou_battles_dev(oakgpu_ctx *c, uint64_t seed0, uint32_t n, uint8_t *battles, uint8_t *durations,
+                                 uint8_t *prng_state, uint8_t *results) {
+  if (!c) return bad("null ctx");
+  if (!c->d_legal) return bad("oakgpu_random_ou_battles_dev: call oakgpu_set_ou_pools first");
+  if (n == 0) return 0;
+  if (!battles || !durations || !prng_state || !results) return bad("oakgpu_random_ou_battles_dev: null pointer");
+  hipLaunchKernelGGL(oak::k_random_ou, dim3(grid_for(n)), dim3(oak::BLOCK), oak::ENGINE_LDS_BYTES, c->stream, seed0, n,
+                     c->d_legal, c->n_legal, c->d_pools, c->d_sizes, battles, durations, prng_state, results);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// ---- host-buffer conveniences (PCIe-inclusive; never the benchmarked path) ------------------
+namespace {
+struct DevBuf {
+  void *p = nullptr;
+  size_t bytes = 0;
+  hipError_t alloc(size_t b) { bytes = b; return b ? hipMalloc(&p, b) : hipSuccess; }
+  ~DevBuf() { if (p) (void)hipFree(p); }
+};
+} // namespace
+#define UP(buf, host, nbytes) do { HIPCHK((buf).alloc(nbytes)); if (host) HIPCHK(hipMemcpyAsync((buf).p, host, nbytes, hipMemcpyHostToDevice, c->stream)); } while (0)
+#define DOWN(host, buf) do { if (host) HIPCHK(hipMemcpyAsync(host, (buf).p, (buf).bytes, hipMemcpyDeviceToHost, c->stream)); } while (0)
+
+int oakgpu_rollout(oakgpu_ctx *c, const uint8_t *battles, const uint8_t *durations, const uint8_t *results_in,
+                   uint8_t *prng_state, uint32_t n, uint32_t max_steps, int prep, uint8_t *results_out, uint32_t *steps_out,
+                   float *values_out, uint8_t *battles_out, uint8_t *durations_out) {
+  if (!c) return bad("null ctx");
+  if (n == 0) return 0;
+  HIPCHK(hipSetDevice(c->device));
+  DevBuf b, d, ri, pr, ro, st, va, bo, dd;
+  UP(b, battles, (size_t)n * 384);
+  UP(d, durations, (size_t)n * 8);
+  UP(ri, results_in, n);
+  UP(pr, prng_state, (size_t)n * 8);
+  UP(ro, (const void *)nullptr, n);
+  UP(st, (const void *)nullptr, (size_t)n * 4);
+  UP(va, (const void *)nullptr, (size_t)n * 4);
+  if (battles_out) UP(bo, (const void *)nullptr, (size_t)n * 384);
+  if (durations_out) UP(dd, (const void *)nullptr, (size_t)n * 8);
+  int r = oakgpu_rollout_dev(c, (uint8_t *)b.p, (uint8_t *)d.p, (uint8_t *)ri.p, (uint8_t *)pr.p, n, max_steps, prep,
+                             (uint8_t *)ro.p, (uint32_t *)st.p, (float *)va.p, (uint8_t *)bo.p, (uint8_t *)dd.p);
+  if (r) return r;
+  DOWN(results_out, ro);
+  DOWN(steps_out, st);
+  DOWN(values_out, va);
+  DOWN(prng_state, pr);
+  DOWN(battles_out, bo);
+  DOWN(durations_out, dd);
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+int oakgpu_update(oakgpu_ctx *c, uint8_t *battles, const uint8_t *c1, const uint8_t *c2, uint8_t *durations, uint8_t *actions,
+                  const uint8_t *overrides, uint32_t n, uint8_t *results) {
+  if (!c) return bad("null ctx");
+  if (n == 0) return 0;
+  HIPCHK(hipSetDevice(c->device));
+  DevBuf b, a1, a2, d, ac, ov, rs;
+  UP(b, battles, (size_t)n * 384);
+  UP(a1, c1, n);
+  UP(a2, c2, n);
+  UP(d, durations, (size_t)n * 8);
+  if (actions) UP(ac, (const void *)nullptr, (size_t)n * 16);
+  if (overrides) UP(ov, overrides, (size_t)n * 16);
+  UP(rs, (const void *)nullptr, n);
+  int r = oakgpu_update_dev(c, (uint8_t *)b.p, (uint8_t *)a1.p, (uint8_t *)a2.p, (uint8_t *)d.p, (uint8_t *)ac.p,
+                            (uint8_t *)ov.p, n, (uint8_t *)rs.p);
+  if (r) return r;
+  DOWN(battles, b);
+  DOWN(durations, d);
+  DOWN(actions, ac);
+  DOWN(results, rs);
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+int oakgpu_choices(oakgpu_ctx *c, const uint8_t *battles, const uint8_t *results, int player, uint8_t *out, uint8_t *counts,
+                   uint32_t n) {
+  if (!c) return bad("null ctx");
+  if (n == 0) return 0;
+  HIPCHK(hipSetDevice(c->device));
+  DevBuf b, rs, o, cn;
+  UP(b, battles, (size_t)n * 384);
+  UP(rs, results, n);
+  UP(o, (const void *)nullptr, (size_t)n * 9);
+  UP(cn, (const void *)nullptr, n);
+  int r = oakgpu_choices_dev(c, (uint8_t *)b.p, (uint8_t *)rs.p, player, (uint8_t *)o.p, (uint8_t *)cn.p, n);
+  if (r) return r;
+  DOWN(out, o);
+  DOWN(counts, cn);
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+int oakgpu_init_battles(oakgpu_ctx *c, const uint8_t *teams, const uint64_t *seeds, uint32_t n, int first_update,
+                        uint8_t *battles, uint8_t *durations, uint8_t *results) {
+  if (!c) return bad("null ctx");
+  if (n == 0) return 0;
+  HIPCHK(hipSetDevice(c->device));
+  DevBuf t, s, b, d, rs;
+  UP(t, teams, (size_t)n * 60);
+  UP(s, seeds, (size_t)n * 8);
+  UP(b, (const void *)nullptr, (size_t)n * 384);
+  UP(d, (const void *)nullptr, (size_t)n * 8);
+  UP(rs, (const void *)nullptr, n);
+  int r = oakgpu_init_battles_dev(c, (uint8_t *)t.p, (uint64_t *)s.p, n, first_update, (uint8_t *)b.p, (uint8_t *)d.p,
+                                  (uint8_t *)rs.p);
+  if (r) return r;
+  DOWN(battles, b);
+  DOWN(durations, d);
+  DOWN(results, rs);
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+} // extern "C"

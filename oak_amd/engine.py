@@ -1,0 +1,114 @@
+"""Host-side mirror of the reference's search-node surface for the rollout / update path.
+
+Names follow the reference (pyoak: `update`, `parse_battle`; libpkmn: `choices`; MCTS:
+`rollout`) but every call is batched: arrays carry one battle per row.  All compute goes
+through the C ABI of liboakgpu.so (include/oakgpu.h); nothing here computes on the CPU.
+
+  Context.rollout(...)   <- MCTS::Search::init_stats_and_rollout   search/mcts.h:448-496
+  Context.update(...)    <- pkmn_gen1_battle_update / PKMN::update libpkmn/pkmn.h:106-139
+  Context.choices(...)   <- pkmn_gen1_battle_choices               libpkmn/pkmn.h:141-156
+  Context.battle(...)    <- PKMN::battle(p1, p2, seed)             libpkmn/pkmn.h:50-57
+"""
+import ctypes as C
+import numpy as np
+
+from . import _lib, gamedata
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _u8(a, shape=None):
+    a = np.ascontiguousarray(a, dtype=np.uint8)
+    return a if shape is None else a.reshape(shape)
+
+
+class Context:
+    """One per process / GPU.  Host-array API (copies over PCIe); the device-pointer API used by
+    bench.py is exposed through `lib` + `handle` with torch tensors' data_ptr()."""
+
+    def __init__(self, device=0):
+        self.lib = _lib.load()
+        h = C.c_void_p()
+        _lib.check(self.lib.oakgpu_create(C.byref(h), device))
+        self.handle = h
+        self._pools = False
+
+    def close(self):
+        if self.handle:
+            self.lib.oakgpu_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_stream(self, stream_ptr):
+        _lib.check(self.lib.oakgpu_set_stream(self.handle, C.c_void_p(stream_ptr)))
+
+    def synchronize(self):
+        _lib.check(self.lib.oakgpu_synchronize(self.handle))
+
+    def ensure_ou_pools(self):
+        if not self._pools:
+            legal, pools, sizes = gamedata.ou_pools()
+            _lib.check(self.lib.oakgpu_set_ou_pools(self.handle, _p(legal), len(legal),
+                                                    _p(np.ascontiguousarray(pools)), _p(sizes)))
+            self._pools = True
+
+    # -- host-array API ------------------------------------------------------------------
+    def rollout(self, battles, durations, results, prng, max_steps=1000, prep=False, return_state=False):
+        battles = _u8(battles)
+        n = battles.shape[0]
+        durations = _u8(durations, (n, 8))
+        results = _u8(results, (n,))
+        prng = _u8(prng, (n, 8)).copy()
+        out = np.zeros(n, dtype=np.uint8)
+        steps = np.zeros(n, dtype=np.uint32)
+        values = np.zeros(n, dtype=np.float32)
+        bo = np.zeros((n, 384), dtype=np.uint8) if return_state else None
+        do = np.zeros((n, 8), dtype=np.uint8) if return_state else None
+        _lib.check(self.lib.oakgpu_rollout(self.handle, _p(battles), _p(durations), _p(results), _p(prng), n,
+                                           max_steps, 1 if prep else 0, _p(out), _p(steps), _p(values), _p(bo), _p(do)))
+        res = dict(results=out, steps=steps, values=values, prng=prng)
+        if return_state:
+            res.update(battles=bo, durations=do)
+        return res
+
+    def update(self, battles, c1, c2, durations, overrides=None, want_actions=True):
+        """In-place batched update; returns (results, actions or None)."""
+        n = battles.shape[0]
+        assert battles.dtype == np.uint8 and battles.flags.c_contiguous
+        assert durations.dtype == np.uint8 and durations.flags.c_contiguous
+        c1 = _u8(c1, (n,))
+        c2 = _u8(c2, (n,))
+        res = np.zeros(n, dtype=np.uint8)
+        actions = np.zeros((n, 16), dtype=np.uint8) if want_actions else None
+        ov = None if overrides is None else _u8(overrides, (n, 16))
+        _lib.check(self.lib.oakgpu_update(self.handle, _p(battles), _p(c1), _p(c2), _p(durations), _p(actions),
+                                          _p(ov), n, _p(res)))
+        return res, actions
+
+    def choices(self, battles, results, player):
+        battles = _u8(battles)
+        n = battles.shape[0]
+        out = np.zeros((n, 9), dtype=np.uint8)
+        counts = np.zeros(n, dtype=np.uint8)
+        _lib.check(self.lib.oakgpu_choices(self.handle, _p(battles), _p(_u8(results, (n,))), player, _p(out), _p(counts), n))
+        return out, counts
+
+    def battle(self, teams, seeds, first_update=True):
+        """teams uint8[n, 2, 6, 5]; seeds uint64[n] -> (battles, durations, results)."""
+        teams = _u8(teams)
+        n = teams.shape[0]
+        teams = teams.reshape(n, 60)
+        seeds = np.ascontiguousarray(seeds, dtype=np.uint64)
+        b = np.zeros((n, 384), dtype=np.uint8)
+        d = np.zeros((n, 8), dtype=np.uint8)
+        r = np.zeros(n, dtype=np.uint8)
+        _lib.check(self.lib.oakgpu_init_battles(self.handle, _p(teams), _p(seeds), n, 1 if first_update else 0,
+                                                _p(b), _p(d), _p(r)))
+        return b, d, r

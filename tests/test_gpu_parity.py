@@ -1,0 +1,140 @@
+"""GPU parity tests proper: HIP path (through the C ABI) vs the CPU oracle, bit-exact."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from oak_amd.parse import parse_battle, result_from_state
+
+pytestmark = pytest.mark.gpu
+
+
+def _seed_prng(n, seed0):
+    prng = np.zeros((n, 8), dtype=np.uint8)
+    for i in range(n):
+        O.LIB.oracle_fast_prng_seed(O.ptr(prng[i]), C.c_uint64(seed0 + i))
+    return prng
+
+
+def test_rollout_bit_exact_random_ou(gpu_ctx):
+    n = 4096
+    b, d, p, r = O.make_random_ou_batch(n)
+    got = gpu_ctx.rollout(b, d, r, p, max_steps=1000, return_state=True)
+    ob, od, op = b.copy(), d.copy(), p.copy()
+    oout, osteps = O.rollout_batch(ob, od, r, op, max_steps=1000, threads=8)
+    assert (got["steps"] == osteps).all()
+    assert (got["results"] == oout).all()
+    bad = np.nonzero((got["battles"] != ob).any(axis=1))[0]
+    assert bad.size == 0, "first differing lane %d" % bad[0]
+    assert (got["durations"] == od).all()
+    assert (got["prng"] == op).all()
+    t = oout & 15
+    exp = np.where(t == 1, 1.0, np.where(t == 2, 0.0, 0.5)).astype(np.float32)
+    assert (got["values"] == exp).all()
+
+
+def test_rollout_ragged_and_capped(gpu_ctx):
+    # non-multiple-of-block batch, small step cap (lanes stop mid-playout with type NONE)
+    n = 777
+    b, d, p, r = O.make_random_ou_batch(n, seed0=0x5EED0000)
+    got = gpu_ctx.rollout(b, d, r, p, max_steps=17, return_state=True)
+    ob, od, op = b.copy(), d.copy(), p.copy()
+    oout, osteps = O.rollout_batch(ob, od, r, op, max_steps=17, threads=4)
+    assert (got["steps"] == osteps).all() and (got["results"] == oout).all()
+    assert (got["battles"] == ob).all() and (got["durations"] == od).all() and (got["prng"] == op).all()
+
+
+def test_rollout_empty(gpu_ctx):
+    got = gpu_ctx.rollout(np.zeros((0, 384), np.uint8), np.zeros((0, 8), np.uint8), np.zeros(0, np.uint8),
+                          np.zeros((0, 8), np.uint8))
+    assert got["steps"].size == 0
+
+
+def test_stepwise_update_choices_actions(gpu_ctx):
+    """Drive 60 turn-steps with batched choices()/update() and compare every intermediate
+    battle, durations, actions key and result byte with the oracle."""
+    n = 1024
+    b, d, p, r = O.make_random_ou_batch(n, seed0=0xABCD0000)
+    gb, gd, gr = b.copy(), d.copy(), r.copy()
+    opts = [O.Options(d[i]) for i in range(n)]
+    rng = np.random.default_rng(5)
+    for step in range(60):
+        ch1, n1 = gpu_ctx.choices(gb, gr, 0)
+        ch2, n2 = gpu_ctx.choices(gb, gr, 1)
+        c1 = np.zeros(n, np.uint8)
+        c2 = np.zeros(n, np.uint8)
+        overrides = np.zeros((n, 16), np.uint8)
+        use_over = step % 5 == 0
+        for i in range(n):
+            o1 = O.choices(b[i], 0, (int(r[i]) >> 4) & 3)
+            o2 = O.choices(b[i], 1, (int(r[i]) >> 6) & 3)
+            assert n1[i] == len(o1) and (ch1[i, :n1[i]] == o1).all(), (step, i)
+            assert n2[i] == len(o2) and (ch2[i, :n2[i]] == o2).all(), (step, i)
+            c1[i] = o1[rng.integers(len(o1))]
+            c2[i] = o2[rng.integers(len(o2))]
+            if use_over:
+                overrides[i, 0] = 217 + rng.integers(39)
+                overrides[i, 8] = 236
+        gres, gact = gpu_ctx.update(gb, c1, c2, gd, overrides=overrides if use_over else None)
+        for i in range(n):
+            if (int(r[i]) & 15) != 0:
+                continue
+            opts[i].set(None, overrides[i] if use_over else None)
+            r[i] = O.update(b[i], int(c1[i]), int(c2[i]), opts[i])
+            d[i] = opts[i].durations
+        live = (gr & 15) == 0
+        assert (gres[live] == r[live]).all(), step
+        assert (gb[live] == b[live]).all(), step
+        assert (gd[live] == d[live]).all(), step
+        acts = np.stack([o.actions for o in opts])
+        assert (gact[live] == acts[live]).all(), step
+        # finished lanes: keep them frozen on both sides
+        gb[~live] = b[~live]
+        gd[~live] = d[~live]
+        gr = np.where(live, gres, gr).astype(np.uint8)
+        r = gr.copy()
+
+
+def test_init_battle_matches_oracle_and_golden(gpu_ctx):
+    from oak_amd import gamedata as G
+    rng = np.random.default_rng(11)
+    legal, pools, sizes = G.ou_pools()
+    n = 300
+    teams = np.zeros((n, 2, 6, 5), np.uint8)
+    for i in range(n):
+        for s in range(2):
+            sp = rng.choice(legal, 6, replace=False)
+            for k in range(6):
+                teams[i, s, k, 0] = sp[k]
+                m = min(4, sizes[sp[k]])
+                teams[i, s, k, 1:1 + m] = rng.choice(pools[sp[k], :sizes[sp[k]]], m, replace=False)
+    seeds = rng.integers(0, 2**63, n).astype(np.uint64)
+    b0, d0, r0 = gpu_ctx.battle(teams, seeds, first_update=False)
+    b1, d1, r1 = gpu_ctx.battle(teams, seeds, first_update=True)
+    for i in range(n):
+        ob = O.init_battle(teams[i], int(seeds[i]))
+        assert (b0[i] == ob).all(), i
+        opt = O.Options()
+        rr = O.update(ob, 0, 0, opt)
+        assert rr == r1[i] and (b1[i] == ob).all() and (d1[i] == opt.durations).all(), i
+
+
+def test_known_answer_positions_on_gpu(gpu_ctx):
+    """cpp/src/search-test.cc:50-109 -- every position has one legal joint action, so the
+    search value equals the mean playout value."""
+    tests = [("starmie seismictoss 1hp (conf:5) | snorlax bodyslam 1hp", 1.0, 0.0),
+             ("starmie seismictoss 1hp (conf:4) | snorlax bodyslam 1hp", .5 + .5 / 2, .03),
+             ("starmie seismictoss 1hp (conf:3) | snorlax bodyslam 1hp", .33 + .66 / 2, .03),
+             ("starmie seismictoss 1hp (conf:2) | snorlax bodyslam 1hp", .25 + .75 / 2, .03),
+             ("starmie seismictoss 1hp (conf:1) | snorlax bodyslam 1hp", .5, .03),
+             ("starmie seismictoss 1hp slp6 | snorlax seismictoss 1hp", 0.0, 0.0)]
+    for k in range(7):
+        tests.append(("starmie seismictoss 101hp slp%d | snorlax seismictoss 1hp" % k, 1.0 / (7 - k), 0.0 if k == 6 else .03))
+    n = 1 << 15
+    prng = _seed_prng(n, 4242)
+    for pos, expected, err in tests:
+        b, d = parse_battle(pos, 99)
+        res = result_from_state(b)
+        got = gpu_ctx.rollout(np.tile(b, (n, 1)), np.tile(d, (n, 1)), np.full(n, res, np.uint8), prng, prep=True)
+        assert abs(float(got["values"].mean()) - expected) <= err + 1e-9, (pos, got["values"].mean())
