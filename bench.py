@@ -1,0 +1,226 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the hot path on MI355X.
+
+Workload (BASELINE.json configs[1]): batch = 65,536 random OU team pairs per GPU, pure
+random-policy rollout to terminal (cap 1000 turn-steps, mirrors search/mcts.h:606-614).
+One *step* = one pass of the rollout kernel over the whole batch; inputs (battles,
+durations, per-lane fast_prng state) are generated ON DEVICE before the timed region and
+stay resident in HBM; the per-lane choice-RNG stream continues from step to step, so every
+step plays different playouts from the same 65,536 openings.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+N > 1: one process per GPU, lanes sharded by rank (weak scaling: 65,536 playouts per GPU,
+disjoint seeds), and every step ends with the path's single exchange: one RCCL all-gather of
+the fp32 leaf values (256 KiB per rank) back to every root.
+
+Prints ONE JSON line (rank 0).  `roofline` prices the rollout kernel against the HBM roof with
+the ALGORITHMIC bytes of SURVEY 8(d): 802 B per turn-step (401 read + 401 written of per-lane
+state); `cpu_baseline` times the CPU oracle (a restatement, not the Oak binary) on the host.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+ALGO_BYTES_PER_STEP = 802          # 384 battle + 8 durations + 8 rng + 1 result, read + written
+HBM_PEAK_GBPS = 8000.0             # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
+SEED0 = 0x0A4B00000000             # SURVEY 8(d) config-2 lane seed base
+MAX_STEPS = 1000
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=65536, help="playouts per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    from oak_amd import _lib
+    from oak_amd.engine import Context
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`"
+                             % (args.gpus, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback exists)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm
+
+    ctx = Context(local_rank)
+    lib, h = ctx.lib, ctx.handle
+    stream = torch.cuda.current_stream(dev)
+    ctx.set_stream(stream.cuda_stream)
+    ctx.ensure_ou_pools()
+
+    n = args.batch
+    u8 = torch.uint8
+    battles = torch.empty((n, 384), dtype=u8, device=dev)
+    durations = torch.empty((n, 8), dtype=u8, device=dev)
+    prng = torch.empty((n, 8), dtype=u8, device=dev)
+    results_in = torch.empty((n,), dtype=u8, device=dev)
+    results = torch.empty((n,), dtype=u8, device=dev)
+    steps_out = torch.empty((n,), dtype=torch.int32, device=dev)
+    values = torch.empty((n,), dtype=torch.float32, device=dev)
+    gathered = torch.empty((world * n,), dtype=torch.float32, device=dev) if world > 1 else None
+    total_steps = torch.zeros((), dtype=torch.int64, device=dev)
+
+    def P(t):
+        return C.c_void_p(t.data_ptr())
+
+    # synthetic input, generated on device: lane seeds are disjoint across ranks
+    _lib.check(lib.oakgpu_random_ou_battles_dev(h, C.c_uint64(SEED0 + rank * n), n, P(battles), P(durations),
+                                                P(prng), P(results_in)))
+    torch.cuda.synchronize(dev)
+
+    def step():
+        _lib.check(lib.oakgpu_rollout_dev(h, P(battles), P(durations), P(results_in), P(prng), n, MAX_STEPS, 0,
+                                          P(results), P(steps_out), P(values), None, None))
+
+    def exchange():
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, values)
+
+    steps_out.zero_()
+    total_steps += steps_out.sum(dtype=torch.int64)   # loads torch's lazily-loaded reduce kernels up front
+    for _ in range(args.warmup):
+        step()
+        total_steps += steps_out.sum(dtype=torch.int64)
+        exchange()
+    total_steps.zero_()
+    torch.cuda.synchronize(dev)
+
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    for a, b in ev:   # force event creation outside the timed region
+        a.record(stream)
+        b.record(stream)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        ev[k][0].record(stream)
+        step()
+        ev[k][1].record(stream)
+        total_steps += steps_out.sum(dtype=torch.int64)   # tiny reduction kernel, inside the timed region
+        exchange()
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+
+    my_steps = int(total_steps.item())
+    kern_ms = [a.elapsed_time(b) for a, b in ev]
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        s = torch.tensor([my_steps], dtype=torch.int64, device=dev)
+        dist.all_reduce(s, op=dist.ReduceOp.SUM)
+        all_steps = int(s.item())
+    else:
+        all_steps = my_steps
+
+    if rank == 0:
+        value = all_steps / elapsed
+        avg_kernel_s = (sum(kern_ms) / len(kern_ms)) / 1e3
+        steps_per_launch = my_steps / args.steps
+        achieved = steps_per_launch * ALGO_BYTES_PER_STEP / avg_kernel_s / 1e9
+        traffic = None
+        tp = os.path.join(ROOT, "profiles", "traffic.json")   # rocprofv3 --pmc result, bytes per launch
+        if os.path.exists(tp):
+            try:
+                traffic = json.load(open(tp)).get("k_rollout_hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "turn-steps/s (batched playouts)",
+            "value": value,
+            "unit": "turn-steps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u16",
+            "data": "synthetic",
+            "config": {
+                "workload": "configs[1]: batch=65536 random OU team pairs per GPU, pure random-policy rollout to "
+                            "terminal (cap 1000 turn-steps)",
+                "batch_per_gpu": n,
+                "playouts_per_s": n * world * args.steps / elapsed,
+                "mean_turn_steps_per_playout": all_steps / (n * world * args.steps),
+                "parallelism": "lanes sharded by rank; 1 RCCL all-gather of fp32 leaf values per step" if world > 1
+                               else "single GPU",
+                "parity": "bit-exact vs this repo's CPU oracle (libpkmn parity unpinned, see DESIGN.md)",
+            },
+            "roofline": {
+                "bound": "hbm",
+                "kernel": "oak::k_rollout",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBPS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBPS,
+                "traffic": traffic,
+                "avg_kernel_ms": avg_kernel_s * 1e3,
+                "algorithmic_bytes_per_turn_step": ALGO_BYTES_PER_STEP,
+                "turn_steps_per_launch": steps_per_launch,
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(n)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(n):
+    """The CPU oracle (kind "port": this repo's restatement, NOT the Oak binary) on the host cores,
+    same lane seeds as the GPU batch, bounded to roughly 10-20 thread-seconds of work."""
+    import numpy as np
+    import oracle_lib as O
+    cores = min(os.cpu_count() or 1, 16)
+    sample = min(n, 65536)
+    b, d, p, r = O.make_random_ou_batch(sample, SEED0)
+    reps = 10
+    total = 0
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        bb, dd = b.copy(), d.copy()
+        _, steps = O.rollout_batch(bb, dd, r, p, max_steps=MAX_STEPS, threads=cores)  # p advances in place
+        total += int(steps.sum())
+    dt = time.perf_counter() - t0
+    return {
+        "value": total / dt,
+        "unit": "turn-steps/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": "%d passes over %d playouts (same lane seeds as the GPU batch), %d threads, oracle/liboracle.so "
+                  "gcc -O3 -march=x86-64-v3" % (reps, sample, cores),
+    }
+
+
+if __name__ == "__main__":
+    main()

@@ -53,25 +53,32 @@ enum : int { AC_DAMAGE = 0, AC_HIT = 8, AC_CRIT = 10, AC_SECONDARY = 12, AC_SPEE
              AC_BINDING = 33, AC_MOVESLOT = 36, AC_MULTIHIT = 44, AC_PSYWAVE = 48, AC_METRONOME = 56 };
 enum : uint32_t { OBS_STARTED = 1, OBS_CONTINUING = 2, OBS_ENDED = 3 };
 
+// LDS-address-space pointer types: keeping the address space in the type makes hipcc emit
+// ds_read/ds_write (lgkmcnt only) instead of flat_load/flat_store for every state access.
+#define OAK_LDS __attribute__((address_space(3)))
+typedef OAK_LDS uint32_t lds_u32;
+typedef OAK_LDS uint16_t lds_u16;
+typedef OAK_LDS uint8_t lds_u8;
+
 struct Tables {
-  const uint32_t *mv;     // [166] effect | bp<<8 | type<<16 | acc<<24
-  const uint8_t *maxpp;   // [166]
-  const uint32_t *sp0;    // [152]
-  const uint32_t *sp1;    // [152]
-  const uint8_t *chart;   // [225]
-  const uint16_t *boost;  // [13] num | den<<8
+  const lds_u32 *mv;     // [166] effect | bp<<8 | type<<16 | acc<<24
+  const lds_u8 *maxpp;   // [166]
+  const lds_u32 *sp0;    // [152]
+  const lds_u32 *sp1;    // [152]
+  const lds_u8 *chart;   // [225]
+  const lds_u16 *boost;  // [13] num | den<<8
 };
 static constexpr int TABLE_LDS_BYTES = 166 * 4 + 168 + 152 * 4 + 152 * 4 + 228 + 28;
 
 // copies the packed table images into LDS; call with all threads of the workgroup, then barrier
-__device__ inline Tables stage_tables(uint8_t *lds, const uint32_t *g_mv, const uint8_t *g_pp, const uint32_t *g_sp0,
+__device__ inline Tables stage_tables(lds_u8 *lds, const uint32_t *g_mv, const uint8_t *g_pp, const uint32_t *g_sp0,
                                       const uint32_t *g_sp1, const uint8_t *g_chart, const uint16_t *g_boost) {
-  uint32_t *mv = (uint32_t *)lds;
-  uint8_t *pp = lds + 166 * 4;
-  uint32_t *sp0 = (uint32_t *)(pp + 168);
-  uint32_t *sp1 = sp0 + 152;
-  uint8_t *chart = (uint8_t *)(sp1 + 152);
-  uint16_t *boost = (uint16_t *)(chart + 228);
+  lds_u32 *mv = (lds_u32 *)lds;
+  lds_u8 *pp = lds + 166 * 4;
+  lds_u32 *sp0 = (lds_u32 *)(pp + 168);
+  lds_u32 *sp1 = sp0 + 152;
+  lds_u8 *chart = (lds_u8 *)(sp1 + 152);
+  lds_u16 *boost = (lds_u16 *)(chart + 228);
   for (int i = threadIdx.x; i < 166; i += blockDim.x) { mv[i] = g_mv[i]; pp[i] = g_pp[i]; }
   for (int i = threadIdx.x; i < 152; i += blockDim.x) { sp0[i] = g_sp0[i]; sp1[i] = g_sp1[i]; }
   for (int i = threadIdx.x; i < 225; i += blockDim.x) chart[i] = g_chart[i];
@@ -91,23 +98,25 @@ struct Move { // unpacked move word
 // ---- one lane's engine -------------------------------------------------------------------
 template <int STRIDE, bool TRACK_ACTIONS>
 struct Engine {
-  uint32_t *m;        // this lane's column in the lane-interleaved LDS state
+  lds_u32 *m;         // this lane's column in the lane-interleaved LDS state
   Tables T;
-  uint32_t dur[2];    // chance durations (public counters), one u32 per side
-  uint64_t act[2];    // chance actions (only maintained when TRACK_ACTIONS)
-  uint32_t over[2];   // calc damage-roll overrides (0 = roll)
+  // Per-player registers are packed into scalars and indexed by shift (never as arrays: a
+  // lane-divergent player index into a register array would be demoted to scratch memory).
+  uint64_t dur64;     // chance durations (public counters): side 0 in bits 0-31, side 1 in 32-63
+  uint64_t act0, act1; // chance actions (only maintained when TRACK_ACTIONS)
+  uint32_t over16;    // calc damage-roll overrides: P1 byte 0, P2 byte 1 (0 = roll)
 
   // -- LDS accessors (byte offset -> lane-interleaved address) --
   __device__ __forceinline__ uint32_t r32(int off) const { return m[(off >> 2) * STRIDE]; }
   __device__ __forceinline__ void w32(int off, uint32_t v) { m[(off >> 2) * STRIDE] = v; }
   __device__ __forceinline__ uint32_t r16(int off) const {
-    return ((const uint16_t *)m)[(off >> 2) * (STRIDE * 2) + ((off >> 1) & 1)];
+    return ((const lds_u16 *)m)[(off >> 2) * (STRIDE * 2) + ((off >> 1) & 1)];
   }
   __device__ __forceinline__ void w16(int off, uint32_t v) {
-    ((uint16_t *)m)[(off >> 2) * (STRIDE * 2) + ((off >> 1) & 1)] = (uint16_t)v;
+    ((lds_u16 *)m)[(off >> 2) * (STRIDE * 2) + ((off >> 1) & 1)] = (uint16_t)v;
   }
-  __device__ __forceinline__ uint32_t r8(int off) const { return ((const uint8_t *)m)[(off >> 2) * (STRIDE * 4) + (off & 3)]; }
-  __device__ __forceinline__ void w8(int off, uint32_t v) { ((uint8_t *)m)[(off >> 2) * (STRIDE * 4) + (off & 3)] = (uint8_t)v; }
+  __device__ __forceinline__ uint32_t r8(int off) const { return ((const lds_u8 *)m)[(off >> 2) * (STRIDE * 4) + (off & 3)]; }
+  __device__ __forceinline__ void w8(int off, uint32_t v) { ((lds_u8 *)m)[(off >> 2) * (STRIDE * 4) + (off & 3)] = (uint8_t)v; }
 
   // -- RNG: showdown PSRNG over the 64-bit LCG (cpp/include/libpkmn/rng.h:9-11) --
   __device__ __forceinline__ uint32_t rng_next() {
@@ -126,14 +135,20 @@ struct Engine {
   __device__ __forceinline__ void act_set(int p, int sh, int bits, uint32_t v) {
     if constexpr (TRACK_ACTIONS) {
       uint64_t mask = ((1ull << bits) - 1) << sh;
-      act[p] = (act[p] & ~mask) | (((uint64_t)v << sh) & mask);
+      uint64_t a = p ? act1 : act0;
+      a = (a & ~mask) | (((uint64_t)v << sh) & mask);
+      if (p) act1 = a; else act0 = a;
     }
   }
   __device__ __forceinline__ void act_bool(int p, int sh, bool v) { act_set(p, sh, 2, v ? 2u : 1u); }
-  __device__ __forceinline__ uint32_t dget(int p, int sh, int bits) const { return (dur[p] >> sh) & ((1u << bits) - 1); }
+  __device__ __forceinline__ uint32_t dur_of(int p) const { return (uint32_t)(dur64 >> (32 * p)); }
+  __device__ __forceinline__ void set_dur_of(int p, uint32_t v) {
+    dur64 = (dur64 & ~(0xFFFFFFFFull << (32 * p))) | ((uint64_t)v << (32 * p));
+  }
+  __device__ __forceinline__ uint32_t dget(int p, int sh, int bits) const { return (uint32_t)(dur64 >> (32 * p + sh)) & ((1u << bits) - 1); }
   __device__ __forceinline__ void dset(int p, int sh, int bits, uint32_t v) {
-    uint32_t mask = ((1u << bits) - 1) << sh;
-    dur[p] = (dur[p] & ~mask) | ((v << sh) & mask);
+    uint64_t mask = (uint64_t)((1u << bits) - 1) << (32 * p + sh);
+    dur64 = (dur64 & ~mask) | (((uint64_t)v << (32 * p + sh)) & mask);
   }
 
   // -- field helpers; `so` = byte offset of a side, `ao` = so + O_ACTIVE --
@@ -213,11 +228,11 @@ struct Engine {
     uint32_t in_id = r8(so + O_ORDER + slot - 1);
     w8(so + O_ORDER, in_id);
     w8(so + O_ORDER + slot - 1, t);
-    uint32_t d = dur[p];
+    uint32_t d = dur_of(p);
     uint32_t s0 = d & 7, sk = (d >> (3 * (slot - 1))) & 7;
     d = (d & ~7u) | sk;
     if (slot != 1) d = (d & ~(7u << (3 * (slot - 1)))) | (s0 << (3 * (slot - 1)));
-    dur[p] = d & ((1u << 18) - 1);
+    set_dur_of(p, d & ((1u << 18) - 1));
     w8(so + O_LAST_USED, 0);
     w8(fo + O_LAST_USED, 0);
     const int in = so + PK_SZ * ((int)in_id - 1), ao = so + O_ACTIVE;
@@ -331,7 +346,7 @@ struct Engine {
   __device__ __forceinline__ void randomize_damage(int p) {
     uint32_t d = r16(B_LAST_DAMAGE);
     if (d <= 1) return;
-    uint32_t roll = over[p];
+    uint32_t roll = (over16 >> (8 * p)) & 0xFF;
     if (roll == 0) roll = rng_range(217, 256);
     act_set(p, AC_DAMAGE, 8, roll);
     w16(B_LAST_DAMAGE, d * roll / 255);
@@ -469,7 +484,7 @@ struct Engine {
       }
       uint32_t fs = r8(fp + P_STATUS);
       if (fs) {
-        if (fs & ST_SLP) dur[p ^ 1] &= ~7u;
+        if (fs & ST_SLP) dset(p ^ 1, 0, 3, 0);
         w8(fp + P_STATUS, 0);
       }
       if (r8(sp + P_STATUS) == ST_TOX) w8(sp + P_STATUS, ST_PSN);
@@ -483,7 +498,7 @@ struct Engine {
       if (delta == 0 || (delta & 255) == 255) return; // gen-1 recovery failure glitch
       if (move_id == M_Rest) {
         w8(sp + P_STATUS, ST_EXT | 2);
-        dur[p] &= ~7u;
+        dset(p, 0, 3, 0);
         w16(sp + P_HP, maxhp);
         vflag_clear(so, V_TOXIC);
         set_toxic_ctr(so, 0);
@@ -577,8 +592,8 @@ struct Engine {
       status -= 1;
       uint32_t left = status & ST_SLP;
       if (!(status & ST_EXT)) {
-        if (left == 0) { dur[p] &= ~7u; act_set(p, AC_SLEEP, 2, OBS_ENDED); }
-        else { dur[p] = (dur[p] & ~7u) | (((dur[p] & 7) + 1) & 7); act_set(p, AC_SLEEP, 2, OBS_CONTINUING); }
+        if (left == 0) { dset(p, 0, 3, 0); act_set(p, AC_SLEEP, 2, OBS_ENDED); }
+        else { dset(p, 0, 3, dget(p, 0, 3) + 1); act_set(p, AC_SLEEP, 2, OBS_CONTINUING); }
       }
       if (left == 0) status = 0;
       w8(sp + P_STATUS, status);
@@ -743,7 +758,7 @@ struct Engine {
           if (!move_hit(p, mv)) return;
         }
         w8(fp + P_STATUS, rng_range(1, 8));
-        dur[p ^ 1] = (dur[p ^ 1] & ~7u) | 1;
+        dset(p ^ 1, 0, 3, 1);
         act_set(p ^ 1, AC_SLEEP, 2, OBS_STARTED);
         return;
       }
@@ -1020,7 +1035,7 @@ struct Engine {
 
   // ---- pkmn_gen1_battle_update ---------------------------------------------------------
   __device__ uint32_t update(uint32_t c1, uint32_t c2) {
-    if constexpr (TRACK_ACTIONS) { act[0] = 0; act[1] = 0; }
+    if constexpr (TRACK_ACTIONS) { act0 = 0; act1 = 0; }
     if (r16(B_TURN) == 0) {
       const bool a1 = any_alive(0), a2 = any_alive(SIDE_SZ);
       if (!a1) return mk_result(a2 ? R_LOSE : R_TIE, 0, 0);
@@ -1071,7 +1086,7 @@ struct Engine {
       return (w >> (8 * (i & 3))) & 0xFF;
     }
   };
-  __device__ Choices choices(int p, uint32_t request) const {
+  __device__ __forceinline__ Choices choices(int p, uint32_t request) const {
     Choices c{0, 0, 0, 0};
     const int so = p * SIDE_SZ;
     if (request == C_PASS) { c.push(0); return c; }

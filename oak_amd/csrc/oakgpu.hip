@@ -26,19 +26,19 @@ constexpr int STATE_LDS_BYTES = STATE_WORDS * BLOCK * 4;
 constexpr int TABLE_LDS_PAD = (TABLE_LDS_BYTES + 15) & ~15;
 constexpr int ENGINE_LDS_BYTES = STATE_LDS_BYTES + TABLE_LDS_PAD;
 
-__device__ __forceinline__ Tables stage_default_tables(uint8_t *lds) {
+__device__ __forceinline__ Tables stage_default_tables(lds_u8 *lds) {
   return stage_tables(lds, OAK_MOVE_WORDS, OAK_MOVE_MAXPP, OAK_SPECIES_W0, OAK_SPECIES_W1, OAK_TYPE_CHART, OAK_BOOSTS);
 }
 
 // AoS (n x 384 B, 4-byte aligned) <-> lane-interleaved LDS, whole workgroup cooperating.
-__device__ __forceinline__ void load_state(uint32_t *state, const uint8_t *battles, uint32_t base, uint32_t count) {
+__device__ __forceinline__ void load_state(lds_u32 *state, const uint8_t *battles, uint32_t base, uint32_t count) {
   const uint32_t *src = (const uint32_t *)battles + (size_t)base * STATE_WORDS;
   for (uint32_t i = threadIdx.x; i < count * STATE_WORDS; i += BLOCK) {
     uint32_t b = i / STATE_WORDS, w = i - b * STATE_WORDS;
     state[w * BLOCK + b] = src[i];
   }
 }
-__device__ __forceinline__ void store_state(const uint32_t *state, uint8_t *battles, uint32_t base, uint32_t count) {
+__device__ __forceinline__ void store_state(const lds_u32 *state, uint8_t *battles, uint32_t base, uint32_t count) {
   uint32_t *dst = (uint32_t *)battles + (size_t)base * STATE_WORDS;
   for (uint32_t i = threadIdx.x; i < count * STATE_WORDS; i += BLOCK) {
     uint32_t b = i / STATE_WORDS, w = i - b * STATE_WORDS;
@@ -100,7 +100,7 @@ __device__ void randomize_hidden(E &e) {
   const uint32_t hi = e.r32(B_RNG + 4), lo = e.r32(B_RNG);
   for (int s = 0; s < 2; ++s) {
     const int so = s * SIDE_SZ;
-    const uint32_t d = e.dur[s];
+    const uint32_t d = e.dur_of(s);
     const uint32_t confusion = (d >> 18) & 7, disable = (d >> 21) & 15, attacking = (d >> 25) & 7, binding = (d >> 28) & 7;
     if (confusion) {
       uint32_t one = confusion == 1;
@@ -145,8 +145,8 @@ struct RolloutArgs {
 
 __global__ __launch_bounds__(BLOCK) void k_rollout(RolloutArgs a) {
   extern __shared__ __align__(16) uint8_t smem[];
-  uint32_t *state = (uint32_t *)smem;
-  Tables T = stage_default_tables(smem + STATE_LDS_BYTES);
+  lds_u32 *state = (lds_u32 *)smem;
+  Tables T = stage_default_tables((lds_u8 *)smem + STATE_LDS_BYTES);
   const uint32_t base = blockIdx.x * BLOCK;
   const uint32_t count = min((uint32_t)BLOCK, a.n - base);
   load_state(state, a.battles, base, count);
@@ -157,9 +157,8 @@ __global__ __launch_bounds__(BLOCK) void k_rollout(RolloutArgs a) {
     e.m = state + tid;
     e.T = T;
     const uint32_t *dsrc = (const uint32_t *)a.durations + 2 * (size_t)lane;
-    e.dur[0] = dsrc[0];
-    e.dur[1] = dsrc[1];
-    e.over[0] = e.over[1] = 0;
+    e.dur64 = (uint64_t)dsrc[0] | ((uint64_t)dsrc[1] << 32);
+    e.over16 = 0;
     FastPrng g;
     const uint32_t *psrc = (const uint32_t *)a.prng + 2 * (size_t)lane;
     g.s0 = psrc[0];
@@ -190,8 +189,8 @@ __global__ __launch_bounds__(BLOCK) void k_rollout(RolloutArgs a) {
     pdst[1] = g.s1;
     if (a.durations_out) {
       uint32_t *ddst = (uint32_t *)a.durations_out + 2 * (size_t)lane;
-      ddst[0] = e.dur[0];
-      ddst[1] = e.dur[1];
+      ddst[0] = e.dur_of(0);
+      ddst[1] = e.dur_of(1);
     }
   }
   if (a.battles_out) {
@@ -205,8 +204,8 @@ __global__ __launch_bounds__(BLOCK) void k_update(uint8_t *battles, const uint8_
                                                   uint8_t *durations, uint8_t *actions, const uint8_t *overrides,
                                                   uint32_t n, uint8_t *results) {
   extern __shared__ __align__(16) uint8_t smem[];
-  uint32_t *state = (uint32_t *)smem;
-  Tables T = stage_default_tables(smem + STATE_LDS_BYTES);
+  lds_u32 *state = (lds_u32 *)smem;
+  Tables T = stage_default_tables((lds_u8 *)smem + STATE_LDS_BYTES);
   const uint32_t base = blockIdx.x * BLOCK;
   const uint32_t count = min((uint32_t)BLOCK, n - base);
   load_state(state, battles, base, count);
@@ -217,18 +216,16 @@ __global__ __launch_bounds__(BLOCK) void k_update(uint8_t *battles, const uint8_
     e.m = state + tid;
     e.T = T;
     uint32_t *d = (uint32_t *)durations + 2 * (size_t)lane;
-    e.dur[0] = d[0];
-    e.dur[1] = d[1];
-    e.over[0] = overrides ? overrides[(size_t)lane * 16] : 0;
-    e.over[1] = overrides ? overrides[(size_t)lane * 16 + 8] : 0;
-    e.act[0] = e.act[1] = 0;
+    e.dur64 = (uint64_t)d[0] | ((uint64_t)d[1] << 32);
+    e.over16 = overrides ? (uint32_t)overrides[(size_t)lane * 16] | ((uint32_t)overrides[(size_t)lane * 16 + 8] << 8) : 0;
+    e.act0 = e.act1 = 0;
     results[lane] = (uint8_t)e.update(c1[lane], c2[lane]);
-    d[0] = e.dur[0];
-    d[1] = e.dur[1];
+    d[0] = e.dur_of(0);
+    d[1] = e.dur_of(1);
     if (actions) {
       uint64_t *ad = (uint64_t *)actions + 2 * (size_t)lane;
-      ad[0] = e.act[0];
-      ad[1] = e.act[1];
+      ad[0] = e.act0;
+      ad[1] = e.act1;
     }
   }
   __syncthreads();
@@ -238,7 +235,7 @@ __global__ __launch_bounds__(BLOCK) void k_update(uint8_t *battles, const uint8_
 __global__ __launch_bounds__(BLOCK) void k_choices(const uint8_t *battles, const uint8_t *results, int player,
                                                    uint8_t *out, uint8_t *counts, uint32_t n) {
   extern __shared__ __align__(16) uint8_t smem[];
-  uint32_t *state = (uint32_t *)smem;
+  lds_u32 *state = (lds_u32 *)smem;
   const uint32_t base = blockIdx.x * BLOCK;
   const uint32_t count = min((uint32_t)BLOCK, n - base);
   load_state(state, battles, base, count);
@@ -293,8 +290,8 @@ __device__ void init_from_teams(E &e, const uint8_t *teams /* 60 B, this lane */
 __global__ __launch_bounds__(BLOCK) void k_init(const uint8_t *teams, const uint64_t *seeds, uint32_t n, int first_update,
                                                 uint8_t *battles, uint8_t *durations, uint8_t *results) {
   extern __shared__ __align__(16) uint8_t smem[];
-  uint32_t *state = (uint32_t *)smem;
-  Tables T = stage_default_tables(smem + STATE_LDS_BYTES);
+  lds_u32 *state = (lds_u32 *)smem;
+  Tables T = stage_default_tables((lds_u8 *)smem + STATE_LDS_BYTES);
   __syncthreads();
   const uint32_t base = blockIdx.x * BLOCK;
   const uint32_t count = min((uint32_t)BLOCK, n - base);
@@ -303,8 +300,8 @@ __global__ __launch_bounds__(BLOCK) void k_init(const uint8_t *teams, const uint
     Engine<BLOCK, false> e;
     e.m = state + tid;
     e.T = T;
-    e.dur[0] = e.dur[1] = 0;
-    e.over[0] = e.over[1] = 0;
+    e.dur64 = 0;
+    e.over16 = 0;
     const uint64_t sd = seeds[lane];
     init_from_teams(e, teams + (size_t)lane * OAKGPU_TEAMS_SIZE, (uint32_t)sd, (uint32_t)(sd >> 32));
     uint32_t r = mk_result(0, C_MOVE, C_MOVE);
@@ -312,8 +309,8 @@ __global__ __launch_bounds__(BLOCK) void k_init(const uint8_t *teams, const uint
     if (results) results[lane] = (uint8_t)r;
     if (durations) {
       uint32_t *d = (uint32_t *)durations + 2 * (size_t)lane;
-      d[0] = e.dur[0];
-      d[1] = e.dur[1];
+      d[0] = e.dur_of(0);
+      d[1] = e.dur_of(1);
     }
   }
   __syncthreads();
@@ -324,8 +321,8 @@ __global__ __launch_bounds__(BLOCK) void k_random_ou(uint64_t seed0, uint32_t n,
                                                      const uint8_t *pools, const uint8_t *sizes, uint8_t *battles,
                                                      uint8_t *durations, uint8_t *prng, uint8_t *results) {
   extern __shared__ __align__(16) uint8_t smem[];
-  uint32_t *state = (uint32_t *)smem;
-  Tables T = stage_default_tables(smem + STATE_LDS_BYTES);
+  lds_u32 *state = (lds_u32 *)smem;
+  Tables T = stage_default_tables((lds_u8 *)smem + STATE_LDS_BYTES);
   __syncthreads();
   const uint32_t base = blockIdx.x * BLOCK;
   const uint32_t count = min((uint32_t)BLOCK, n - base);
@@ -334,8 +331,8 @@ __global__ __launch_bounds__(BLOCK) void k_random_ou(uint64_t seed0, uint32_t n,
     Engine<BLOCK, false> e;
     e.m = state + tid;
     e.T = T;
-    e.dur[0] = e.dur[1] = 0;
-    e.over[0] = e.over[1] = 0;
+    e.dur64 = 0;
+    e.over16 = 0;
     FastPrng g;
     g.seed(seed0 + lane);
     uint8_t teams[OAKGPU_TEAMS_SIZE];
@@ -367,8 +364,8 @@ __global__ __launch_bounds__(BLOCK) void k_random_ou(uint64_t seed0, uint32_t n,
     const uint32_t r = e.update(0, 0);
     results[lane] = (uint8_t)r;
     uint32_t *d = (uint32_t *)durations + 2 * (size_t)lane;
-    d[0] = e.dur[0];
-    d[1] = e.dur[1];
+    d[0] = e.dur_of(0);
+    d[1] = e.dur_of(1);
     uint32_t *pd = (uint32_t *)prng + 2 * (size_t)lane;
     pd[0] = g.s0;
     pd[1] = g.s1;
