@@ -97,6 +97,27 @@ int oakgpu_set_ou_pools(oakgpu_ctx *ctx, const uint8_t *ou_legal, int n_legal, c
 int oakgpu_random_ou_battles_dev(oakgpu_ctx *ctx, uint64_t seed0, uint32_t n, uint8_t *battles,
                                  uint8_t *durations, uint8_t *prng_state, uint8_t *results);
 
+/* ---- leaf evaluator: replaces NN::Battle::NetworkImpl (cpp/include/nn/battle/network.h:22-176).
+ * oakgpu_net_load parses a `.battle.net` parameter file exactly as the reference does (8-byte
+ * header, byte 0 = activation - 1: cpp/src/search.cc:127-131; then 12 Affine blocks
+ * `u32 in, u32 out, f32 bias[out], f32 W[out][in]`: nn/affine.h:35-70; must end at EOF:
+ * network.h:60-63) and uploads the weights.  Errors (unreadable file, malformed / trailing
+ * bytes, unsupported widths) return non-zero with a message, where the reference throws
+ * std::runtime_error (search.cc:81,92,103,138,146).
+ * oakgpu_leaf_eval* = value_inference(battle, durations) for n leaves (network.h:72-79):
+ * encode + both embedding nets + MainNet value path + sigmoid, fp32 throughout (dense layers on
+ * fp32 MFMA).  embedding_out (nullable): the n x in_dim battle embeddings (network.h:131-175). */
+typedef struct oakgpu_net oakgpu_net;
+int oakgpu_net_load(oakgpu_ctx *ctx, const char *path, oakgpu_net **out);
+int oakgpu_net_load_memory(oakgpu_ctx *ctx, const void *bytes, size_t size, oakgpu_net **out);
+void oakgpu_net_free(oakgpu_ctx *ctx, oakgpu_net *net);
+/* MainNet::shape() (main-net.h:32-34): fc0.in, fc0.out, value_fc2.out, p1_policy_fc2.out */
+int oakgpu_net_shape(const oakgpu_net *net, int *in_dim, int *hidden, int *value_hidden, int *policy_hidden);
+int oakgpu_leaf_eval_dev(oakgpu_ctx *ctx, oakgpu_net *net, const uint8_t *battles, const uint8_t *durations,
+                         uint32_t n, float *values, float *embedding_out);
+int oakgpu_leaf_eval(oakgpu_ctx *ctx, oakgpu_net *net, const uint8_t *battles, const uint8_t *durations, uint32_t n,
+                     float *values, float *embedding_out);
+
 #ifdef __cplusplus
 }
 #endif

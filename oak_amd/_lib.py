@@ -12,6 +12,8 @@ SYMBOLS = [
     "oakgpu_device_count", "oakgpu_rollout_dev", "oakgpu_rollout", "oakgpu_update_dev", "oakgpu_update",
     "oakgpu_choices_dev", "oakgpu_choices", "oakgpu_init_battles_dev", "oakgpu_init_battles",
     "oakgpu_set_ou_pools", "oakgpu_random_ou_battles_dev",
+    "oakgpu_net_load", "oakgpu_net_load_memory", "oakgpu_net_free", "oakgpu_net_shape",
+    "oakgpu_leaf_eval_dev", "oakgpu_leaf_eval",
 ]
 
 _lib = None
@@ -46,6 +48,13 @@ def load():
     lib.oakgpu_init_battles.argtypes = [vp, vp, vp, u32, i32, vp, vp, vp]
     lib.oakgpu_set_ou_pools.argtypes = [vp, vp, i32, vp, vp]
     lib.oakgpu_random_ou_battles_dev.argtypes = [vp, u64, u32, vp, vp, vp, vp]
+    lib.oakgpu_net_load.argtypes = [vp, C.c_char_p, C.POINTER(vp)]
+    lib.oakgpu_net_load_memory.argtypes = [vp, vp, C.c_size_t, C.POINTER(vp)]
+    lib.oakgpu_net_free.argtypes = [vp, vp]
+    lib.oakgpu_net_free.restype = None
+    lib.oakgpu_net_shape.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
+    lib.oakgpu_leaf_eval_dev.argtypes = [vp, vp, vp, vp, u32, vp, vp]
+    lib.oakgpu_leaf_eval.argtypes = [vp, vp, vp, vp, u32, vp, vp]
     _lib = lib
     return lib
 

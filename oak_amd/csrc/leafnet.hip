@@ -1,0 +1,545 @@
+// oak_amd/csrc/leafnet.hip -- fp32 leaf evaluator on gfx950 (K2 + K3) and its C ABI.
+//
+// Replaces NN::Battle::NetworkImpl::value_inference (cpp/include/nn/battle/network.h:72-79):
+//   K2  k_embed   : Encode::Battle::{Pokemon,ActivePokemon}::write (encode/battle/battle.h:208-214,
+//                   544-551) fused with EmbeddingNet::propagate (nn/ffn.h:47-51, affine.h:87-103)
+//                   and write_battle_embedding (network.h:131-175).  One wave per (leaf, party
+//                   slot); the sparse first layer is a gather-add over 512-byte weight rows driven
+//                   by wave-uniform control flow, the dense second layer streams W1^T from LDS.
+//                   The reference's per-battle embedding caches (nn/battle/cache.h) are replaced
+//                   by recomputation.
+//   K3  k_mainnet : MainNet::propagate value path (nn/battle/main-net.h:57-64) + sigmoid, the three
+//                   dense layers on v_mfma_f32_32x32x2_f32 (exact fp32), activations never leave LDS.
+// Parameter file reader: nn/affine.h:35-70, network.h:52-70, main-net.h:36-55, search.cc:127-131.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <string>
+#include <vector>
+
+#include "../../include/oakgpu.h"
+#include "oakgpu_internal.h"
+
+namespace oak {
+
+struct NetDev {
+  // embedding nets: W0t [in][128-ish hidden] (transposed for row gathers), b0, W1t [hidden][out], b1
+  const float *p_w0t, *p_b0, *p_w1t, *p_b1;
+  const float *a_w0t, *a_b0, *a_w1t, *a_b1;
+  int p_hidden, p_out, a_hidden, a_out;
+  int side_dim, emb_dim;
+  int activation; // 1 relu, 2 clamp
+  // main net (value path), rows padded to multiples of 32 with zeros
+  const float *w0, *b0, *w1, *b1, *w2, *b2, *w3;
+  float b3;
+  int H, VH; // padded dims
+};
+
+__device__ __forceinline__ float act_fn(float x, int activation) {
+  x = fmaxf(x, 0.0f);
+  return activation == 2 ? fminf(x, 1.0f) : x;
+}
+
+// ---- K2 ---------------------------------------------------------------------------------------
+constexpr int EMB_BLOCK = 256;
+constexpr int MAX_HIDDEN = 128; // embedding hidden width handled as 2 channels per lane
+
+struct EmbedArgs {
+  NetDev net;
+  const uint8_t *battles;
+  const uint8_t *durations;
+  uint32_t n;
+  float *emb; // n x emb_dim
+};
+
+// gather-add of one feature row: h{0,1} += W0t[idx][c], W0t row-major [in][hidden]
+#define ROW_ADD(w0t, hidden, idx, val)                                              \
+  do {                                                                              \
+    const float *_r = (w0t) + (size_t)(idx) * (hidden);                             \
+    if (c0 < (hidden)) h0 = fmaf(_r[c0], (val), h0);                                \
+    if (c1 < (hidden)) h1 = fmaf(_r[c1], (val), h1);                                \
+  } while (0)
+
+__device__ __forceinline__ uint32_t status_index(uint32_t status, uint32_t sleeps) { // battle.h:103-123
+  if (!(status & 7)) return (uint32_t)__builtin_ctz(status) - 3;
+  if (!(status & 0x80)) return 3 + sleeps;
+  return 14 - (status & 7);
+}
+
+// Pokemon features (battle.h:16-214) accumulated into h0/h1; pk = 6 dwords of the 24-byte slot
+#define POKEMON_FEATURES(w0t, hidden, pk0, pk1, pk2, pk3, pk4, pk5, sleep, off)                       \
+  do {                                                                                                \
+    ROW_ADD(w0t, hidden, (off) + 0, (float)((pk0) & 0xFFFF) / 703.0f);                                \
+    ROW_ADD(w0t, hidden, (off) + 1, (float)((pk0) >> 16) / 999.0f);                                   \
+    ROW_ADD(w0t, hidden, (off) + 2, (float)((pk1) & 0xFFFF) / 999.0f);                                \
+    ROW_ADD(w0t, hidden, (off) + 3, (float)((pk1) >> 16) / 999.0f);                                   \
+    ROW_ADD(w0t, hidden, (off) + 4, (float)((pk2) & 0xFFFF) / 999.0f);                                \
+    const uint32_t _mv[4] = {(pk2) >> 16, (pk3) & 0xFFFF, (pk3) >> 16, (pk4) & 0xFFFF};               \
+    for (int _m = 0; _m < 4; ++_m) {                                                                  \
+      const uint32_t _id = _mv[_m] & 0xFF, _pp = _mv[_m] >> 8;                                        \
+      if (_id != 0 && _id != 165 && _pp != 0) ROW_ADD(w0t, hidden, (off) + 5 + _id - 1, 1.0f);       \
+    }                                                                                                 \
+    const uint32_t _st = (pk5) & 0xFF;                                                                \
+    if (_st) ROW_ADD(w0t, hidden, (off) + 169 + status_index(_st, (sleep)), 1.0f);                    \
+    const uint32_t _ty = ((pk5) >> 16) & 0xFF, _t1 = _ty & 15, _t2 = _ty >> 4;                        \
+    ROW_ADD(w0t, hidden, (off) + 183 + _t1, 1.0f);                                                    \
+    if (_t2 != _t1) ROW_ADD(w0t, hidden, (off) + 183 + _t2, 1.0f);                                    \
+  } while (0)
+
+__global__ __launch_bounds__(EMB_BLOCK) void k_embed(EmbedArgs a) {
+  extern __shared__ __align__(16) float lds_f[];
+  const NetDev &N = a.net;
+  // stage W1^T of both embedding nets in LDS: [hidden][out] row-major
+  float *p_w1t = lds_f;
+  float *a_w1t = p_w1t + N.p_hidden * N.p_out;
+  for (int i = threadIdx.x; i < N.p_hidden * N.p_out; i += EMB_BLOCK) p_w1t[i] = N.p_w1t[i];
+  for (int i = threadIdx.x; i < N.a_hidden * N.a_out; i += EMB_BLOCK) a_w1t[i] = N.a_w1t[i];
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63;
+  const int c0 = lane, c1 = lane + 64;
+  const uint32_t wave = __builtin_amdgcn_readfirstlane((blockIdx.x * EMB_BLOCK + threadIdx.x) >> 6);
+  const uint32_t n_waves = (gridDim.x * EMB_BLOCK) >> 6;
+  const uint32_t items = a.n * 12;
+  for (uint32_t item = wave; item < items; item += n_waves) {
+    const uint32_t leaf = item / 12, t = item - leaf * 12;
+    const uint32_t side = t / 6, slot = t - side * 6; // slot 0 = active
+    const uint32_t *sb = (const uint32_t *)(a.battles + (size_t)leaf * 384 + side * 184);
+    const uint32_t dur = ((const uint32_t *)a.durations)[(size_t)leaf * 2 + side];
+    // order bytes live at side offset 176..181: dwords 44, 45
+    const uint32_t o0 = sb[44], o1 = sb[45];
+    const uint32_t id = slot < 4 ? (o0 >> (8 * slot)) & 0xFF : (o1 >> (8 * (slot - 4))) & 0xFF;
+    const int out_dim = slot == 0 ? N.a_out : N.p_out;
+    float *dst = a.emb + (size_t)leaf * N.emb_dim + side * N.side_dim +
+                 (slot == 0 ? 0 : (1 + N.a_out) + (slot - 1) * (1 + N.p_out));
+    uint32_t pk0 = 0, pk1 = 0, pk2 = 0, pk3 = 0, pk4 = 0, pk5 = 0, hp = 0;
+    if (id != 0) {
+      const uint32_t *pk = sb + 6 * (id - 1);
+      pk0 = pk[0]; pk1 = pk[1]; pk2 = pk[2]; pk3 = pk[3]; pk4 = pk[4]; pk5 = pk[5];
+      hp = pk4 >> 16;
+    }
+    if (hp == 0) { // empty or fainted: zero block (network.h:142-143,153-160)
+      for (int o = lane; o < out_dim + 1; o += 64) dst[o] = 0.0f;
+      continue;
+    }
+    float h0, h1;
+    const float *w1t;
+    int hidden;
+    if (slot == 0) {
+      hidden = N.a_hidden;
+      h0 = c0 < hidden ? N.a_b0[c0] : 0.0f;
+      h1 = c1 < hidden ? N.a_b0[c1] : 0.0f;
+      const uint32_t *ac = sb + 36; // active at byte 144
+      const uint32_t a0 = ac[0], a1 = ac[1], a2 = ac[2], a3 = ac[3], vlo = ac[4], vhi = ac[5], m01 = ac[6], m23 = ac[7];
+      const float *w0t = N.a_w0t;
+      ROW_ADD(w0t, hidden, 0, (float)(a0 & 0xFFFF) / 703.0f);
+      ROW_ADD(w0t, hidden, 1, (float)(a0 >> 16) / 999.0f);
+      ROW_ADD(w0t, hidden, 2, (float)(a1 & 0xFFFF) / 999.0f);
+      ROW_ADD(w0t, hidden, 3, (float)(a1 >> 16) / 999.0f);
+      ROW_ADD(w0t, hidden, 4, (float)(a2 & 0xFFFF) / 999.0f);
+      const uint32_t ty = a2 >> 24, t1 = ty & 15, t2 = ty >> 4;
+      ROW_ADD(w0t, hidden, 5 + t1, 1.0f);
+      if (t2 != t1) ROW_ADD(w0t, hidden, 5 + t2, 1.0f);
+      for (int i = 0; i < 6; ++i) { // boosts (battle.h:271-285): ratio * 1/4 (acc/eva 1/3)
+        const int st = (int)((((a3 >> (4 * i)) & 15) ^ 8) - 8);
+        static const float RATIO[13] = {25.0f / 100, 28.0f / 100, 33.0f / 100, 40.0f / 100, 50.0f / 100, 66.0f / 100, 1.0f,
+                                        15.0f / 10, 2.0f, 25.0f / 10, 3.0f, 35.0f / 10, 4.0f};
+        ROW_ADD(w0t, hidden, 20 + i, RATIO[st + 6] * (i < 4 ? 0.25f : (float)(1 / 3.0)));
+      }
+      // volatiles (battle.h:322-352): 16 flags then state / sub hp / toxic counter
+      const uint32_t flagbits[16] = {0, 1, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17};
+      for (int i = 0; i < 16; ++i)
+        if ((vlo >> flagbits[i]) & 1) ROW_ADD(w0t, hidden, 26 + i, 1.0f);
+      const uint32_t state = (vlo >> 24) | ((vhi & 0xFF) << 8), sub = (vhi >> 8) & 0xFF, tox = vhi >> 27;
+      if (state) ROW_ADD(w0t, hidden, 26 + 16, (float)state / 65535.0f);
+      if (sub) ROW_ADD(w0t, hidden, 26 + 17, (float)sub / 177.0f);
+      if (tox) ROW_ADD(w0t, hidden, 26 + 18, (float)tox / 16.0f);
+      const uint32_t mv[4] = {m01 & 0xFFFF, m01 >> 16, m23 & 0xFFFF, m23 >> 16};
+      for (int m = 0; m < 4; ++m) {
+        const uint32_t mid = mv[m] & 0xFF, pp = mv[m] >> 8;
+        if (mid != 0 && mid != 165 && pp != 0) ROW_ADD(w0t, hidden, 45 + mid - 1, 1.0f);
+      }
+      const uint32_t dc = (dur >> 18) & 7, dd = (dur >> 21) & 15, da = (dur >> 25) & 7, db = (dur >> 28) & 7;
+      if (dc) ROW_ADD(w0t, hidden, 209 + dc - 1, 1.0f);
+      if (dd) ROW_ADD(w0t, hidden, 214 + dd - 1, 1.0f);
+      if (da) ROW_ADD(w0t, hidden, 222 + da - 1, 1.0f);
+      if (db) ROW_ADD(w0t, hidden, 225 + db - 1, 1.0f);
+      POKEMON_FEATURES(w0t, hidden, pk0, pk1, pk2, pk3, pk4, pk5, dur & 7, 229);
+      w1t = a_w1t;
+    } else {
+      hidden = N.p_hidden;
+      h0 = c0 < hidden ? N.p_b0[c0] : 0.0f;
+      h1 = c1 < hidden ? N.p_b0[c1] : 0.0f;
+      const float *w0t = N.p_w0t;
+      POKEMON_FEATURES(w0t, hidden, pk0, pk1, pk2, pk3, pk4, pk5, (dur >> (3 * slot)) & 7, 0);
+      w1t = p_w1t;
+    }
+    h0 = act_fn(h0, N.activation);
+    h1 = act_fn(h1, N.activation);
+    // dense second layer: out[o] = b1[o] + sum_c W1t[c][o] * h[c]; h[c] broadcast by readlane
+    const float *b1 = slot == 0 ? N.a_b1 : N.p_b1;
+    const int oa = lane, ob = lane + 64;
+    float ya = oa < out_dim ? b1[oa] : 0.0f, yb = ob < out_dim ? b1[ob] : 0.0f;
+    const int nlo = hidden < 64 ? hidden : 64;
+    for (int c = 0; c < nlo; ++c) {
+      const float hc = __shfl(h0, c, 64);
+      if (oa < out_dim) ya = fmaf(w1t[c * out_dim + oa], hc, ya);
+      if (ob < out_dim) yb = fmaf(w1t[c * out_dim + ob], hc, yb);
+    }
+    for (int c = 64; c < hidden; ++c) {
+      const float hc = __shfl(h1, c - 64, 64);
+      if (oa < out_dim) ya = fmaf(w1t[c * out_dim + oa], hc, ya);
+      if (ob < out_dim) yb = fmaf(w1t[c * out_dim + ob], hc, yb);
+    }
+    if (lane == 0) dst[0] = (float)hp / (float)(pk0 & 0xFFFF);
+    if (oa < out_dim) dst[1 + oa] = act_fn(ya, N.activation);
+    if (ob < out_dim) dst[1 + ob] = act_fn(yb, N.activation);
+  }
+}
+
+// ---- K3: main net on fp32 MFMA ------------------------------------------------------------------
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+constexpr int MN_BLOCK = 256; // 4 waves
+constexpr int TM = 64;        // leaves per workgroup tile
+constexpr int KC = 32;        // K chunk staged per iteration
+constexpr int KCP = KC + 1;   // padded LDS row stride (odd => conflict-free column reads)
+constexpr int MAXH = 256;
+
+struct MainArgs {
+  NetDev net;
+  const float *emb; // n x emb_dim
+  uint32_t n;
+  float *values;
+};
+
+// One dense layer for a TM x Hout tile: acc = A(TM x K) . W^T, A read through a_at(row, k).
+// A either comes from global (staged in xs per chunk) or from the LDS activation tile.
+template <bool A_FROM_GLOBAL>
+__device__ __forceinline__ void dense_layer(const float *a_global, int a_ld, uint32_t row0, uint32_t n_rows, // global A
+                                            const float *a_lds, int a_lds_ld,                               // LDS A
+                                            const float *W, int K, int Hout, float *xs, float *ws, f32x16 (&acc)[4]) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int mi = wave & 1, nb0 = wave >> 1, NB = Hout / 32;
+  const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[j][q] = 0.0f;
+  for (int k0 = 0; k0 < K; k0 += KC) {
+    __syncthreads(); // previous chunk fully consumed
+    if (A_FROM_GLOBAL) {
+      // X chunk: TM rows x KC floats; 8 threads per row, float4 each
+      for (int i = tid; i < TM * (KC / 4); i += MN_BLOCK) {
+        const int row = i / (KC / 4), q = i - row * (KC / 4);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if ((uint32_t)row < n_rows && k0 + 4 * q < K) v = *(const float4 *)(a_global + (size_t)(row0 + row) * a_ld + k0 + 4 * q);
+        float *d = xs + row * KCP + 4 * q;
+        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+      }
+    }
+    for (int i = tid; i < Hout * (KC / 4); i += MN_BLOCK) {
+      const int row = i / (KC / 4), q = i - row * (KC / 4);
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (k0 + 4 * q < K) v = *(const float4 *)(W + (size_t)row * K + k0 + 4 * q);
+      float *d = ws + row * KCP + 4 * q;
+      d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    }
+    __syncthreads();
+    const int kmax = (K - k0) < KC ? (K - k0) : KC;
+    for (int s = 0; s < kmax / 2; ++s) {
+      const int k = 2 * s + h;
+      const float av = A_FROM_GLOBAL ? xs[(mi * 32 + r) * KCP + k] : a_lds[(mi * 32 + r) * a_lds_ld + k0 + k];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int ni = nb0 + 2 * j;
+        if (ni < NB) {
+          const float bv = ws[(ni * 32 + r) * KCP + k];
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[j], 0, 0, 0);
+        }
+      }
+    }
+  }
+}
+
+// bias + activation, accumulators -> LDS activation tile [TM][ld]
+__device__ __forceinline__ void store_act(const f32x16 (&acc)[4], const float *bias, int Hout, int activation, float *hs, int ld) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int mi = wave & 1, nb0 = wave >> 1, NB = Hout / 32;
+  const int col = lane & 31, hh = lane >> 5;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int ni = nb0 + 2 * j;
+    if (ni < NB) {
+      const int nn = ni * 32 + col;
+      const float b = bias[nn];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int row = (q & 3) + 8 * (q >> 2) + 4 * hh;
+        hs[(mi * 32 + row) * ld + nn] = act_fn(acc[j][q] + b, activation);
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(MN_BLOCK) void k_mainnet(MainArgs a) {
+  extern __shared__ __align__(16) float lds_f[];
+  const NetDev &N = a.net;
+  const int H = N.H, VH = N.VH;
+  const int hld = (H > VH ? H : VH) + 1;
+  float *xs = lds_f;              // TM x KCP
+  float *ws = xs + TM * KCP;      // MAXH x KCP
+  float *hs = ws + MAXH * KCP;    // TM x hld
+  const uint32_t row0 = blockIdx.x * TM;
+  const uint32_t n_rows = min((uint32_t)TM, a.n - row0);
+  f32x16 acc[4];
+  dense_layer<true>(a.emb, N.emb_dim, row0, n_rows, nullptr, 0, N.w0, N.emb_dim, H, xs, ws, acc);
+  __syncthreads();
+  store_act(acc, N.b0, H, N.activation, hs, hld);
+  __syncthreads();
+  dense_layer<false>(nullptr, 0, 0, 0, hs, hld, N.w1, H, H, xs, ws, acc);
+  __syncthreads(); // every wave done reading hs
+  store_act(acc, N.b1, H, N.activation, hs, hld);
+  __syncthreads();
+  dense_layer<false>(nullptr, 0, 0, 0, hs, hld, N.w2, H, VH, xs, ws, acc);
+  __syncthreads();
+  store_act(acc, N.b2, VH, N.activation, hs, hld);
+  __syncthreads();
+  if (threadIdx.x < n_rows) { // value_fc3 + sigmoid (network.h:14,75)
+    const float *hrow = hs + threadIdx.x * hld;
+    float y = N.b3;
+    for (int j = 0; j < VH; ++j) y = fmaf(hrow[j], N.w3[j], y);
+    a.values[row0 + threadIdx.x] = 1.0f / (1.0f + expf(-y));
+  }
+}
+
+} // namespace oak
+
+// =================================== C ABI =====================================================
+struct oakgpu_net {
+  oak::NetDev dev;
+  std::vector<void *> allocs;
+  int in_dim, hidden, value_hidden, policy_hidden; // unpadded, as in the file
+  float *emb_ws;     // lazily grown workspace: n x emb_dim
+  size_t emb_ws_rows;
+};
+
+namespace {
+struct HostAffine { uint32_t in, out; std::vector<float> b, w; };
+
+bool read_affine(const uint8_t *&p, const uint8_t *end, HostAffine &a) {
+  if (end - p < 8) return false;
+  memcpy(&a.in, p, 4);
+  memcpy(&a.out, p + 4, 4);
+  p += 8;
+  if (a.in == 0 || a.out == 0 || a.in > (1u << 16) || a.out > (1u << 16)) return false;
+  const size_t nb = (size_t)a.out * 4, nw = (size_t)a.out * a.in * 4;
+  if ((size_t)(end - p) < nb + nw) return false;
+  a.b.resize(a.out);
+  a.w.resize((size_t)a.out * a.in);
+  memcpy(a.b.data(), p, nb);
+  p += nb;
+  memcpy(a.w.data(), p, nw);
+  p += nw;
+  return true;
+}
+
+int upload(oakgpu_net *net, const std::vector<float> &h, const float **out) {
+  void *d = nullptr;
+  hipError_t e = hipMalloc(&d, h.size() * 4);
+  if (e != hipSuccess) return oakgpu_fail_hip((int)e, "hipMalloc(net)");
+  net->allocs.push_back(d);
+  e = hipMemcpy(d, h.data(), h.size() * 4, hipMemcpyHostToDevice);
+  if (e != hipSuccess) return oakgpu_fail_hip((int)e, "hipMemcpy(net)");
+  *out = (const float *)d;
+  return 0;
+}
+
+std::vector<float> transpose(const HostAffine &a) { // W[out][in] -> Wt[in][out]
+  std::vector<float> t((size_t)a.in * a.out);
+  for (uint32_t o = 0; o < a.out; ++o)
+    for (uint32_t i = 0; i < a.in; ++i) t[(size_t)i * a.out + o] = a.w[(size_t)o * a.in + i];
+  return t;
+}
+// pad rows (out) to a multiple of 32 and columns (in) to `in_pad` with zeros
+std::vector<float> pad_rows(const HostAffine &a, uint32_t out_pad, uint32_t in_pad) {
+  std::vector<float> t((size_t)out_pad * in_pad, 0.0f);
+  for (uint32_t o = 0; o < a.out; ++o)
+    for (uint32_t i = 0; i < a.in; ++i) t[(size_t)o * in_pad + i] = a.w[(size_t)o * a.in + i];
+  return t;
+}
+std::vector<float> pad_vec(const std::vector<float> &v, uint32_t n) {
+  std::vector<float> t(n, 0.0f);
+  for (size_t i = 0; i < v.size(); ++i) t[i] = v[i];
+  return t;
+}
+uint32_t up32(uint32_t x) { return (x + 31) & ~31u; }
+} // namespace
+
+extern "C" {
+
+void oakgpu_net_free(oakgpu_ctx *ctx, oakgpu_net *net) {
+  (void)ctx;
+  if (!net) return;
+  for (void *p : net->allocs) (void)hipFree(p);
+  if (net->emb_ws) (void)hipFree(net->emb_ws);
+  delete net;
+}
+
+int oakgpu_net_load_memory(oakgpu_ctx *ctx, const void *bytes, size_t size, oakgpu_net **out) {
+  if (!ctx || !bytes || !out) return oakgpu_fail_msg("oakgpu_net_load_memory: null argument");
+  const uint8_t *p = (const uint8_t *)bytes, *end = p + size;
+  if (size < 8) return oakgpu_fail_msg("network file: truncated header");
+  const int activation = (int)p[0] + 1; // search.cc:127-131: byte0 = activation - 1
+  if (activation != 1 && activation != 2) return oakgpu_fail_msg("network file: unknown activation byte");
+  p += 8;
+  HostAffine L[12]; // p0 p1 a0 a1 fc0 fc1 v2 v3 q1a q1b q2a q2b
+  for (int i = 0; i < 12; ++i)
+    if (!read_affine(p, end, L[i])) return oakgpu_fail_msg("network file: truncated or malformed layer");
+  if (p != end) return oakgpu_fail_msg("network file: trailing bytes (network.h:60-63)");
+  const HostAffine &p0 = L[0], &p1 = L[1], &a0 = L[2], &a1 = L[3], &fc0 = L[4], &fc1 = L[5], &v2 = L[6], &v3 = L[7];
+  if (p0.in != 198 || a0.in != 427) return oakgpu_fail_msg("network file: embedding input dims must be 198 / 427");
+  if (p1.in != p0.out || a1.in != a0.out || fc1.in != fc0.out || v2.in != fc1.out || v3.in != v2.out || v3.out != 1)
+    return oakgpu_fail_msg("network file: inconsistent layer dims");
+  if (p0.out > 128 || a0.out > 128 || p1.out > 128 || a1.out > 128) return oakgpu_fail_msg("embedding widths above 128 unsupported");
+  const uint32_t side_dim = (1 + a1.out) + 5 * (1 + p1.out);
+  if (fc0.in != 2 * side_dim) return oakgpu_fail_msg("network file: fc0 input != 2 * side embedding");
+  if (fc0.out != fc1.out) return oakgpu_fail_msg("network file: fc0/fc1 widths differ");
+  const uint32_t H = up32(fc0.out), VH = up32(v2.out);
+  if (H > (uint32_t)oak::MAXH || VH > (uint32_t)oak::MAXH) return oakgpu_fail_msg("main-net widths above 256 unsupported");
+  if (fc0.in % 4) return oakgpu_fail_msg("embedding dim must be a multiple of 4");
+  hipError_t he = hipSetDevice(oakgpu_ctx_device(ctx));
+  if (he != hipSuccess) return oakgpu_fail_hip((int)he, "hipSetDevice");
+  oakgpu_net *net = new oakgpu_net();
+  net->emb_ws = nullptr;
+  net->emb_ws_rows = 0;
+  net->in_dim = (int)fc0.in;
+  net->hidden = (int)fc0.out;
+  net->value_hidden = (int)v2.out;
+  net->policy_hidden = (int)L[8].out;
+  oak::NetDev &D = net->dev;
+  D.activation = activation;
+  D.p_hidden = (int)p0.out; D.p_out = (int)p1.out; D.a_hidden = (int)a0.out; D.a_out = (int)a1.out;
+  D.side_dim = (int)side_dim; D.emb_dim = (int)fc0.in;
+  D.H = (int)H; D.VH = (int)VH;
+  D.b3 = v3.b[0];
+  int rc = 0;
+  rc = rc ? rc : upload(net, transpose(p0), &D.p_w0t);
+  rc = rc ? rc : upload(net, p0.b, &D.p_b0);
+  rc = rc ? rc : upload(net, transpose(p1), &D.p_w1t);
+  rc = rc ? rc : upload(net, p1.b, &D.p_b1);
+  rc = rc ? rc : upload(net, transpose(a0), &D.a_w0t);
+  rc = rc ? rc : upload(net, a0.b, &D.a_b0);
+  rc = rc ? rc : upload(net, transpose(a1), &D.a_w1t);
+  rc = rc ? rc : upload(net, a1.b, &D.a_b1);
+  rc = rc ? rc : upload(net, pad_rows(fc0, H, fc0.in), &D.w0);
+  rc = rc ? rc : upload(net, pad_vec(fc0.b, H), &D.b0);
+  rc = rc ? rc : upload(net, pad_rows(fc1, H, H), &D.w1);
+  rc = rc ? rc : upload(net, pad_vec(fc1.b, H), &D.b1);
+  rc = rc ? rc : upload(net, pad_rows(v2, VH, H), &D.w2);
+  rc = rc ? rc : upload(net, pad_vec(v2.b, VH), &D.b2);
+  rc = rc ? rc : upload(net, pad_vec(v3.w, VH), &D.w3);
+  if (rc) { oakgpu_net_free(ctx, net); return rc; }
+  *out = net;
+  return 0;
+}
+
+int oakgpu_net_load(oakgpu_ctx *ctx, const char *path, oakgpu_net **out) {
+  if (!path) return oakgpu_fail_msg("oakgpu_net_load: null path");
+  FILE *f = fopen(path, "rb");
+  if (!f) return oakgpu_fail_msg((std::string("Cannot open network file: ") + path).c_str());
+  std::vector<uint8_t> buf;
+  uint8_t tmp[1 << 16];
+  size_t r;
+  while ((r = fread(tmp, 1, sizeof tmp, f)) > 0) buf.insert(buf.end(), tmp, tmp + r);
+  fclose(f);
+  return oakgpu_net_load_memory(ctx, buf.data(), buf.size(), out);
+}
+
+int oakgpu_net_shape(const oakgpu_net *net, int *in_dim, int *hidden, int *value_hidden, int *policy_hidden) {
+  if (!net) return oakgpu_fail_msg("null net");
+  if (in_dim) *in_dim = net->in_dim;
+  if (hidden) *hidden = net->hidden;
+  if (value_hidden) *value_hidden = net->value_hidden;
+  if (policy_hidden) *policy_hidden = net->policy_hidden;
+  return 0;
+}
+
+static int lds_attrs_once() {
+  static bool done = false;
+  if (done) return 0;
+  hipError_t e = hipFuncSetAttribute((const void *)oak::k_embed, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+  if (e != hipSuccess) return oakgpu_fail_hip((int)e, "hipFuncSetAttribute(k_embed)");
+  e = hipFuncSetAttribute((const void *)oak::k_mainnet, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+  if (e != hipSuccess) return oakgpu_fail_hip((int)e, "hipFuncSetAttribute(k_mainnet)");
+  done = true;
+  return 0;
+}
+
+int oakgpu_leaf_eval_dev(oakgpu_ctx *ctx, oakgpu_net *net, const uint8_t *battles, const uint8_t *durations, uint32_t n,
+                         float *values, float *embedding_out) {
+  if (!ctx || !net) return oakgpu_fail_msg("oakgpu_leaf_eval_dev: null ctx/net");
+  if (n == 0) return 0;
+  if (!battles || !durations || !values) return oakgpu_fail_msg("oakgpu_leaf_eval_dev: null required pointer");
+  if (int rc = lds_attrs_once()) return rc;
+  hipStream_t stream = (hipStream_t)oakgpu_ctx_stream(ctx);
+  float *emb = embedding_out;
+  if (!emb) {
+    if (net->emb_ws_rows < n) {
+      hipError_t e = hipStreamSynchronize(stream);
+      if (e != hipSuccess) return oakgpu_fail_hip((int)e, "hipStreamSynchronize");
+      if (net->emb_ws) (void)hipFree(net->emb_ws);
+      net->emb_ws = nullptr;
+      e = hipMalloc((void **)&net->emb_ws, (size_t)n * net->dev.emb_dim * 4);
+      if (e != hipSuccess) return oakgpu_fail_hip((int)e, "hipMalloc(embedding workspace)");
+      net->emb_ws_rows = n;
+    }
+    emb = net->emb_ws;
+  }
+  const oak::NetDev &D = net->dev;
+  oak::EmbedArgs ea{D, battles, durations, n, emb};
+  const size_t emb_lds = (size_t)(D.p_hidden * D.p_out + D.a_hidden * D.a_out) * 4;
+  uint32_t waves_needed = n * 12;
+  uint32_t grid = (waves_needed + 3) / 4;
+  if (grid > 256 * 8) grid = 256 * 8;
+  hipLaunchKernelGGL(oak::k_embed, dim3(grid), dim3(oak::EMB_BLOCK), emb_lds, stream, ea);
+  oak::MainArgs ma{D, emb, n, values};
+  const int hld = (D.H > D.VH ? D.H : D.VH) + 1;
+  const size_t mn_lds = (size_t)(oak::TM * oak::KCP + oak::MAXH * oak::KCP + oak::TM * hld) * 4;
+  hipLaunchKernelGGL(oak::k_mainnet, dim3((n + oak::TM - 1) / oak::TM), dim3(oak::MN_BLOCK), mn_lds, stream, ma);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return oakgpu_fail_hip((int)e, "leaf_eval launch");
+  return 0;
+}
+
+int oakgpu_leaf_eval(oakgpu_ctx *ctx, oakgpu_net *net, const uint8_t *battles, const uint8_t *durations, uint32_t n,
+                     float *values, float *embedding_out) {
+  if (!ctx || !net) return oakgpu_fail_msg("oakgpu_leaf_eval: null ctx/net");
+  if (n == 0) return 0;
+  hipStream_t stream = (hipStream_t)oakgpu_ctx_stream(ctx);
+  void *db = nullptr, *dd = nullptr, *dv = nullptr, *de = nullptr;
+  int rc = 0;
+  hipError_t e;
+#define TRY(x) do { e = (x); if (e != hipSuccess) { rc = oakgpu_fail_hip((int)e, #x); goto done; } } while (0)
+  TRY(hipSetDevice(oakgpu_ctx_device(ctx)));
+  TRY(hipMalloc(&db, (size_t)n * 384));
+  TRY(hipMalloc(&dd, (size_t)n * 8));
+  TRY(hipMalloc(&dv, (size_t)n * 4));
+  if (embedding_out) TRY(hipMalloc(&de, (size_t)n * net->dev.emb_dim * 4));
+  TRY(hipMemcpyAsync(db, battles, (size_t)n * 384, hipMemcpyHostToDevice, stream));
+  TRY(hipMemcpyAsync(dd, durations, (size_t)n * 8, hipMemcpyHostToDevice, stream));
+  rc = oakgpu_leaf_eval_dev(ctx, net, (const uint8_t *)db, (const uint8_t *)dd, n, (float *)dv, (float *)de);
+  if (rc) goto done;
+  TRY(hipMemcpyAsync(values, dv, (size_t)n * 4, hipMemcpyDeviceToHost, stream));
+  if (embedding_out) TRY(hipMemcpyAsync(embedding_out, de, (size_t)n * net->dev.emb_dim * 4, hipMemcpyDeviceToHost, stream));
+  TRY(hipStreamSynchronize(stream));
+done:
+  if (db) (void)hipFree(db);
+  if (dd) (void)hipFree(dd);
+  if (dv) (void)hipFree(dv);
+  if (de) (void)hipFree(de);
+  return rc;
+#undef TRY
+}
+
+} // extern "C"

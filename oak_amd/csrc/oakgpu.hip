@@ -12,11 +12,13 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <string>
 
 #include "../../include/oakgpu.h"
 #include "gen1_device.hpp"
+#include "oakgpu_internal.h"
 
 namespace oak {
 
@@ -31,18 +33,20 @@ __device__ __forceinline__ Tables stage_default_tables(lds_u8 *lds) {
 }
 
 // AoS (n x 384 B, 4-byte aligned) <-> lane-interleaved LDS, whole workgroup cooperating.
+template <int BLK = BLOCK>
 __device__ __forceinline__ void load_state(lds_u32 *state, const uint8_t *battles, uint32_t base, uint32_t count) {
   const uint32_t *src = (const uint32_t *)battles + (size_t)base * STATE_WORDS;
-  for (uint32_t i = threadIdx.x; i < count * STATE_WORDS; i += BLOCK) {
+  for (uint32_t i = threadIdx.x; i < count * STATE_WORDS; i += BLK) {
     uint32_t b = i / STATE_WORDS, w = i - b * STATE_WORDS;
-    state[w * BLOCK + b] = src[i];
+    state[w * BLK + b] = src[i];
   }
 }
+template <int BLK = BLOCK>
 __device__ __forceinline__ void store_state(const lds_u32 *state, uint8_t *battles, uint32_t base, uint32_t count) {
   uint32_t *dst = (uint32_t *)battles + (size_t)base * STATE_WORDS;
-  for (uint32_t i = threadIdx.x; i < count * STATE_WORDS; i += BLOCK) {
+  for (uint32_t i = threadIdx.x; i < count * STATE_WORDS; i += BLK) {
     uint32_t b = i / STATE_WORDS, w = i - b * STATE_WORDS;
-    dst[i] = state[w * BLOCK + b];
+    dst[i] = state[w * BLK + b];
   }
 }
 
@@ -143,17 +147,18 @@ struct RolloutArgs {
   uint8_t *durations_out;
 };
 
-__global__ __launch_bounds__(BLOCK) void k_rollout(RolloutArgs a) {
+template <int BLK>
+__global__ __launch_bounds__(BLK) void k_rollout(RolloutArgs a) {
   extern __shared__ __align__(16) uint8_t smem[];
   lds_u32 *state = (lds_u32 *)smem;
-  Tables T = stage_default_tables((lds_u8 *)smem + STATE_LDS_BYTES);
-  const uint32_t base = blockIdx.x * BLOCK;
-  const uint32_t count = min((uint32_t)BLOCK, a.n - base);
-  load_state(state, a.battles, base, count);
+  Tables T = stage_default_tables((lds_u8 *)smem + STATE_WORDS * BLK * 4);
+  const uint32_t base = blockIdx.x * BLK;
+  const uint32_t count = min((uint32_t)BLK, a.n - base);
+  load_state<BLK>(state, a.battles, base, count);
   __syncthreads();
   const uint32_t tid = threadIdx.x, lane = base + tid;
   if (tid < count) {
-    Engine<BLOCK, false> e;
+    Engine<BLK, false> e;
     e.m = state + tid;
     e.T = T;
     const uint32_t *dsrc = (const uint32_t *)a.durations + 2 * (size_t)lane;
@@ -195,7 +200,7 @@ __global__ __launch_bounds__(BLOCK) void k_rollout(RolloutArgs a) {
   }
   if (a.battles_out) {
     __syncthreads();
-    store_state(state, a.battles_out, base, count);
+    store_state<BLK>(state, a.battles_out, base, count);
   }
 }
 
@@ -383,6 +388,7 @@ struct oakgpu_ctx {
   bool own_stream;
   uint8_t *d_legal, *d_pools, *d_sizes;
   int n_legal;
+  int rollout_block; // threads per workgroup of k_rollout (64 or 256)
 };
 
 static thread_local std::string g_err;
@@ -394,6 +400,10 @@ static int bad(const char *what) {
   g_err = what;
   return -1;
 }
+int oakgpu_fail_hip(int e, const char *what) { return fail((hipError_t)e, what); }
+int oakgpu_fail_msg(const char *what) { return bad(what); }
+int oakgpu_ctx_device(const oakgpu_ctx *c) { return c->device; }
+void *oakgpu_ctx_stream(const oakgpu_ctx *c) { return (void *)c->stream; }
 #define HIPCHK(x) do { hipError_t _e = (x); if (_e != hipSuccess) return fail(_e, #x); } while (0)
 
 extern "C" {
@@ -407,7 +417,8 @@ int oakgpu_device_count(void) {
 }
 
 static int set_lds_limits() {
-  HIPCHK(hipFuncSetAttribute((const void *)oak::k_rollout, hipFuncAttributeMaxDynamicSharedMemorySize, oak::ENGINE_LDS_BYTES));
+  HIPCHK(hipFuncSetAttribute((const void *)oak::k_rollout<256>, hipFuncAttributeMaxDynamicSharedMemorySize, oak::ENGINE_LDS_BYTES));
+  HIPCHK(hipFuncSetAttribute((const void *)oak::k_rollout<64>, hipFuncAttributeMaxDynamicSharedMemorySize, oak::STATE_WORDS * 64 * 4 + oak::TABLE_LDS_PAD));
   HIPCHK(hipFuncSetAttribute((const void *)oak::k_update, hipFuncAttributeMaxDynamicSharedMemorySize, oak::ENGINE_LDS_BYTES));
   HIPCHK(hipFuncSetAttribute((const void *)oak::k_choices, hipFuncAttributeMaxDynamicSharedMemorySize, oak::ENGINE_LDS_BYTES));
   HIPCHK(hipFuncSetAttribute((const void *)oak::k_init, hipFuncAttributeMaxDynamicSharedMemorySize, oak::ENGINE_LDS_BYTES));
@@ -428,6 +439,8 @@ int oakgpu_create(oakgpu_ctx **out, int device) {
   c->own_stream = true;
   c->d_legal = c->d_pools = c->d_sizes = nullptr;
   c->n_legal = 0;
+  c->rollout_block = 64;
+  if (const char *env = getenv("OAKGPU_ROLLOUT_BLOCK")) c->rollout_block = atoi(env) == 256 ? 256 : 64;
   hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
   if (e != hipSuccess) { delete c; return fail(e, "hipStreamCreate"); }
   *out = c;
@@ -470,7 +483,10 @@ int oakgpu_rollout_dev(oakgpu_ctx *c, const uint8_t *battles, const uint8_t *dur
     return bad("oakgpu_rollout_dev: null required pointer");
   oak::RolloutArgs a{battles, durations, results_in, prng_state, n, max_steps, prep, results_out, steps_out, values_out,
                      battles_out, durations_out};
-  hipLaunchKernelGGL(oak::k_rollout, dim3(grid_for(n)), dim3(oak::BLOCK), oak::ENGINE_LDS_BYTES, c->stream, a);
+  if (c->rollout_block == 64)
+    hipLaunchKernelGGL(oak::k_rollout<64>, dim3((n + 63) / 64), dim3(64), oak::STATE_WORDS * 64 * 4 + oak::TABLE_LDS_PAD, c->stream, a);
+  else
+    hipLaunchKernelGGL(oak::k_rollout<256>, dim3(grid_for(n)), dim3(256), oak::ENGINE_LDS_BYTES, c->stream, a);
   HIPCHK(hipGetLastError());
   return 0;
 }

@@ -8,8 +8,11 @@ through the C ABI of liboakgpu.so (include/oakgpu.h); nothing here computes on t
   Context.update(...)    <- pkmn_gen1_battle_update / PKMN::update libpkmn/pkmn.h:106-139
   Context.choices(...)   <- pkmn_gen1_battle_choices               libpkmn/pkmn.h:141-156
   Context.battle(...)    <- PKMN::battle(p1, p2, seed)             libpkmn/pkmn.h:50-57
+  Network.value_inference(...) <- NN::Battle::NetworkImpl::value_inference  nn/battle/network.h:72-79
 """
 import ctypes as C
+import os
+
 import numpy as np
 
 from . import _lib, gamedata
@@ -112,3 +115,40 @@ class Context:
         _lib.check(self.lib.oakgpu_init_battles(self.handle, _p(teams), _p(seeds), n, 1 if first_update else 0,
                                                 _p(b), _p(d), _p(r)))
         return b, d, r
+
+
+class Network:
+    """Battle network on the GPU.  Mirrors NN::Battle::Network (nn/battle/network.h:22-176): constructed
+    from a `.battle.net` parameter file; raises RuntimeError (OakGpuError) on an unreadable or malformed
+    file like the reference's loader (search.cc:62-148)."""
+
+    def __init__(self, ctx, path=None, data=None):
+        self.ctx = ctx
+        h = C.c_void_p()
+        if path is not None:
+            _lib.check(ctx.lib.oakgpu_net_load(ctx.handle, os.fsencode(path), C.byref(h)))
+        else:
+            buf = (C.c_ubyte * len(data)).from_buffer_copy(data)
+            _lib.check(ctx.lib.oakgpu_net_load_memory(ctx.handle, buf, len(data), C.byref(h)))
+        self.handle = h
+
+    def shape(self):
+        """(fc0.in, fc0.out, value_fc2.out, p1_policy_fc2.out) -- MainNet::shape(), main-net.h:32-34."""
+        v = [C.c_int() for _ in range(4)]
+        _lib.check(self.ctx.lib.oakgpu_net_shape(self.handle, *[C.byref(x) for x in v]))
+        return tuple(x.value for x in v)
+
+    def value_inference(self, battles, durations, return_embedding=False):
+        battles = _u8(battles)
+        n = battles.shape[0]
+        durations = _u8(durations, (n, 8))
+        values = np.zeros(n, dtype=np.float32)
+        emb = np.zeros((n, self.shape()[0]), dtype=np.float32) if return_embedding else None
+        _lib.check(self.ctx.lib.oakgpu_leaf_eval(self.ctx.handle, self.handle, _p(battles), _p(durations), n,
+                                                 _p(values), _p(emb)))
+        return (values, emb) if return_embedding else values
+
+    def close(self):
+        if self.handle:
+            self.ctx.lib.oakgpu_net_free(self.ctx.handle, self.handle)
+            self.handle = None

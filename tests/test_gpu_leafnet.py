@@ -1,0 +1,69 @@
+"""GPU: fused leaf evaluator (K2 encode+embed, K3 fp32-MFMA main net) vs the numpy oracle.
+Tolerance from BASELINE.json north_star: |value - reference| <= 1e-5."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import nn_oracle as NN  # noqa: E402
+import oracle_lib as O  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+def _midgame_states(n, steps, seed0):
+    """Random OU battles advanced `steps` random turn-steps on the oracle (statuses, boosts,
+    volatiles, durations, fainted slots all appear)."""
+    b, d, p, r = O.make_random_ou_batch(n, seed0=seed0)
+    out, _ = O.rollout_batch(b, d, r, p, max_steps=steps, threads=4)
+    return b, d
+
+
+@pytest.mark.parametrize("tag", ["default", "tiny"])
+def test_value_inference_matches_oracle(gpu_ctx, tag):
+    from oak_amd.engine import Network
+    path = os.path.join(ROOT, "tests", "golden", "net_%s.battle.net" % tag)
+    net = Network(gpu_ctx, path=path)
+    onet = NN.Net(path)
+    assert net.shape()[:3] == (onet.fc0.in_dim, onet.fc0.out_dim, onet.v2.out_dim)
+    worst = 0.0
+    for steps, seed0 in ((0, 1000), (7, 2000), (40, 3000), (90, 4000)):
+        b, d = _midgame_states(192, steps, seed0)
+        vals, emb = net.value_inference(b, d, return_embedding=True)
+        for i in range(b.shape[0]):
+            oe = NN.battle_embedding(onet, b[i], d[i])
+            assert np.abs(emb[i] - oe).max() <= 2e-5, (steps, i, np.abs(emb[i] - oe).argmax())
+            ov = float(onet.main_value(oe))
+            worst = max(worst, abs(float(vals[i]) - ov))
+    assert worst <= TOL, worst
+    net.close()
+
+
+def test_config3_net_256(gpu_ctx, tmp_path):
+    """BASELINE config 3: 768 -> 256 -> 256 -> 256 -> 1 value path, seeded synthetic weights."""
+    from oak_amd.engine import Network
+    path = str(tmp_path / "c3.battle.net")
+    NN.write_random_net(path, hidden=256, value_hidden=256, seed=7)
+    net = Network(gpu_ctx, path=path)
+    onet = NN.Net(path)
+    b, d = _midgame_states(130, 25, 777)   # ragged: not a multiple of the 64-row tile
+    vals = net.value_inference(b, d)
+    exp = np.array([float(NN.value_inference(onet, b[i], d[i])) for i in range(b.shape[0])])
+    assert np.abs(vals - exp).max() <= TOL
+    net.close()
+
+
+def test_bad_network_files_raise(gpu_ctx, tmp_path):
+    from oak_amd.engine import Network
+    from oak_amd._lib import OakGpuError
+    with pytest.raises(OakGpuError):
+        Network(gpu_ctx, path=str(tmp_path / "missing.battle.net"))
+    good = open(os.path.join(ROOT, "tests", "golden", "net_tiny.battle.net"), "rb").read()
+    with pytest.raises(OakGpuError):
+        Network(gpu_ctx, data=good[:-5])          # truncated
+    with pytest.raises(OakGpuError):
+        Network(gpu_ctx, data=good + b"\x00")      # trailing byte (network.h:60-63)

@@ -1,0 +1,55 @@
+"""CPU: the numpy leaf-evaluator oracle against goldens produced by the reference's torch mirror."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import nn_oracle as NN  # noqa: E402
+
+G = np.load(os.path.join(ROOT, "tests", "golden", "nn_goldens.npz"))
+
+
+@pytest.mark.parametrize("tag", ["default", "tiny"])
+def test_subnetworks_match_reference_torch(tag):
+    net = NN.Net(os.path.join(ROOT, "tests", "golden", "net_%s.battle.net" % tag))
+    assert net.activation == (1 if tag == "default" else 2)
+    for x, y in zip(G[tag + "_xp"], G[tag + "_yp"]):
+        nz = np.nonzero(x)[0]
+        got = net.embed(net.p0, net.p1, nz, x[nz])
+        assert np.abs(got - y).max() < 2e-6
+    for x, y in zip(G[tag + "_xa"], G[tag + "_ya"]):
+        nz = np.nonzero(x)[0]
+        got = net.embed(net.a0, net.a1, nz, x[nz])
+        assert np.abs(got - y).max() < 2e-6
+    for x, y in zip(G[tag + "_xm"], G[tag + "_ym"]):
+        assert abs(float(net.main_value(x)) - float(y[0])) < 1e-6
+
+
+def test_default_file_size_matches_reference():
+    # torch.py default BattleNetwork().write_parameters -> 813,436 bytes
+    assert os.path.getsize(os.path.join(ROOT, "tests", "golden", "net_default.battle.net")) == 813436
+
+
+def test_status_index_static_asserts():
+    # cpp/include/encode/battle/battle.h:125-140
+    exp = {(0x08, 0): 0, (0x10, 0): 1, (0x20, 0): 2, (0x40, 0): 3, (0x88, 0): 0, (7, 1): 4, (6, 2): 5, (5, 3): 6, (4, 4): 7,
+           (3, 5): 8, (2, 6): 9, (1, 7): 10, (0x83, 1): 11, (0x82, 2): 12, (0x81, 3): 13}
+    for (st, sl), want in exp.items():
+        assert NN.status_index(st, sl) == want
+
+
+def test_encoder_dims_and_embedding_layout():
+    import oracle_lib as O
+    net = NN.Net(os.path.join(ROOT, "tests", "golden", "net_default.battle.net"))
+    b, d, p, r = O.make_random_ou_batch(4)
+    for i in range(4):
+        side = b[i][:184]
+        idx, val = NN.encode_active_pokemon(side[0:24], side[144:176], 0)
+        assert max(idx) < NN.ACTIVE_POKEMON_IN and len(idx) == len(set(idx))
+        emb = NN.battle_embedding(net, b[i], d[i])
+        assert emb.shape == (768,) and emb[0] == 1.0 and emb[384] == 1.0   # full-HP leads
+        v = NN.value_inference(net, b[i], d[i])
+        assert 0.0 < float(v) < 1.0
