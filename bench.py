@@ -48,6 +48,7 @@ def main():
     import numpy as np
     import torch
     from oak_amd import _lib
+    from oak_amd import dist as oakdist
     from oak_amd.engine import Context
 
     rank = int(os.environ.get("RANK", "0"))
@@ -82,15 +83,14 @@ def main():
     results = torch.empty((n,), dtype=u8, device=dev)
     steps_out = torch.empty((n,), dtype=torch.int32, device=dev)
     values = torch.empty((n,), dtype=torch.float32, device=dev)
-    gathered = torch.empty((world * n,), dtype=torch.float32, device=dev) if world > 1 else None
     total_steps = torch.zeros((), dtype=torch.int64, device=dev)
 
     def P(t):
         return C.c_void_p(t.data_ptr())
 
     # synthetic input, generated on device: lane seeds are disjoint across ranks
-    _lib.check(lib.oakgpu_random_ou_battles_dev(h, C.c_uint64(SEED0 + rank * n), n, P(battles), P(durations),
-                                                P(prng), P(results_in)))
+    _lib.check(lib.oakgpu_random_ou_battles_dev(h, C.c_uint64(oakdist.lane_seed0(SEED0, n * world, rank, world)), n,
+                                                P(battles), P(durations), P(prng), P(results_in)))
     torch.cuda.synchronize(dev)
 
     def step():
@@ -99,7 +99,8 @@ def main():
 
     def exchange():
         if world > 1:
-            dist.all_gather_into_tensor(gathered, values)
+            return oakdist.gather_values(values, n * world)   # one RCCL all-gather of fp32 leaf values
+        return values
 
     steps_out.zero_()
     total_steps += steps_out.sum(dtype=torch.int64)   # loads torch's lazily-loaded reduce kernels up front

@@ -1,0 +1,1120 @@
+// oak_amd/csrc/gen1_regs.hpp -- register-resident gen-1 turn resolution for the rollout kernel.
+//
+// Same semantics as gen1_device.hpp (and bit-identical results), different data placement:
+// with one wave per SIMD every LDS round trip (~64-128 cycles) is exposed, and the LDS-resident
+// engine makes ~150 of them per turn-step.  Here everything a turn touches lives in VGPRs:
+//   * per side (struct SideR): the 32-byte active block, a cached copy of the stored (party)
+//     Pokemon behind it, the order bytes + last selected/used move, the chance durations word
+//     and a 6-bit "alive" mask (so legal-choice enumeration and faint checks need no memory);
+//   * per battle: RNG seed, turn, last_damage, last_moves.
+// LDS (lane-interleaved, as in gen1_device.hpp) keeps the 12 party slots and is touched only on
+// switches (write back the outgoing Pokemon, read the incoming one) and Transform bookkeeping.
+//
+// Player indices are lane-divergent (who moves first differs per lane), and indexing registers by
+// a divergent value would spill them to scratch.  So the code is written in a MOVER / TARGET frame:
+// `S` is always the side acting, `F` its foe, and the two register sets are physically swapped
+// (v_cndmask / v_swap) between the two halves of a turn.  One copy of the move code serves both.
+//
+// Reference call sites replaced: cpp/include/search/mcts.h:453-479 (choices x2 + update per
+// turn-step); build configuration mirrored: /root/reference/dev/libpkmn:9.
+#pragma once
+#include "gen1_device.hpp"
+
+namespace oak {
+
+struct SideR {
+  uint32_t a0, a1, a2; // active: hp|atk<<16, def|spe<<16, spc|species<<16|types<<24
+  uint32_t bo;         // boosts nibbles: atk def | spe spc | acc eva
+  uint32_t vlo, vhi;   // volatiles
+  uint32_t m01, m23;   // active move slots (id | pp<<8) x4
+  uint32_t p0, p1, p2, p3, p4, p5; // stored Pokemon dwords (layout.h:33-41)
+  uint32_t o0, o1;     // order[0..3]; order[4], order[5], last_selected_move, last_used_move
+  uint32_t dur;        // chance durations of this side
+  uint32_t misc;       // bits 0-5 alive mask by order position, bit 8 absolute player, bits 16-23 damage override
+};
+
+#define OAK_FOR_SIDE_FIELDS(X) X(a0) X(a1) X(a2) X(bo) X(vlo) X(vhi) X(m01) X(m23) X(p0) X(p1) X(p2) X(p3) X(p4) X(p5) X(o0) X(o1) X(dur) X(misc)
+
+__device__ __forceinline__ void swap_sides(SideR &a, SideR &b) {
+#define X(f) { uint32_t t = a.f; a.f = b.f; b.f = t; }
+  OAK_FOR_SIDE_FIELDS(X)
+#undef X
+}
+__device__ __forceinline__ void cswap_sides(bool c, SideR &a, SideR &b) {
+#define X(f) { uint32_t t = c ? b.f : a.f; b.f = c ? a.f : b.f; a.f = t; }
+  OAK_FOR_SIDE_FIELDS(X)
+#undef X
+}
+
+template <int STRIDE, bool TRACK_ACTIONS>
+struct EngineR {
+  lds_u32 *m; // party storage (lane-interleaved LDS, same addressing as Engine)
+  Tables T;
+  SideR S, F; // mover / target frame
+  uint64_t actS, actF; // chance actions (TRACK_ACTIONS only)
+  uint64_t rng;
+  uint32_t turn, last_damage;
+  uint32_t lm; // last_moves: index0 | counterable0<<8 | index1<<16 | counterable1<<24 (absolute players)
+
+  // ---- LDS party access ----
+  __device__ __forceinline__ uint32_t r32(int off) const { return m[(off >> 2) * STRIDE]; }
+  __device__ __forceinline__ void w32(int off, uint32_t v) { m[(off >> 2) * STRIDE] = v; }
+  __device__ __forceinline__ uint32_t r16(int off) const { return ((const lds_u16 *)m)[(off >> 2) * (STRIDE * 2) + ((off >> 1) & 1)]; }
+
+  // ---- per-side field helpers ----
+  static __device__ __forceinline__ uint32_t absp(const SideR &x) { return (x.misc >> 8) & 1; }
+  static __device__ __forceinline__ uint32_t hp(const SideR &x) { return x.p4 >> 16; }
+  static __device__ __forceinline__ void set_hp(SideR &x, uint32_t v) { x.p4 = (x.p4 & 0xFFFF) | (v << 16); }
+  static __device__ __forceinline__ uint32_t maxhp(const SideR &x) { return x.p0 & 0xFFFF; }
+  static __device__ __forceinline__ uint32_t status(const SideR &x) { return x.p5 & 0xFF; }
+  static __device__ __forceinline__ void set_status(SideR &x, uint32_t v) { x.p5 = (x.p5 & ~0xFFu) | (v & 0xFF); }
+  static __device__ __forceinline__ uint32_t level(const SideR &x) { return x.p5 >> 24; }
+  static __device__ __forceinline__ uint32_t species_stored(const SideR &x) { return (x.p5 >> 8) & 0xFF; }
+  static __device__ __forceinline__ uint32_t types(const SideR &x) { return x.a2 >> 24; }
+  static __device__ __forceinline__ uint32_t spe(const SideR &x) { return x.a1 >> 16; }
+  static __device__ __forceinline__ uint32_t last_sel(const SideR &x) { return (x.o1 >> 16) & 0xFF; }
+  static __device__ __forceinline__ void set_last_sel(SideR &x, uint32_t v) { x.o1 = (x.o1 & ~(0xFFu << 16)) | ((v & 0xFF) << 16); }
+  static __device__ __forceinline__ uint32_t last_used(const SideR &x) { return x.o1 >> 24; }
+  static __device__ __forceinline__ void set_last_used(SideR &x, uint32_t v) { x.o1 = (x.o1 & 0x00FFFFFFu) | (v << 24); }
+  static __device__ __forceinline__ uint32_t order0(const SideR &x) { return x.o0 & 0xFF; }
+  // Packed accessors always read / write BOTH dwords through one 64-bit value: selecting one of
+  // several struct fields by a lane-divergent slot makes the compiler demote the fields to scratch.
+  static __device__ __forceinline__ uint64_t amoves(const SideR &x) { return (uint64_t)x.m01 | ((uint64_t)x.m23 << 32); }
+  static __device__ __forceinline__ void set_amoves(SideR &x, uint64_t v) { x.m01 = (uint32_t)v; x.m23 = (uint32_t)(v >> 32); }
+  static __device__ __forceinline__ uint32_t active_move(const SideR &x, uint32_t slot) { // id | pp<<8, slot 1..4
+    return (uint32_t)(amoves(x) >> (16 * (slot - 1))) & 0xFFFF;
+  }
+  // stored move slots live in p2 (high half), p3, p4 (low half)
+  static __device__ __forceinline__ uint64_t smoves(const SideR &x) {
+    return (uint64_t)(x.p2 >> 16) | ((uint64_t)x.p3 << 16) | ((uint64_t)(x.p4 & 0xFFFF) << 48);
+  }
+  static __device__ __forceinline__ void set_smoves(SideR &x, uint64_t v) {
+    x.p2 = (x.p2 & 0xFFFF) | ((uint32_t)(v & 0xFFFF) << 16);
+    x.p3 = (uint32_t)(v >> 16);
+    x.p4 = (x.p4 & 0xFFFF0000u) | (uint32_t)(v >> 48);
+  }
+  // active stat by index: 0 atk 1 def 2 spe 3 spc
+  static __device__ __forceinline__ uint32_t astat(const SideR &x, int idx) {
+    return idx == 0 ? x.a0 >> 16 : idx == 1 ? x.a1 & 0xFFFF : idx == 2 ? x.a1 >> 16 : x.a2 & 0xFFFF;
+  }
+  static __device__ __forceinline__ void set_astat(SideR &x, int idx, uint32_t v) {
+    if (idx == 0) x.a0 = (x.a0 & 0xFFFF) | (v << 16);
+    else if (idx == 1) x.a1 = (x.a1 & 0xFFFF0000u) | v;
+    else if (idx == 2) x.a1 = (x.a1 & 0xFFFF) | (v << 16);
+    else x.a2 = (x.a2 & 0xFFFF0000u) | v;
+  }
+  // volatile sub-fields
+  static __device__ __forceinline__ uint32_t conf_left(const SideR &x) { return (x.vlo >> 18) & 7; }
+  static __device__ __forceinline__ void set_conf_left(SideR &x, uint32_t v) { x.vlo = (x.vlo & ~(7u << 18)) | ((v & 7) << 18); }
+  static __device__ __forceinline__ uint32_t attacks(const SideR &x) { return (x.vlo >> 21) & 7; }
+  static __device__ __forceinline__ void set_attacks(SideR &x, uint32_t v) { x.vlo = (x.vlo & ~(7u << 21)) | ((v & 7) << 21); }
+  static __device__ __forceinline__ uint32_t vstate(const SideR &x) { return (x.vlo >> 24) | ((x.vhi & 0xFF) << 8); }
+  static __device__ __forceinline__ void set_vstate(SideR &x, uint32_t v) {
+    x.vlo = (x.vlo & 0x00FFFFFFu) | ((v & 0xFF) << 24);
+    x.vhi = (x.vhi & ~0xFFu) | ((v >> 8) & 0xFF);
+  }
+  static __device__ __forceinline__ uint32_t sub_hp(const SideR &x) { return (x.vhi >> 8) & 0xFF; }
+  static __device__ __forceinline__ void set_sub_hp(SideR &x, uint32_t v) { x.vhi = (x.vhi & ~(0xFFu << 8)) | ((v & 0xFF) << 8); }
+  static __device__ __forceinline__ uint32_t transform_id(const SideR &x) { return (x.vhi >> 16) & 15; }
+  static __device__ __forceinline__ void set_transform_id(SideR &x, uint32_t v) { x.vhi = (x.vhi & ~(15u << 16)) | ((v & 15) << 16); }
+  static __device__ __forceinline__ uint32_t disable_left(const SideR &x) { return (x.vhi >> 20) & 15; }
+  static __device__ __forceinline__ void set_disable_left(SideR &x, uint32_t v) { x.vhi = (x.vhi & ~(15u << 20)) | ((v & 15) << 20); }
+  static __device__ __forceinline__ uint32_t disable_move(const SideR &x) { return (x.vhi >> 24) & 7; }
+  static __device__ __forceinline__ void set_disable_move(SideR &x, uint32_t v) { x.vhi = (x.vhi & ~(7u << 24)) | ((v & 7) << 24); }
+  static __device__ __forceinline__ uint32_t toxic_ctr(const SideR &x) { return x.vhi >> 27; }
+  static __device__ __forceinline__ void set_toxic_ctr(SideR &x, uint32_t v) { x.vhi = (x.vhi & ~(31u << 27)) | ((v & 31) << 27); }
+  static __device__ __forceinline__ int boost_get(const SideR &x, int idx) { // 0 atk 1 def 2 spe 3 spc 4 acc 5 eva
+    uint32_t n = (x.bo >> (4 * idx)) & 15;
+    return (int)((n ^ 8) - 8);
+  }
+  static __device__ __forceinline__ void boost_put(SideR &x, int idx, int v) {
+    x.bo = (x.bo & ~(15u << (4 * idx))) | (((uint32_t)v & 15) << (4 * idx));
+  }
+  static __device__ __forceinline__ uint32_t dget(const SideR &x, int sh, int bits) { return (x.dur >> sh) & ((1u << bits) - 1); }
+  static __device__ __forceinline__ void dset(SideR &x, int sh, int bits, uint32_t v) {
+    uint32_t mask = ((1u << bits) - 1) << sh;
+    x.dur = (x.dur & ~mask) | ((v << sh) & mask);
+  }
+  static __device__ __forceinline__ void clear_binding(SideR &x) { x.vlo &= ~V_BINDING; dset(x, 28, 3, 0); }
+  static __device__ __forceinline__ void status_modify(uint32_t st, SideR &x) {
+    if (st & ST_PAR) { uint32_t s = (x.a1 >> 16) / 4; set_astat(x, 2, s < 1 ? 1 : s); }
+    else if (st & ST_BRN) { uint32_t a = (x.a0 >> 16) / 2; set_astat(x, 0, a < 1 ? 1 : a); }
+  }
+
+  // ---- actions (mover frame: `self` selects actS / actF) ----
+  __device__ __forceinline__ void act_set(bool self, int sh, int bits, uint32_t v) {
+    if constexpr (TRACK_ACTIONS) {
+      uint64_t mask = ((1ull << bits) - 1) << sh;
+      uint64_t &a = self ? actS : actF;
+      a = (a & ~mask) | (((uint64_t)v << sh) & mask);
+    }
+  }
+  __device__ __forceinline__ void act_bool(bool self, int sh, bool v) { act_set(self, sh, 2, v ? 2u : 1u); }
+
+  // ---- RNG ----
+  __device__ __forceinline__ uint32_t rng_next() {
+    rng = 0x5D588B656C078965ull * rng + 0x0000000000269EC3ull;
+    return (uint32_t)(rng >> 32);
+  }
+  __device__ __forceinline__ uint32_t rng_range(uint32_t from, uint32_t to) {
+    return from + __umulhi(rng_next(), to - from);
+  }
+  __device__ __forceinline__ bool rng_chance(uint32_t num) { return (rng_next() >> 24) < num; } // range(0,256) < num
+
+  __device__ __forceinline__ Move move_data(uint32_t id) const { return Move{T.mv[id]}; }
+  __device__ __forceinline__ uint32_t chart(uint32_t atk_type, uint32_t def_type) const { return T.chart[atk_type * 15 + def_type]; }
+  static __device__ __forceinline__ bool has_type(uint32_t ty, uint32_t t) { return (ty & 15) == t || (ty >> 4) == t; }
+  __device__ __forceinline__ uint32_t scale_boost(uint32_t x, int stage) const {
+    uint32_t b = T.boost[stage + 6];
+    return x * (b & 0xFF) / (b >> 8);
+  }
+
+  // unmodified (party) stat idx of side x; through Transform this is the copied Pokemon's stat (LDS)
+  __device__ __forceinline__ uint32_t unmodified_stat(const SideR &x, int idx) { // 0 atk 1 def 2 spe 3 spc
+    if (!(x.vlo & V_TRANSFORM))
+      return idx == 0 ? x.p0 >> 16 : idx == 1 ? x.p1 & 0xFFFF : idx == 2 ? x.p1 >> 16 : x.p2 & 0xFFFF;
+    uint32_t id = transform_id(x);
+    return r16((int)(id >> 3) * SIDE_SZ + PK_SZ * ((int)(id & 7) - 1) + P_ATK + 2 * idx);
+  }
+
+  // ---- register <-> LDS movement ----
+  __device__ __forceinline__ int stored_lds_off(const SideR &x) const { return (int)absp(x) * SIDE_SZ + PK_SZ * ((int)order0(x) - 1); }
+  __device__ __forceinline__ void writeback_stored(const SideR &x) { // stats never change: dwords 2..5 only
+    const int off = stored_lds_off(x);
+    w32(off + 8, x.p2); w32(off + 12, x.p3); w32(off + 16, x.p4); w32(off + 20, x.p5);
+  }
+  __device__ __forceinline__ void load_side(SideR &x, uint32_t ap, uint32_t dur_word) {
+    const int so = (int)ap * SIDE_SZ;
+    x.a0 = r32(so + 144); x.a1 = r32(so + 148); x.a2 = r32(so + 152); x.bo = r32(so + 156);
+    x.vlo = r32(so + 160); x.vhi = r32(so + 164); x.m01 = r32(so + 168); x.m23 = r32(so + 172);
+    x.o0 = r32(so + 176); x.o1 = r32(so + 180);
+    x.dur = dur_word;
+    uint32_t alive = 0;
+    for (int k = 0; k < 6; ++k) {
+      uint32_t id = (k < 4 ? x.o0 >> (8 * k) : x.o1 >> (8 * (k - 4))) & 0xFF;
+      if (id != 0 && r16(so + PK_SZ * ((int)id - 1) + P_HP) != 0) alive |= 1u << k;
+    }
+    x.misc = alive | (ap << 8);
+    const uint32_t id0 = x.o0 & 0xFF;
+    if (id0 != 0) {
+      const int off = so + PK_SZ * ((int)id0 - 1);
+      x.p0 = r32(off); x.p1 = r32(off + 4); x.p2 = r32(off + 8); x.p3 = r32(off + 12); x.p4 = r32(off + 16); x.p5 = r32(off + 20);
+    } else { x.p0 = x.p1 = x.p2 = x.p3 = x.p4 = x.p5 = 0; }
+  }
+  __device__ __forceinline__ void store_side(const SideR &x) {
+    const int so = (int)absp(x) * SIDE_SZ;
+    w32(so + 144, x.a0); w32(so + 148, x.a1); w32(so + 152, x.a2); w32(so + 156, x.bo);
+    w32(so + 160, x.vlo); w32(so + 164, x.vhi); w32(so + 168, x.m01); w32(so + 172, x.m23);
+    w32(so + 176, x.o0); w32(so + 180, x.o1);
+    if (order0(x) != 0) writeback_stored(x);
+  }
+  // whole-battle load / store (frame normalised: S = P1, F = P2)
+  __device__ __forceinline__ void load_battle(uint32_t dur0, uint32_t dur1) {
+    load_side(S, 0, dur0);
+    load_side(F, 1, dur1);
+    uint32_t t = r32(B_TURN);
+    turn = t & 0xFFFF;
+    last_damage = t >> 16;
+    lm = r32(B_LAST_MOVES);
+    rng = (uint64_t)r32(B_RNG) | ((uint64_t)r32(B_RNG + 4) << 32);
+    actS = actF = 0;
+  }
+  __device__ __forceinline__ void store_battle() {
+    store_side(S);
+    store_side(F);
+    w32(B_TURN, turn | (last_damage << 16));
+    w32(B_LAST_MOVES, lm);
+    w32(B_RNG, (uint32_t)rng);
+    w32(B_RNG + 4, (uint32_t)(rng >> 32));
+  }
+  // last_moves accessors by absolute player
+  __device__ __forceinline__ uint32_t lm_index(uint32_t ap) const { return (lm >> (16 * ap)) & 0xFF; }
+  __device__ __forceinline__ void set_lm_index(uint32_t ap, uint32_t v) { lm = (lm & ~(0xFFu << (16 * ap))) | ((v & 0xFF) << (16 * ap)); }
+  __device__ __forceinline__ uint32_t lm_counterable(uint32_t ap) const { return (lm >> (16 * ap + 8)) & 0xFF; }
+  __device__ __forceinline__ void set_lm_counterable(uint32_t ap, uint32_t v) { lm = (lm & ~(0xFFu << (16 * ap + 8))) | ((v & 0xFF) << (16 * ap + 8)); }
+
+  // ---- switching: side x switches to party position `slot`; y is the other side --------------
+  __device__ __forceinline__ void switch_in(SideR &x, SideR &y, uint32_t slot) {
+    if (order0(x) != 0) {
+      if (status(x) == ST_TOX) set_status(x, ST_PSN); // toxic reverts on leaving the field
+      writeback_stored(x);
+    }
+    // swap order bytes 0 and slot-1, alive bits 0 and slot-1
+    uint64_t o = (uint64_t)x.o0 | ((uint64_t)(x.o1 & 0xFFFF) << 32);
+    const uint32_t sh = 8 * (slot - 1);
+    const uint64_t b0 = o & 0xFF, bk = (o >> sh) & 0xFF;
+    o = (o & ~(0xFFull << sh)) | (b0 << sh);
+    o = (o & ~0xFFull) | bk;
+    x.o0 = (uint32_t)o;
+    x.o1 = (x.o1 & 0xFFFF0000u) | (uint32_t)(o >> 32);
+    const uint32_t al = x.misc & 63, a0b = al & 1, akb = (al >> (slot - 1)) & 1;
+    uint32_t nal = (al & ~(1u | (1u << (slot - 1)))) | akb | (a0b << (slot - 1));
+    if (slot == 1) nal = al;
+    x.misc = (x.misc & ~63u) | nal;
+    uint32_t d = x.dur;
+    const uint32_t s0 = d & 7, sk = (d >> (3 * (slot - 1))) & 7;
+    d = (d & ~7u) | sk;
+    if (slot != 1) d = (d & ~(7u << (3 * (slot - 1)))) | (s0 << (3 * (slot - 1)));
+    x.dur = d & ((1u << 18) - 1);
+    set_last_used(x, 0);
+    set_last_used(y, 0);
+    const int off = stored_lds_off(x);
+    x.p0 = r32(off); x.p1 = r32(off + 4); x.p2 = r32(off + 8); x.p3 = r32(off + 12); x.p4 = r32(off + 16); x.p5 = r32(off + 20);
+    x.a0 = x.p0;
+    x.a1 = x.p1;
+    x.a2 = (x.p2 & 0xFFFF) | (((x.p5 >> 8) & 0xFF) << 16) | (((x.p5 >> 16) & 0xFF) << 24);
+    x.bo = 0;
+    x.vlo = 0;
+    x.vhi = 0;
+    x.m01 = (x.p2 >> 16) | (x.p3 << 16);
+    x.m23 = (x.p3 >> 16) | (x.p4 << 16);
+    status_modify(x.p5 & 0xFF, x);
+    clear_binding(y);
+  }
+
+  // ---- move selection (absolute player ap owns side x) ---------------------------------------
+  __device__ __forceinline__ void select_move(SideR &x, uint32_t choice) {
+    if ((choice & 3) == C_PASS) return;
+    if (x.vlo & (V_RECHARGING | V_RAGE)) return;
+    x.vlo &= ~V_FLINCH;
+    if (x.vlo & (V_THRASHING | V_CHARGING)) return;
+    if ((choice & 3) == C_SWITCH) return;
+    if (x.vlo & (V_BIDE | V_BINDING)) return;
+    const uint32_t data = choice >> 2;
+    set_last_sel(x, data == 0 ? (uint32_t)M_Struggle : active_move(x, data) & 0xFF);
+    set_lm_index(absp(x), data);
+  }
+
+  // ---- damage ------------------------------------------------------------------------------------
+  __device__ __forceinline__ bool check_crit(Move mv) {
+    uint32_t chance = (T.sp0[species_stored(S)] >> 24) / 2;
+    if (S.vlo & V_FOCUSENERGY) chance = chance / 2;
+    else { chance *= 2; if (chance > 255) chance = 255; }
+    if (mv.effect() == E_HighCritical) { chance *= 4; if (chance > 255) chance = 255; }
+    else chance = chance / 2;
+    bool crit = rng_chance(chance);
+    act_bool(true, AC_CRIT, crit);
+    return crit;
+  }
+
+  // base damage of S attacking `tgt` (tgt = S for confusion self-hits)
+  __device__ __forceinline__ bool calc_damage(const SideR &tgt, uint32_t bp, uint32_t type, bool explode, bool crit) {
+    const bool special = type >= 8;
+    uint32_t atk, def;
+    if (crit) {
+      atk = unmodified_stat(S, special ? 3 : 0);
+      def = unmodified_stat(tgt, special ? 3 : 1);
+    } else {
+      atk = special ? S.a2 & 0xFFFF : S.a0 >> 16;
+      def = (special ? tgt.a2 & 0xFFFF : tgt.a1 & 0xFFFF) * ((tgt.vlo & (special ? V_LIGHTSCREEN : V_REFLECT)) ? 2u : 1u);
+    }
+    if (atk > 255 || def > 255) {
+      atk = (atk / 4) & 255; if (atk < 1) atk = 1;
+      def = (def / 4) & 255; if (def < 1) def = 1;
+    }
+    uint32_t lvl = level(S) * (crit ? 2u : 1u);
+    if (explode) { def = def / 2; if (def < 1) def = 1; }
+    if (def == 0) return false;
+    uint32_t d = (lvl * 2 / 5) + 2;
+    d *= bp;
+    d *= atk;
+    d /= def;
+    d /= 50;
+    if (d > 997) d = 997;
+    d += 2;
+    last_damage = d;
+    return true;
+  }
+
+  __device__ __forceinline__ void adjust_damage(Move mv) {
+    const uint32_t ft = types(F), t1 = ft & 15, t2 = ft >> 4;
+    uint32_t d = last_damage;
+    if (has_type(types(S), mv.type())) d = (d + d / 2) & 0xFFFF;
+    const uint32_t e1 = chart(mv.type(), t1), e2 = chart(mv.type(), t2);
+    if (e1 != 2) d = (d * e1 / 2) & 0xFFFF;
+    if (t1 != t2 && e2 != 2) d = (d * e2 / 2) & 0xFFFF;
+    last_damage = d;
+  }
+
+  __device__ __forceinline__ void randomize_damage() {
+    if (last_damage <= 1) return;
+    uint32_t roll = (S.misc >> 16) & 0xFF;
+    if (roll == 0) roll = rng_range(217, 256);
+    act_set(true, AC_DAMAGE, 8, roll);
+    last_damage = last_damage * roll / 255;
+  }
+
+  // damage to `tgt` through `sub`'s substitute when up; returns true when a substitute broke
+  __device__ __forceinline__ bool apply_damage(SideR &tgt, SideR &sub, bool &hit_sub) {
+    hit_sub = false;
+    if (sub.vlo & V_SUBSTITUTE) {
+      hit_sub = true;
+      const uint32_t shp = sub_hp(sub);
+      if (last_damage >= shp) { set_sub_hp(sub, 0); sub.vlo &= ~V_SUBSTITUTE; return true; }
+      set_sub_hp(sub, shp - last_damage);
+      return false;
+    }
+    const uint32_t h = hp(tgt);
+    if (last_damage > h) last_damage = h;
+    set_hp(tgt, h - last_damage);
+    return false;
+  }
+
+  __device__ __forceinline__ bool move_hit(Move mv) {
+    bool miss;
+    const uint32_t eff = mv.effect();
+    if (eff == E_Swift) return true;
+    if (F.vlo & V_INVULNERABLE) miss = true;
+    else if ((eff == E_DrainHP || eff == E_DreamEater) && (F.vlo & V_SUBSTITUTE)) miss = true;
+    else if (eff >= E_AccuracyDown1 && eff <= E_SpeedDown1 && (F.vlo & V_MIST)) miss = true;
+    else {
+      uint32_t acc = mv.acc();
+      acc = scale_boost(acc, boost_get(S, 4));
+      acc = scale_boost(acc, -boost_get(F, 5));
+      if (acc > 255) acc = 255;
+      if (acc < 1) acc = 1;
+      if (acc == 255) miss = false;
+      else { miss = !rng_chance(acc); act_bool(true, AC_HIT, !miss); }
+    }
+    if (!miss) return true;
+    last_damage = 0;
+    clear_binding(S);
+    return false;
+  }
+
+  // ---- stat stages: x gains / loses stages; `other` gets the status penalty re-applied ------------
+  __device__ __forceinline__ bool boost_side(SideR &x, SideR &other, int idx, int n) {
+    int cur = boost_get(x, idx);
+    if (cur >= 6) return false;
+    int nv = cur + n; if (nv > 6) nv = 6;
+    if (idx < 4) {
+      if (astat(x, idx) == 999) return false;
+      boost_put(x, idx, nv);
+      uint32_t v = scale_boost(unmodified_stat(x, idx), nv);
+      if (v > 999) v = 999;
+      set_astat(x, idx, v);
+    } else boost_put(x, idx, nv);
+    status_modify(status(other), other); // stat modification glitch
+    return true;
+  }
+  __device__ __forceinline__ bool unboost_foe(int idx, int n) {
+    int cur = boost_get(F, idx);
+    if (cur <= -6) return false;
+    int nv = cur - n; if (nv < -6) nv = -6;
+    if (idx < 4) {
+      if (astat(F, idx) == 1) return false;
+      boost_put(F, idx, nv);
+      uint32_t v = scale_boost(unmodified_stat(F, idx), nv);
+      if (v < 1) v = 1;
+      set_astat(F, idx, v);
+    } else boost_put(F, idx, nv);
+    status_modify(status(F), F);
+    return true;
+  }
+
+  __device__ __forceinline__ void haze_clear(SideR &x) {
+    set_disable_move(x, 0);
+    set_disable_left(x, 0);
+    dset(x, 21, 4, 0);
+    if (x.vlo & V_CONFUSION) { x.vlo &= ~(V_CONFUSION | (7u << 18)); dset(x, 18, 3, 0); }
+    x.vlo &= ~(V_MIST | V_FOCUSENERGY | V_LEECHSEED | V_LIGHTSCREEN | V_REFLECT);
+    if (x.vlo & V_TOXIC) {
+      x.vlo &= ~V_TOXIC;
+      set_toxic_ctr(x, 0);
+      if (status(x) == ST_TOX) set_status(x, ST_PSN);
+    }
+  }
+  __device__ __forceinline__ void start_confusion(SideR &x, bool self) {
+    x.vlo |= V_CONFUSION;
+    set_conf_left(x, rng_range(2, 6));
+    dset(x, 18, 3, 1);
+    act_set(self, AC_CONFUSION, 3, OBS_STARTED);
+  }
+  __device__ __forceinline__ void unmodified_to_active(SideR &x) { // Haze: active stats <- unmodified stats
+    const uint32_t hpmax = x.a0 & 0xFFFF;
+    if (!(x.vlo & V_TRANSFORM)) {
+      x.a0 = x.p0; x.a1 = x.p1; x.a2 = (x.a2 & 0xFFFF0000u) | (x.p2 & 0xFFFF);
+    } else {
+      uint32_t id = transform_id(x);
+      const int off = (int)(id >> 3) * SIDE_SZ + PK_SZ * ((int)(id & 7) - 1);
+      x.a0 = r32(off); x.a1 = r32(off + 4); x.a2 = (x.a2 & 0xFFFF0000u) | (r32(off + 8) & 0xFFFF);
+    }
+    (void)hpmax;
+  }
+
+  __device__ void on_begin(Move mv, uint32_t move_id, uint32_t mslot) {
+    last_damage = 0;
+    switch (mv.effect()) {
+    case E_Confusion:
+      if (F.vlo & V_SUBSTITUTE) return;
+      if (!move_hit(mv)) return;
+      if (F.vlo & V_CONFUSION) return;
+      start_confusion(F, false);
+      return;
+    case E_Conversion:
+      if (F.vlo & V_INVULNERABLE) return;
+      S.a2 = (S.a2 & 0x00FFFFFFu) | (F.a2 & 0xFF000000u);
+      return;
+    case E_FocusEnergy: S.vlo |= V_FOCUSENERGY; return;
+    case E_Haze: {
+      S.bo = 0;
+      F.bo = 0;
+      unmodified_to_active(S);
+      unmodified_to_active(F);
+      const uint32_t fs = status(F);
+      if (fs) {
+        if (fs & ST_SLP) dset(F, 0, 3, 0);
+        set_status(F, 0);
+      }
+      if (status(S) == ST_TOX) set_status(S, ST_PSN);
+      haze_clear(S);
+      haze_clear(F);
+      return;
+    }
+    case E_Heal: {
+      const uint32_t mx = maxhp(S), h = hp(S), delta = mx - h;
+      if (delta == 0 || (delta & 255) == 255) return;
+      if (move_id == M_Rest) {
+        set_status(S, ST_EXT | 2);
+        dset(S, 0, 3, 0);
+        set_hp(S, mx);
+        S.vlo &= ~V_TOXIC;
+        set_toxic_ctr(S, 0);
+      } else {
+        uint32_t nh = h + mx / 2;
+        set_hp(S, nh > mx ? mx : nh);
+      }
+      return;
+    }
+    case E_LeechSeed:
+      if (has_type(types(F), T_Grass)) return;
+      if (!move_hit(mv)) return;
+      if (F.vlo & V_LEECHSEED) return;
+      F.vlo |= V_LEECHSEED;
+      return;
+    case E_LightScreen: S.vlo |= V_LIGHTSCREEN; return;
+    case E_Reflect: S.vlo |= V_REFLECT; return;
+    case E_Mist: S.vlo |= V_MIST; return;
+    case E_Mimic: {
+      if (!move_hit(mv)) return;
+      uint32_t n = 0;
+      for (uint32_t i = 1; i <= 4; ++i) n += (active_move(F, i) & 0xFF) != 0;
+      if (n == 0 || mslot == 0) return;
+      const uint32_t r = rng_range(0, n);
+      act_set(true, AC_MOVESLOT, 4, r + 1);
+      const uint64_t nid = active_move(F, r + 1) & 0xFF;
+      const uint32_t sh = 16 * (mslot - 1);
+      set_amoves(S, (amoves(S) & ~(0xFFull << sh)) | (nid << sh));
+      return;
+    }
+    case E_Paralyze: {
+      if (status(F)) return;
+      const uint32_t ft = types(F);
+      if (chart(mv.type(), ft & 15) == 0 || chart(mv.type(), ft >> 4) == 0) return;
+      if (!move_hit(mv)) return;
+      set_status(F, ST_PAR);
+      uint32_t s = spe(F) / 4;
+      set_astat(F, 2, s < 1 ? 1 : s);
+      return;
+    }
+    case E_Poison:
+      if (status(F)) return;
+      if (has_type(types(F), T_Poison)) return;
+      if (F.vlo & V_SUBSTITUTE) return;
+      if (!move_hit(mv)) return;
+      if (move_id == M_Toxic) { set_status(F, ST_TOX); F.vlo |= V_TOXIC; set_toxic_ctr(F, 0); }
+      else set_status(F, ST_PSN);
+      return;
+    case E_Splash: return;
+    case E_Substitute: {
+      if (S.vlo & V_SUBSTITUTE) return;
+      const uint32_t cost = maxhp(S) / 4, h = hp(S);
+      if (h < cost) return;
+      set_hp(S, h - cost);
+      set_sub_hp(S, cost + 1);
+      S.vlo |= V_SUBSTITUTE;
+      return;
+    }
+    case E_SwitchAndTeleport:
+      if (move_id != M_Teleport) (void)move_hit(mv);
+      return;
+    case E_Transform: {
+      if (F.vlo & V_INVULNERABLE) return;
+      const uint32_t id = (F.vlo & V_TRANSFORM) ? transform_id(F) : ((absp(F) << 3) | order0(F));
+      S.vlo |= V_TRANSFORM;
+      set_transform_id(S, id);
+      S.a0 = F.a0; S.a1 = F.a1; S.a2 = F.a2; S.bo = F.bo;
+      uint32_t n01 = 0, n23 = 0;
+      for (uint32_t i = 1; i <= 4; ++i) {
+        const uint32_t mid = active_move(F, i) & 0xFF;
+        const uint32_t slotw = mid | ((mid ? 5u : 0u) << 8);
+        if (i <= 2) n01 |= slotw << (16 * (i - 1)); else n23 |= slotw << (16 * (i - 3));
+      }
+      S.m01 = n01;
+      S.m23 = n23;
+      return;
+    }
+    default: return;
+    }
+  }
+
+  // ---- pre-move checks ---------------------------------------------------------------------
+  enum : int { BM_OK = 0, BM_DONE = 1, BM_SKIP_CAN = 2, BM_SKIP_PP = 3, BM_ERR = 4 };
+
+  __device__ int before_move() {
+    bool dummy;
+    uint32_t st = status(S);
+    if (st & ST_SLP) {
+      st -= 1;
+      const uint32_t left = st & ST_SLP;
+      if (!(st & ST_EXT)) {
+        if (left == 0) { dset(S, 0, 3, 0); act_set(true, AC_SLEEP, 2, OBS_ENDED); }
+        else { dset(S, 0, 3, dget(S, 0, 3) + 1); act_set(true, AC_SLEEP, 2, OBS_CONTINUING); }
+      }
+      if (left == 0) st = 0;
+      set_status(S, st);
+      set_last_used(S, 0);
+      return BM_DONE;
+    }
+    if (st & ST_FRZ) { set_last_used(S, 0); return BM_DONE; }
+    if (F.vlo & V_BINDING) return BM_DONE;
+    if (S.vlo & V_FLINCH) { S.vlo &= ~V_FLINCH; return BM_DONE; }
+    if (S.vlo & V_RECHARGING) { S.vlo &= ~V_RECHARGING; return BM_DONE; }
+    uint32_t dl = disable_left(S);
+    if (dl > 0) {
+      dl -= 1;
+      set_disable_left(S, dl);
+      if (dl == 0) { set_disable_move(S, 0); dset(S, 21, 4, 0); act_set(true, AC_DISABLE, 2, OBS_ENDED); }
+      else { dset(S, 21, 4, dget(S, 21, 4) + 1); act_set(true, AC_DISABLE, 2, OBS_CONTINUING); }
+    }
+    if (S.vlo & V_CONFUSION) {
+      const uint32_t left = conf_left(S) - 1;
+      set_conf_left(S, left);
+      if (left == 0) {
+        S.vlo &= ~V_CONFUSION;
+        dset(S, 18, 3, 0);
+        act_set(true, AC_CONFUSION, 3, OBS_ENDED);
+      } else {
+        dset(S, 18, 3, dget(S, 18, 3) + 1);
+        act_set(true, AC_CONFUSION, 3, OBS_CONTINUING);
+        const bool confused = !rng_chance(128);
+        act_bool(true, AC_CONFUSED, confused);
+        if (confused) {
+          S.vlo &= ~(V_BIDE | V_THRASHING | V_MULTIHIT | V_FLINCH | V_CHARGING | V_BINDING | V_INVULNERABLE);
+          dset(S, 25, 3, 0);
+          dset(S, 28, 3, 0);
+          if (!calc_damage(S, 40, T_Normal, false, false)) return BM_ERR;
+          (void)apply_damage(S, F, dummy); // gen-1 quirk: the FOE's substitute absorbs the self-hit
+          return BM_DONE;
+        }
+      }
+    }
+    const uint32_t dm = disable_move(S), sel = last_sel(S);
+    if (dm != 0 && sel != M_Struggle && (active_move(S, dm) & 0xFF) == sel) {
+      S.vlo &= ~V_CHARGING;
+      return BM_DONE;
+    }
+    if (st & ST_PAR) {
+      const bool par = rng_chance(63);
+      act_bool(true, AC_PARALYZED, par);
+      if (par) {
+        S.vlo &= ~(V_BIDE | V_THRASHING | V_CHARGING | V_BINDING | V_INVULNERABLE);
+        dset(S, 25, 3, 0);
+        dset(S, 28, 3, 0);
+        return BM_DONE;
+      }
+    }
+    if (S.vlo & V_BIDE) {
+      const uint32_t left = attacks(S) - 1;
+      set_attacks(S, left);
+      if (left != 0) { dset(S, 25, 3, dget(S, 25, 3) + 1); act_set(true, AC_ATTACKING, 2, OBS_CONTINUING); return BM_DONE; }
+      dset(S, 25, 3, 0);
+      act_set(true, AC_ATTACKING, 2, OBS_ENDED);
+      S.vlo &= ~V_BIDE;
+      const uint32_t dmg = (vstate(S) * 2) & 0xFFFF;
+      set_vstate(S, 0);
+      last_damage = dmg;
+      if (dmg == 0) return BM_DONE;
+      if (F.vlo & V_INVULNERABLE) return BM_DONE;
+      (void)apply_damage(F, F, dummy);
+      return BM_DONE;
+    }
+    if (S.vlo & V_THRASHING) {
+      const uint32_t left = attacks(S) - 1;
+      set_attacks(S, left);
+      if (left == 0) {
+        S.vlo &= ~V_THRASHING;
+        dset(S, 25, 3, 0);
+        act_set(true, AC_ATTACKING, 2, OBS_ENDED);
+        start_confusion(S, true);
+      } else {
+        dset(S, 25, 3, dget(S, 25, 3) + 1);
+        act_set(true, AC_ATTACKING, 2, OBS_CONTINUING);
+      }
+      return BM_SKIP_CAN;
+    }
+    if (S.vlo & V_BINDING) {
+      set_attacks(S, attacks(S) - 1);
+      dset(S, 28, 3, dget(S, 28, 3) + 1);
+      act_set(true, AC_BINDING, 3, OBS_CONTINUING);
+      if (last_damage != 0) (void)apply_damage(F, F, dummy);
+      return BM_DONE;
+    }
+    return (S.vlo & V_RAGE) ? BM_SKIP_PP : BM_OK;
+  }
+
+  __device__ __forceinline__ void decrement_pp(uint32_t mslot) {
+    if (mslot == 0) return;
+    const uint32_t sh = 16 * (mslot - 1) + 8;
+    const uint64_t am = amoves(S);
+    set_amoves(S, (am & ~(0xFFull << sh)) | ((uint64_t)((((uint32_t)(am >> sh) & 0xFF) - 1) & 63) << sh));
+    if (S.vlo & V_TRANSFORM) return;
+    const uint64_t sm = smoves(S);
+    set_smoves(S, (sm & ~(0xFFull << sh)) | ((uint64_t)((((uint32_t)(sm >> sh) & 0xFF) - 1) & 63) << sh));
+  }
+
+  __device__ void secondary_status(Move mv, uint32_t st, uint32_t num) {
+    const uint32_t fs = status(F);
+    if (st == ST_BRN && (fs & ST_FRZ)) { set_status(F, 0); return; }
+    if (fs) return;
+    if (has_type(types(F), st == ST_PSN ? (uint32_t)T_Poison : mv.type())) return;
+    const bool proc = rng_chance(num);
+    act_bool(true, AC_SECONDARY, proc);
+    if (!proc) return;
+    set_status(F, st);
+    if (st == ST_PAR) { uint32_t s = spe(F) / 4; set_astat(F, 2, s < 1 ? 1 : s); }
+    if (st == ST_BRN) { uint32_t a = (F.a0 >> 16) / 2; set_astat(F, 0, a < 1 ? 1 : a); }
+  }
+
+  __device__ void do_move() {
+    const uint32_t move_id = last_sel(S);
+    const Move mv = move_data(move_id);
+    const uint32_t eff = mv.effect();
+    const uint32_t sap = absp(S), fap = sap ^ 1;
+    set_lm_counterable(sap, 0);
+
+    if (mv.bp() == 0) {
+      last_damage = 0;
+      switch (eff) {
+      case E_AttackUp1: case E_AttackUp2: case E_DefenseUp1: case E_DefenseUp2: case E_SpeedUp2: case E_SpecialUp1:
+      case E_SpecialUp2: case E_EvasionUp1: {
+        const int idx = (eff == E_AttackUp1 || eff == E_AttackUp2) ? 0 : (eff == E_DefenseUp1 || eff == E_DefenseUp2) ? 1
+                        : eff == E_SpeedUp2 ? 2 : eff == E_EvasionUp1 ? 5 : 3;
+        const int n = (eff == E_AttackUp2 || eff == E_DefenseUp2 || eff == E_SpeedUp2 || eff == E_SpecialUp2) ? 2 : 1;
+        boost_side(S, F, idx, n);
+        return;
+      }
+      case E_Bide:
+        S.vlo |= V_BIDE;
+        set_vstate(S, 0);
+        set_attacks(S, rng_range(2, 4));
+        dset(S, 25, 3, 1);
+        act_set(true, AC_ATTACKING, 2, OBS_STARTED);
+        return;
+      case E_AccuracyDown1: case E_AttackDown1: case E_DefenseDown1: case E_DefenseDown2: case E_SpeedDown1: {
+        if (F.vlo & V_SUBSTITUTE) return;
+        if (!move_hit(mv)) return;
+        const int idx = eff == E_AccuracyDown1 ? 4 : eff == E_AttackDown1 ? 0 : eff == E_SpeedDown1 ? 2 : 1;
+        unboost_foe(idx, eff == E_DefenseDown2 ? 2 : 1);
+        return;
+      }
+      case E_Sleep: {
+        const uint32_t fs = status(F);
+        if (F.vlo & V_RECHARGING) {
+          F.vlo &= ~V_RECHARGING;
+          if (fs & ST_SLP) return;
+        } else {
+          if (fs) return;
+          if (!move_hit(mv)) return;
+        }
+        set_status(F, rng_range(1, 8));
+        dset(F, 0, 3, 1);
+        act_set(false, AC_SLEEP, 2, OBS_STARTED);
+        return;
+      }
+      case E_Disable: {
+        if (disable_move(F) != 0) return;
+        if (!move_hit(mv)) return;
+        uint32_t n = 0, packed = 0;
+        for (uint32_t i = 1; i <= 4; ++i) {
+          const uint32_t ms = active_move(F, i);
+          if ((ms & 0xFF) && (ms >> 8)) { packed |= i << (4 * n); ++n; }
+        }
+        if (n == 0) return;
+        const uint32_t slot = (packed >> (4 * rng_range(0, n))) & 15;
+        act_set(true, AC_MOVESLOT, 4, slot);
+        set_disable_move(F, slot);
+        set_disable_left(F, rng_range(1, 9));
+        dset(F, 21, 4, 1);
+        act_set(false, AC_DISABLE, 2, OBS_STARTED);
+        return;
+      }
+      default: return;
+      }
+    }
+
+    const bool fixed = eff == E_SpecialDamage || eff == E_SuperFang || move_id == M_Counter;
+    const bool ohko = eff == E_OHKO;
+    const uint32_t ft = types(F);
+    bool immune = false;
+    if (!fixed) immune = chart(mv.type(), ft & 15) == 0 || chart(mv.type(), ft >> 4) == 0;
+    if (eff == E_DreamEater && !(status(F) & ST_SLP)) immune = true;
+    if (ohko && spe(S) < spe(F)) immune = true;
+    if (move_id == M_Counter && (!lm_counterable(fap) || last_damage == 0)) immune = true;
+    bool hit = false;
+    if (!immune) hit = move_hit(mv);
+    if (immune || !hit) {
+      last_damage = 0;
+      clear_binding(S);
+      if (eff == E_Explode) { set_hp(S, 0); set_status(S, 0); }
+      if (eff == E_JumpKick && !immune) { const uint32_t h = hp(S); if (h > 0) set_hp(S, h - 1); }
+      return;
+    }
+
+    if (fixed) {
+      uint32_t d;
+      if (move_id == M_Counter) { d = last_damage * 2; if (d > 65535) d = 65535; }
+      else if (eff == E_SuperFang) { d = hp(F) / 2; if (d < 1) d = 1; }
+      else if (move_id == M_SonicBoom) d = 20;
+      else if (move_id == M_DragonRage) d = 40;
+      else if (move_id == M_Psywave) {
+        const uint32_t max = level(S) * 3 / 2;
+        d = max <= 1 ? 1 : rng_range(1, max);
+        act_set(true, AC_PSYWAVE, 8, d);
+      } else d = level(S);
+      last_damage = d;
+    } else if (ohko) {
+      last_damage = 65535;
+    } else {
+      const bool crit = check_crit(mv);
+      if (!calc_damage(F, mv.bp(), mv.type(), eff == E_Explode, crit)) return;
+      adjust_damage(mv);
+      randomize_damage();
+      if (last_damage == 0) { clear_binding(S); return; }
+    }
+
+    uint32_t hits = 1;
+    if (eff == E_DoubleHit || eff == E_Twineedle) hits = 2;
+    else if (eff == E_MultiHit) {
+      hits = (0x54333222u >> (4 * rng_range(0, 8))) & 15;
+      act_set(true, AC_MULTIHIT, 4, hits);
+    }
+
+    bool broke = false, hit_sub = false;
+    uint32_t dealt = 0;
+    const uint32_t per_hit = last_damage;
+    for (uint32_t h = 0; h < hits; ++h) {
+      last_damage = per_hit;
+      broke = apply_damage(F, F, hit_sub);
+      dealt = last_damage;
+      if (!hit_sub) {
+        if (F.vlo & V_BIDE) set_vstate(F, (vstate(F) + dealt) & 0xFFFF);
+        if ((F.vlo & V_RAGE) && hp(F) > 0) (void)boost_side(F, S, 0, 1); // rage builds
+      }
+      if (broke || hp(F) == 0) break;
+    }
+    set_lm_counterable(sap, (mv.type() == T_Normal || mv.type() == T_Fighting) && move_id != M_Counter);
+
+    if (eff == E_Explode && !broke) { set_hp(S, 0); set_status(S, 0); }
+    if (eff == E_Recoil && !broke && dealt > 0) {
+      uint32_t r = dealt / (move_id == M_Struggle ? 2u : 4u); if (r < 1) r = 1;
+      const uint32_t h = hp(S);
+      set_hp(S, r > h ? 0 : h - r);
+    }
+    if ((eff == E_DrainHP || eff == E_DreamEater) && dealt > 0) {
+      uint32_t h = dealt / 2; if (h < 1) h = 1;
+      h += hp(S);
+      const uint32_t mx = maxhp(S);
+      set_hp(S, h > mx ? mx : h);
+    }
+    if (hp(F) == 0 || broke) return;
+    if (eff == E_HyperBeam) { S.vlo |= V_RECHARGING; return; }
+    if (eff == E_Binding) {
+      if (!(S.vlo & V_BINDING)) {
+        const uint32_t n = (0x54333222u >> (4 * rng_range(0, 8))) & 15;
+        S.vlo |= V_BINDING;
+        set_attacks(S, n - 1);
+        dset(S, 28, 3, 1);
+        act_set(true, AC_BINDING, 3, OBS_STARTED);
+      }
+      return;
+    }
+    if (hit_sub) return;
+    switch (eff) {
+    case E_BurnChance1: secondary_status(mv, ST_BRN, 26); break;
+    case E_BurnChance2: secondary_status(mv, ST_BRN, 77); break;
+    case E_FreezeChance: secondary_status(mv, ST_FRZ, 26); break;
+    case E_ParalyzeChance1: secondary_status(mv, ST_PAR, 26); break;
+    case E_ParalyzeChance2: secondary_status(mv, ST_PAR, 77); break;
+    case E_PoisonChance1: secondary_status(mv, ST_PSN, 52); break;
+    case E_PoisonChance2: secondary_status(mv, ST_PSN, 103); break;
+    case E_Twineedle: secondary_status(mv, ST_PSN, 52); break;
+    case E_FlinchChance1: case E_FlinchChance2: {
+      const bool proc = rng_chance(eff == E_FlinchChance1 ? 26 : 77);
+      act_bool(true, AC_SECONDARY, proc);
+      if (proc) F.vlo |= V_FLINCH;
+      break;
+    }
+    case E_ConfusionChance: {
+      if (F.vlo & V_CONFUSION) break;
+      const bool proc = rng_chance(25);
+      act_bool(true, AC_SECONDARY, proc);
+      if (proc) start_confusion(F, false);
+      break;
+    }
+    case E_AttackDownChance: case E_DefenseDownChance: case E_SpeedDownChance: case E_SpecialDownChance: {
+      const bool proc = rng_chance(85);
+      act_bool(true, AC_SECONDARY, proc);
+      if (proc) unboost_foe((int)eff - (int)E_AttackDownChance, 1);
+      break;
+    }
+    default: break;
+    }
+  }
+
+  __device__ void execute_selected(uint32_t mslot, bool skip_can, bool skip_pp) {
+    const uint32_t sap = absp(S);
+    if (!skip_can) {
+#pragma unroll 1
+      for (int depth = 0; depth < 4; ++depth) {
+        const uint32_t move_id = last_sel(S);
+        const Move mv = move_data(move_id);
+        const uint32_t eff = mv.effect();
+        if (S.vlo & V_CHARGING) {
+          S.vlo &= ~(V_CHARGING | V_INVULNERABLE);
+        } else if (eff == E_Charge) {
+          S.vlo |= V_CHARGING;
+          if (move_id == M_Fly || move_id == M_Dig) S.vlo |= V_INVULNERABLE;
+          set_last_used(S, move_id);
+          set_lm_counterable(sap, 0);
+          return;
+        }
+        set_last_used(S, move_id);
+        set_lm_counterable(sap, 0);
+        if (!skip_pp) decrement_pp(mslot);
+        skip_pp = true;
+        if (eff == E_Metronome) {
+          const uint32_t r = rng_range(0, 163);
+          const uint32_t pick = (r + 1 >= M_Metronome) ? r + 2 : r + 1;
+          act_set(true, AC_METRONOME, 8, pick);
+          set_last_sel(S, pick);
+          continue;
+        }
+        if (eff == E_MirrorMove) {
+          const uint32_t mm = last_used(F);
+          if (mm == 0 || mm == M_MirrorMove) { last_damage = 0; return; }
+          set_last_sel(S, mm);
+          continue;
+        }
+        if (eff >= E_Confusion && eff <= E_Transform) { on_begin(mv, move_id, mslot); return; }
+        if (eff == E_Thrashing) {
+          S.vlo |= V_THRASHING;
+          set_attacks(S, rng_range(2, 4));
+          dset(S, 25, 3, 1);
+          act_set(true, AC_ATTACKING, 2, OBS_STARTED);
+        } else if (eff == E_Rage) {
+          S.vlo |= V_RAGE;
+        }
+        break;
+      }
+    }
+    do_move();
+  }
+
+  __device__ bool execute_move(uint32_t choice, bool &err) {
+    const uint32_t type = choice & 3;
+    if (type == C_SWITCH) { switch_in(S, F, choice >> 2); return false; }
+    if (type == C_PASS) return false;
+    uint32_t mslot = choice >> 2;
+    if (last_sel(S) == M_Struggle) mslot = 0;
+    else if (mslot == 0) mslot = lm_index(absp(S));
+    const int r = before_move();
+    if (r == BM_ERR) { err = true; return true; }
+    if (r == BM_DONE) return true;
+    execute_selected(mslot, r == BM_SKIP_CAN, r == BM_SKIP_PP);
+    return true;
+  }
+
+  __device__ void handle_residual() {
+    uint32_t h = hp(S);
+    if (h == 0) return;
+    const uint32_t mx = maxhp(S);
+    if (status(S) & (ST_BRN | ST_PSN)) {
+      uint32_t dmg = mx / 16; if (dmg < 1) dmg = 1;
+      if (S.vlo & V_TOXIC) { const uint32_t t = (toxic_ctr(S) + 1) & 31; set_toxic_ctr(S, t); dmg *= t; }
+      h = dmg > h ? 0 : h - dmg;
+      set_hp(S, h);
+      if (h == 0) return;
+    }
+    if (S.vlo & V_LEECHSEED) {
+      uint32_t dmg = mx / 16; if (dmg < 1) dmg = 1;
+      if (S.vlo & V_TOXIC) { const uint32_t t = (toxic_ctr(S) + 1) & 31; set_toxic_ctr(S, t); dmg *= t; }
+      h = dmg > h ? 0 : h - dmg;
+      set_hp(S, h);
+      const uint32_t fh = hp(F);
+      if (fh > 0) {
+        const uint32_t nh = fh + dmg, fm = maxhp(F);
+        set_hp(F, nh > fm ? fm : nh);
+      }
+    }
+  }
+
+  // side x fainted, y is its foe
+  __device__ __forceinline__ void faint(SideR &x, SideR &y) {
+    y.vlo &= ~V_MULTIHIT;
+    if (y.vlo & V_BIDE) set_vstate(y, 0);
+    x.vlo = 0;
+    x.vhi = 0;
+    set_last_used(x, 0);
+    set_status(x, 0);
+    x.misc &= ~1u; // the active (order position 0) is no longer alive
+    clear_binding(y);
+  }
+  // result if side x (foe y) has fainted, 0 otherwise
+  __device__ __forceinline__ uint32_t check_faint(SideR &x, SideR &y) {
+    if (hp(x) > 0) return 0;
+    const bool foe_fainted = hp(y) == 0;
+    faint(x, y);
+    if (foe_fainted) faint(y, x);
+    const bool x_out = (x.misc & 63) == 0, y_out = (y.misc & 63) == 0;
+    const uint32_t xp = absp(x);
+    if (x_out && y_out) return mk_result(R_TIE, 0, 0);
+    if (x_out) return mk_result(xp == 0 ? R_LOSE : R_WIN, 0, 0);
+    if (y_out) return mk_result(xp == 0 ? R_WIN : R_LOSE, 0, 0);
+    const uint32_t fc = foe_fainted ? C_SWITCH : C_PASS;
+    return xp == 0 ? mk_result(0, C_SWITCH, fc) : mk_result(0, fc, C_SWITCH);
+  }
+  __device__ __forceinline__ uint32_t end_turn() {
+    turn += 1;
+    if (turn >= 1000) return mk_result(R_TIE, 0, 0);
+    return mk_result(0, C_MOVE, C_MOVE);
+  }
+
+  // frame normalisation: afterwards S = P1, F = P2
+  __device__ __forceinline__ void normalize() {
+    const bool flipped = absp(S) != 0;
+    cswap_sides(flipped, S, F);
+    if constexpr (TRACK_ACTIONS) { uint64_t t = flipped ? actF : actS; actF = flipped ? actS : actF; actS = t; }
+  }
+
+  // ---- pkmn_gen1_battle_update; expects and leaves the normalised frame ---------------------------
+  __device__ uint32_t update(uint32_t c1, uint32_t c2) {
+    if constexpr (TRACK_ACTIONS) { actS = 0; actF = 0; }
+    if (turn == 0) {
+      const bool a1 = (S.misc & 63) != 0, a2 = (F.misc & 63) != 0;
+      if (!a1) return mk_result(a2 ? R_LOSE : R_TIE, 0, 0);
+      if (!a2) return mk_result(R_WIN, 0, 0);
+#pragma unroll 1
+      for (int k = 0; k < 2; ++k) { switch_in(S, F, 1); swap_sides(S, F); } // both leads, one copy of the code
+      return end_turn();
+    }
+    select_move(S, c1);
+    select_move(F, c2);
+    // turn order (S = P1, F = P2 here)
+    bool p2_first;
+    {
+      const uint32_t t1 = c1 & 3, t2 = c2 & 3;
+      if (t1 == C_PASS) p2_first = true;
+      else if (t2 == C_PASS) p2_first = false;
+      else if ((t1 == C_SWITCH) != (t2 == C_SWITCH)) p2_first = t1 != C_SWITCH;
+      else {
+        const uint32_t m1 = last_sel(S), m2 = last_sel(F);
+        bool decided = false;
+        p2_first = false;
+        if (t1 == C_MOVE) {
+          if ((m1 == M_QuickAttack) != (m2 == M_QuickAttack)) { p2_first = m1 != M_QuickAttack; decided = true; }
+          else if ((m1 == M_Counter) != (m2 == M_Counter)) { p2_first = m1 == M_Counter; decided = true; }
+        }
+        if (!decided) {
+          const uint32_t s1 = spe(S), s2 = spe(F);
+          if (s1 == s2) {
+            const bool p1 = rng_range(0, 2) == 0;
+            act_set(true, AC_SPEEDTIE, 2, p1 ? 1 : 2);
+            act_set(false, AC_SPEEDTIE, 2, p1 ? 1 : 2);
+            p2_first = !p1;
+          } else p2_first = s1 < s2;
+        }
+      }
+    }
+    uint32_t pc = p2_first ? c2 : c1, qc = p2_first ? c1 : c2;
+    cswap_sides(p2_first, S, F);
+    if constexpr (TRACK_ACTIONS) { uint64_t t = p2_first ? actF : actS; actF = p2_first ? actS : actF; actS = t; }
+    uint32_t result = 0;
+#pragma unroll 1
+    for (int k = 0; k < 2; ++k) {
+      bool err = false;
+      const bool replace = hp(S) == 0;
+      const bool residual = execute_move(pc, err);
+      if (err) { result = mk_result(R_ERROR, 0, 0); break; }
+      if (!replace) {
+        uint32_t r = 0;
+        if ((pc & 3) != C_SWITCH) r = check_faint(F, S);
+        if (r == 0) {
+          if (residual) handle_residual();
+          r = check_faint(S, F);
+        }
+        if (r) { result = r; break; }
+      }
+      if ((qc & 3) == C_PASS) break;
+      swap_sides(S, F);
+      if constexpr (TRACK_ACTIONS) { uint64_t t = actS; actS = actF; actF = t; }
+      uint32_t t = pc; pc = qc; qc = t;
+    }
+    normalize();
+    if (result) return result;
+    if ((S.vlo & V_BINDING) && attacks(S) == 0) clear_binding(S);
+    if ((F.vlo & V_BINDING) && attacks(F) == 0) clear_binding(F);
+    return end_turn();
+  }
+
+  // ---- pkmn_gen1_battle_choices from registers (side x) -------------------------------------------
+  struct Choices { uint32_t n; uint64_t lo; uint32_t hi; // up to 9 choice bytes, shift-indexed (no field select)
+    __device__ __forceinline__ void push(uint32_t c) {
+      lo |= n < 8 ? (uint64_t)c << (8 * n) : 0ull;
+      hi |= n >= 8 ? c : 0u;
+      ++n;
+    }
+    __device__ __forceinline__ uint32_t get(uint32_t i) const {
+      const uint32_t a = (uint32_t)(lo >> (8 * (i & 7))) & 0xFF;
+      return i < 8 ? a : hi;
+    }
+  };
+  __device__ __forceinline__ Choices choices(const SideR &x, uint32_t request) const {
+    Choices c{0, 0, 0};
+    if (request == C_PASS) { c.push(0); return c; }
+    const uint32_t alive = x.misc & 63;
+    if (request == C_SWITCH) {
+#pragma unroll
+      for (uint32_t slot = 2; slot <= 6; ++slot)
+        if ((alive >> (slot - 1)) & 1) c.push((slot << 2) | C_SWITCH);
+      if (c.n == 0) c.push(0);
+      return c;
+    }
+    if (x.vlo & (V_RECHARGING | V_RAGE | V_THRASHING | V_CHARGING)) { c.push(C_MOVE); return c; }
+    if (x.vlo & (V_BIDE | V_BINDING)) {
+      const uint32_t sel = last_sel(x);
+#pragma unroll
+      for (uint32_t i = 1; i <= 4; ++i) {
+        const uint32_t ms = active_move(x, i);
+        if ((ms & 0xFF) && (ms & 0xFF) == sel) { c.push((i << 2) | C_MOVE); return c; }
+      }
+      c.push(C_MOVE);
+      return c;
+    }
+#pragma unroll
+    for (uint32_t slot = 2; slot <= 6; ++slot)
+      if ((alive >> (slot - 1)) & 1) c.push((slot << 2) | C_SWITCH);
+    const uint32_t before = c.n, dm = disable_move(x);
+    bool open = true;
+#pragma unroll
+    for (uint32_t i = 1; i <= 4; ++i) {
+      const uint32_t ms = active_move(x, i);
+      if ((ms & 0xFF) == 0) open = false;
+      if (open && (ms >> 8) != 0 && dm != i) c.push((i << 2) | C_MOVE);
+    }
+    if (c.n == before) c.push(C_MOVE);
+    return c;
+  }
+};
+
+} // namespace oak
