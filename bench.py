@@ -3,10 +3,14 @@
 
 Workload (BASELINE.json configs[1]): batch = 65,536 random OU team pairs per GPU, pure
 random-policy rollout to terminal (cap 1000 turn-steps, mirrors search/mcts.h:606-614).
-One *step* = one pass of the rollout kernel over the whole batch; inputs (battles,
+One *step* = one pass of the rollout kernel over one whole batch; inputs (battles,
 durations, per-lane fast_prng state) are generated ON DEVICE before the timed region and
-stay resident in HBM; the per-lane choice-RNG stream continues from step to step, so every
-step plays different playouts from the same 65,536 openings.
+stay resident in HBM; the per-lane choice-RNG stream continues from pass to pass, so every
+step plays different playouts.  Steps are independent batches (as in root-parallel MCTS), so
+they are issued round-robin on `--streams` HIP streams (default 6, each with its own batch
+buffers): a batch's long tail (0.1% of playouts run to the 1000-step cap on a handful of
+waves) then overlaps the next batches instead of idling the GPU.  `--streams 1` gives the
+strictly serial latency figure quoted in DESIGN.md.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
@@ -26,6 +30,7 @@ import os
 import sys
 import time
 
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # let every in-flight batch have its own hardware queue
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -42,6 +47,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=65536, help="playouts per GPU")
+    ap.add_argument("--streams", type=int, default=6, help="independent batches in flight (HIP streams)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -68,68 +74,75 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm
 
-    ctx = Context(local_rank)
-    lib, h = ctx.lib, ctx.handle
-    stream = torch.cuda.current_stream(dev)
-    ctx.set_stream(stream.cuda_stream)
-    ctx.ensure_ou_pools()
-
     n = args.batch
+    S = max(1, min(args.streams, args.steps if args.steps > 0 else 1))
     u8 = torch.uint8
-    battles = torch.empty((n, 384), dtype=u8, device=dev)
-    durations = torch.empty((n, 8), dtype=u8, device=dev)
-    prng = torch.empty((n, 8), dtype=u8, device=dev)
-    results_in = torch.empty((n,), dtype=u8, device=dev)
-    results = torch.empty((n,), dtype=u8, device=dev)
-    steps_out = torch.empty((n,), dtype=torch.int32, device=dev)
-    values = torch.empty((n,), dtype=torch.float32, device=dev)
-    total_steps = torch.zeros((), dtype=torch.int64, device=dev)
 
     def P(t):
         return C.c_void_p(t.data_ptr())
 
-    # synthetic input, generated on device: lane seeds are disjoint across ranks
-    _lib.check(lib.oakgpu_random_ou_battles_dev(h, C.c_uint64(oakdist.lane_seed0(SEED0, n * world, rank, world)), n,
-                                                P(battles), P(durations), P(prng), P(results_in)))
+    class Slot:
+        """One batch in flight: its own context (HIP stream) and buffers."""
+
+        def __init__(self, idx):
+            self.ctx = Context(local_rank)   # owns a dedicated non-blocking HIP stream
+            self.stream = torch.cuda.ExternalStream(self.ctx.stream_ptr(), device=dev)
+            self.ctx.ensure_ou_pools()
+            self.battles = torch.empty((n, 384), dtype=u8, device=dev)
+            self.durations = torch.empty((n, 8), dtype=u8, device=dev)
+            self.prng = torch.empty((n, 8), dtype=u8, device=dev)
+            self.results_in = torch.empty((n,), dtype=u8, device=dev)
+            self.results = torch.empty((n,), dtype=u8, device=dev)
+            self.steps_out = torch.zeros((n,), dtype=torch.int32, device=dev)
+            self.values = torch.empty((n,), dtype=torch.float32, device=dev)
+            self.total = torch.zeros((), dtype=torch.int64, device=dev)
+            # synthetic input, generated on device; lane seeds disjoint across ranks and slots
+            seed0 = oakdist.lane_seed0(SEED0 + idx * n * world, n * world, rank, world)
+            _lib.check(self.ctx.lib.oakgpu_random_ou_battles_dev(self.ctx.handle, C.c_uint64(seed0), n, P(self.battles),
+                                                                 P(self.durations), P(self.prng), P(self.results_in)))
+
+        def step(self):
+            _lib.check(self.ctx.lib.oakgpu_rollout_dev(self.ctx.handle, P(self.battles), P(self.durations), P(self.results_in),
+                                                       P(self.prng), n, MAX_STEPS, 0, P(self.results), P(self.steps_out),
+                                                       P(self.values), None, None))
+
+        def finish(self):
+            with torch.cuda.stream(self.stream):
+                self.total += self.steps_out.sum(dtype=torch.int64)   # tiny reduction kernel, inside the timed region
+                if world > 1:   # the path's single exchange: one RCCL all-gather of the fp32 leaf values
+                    self.gathered = oakdist.gather_values(self.values, n * world)
+
+    slots = [Slot(i) for i in range(S)]
     torch.cuda.synchronize(dev)
-
-    def step():
-        _lib.check(lib.oakgpu_rollout_dev(h, P(battles), P(durations), P(results_in), P(prng), n, MAX_STEPS, 0,
-                                          P(results), P(steps_out), P(values), None, None))
-
-    def exchange():
-        if world > 1:
-            return oakdist.gather_values(values, n * world)   # one RCCL all-gather of fp32 leaf values
-        return values
-
-    steps_out.zero_()
-    total_steps += steps_out.sum(dtype=torch.int64)   # loads torch's lazily-loaded reduce kernels up front
-    for _ in range(args.warmup):
-        step()
-        total_steps += steps_out.sum(dtype=torch.int64)
-        exchange()
-    total_steps.zero_()
+    for sl in slots:   # loads torch's lazily-loaded reduce kernels up front
+        sl.finish()
+    for k in range(args.warmup):
+        slots[k % S].step()
+        slots[k % S].finish()
     torch.cuda.synchronize(dev)
+    for sl in slots:
+        sl.total.zero_()
 
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    for a, b in ev:   # force event creation outside the timed region
-        a.record(stream)
-        b.record(stream)
+    for k, (a, b) in enumerate(ev):   # force event creation outside the timed region
+        a.record(slots[k % S].stream)
+        b.record(slots[k % S].stream)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     for k in range(args.steps):
-        ev[k][0].record(stream)
-        step()
-        ev[k][1].record(stream)
-        total_steps += steps_out.sum(dtype=torch.int64)   # tiny reduction kernel, inside the timed region
-        exchange()
+        sl = slots[k % S]
+        ev[k][0].record(sl.stream)
+        sl.step()
+        ev[k][1].record(sl.stream)
+        sl.finish()
     torch.cuda.synchronize(dev)
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
 
+    total_steps = sum(sl.total for sl in slots)
     my_steps = int(total_steps.item())
     kern_ms = [a.elapsed_time(b) for a, b in ev]
     if world > 1:
@@ -173,8 +186,9 @@ def main():
                 "batch_per_gpu": n,
                 "playouts_per_s": n * world * args.steps / elapsed,
                 "mean_turn_steps_per_playout": all_steps / (n * world * args.steps),
-                "parallelism": "lanes sharded by rank; 1 RCCL all-gather of fp32 leaf values per step" if world > 1
-                               else "single GPU",
+                "parallelism": ("lanes sharded by rank; 1 RCCL all-gather of fp32 leaf values per step" if world > 1
+                                else "single GPU") + "; %d independent batches in flight on %d HIP streams" % (S, S),
+                "streams": S,
                 "parity": "bit-exact vs this repo's CPU oracle (libpkmn parity unpinned, see DESIGN.md)",
             },
             "roofline": {
@@ -186,6 +200,8 @@ def main():
                 "frac": achieved / HBM_PEAK_GBPS,
                 "traffic": traffic,
                 "avg_kernel_ms": avg_kernel_s * 1e3,
+                "concurrent_launches": S,
+                "achieved_aggregate": value / world * ALGO_BYTES_PER_STEP / 1e9,
                 "algorithmic_bytes_per_turn_step": ALGO_BYTES_PER_STEP,
                 "turn_steps_per_launch": steps_per_launch,
             },

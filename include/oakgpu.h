@@ -38,6 +38,8 @@ void oakgpu_destroy(oakgpu_ctx *ctx);
 const char *oakgpu_last_error(void);
 /* Use an existing hipStream_t (e.g. torch's current stream) for all *_dev launches. */
 int oakgpu_set_stream(oakgpu_ctx *ctx, void *hip_stream);
+/* The hipStream_t all *_dev launches of this context go to (own stream unless oakgpu_set_stream was called). */
+void *oakgpu_get_stream(oakgpu_ctx *ctx);
 int oakgpu_synchronize(oakgpu_ctx *ctx);
 int oakgpu_device_count(void);
 

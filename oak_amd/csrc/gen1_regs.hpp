@@ -56,10 +56,14 @@ struct EngineR {
   uint32_t turn, last_damage;
   uint32_t lm; // last_moves: index0 | counterable0<<8 | index1<<16 | counterable1<<24 (absolute players)
 
-  // ---- LDS party access ----
-  __device__ __forceinline__ uint32_t r32(int off) const { return m[(off >> 2) * STRIDE]; }
-  __device__ __forceinline__ void w32(int off, uint32_t v) { m[(off >> 2) * STRIDE] = v; }
-  __device__ __forceinline__ uint32_t r16(int off) const { return ((const lds_u16 *)m)[(off >> 2) * (STRIDE * 2) + ((off >> 1) & 1)]; }
+  // ---- LDS party access: only the 2 x 6 party slots live in LDS (PARTY_WORDS dwords per lane).
+  // `off` is the battle byte offset (layout.h); side 1's party starts at byte 184 = dword 46 and is
+  // stored right after side 0's 36 party dwords.
+  static constexpr int PARTY_WORDS = 72;
+  static __device__ __forceinline__ int widx(int off) { return (off >> 2) - (off >= SIDE_SZ ? 10 : 0); }
+  __device__ __forceinline__ uint32_t r32(int off) const { return m[widx(off) * STRIDE]; }
+  __device__ __forceinline__ void w32(int off, uint32_t v) { m[widx(off) * STRIDE] = v; }
+  __device__ __forceinline__ uint32_t r16(int off) const { return ((const lds_u16 *)m)[widx(off) * (STRIDE * 2) + ((off >> 1) & 1)]; }
 
   // ---- per-side field helpers ----
   static __device__ __forceinline__ uint32_t absp(const SideR &x) { return (x.misc >> 8) & 1; }
@@ -183,50 +187,123 @@ struct EngineR {
     const int off = stored_lds_off(x);
     w32(off + 8, x.p2); w32(off + 12, x.p3); w32(off + 16, x.p4); w32(off + 20, x.p5);
   }
-  __device__ __forceinline__ void load_side(SideR &x, uint32_t ap, uint32_t dur_word) {
-    const int so = (int)ap * SIDE_SZ;
-    x.a0 = r32(so + 144); x.a1 = r32(so + 148); x.a2 = r32(so + 152); x.bo = r32(so + 156);
-    x.vlo = r32(so + 160); x.vhi = r32(so + 164); x.m01 = r32(so + 168); x.m23 = r32(so + 172);
-    x.o0 = r32(so + 176); x.o1 = r32(so + 180);
-    x.dur = dur_word;
-    uint32_t alive = 0;
-    for (int k = 0; k < 6; ++k) {
-      uint32_t id = (k < 4 ? x.o0 >> (8 * k) : x.o1 >> (8 * (k - 4))) & 0xFF;
-      if (id != 0 && r16(so + PK_SZ * ((int)id - 1) + P_HP) != 0) alive |= 1u << k;
-    }
-    x.misc = alive | (ap << 8);
-    const uint32_t id0 = x.o0 & 0xFF;
-    if (id0 != 0) {
-      const int off = so + PK_SZ * ((int)id0 - 1);
-      x.p0 = r32(off); x.p1 = r32(off + 4); x.p2 = r32(off + 8); x.p3 = r32(off + 12); x.p4 = r32(off + 16); x.p5 = r32(off + 20);
-    } else { x.p0 = x.p1 = x.p2 = x.p3 = x.p4 = x.p5 = 0; }
-  }
-  __device__ __forceinline__ void store_side(const SideR &x) {
+  // One lane's battle: global AoS (96 dwords, 16-byte aligned) -> registers + party LDS.
+  // Done in small chunk groups (scheduling barriers in between) so the staging registers never
+  // pile up on top of the engine's own ~45 live registers.
+  __device__ __forceinline__ void alive_from_lds(SideR &x) {
     const int so = (int)absp(x) * SIDE_SZ;
-    w32(so + 144, x.a0); w32(so + 148, x.a1); w32(so + 152, x.a2); w32(so + 156, x.bo);
-    w32(so + 160, x.vlo); w32(so + 164, x.vhi); w32(so + 168, x.m01); w32(so + 172, x.m23);
-    w32(so + 176, x.o0); w32(so + 180, x.o1);
-    if (order0(x) != 0) writeback_stored(x);
+    uint32_t hpmask = 0; // bit i: party member i+1 has hp > 0
+#pragma unroll
+    for (int i = 0; i < 6; ++i) hpmask |= (r16(so + PK_SZ * i + P_HP) != 0 ? 1u : 0u) << i;
+    const uint64_t ord = (uint64_t)x.o0 | ((uint64_t)(x.o1 & 0xFFFF) << 32);
+    uint32_t alive = 0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      const uint32_t id = (uint32_t)(ord >> (8 * k)) & 0xFF;
+      alive |= (id != 0 ? (hpmask >> ((id - 1) & 7)) & 1u : 0u) << k;
+    }
+    x.misc = (x.misc & ~63u) | alive;
   }
-  // whole-battle load / store (frame normalised: S = P1, F = P2)
-  __device__ __forceinline__ void load_battle(uint32_t dur0, uint32_t dur1) {
-    load_side(S, 0, dur0);
-    load_side(F, 1, dur1);
-    uint32_t t = r32(B_TURN);
-    turn = t & 0xFFFF;
-    last_damage = t >> 16;
-    lm = r32(B_LAST_MOVES);
-    rng = (uint64_t)r32(B_RNG) | ((uint64_t)r32(B_RNG + 4) << 32);
+  __device__ __forceinline__ void load_stored(SideR &x) { // branch-free: an empty side (order[0] == 0) reads slot 1, masked to 0
+    const uint32_t id = order0(x);
+    const uint32_t keep = id != 0 ? 0xFFFFFFFFu : 0u;
+    const int off = (int)absp(x) * SIDE_SZ + PK_SZ * ((int)(id != 0 ? id : 1u) - 1);
+    x.p0 = r32(off) & keep; x.p1 = r32(off + 4) & keep; x.p2 = r32(off + 8) & keep;
+    x.p3 = r32(off + 12) & keep; x.p4 = r32(off + 16) & keep; x.p5 = r32(off + 20) & keep;
+  }
+#define OAK_PARTY4(c, pw) { const uint4 v = g[c]; m[((pw) + 0) * STRIDE] = v.x; m[((pw) + 1) * STRIDE] = v.y; m[((pw) + 2) * STRIDE] = v.z; m[((pw) + 3) * STRIDE] = v.w; }
+  __device__ __forceinline__ void load_battle_global(const uint8_t *battle384, uint32_t dur0, uint32_t dur1) {
+    const uint4 *g = (const uint4 *)battle384;
+    // side 0 party: dwords 0..35 -> party words 0..35
+    OAK_PARTY4(0, 0) OAK_PARTY4(1, 4) OAK_PARTY4(2, 8) OAK_PARTY4(3, 12) OAK_PARTY4(4, 16)
+    __builtin_amdgcn_sched_barrier(0);
+    OAK_PARTY4(5, 20) OAK_PARTY4(6, 24) OAK_PARTY4(7, 28) OAK_PARTY4(8, 32)
+    __builtin_amdgcn_sched_barrier(0);
+    { const uint4 v = g[9]; S.a0 = v.x; S.a1 = v.y; S.a2 = v.z; S.bo = v.w; }
+    { const uint4 v = g[10]; S.vlo = v.x; S.vhi = v.y; S.m01 = v.z; S.m23 = v.w; }
+    { const uint4 v = g[11]; S.o0 = v.x; S.o1 = v.y; m[36 * STRIDE] = v.z; m[37 * STRIDE] = v.w; }
+    __builtin_amdgcn_sched_barrier(0);
+    // side 1 party: dwords 46..81 -> party words 36..71
+    OAK_PARTY4(12, 38) OAK_PARTY4(13, 42) OAK_PARTY4(14, 46) OAK_PARTY4(15, 50)
+    __builtin_amdgcn_sched_barrier(0);
+    OAK_PARTY4(16, 54) OAK_PARTY4(17, 58) OAK_PARTY4(18, 62) OAK_PARTY4(19, 66)
+    __builtin_amdgcn_sched_barrier(0);
+    { const uint4 v = g[20]; m[70 * STRIDE] = v.x; m[71 * STRIDE] = v.y; F.a0 = v.z; F.a1 = v.w; }
+    { const uint4 v = g[21]; F.a2 = v.x; F.bo = v.y; F.vlo = v.z; F.vhi = v.w; }
+    { const uint4 v = g[22]; F.m01 = v.x; F.m23 = v.y; F.o0 = v.z; F.o1 = v.w; }
+    { const uint4 v = g[23]; turn = v.x & 0xFFFF; last_damage = v.x >> 16; lm = v.y; rng = (uint64_t)v.z | ((uint64_t)v.w << 32); }
+    __builtin_amdgcn_sched_barrier(0);
+    S.dur = dur0; F.dur = dur1;
+    S.misc = 0; F.misc = 1u << 8;
     actS = actF = 0;
+    alive_from_lds(S); // same-lane LDS write -> read: ordered by the wave's own lgkmcnt
+    alive_from_lds(F);
+    load_stored(S);
+    load_stored(F);
   }
-  __device__ __forceinline__ void store_battle() {
-    store_side(S);
-    store_side(F);
-    w32(B_TURN, turn | (last_damage << 16));
-    w32(B_LAST_MOVES, lm);
-    w32(B_RNG, (uint32_t)rng);
-    w32(B_RNG + 4, (uint32_t)(rng >> 32));
+#undef OAK_PARTY4
+  // registers + party LDS -> global AoS (frame must be normalised: S = P1, F = P2)
+#define OAK_PARTY4S(c, pw) g[c] = make_uint4(m[((pw) + 0) * STRIDE], m[((pw) + 1) * STRIDE], m[((pw) + 2) * STRIDE], m[((pw) + 3) * STRIDE]);
+  __device__ __forceinline__ void store_battle_global(uint8_t *battle384) {
+    if (order0(S) != 0) writeback_stored(S);
+    if (order0(F) != 0) writeback_stored(F);
+    uint4 *g = (uint4 *)battle384;
+    OAK_PARTY4S(0, 0) OAK_PARTY4S(1, 4) OAK_PARTY4S(2, 8) OAK_PARTY4S(3, 12) OAK_PARTY4S(4, 16)
+    __builtin_amdgcn_sched_barrier(0);
+    OAK_PARTY4S(5, 20) OAK_PARTY4S(6, 24) OAK_PARTY4S(7, 28) OAK_PARTY4S(8, 32)
+    __builtin_amdgcn_sched_barrier(0);
+    g[9] = make_uint4(S.a0, S.a1, S.a2, S.bo);
+    g[10] = make_uint4(S.vlo, S.vhi, S.m01, S.m23);
+    g[11] = make_uint4(S.o0, S.o1, m[36 * STRIDE], m[37 * STRIDE]);
+    OAK_PARTY4S(12, 38) OAK_PARTY4S(13, 42) OAK_PARTY4S(14, 46) OAK_PARTY4S(15, 50)
+    __builtin_amdgcn_sched_barrier(0);
+    OAK_PARTY4S(16, 54) OAK_PARTY4S(17, 58) OAK_PARTY4S(18, 62) OAK_PARTY4S(19, 66)
+    __builtin_amdgcn_sched_barrier(0);
+    g[20] = make_uint4(m[70 * STRIDE], m[71 * STRIDE], F.a0, F.a1);
+    g[21] = make_uint4(F.a2, F.bo, F.vlo, F.vhi);
+    g[22] = make_uint4(F.m01, F.m23, F.o0, F.o1);
+    g[23] = make_uint4(turn | (last_damage << 16), lm, (uint32_t)rng, (uint32_t)(rng >> 32));
   }
+#undef OAK_PARTY4S
+  // MCTS::randomize_hidden_variables (cpp/include/search/durations.h:25-97) on the register image;
+  // every draw reuses the same un-advanced battle.rng value
+  __device__ __forceinline__ void randomize_hidden_side(SideR &x) {
+    const uint32_t hi = (uint32_t)(rng >> 32), lo = (uint32_t)rng;
+    auto mod = [&](uint32_t mm) { uint32_t two32 = (0xFFFFFFFFu % mm + 1) % mm; return ((hi % mm) * two32 + (lo % mm)) % mm; };
+    const uint32_t d = x.dur;
+    const uint32_t confusion = (d >> 18) & 7, disable = (d >> 21) & 15, attacking = (d >> 25) & 7, binding = (d >> 28) & 7;
+    if (confusion) {
+      const uint32_t one = confusion == 1;
+      set_conf_left(x, (mod((6 - (confusion + one)) & 0xFF) + 1 + one) & 0xFF);
+    }
+    if (disable) set_disable_left(x, (mod((9 - disable) & 0xFF) + 1) & 0xFF);
+    if (attacking && (x.vlo & (V_BIDE | V_THRASHING))) set_attacks(x, attacking == 3 ? 1u : 4u - (attacking + mod(2)));
+    if (binding) {
+      const uint32_t idx = mod(40);
+      uint32_t a; // rows of the reference's 4 x 40 table as run lengths {15,15,6,4} {24,8,8} {20,20} {40}
+      if (binding == 1) a = idx < 15 ? 1 : idx < 30 ? 2 : idx < 36 ? 3 : 4;
+      else if (binding == 2) a = idx < 24 ? 1 : idx < 32 ? 2 : 3;
+      else if (binding == 3) a = idx < 20 ? 1 : 2;
+      else a = 1;
+      set_attacks(x, a);
+    }
+    const uint64_t ord = (uint64_t)x.o0 | ((uint64_t)(x.o1 & 0xFFFF) << 32);
+    for (int i = 0; i < 6; ++i) {
+      const uint32_t sleep = (d >> (3 * i)) & 7;
+      if (!sleep) continue;
+      const uint32_t draw = (mod((8 - sleep) & 0xFF) + 1) & 0xFF;
+      if (i == 0) {
+        const uint32_t st = status(x);
+        if ((st & 7) && !(st & 0x80)) set_status(x, (st & 0xF8) | draw);
+      } else {
+        const uint32_t id = (uint32_t)(ord >> (8 * i)) & 0xFF;
+        const int off = (int)absp(x) * SIDE_SZ + PK_SZ * ((int)id - 1) + 20;
+        const uint32_t w5 = r32(off), st = w5 & 0xFF;
+        if ((st & 7) && !(st & 0x80)) w32(off, (w5 & ~0xFFu) | (st & 0xF8) | draw);
+      }
+    }
+  }
+  __device__ __forceinline__ void randomize_hidden() { randomize_hidden_side(S); randomize_hidden_side(F); }
   // last_moves accessors by absolute player
   __device__ __forceinline__ uint32_t lm_index(uint32_t ap) const { return (lm >> (16 * ap)) & 0xFF; }
   __device__ __forceinline__ void set_lm_index(uint32_t ap, uint32_t v) { lm = (lm & ~(0xFFu << (16 * ap))) | ((v & 0xFF) << (16 * ap)); }

@@ -205,68 +205,55 @@ __global__ __launch_bounds__(BLK) void k_rollout(RolloutArgs a) {
   }
 }
 
-// ---- K1 (register-resident engine, gen1_regs.hpp): same contract as k_rollout -----------------
+// ---- K1 (register-resident engine, gen1_regs.hpp): same contract as k_rollout.  LDS holds only
+// the party slots (72 dwords per lane) + one table image per workgroup, so 8 waves fit on a CU.
 template <int BLK>
-__global__ __launch_bounds__(BLK) void k_rollout_regs(RolloutArgs a) {
+__global__ __launch_bounds__(BLK, 2) void k_rollout_regs(RolloutArgs a) {
   extern __shared__ __align__(16) uint8_t smem[];
-  lds_u32 *state = (lds_u32 *)smem;
-  Tables T = stage_default_tables((lds_u8 *)smem + STATE_WORDS * BLK * 4);
-  const uint32_t base = blockIdx.x * BLK;
-  const uint32_t count = min((uint32_t)BLK, a.n - base);
-  load_state<BLK>(state, a.battles, base, count);
+  lds_u32 *party = (lds_u32 *)smem;
+  using ER = EngineR<BLK, false>;
+  Tables T = stage_default_tables((lds_u8 *)smem + ER::PARTY_WORDS * BLK * 4);
   __syncthreads();
-  const uint32_t tid = threadIdx.x, lane = base + tid;
-  if (tid < count) {
-    const uint32_t *dsrc = (const uint32_t *)a.durations + 2 * (size_t)lane;
-    const uint32_t d0 = dsrc[0], d1 = dsrc[1];
-    FastPrng g;
-    const uint32_t *psrc = (const uint32_t *)a.prng + 2 * (size_t)lane;
-    g.s0 = psrc[0];
-    g.s1 = psrc[1];
-    if (a.prep) { // mcts.h:254-259, on the LDS image before it is pulled into registers
-      Engine<BLK, false> e0;
-      e0.m = state + tid;
-      e0.T = T;
-      e0.dur64 = (uint64_t)d0 | ((uint64_t)d1 << 32);
-      e0.over16 = 0;
-      uint32_t hi = g.next32(), lo = g.next32();
-      e0.w32(B_RNG, lo);
-      e0.w32(B_RNG + 4, hi);
-      randomize_hidden(e0);
-    }
-    EngineR<BLK, false> e;
-    e.m = state + tid;
-    e.T = T;
-    e.load_battle(d0, d1);
-    uint32_t result = a.results_in[lane];
-    uint32_t steps = 0;
-    while ((result & 15) == 0 && steps < a.max_steps) {
-      const uint32_t hi = g.next32(), lo = g.next32(); // uniform_64 = hi << 32 | lo
-      const auto c1s = e.choices(e.S, (result >> 4) & 3);
-      const uint32_t c1 = c1s.get(mod64_small(hi, lo, c1s.n));
-      const auto c2s = e.choices(e.F, (result >> 6) & 3);
-      const uint32_t c2 = c2s.get(hi % c2s.n);
-      result = e.update(c1, c2);
-      ++steps;
-    }
-    e.store_battle();
-    a.results_out[lane] = (uint8_t)result;
-    a.steps_out[lane] = steps;
-    const uint32_t t = result & 15;
-    a.values_out[lane] = t == R_WIN ? 1.0f : t == R_LOSE ? 0.0f : 0.5f;
-    uint32_t *pdst = (uint32_t *)a.prng + 2 * (size_t)lane;
-    pdst[0] = g.s0;
-    pdst[1] = g.s1;
-    if (a.durations_out) {
-      uint32_t *ddst = (uint32_t *)a.durations_out + 2 * (size_t)lane;
-      ddst[0] = e.S.dur;
-      ddst[1] = e.F.dur;
-    }
+  const uint32_t tid = threadIdx.x, lane = blockIdx.x * BLK + tid;
+  if (lane >= a.n) return;
+  const uint32_t *dsrc = (const uint32_t *)a.durations + 2 * (size_t)lane;
+  FastPrng g;
+  const uint32_t *psrc = (const uint32_t *)a.prng + 2 * (size_t)lane;
+  g.s0 = psrc[0];
+  g.s1 = psrc[1];
+  ER e;
+  e.m = party + tid;
+  e.T = T;
+  e.load_battle_global(a.battles + (size_t)lane * 384, dsrc[0], dsrc[1]);
+  if (a.prep) { // mcts.h:254-259
+    const uint32_t hi = g.next32(), lo = g.next32();
+    e.rng = ((uint64_t)hi << 32) | lo;
+    e.randomize_hidden();
   }
-  if (a.battles_out) {
-    __syncthreads();
-    store_state<BLK>(state, a.battles_out, base, count);
+  uint32_t result = a.results_in[lane];
+  uint32_t steps = 0;
+  while ((result & 15) == 0 && steps < a.max_steps) {
+    const uint32_t hi = g.next32(), lo = g.next32(); // uniform_64 = hi << 32 | lo
+    const auto c1s = e.choices(e.S, (result >> 4) & 3);
+    const uint32_t c1 = c1s.get(mod64_small(hi, lo, c1s.n));
+    const auto c2s = e.choices(e.F, (result >> 6) & 3);
+    const uint32_t c2 = c2s.get(hi % c2s.n);
+    result = e.update(c1, c2);
+    ++steps;
   }
+  a.results_out[lane] = (uint8_t)result;
+  a.steps_out[lane] = steps;
+  const uint32_t t = result & 15;
+  a.values_out[lane] = t == R_WIN ? 1.0f : t == R_LOSE ? 0.0f : 0.5f;
+  uint32_t *pdst = (uint32_t *)a.prng + 2 * (size_t)lane;
+  pdst[0] = g.s0;
+  pdst[1] = g.s1;
+  if (a.durations_out) {
+    uint32_t *ddst = (uint32_t *)a.durations_out + 2 * (size_t)lane;
+    ddst[0] = e.S.dur;
+    ddst[1] = e.F.dur;
+  }
+  if (a.battles_out) e.store_battle_global(a.battles_out + (size_t)lane * 384);
 }
 
 // ---- batched single update -------------------------------------------------------------------
@@ -485,8 +472,8 @@ int oakgpu_device_count(void) {
 static int set_lds_limits() {
   HIPCHK(hipFuncSetAttribute((const void *)oak::k_rollout<256>, hipFuncAttributeMaxDynamicSharedMemorySize, oak::ENGINE_LDS_BYTES));
   HIPCHK(hipFuncSetAttribute((const void *)oak::k_rollout<64>, hipFuncAttributeMaxDynamicSharedMemorySize, oak::STATE_WORDS * 64 * 4 + oak::TABLE_LDS_PAD));
-  HIPCHK(hipFuncSetAttribute((const void *)oak::k_rollout_regs<256>, hipFuncAttributeMaxDynamicSharedMemorySize, oak::ENGINE_LDS_BYTES));
-  HIPCHK(hipFuncSetAttribute((const void *)oak::k_rollout_regs<64>, hipFuncAttributeMaxDynamicSharedMemorySize, oak::STATE_WORDS * 64 * 4 + oak::TABLE_LDS_PAD));
+  HIPCHK(hipFuncSetAttribute((const void *)oak::k_rollout_regs<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 128 * 4 + oak::TABLE_LDS_PAD));
+  HIPCHK(hipFuncSetAttribute((const void *)oak::k_rollout_regs<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 64 * 4 + oak::TABLE_LDS_PAD));
   HIPCHK(hipFuncSetAttribute((const void *)oak::k_update, hipFuncAttributeMaxDynamicSharedMemorySize, oak::ENGINE_LDS_BYTES));
   HIPCHK(hipFuncSetAttribute((const void *)oak::k_choices, hipFuncAttributeMaxDynamicSharedMemorySize, oak::ENGINE_LDS_BYTES));
   HIPCHK(hipFuncSetAttribute((const void *)oak::k_init, hipFuncAttributeMaxDynamicSharedMemorySize, oak::ENGINE_LDS_BYTES));
@@ -507,8 +494,8 @@ int oakgpu_create(oakgpu_ctx **out, int device) {
   c->own_stream = true;
   c->d_legal = c->d_pools = c->d_sizes = nullptr;
   c->n_legal = 0;
-  c->rollout_block = 64;
-  if (const char *env = getenv("OAKGPU_ROLLOUT_BLOCK")) c->rollout_block = atoi(env) == 256 ? 256 : 64;
+  c->rollout_block = 64; // register engine: 64 (default: single-wave workgroups spread evenly over SIMDs) or 128; LDS engine: 64 or 256
+  if (const char *env = getenv("OAKGPU_ROLLOUT_BLOCK")) c->rollout_block = atoi(env);
   c->rollout_engine = 2;
   if (const char *env = getenv("OAKGPU_ROLLOUT_ENGINE")) c->rollout_engine = atoi(env) == 1 ? 1 : 2;
   hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
@@ -536,6 +523,8 @@ int oakgpu_set_stream(oakgpu_ctx *c, void *hip_stream) {
   return 0;
 }
 
+void *oakgpu_get_stream(oakgpu_ctx *c) { return c ? (void *)c->stream : nullptr; }
+
 int oakgpu_synchronize(oakgpu_ctx *c) {
   if (!c) return bad("null ctx");
   HIPCHK(hipStreamSynchronize(c->stream));
@@ -555,11 +544,13 @@ int oakgpu_rollout_dev(oakgpu_ctx *c, const uint8_t *battles, const uint8_t *dur
                      battles_out, durations_out};
   const size_t lds64 = oak::STATE_WORDS * 64 * 4 + oak::TABLE_LDS_PAD;
   if (c->rollout_engine == 1) { // LDS-resident engine (gen1_device.hpp), kept for A/B and as a second implementation
-    if (c->rollout_block == 64) hipLaunchKernelGGL(oak::k_rollout<64>, dim3((n + 63) / 64), dim3(64), lds64, c->stream, a);
+    if (c->rollout_block <= 64) hipLaunchKernelGGL(oak::k_rollout<64>, dim3((n + 63) / 64), dim3(64), lds64, c->stream, a);
     else hipLaunchKernelGGL(oak::k_rollout<256>, dim3(grid_for(n)), dim3(256), oak::ENGINE_LDS_BYTES, c->stream, a);
   } else {                      // register-resident engine (gen1_regs.hpp): the default
-    if (c->rollout_block == 64) hipLaunchKernelGGL(oak::k_rollout_regs<64>, dim3((n + 63) / 64), dim3(64), lds64, c->stream, a);
-    else hipLaunchKernelGGL(oak::k_rollout_regs<256>, dim3(grid_for(n)), dim3(256), oak::ENGINE_LDS_BYTES, c->stream, a);
+    if (c->rollout_block == 64)
+      hipLaunchKernelGGL(oak::k_rollout_regs<64>, dim3((n + 63) / 64), dim3(64), 72 * 64 * 4 + oak::TABLE_LDS_PAD, c->stream, a);
+    else
+      hipLaunchKernelGGL(oak::k_rollout_regs<128>, dim3((n + 127) / 128), dim3(128), 72 * 128 * 4 + oak::TABLE_LDS_PAD, c->stream, a);
   }
   HIPCHK(hipGetLastError());
   return 0;

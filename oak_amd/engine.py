@@ -52,6 +52,10 @@ class Context:
     def set_stream(self, stream_ptr):
         _lib.check(self.lib.oakgpu_set_stream(self.handle, C.c_void_p(stream_ptr)))
 
+    def stream_ptr(self):
+        """hipStream_t of this context (wrap with torch.cuda.ExternalStream to share it with torch)."""
+        return self.lib.oakgpu_get_stream(self.handle)
+
     def synchronize(self):
         _lib.check(self.lib.oakgpu_synchronize(self.handle))
 
