@@ -41,6 +41,10 @@ int oakgpu_set_stream(oakgpu_ctx *ctx, void *hip_stream);
 /* The hipStream_t all *_dev launches of this context go to (own stream unless oakgpu_set_stream was called). */
 void *oakgpu_get_stream(oakgpu_ctx *ctx);
 int oakgpu_synchronize(oakgpu_ctx *ctx);
+/* Rollout scheduling: k = 1 (default) launches one lane per playout; k > 1 launches n/k persistent lanes
+ * that refill from an atomic playout queue as playouts finish (same results, better lane utilisation
+ * when several batches share the GPU). */
+int oakgpu_set_playouts_per_lane(oakgpu_ctx *ctx, int k);
 int oakgpu_device_count(void);
 
 /* ---- rollout: replaces MCTS::Search::init_stats_and_rollout (search/mcts.h:448-496) and,

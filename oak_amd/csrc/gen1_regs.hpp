@@ -7,8 +7,8 @@
 //     Pokemon behind it, the order bytes + last selected/used move, the chance durations word
 //     and a 6-bit "alive" mask (so legal-choice enumeration and faint checks need no memory);
 //   * per battle: RNG seed, turn, last_damage, last_moves.
-// LDS (lane-interleaved, as in gen1_device.hpp) keeps the 12 party slots and is touched only on
-// switches (write back the outgoing Pokemon, read the incoming one) and Transform bookkeeping.
+// LDS (lane-interleaved) keeps only the MUTABLE part of the 12 party slots (PP, hp, status: 24 dwords
+// per lane) and is touched only on switches; immutable party data is re-read from the input battle.
 //
 // Player indices are lane-divergent (who moves first differs per lane), and indexing registers by
 // a divergent value would spill them to scratch.  So the code is written in a MOVER / TARGET frame:
@@ -56,15 +56,19 @@ struct EngineR {
   uint32_t turn, last_damage;
   uint32_t lm; // last_moves: index0 | counterable0<<8 | index1<<16 | counterable1<<24 (absolute players)
 
-  // ---- LDS party access: only the 2 x 6 party slots live in LDS (PARTY_WORDS dwords per lane).
-  // `off` is the battle byte offset (layout.h); side 1's party starts at byte 184 = dword 46 and is
-  // stored right after side 0's 36 party dwords.
-  static constexpr int PARTY_WORDS = 72;
-  static __device__ __forceinline__ int widx(int off) { return (off >> 2) - (off >= SIDE_SZ ? 10 : 0); }
-  __device__ __forceinline__ uint32_t r32(int off) const { return m[widx(off) * STRIDE]; }
-  __device__ __forceinline__ void w32(int off, uint32_t v) { m[widx(off) * STRIDE] = v; }
-  __device__ __forceinline__ uint32_t r16(int off) const { return ((const lds_u16 *)m)[widx(off) * (STRIDE * 2) + ((off >> 1) & 1)]; }
-
+  // ---- party storage.  Only what can CHANGE on a benched Pokemon lives in LDS: two dwords per party
+  // member (w0 = the four PP bytes, w1 = hp | status << 16), 24 dwords per lane, lane-interleaved.
+  // Everything immutable (stats, move ids, species, types, level) is re-read from the lane's INPUT
+  // battle in global memory (`gin`, L2-resident) on the rare occasions it is needed (switch-in,
+  // Transform bookkeeping, final write-back).  6 KB of LDS per wave leaves occupancy to the VGPR budget.
+  static constexpr int PARTY_WORDS = 24;
+  const uint32_t *gin; // this lane's input battle: 96 dwords
+  __device__ __forceinline__ uint32_t pw(uint32_t side, uint32_t i, int k) const { return m[((side * 6 + i) * 2 + k) * STRIDE]; }
+  __device__ __forceinline__ void set_pw(uint32_t side, uint32_t i, int k, uint32_t v) { m[((side * 6 + i) * 2 + k) * STRIDE] = v; }
+  __device__ __forceinline__ uint32_t gdw(uint32_t side, uint32_t i, int k) const { return gin[side * 46 + i * 6 + k]; }
+  static __device__ __forceinline__ uint32_t pack_pp(uint32_t d2, uint32_t d3, uint32_t d4) { // stored dwords 2..4 -> 4 PP bytes
+    return (d2 >> 24) | (((d3 >> 8) & 0xFF) << 8) | ((d3 >> 24) << 16) | (((d4 >> 8) & 0xFF) << 24);
+  }
   // ---- per-side field helpers ----
   static __device__ __forceinline__ uint32_t absp(const SideR &x) { return (x.misc >> 8) & 1; }
   static __device__ __forceinline__ uint32_t hp(const SideR &x) { return x.p4 >> 16; }
@@ -177,24 +181,25 @@ struct EngineR {
   __device__ __forceinline__ uint32_t unmodified_stat(const SideR &x, int idx) { // 0 atk 1 def 2 spe 3 spc
     if (!(x.vlo & V_TRANSFORM))
       return idx == 0 ? x.p0 >> 16 : idx == 1 ? x.p1 & 0xFFFF : idx == 2 ? x.p1 >> 16 : x.p2 & 0xFFFF;
-    uint32_t id = transform_id(x);
-    return r16((int)(id >> 3) * SIDE_SZ + PK_SZ * ((int)(id & 7) - 1) + P_ATK + 2 * idx);
+    const uint32_t id = transform_id(x), sd = id >> 3, pi = (id & 7) - 1; // immutable stats of the copied Pokemon
+    const uint32_t d = gdw(sd, pi, idx == 0 ? 0 : idx == 3 ? 2 : 1);
+    return (idx == 0 || idx == 2) ? d >> 16 : d & 0xFFFF;
   }
 
   // ---- register <-> LDS movement ----
-  __device__ __forceinline__ int stored_lds_off(const SideR &x) const { return (int)absp(x) * SIDE_SZ + PK_SZ * ((int)order0(x) - 1); }
-  __device__ __forceinline__ void writeback_stored(const SideR &x) { // stats never change: dwords 2..5 only
-    const int off = stored_lds_off(x);
-    w32(off + 8, x.p2); w32(off + 12, x.p3); w32(off + 16, x.p4); w32(off + 20, x.p5);
+  __device__ __forceinline__ void writeback_stored(const SideR &x) { // mutable part of the active's party slot
+    const uint32_t sd = absp(x), pi = order0(x) - 1;
+    set_pw(sd, pi, 0, pack_pp(x.p2, x.p3, x.p4));
+    set_pw(sd, pi, 1, (x.p4 >> 16) | ((x.p5 & 0xFF) << 16));
   }
   // One lane's battle: global AoS (96 dwords, 16-byte aligned) -> registers + party LDS.
   // Done in small chunk groups (scheduling barriers in between) so the staging registers never
   // pile up on top of the engine's own ~45 live registers.
   __device__ __forceinline__ void alive_from_lds(SideR &x) {
-    const int so = (int)absp(x) * SIDE_SZ;
+    const uint32_t sd = absp(x);
     uint32_t hpmask = 0; // bit i: party member i+1 has hp > 0
 #pragma unroll
-    for (int i = 0; i < 6; ++i) hpmask |= (r16(so + PK_SZ * i + P_HP) != 0 ? 1u : 0u) << i;
+    for (int i = 0; i < 6; ++i) hpmask |= ((pw(sd, i, 1) & 0xFFFF) != 0 ? 1u : 0u) << i;
     const uint64_t ord = (uint64_t)x.o0 | ((uint64_t)(x.o1 & 0xFFFF) << 32);
     uint32_t alive = 0;
 #pragma unroll
@@ -207,32 +212,32 @@ struct EngineR {
   __device__ __forceinline__ void load_stored(SideR &x) { // branch-free: an empty side (order[0] == 0) reads slot 1, masked to 0
     const uint32_t id = order0(x);
     const uint32_t keep = id != 0 ? 0xFFFFFFFFu : 0u;
-    const int off = (int)absp(x) * SIDE_SZ + PK_SZ * ((int)(id != 0 ? id : 1u) - 1);
-    x.p0 = r32(off) & keep; x.p1 = r32(off + 4) & keep; x.p2 = r32(off + 8) & keep;
-    x.p3 = r32(off + 12) & keep; x.p4 = r32(off + 16) & keep; x.p5 = r32(off + 20) & keep;
+    const uint32_t sd = absp(x), pi = (id != 0 ? id : 1u) - 1;
+    const uint32_t pp = pw(sd, pi, 0), hs = pw(sd, pi, 1);
+    x.p0 = gdw(sd, pi, 0) & keep;
+    x.p1 = gdw(sd, pi, 1) & keep;
+    x.p2 = ((gdw(sd, pi, 2) & 0x00FFFFFFu) | ((pp & 0xFF) << 24)) & keep;
+    x.p3 = ((gdw(sd, pi, 3) & 0x00FF00FFu) | (((pp >> 8) & 0xFF) << 8) | (((pp >> 16) & 0xFF) << 24)) & keep;
+    x.p4 = ((gdw(sd, pi, 4) & 0x000000FFu) | ((pp >> 24) << 8) | ((hs & 0xFFFF) << 16)) & keep;
+    x.p5 = ((gdw(sd, pi, 5) & 0xFFFFFF00u) | ((hs >> 16) & 0xFF)) & keep;
   }
-#define OAK_PARTY4(c, pw) { const uint4 v = g[c]; m[((pw) + 0) * STRIDE] = v.x; m[((pw) + 1) * STRIDE] = v.y; m[((pw) + 2) * STRIDE] = v.z; m[((pw) + 3) * STRIDE] = v.w; }
   __device__ __forceinline__ void load_battle_global(const uint8_t *battle384, uint32_t dur0, uint32_t dur1) {
-    const uint4 *g = (const uint4 *)battle384;
-    // side 0 party: dwords 0..35 -> party words 0..35
-    OAK_PARTY4(0, 0) OAK_PARTY4(1, 4) OAK_PARTY4(2, 8) OAK_PARTY4(3, 12) OAK_PARTY4(4, 16)
-    __builtin_amdgcn_sched_barrier(0);
-    OAK_PARTY4(5, 20) OAK_PARTY4(6, 24) OAK_PARTY4(7, 28) OAK_PARTY4(8, 32)
-    __builtin_amdgcn_sched_barrier(0);
-    { const uint4 v = g[9]; S.a0 = v.x; S.a1 = v.y; S.a2 = v.z; S.bo = v.w; }
-    { const uint4 v = g[10]; S.vlo = v.x; S.vhi = v.y; S.m01 = v.z; S.m23 = v.w; }
-    { const uint4 v = g[11]; S.o0 = v.x; S.o1 = v.y; m[36 * STRIDE] = v.z; m[37 * STRIDE] = v.w; }
-    __builtin_amdgcn_sched_barrier(0);
-    // side 1 party: dwords 46..81 -> party words 36..71
-    OAK_PARTY4(12, 38) OAK_PARTY4(13, 42) OAK_PARTY4(14, 46) OAK_PARTY4(15, 50)
-    __builtin_amdgcn_sched_barrier(0);
-    OAK_PARTY4(16, 54) OAK_PARTY4(17, 58) OAK_PARTY4(18, 62) OAK_PARTY4(19, 66)
-    __builtin_amdgcn_sched_barrier(0);
-    { const uint4 v = g[20]; m[70 * STRIDE] = v.x; m[71 * STRIDE] = v.y; F.a0 = v.z; F.a1 = v.w; }
-    { const uint4 v = g[21]; F.a2 = v.x; F.bo = v.y; F.vlo = v.z; F.vhi = v.w; }
-    { const uint4 v = g[22]; F.m01 = v.x; F.m23 = v.y; F.o0 = v.z; F.o1 = v.w; }
-    { const uint4 v = g[23]; turn = v.x & 0xFFFF; last_damage = v.x >> 16; lm = v.y; rng = (uint64_t)v.z | ((uint64_t)v.w << 32); }
-    __builtin_amdgcn_sched_barrier(0);
+    gin = (const uint32_t *)battle384;
+#pragma unroll
+    for (uint32_t sd = 0; sd < 2; ++sd)
+#pragma unroll
+      for (uint32_t i = 0; i < 6; ++i) {
+        const uint32_t d2 = gdw(sd, i, 2), d3 = gdw(sd, i, 3), d4 = gdw(sd, i, 4), d5 = gdw(sd, i, 5);
+        set_pw(sd, i, 0, pack_pp(d2, d3, d4));
+        set_pw(sd, i, 1, (d4 >> 16) | ((d5 & 0xFF) << 16));
+      }
+    { const uint4 v = *(const uint4 *)(gin + 36); S.a0 = v.x; S.a1 = v.y; S.a2 = v.z; S.bo = v.w; }
+    { const uint4 v = *(const uint4 *)(gin + 40); S.vlo = v.x; S.vhi = v.y; S.m01 = v.z; S.m23 = v.w; }
+    S.o0 = gin[44]; S.o1 = gin[45];
+    F.a0 = gin[82]; F.a1 = gin[83];
+    { const uint4 v = *(const uint4 *)(gin + 84); F.a2 = v.x; F.bo = v.y; F.vlo = v.z; F.vhi = v.w; }
+    { const uint4 v = *(const uint4 *)(gin + 88); F.m01 = v.x; F.m23 = v.y; F.o0 = v.z; F.o1 = v.w; }
+    { const uint4 v = *(const uint4 *)(gin + 92); turn = v.x & 0xFFFF; last_damage = v.x >> 16; lm = v.y; rng = (uint64_t)v.z | ((uint64_t)v.w << 32); }
     S.dur = dur0; F.dur = dur1;
     S.misc = 0; F.misc = 1u << 8;
     actS = actF = 0;
@@ -241,30 +246,32 @@ struct EngineR {
     load_stored(S);
     load_stored(F);
   }
-#undef OAK_PARTY4
-  // registers + party LDS -> global AoS (frame must be normalised: S = P1, F = P2)
-#define OAK_PARTY4S(c, pw) g[c] = make_uint4(m[((pw) + 0) * STRIDE], m[((pw) + 1) * STRIDE], m[((pw) + 2) * STRIDE], m[((pw) + 3) * STRIDE]);
+  // registers + party LDS (+ immutable input fields) -> global AoS; frame must be normalised (S = P1, F = P2)
   __device__ __forceinline__ void store_battle_global(uint8_t *battle384) {
     if (order0(S) != 0) writeback_stored(S);
     if (order0(F) != 0) writeback_stored(F);
-    uint4 *g = (uint4 *)battle384;
-    OAK_PARTY4S(0, 0) OAK_PARTY4S(1, 4) OAK_PARTY4S(2, 8) OAK_PARTY4S(3, 12) OAK_PARTY4S(4, 16)
-    __builtin_amdgcn_sched_barrier(0);
-    OAK_PARTY4S(5, 20) OAK_PARTY4S(6, 24) OAK_PARTY4S(7, 28) OAK_PARTY4S(8, 32)
-    __builtin_amdgcn_sched_barrier(0);
-    g[9] = make_uint4(S.a0, S.a1, S.a2, S.bo);
-    g[10] = make_uint4(S.vlo, S.vhi, S.m01, S.m23);
-    g[11] = make_uint4(S.o0, S.o1, m[36 * STRIDE], m[37 * STRIDE]);
-    OAK_PARTY4S(12, 38) OAK_PARTY4S(13, 42) OAK_PARTY4S(14, 46) OAK_PARTY4S(15, 50)
-    __builtin_amdgcn_sched_barrier(0);
-    OAK_PARTY4S(16, 54) OAK_PARTY4S(17, 58) OAK_PARTY4S(18, 62) OAK_PARTY4S(19, 66)
-    __builtin_amdgcn_sched_barrier(0);
-    g[20] = make_uint4(m[70 * STRIDE], m[71 * STRIDE], F.a0, F.a1);
-    g[21] = make_uint4(F.a2, F.bo, F.vlo, F.vhi);
-    g[22] = make_uint4(F.m01, F.m23, F.o0, F.o1);
-    g[23] = make_uint4(turn | (last_damage << 16), lm, (uint32_t)rng, (uint32_t)(rng >> 32));
+    uint32_t *g = (uint32_t *)battle384;
+#pragma unroll
+    for (uint32_t sd = 0; sd < 2; ++sd)
+#pragma unroll
+      for (uint32_t i = 0; i < 6; ++i) {
+        const uint32_t pp = pw(sd, i, 0), hs = pw(sd, i, 1);
+        uint32_t *d = g + sd * 46 + i * 6;
+        d[0] = gdw(sd, i, 0);
+        d[1] = gdw(sd, i, 1);
+        d[2] = (gdw(sd, i, 2) & 0x00FFFFFFu) | ((pp & 0xFF) << 24);
+        d[3] = (gdw(sd, i, 3) & 0x00FF00FFu) | (((pp >> 8) & 0xFF) << 8) | (((pp >> 16) & 0xFF) << 24);
+        d[4] = (gdw(sd, i, 4) & 0x000000FFu) | ((pp >> 24) << 8) | ((hs & 0xFFFF) << 16);
+        d[5] = (gdw(sd, i, 5) & 0xFFFFFF00u) | ((hs >> 16) & 0xFF);
+      }
+    *(uint4 *)(g + 36) = make_uint4(S.a0, S.a1, S.a2, S.bo);
+    *(uint4 *)(g + 40) = make_uint4(S.vlo, S.vhi, S.m01, S.m23);
+    g[44] = S.o0; g[45] = S.o1;
+    g[82] = F.a0; g[83] = F.a1;
+    *(uint4 *)(g + 84) = make_uint4(F.a2, F.bo, F.vlo, F.vhi);
+    *(uint4 *)(g + 88) = make_uint4(F.m01, F.m23, F.o0, F.o1);
+    *(uint4 *)(g + 92) = make_uint4(turn | (last_damage << 16), lm, (uint32_t)rng, (uint32_t)(rng >> 32));
   }
-#undef OAK_PARTY4S
   // MCTS::randomize_hidden_variables (cpp/include/search/durations.h:25-97) on the register image;
   // every draw reuses the same un-advanced battle.rng value
   __device__ __forceinline__ void randomize_hidden_side(SideR &x) {
@@ -297,9 +304,8 @@ struct EngineR {
         if ((st & 7) && !(st & 0x80)) set_status(x, (st & 0xF8) | draw);
       } else {
         const uint32_t id = (uint32_t)(ord >> (8 * i)) & 0xFF;
-        const int off = (int)absp(x) * SIDE_SZ + PK_SZ * ((int)id - 1) + 20;
-        const uint32_t w5 = r32(off), st = w5 & 0xFF;
-        if ((st & 7) && !(st & 0x80)) w32(off, (w5 & ~0xFFu) | (st & 0xF8) | draw);
+        const uint32_t hs = pw(absp(x), id - 1, 1), st = (hs >> 16) & 0xFF;
+        if ((st & 7) && !(st & 0x80)) set_pw(absp(x), id - 1, 1, (hs & 0xFFFF) | (((st & 0xF8) | draw) << 16));
       }
     }
   }
@@ -335,8 +341,7 @@ struct EngineR {
     x.dur = d & ((1u << 18) - 1);
     set_last_used(x, 0);
     set_last_used(y, 0);
-    const int off = stored_lds_off(x);
-    x.p0 = r32(off); x.p1 = r32(off + 4); x.p2 = r32(off + 8); x.p3 = r32(off + 12); x.p4 = r32(off + 16); x.p5 = r32(off + 20);
+    load_stored(x);
     x.a0 = x.p0;
     x.a1 = x.p1;
     x.a2 = (x.p2 & 0xFFFF) | (((x.p5 >> 8) & 0xFF) << 16) | (((x.p5 >> 16) & 0xFF) << 24);
@@ -512,9 +517,8 @@ struct EngineR {
     if (!(x.vlo & V_TRANSFORM)) {
       x.a0 = x.p0; x.a1 = x.p1; x.a2 = (x.a2 & 0xFFFF0000u) | (x.p2 & 0xFFFF);
     } else {
-      uint32_t id = transform_id(x);
-      const int off = (int)(id >> 3) * SIDE_SZ + PK_SZ * ((int)(id & 7) - 1);
-      x.a0 = r32(off); x.a1 = r32(off + 4); x.a2 = (x.a2 & 0xFFFF0000u) | (r32(off + 8) & 0xFFFF);
+      const uint32_t id = transform_id(x), sd = id >> 3, pi = (id & 7) - 1;
+      x.a0 = gdw(sd, pi, 0); x.a1 = gdw(sd, pi, 1); x.a2 = (x.a2 & 0xFFFF0000u) | (gdw(sd, pi, 2) & 0xFFFF);
     }
     (void)hpmax;
   }

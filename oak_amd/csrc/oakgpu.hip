@@ -256,6 +256,82 @@ __global__ __launch_bounds__(BLK, 2) void k_rollout_regs(RolloutArgs a) {
   if (a.battles_out) e.store_battle_global(a.battles_out + (size_t)lane * 384);
 }
 
+// ---- K1 with lane refill: a persistent grid of `gridDim.x * BLK` lanes pulls playouts from an atomic
+// queue.  A lane that finishes its playout immediately starts the next unassigned one (wave ballot ->
+// one atomicAdd per wave -> prefix rank), so waves stay full instead of idling on their longest lane.
+// Results are indexed by playout, each playout owns its RNG streams: output is identical to k_rollout*.
+template <int BLK>
+__global__ __launch_bounds__(BLK, 2) void k_rollout_queue(RolloutArgs a, uint32_t *queue) {
+  extern __shared__ __align__(16) uint8_t smem[];
+  lds_u32 *party = (lds_u32 *)smem;
+  using ER = EngineR<BLK, false>;
+  Tables T = stage_default_tables((lds_u8 *)smem + ER::PARTY_WORDS * BLK * 4);
+  __syncthreads();
+  const uint32_t tid = threadIdx.x, wl = tid & 63;
+  constexpr uint32_t NONE = 0xFFFFFFFFu, DONE = 0xFFFFFFFEu;
+  ER e;
+  e.m = party + tid;
+  e.T = T;
+  FastPrng g;
+  g.s0 = g.s1 = 0;
+  uint32_t idx = NONE, result = 0, steps = 0;
+  for (;;) {
+    const bool need = idx == NONE;
+    const uint64_t mask = __ballot(need);
+    if (mask) { // wave-uniform
+      uint32_t base = 0;
+      if (wl == 0) base = atomicAdd(queue, (uint32_t)__popcll(mask));
+      base = __shfl(base, 0, 64);
+      if (need) {
+        const uint32_t my = base + (uint32_t)__popcll(mask & ((1ull << wl) - 1));
+        if (my < a.n) {
+          idx = my;
+          const uint32_t *dsrc = (const uint32_t *)a.durations + 2 * (size_t)my;
+          const uint32_t *psrc = (const uint32_t *)a.prng + 2 * (size_t)my;
+          g.s0 = psrc[0];
+          g.s1 = psrc[1];
+          e.load_battle_global(a.battles + (size_t)my * 384, dsrc[0], dsrc[1]);
+          if (a.prep) { // mcts.h:254-259
+            const uint32_t hi = g.next32(), lo = g.next32();
+            e.rng = ((uint64_t)hi << 32) | lo;
+            e.randomize_hidden();
+          }
+          result = a.results_in[my];
+          steps = 0;
+        } else idx = DONE;
+      }
+    }
+    if (__ballot(idx != DONE) == 0) break;
+    if (idx != DONE) {
+      if ((result & 15) == 0 && steps < a.max_steps) {
+        const uint32_t hi = g.next32(), lo = g.next32(); // uniform_64 = hi << 32 | lo
+        const auto c1s = e.choices(e.S, (result >> 4) & 3);
+        const uint32_t c1 = c1s.get(mod64_small(hi, lo, c1s.n));
+        const auto c2s = e.choices(e.F, (result >> 6) & 3);
+        const uint32_t c2 = c2s.get(hi % c2s.n);
+        result = e.update(c1, c2);
+        ++steps;
+      }
+      if (!((result & 15) == 0 && steps < a.max_steps)) { // playout finished: publish and free the lane
+        a.results_out[idx] = (uint8_t)result;
+        a.steps_out[idx] = steps;
+        const uint32_t t = result & 15;
+        a.values_out[idx] = t == R_WIN ? 1.0f : t == R_LOSE ? 0.0f : 0.5f;
+        uint32_t *pdst = (uint32_t *)a.prng + 2 * (size_t)idx;
+        pdst[0] = g.s0;
+        pdst[1] = g.s1;
+        if (a.durations_out) {
+          uint32_t *ddst = (uint32_t *)a.durations_out + 2 * (size_t)idx;
+          ddst[0] = e.S.dur;
+          ddst[1] = e.F.dur;
+        }
+        if (a.battles_out) e.store_battle_global(a.battles_out + (size_t)idx * 384);
+        idx = NONE;
+      }
+    }
+  }
+}
+
 // ---- batched single update -------------------------------------------------------------------
 __global__ __launch_bounds__(BLOCK) void k_update(uint8_t *battles, const uint8_t *c1, const uint8_t *c2,
                                                   uint8_t *durations, uint8_t *actions, const uint8_t *overrides,
@@ -442,6 +518,8 @@ struct oakgpu_ctx {
   int n_legal;
   int rollout_block;  // threads per workgroup of the rollout kernel (64 or 256)
   int rollout_engine; // 2 = register-resident (default), 1 = LDS-resident
+  int playouts_per_lane; // > 1: persistent grid of n / this lanes with queue refill (k_rollout_queue)
+  uint32_t *d_queue;
 };
 
 static thread_local std::string g_err;
@@ -472,8 +550,9 @@ int oakgpu_device_count(void) {
 static int set_lds_limits() {
   HIPCHK(hipFuncSetAttribute((const void *)oak::k_rollout<256>, hipFuncAttributeMaxDynamicSharedMemorySize, oak::ENGINE_LDS_BYTES));
   HIPCHK(hipFuncSetAttribute((const void *)oak::k_rollout<64>, hipFuncAttributeMaxDynamicSharedMemorySize, oak::STATE_WORDS * 64 * 4 + oak::TABLE_LDS_PAD));
-  HIPCHK(hipFuncSetAttribute((const void *)oak::k_rollout_regs<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 128 * 4 + oak::TABLE_LDS_PAD));
-  HIPCHK(hipFuncSetAttribute((const void *)oak::k_rollout_regs<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 64 * 4 + oak::TABLE_LDS_PAD));
+  HIPCHK(hipFuncSetAttribute((const void *)oak::k_rollout_regs<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 24 * 128 * 4 + oak::TABLE_LDS_PAD));
+  HIPCHK(hipFuncSetAttribute((const void *)oak::k_rollout_regs<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 24 * 64 * 4 + oak::TABLE_LDS_PAD));
+  HIPCHK(hipFuncSetAttribute((const void *)oak::k_rollout_queue<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 24 * 64 * 4 + oak::TABLE_LDS_PAD));
   HIPCHK(hipFuncSetAttribute((const void *)oak::k_update, hipFuncAttributeMaxDynamicSharedMemorySize, oak::ENGINE_LDS_BYTES));
   HIPCHK(hipFuncSetAttribute((const void *)oak::k_choices, hipFuncAttributeMaxDynamicSharedMemorySize, oak::ENGINE_LDS_BYTES));
   HIPCHK(hipFuncSetAttribute((const void *)oak::k_init, hipFuncAttributeMaxDynamicSharedMemorySize, oak::ENGINE_LDS_BYTES));
@@ -496,6 +575,9 @@ int oakgpu_create(oakgpu_ctx **out, int device) {
   c->n_legal = 0;
   c->rollout_block = 64; // register engine: 64 (default: single-wave workgroups spread evenly over SIMDs) or 128; LDS engine: 64 or 256
   if (const char *env = getenv("OAKGPU_ROLLOUT_BLOCK")) c->rollout_block = atoi(env);
+  c->playouts_per_lane = 1;
+  if (const char *env = getenv("OAKGPU_PLAYOUTS_PER_LANE")) c->playouts_per_lane = atoi(env) > 0 ? atoi(env) : 1;
+  c->d_queue = nullptr;
   c->rollout_engine = 2;
   if (const char *env = getenv("OAKGPU_ROLLOUT_ENGINE")) c->rollout_engine = atoi(env) == 1 ? 1 : 2;
   hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
@@ -512,6 +594,7 @@ void oakgpu_destroy(oakgpu_ctx *c) {
   if (c->d_legal) (void)hipFree(c->d_legal);
   if (c->d_pools) (void)hipFree(c->d_pools);
   if (c->d_sizes) (void)hipFree(c->d_sizes);
+  if (c->d_queue) (void)hipFree(c->d_queue);
   delete c;
 }
 
@@ -520,6 +603,12 @@ int oakgpu_set_stream(oakgpu_ctx *c, void *hip_stream) {
   if (c->own_stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
   c->stream = (hipStream_t)hip_stream;
   c->own_stream = false;
+  return 0;
+}
+
+int oakgpu_set_playouts_per_lane(oakgpu_ctx *c, int k) {
+  if (!c || k < 1) return bad("oakgpu_set_playouts_per_lane: bad argument");
+  c->playouts_per_lane = k;
   return 0;
 }
 
@@ -546,11 +635,17 @@ int oakgpu_rollout_dev(oakgpu_ctx *c, const uint8_t *battles, const uint8_t *dur
   if (c->rollout_engine == 1) { // LDS-resident engine (gen1_device.hpp), kept for A/B and as a second implementation
     if (c->rollout_block <= 64) hipLaunchKernelGGL(oak::k_rollout<64>, dim3((n + 63) / 64), dim3(64), lds64, c->stream, a);
     else hipLaunchKernelGGL(oak::k_rollout<256>, dim3(grid_for(n)), dim3(256), oak::ENGINE_LDS_BYTES, c->stream, a);
+  } else if (c->playouts_per_lane > 1) { // register engine + lane refill from an atomic playout queue
+    if (!c->d_queue) HIPCHK(hipMalloc((void **)&c->d_queue, 256));
+    HIPCHK(hipMemsetAsync(c->d_queue, 0, 4, c->stream));
+    uint32_t waves = ((n + 63) / 64 + c->playouts_per_lane - 1) / c->playouts_per_lane;
+    if (waves < 1) waves = 1;
+    hipLaunchKernelGGL(oak::k_rollout_queue<64>, dim3(waves), dim3(64), 24 * 64 * 4 + oak::TABLE_LDS_PAD, c->stream, a, c->d_queue);
   } else {                      // register-resident engine (gen1_regs.hpp): the default
     if (c->rollout_block == 64)
-      hipLaunchKernelGGL(oak::k_rollout_regs<64>, dim3((n + 63) / 64), dim3(64), 72 * 64 * 4 + oak::TABLE_LDS_PAD, c->stream, a);
+      hipLaunchKernelGGL(oak::k_rollout_regs<64>, dim3((n + 63) / 64), dim3(64), 24 * 64 * 4 + oak::TABLE_LDS_PAD, c->stream, a);
     else
-      hipLaunchKernelGGL(oak::k_rollout_regs<128>, dim3((n + 127) / 128), dim3(128), 72 * 128 * 4 + oak::TABLE_LDS_PAD, c->stream, a);
+      hipLaunchKernelGGL(oak::k_rollout_regs<128>, dim3((n + 127) / 128), dim3(128), 24 * 128 * 4 + oak::TABLE_LDS_PAD, c->stream, a);
   }
   HIPCHK(hipGetLastError());
   return 0;

@@ -52,6 +52,9 @@ class Context:
     def set_stream(self, stream_ptr):
         _lib.check(self.lib.oakgpu_set_stream(self.handle, C.c_void_p(stream_ptr)))
 
+    def set_playouts_per_lane(self, k):
+        _lib.check(self.lib.oakgpu_set_playouts_per_lane(self.handle, int(k)))
+
     def stream_ptr(self):
         """hipStream_t of this context (wrap with torch.cuda.ExternalStream to share it with torch)."""
         return self.lib.oakgpu_get_stream(self.handle)
