@@ -53,52 +53,115 @@ struct EmbedArgs {
   float *emb; // n x emb_dim
 };
 
-// gather-add of one feature row: h{0,1} += W0t[idx][c], W0t row-major [in][hidden]
-#define ROW_ADD(w0t, hidden, idx, val)                                              \
-  do {                                                                              \
-    const float *_r = (w0t) + (size_t)(idx) * (hidden);                             \
-    if (c0 < (hidden)) h0 = fmaf(_r[c0], (val), h0);                                \
-    if (c1 < (hidden)) h1 = fmaf(_r[c1], (val), h1);                                \
-  } while (0)
-
 __device__ __forceinline__ uint32_t status_index(uint32_t status, uint32_t sleeps) { // battle.h:103-123
   if (!(status & 7)) return (uint32_t)__builtin_ctz(status) - 3;
   if (!(status & 0x80)) return 3 + sleeps;
   return 14 - (status & 7);
 }
 
-// Pokemon features (battle.h:16-214) accumulated into h0/h1; pk = 6 dwords of the 24-byte slot
-#define POKEMON_FEATURES(w0t, hidden, pk0, pk1, pk2, pk3, pk4, pk5, sleep, off)                       \
-  do {                                                                                                \
-    ROW_ADD(w0t, hidden, (off) + 0, (float)((pk0) & 0xFFFF) / 703.0f);                                \
-    ROW_ADD(w0t, hidden, (off) + 1, (float)((pk0) >> 16) / 999.0f);                                   \
-    ROW_ADD(w0t, hidden, (off) + 2, (float)((pk1) & 0xFFFF) / 999.0f);                                \
-    ROW_ADD(w0t, hidden, (off) + 3, (float)((pk1) >> 16) / 999.0f);                                   \
-    ROW_ADD(w0t, hidden, (off) + 4, (float)((pk2) & 0xFFFF) / 999.0f);                                \
-    const uint32_t _mv[4] = {(pk2) >> 16, (pk3) & 0xFFFF, (pk3) >> 16, (pk4) & 0xFFFF};               \
-    for (int _m = 0; _m < 4; ++_m) {                                                                  \
-      const uint32_t _id = _mv[_m] & 0xFF, _pp = _mv[_m] >> 8;                                        \
-      if (_id != 0 && _id != 165 && _pp != 0) ROW_ADD(w0t, hidden, (off) + 5 + _id - 1, 1.0f);       \
-    }                                                                                                 \
-    const uint32_t _st = (pk5) & 0xFF;                                                                \
-    if (_st) ROW_ADD(w0t, hidden, (off) + 169 + status_index(_st, (sleep)), 1.0f);                    \
-    const uint32_t _ty = ((pk5) >> 16) & 0xFF, _t1 = _ty & 15, _t2 = _ty >> 4;                        \
-    ROW_ADD(w0t, hidden, (off) + 183 + _t1, 1.0f);                                                    \
-    if (_t2 != _t1) ROW_ADD(w0t, hidden, (off) + 183 + _t2, 1.0f);                                    \
-  } while (0)
+// Feature `j` (0..11) of Encode::Battle::Pokemon (battle.h:16-214) from the 6 dwords of a party slot:
+// 0-4 stats, 5-8 move slots, 9 status, 10-11 types.  Returns false when the feature is absent.
+__device__ __forceinline__ bool pokemon_feature(uint32_t j, uint32_t pk0, uint32_t pk1, uint32_t pk2, uint32_t pk3, uint32_t pk4,
+                                                uint32_t pk5, uint32_t sleep, uint32_t &idx, float &val) {
+  if (j < 5) {
+    const uint32_t raw = j == 0 ? pk0 & 0xFFFF : j == 1 ? pk0 >> 16 : j == 2 ? pk1 & 0xFFFF : j == 3 ? pk1 >> 16 : pk2 & 0xFFFF;
+    idx = j;
+    val = (float)raw / (j == 0 ? 703.0f : 999.0f);
+    return true;
+  }
+  if (j < 9) {
+    const uint32_t ms = j == 5 ? pk2 >> 16 : j == 6 ? pk3 & 0xFFFF : j == 7 ? pk3 >> 16 : pk4 & 0xFFFF;
+    const uint32_t id = ms & 0xFF, pp = ms >> 8;
+    idx = 5 + id - 1;
+    val = 1.0f;
+    return id != 0 && id != 165 && pp != 0;
+  }
+  if (j == 9) {
+    const uint32_t st = pk5 & 0xFF;
+    idx = 169 + (st ? status_index(st, sleep) : 0);
+    val = 1.0f;
+    return st != 0;
+  }
+  const uint32_t ty = (pk5 >> 16) & 0xFF, t1 = ty & 15, t2 = ty >> 4;
+  idx = 183 + (j == 10 ? t1 : t2);
+  val = 1.0f;
+  return j == 10 || t2 != t1;
+}
 
+// Feature `j` (0..39) of Encode::Battle::Active (battle.h:229-489, sparse form): 0-4 stats, 5-6 types,
+// 7-12 boosts, 13-31 volatiles, 32-35 move slots, 36-39 durations.
+__device__ __forceinline__ bool active_feature(uint32_t j, uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3, uint32_t vlo,
+                                               uint32_t vhi, uint32_t m01, uint32_t m23, uint32_t dur, uint32_t &idx, float &val) {
+  if (j < 5) {
+    const uint32_t raw = j == 0 ? a0 & 0xFFFF : j == 1 ? a0 >> 16 : j == 2 ? a1 & 0xFFFF : j == 3 ? a1 >> 16 : a2 & 0xFFFF;
+    idx = j;
+    val = (float)raw / (j == 0 ? 703.0f : 999.0f);
+    return true;
+  }
+  if (j < 7) {
+    const uint32_t ty = a2 >> 24, t1 = ty & 15, t2 = ty >> 4;
+    idx = 5 + (j == 5 ? t1 : t2);
+    val = 1.0f;
+    return j == 5 || t2 != t1;
+  }
+  if (j < 13) { // boosts (battle.h:271-285): stage ratio * 1/4 (accuracy / evasion: 1/3)
+    const uint32_t i = j - 7;
+    const int st = (int)((((a3 >> (4 * i)) & 15) ^ 8) - 8);
+    // ratios of libpkmn/data/boosts.h:10-24 as float(num) / den
+    const float num = st == -6 ? 25.f : st == -5 ? 28.f : st == -4 ? 33.f : st == -3 ? 40.f : st == -2 ? 50.f : st == -1 ? 66.f
+                      : st == 0 ? 1.f : st == 1 ? 15.f : st == 2 ? 2.f : st == 3 ? 25.f : st == 4 ? 3.f : st == 5 ? 35.f : 4.f;
+    const float den = st < 0 ? 100.f : (st == 1 || st == 3 || st == 5) ? 10.f : 1.f;
+    idx = 20 + i;
+    val = (num / den) * (i < 4 ? 0.25f : (float)(1 / 3.0));
+    return true;
+  }
+  if (j < 32) { // volatiles (battle.h:322-352)
+    const uint32_t i = j - 13;
+    idx = 26 + i;
+    if (i < 16) {
+      const uint32_t bit = i < 2 ? i : i + 2; // bide, thrashing, then charging(4)..transform(17)
+      val = 1.0f;
+      return (vlo >> bit) & 1;
+    }
+    const uint32_t state = (vlo >> 24) | ((vhi & 0xFF) << 8), sub = (vhi >> 8) & 0xFF, tox = vhi >> 27;
+    if (i == 16) { val = (float)state / 65535.0f; return state != 0; }
+    if (i == 17) { val = (float)sub / 177.0f; return sub != 0; }
+    val = (float)tox / 16.0f;
+    return tox != 0;
+  }
+  if (j < 36) {
+    const uint32_t i = j - 32;
+    const uint32_t ms = (i < 2 ? m01 >> (16 * i) : m23 >> (16 * (i - 2))) & 0xFFFF;
+    const uint32_t id = ms & 0xFF, pp = ms >> 8;
+    idx = 45 + id - 1;
+    val = 1.0f;
+    return id != 0 && id != 165 && pp != 0;
+  }
+  const uint32_t i = j - 36;
+  const uint32_t v = i == 0 ? (dur >> 18) & 7 : i == 1 ? (dur >> 21) & 15 : i == 2 ? (dur >> 25) & 7 : (dur >> 28) & 7;
+  idx = (i == 0 ? 209 : i == 1 ? 214 : i == 2 ? 222 : 225) + v - 1;
+  val = 1.0f;
+  return v != 0;
+}
+
+// One wave per (leaf, party slot).  Lanes build the sparse feature list in parallel, compact it with a
+// ballot into LDS, then the wave streams the selected 512-byte rows of W0^T with 8 loads in flight
+// (2 channels per lane), and finishes with the dense second layer out of LDS.
 __global__ __launch_bounds__(EMB_BLOCK) void k_embed(EmbedArgs a) {
   extern __shared__ __align__(16) float lds_f[];
   const NetDev &N = a.net;
-  // stage W1^T of both embedding nets in LDS: [hidden][out] row-major
-  float *p_w1t = lds_f;
-  float *a_w1t = p_w1t + N.p_hidden * N.p_out;
+  float *p_w1t = lds_f;                                   // [p_hidden][p_out]
+  float *a_w1t = p_w1t + N.p_hidden * N.p_out;            // [a_hidden][a_out]
+  float *scratch = a_w1t + N.a_hidden * N.a_out;          // per wave: 64 idx + 64 val + 128 h
   for (int i = threadIdx.x; i < N.p_hidden * N.p_out; i += EMB_BLOCK) p_w1t[i] = N.p_w1t[i];
   for (int i = threadIdx.x; i < N.a_hidden * N.a_out; i += EMB_BLOCK) a_w1t[i] = N.a_w1t[i];
   __syncthreads();
 
-  const int lane = threadIdx.x & 63;
-  const int c0 = lane, c1 = lane + 64;
+  const uint32_t lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+  uint32_t *list_idx = (uint32_t *)(scratch + wib * 256);
+  float *list_val = scratch + wib * 256 + 64;
+  float *hbuf = scratch + wib * 256 + 128;
+  const uint32_t c0 = lane, c1 = lane + 64;
   const uint32_t wave = __builtin_amdgcn_readfirstlane((blockIdx.x * EMB_BLOCK + threadIdx.x) >> 6);
   const uint32_t n_waves = (gridDim.x * EMB_BLOCK) >> 6;
   const uint32_t items = a.n * 12;
@@ -107,12 +170,11 @@ __global__ __launch_bounds__(EMB_BLOCK) void k_embed(EmbedArgs a) {
     const uint32_t side = t / 6, slot = t - side * 6; // slot 0 = active
     const uint32_t *sb = (const uint32_t *)(a.battles + (size_t)leaf * 384 + side * 184);
     const uint32_t dur = ((const uint32_t *)a.durations)[(size_t)leaf * 2 + side];
-    // order bytes live at side offset 176..181: dwords 44, 45
-    const uint32_t o0 = sb[44], o1 = sb[45];
+    const uint32_t o0 = sb[44], o1 = sb[45]; // order bytes at side offset 176
     const uint32_t id = slot < 4 ? (o0 >> (8 * slot)) & 0xFF : (o1 >> (8 * (slot - 4))) & 0xFF;
-    const int out_dim = slot == 0 ? N.a_out : N.p_out;
-    float *dst = a.emb + (size_t)leaf * N.emb_dim + side * N.side_dim +
-                 (slot == 0 ? 0 : (1 + N.a_out) + (slot - 1) * (1 + N.p_out));
+    const bool is_active = slot == 0;
+    const uint32_t out_dim = is_active ? N.a_out : N.p_out;
+    float *dst = a.emb + (size_t)leaf * N.emb_dim + side * N.side_dim + (is_active ? 0 : (1 + N.a_out) + (slot - 1) * (1 + N.p_out));
     uint32_t pk0 = 0, pk1 = 0, pk2 = 0, pk3 = 0, pk4 = 0, pk5 = 0, hp = 0;
     if (id != 0) {
       const uint32_t *pk = sb + 6 * (id - 1);
@@ -120,81 +182,67 @@ __global__ __launch_bounds__(EMB_BLOCK) void k_embed(EmbedArgs a) {
       hp = pk4 >> 16;
     }
     if (hp == 0) { // empty or fainted: zero block (network.h:142-143,153-160)
-      for (int o = lane; o < out_dim + 1; o += 64) dst[o] = 0.0f;
+      for (uint32_t o = lane; o < out_dim + 1; o += 64) dst[o] = 0.0f;
       continue;
     }
-    float h0, h1;
-    const float *w1t;
-    int hidden;
-    if (slot == 0) {
-      hidden = N.a_hidden;
-      h0 = c0 < hidden ? N.a_b0[c0] : 0.0f;
-      h1 = c1 < hidden ? N.a_b0[c1] : 0.0f;
-      const uint32_t *ac = sb + 36; // active at byte 144
-      const uint32_t a0 = ac[0], a1 = ac[1], a2 = ac[2], a3 = ac[3], vlo = ac[4], vhi = ac[5], m01 = ac[6], m23 = ac[7];
-      const float *w0t = N.a_w0t;
-      ROW_ADD(w0t, hidden, 0, (float)(a0 & 0xFFFF) / 703.0f);
-      ROW_ADD(w0t, hidden, 1, (float)(a0 >> 16) / 999.0f);
-      ROW_ADD(w0t, hidden, 2, (float)(a1 & 0xFFFF) / 999.0f);
-      ROW_ADD(w0t, hidden, 3, (float)(a1 >> 16) / 999.0f);
-      ROW_ADD(w0t, hidden, 4, (float)(a2 & 0xFFFF) / 999.0f);
-      const uint32_t ty = a2 >> 24, t1 = ty & 15, t2 = ty >> 4;
-      ROW_ADD(w0t, hidden, 5 + t1, 1.0f);
-      if (t2 != t1) ROW_ADD(w0t, hidden, 5 + t2, 1.0f);
-      for (int i = 0; i < 6; ++i) { // boosts (battle.h:271-285): ratio * 1/4 (acc/eva 1/3)
-        const int st = (int)((((a3 >> (4 * i)) & 15) ^ 8) - 8);
-        static const float RATIO[13] = {25.0f / 100, 28.0f / 100, 33.0f / 100, 40.0f / 100, 50.0f / 100, 66.0f / 100, 1.0f,
-                                        15.0f / 10, 2.0f, 25.0f / 10, 3.0f, 35.0f / 10, 4.0f};
-        ROW_ADD(w0t, hidden, 20 + i, RATIO[st + 6] * (i < 4 ? 0.25f : (float)(1 / 3.0)));
-      }
-      // volatiles (battle.h:322-352): 16 flags then state / sub hp / toxic counter
-      const uint32_t flagbits[16] = {0, 1, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17};
-      for (int i = 0; i < 16; ++i)
-        if ((vlo >> flagbits[i]) & 1) ROW_ADD(w0t, hidden, 26 + i, 1.0f);
-      const uint32_t state = (vlo >> 24) | ((vhi & 0xFF) << 8), sub = (vhi >> 8) & 0xFF, tox = vhi >> 27;
-      if (state) ROW_ADD(w0t, hidden, 26 + 16, (float)state / 65535.0f);
-      if (sub) ROW_ADD(w0t, hidden, 26 + 17, (float)sub / 177.0f);
-      if (tox) ROW_ADD(w0t, hidden, 26 + 18, (float)tox / 16.0f);
-      const uint32_t mv[4] = {m01 & 0xFFFF, m01 >> 16, m23 & 0xFFFF, m23 >> 16};
-      for (int m = 0; m < 4; ++m) {
-        const uint32_t mid = mv[m] & 0xFF, pp = mv[m] >> 8;
-        if (mid != 0 && mid != 165 && pp != 0) ROW_ADD(w0t, hidden, 45 + mid - 1, 1.0f);
-      }
-      const uint32_t dc = (dur >> 18) & 7, dd = (dur >> 21) & 15, da = (dur >> 25) & 7, db = (dur >> 28) & 7;
-      if (dc) ROW_ADD(w0t, hidden, 209 + dc - 1, 1.0f);
-      if (dd) ROW_ADD(w0t, hidden, 214 + dd - 1, 1.0f);
-      if (da) ROW_ADD(w0t, hidden, 222 + da - 1, 1.0f);
-      if (db) ROW_ADD(w0t, hidden, 225 + db - 1, 1.0f);
-      POKEMON_FEATURES(w0t, hidden, pk0, pk1, pk2, pk3, pk4, pk5, dur & 7, 229);
-      w1t = a_w1t;
-    } else {
-      hidden = N.p_hidden;
-      h0 = c0 < hidden ? N.p_b0[c0] : 0.0f;
-      h1 = c1 < hidden ? N.p_b0[c1] : 0.0f;
-      const float *w0t = N.p_w0t;
-      POKEMON_FEATURES(w0t, hidden, pk0, pk1, pk2, pk3, pk4, pk5, (dur >> (3 * slot)) & 7, 0);
-      w1t = p_w1t;
+    // 1. sparse feature list: lane j evaluates feature j
+    uint32_t fidx = 0;
+    float fval = 0.0f;
+    bool valid = false;
+    if (is_active) {
+      const uint32_t *ac = sb + 36; // active block at byte 144
+      if (lane < 40) valid = active_feature(lane, ac[0], ac[1], ac[2], ac[3], ac[4], ac[5], ac[6], ac[7], dur, fidx, fval);
+      else if (lane < 52) { valid = pokemon_feature(lane - 40, pk0, pk1, pk2, pk3, pk4, pk5, dur & 7, fidx, fval); fidx += 229; }
+    } else if (lane < 12) {
+      valid = pokemon_feature(lane, pk0, pk1, pk2, pk3, pk4, pk5, (dur >> (3 * slot)) & 7, fidx, fval);
     }
-    h0 = act_fn(h0, N.activation);
-    h1 = act_fn(h1, N.activation);
-    // dense second layer: out[o] = b1[o] + sum_c W1t[c][o] * h[c]; h[c] broadcast by readlane
-    const float *b1 = slot == 0 ? N.a_b1 : N.p_b1;
-    const int oa = lane, ob = lane + 64;
-    float ya = oa < out_dim ? b1[oa] : 0.0f, yb = ob < out_dim ? b1[ob] : 0.0f;
-    const int nlo = hidden < 64 ? hidden : 64;
-    for (int c = 0; c < nlo; ++c) {
-      const float hc = __shfl(h0, c, 64);
-      if (oa < out_dim) ya = fmaf(w1t[c * out_dim + oa], hc, ya);
-      if (ob < out_dim) yb = fmaf(w1t[c * out_dim + ob], hc, yb);
+    const uint64_t mask = __ballot(valid);
+    const uint32_t count = (uint32_t)__popcll(mask);
+    list_idx[lane] = 0; // padding entries: row 0 with weight 0
+    list_val[lane] = 0.0f;
+    if (valid) {
+      const uint32_t pos = (uint32_t)__popcll(mask & ((1ull << lane) - 1));
+      list_idx[pos] = fidx;
+      list_val[pos] = fval;
     }
-    for (int c = 64; c < hidden; ++c) {
-      const float hc = __shfl(h1, c - 64, 64);
-      if (oa < out_dim) ya = fmaf(w1t[c * out_dim + oa], hc, ya);
-      if (ob < out_dim) yb = fmaf(w1t[c * out_dim + ob], hc, yb);
+    // 2. first layer: h = b0 + sum_k W0t[idx_k][:] * val_k, 4 rows (8 loads) in flight
+    const uint32_t hidden = is_active ? N.a_hidden : N.p_hidden;
+    const float *w0t = is_active ? N.a_w0t : N.p_w0t;
+    const float *b0 = is_active ? N.a_b0 : N.p_b0;
+    const bool on0 = c0 < hidden, on1 = c1 < hidden;
+    float h0 = on0 ? b0[c0] : 0.0f, h1 = on1 ? b0[c1] : 0.0f;
+    const uint32_t cc0 = on0 ? c0 : 0, cc1 = on1 ? c1 : 0;
+    for (uint32_t k = 0; k < count; k += 4) {
+      const uint4 iv = *(const uint4 *)(list_idx + k);
+      const float4 vv = *(const float4 *)(list_val + k);
+      const float *r0 = w0t + (size_t)iv.x * hidden, *r1 = w0t + (size_t)iv.y * hidden, *r2 = w0t + (size_t)iv.z * hidden,
+                  *r3 = w0t + (size_t)iv.w * hidden;
+      const float x00 = r0[cc0], x01 = r0[cc1], x10 = r1[cc0], x11 = r1[cc1], x20 = r2[cc0], x21 = r2[cc1], x30 = r3[cc0], x31 = r3[cc1];
+      h0 = fmaf(x00, vv.x, h0); h1 = fmaf(x01, vv.x, h1);
+      h0 = fmaf(x10, vv.y, h0); h1 = fmaf(x11, vv.y, h1);
+      h0 = fmaf(x20, vv.z, h0); h1 = fmaf(x21, vv.z, h1);
+      h0 = fmaf(x30, vv.w, h0); h1 = fmaf(x31, vv.w, h1);
+    }
+    hbuf[c0] = on0 ? act_fn(h0, N.activation) : 0.0f;
+    hbuf[c1] = on1 ? act_fn(h1, N.activation) : 0.0f;
+    // 3. dense second layer: out[o] = b1[o] + sum_c W1t[c][o] * h[c]; h broadcast from LDS
+    const float *w1t = is_active ? a_w1t : p_w1t;
+    const float *b1 = is_active ? N.a_b1 : N.p_b1;
+    const uint32_t oa = lane, ob = lane + 64;
+    const bool ona = oa < out_dim, onb = ob < out_dim;
+    const uint32_t oca = ona ? oa : 0, ocb = onb ? ob : 0;
+    float ya = ona ? b1[oa] : 0.0f, yb = onb ? b1[ob] : 0.0f;
+    for (uint32_t c = 0; c < hidden; c += 4) {
+      const float4 hv = *(const float4 *)(hbuf + c);
+      const float *w = w1t + c * out_dim;
+      ya = fmaf(w[oca], hv.x, ya);                 yb = fmaf(w[ocb], hv.x, yb);
+      ya = fmaf(w[out_dim + oca], hv.y, ya);       yb = fmaf(w[out_dim + ocb], hv.y, yb);
+      ya = fmaf(w[2 * out_dim + oca], hv.z, ya);   yb = fmaf(w[2 * out_dim + ocb], hv.z, yb);
+      ya = fmaf(w[3 * out_dim + oca], hv.w, ya);   yb = fmaf(w[3 * out_dim + ocb], hv.w, yb);
     }
     if (lane == 0) dst[0] = (float)hp / (float)(pk0 & 0xFFFF);
-    if (oa < out_dim) dst[1 + oa] = act_fn(ya, N.activation);
-    if (ob < out_dim) dst[1 + ob] = act_fn(yb, N.activation);
+    if (ona) dst[1 + oa] = act_fn(ya, N.activation);
+    if (onb) dst[1 + ob] = act_fn(yb, N.activation);
   }
 }
 
@@ -498,7 +546,7 @@ int oakgpu_leaf_eval_dev(oakgpu_ctx *ctx, oakgpu_net *net, const uint8_t *battle
   }
   const oak::NetDev &D = net->dev;
   oak::EmbedArgs ea{D, battles, durations, n, emb};
-  const size_t emb_lds = (size_t)(D.p_hidden * D.p_out + D.a_hidden * D.a_out) * 4;
+  const size_t emb_lds = (size_t)(D.p_hidden * D.p_out + D.a_hidden * D.a_out + 4 * 256) * 4;
   uint32_t waves_needed = n * 12;
   uint32_t grid = (waves_needed + 3) / 4;
   if (grid > 256 * 8) grid = 256 * 8;

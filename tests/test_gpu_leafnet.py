@@ -67,3 +67,30 @@ def test_bad_network_files_raise(gpu_ctx, tmp_path):
         Network(gpu_ctx, data=good[:-5])          # truncated
     with pytest.raises(OakGpuError):
         Network(gpu_ctx, data=good + b"\x00")      # trailing byte (network.h:60-63)
+
+
+def test_config3_rollout_with_leaf_eval_every_turn(gpu_ctx, tmp_path):
+    """BASELINE config 3 at test size: after EVERY turn-step run value_inference on the new state.
+    GPU: rollout(max_steps=1) + leaf eval per turn; oracle: update + numpy network per turn."""
+    from oak_amd.engine import Network
+    path = str(tmp_path / "c3.battle.net")
+    NN.write_random_net(path, hidden=256, value_hidden=256, seed=11)
+    net = Network(gpu_ctx, path=path)
+    onet = NN.Net(path)
+    n, turns = 96, 30
+    b, d, p, r = O.make_random_ou_batch(n, seed0=0xFACE0000)
+    gb, gd, gp, gr = b.copy(), d.copy(), p.copy(), r.copy()
+    worst = 0.0
+    for t in range(turns):
+        got = gpu_ctx.rollout(gb, gd, gr, gp, max_steps=1, return_state=True)
+        gb, gd, gp, gr = got["battles"], got["durations"], got["prng"], got["results"]
+        vals = net.value_inference(gb, gd)
+        out, steps = O.rollout_batch(b, d, r, p, max_steps=1)      # in place on b, d, p
+        r = out
+        assert (gb == b).all() and (gd == d).all() and (gr == r).all(), t
+        for i in range(0, n, 7):
+            if int(r[i]) & 15:
+                continue
+            worst = max(worst, abs(float(vals[i]) - float(NN.value_inference(onet, b[i], d[i]))))
+    assert worst <= TOL, worst
+    net.close()

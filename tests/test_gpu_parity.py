@@ -138,3 +138,38 @@ def test_known_answer_positions_on_gpu(gpu_ctx):
         res = result_from_state(b)
         got = gpu_ctx.rollout(np.tile(b, (n, 1)), np.tile(d, (n, 1)), np.full(n, res, np.uint8), prng, prep=True)
         assert abs(float(got["values"].mean()) - expected) <= err + 1e-9, (pos, got["values"].mean())
+
+
+def test_root_parallel_prep_bit_exact(gpu_ctx):
+    """BASELINE config 4 shape at test size: R roots x P replicas, each replica re-seeded and its hidden
+    counters resampled on the device (mcts.h:250-263 + durations.h:25-97), then rolled out."""
+    roots, reps = 24, 96
+    b, d, p, r = O.make_random_ou_batch(roots, seed0=0xC0FFEE00)
+    # advance the roots so that sleep / confusion / disable / binding durations are live
+    O.rollout_batch(b, d, r, p, max_steps=12, threads=2)
+    r = np.array([O.LIB.oracle_result_from_state(O.ptr(b[i])) for i in range(roots)], dtype=np.uint8)
+    keep = (r & 15) == 0
+    b, d, r = b[keep], d[keep], r[keep]
+    n = b.shape[0] * reps
+    B, D, R = np.repeat(b, reps, axis=0), np.repeat(d, reps, axis=0), np.repeat(r, reps)
+    prng = _seed_prng(n, 0xABCDEF)
+    got = gpu_ctx.rollout(B, D, R, prng, max_steps=1000, prep=True, return_state=True)
+    ob, od, op = B.copy(), D.copy(), prng.copy()
+    oout, osteps = O.rollout_batch(ob, od, R, op, max_steps=1000, prep=True, threads=8)
+    assert (got["steps"] == osteps).all() and (got["results"] == oout).all()
+    assert (got["battles"] == ob).all() and (got["durations"] == od).all() and (got["prng"] == op).all()
+    per_root = got["values"].reshape(-1, reps).mean(axis=1)
+    assert ((per_root >= 0) & (per_root <= 1)).all()
+
+
+def test_queue_refill_matches_plain_launch(gpu_ctx):
+    """k_rollout_queue (persistent lanes refilled from an atomic playout queue) == one lane per playout."""
+    n = 3000
+    b, d, p, r = O.make_random_ou_batch(n, seed0=0x51515151)
+    plain = gpu_ctx.rollout(b, d, r, p, max_steps=1000, return_state=True)
+    for k in (2, 5, 64):
+        gpu_ctx.set_playouts_per_lane(k)
+        q = gpu_ctx.rollout(b, d, r, p, max_steps=1000, return_state=True)
+        for key in ("results", "steps", "values", "battles", "durations", "prng"):
+            assert (q[key] == plain[key]).all(), (k, key)
+    gpu_ctx.set_playouts_per_lane(1)
