@@ -16,6 +16,13 @@ SYMBOLS = [
     "oakgpu_leaf_eval_dev", "oakgpu_leaf_eval",
 ]
 
+# include/pkmn.h: the libpkmn-named single-battle ABI (batch-of-one wrappers, pkmn_shim.hip)
+PKMN_SYMBOLS = [
+    "pkmn_gen1_battle_update", "pkmn_gen1_battle_choices", "pkmn_gen1_battle_options_set",
+    "pkmn_gen1_battle_options_chance_actions", "pkmn_gen1_battle_options_chance_durations",
+    "pkmn_result_type", "pkmn_result_p1", "pkmn_result_p2",
+]
+
 _lib = None
 
 

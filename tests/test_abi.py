@@ -18,6 +18,11 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
     for name in declared:
         assert getattr(lib, name) is not None, name
+    pk = open(os.path.join(ROOT, "include", "pkmn.h")).read()
+    pk_declared = set(re.findall(r"\b(pkmn_(?:gen1_battle|result)_[a-z0-9_]+)\s*\(", pk))
+    assert pk_declared == set(_lib.PKMN_SYMBOLS), pk_declared ^ set(_lib.PKMN_SYMBOLS)
+    for name in pk_declared:
+        assert getattr(lib, name) is not None, name
 
 
 def test_no_gpu_means_loud_failure():

@@ -173,3 +173,44 @@ def test_queue_refill_matches_plain_launch(gpu_ctx):
         for key in ("results", "steps", "values", "battles", "durations", "prng"):
             assert (q[key] == plain[key]).all(), (k, key)
     gpu_ctx.set_playouts_per_lane(1)
+
+
+def test_libpkmn_named_single_battle_abi(gpu_ctx):
+    """include/pkmn.h: pkmn_gen1_battle_update / _choices / _options_* as batches of one on the GPU,
+    driven exactly like the reference's rollout loop (mcts.h:448-496) and compared with the oracle."""
+    import ctypes as C
+    from oak_amd import _lib
+    lib = _lib.load()
+
+    class Options(C.Structure):
+        _fields_ = [("actions", C.c_uint8 * 16), ("durations", C.c_uint8 * 8), ("overrides", C.c_uint8 * 16), ("has", C.c_uint8)]
+    lib.pkmn_gen1_battle_update.restype = C.c_uint8
+    lib.pkmn_gen1_battle_update.argtypes = [C.c_void_p, C.c_uint8, C.c_uint8, C.c_void_p]
+    lib.pkmn_gen1_battle_choices.restype = C.c_uint8
+    lib.pkmn_gen1_battle_choices.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t]
+    lib.pkmn_gen1_battle_options_set.argtypes = [C.c_void_p] * 4
+    lib.pkmn_result_type.restype = C.c_int
+    lib.pkmn_result_type.argtypes = [C.c_uint8]
+    b, d, p, r = O.make_random_ou_batch(3, seed0=0xBEEF)
+    rng = np.random.default_rng(1)
+    for i in range(3):
+        gb = b[i].copy()
+        opt, oopt = Options(), O.Options()
+        res = ores = int(r[i])
+        out = (C.c_uint8 * 9)()
+        for _ in range(40):
+            if lib.pkmn_result_type(res) != 0:
+                break
+            picks = []
+            for pl in (0, 1):
+                req = (res >> (4 + 2 * pl)) & 3
+                n = lib.pkmn_gen1_battle_choices(O.ptr(gb), pl, req, out, 9)
+                oc = O.choices(b[i], pl, req)
+                assert n == len(oc) and list(out[:n]) == list(oc)
+                picks.append(int(oc[rng.integers(n)]))
+            lib.pkmn_gen1_battle_options_set(C.byref(opt), None, None, None)
+            res = lib.pkmn_gen1_battle_update(O.ptr(gb), picks[0], picks[1], C.byref(opt))
+            oopt.set()
+            ores = O.update(b[i], picks[0], picks[1], oopt)
+            assert res == ores and (gb == b[i]).all()
+            assert bytes(opt.durations) == oopt.durations.tobytes() and bytes(opt.actions) == oopt.actions.tobytes()
