@@ -67,8 +67,9 @@ struct Tables {
   const lds_u32 *sp1;    // [152]
   const lds_u8 *chart;   // [225]
   const lds_u16 *boost;  // [13] num | den<<8
+  const lds_u32 *rcp;    // [256] floor((2^32-1)/d) + 1: exact x / d by one mul-hi for x < 2^24, d in 2..255
 };
-static constexpr int TABLE_LDS_BYTES = 166 * 4 + 168 + 152 * 4 + 152 * 4 + 228 + 28;
+static constexpr int TABLE_LDS_BYTES = 166 * 4 + 168 + 152 * 4 + 152 * 4 + 228 + 28 + 256 * 4;
 
 // copies the packed table images into LDS; call with all threads of the workgroup, then barrier
 __device__ inline Tables stage_tables(lds_u8 *lds, const uint32_t *g_mv, const uint8_t *g_pp, const uint32_t *g_sp0,
@@ -79,11 +80,13 @@ __device__ inline Tables stage_tables(lds_u8 *lds, const uint32_t *g_mv, const u
   lds_u32 *sp1 = sp0 + 152;
   lds_u8 *chart = (lds_u8 *)(sp1 + 152);
   lds_u16 *boost = (lds_u16 *)(chart + 228);
+  lds_u32 *rcp = (lds_u32 *)(chart + 228 + 28);
+  for (int i = threadIdx.x; i < 256; i += blockDim.x) rcp[i] = i ? 0xFFFFFFFFu / (uint32_t)i + 1u : 0u;
   for (int i = threadIdx.x; i < 166; i += blockDim.x) { mv[i] = g_mv[i]; pp[i] = g_pp[i]; }
   for (int i = threadIdx.x; i < 152; i += blockDim.x) { sp0[i] = g_sp0[i]; sp1[i] = g_sp1[i]; }
   for (int i = threadIdx.x; i < 225; i += blockDim.x) chart[i] = g_chart[i];
   for (int i = threadIdx.x; i < 13; i += blockDim.x) boost[i] = g_boost[i];
-  Tables t{mv, pp, sp0, sp1, chart, boost};
+  Tables t{mv, pp, sp0, sp1, chart, boost, rcp};
   return t;
 }
 

@@ -172,9 +172,18 @@ struct EngineR {
   __device__ __forceinline__ Move move_data(uint32_t id) const { return Move{T.mv[id]}; }
   __device__ __forceinline__ uint32_t chart(uint32_t atk_type, uint32_t def_type) const { return T.chart[atk_type * 15 + def_type]; }
   static __device__ __forceinline__ bool has_type(uint32_t ty, uint32_t t) { return (ty & 15) == t || (ty >> 4) == t; }
+  // Variable integer division costs ~40 VALU on gfx950; the engine's divisors are tiny, so use one mul-hi
+  // against the LDS reciprocal table instead (exact for x < 2^24, d <= 255; see gen1_device.hpp).
+  __device__ __forceinline__ uint32_t fast_div24(uint32_t x, uint32_t d) const { return d == 1 ? x : __umulhi(x, T.rcp[d]); }
+  __device__ __forceinline__ uint32_t fast_mod(uint32_t x, uint32_t n) const { // any 32-bit x, n in 1..255
+    if (n == 1) return 0;
+    uint32_t r = x - __umulhi(x, T.rcp[n]) * n; // quotient estimate is exact or one too large
+    return (int32_t)r < 0 ? r + n : r;
+  }
   __device__ __forceinline__ uint32_t scale_boost(uint32_t x, int stage) const {
-    uint32_t b = T.boost[stage + 6];
-    return x * (b & 0xFF) / (b >> 8);
+    if (stage == 0) return x;
+    const uint32_t b = T.boost[stage + 6], v = x * (b & 0xFF), den = b >> 8; // den is 100, 10 or 1
+    return den == 100 ? v / 100 : den == 10 ? v / 10 : v;
   }
 
   // unmodified (party) stat idx of side x; through Transform this is the copied Pokemon's stat (LDS)
@@ -399,8 +408,8 @@ struct EngineR {
     if (def == 0) return false;
     uint32_t d = (lvl * 2 / 5) + 2;
     d *= bp;
-    d *= atk;
-    d /= def;
+    d *= atk;                 // <= 206 * 255 * 255 < 2^24
+    d = fast_div24(d, def);   // def in 1..255 here
     d /= 50;
     if (d > 997) d = 997;
     d += 2;
@@ -1078,55 +1087,56 @@ struct EngineR {
     if constexpr (TRACK_ACTIONS) { uint64_t t = flipped ? actF : actS; actF = flipped ? actS : actF; actS = t; }
   }
 
-  // ---- pkmn_gen1_battle_update; expects and leaves the normalised frame ---------------------------
-  __device__ uint32_t update(uint32_t c1, uint32_t c2) {
+  // ---- pkmn_gen1_battle_update in FRAME terms: cS / cF are the choices of whoever currently sits in S / F
+  // (absp() tells which player that is).  The frame is left wherever the turn ends -- callers that need
+  // S = P1 call normalize().  Skipping the per-turn normalisation saves a 54-instruction conditional swap.
+  __device__ uint32_t update_frame(uint32_t cS, uint32_t cF) {
     if constexpr (TRACK_ACTIONS) { actS = 0; actF = 0; }
     if (turn == 0) {
-      const bool a1 = (S.misc & 63) != 0, a2 = (F.misc & 63) != 0;
-      if (!a1) return mk_result(a2 ? R_LOSE : R_TIE, 0, 0);
-      if (!a2) return mk_result(R_WIN, 0, 0);
+      const bool aS = (S.misc & 63) != 0, aF = (F.misc & 63) != 0;
+      const bool s_p1 = absp(S) == 0;
+      if (!aS) return mk_result(aF ? (s_p1 ? R_LOSE : R_WIN) : R_TIE, 0, 0);
+      if (!aF) return mk_result(s_p1 ? R_WIN : R_LOSE, 0, 0);
 #pragma unroll 1
       for (int k = 0; k < 2; ++k) { switch_in(S, F, 1); swap_sides(S, F); } // both leads, one copy of the code
       return end_turn();
     }
-    select_move(S, c1);
-    select_move(F, c2);
-    // turn order (S = P1, F = P2 here)
-    bool p2_first;
+    select_move(S, cS);
+    select_move(F, cF);
+    bool f_first;
     {
-      const uint32_t t1 = c1 & 3, t2 = c2 & 3;
-      if (t1 == C_PASS) p2_first = true;
-      else if (t2 == C_PASS) p2_first = false;
-      else if ((t1 == C_SWITCH) != (t2 == C_SWITCH)) p2_first = t1 != C_SWITCH;
+      const uint32_t tS = cS & 3, tF = cF & 3;
+      if (tS == C_PASS) f_first = true;
+      else if (tF == C_PASS) f_first = false;
+      else if ((tS == C_SWITCH) != (tF == C_SWITCH)) f_first = tS != C_SWITCH;
       else {
-        const uint32_t m1 = last_sel(S), m2 = last_sel(F);
+        const uint32_t mS = last_sel(S), mF = last_sel(F);
         bool decided = false;
-        p2_first = false;
-        if (t1 == C_MOVE) {
-          if ((m1 == M_QuickAttack) != (m2 == M_QuickAttack)) { p2_first = m1 != M_QuickAttack; decided = true; }
-          else if ((m1 == M_Counter) != (m2 == M_Counter)) { p2_first = m1 == M_Counter; decided = true; }
+        f_first = false;
+        if (tS == C_MOVE) {
+          if ((mS == M_QuickAttack) != (mF == M_QuickAttack)) { f_first = mS != M_QuickAttack; decided = true; }
+          else if ((mS == M_Counter) != (mF == M_Counter)) { f_first = mS == M_Counter; decided = true; }
         }
         if (!decided) {
-          const uint32_t s1 = spe(S), s2 = spe(F);
-          if (s1 == s2) {
-            const bool p1 = rng_range(0, 2) == 0;
+          const uint32_t sS = spe(S), sF = spe(F);
+          if (sS == sF) {
+            const bool p1 = rng_range(0, 2) == 0; // P1 moves first on 0
             act_set(true, AC_SPEEDTIE, 2, p1 ? 1 : 2);
             act_set(false, AC_SPEEDTIE, 2, p1 ? 1 : 2);
-            p2_first = !p1;
-          } else p2_first = s1 < s2;
+            f_first = p1 != (absp(S) == 0);
+          } else f_first = sS < sF;
         }
       }
     }
-    uint32_t pc = p2_first ? c2 : c1, qc = p2_first ? c1 : c2;
-    cswap_sides(p2_first, S, F);
-    if constexpr (TRACK_ACTIONS) { uint64_t t = p2_first ? actF : actS; actF = p2_first ? actS : actF; actS = t; }
-    uint32_t result = 0;
+    uint32_t pc = f_first ? cF : cS, qc = f_first ? cS : cF;
+    cswap_sides(f_first, S, F);
+    if constexpr (TRACK_ACTIONS) { uint64_t t = f_first ? actF : actS; actF = f_first ? actS : actF; actS = t; }
 #pragma unroll 1
     for (int k = 0; k < 2; ++k) {
       bool err = false;
       const bool replace = hp(S) == 0;
       const bool residual = execute_move(pc, err);
-      if (err) { result = mk_result(R_ERROR, 0, 0); break; }
+      if (err) return mk_result(R_ERROR, 0, 0);
       if (!replace) {
         uint32_t r = 0;
         if ((pc & 3) != C_SWITCH) r = check_faint(F, S);
@@ -1134,18 +1144,94 @@ struct EngineR {
           if (residual) handle_residual();
           r = check_faint(S, F);
         }
-        if (r) { result = r; break; }
+        if (r) return r;
       }
       if ((qc & 3) == C_PASS) break;
       swap_sides(S, F);
       if constexpr (TRACK_ACTIONS) { uint64_t t = actS; actS = actF; actF = t; }
       uint32_t t = pc; pc = qc; qc = t;
     }
-    normalize();
-    if (result) return result;
     if ((S.vlo & V_BINDING) && attacks(S) == 0) clear_binding(S);
     if ((F.vlo & V_BINDING) && attacks(F) == 0) clear_binding(F);
     return end_turn();
+  }
+  // normalised-frame form (S = P1, F = P2 before and after)
+  __device__ __forceinline__ uint32_t update(uint32_t c1, uint32_t c2) {
+    const uint32_t r = update_frame(c1, c2);
+    normalize();
+    return r;
+  }
+
+  // ---- pkmn_gen1_battle_choices from registers, as (count, k-th choice) instead of a materialised list:
+  // the rollout only ever needs `choices[seed % n]`.  Order = the reference's: switches by slot, then moves.
+  struct Legal { uint32_t n, sw, mv, forced; }; // sw: bit s-2 for party position s; mv: bit i-1 for move slot i
+  __device__ __forceinline__ Legal legal(const SideR &x, uint32_t request) const {
+    const uint32_t sw = (x.misc >> 1) & 31;
+    if (request == C_PASS) return Legal{1, 0, 0, 0};
+    if (request == C_SWITCH) {
+      const uint32_t n = (uint32_t)__popc(sw);
+      return n ? Legal{n, sw, 0, 0} : Legal{1, 0, 0, 0};
+    }
+    if (x.vlo & (V_RECHARGING | V_RAGE | V_THRASHING | V_CHARGING)) return Legal{1, 0, 0, C_MOVE};
+    const uint64_t am = amoves(x);
+    if (x.vlo & (V_BIDE | V_BINDING)) {
+      const uint32_t sel = last_sel(x);
+      uint32_t forced = C_MOVE;
+#pragma unroll
+      for (int i = 3; i >= 0; --i) {
+        const uint32_t id = (uint32_t)(am >> (16 * i)) & 0xFF;
+        if (id != 0 && id == sel) forced = ((uint32_t)(i + 1) << 2) | C_MOVE;
+      }
+      return Legal{1, 0, 0, forced};
+    }
+    const uint32_t dm = disable_move(x);
+    uint32_t mv = 0;
+    bool open = true;
+#pragma unroll
+    for (uint32_t i = 0; i < 4; ++i) {
+      const uint32_t ms = (uint32_t)(am >> (16 * i)) & 0xFFFF;
+      open = open && (ms & 0xFF) != 0;
+      mv |= (open && (ms >> 8) != 0 && dm != i + 1 ? 1u : 0u) << i;
+    }
+    const uint32_t nm = (uint32_t)__popc(mv);
+    return Legal{(uint32_t)__popc(sw) + (nm ? nm : 1u), sw, mv, C_MOVE}; // no usable move: Struggle (move, data 0)
+  }
+  static __device__ __forceinline__ uint32_t kth_bit(uint32_t mask, uint32_t k) { // index of the k-th set bit (mask < 32)
+    uint32_t idx = 0, seen = 0;
+#pragma unroll
+    for (uint32_t b = 0; b < 5; ++b) {
+      const uint32_t bit = (mask >> b) & 1;
+      idx = (bit && seen == k) ? b : idx;
+      seen += bit;
+    }
+    return idx;
+  }
+  __device__ __forceinline__ uint32_t nth_choice(const Legal &L, uint32_t r) const {
+    if (L.n == 1 && L.sw == 0 && L.mv == 0) return L.forced;
+    const uint32_t nsw = (uint32_t)__popc(L.sw);
+    if (r < nsw) return ((kth_bit(L.sw, r) + 2) << 2) | C_SWITCH;
+    if (L.mv == 0) return C_MOVE;
+    return ((kth_bit(L.mv, r - nsw) + 1) << 2) | C_MOVE;
+  }
+  // the reference's draw (mcts.h:452-476): P1 takes seed % m on the 64-bit seed, P2 (seed >> 32) % n
+  __device__ __forceinline__ uint32_t draw_index(bool is_p1, uint32_t hi, uint32_t lo, uint32_t n) const {
+    if (n == 1) return 0;
+    uint32_t a = fast_mod(hi, n);
+    if (is_p1) {
+      uint32_t two32 = fast_mod(0xFFFFFFFFu, n) + 1; // 2^32 mod n
+      two32 = two32 == n ? 0 : two32;
+      a = fast_mod(a * two32 + fast_mod(lo, n), n);
+    }
+    return a;
+  }
+  // one random-policy turn-step of the rollout (choices x2 + update), frame-agnostic
+  __device__ __forceinline__ uint32_t random_step(uint32_t result, uint32_t hi, uint32_t lo) {
+    const bool s_p1 = absp(S) == 0;
+    const uint32_t req1 = (result >> 4) & 3, req2 = (result >> 6) & 3;
+    const Legal LS = legal(S, s_p1 ? req1 : req2), LF = legal(F, s_p1 ? req2 : req1);
+    const uint32_t cS = nth_choice(LS, draw_index(s_p1, hi, lo, LS.n));
+    const uint32_t cF = nth_choice(LF, draw_index(!s_p1, hi, lo, LF.n));
+    return update_frame(cS, cF);
   }
 
   // ---- pkmn_gen1_battle_choices from registers (side x) -------------------------------------------

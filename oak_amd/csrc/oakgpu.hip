@@ -234,13 +234,10 @@ __global__ __launch_bounds__(BLK, 2) void k_rollout_regs(RolloutArgs a) {
   uint32_t steps = 0;
   while ((result & 15) == 0 && steps < a.max_steps) {
     const uint32_t hi = g.next32(), lo = g.next32(); // uniform_64 = hi << 32 | lo
-    const auto c1s = e.choices(e.S, (result >> 4) & 3);
-    const uint32_t c1 = c1s.get(mod64_small(hi, lo, c1s.n));
-    const auto c2s = e.choices(e.F, (result >> 6) & 3);
-    const uint32_t c2 = c2s.get(hi % c2s.n);
-    result = e.update(c1, c2);
+    result = e.random_step(result, hi, lo);
     ++steps;
   }
+  e.normalize();
   a.results_out[lane] = (uint8_t)result;
   a.steps_out[lane] = steps;
   const uint32_t t = result & 15;
@@ -260,8 +257,8 @@ __global__ __launch_bounds__(BLK, 2) void k_rollout_regs(RolloutArgs a) {
 // queue.  A lane that finishes its playout immediately starts the next unassigned one (wave ballot ->
 // one atomicAdd per wave -> prefix rank), so waves stay full instead of idling on their longest lane.
 // Results are indexed by playout, each playout owns its RNG streams: output is identical to k_rollout*.
-template <int BLK>
-__global__ __launch_bounds__(BLK, 2) void k_rollout_queue(RolloutArgs a, uint32_t *queue) {
+template <int BLK, int WPS>
+__global__ __launch_bounds__(BLK, WPS) void k_rollout_queue(RolloutArgs a, uint32_t *queue) {
   extern __shared__ __align__(16) uint8_t smem[];
   lds_u32 *party = (lds_u32 *)smem;
   using ER = EngineR<BLK, false>;
@@ -305,14 +302,11 @@ __global__ __launch_bounds__(BLK, 2) void k_rollout_queue(RolloutArgs a, uint32_
     if (idx != DONE) {
       if ((result & 15) == 0 && steps < a.max_steps) {
         const uint32_t hi = g.next32(), lo = g.next32(); // uniform_64 = hi << 32 | lo
-        const auto c1s = e.choices(e.S, (result >> 4) & 3);
-        const uint32_t c1 = c1s.get(mod64_small(hi, lo, c1s.n));
-        const auto c2s = e.choices(e.F, (result >> 6) & 3);
-        const uint32_t c2 = c2s.get(hi % c2s.n);
-        result = e.update(c1, c2);
+        result = e.random_step(result, hi, lo);
         ++steps;
       }
       if (!((result & 15) == 0 && steps < a.max_steps)) { // playout finished: publish and free the lane
+        e.normalize();
         a.results_out[idx] = (uint8_t)result;
         a.steps_out[idx] = steps;
         const uint32_t t = result & 15;
@@ -519,6 +513,7 @@ struct oakgpu_ctx {
   int rollout_block;  // threads per workgroup of the rollout kernel (64 or 256)
   int rollout_engine; // 2 = register-resident (default), 1 = LDS-resident
   int playouts_per_lane; // > 1: persistent grid of n / this lanes with queue refill (k_rollout_queue)
+  int waves_per_simd;    // register budget of the queue kernel: 2 (no spills), 3 or 4
   uint32_t *d_queue;
 };
 
@@ -552,7 +547,9 @@ static int set_lds_limits() {
   HIPCHK(hipFuncSetAttribute((const void *)oak::k_rollout<64>, hipFuncAttributeMaxDynamicSharedMemorySize, oak::STATE_WORDS * 64 * 4 + oak::TABLE_LDS_PAD));
   HIPCHK(hipFuncSetAttribute((const void *)oak::k_rollout_regs<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 24 * 128 * 4 + oak::TABLE_LDS_PAD));
   HIPCHK(hipFuncSetAttribute((const void *)oak::k_rollout_regs<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 24 * 64 * 4 + oak::TABLE_LDS_PAD));
-  HIPCHK(hipFuncSetAttribute((const void *)oak::k_rollout_queue<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 24 * 64 * 4 + oak::TABLE_LDS_PAD));
+  HIPCHK(hipFuncSetAttribute((const void *)oak::k_rollout_queue<64, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 24 * 64 * 4 + oak::TABLE_LDS_PAD));
+  HIPCHK(hipFuncSetAttribute((const void *)oak::k_rollout_queue<64, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 24 * 64 * 4 + oak::TABLE_LDS_PAD));
+  HIPCHK(hipFuncSetAttribute((const void *)oak::k_rollout_queue<64, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 24 * 64 * 4 + oak::TABLE_LDS_PAD));
   HIPCHK(hipFuncSetAttribute((const void *)oak::k_update, hipFuncAttributeMaxDynamicSharedMemorySize, oak::ENGINE_LDS_BYTES));
   HIPCHK(hipFuncSetAttribute((const void *)oak::k_choices, hipFuncAttributeMaxDynamicSharedMemorySize, oak::ENGINE_LDS_BYTES));
   HIPCHK(hipFuncSetAttribute((const void *)oak::k_init, hipFuncAttributeMaxDynamicSharedMemorySize, oak::ENGINE_LDS_BYTES));
@@ -578,6 +575,8 @@ int oakgpu_create(oakgpu_ctx **out, int device) {
   c->playouts_per_lane = 1;
   if (const char *env = getenv("OAKGPU_PLAYOUTS_PER_LANE")) c->playouts_per_lane = atoi(env) > 0 ? atoi(env) : 1;
   c->d_queue = nullptr;
+  c->waves_per_simd = 3; // measured best on MI355X: 168 VGPRs (a dozen cold spills) beats 2 waves without spills
+  if (const char *env = getenv("OAKGPU_WAVES_PER_SIMD")) c->waves_per_simd = atoi(env);
   c->rollout_engine = 2;
   if (const char *env = getenv("OAKGPU_ROLLOUT_ENGINE")) c->rollout_engine = atoi(env) == 1 ? 1 : 2;
   hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
@@ -640,7 +639,10 @@ int oakgpu_rollout_dev(oakgpu_ctx *c, const uint8_t *battles, const uint8_t *dur
     HIPCHK(hipMemsetAsync(c->d_queue, 0, 4, c->stream));
     uint32_t waves = ((n + 63) / 64 + c->playouts_per_lane - 1) / c->playouts_per_lane;
     if (waves < 1) waves = 1;
-    hipLaunchKernelGGL(oak::k_rollout_queue<64>, dim3(waves), dim3(64), 24 * 64 * 4 + oak::TABLE_LDS_PAD, c->stream, a, c->d_queue);
+    const size_t lq = 24 * 64 * 4 + oak::TABLE_LDS_PAD;
+    if (c->waves_per_simd >= 4) hipLaunchKernelGGL((oak::k_rollout_queue<64, 4>), dim3(waves), dim3(64), lq, c->stream, a, c->d_queue);
+    else if (c->waves_per_simd == 3) hipLaunchKernelGGL((oak::k_rollout_queue<64, 3>), dim3(waves), dim3(64), lq, c->stream, a, c->d_queue);
+    else hipLaunchKernelGGL((oak::k_rollout_queue<64, 2>), dim3(waves), dim3(64), lq, c->stream, a, c->d_queue);
   } else {                      // register-resident engine (gen1_regs.hpp): the default
     if (c->rollout_block == 64)
       hipLaunchKernelGGL(oak::k_rollout_regs<64>, dim3((n + 63) / 64), dim3(64), 24 * 64 * 4 + oak::TABLE_LDS_PAD, c->stream, a);
