@@ -73,7 +73,8 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    force_dist = bool(os.environ.get("BENCH_FORCE_DIST"))   # exercise the RCCL path with a single rank (tests)
+    if world > 1 or force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm
@@ -117,8 +118,8 @@ def main():
         def finish(self):
             with torch.cuda.stream(self.stream):
                 self.total += self.steps_out.sum(dtype=torch.int64)   # tiny reduction kernel, inside the timed region
-                if world > 1:   # the path's single exchange: one RCCL all-gather of the fp32 leaf values
-                    self.gathered = oakdist.gather_values(self.values, n * world)
+                if world > 1 or force_dist:   # the path's single exchange: one RCCL all-gather of the fp32 leaf values
+                    self.gathered = oakdist.gather_values(self.values, n * world, force=force_dist)
 
     slots = [Slot(i) for i in range(S)]
     torch.cuda.synchronize(dev)
@@ -218,7 +219,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(n)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or force_dist:
         dist.destroy_process_group()
 
 

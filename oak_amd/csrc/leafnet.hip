@@ -14,6 +14,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <string>
 #include <vector>
@@ -27,6 +28,7 @@ struct NetDev {
   // embedding nets: W0t [in][128-ish hidden] (transposed for row gathers), b0, W1t [hidden][out], b1
   const float *p_w0t, *p_b0, *p_w1t, *p_b1;
   const float *a_w0t, *a_b0, *a_w1t, *a_b1;
+  const float *p_w1, *a_w1; // second layers in file layout [out][hidden] (MFMA B operand of k_embed_tile)
   int p_hidden, p_out, a_hidden, a_out;
   int side_dim, emb_dim;
   int activation; // 1 relu, 2 clamp
@@ -246,8 +248,173 @@ __global__ __launch_bounds__(EMB_BLOCK) void k_embed(EmbedArgs a) {
   }
 }
 
-// ---- K3: main net on fp32 MFMA ------------------------------------------------------------------
 using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+// ---- K2, tiled form: 64 same-kind items (party slots or actives) per workgroup pass.
+// Phase 1 (per wave, 16 items): sparse feature list -> gather-add of W0^T rows (8 rows = 16 loads in
+// flight) -> activated hidden row into an LDS tile H[64][hidden].  Phase 2: H . W1^T on fp32 MFMA
+// (W1 staged once per workgroup in its file layout [out][hidden]).  Phase 3: bias + activation + scatter
+// into the battle embedding.  The dense second layer is ~80% of the embedding FLOPs, so it belongs on
+// the matrix pipe; the sparse first layer stays a VALU gather.
+constexpr int ET = 64;          // items per tile
+constexpr int EHP = 129;        // padded LDS row (odd stride: conflict-free column reads)
+struct EmbedTileArgs {
+  NetDev net;
+  const uint8_t *battles;
+  const uint8_t *durations;
+  uint32_t n;
+  float *emb;
+  int kind; // 0: party slots (10 per leaf), 1: actives (2 per leaf)
+};
+
+__global__ __launch_bounds__(EMB_BLOCK) void k_embed_tile(EmbedTileArgs a) {
+  extern __shared__ __align__(16) float lds_f[];
+  const NetDev &N = a.net;
+  const bool act_kind = a.kind == 1;
+  const int hidden = act_kind ? N.a_hidden : N.p_hidden;
+  const int out_dim = act_kind ? N.a_out : N.p_out;
+  const int out_pad = (out_dim + 31) & ~31;
+  const int NBo = out_pad / 32;
+  float *Hs = lds_f;                       // ET x EHP
+  float *Ws = Hs + ET * EHP;               // out_pad x EHP
+  float *scratch = Ws + out_pad * EHP;     // per wave 128 floats: idx list, val list
+  uint32_t *dst_off = (uint32_t *)(scratch + 4 * 128); // ET
+  float *hp_ratio = (float *)(dst_off + ET);           // ET
+  uint32_t *Bs = (uint32_t *)(hp_ratio + ET);          // staged battles of the tile's leaves: 98 dwords each
+  const float *W1 = act_kind ? N.a_w1 : N.p_w1;
+  for (int i = threadIdx.x; i < out_pad * 128; i += EMB_BLOCK) {
+    const int o = i >> 7, c = i & 127;
+    Ws[o * EHP + c] = (o < out_dim && c < hidden) ? W1[o * hidden + c] : 0.0f;
+  }
+  const uint32_t lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+  uint32_t *list_idx = (uint32_t *)(scratch + wib * 128);
+  float *list_val = scratch + wib * 128 + 64;
+  const uint32_t per_leaf = act_kind ? 2 : 10;
+  const uint32_t items = a.n * per_leaf;
+  const uint32_t ntiles = (items + ET - 1) / ET;
+  const float *w0t = act_kind ? N.a_w0t : N.p_w0t;
+  const float *b0 = act_kind ? N.a_b0 : N.p_b0;
+  const float *b1 = act_kind ? N.a_b1 : N.p_b1;
+  const uint32_t c0 = lane, c1 = lane + 64;
+  const bool on0 = (int)c0 < hidden, on1 = (int)c1 < hidden;
+  const uint32_t cc0 = on0 ? c0 : 0, cc1 = on1 ? c1 : 0;
+  for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    __syncthreads(); // previous tile fully consumed (also orders the one-time Ws staging)
+    // ---- phase 0: stage the battles this tile touches (<= ET_LEAVES leaves) with coalesced loads ----
+    const uint32_t first_leaf = (tile * ET) / per_leaf;
+    uint32_t last_leaf = (tile * ET + ET - 1) / per_leaf;
+    if (last_leaf >= a.n) last_leaf = a.n - 1;
+    const uint32_t nleaves = last_leaf - first_leaf + 1;
+    {
+      const uint32_t *gb = (const uint32_t *)a.battles + (size_t)first_leaf * 96;
+      const uint32_t *gd = (const uint32_t *)a.durations + (size_t)first_leaf * 2;
+      for (uint32_t i = threadIdx.x; i < nleaves * 96; i += EMB_BLOCK) { const uint32_t l = i / 96; Bs[l * 98 + (i - l * 96)] = gb[i]; }
+      for (uint32_t i = threadIdx.x; i < nleaves * 2; i += EMB_BLOCK) Bs[(i >> 1) * 98 + 96 + (i & 1)] = gd[i];
+    }
+    __syncthreads();
+    // ---- phase 1: this wave's 16 items ----
+    for (uint32_t ii = 0; ii < 16; ++ii) {
+      const uint32_t i = wib * 16 + ii;
+      const uint32_t g = tile * ET + i;
+      float *hrow = Hs + i * EHP;
+      if (g >= items) { if (lane == 0) dst_off[i] = 0xFFFFFFFFu; hrow[c0] = 0.0f; hrow[c1] = 0.0f; continue; }
+      const uint32_t leaf = g / per_leaf, q = g - leaf * per_leaf;
+      const uint32_t side = act_kind ? q : q / 5, slot = act_kind ? 0 : 1 + (q - side * 5);
+      const uint32_t *lb = Bs + (leaf - first_leaf) * 98;
+      const uint32_t *sb = lb + side * 46;
+      const uint32_t dur = lb[96 + side];
+      const uint32_t o0 = sb[44], o1 = sb[45];
+      const uint32_t id = slot < 4 ? (o0 >> (8 * slot)) & 0xFF : (o1 >> (8 * (slot - 4))) & 0xFF;
+      const uint32_t doff = leaf * N.emb_dim + side * N.side_dim + (act_kind ? 0 : (1 + N.a_out) + (slot - 1) * (1 + N.p_out));
+      uint32_t pk0 = 0, pk1 = 0, pk2 = 0, pk3 = 0, pk4 = 0, pk5 = 0, hp = 0;
+      if (id != 0) {
+        const uint32_t *pk = sb + 6 * (id - 1);
+        pk0 = pk[0]; pk1 = pk[1]; pk2 = pk[2]; pk3 = pk[3]; pk4 = pk[4]; pk5 = pk[5];
+        hp = pk4 >> 16;
+      }
+      if (hp == 0) { // empty or fainted: zero block now, and keep it out of phase 3
+        float *dst = a.emb + doff;
+        for (uint32_t o = lane; o < (uint32_t)out_dim + 1; o += 64) dst[o] = 0.0f;
+        if (lane == 0) dst_off[i] = 0xFFFFFFFFu;
+        hrow[c0] = 0.0f; hrow[c1] = 0.0f;
+        continue;
+      }
+      uint32_t fidx = 0;
+      float fval = 0.0f;
+      bool valid = false;
+      if (act_kind) {
+        const uint32_t *ac = sb + 36;
+        if (lane < 40) valid = active_feature(lane, ac[0], ac[1], ac[2], ac[3], ac[4], ac[5], ac[6], ac[7], dur, fidx, fval);
+        else if (lane < 52) { valid = pokemon_feature(lane - 40, pk0, pk1, pk2, pk3, pk4, pk5, dur & 7, fidx, fval); fidx += 229; }
+      } else if (lane < 12) {
+        valid = pokemon_feature(lane, pk0, pk1, pk2, pk3, pk4, pk5, (dur >> (3 * slot)) & 7, fidx, fval);
+      }
+      const uint64_t mask = __ballot(valid);
+      const uint32_t count = (uint32_t)__popcll(mask);
+      list_idx[lane] = 0;
+      list_val[lane] = 0.0f;
+      if (valid) {
+        const uint32_t pos = (uint32_t)__popcll(mask & ((1ull << lane) - 1));
+        list_idx[pos] = fidx;
+        list_val[pos] = fval;
+      }
+      float h0 = on0 ? b0[c0] : 0.0f, h1 = on1 ? b0[c1] : 0.0f;
+      for (uint32_t k = 0; k < count; k += 16) { // 16 rows = 32 independent loads in flight
+        uint32_t ix[16];
+        float vx[16], x0[16], x1[16];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const uint4 iv = *(const uint4 *)(list_idx + k + 4 * u);
+          const float4 vv = *(const float4 *)(list_val + k + 4 * u);
+          ix[4 * u] = iv.x; ix[4 * u + 1] = iv.y; ix[4 * u + 2] = iv.z; ix[4 * u + 3] = iv.w;
+          vx[4 * u] = vv.x; vx[4 * u + 1] = vv.y; vx[4 * u + 2] = vv.z; vx[4 * u + 3] = vv.w;
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) { const float *rr = w0t + (size_t)ix[u] * hidden; x0[u] = rr[cc0]; x1[u] = rr[cc1]; }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) { h0 = fmaf(x0[u], vx[u], h0); h1 = fmaf(x1[u], vx[u], h1); }
+      }
+      hrow[c0] = on0 ? act_fn(h0, N.activation) : 0.0f;
+      hrow[c1] = on1 ? act_fn(h1, N.activation) : 0.0f;
+      if (lane == 0) { dst_off[i] = doff; hp_ratio[i] = (float)hp / (float)(pk0 & 0xFFFF); }
+    }
+    __syncthreads();
+    // ---- phase 2: OUT[64][out_pad] = H[64][128] . W1^T on fp32 MFMA ----
+    const int mi = wib & 1, nb0 = wib >> 1, r = lane & 31, hh = lane >> 5;
+    f32x16 acc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[j][q] = 0.0f;
+    const float *arow = Hs + (mi * 32 + r) * EHP + hh;
+    const float *brow = Ws + (nb0 * 32 + r) * EHP + hh;
+#pragma unroll 16
+    for (int s = 0; s < 64; ++s) {
+      const float av = arow[2 * s];
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        if (nb0 + 2 * j < NBo) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, brow[j * 64 * EHP + 2 * s], acc[j], 0, 0, 0);
+    }
+    // ---- phase 3: bias + activation + scatter ----
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int nb = nb0 + 2 * j;
+      if (nb < NBo) {
+        const int o = nb * 32 + r;
+        const float bias = o < out_dim ? b1[o] : 0.0f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const int row = (q & 3) + 8 * (q >> 2) + 4 * hh;
+          const uint32_t doff = dst_off[mi * 32 + row];
+          if (o < out_dim && doff != 0xFFFFFFFFu) a.emb[(size_t)doff + 1 + o] = act_fn(acc[j][q] + bias, N.activation);
+        }
+      }
+    }
+    if (threadIdx.x < ET && dst_off[threadIdx.x] != 0xFFFFFFFFu) a.emb[dst_off[threadIdx.x]] = hp_ratio[threadIdx.x];
+  }
+}
+
+// ---- K3: main net on fp32 MFMA ------------------------------------------------------------------
 constexpr int MN_BLOCK = 256; // 4 waves
 constexpr int TM = 64;        // leaves per workgroup tile
 constexpr int KC = 32;        // K chunk staged per iteration
@@ -261,8 +428,13 @@ struct MainArgs {
   float *values;
 };
 
-// One dense layer for a TM x Hout tile: acc = A(TM x K) . W^T, A read through a_at(row, k).
-// A either comes from global (staged in xs per chunk) or from the LDS activation tile.
+// One dense layer for a TM x Hout tile: acc = A(TM x K) . W^T.
+// A comes either from global (X, staged per K-chunk into xs) or from the LDS activation tile.
+// Staging is software-pipelined: the NEXT chunk's global loads are issued into registers before the
+// MFMAs of the current chunk, so L2 latency hides behind the matrix pipe (one wave per SIMD here).
+constexpr int WREG = MAXH * (KC / 4) / MN_BLOCK; // float4 per thread per W chunk (8)
+constexpr int XREG = TM * (KC / 4) / MN_BLOCK;   // float4 per thread per X chunk (2)
+
 template <bool A_FROM_GLOBAL>
 __device__ __forceinline__ void dense_layer(const float *a_global, int a_ld, uint32_t row0, uint32_t n_rows, // global A
                                             const float *a_lds, int a_lds_ld,                               // LDS A
@@ -274,38 +446,54 @@ __device__ __forceinline__ void dense_layer(const float *a_global, int a_ld, uin
   for (int j = 0; j < 4; ++j)
 #pragma unroll
     for (int q = 0; q < 16; ++q) acc[j][q] = 0.0f;
+  float4 wreg[WREG], xreg[XREG];
+  auto prefetch = [&](int k0) {
+#pragma unroll
+    for (int u = 0; u < WREG; ++u) {
+      const int i = tid + u * MN_BLOCK, row = i / (KC / 4), q = i - row * (KC / 4);
+      wreg[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (row < Hout && k0 + 4 * q < K) wreg[u] = *(const float4 *)(W + (size_t)row * K + k0 + 4 * q);
+    }
+    if (A_FROM_GLOBAL) {
+#pragma unroll
+      for (int u = 0; u < XREG; ++u) {
+        const int i = tid + u * MN_BLOCK, row = i / (KC / 4), q = i - row * (KC / 4);
+        xreg[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if ((uint32_t)row < n_rows && k0 + 4 * q < K) xreg[u] = *(const float4 *)(a_global + (size_t)(row0 + row) * a_ld + k0 + 4 * q);
+      }
+    }
+  };
+  prefetch(0);
   for (int k0 = 0; k0 < K; k0 += KC) {
     __syncthreads(); // previous chunk fully consumed
-    if (A_FROM_GLOBAL) {
-      // X chunk: TM rows x KC floats; 8 threads per row, float4 each
-      for (int i = tid; i < TM * (KC / 4); i += MN_BLOCK) {
-        const int row = i / (KC / 4), q = i - row * (KC / 4);
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if ((uint32_t)row < n_rows && k0 + 4 * q < K) v = *(const float4 *)(a_global + (size_t)(row0 + row) * a_ld + k0 + 4 * q);
-        float *d = xs + row * KCP + 4 * q;
-        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
-      }
+#pragma unroll
+    for (int u = 0; u < WREG; ++u) {
+      const int i = tid + u * MN_BLOCK, row = i / (KC / 4), q = i - row * (KC / 4);
+      if (row < Hout) { float *d = ws + row * KCP + 4 * q; d[0] = wreg[u].x; d[1] = wreg[u].y; d[2] = wreg[u].z; d[3] = wreg[u].w; }
     }
-    for (int i = tid; i < Hout * (KC / 4); i += MN_BLOCK) {
-      const int row = i / (KC / 4), q = i - row * (KC / 4);
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (k0 + 4 * q < K) v = *(const float4 *)(W + (size_t)row * K + k0 + 4 * q);
-      float *d = ws + row * KCP + 4 * q;
-      d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    if (A_FROM_GLOBAL) {
+#pragma unroll
+      for (int u = 0; u < XREG; ++u) {
+        const int i = tid + u * MN_BLOCK, row = i / (KC / 4), q = i - row * (KC / 4);
+        float *d = xs + row * KCP + 4 * q; d[0] = xreg[u].x; d[1] = xreg[u].y; d[2] = xreg[u].z; d[3] = xreg[u].w;
+      }
     }
     __syncthreads();
+    if (k0 + KC < K) prefetch(k0 + KC); // in flight during the MFMAs below
     const int kmax = (K - k0) < KC ? (K - k0) : KC;
-    for (int s = 0; s < kmax / 2; ++s) {
-      const int k = 2 * s + h;
-      const float av = A_FROM_GLOBAL ? xs[(mi * 32 + r) * KCP + k] : a_lds[(mi * 32 + r) * a_lds_ld + k0 + k];
+    const float *arow = A_FROM_GLOBAL ? xs + (mi * 32 + r) * KCP + h : a_lds + (mi * 32 + r) * a_lds_ld + k0 + h;
+    const float *brow = ws + (nb0 * 32 + r) * KCP + h; // n-block j of this wave sits 64 rows further per j
+    auto step = [&](int s) {
+      const float av = arow[2 * s];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int ni = nb0 + 2 * j;
-        if (ni < NB) {
-          const float bv = ws[(ni * 32 + r) * KCP + k];
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[j], 0, 0, 0);
-        }
-      }
+      for (int j = 0; j < 4; ++j)
+        if (nb0 + 2 * j < NB) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, brow[j * 64 * KCP + 2 * s], acc[j], 0, 0, 0);
+    };
+    if (kmax == KC) {
+#pragma unroll
+      for (int s = 0; s < KC / 2; ++s) step(s); // fully unrolled: next step's ds_reads issue under this step's MFMAs
+    } else {
+      for (int s = 0; s < kmax / 2; ++s) step(s);
     }
   }
 }
@@ -475,6 +663,8 @@ int oakgpu_net_load_memory(oakgpu_ctx *ctx, const void *bytes, size_t size, oakg
   rc = rc ? rc : upload(net, transpose(p0), &D.p_w0t);
   rc = rc ? rc : upload(net, p0.b, &D.p_b0);
   rc = rc ? rc : upload(net, transpose(p1), &D.p_w1t);
+  rc = rc ? rc : upload(net, p1.w, &D.p_w1);
+  rc = rc ? rc : upload(net, a1.w, &D.a_w1);
   rc = rc ? rc : upload(net, p1.b, &D.p_b1);
   rc = rc ? rc : upload(net, transpose(a0), &D.a_w0t);
   rc = rc ? rc : upload(net, a0.b, &D.a_b0);
@@ -518,6 +708,8 @@ static int lds_attrs_once() {
   if (done) return 0;
   hipError_t e = hipFuncSetAttribute((const void *)oak::k_embed, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
   if (e != hipSuccess) return oakgpu_fail_hip((int)e, "hipFuncSetAttribute(k_embed)");
+  e = hipFuncSetAttribute((const void *)oak::k_embed_tile, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+  if (e != hipSuccess) return oakgpu_fail_hip((int)e, "hipFuncSetAttribute(k_embed_tile)");
   e = hipFuncSetAttribute((const void *)oak::k_mainnet, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
   if (e != hipSuccess) return oakgpu_fail_hip((int)e, "hipFuncSetAttribute(k_mainnet)");
   done = true;
@@ -545,12 +737,22 @@ int oakgpu_leaf_eval_dev(oakgpu_ctx *ctx, oakgpu_net *net, const uint8_t *battle
     emb = net->emb_ws;
   }
   const oak::NetDev &D = net->dev;
-  oak::EmbedArgs ea{D, battles, durations, n, emb};
-  const size_t emb_lds = (size_t)(D.p_hidden * D.p_out + D.a_hidden * D.a_out + 4 * 256) * 4;
-  uint32_t waves_needed = n * 12;
-  uint32_t grid = (waves_needed + 3) / 4;
-  if (grid > 256 * 8) grid = 256 * 8;
-  hipLaunchKernelGGL(oak::k_embed, dim3(grid), dim3(oak::EMB_BLOCK), emb_lds, stream, ea);
+  if (getenv("OAKGPU_EMBED_V1")) { // first implementation (one wave per item, VALU second layer), kept for A/B
+    oak::EmbedArgs ea{D, battles, durations, n, emb};
+    const size_t emb_lds = (size_t)(D.p_hidden * D.p_out + D.a_hidden * D.a_out + 4 * 256) * 4;
+    uint32_t grid = (n * 12 + 3) / 4;
+    if (grid > 256 * 8) grid = 256 * 8;
+    hipLaunchKernelGGL(oak::k_embed, dim3(grid), dim3(oak::EMB_BLOCK), emb_lds, stream, ea);
+  } else {
+    for (int kind = 0; kind < 2; ++kind) {
+      oak::EmbedTileArgs ta{D, battles, durations, n, emb, kind};
+      const int out_pad = ((kind ? D.a_out : D.p_out) + 31) & ~31;
+      const size_t lds = (size_t)(oak::ET * oak::EHP + out_pad * oak::EHP + 4 * 128 + 2 * oak::ET + (kind ? 34 : 9) * 98) * 4;
+      const uint32_t ntiles = (n * (kind ? 2u : 10u) + oak::ET - 1) / oak::ET;
+      uint32_t grid = ntiles < 1024 ? ntiles : 1024;
+      hipLaunchKernelGGL(oak::k_embed_tile, dim3(grid), dim3(oak::EMB_BLOCK), lds, stream, ta);
+    }
+  }
   oak::MainArgs ma{D, emb, n, values};
   const int hld = (D.H > D.VH ? D.H : D.VH) + 1;
   const size_t mn_lds = (size_t)(oak::TM * oak::KCP + oak::MAXH * oak::KCP + oak::TM * hld) * 4;

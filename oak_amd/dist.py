@@ -21,9 +21,9 @@ def lane_seed0(seed0, n_total, rank, world):
     return seed0 + shard_range(n_total, rank, world)[0]
 
 
-def gather_values(values, n_total=None):
+def gather_values(values, n_total=None, force=False):
     """All-gather per-rank fp32 leaf values into the global lane order on every rank."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_initialized() or (dist.get_world_size() == 1 and not force):
         return values
     world = dist.get_world_size()
     if n_total is None or n_total % world == 0:
