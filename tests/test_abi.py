@@ -47,3 +47,14 @@ def test_product_never_references_the_oracle():
                 if re.search(r"oracle_lib|liboracle|nn_oracle|oracle/", txt):
                     bad.append(f)
     assert not bad, bad
+
+
+def test_cpp_host_layer_compiles_and_links(tmp_path):
+    """include/oakgpu.hpp + include/pkmn.h compile as C++17 and link against liboakgpu.so."""
+    import subprocess
+    exe = str(tmp_path / "cpp_host_smoke")
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp_host_smoke.cc"), "-L", os.path.join(ROOT, "oak_amd"), "-loakgpu",
+                           "-Wl,-rpath," + os.path.join(ROOT, "oak_amd"), "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
