@@ -124,6 +124,18 @@ int oakgpu_leaf_eval_dev(oakgpu_ctx *ctx, oakgpu_net *net, const uint8_t *battle
 int oakgpu_leaf_eval(oakgpu_ctx *ctx, oakgpu_net *net, const uint8_t *battles, const uint8_t *durations, uint32_t n,
                      float *values, float *embedding_out);
 
+/* value_policy_inference (network.h:102-123): value plus, per side, the logits of the <= 9 legal choices
+ * (choices n x 9 bytes + counts n bytes per side, as produced by oakgpu_choices*; logits n x 9 floats,
+ * entries past the count are 0).  Choice -> policy row via Encode::Battle::Policy::get_index
+ * (encode/battle/policy.h:29-58): move -> stored move id - 1, switch -> 164 + species - 1, pass -> 0. */
+int oakgpu_leaf_eval_policy_dev(oakgpu_ctx *ctx, oakgpu_net *net, const uint8_t *battles, const uint8_t *durations,
+                                uint32_t n, const uint8_t *p1_choices, const uint8_t *p1_counts,
+                                const uint8_t *p2_choices, const uint8_t *p2_counts, float *values, float *p1_logits,
+                                float *p2_logits);
+int oakgpu_leaf_eval_policy(oakgpu_ctx *ctx, oakgpu_net *net, const uint8_t *battles, const uint8_t *durations, uint32_t n,
+                            const uint8_t *p1_choices, const uint8_t *p1_counts, const uint8_t *p2_choices,
+                            const uint8_t *p2_counts, float *values, float *p1_logits, float *p2_logits);
+
 #ifdef __cplusplus
 }
 #endif

@@ -13,7 +13,7 @@ SYMBOLS = [
     "oakgpu_choices_dev", "oakgpu_choices", "oakgpu_init_battles_dev", "oakgpu_init_battles",
     "oakgpu_set_ou_pools", "oakgpu_random_ou_battles_dev",
     "oakgpu_net_load", "oakgpu_net_load_memory", "oakgpu_net_free", "oakgpu_net_shape",
-    "oakgpu_leaf_eval_dev", "oakgpu_leaf_eval",
+    "oakgpu_leaf_eval_dev", "oakgpu_leaf_eval", "oakgpu_leaf_eval_policy_dev", "oakgpu_leaf_eval_policy",
 ]
 
 # include/pkmn.h: the libpkmn-named single-battle ABI (batch-of-one wrappers, pkmn_shim.hip)
@@ -65,6 +65,8 @@ def load():
     lib.oakgpu_net_shape.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
     lib.oakgpu_leaf_eval_dev.argtypes = [vp, vp, vp, vp, u32, vp, vp]
     lib.oakgpu_leaf_eval.argtypes = [vp, vp, vp, vp, u32, vp, vp]
+    lib.oakgpu_leaf_eval_policy_dev.argtypes = [vp, vp, vp, vp, u32, vp, vp, vp, vp, vp, vp, vp]
+    lib.oakgpu_leaf_eval_policy.argtypes = [vp, vp, vp, vp, u32, vp, vp, vp, vp, vp, vp, vp]
     _lib = lib
     return lib
 

@@ -36,6 +36,9 @@ struct NetDev {
   const float *w0, *b0, *w1, *b1, *w2, *b2, *w3;
   float b3;
   int H, VH; // padded dims
+  // policy heads (main-net.h:67-107): fc2 [PHp][H] (rows padded to 32), fc3 [315][PHp] (+ biases)
+  const float *q1a, *q1a_b, *q1b, *q1b_b, *q2a, *q2a_b, *q2b, *q2b_b;
+  int PH; // padded policy hidden width
 };
 
 __device__ __forceinline__ float act_fn(float x, int activation) {
@@ -426,6 +429,7 @@ struct MainArgs {
   const float *emb; // n x emb_dim
   uint32_t n;
   float *values;
+  float *h1_out; // nullable: n x H activated fc1 outputs, input of the policy heads (k_policy)
 };
 
 // One dense layer for a TM x Hout tile: acc = A(TM x K) . W^T.
@@ -537,6 +541,12 @@ __global__ __launch_bounds__(MN_BLOCK) void k_mainnet(MainArgs a) {
   __syncthreads(); // every wave done reading hs
   store_act(acc, N.b1, H, N.activation, hs, hld);
   __syncthreads();
+  if (a.h1_out) { // keep fc1's activations for the policy heads
+    for (uint32_t i = threadIdx.x; i < n_rows * (uint32_t)H; i += MN_BLOCK) {
+      const uint32_t row = i / (uint32_t)H, c = i - row * (uint32_t)H;
+      a.h1_out[(size_t)(row0 + row) * H + c] = hs[row * hld + c];
+    }
+  }
   dense_layer<false>(nullptr, 0, 0, 0, hs, hld, N.w2, H, VH, xs, ws, acc);
   __syncthreads();
   store_act(acc, N.b2, VH, N.activation, hs, hld);
@@ -549,6 +559,74 @@ __global__ __launch_bounds__(MN_BLOCK) void k_mainnet(MainArgs a) {
   }
 }
 
+// ---- policy heads: value_policy_inference's logits (network.h:102-123, main-net.h:67-107) ----------
+// Encode::Battle::Policy::get_index (encode/battle/policy.h:29-58) on the raw battle bytes
+__device__ __forceinline__ uint32_t policy_index(const uint8_t *side, uint32_t choice) {
+  const uint32_t kind = choice & 3, data = choice >> 2;
+  if (kind == 1) {
+    if (data == 0) return 0; // Struggle / forced continue: only ever a sole option (policy.h:11-19)
+    const uint32_t sid = side[176] - 1u;
+    const uint32_t mid = side[24 * sid + 10 + 2 * (data - 1)]; // side.stored().moves[data - 1].id
+    return mid == 0 ? 0 : mid - 1;
+  }
+  if (kind == 2) {
+    const uint32_t pid = side[176 + data - 1];
+    return 164 + side[24 * (pid - 1) + 21] - 1u;
+  }
+  return 0;
+}
+
+struct PolicyArgs {
+  NetDev net;
+  const float *h1;  // n x H
+  const uint8_t *battles;
+  const uint8_t *choices[2]; // n x 9 each
+  const uint8_t *counts[2];  // n each
+  float *logits[2];          // n x 9 each
+  uint32_t n;
+};
+
+__global__ __launch_bounds__(MN_BLOCK) void k_policy(PolicyArgs a) {
+  extern __shared__ __align__(16) float lds_f[];
+  const NetDev &N = a.net;
+  const int H = N.H, PH = N.PH;
+  const int hld = H + 1, old = PH + 1;
+  float *xs = lds_f;              // unused staging slot of dense_layer<false> (kept for its signature)
+  float *ws = xs + TM * KCP;      // MAXH x KCP
+  float *hs = ws + MAXH * KCP;    // TM x hld : fc1 activations
+  float *os = hs + TM * hld;      // TM x old : policy fc2 activations
+  const uint32_t row0 = blockIdx.x * TM;
+  const uint32_t n_rows = min((uint32_t)TM, a.n - row0);
+  for (uint32_t i = threadIdx.x; i < TM * (uint32_t)H; i += MN_BLOCK) {
+    const uint32_t row = i / (uint32_t)H, c = i - row * (uint32_t)H;
+    hs[row * hld + c] = row < n_rows ? a.h1[(size_t)(row0 + row) * H + c] : 0.0f;
+  }
+  __syncthreads();
+  f32x16 acc[4];
+  for (int head = 0; head < 2; ++head) {
+    const float *Wa = head ? N.q2a : N.q1a, *ba = head ? N.q2a_b : N.q1a_b;
+    const float *Wb = head ? N.q2b : N.q1b, *bb = head ? N.q2b_b : N.q1b_b;
+    dense_layer<false>(nullptr, 0, 0, 0, hs, hld, Wa, H, PH, xs, ws, acc);
+    __syncthreads();
+    store_act(acc, ba, PH, N.activation, os, old);
+    __syncthreads();
+    for (uint32_t e = threadIdx.x; e < TM * OAKGPU_MAX_CHOICES; e += MN_BLOCK) {
+      const uint32_t row = e / OAKGPU_MAX_CHOICES, j = e - row * OAKGPU_MAX_CHOICES;
+      if (row >= n_rows) continue;
+      const size_t leaf = row0 + row;
+      float logit = 0.0f;
+      if (j < a.counts[head][leaf]) {
+        const uint32_t idx = policy_index(a.battles + leaf * 384 + head * 184, a.choices[head][leaf * OAKGPU_MAX_CHOICES + j]);
+        const float *w = Wb + (size_t)idx * PH, *o = os + row * old;
+        logit = bb[idx];
+        for (int c = 0; c < PH; ++c) logit = fmaf(w[c], o[c], logit);
+      }
+      a.logits[head][leaf * OAKGPU_MAX_CHOICES + j] = logit;
+    }
+    __syncthreads(); // os / ws reused by the second head
+  }
+}
+
 } // namespace oak
 
 // =================================== C ABI =====================================================
@@ -558,6 +636,8 @@ struct oakgpu_net {
   int in_dim, hidden, value_hidden, policy_hidden; // unpadded, as in the file
   float *emb_ws;     // lazily grown workspace: n x emb_dim
   size_t emb_ws_rows;
+  float *h1_ws;      // lazily grown workspace: n x H (policy path only)
+  size_t h1_ws_rows;
 };
 
 namespace {
@@ -619,6 +699,7 @@ void oakgpu_net_free(oakgpu_ctx *ctx, oakgpu_net *net) {
   if (!net) return;
   for (void *p : net->allocs) (void)hipFree(p);
   if (net->emb_ws) (void)hipFree(net->emb_ws);
+  if (net->h1_ws) (void)hipFree(net->h1_ws);
   delete net;
 }
 
@@ -649,6 +730,8 @@ int oakgpu_net_load_memory(oakgpu_ctx *ctx, const void *bytes, size_t size, oakg
   oakgpu_net *net = new oakgpu_net();
   net->emb_ws = nullptr;
   net->emb_ws_rows = 0;
+  net->h1_ws = nullptr;
+  net->h1_ws_rows = 0;
   net->in_dim = (int)fc0.in;
   net->hidden = (int)fc0.out;
   net->value_hidden = (int)v2.out;
@@ -677,6 +760,22 @@ int oakgpu_net_load_memory(oakgpu_ctx *ctx, const void *bytes, size_t size, oakg
   rc = rc ? rc : upload(net, pad_rows(v2, VH, H), &D.w2);
   rc = rc ? rc : upload(net, pad_vec(v2.b, VH), &D.b2);
   rc = rc ? rc : upload(net, pad_vec(v3.w, VH), &D.w3);
+  {
+    const HostAffine &q1a = L[8], &q1b = L[9], &q2a = L[10], &q2b = L[11];
+    if (q1a.in != fc1.out || q2a.in != fc1.out || q1b.in != q1a.out || q2b.in != q2a.out || q1a.out != q2a.out ||
+        q1b.out != 315 || q2b.out != 315) { oakgpu_net_free(ctx, net); return oakgpu_fail_msg("network file: inconsistent policy-head dims"); }
+    const uint32_t PH = up32(q1a.out);
+    if (PH > (uint32_t)oak::MAXH) { oakgpu_net_free(ctx, net); return oakgpu_fail_msg("policy hidden width above 256 unsupported"); }
+    D.PH = (int)PH;
+    rc = rc ? rc : upload(net, pad_rows(q1a, PH, H), &D.q1a);
+    rc = rc ? rc : upload(net, pad_vec(q1a.b, PH), &D.q1a_b);
+    rc = rc ? rc : upload(net, pad_rows(q1b, 315, PH), &D.q1b);
+    rc = rc ? rc : upload(net, q1b.b, &D.q1b_b);
+    rc = rc ? rc : upload(net, pad_rows(q2a, PH, H), &D.q2a);
+    rc = rc ? rc : upload(net, pad_vec(q2a.b, PH), &D.q2a_b);
+    rc = rc ? rc : upload(net, pad_rows(q2b, 315, PH), &D.q2b);
+    rc = rc ? rc : upload(net, q2b.b, &D.q2b_b);
+  }
   if (rc) { oakgpu_net_free(ctx, net); return rc; }
   *out = net;
   return 0;
@@ -710,14 +809,16 @@ static int lds_attrs_once() {
   if (e != hipSuccess) return oakgpu_fail_hip((int)e, "hipFuncSetAttribute(k_embed)");
   e = hipFuncSetAttribute((const void *)oak::k_embed_tile, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
   if (e != hipSuccess) return oakgpu_fail_hip((int)e, "hipFuncSetAttribute(k_embed_tile)");
+  e = hipFuncSetAttribute((const void *)oak::k_policy, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+  if (e != hipSuccess) return oakgpu_fail_hip((int)e, "hipFuncSetAttribute(k_policy)");
   e = hipFuncSetAttribute((const void *)oak::k_mainnet, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
   if (e != hipSuccess) return oakgpu_fail_hip((int)e, "hipFuncSetAttribute(k_mainnet)");
   done = true;
   return 0;
 }
 
-int oakgpu_leaf_eval_dev(oakgpu_ctx *ctx, oakgpu_net *net, const uint8_t *battles, const uint8_t *durations, uint32_t n,
-                         float *values, float *embedding_out) {
+static int leaf_eval_impl(oakgpu_ctx *ctx, oakgpu_net *net, const uint8_t *battles, const uint8_t *durations, uint32_t n,
+                          float *values, float *embedding_out, const oak::PolicyArgs *pol) {
   if (!ctx || !net) return oakgpu_fail_msg("oakgpu_leaf_eval_dev: null ctx/net");
   if (n == 0) return 0;
   if (!battles || !durations || !values) return oakgpu_fail_msg("oakgpu_leaf_eval_dev: null required pointer");
@@ -753,13 +854,52 @@ int oakgpu_leaf_eval_dev(oakgpu_ctx *ctx, oakgpu_net *net, const uint8_t *battle
       hipLaunchKernelGGL(oak::k_embed_tile, dim3(grid), dim3(oak::EMB_BLOCK), lds, stream, ta);
     }
   }
-  oak::MainArgs ma{D, emb, n, values};
+  float *h1 = nullptr;
+  if (pol) {
+    if (net->h1_ws_rows < n) {
+      hipError_t e2 = hipStreamSynchronize(stream);
+      if (e2 != hipSuccess) return oakgpu_fail_hip((int)e2, "hipStreamSynchronize");
+      if (net->h1_ws) (void)hipFree(net->h1_ws);
+      net->h1_ws = nullptr;
+      e2 = hipMalloc((void **)&net->h1_ws, (size_t)n * D.H * 4);
+      if (e2 != hipSuccess) return oakgpu_fail_hip((int)e2, "hipMalloc(policy workspace)");
+      net->h1_ws_rows = n;
+    }
+    h1 = net->h1_ws;
+  }
+  oak::MainArgs ma{D, emb, n, values, h1};
   const int hld = (D.H > D.VH ? D.H : D.VH) + 1;
   const size_t mn_lds = (size_t)(oak::TM * oak::KCP + oak::MAXH * oak::KCP + oak::TM * hld) * 4;
   hipLaunchKernelGGL(oak::k_mainnet, dim3((n + oak::TM - 1) / oak::TM), dim3(oak::MN_BLOCK), mn_lds, stream, ma);
+  if (pol) {
+    oak::PolicyArgs pa = *pol;
+    pa.net = D;
+    pa.h1 = h1;
+    const size_t pl_lds = (size_t)(oak::TM * oak::KCP + oak::MAXH * oak::KCP + oak::TM * (D.H + 1) + oak::TM * (D.PH + 1)) * 4;
+    hipLaunchKernelGGL(oak::k_policy, dim3((n + oak::TM - 1) / oak::TM), dim3(oak::MN_BLOCK), pl_lds, stream, pa);
+  }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return oakgpu_fail_hip((int)e, "leaf_eval launch");
   return 0;
+}
+
+int oakgpu_leaf_eval_dev(oakgpu_ctx *ctx, oakgpu_net *net, const uint8_t *battles, const uint8_t *durations, uint32_t n,
+                         float *values, float *embedding_out) {
+  return leaf_eval_impl(ctx, net, battles, durations, n, values, embedding_out, nullptr);
+}
+
+int oakgpu_leaf_eval_policy_dev(oakgpu_ctx *ctx, oakgpu_net *net, const uint8_t *battles, const uint8_t *durations, uint32_t n,
+                                const uint8_t *p1_choices, const uint8_t *p1_counts, const uint8_t *p2_choices,
+                                const uint8_t *p2_counts, float *values, float *p1_logits, float *p2_logits) {
+  if (!p1_choices || !p1_counts || !p2_choices || !p2_counts || !p1_logits || !p2_logits)
+    return oakgpu_fail_msg("oakgpu_leaf_eval_policy_dev: null pointer");
+  oak::PolicyArgs pa{};
+  pa.battles = battles;
+  pa.choices[0] = p1_choices; pa.choices[1] = p2_choices;
+  pa.counts[0] = p1_counts; pa.counts[1] = p2_counts;
+  pa.logits[0] = p1_logits; pa.logits[1] = p2_logits;
+  pa.n = n;
+  return leaf_eval_impl(ctx, net, battles, durations, n, values, nullptr, &pa);
 }
 
 int oakgpu_leaf_eval(oakgpu_ctx *ctx, oakgpu_net *net, const uint8_t *battles, const uint8_t *durations, uint32_t n,
@@ -788,6 +928,39 @@ done:
   if (dd) (void)hipFree(dd);
   if (dv) (void)hipFree(dv);
   if (de) (void)hipFree(de);
+  return rc;
+#undef TRY
+}
+
+int oakgpu_leaf_eval_policy(oakgpu_ctx *ctx, oakgpu_net *net, const uint8_t *battles, const uint8_t *durations, uint32_t n,
+                            const uint8_t *p1_choices, const uint8_t *p1_counts, const uint8_t *p2_choices, const uint8_t *p2_counts,
+                            float *values, float *p1_logits, float *p2_logits) {
+  if (!ctx || !net) return oakgpu_fail_msg("oakgpu_leaf_eval_policy: null ctx/net");
+  if (n == 0) return 0;
+  hipStream_t stream = (hipStream_t)oakgpu_ctx_stream(ctx);
+  void *db = nullptr, *dd = nullptr, *dv = nullptr, *dc1 = nullptr, *dc2 = nullptr, *dn1 = nullptr, *dn2 = nullptr, *dl1 = nullptr, *dl2 = nullptr;
+  int rc = 0;
+  hipError_t e;
+#define TRY(x) do { e = (x); if (e != hipSuccess) { rc = oakgpu_fail_hip((int)e, #x); goto done; } } while (0)
+  TRY(hipSetDevice(oakgpu_ctx_device(ctx)));
+  TRY(hipMalloc(&db, (size_t)n * 384)); TRY(hipMalloc(&dd, (size_t)n * 8)); TRY(hipMalloc(&dv, (size_t)n * 4));
+  TRY(hipMalloc(&dc1, (size_t)n * 9)); TRY(hipMalloc(&dc2, (size_t)n * 9)); TRY(hipMalloc(&dn1, n)); TRY(hipMalloc(&dn2, n));
+  TRY(hipMalloc(&dl1, (size_t)n * 36)); TRY(hipMalloc(&dl2, (size_t)n * 36));
+  TRY(hipMemcpyAsync(db, battles, (size_t)n * 384, hipMemcpyHostToDevice, stream));
+  TRY(hipMemcpyAsync(dd, durations, (size_t)n * 8, hipMemcpyHostToDevice, stream));
+  TRY(hipMemcpyAsync(dc1, p1_choices, (size_t)n * 9, hipMemcpyHostToDevice, stream));
+  TRY(hipMemcpyAsync(dc2, p2_choices, (size_t)n * 9, hipMemcpyHostToDevice, stream));
+  TRY(hipMemcpyAsync(dn1, p1_counts, n, hipMemcpyHostToDevice, stream));
+  TRY(hipMemcpyAsync(dn2, p2_counts, n, hipMemcpyHostToDevice, stream));
+  rc = oakgpu_leaf_eval_policy_dev(ctx, net, (const uint8_t *)db, (const uint8_t *)dd, n, (const uint8_t *)dc1, (const uint8_t *)dn1,
+                                   (const uint8_t *)dc2, (const uint8_t *)dn2, (float *)dv, (float *)dl1, (float *)dl2);
+  if (rc) goto done;
+  TRY(hipMemcpyAsync(values, dv, (size_t)n * 4, hipMemcpyDeviceToHost, stream));
+  TRY(hipMemcpyAsync(p1_logits, dl1, (size_t)n * 36, hipMemcpyDeviceToHost, stream));
+  TRY(hipMemcpyAsync(p2_logits, dl2, (size_t)n * 36, hipMemcpyDeviceToHost, stream));
+  TRY(hipStreamSynchronize(stream));
+done:
+  for (void *p : {db, dd, dv, dc1, dc2, dn1, dn2, dl1, dl2}) if (p) (void)hipFree(p);
   return rc;
 #undef TRY
 }

@@ -155,6 +155,20 @@ class Network:
                                                  _p(values), _p(emb)))
         return (values, emb) if return_embedding else values
 
+    def value_policy_inference(self, battles, durations, p1_choices, p1_counts, p2_choices, p2_counts):
+        """(values[n], p1_logits[n, 9], p2_logits[n, 9]) -- NetworkImpl::value_policy_inference, network.h:102-123.
+        choices / counts as returned by Context.choices()."""
+        battles = _u8(battles)
+        n = battles.shape[0]
+        values = np.zeros(n, dtype=np.float32)
+        l1 = np.zeros((n, 9), dtype=np.float32)
+        l2 = np.zeros((n, 9), dtype=np.float32)
+        _lib.check(self.ctx.lib.oakgpu_leaf_eval_policy(self.ctx.handle, self.handle, _p(battles), _p(_u8(durations, (n, 8))), n,
+                                                        _p(_u8(p1_choices, (n, 9))), _p(_u8(p1_counts, (n,))),
+                                                        _p(_u8(p2_choices, (n, 9))), _p(_u8(p2_counts, (n,))),
+                                                        _p(values), _p(l1), _p(l2)))
+        return values, l1, l2
+
     def close(self):
         if self.handle:
             self.ctx.lib.oakgpu_net_free(self.ctx.handle, self.handle)

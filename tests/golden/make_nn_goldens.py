@@ -9,8 +9,8 @@ integer constants torch.py reads (values from cpp/src/pyoak.cc:586-600 /
 cpp/include/nn/default-hyperparameters.h).  Outputs (data only):
   tests/golden/net_default.battle.net   seeded default-dim network file (reference writer)
   tests/golden/net_tiny.battle.net      small-dim network (generic-dimension coverage)
-  tests/golden/nn_goldens.npz           inputs + reference outputs of pokemon_net,
-                                        active_net and main_net.forward_value_only
+  tests/golden/nn_goldens.npz           inputs + reference outputs of pokemon_net, active_net,
+                                        main_net.forward_value_only and main_net.forward (policy logits)
 """
 import importlib.util
 import io
@@ -74,7 +74,9 @@ def main():
             yp = net.pokemon_net.forward(torch.from_numpy(xp)).numpy()
             ya = net.active_net.forward(torch.from_numpy(xa)).numpy()
             ym = net.main_net.forward_value_only(torch.from_numpy(xm)).numpy()
-        out.update({tag + "_xp": xp, tag + "_yp": yp, tag + "_xa": xa, tag + "_ya": ya, tag + "_xm": xm, tag + "_ym": ym})
+            _, l1, l2 = net.main_net.forward(torch.from_numpy(xm))   # full 315-wide policy logits per side
+        out.update({tag + "_xp": xp, tag + "_yp": yp, tag + "_xa": xa, tag + "_ya": ya, tag + "_xm": xm, tag + "_ym": ym,
+                    tag + "_l1": l1.numpy(), tag + "_l2": l2.numpy()})
         print(tag, "file bytes", len(buf.getvalue()), "value range", ym.min(), ym.max())
     np.savez_compressed(os.path.join(HERE, "nn_goldens.npz"), **out)
 

@@ -94,3 +94,27 @@ def test_config3_rollout_with_leaf_eval_every_turn(gpu_ctx, tmp_path):
             worst = max(worst, abs(float(vals[i]) - float(NN.value_inference(onet, b[i], d[i]))))
     assert worst <= TOL, worst
     net.close()
+
+
+@pytest.mark.parametrize("tag", ["default", "tiny"])
+def test_value_policy_inference_matches_oracle(gpu_ctx, tag):
+    """network.h:102-123: value + the legal choices' logits of both policy heads."""
+    from oak_amd.engine import Network
+    path = os.path.join(ROOT, "tests", "golden", "net_%s.battle.net" % tag)
+    net = Network(gpu_ctx, path=path)
+    onet = NN.Net(path)
+    b, d = _midgame_states(150, 12, 8080)
+    r = np.array([O.LIB.oracle_result_from_state(O.ptr(b[i])) for i in range(b.shape[0])], dtype=np.uint8)
+    c1, n1 = gpu_ctx.choices(b, r, 0)
+    c2, n2 = gpu_ctx.choices(b, r, 1)
+    vals, l1, l2 = net.value_policy_inference(b, d, c1, n1, c2, n2)
+    plain = net.value_inference(b, d)
+    assert np.abs(vals - plain).max() == 0.0
+    worst = 0.0
+    for i in range(b.shape[0]):
+        ov, o1, o2 = NN.value_policy_inference(onet, b[i], d[i], c1[i, :n1[i]], c2[i, :n2[i]])
+        worst = max(worst, abs(float(vals[i]) - float(ov)))
+        assert np.abs(l1[i, :n1[i]] - o1).max() <= 2e-5 and np.abs(l2[i, :n2[i]] - o2).max() <= 2e-5, i
+        assert (l1[i, n1[i]:] == 0).all() and (l2[i, n2[i]:] == 0).all()
+    assert worst <= TOL
+    net.close()

@@ -26,6 +26,9 @@ def test_subnetworks_match_reference_torch(tag):
         assert np.abs(got - y).max() < 2e-6
     for x, y in zip(G[tag + "_xm"], G[tag + "_ym"]):
         assert abs(float(net.main_value(x)) - float(y[0])) < 1e-6
+    for x, l1, l2 in zip(G[tag + "_xm"], G[tag + "_l1"], G[tag + "_l2"]):
+        p1, p2 = net.policy_logits(x)
+        assert np.abs(p1 - l1).max() < 5e-6 and np.abs(p2 - l2).max() < 5e-6
 
 
 def test_default_file_size_matches_reference():
