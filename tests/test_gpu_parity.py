@@ -214,3 +214,43 @@ def test_libpkmn_named_single_battle_abi(gpu_ctx):
             ores = O.update(b[i], picks[0], picks[1], oopt)
             assert res == ores and (gb == b[i]).all()
             assert bytes(opt.durations) == oopt.durations.tobytes() and bytes(opt.actions) == oopt.actions.tobytes()
+
+
+def test_full_size_config2_bit_exact(gpu_ctx):
+    """BASELINE configs[1] at its full size: all 65,536 random OU playouts, every output byte vs the oracle."""
+    n = 65536
+    b, d, p, r = O.make_random_ou_batch(n)
+    gpu_ctx.set_playouts_per_lane(2)          # the scheduling bench.py uses
+    got = gpu_ctx.rollout(b, d, r, p, max_steps=1000, return_state=True)
+    gpu_ctx.set_playouts_per_lane(1)
+    ob, od, op = b.copy(), d.copy(), p.copy()
+    oout, osteps = O.rollout_batch(ob, od, r, op, max_steps=1000, threads=16)
+    assert (got["steps"] == osteps).all() and (got["results"] == oout).all()
+    assert (got["battles"] == ob).all() and (got["durations"] == od).all() and (got["prng"] == op).all()
+    assert int(osteps.sum()) > 6_000_000
+
+
+def test_full_size_config4_properties_and_sampled_parity(gpu_ctx):
+    """BASELINE config 4 at full size (256 roots x 4096 replicas = 1,048,576 playouts, device-side prep):
+    size-independent properties on everything, bit-exact parity on a random 8,192-lane sample (lanes are
+    independent, so a lane's outputs depend only on its own inputs), determinism across launches."""
+    roots, reps = 256, 4096
+    b, d, p, r = O.make_random_ou_batch(roots, seed0=0x0A4B00000000)     # first 256 lanes of config 2
+    n = roots * reps
+    B, D, R = np.repeat(b, reps, axis=0), np.repeat(d, reps, axis=0), np.repeat(r, reps)
+    rng = np.random.default_rng(4)
+    prng = rng.integers(0, 256, (n, 8), dtype=np.uint8)
+    prng[:, 0] |= 1                                                      # never the all-zero state
+    got = gpu_ctx.rollout(B, D, R, prng, max_steps=1000, prep=True, return_state=True)
+    again = gpu_ctx.rollout(B, D, R, prng, max_steps=1000, prep=True)
+    assert (again["results"] == got["results"]).all() and (again["steps"] == got["steps"]).all()
+    t = got["results"] & 15
+    assert ((t <= 3)).all() and (got["steps"] <= 1000).all() and (got["steps"][t == 0] == 1000).all()
+    assert set(np.unique(got["values"])) <= {0.0, 0.5, 1.0}
+    per_root = got["values"].reshape(roots, reps).mean(axis=1)
+    assert ((per_root >= 0.0) & (per_root <= 1.0)).all() and 0.4 < float(per_root.mean()) < 0.6   # random teams: no side bias
+    pick = rng.choice(n, 8192, replace=False)
+    ob, od, op = B[pick].copy(), D[pick].copy(), prng[pick].copy()
+    oout, osteps = O.rollout_batch(ob, od, R[pick], op, max_steps=1000, prep=True, threads=16)
+    assert (got["results"][pick] == oout).all() and (got["steps"][pick] == osteps).all()
+    assert (got["battles"][pick] == ob).all() and (got["durations"][pick] == od).all() and (got["prng"][pick] == op).all()
