@@ -1,0 +1,124 @@
+"""Nash-at-root search fed by GPU batches (BASELINE config 5) -- host-side consumer of the hot path.
+
+Mirrors two pieces of the reference's search surface:
+  * `solve_matrix(payoffs, discretize_factor) -> (p1, p2, value)`  (pyoak: cpp/src/pyoak.cc:394-426; used by
+    MCTS::Search::process_output, cpp/include/search/mcts.h:620-659, through the absent lrsnash/GMP library):
+    exact Nash equilibrium of a <= 9 x 9 one-sum matrix game with integer payoffs.  Here: exact rational
+    simplex (fractions.Fraction, Bland's rule) -- no floating point in the solve, like the reference's GMP path.
+  * `root_matrix_search(...)`: for every joint action (i, j) of the root and R replicas, re-seed + resample hidden
+    counters (mcts.h:254-259), apply the joint action with ONE batched update on the GPU, evaluate the R x m x n
+    children with GPU rollouts (or the GPU network), average into the value matrix and solve it.  Output fields
+    follow MCTS::Output (mcts.h:68-90).
+All battle arithmetic runs through the C ABI (oak_amd.engine); this module only orchestrates and solves.
+"""
+from fractions import Fraction
+
+import numpy as np
+
+
+def _simplex_max(A, b, c):
+    """maximise c.x s.t. A x <= b, x >= 0 with b > 0; exact Fractions; returns (x, dual y, value)."""
+    m, n = len(A), len(A[0])
+    T = [[Fraction(v) for v in A[i]] + [Fraction(int(i == k)) for k in range(m)] + [Fraction(b[i])] for i in range(m)]
+    z = [-Fraction(v) for v in c] + [Fraction(0)] * m + [Fraction(0)]
+    basis = [n + i for i in range(m)]
+    while True:
+        col = next((j for j in range(n + m) if z[j] < 0), None)       # Bland: lowest index with negative reduced cost
+        if col is None:
+            break
+        best, row = None, None
+        for i in range(m):
+            if T[i][col] > 0:
+                ratio = T[i][-1] / T[i][col]
+                if best is None or ratio < best or (ratio == best and basis[i] < basis[row]):
+                    best, row = ratio, i
+        if row is None:
+            raise ArithmeticError("unbounded LP")
+        piv = T[row][col]
+        T[row] = [v / piv for v in T[row]]
+        for i in range(m):
+            if i != row and T[i][col] != 0:
+                f = T[i][col]
+                T[i] = [a - f * p for a, p in zip(T[i], T[row])]
+        f = z[col]
+        z = [a - f * p for a, p in zip(z, T[row])]
+        basis[row] = col
+    x = [Fraction(0)] * n
+    for i, bi in enumerate(basis):
+        if bi < n:
+            x[bi] = T[i][-1]
+    y = [z[n + i] for i in range(m)]                                    # dual values = reduced costs of the slacks
+    return x, y, z[-1]
+
+
+def solve_matrix_exact(payoffs):
+    """Exact equilibrium of the zero-sum game where the row player maximises payoffs[i][j].
+    Returns (p1 [Fraction], p2 [Fraction], value Fraction)."""
+    A = [[Fraction(v) for v in row] for row in payoffs]
+    m, n = len(A), len(A[0])
+    shift = 1 - min(min(r) for r in A)                                  # make every entry >= 1
+    B = [[v + shift for v in row] for row in A]
+    # column player: maximise sum z s.t. B z <= 1  ->  p2 = z / sum z, value' = 1 / sum z; duals give p1
+    z, y, tot = _simplex_max(B, [1] * m, [1] * n)
+    v = 1 / tot
+    p2 = [zi * v for zi in z]
+    p1 = [yi * v for yi in y]
+    return p1, p2, v - shift
+
+
+def solve_matrix(payoffs, discretize_factor=256):
+    """pyoak `solve_matrix` (pyoak.cc:394-426).  payoffs: m x n integers = value * discretize_factor (the row
+    player's one-sum payoff).  Returns (p1 float[m], p2 float[n], value float in [0, 1])."""
+    P = np.asarray(payoffs)
+    if P.ndim != 2 or P.shape[0] < 1 or P.shape[1] < 1 or P.shape[0] > 9 or P.shape[1] > 9:
+        raise RuntimeError("solve_matrix: payoff matrix must be between 1x1 and 9x9")
+    p1, p2, v = solve_matrix_exact([[int(x) for x in row] for row in P])
+    return (np.array([float(x) for x in p1]), np.array([float(x) for x in p2]), float(v / discretize_factor))
+
+
+def root_matrix_search(ctx, battle, durations, result, replicas=256, seed=0x5EED, evaluator="mc", max_steps=1000):
+    """One-ply Nash-at-root search of a position (battle uint8[384], durations uint8[8], result byte).
+
+    evaluator: "mc" (random rollouts on the GPU, MCTS::MonteCarlo) or an oak_amd.engine.Network
+    (value_inference on the GPU).  Returns a dict shaped like MCTS::Output (mcts.h:68-90)."""
+    battle = np.ascontiguousarray(battle, dtype=np.uint8).reshape(1, 384)
+    durations = np.ascontiguousarray(durations, dtype=np.uint8).reshape(1, 8)
+    res = np.array([result], dtype=np.uint8)
+    c1, n1 = ctx.choices(battle, res, 0)
+    c2, n2 = ctx.choices(battle, res, 1)
+    m, n = int(n1[0]), int(n2[0])
+    lanes = m * n * replicas
+    B = np.repeat(battle, lanes, axis=0)
+    D = np.repeat(durations, lanes, axis=0)
+    R = np.repeat(res, lanes)
+    # one fast_prng stream per lane (util/random.h:67-133); seeded counter-style, state never all-zero
+    rng = np.random.default_rng(seed)
+    prng = rng.integers(0, 256, (lanes, 8), dtype=np.uint8)
+    prng[:, 0] |= 1
+    # root-iteration prep on the device (mcts.h:254-259): max_steps = 0 -> only re-seed + hidden-variable resampling
+    prepped = ctx.rollout(B, D, R, prng, max_steps=0, prep=True, return_state=True)
+    B, D, prng = prepped["battles"], prepped["durations"], prepped["prng"]
+    ii, jj = np.meshgrid(np.arange(m), np.arange(n), indexing="ij")
+    a1 = np.repeat(c1[0, ii.ravel()], replicas)
+    a2 = np.repeat(c2[0, jj.ravel()], replicas)
+    child_res, _ = ctx.update(B, a1, a2, D, want_actions=False)          # in place on B, D
+    t = child_res & 15
+    values = np.where(t == 1, 1.0, np.where(t == 2, 0.0, 0.5)).astype(np.float32)
+    live = t == 0
+    if live.any():
+        if evaluator == "mc":
+            out = ctx.rollout(B[live], D[live], child_res[live], prng[live], max_steps=max_steps)
+            values[live] = out["values"]
+        else:
+            values[live] = evaluator.value_inference(B[live], D[live])
+    cum = values.reshape(m, n, replicas).sum(axis=2).astype(np.float64)
+    visits = np.full((m, n), replicas, dtype=np.int64)
+    mean = cum / visits
+    p1, p2, nash_value = solve_matrix(np.floor(mean * 256).astype(np.int64), 256)   # mcts.h:631-633: value / n * 256 as int
+    return {
+        "m": m, "n": n, "p1_choices": c1[0, :m].copy(), "p2_choices": c2[0, :n].copy(),
+        "visit_matrix": visits, "value_matrix": cum,                       # cumulative, like the reference (mcts.h:80-81)
+        "iterations": lanes, "empirical_value": float(values.mean()), "nash_value": nash_value,
+        "p1_nash": p1, "p2_nash": p2,
+        "p1_empirical": np.full(m, 1.0 / m), "p2_empirical": np.full(n, 1.0 / n),
+    }
