@@ -532,122 +532,6 @@ struct EngineR {
     (void)hpmax;
   }
 
-  __device__ void on_begin(Move mv, uint32_t move_id, uint32_t mslot) {
-    last_damage = 0;
-    switch (mv.effect()) {
-    case E_Confusion:
-      if (F.vlo & V_SUBSTITUTE) return;
-      if (!move_hit(mv)) return;
-      if (F.vlo & V_CONFUSION) return;
-      start_confusion(F, false);
-      return;
-    case E_Conversion:
-      if (F.vlo & V_INVULNERABLE) return;
-      S.a2 = (S.a2 & 0x00FFFFFFu) | (F.a2 & 0xFF000000u);
-      return;
-    case E_FocusEnergy: S.vlo |= V_FOCUSENERGY; return;
-    case E_Haze: {
-      S.bo = 0;
-      F.bo = 0;
-      unmodified_to_active(S);
-      unmodified_to_active(F);
-      const uint32_t fs = status(F);
-      if (fs) {
-        if (fs & ST_SLP) dset(F, 0, 3, 0);
-        set_status(F, 0);
-      }
-      if (status(S) == ST_TOX) set_status(S, ST_PSN);
-      haze_clear(S);
-      haze_clear(F);
-      return;
-    }
-    case E_Heal: {
-      const uint32_t mx = maxhp(S), h = hp(S), delta = mx - h;
-      if (delta == 0 || (delta & 255) == 255) return;
-      if (move_id == M_Rest) {
-        set_status(S, ST_EXT | 2);
-        dset(S, 0, 3, 0);
-        set_hp(S, mx);
-        S.vlo &= ~V_TOXIC;
-        set_toxic_ctr(S, 0);
-      } else {
-        uint32_t nh = h + mx / 2;
-        set_hp(S, nh > mx ? mx : nh);
-      }
-      return;
-    }
-    case E_LeechSeed:
-      if (has_type(types(F), T_Grass)) return;
-      if (!move_hit(mv)) return;
-      if (F.vlo & V_LEECHSEED) return;
-      F.vlo |= V_LEECHSEED;
-      return;
-    case E_LightScreen: S.vlo |= V_LIGHTSCREEN; return;
-    case E_Reflect: S.vlo |= V_REFLECT; return;
-    case E_Mist: S.vlo |= V_MIST; return;
-    case E_Mimic: {
-      if (!move_hit(mv)) return;
-      uint32_t n = 0;
-      for (uint32_t i = 1; i <= 4; ++i) n += (active_move(F, i) & 0xFF) != 0;
-      if (n == 0 || mslot == 0) return;
-      const uint32_t r = rng_range(0, n);
-      act_set(true, AC_MOVESLOT, 4, r + 1);
-      const uint64_t nid = active_move(F, r + 1) & 0xFF;
-      const uint32_t sh = 16 * (mslot - 1);
-      set_amoves(S, (amoves(S) & ~(0xFFull << sh)) | (nid << sh));
-      return;
-    }
-    case E_Paralyze: {
-      if (status(F)) return;
-      const uint32_t ft = types(F);
-      if (chart(mv.type(), ft & 15) == 0 || chart(mv.type(), ft >> 4) == 0) return;
-      if (!move_hit(mv)) return;
-      set_status(F, ST_PAR);
-      uint32_t s = spe(F) / 4;
-      set_astat(F, 2, s < 1 ? 1 : s);
-      return;
-    }
-    case E_Poison:
-      if (status(F)) return;
-      if (has_type(types(F), T_Poison)) return;
-      if (F.vlo & V_SUBSTITUTE) return;
-      if (!move_hit(mv)) return;
-      if (move_id == M_Toxic) { set_status(F, ST_TOX); F.vlo |= V_TOXIC; set_toxic_ctr(F, 0); }
-      else set_status(F, ST_PSN);
-      return;
-    case E_Splash: return;
-    case E_Substitute: {
-      if (S.vlo & V_SUBSTITUTE) return;
-      const uint32_t cost = maxhp(S) / 4, h = hp(S);
-      if (h < cost) return;
-      set_hp(S, h - cost);
-      set_sub_hp(S, cost + 1);
-      S.vlo |= V_SUBSTITUTE;
-      return;
-    }
-    case E_SwitchAndTeleport:
-      if (move_id != M_Teleport) (void)move_hit(mv);
-      return;
-    case E_Transform: {
-      if (F.vlo & V_INVULNERABLE) return;
-      const uint32_t id = (F.vlo & V_TRANSFORM) ? transform_id(F) : ((absp(F) << 3) | order0(F));
-      S.vlo |= V_TRANSFORM;
-      set_transform_id(S, id);
-      S.a0 = F.a0; S.a1 = F.a1; S.a2 = F.a2; S.bo = F.bo;
-      uint32_t n01 = 0, n23 = 0;
-      for (uint32_t i = 1; i <= 4; ++i) {
-        const uint32_t mid = active_move(F, i) & 0xFF;
-        const uint32_t slotw = mid | ((mid ? 5u : 0u) << 8);
-        if (i <= 2) n01 |= slotw << (16 * (i - 1)); else n23 |= slotw << (16 * (i - 3));
-      }
-      S.m01 = n01;
-      S.m23 = n23;
-      return;
-    }
-    default: return;
-    }
-  }
-
   // ---- pre-move checks ---------------------------------------------------------------------
   enum : int { BM_OK = 0, BM_DONE = 1, BM_SKIP_CAN = 2, BM_SKIP_PP = 3, BM_ERR = 4 };
 
@@ -763,203 +647,307 @@ struct EngineR {
     set_smoves(S, (sm & ~(0xFFull << sh)) | ((uint64_t)((((uint32_t)(sm >> sh) & 0xFF) - 1) & 63) << sh));
   }
 
-  __device__ void secondary_status(Move mv, uint32_t st, uint32_t num) {
-    const uint32_t fs = status(F);
-    if (st == ST_BRN && (fs & ST_FRZ)) { set_status(F, 0); return; }
-    if (fs) return;
-    if (has_type(types(F), st == ST_PSN ? (uint32_t)T_Poison : mv.type())) return;
-    const bool proc = rng_chance(num);
-    act_bool(true, AC_SECONDARY, proc);
-    if (!proc) return;
-    set_status(F, st);
-    if (st == ST_PAR) { uint32_t s = spe(F) / 4; set_astat(F, 2, s < 1 ? 1 : s); }
-    if (st == ST_BRN) { uint32_t a = (F.a0 >> 16) / 2; set_astat(F, 0, a < 1 ? 1 : a); }
-  }
+  // ---- the move itself, as ONE staged pipeline -------------------------------------------------------
+  // Every lane of a wave is executing a different move, and SIMT only reconverges at common program
+  // points.  So instead of ~60 effect bodies that each call the accuracy check / secondary roll / status /
+  // stat-stage code (ten copies of each, executed one after another by whichever lanes sit in them), the
+  // effect-specific part only computes small decisions (gates, parameters) and all lanes meet at ONE
+  // accuracy site, ONE secondary-roll site, ONE status site, ONE confusion site, ONE stat-stage site.
+  // Per-lane RNG order is unchanged (accuracy -> effect rolls -> crit -> damage -> counts -> secondary
+  // chance -> secondary duration), so results stay bit-identical to gen1_device.hpp and the oracle.
+  enum : uint32_t { SEC_NONE = 0, SEC_STATUS = 1, SEC_FLINCH = 2, SEC_CONF = 3, SEC_UNBOOST = 4 };
 
-  __device__ void do_move() {
+  __device__ void run_move(uint32_t mslot) {
     const uint32_t move_id = last_sel(S);
     const Move mv = move_data(move_id);
-    const uint32_t eff = mv.effect();
+    const uint32_t eff = mv.effect(), mtype = mv.type();
     const uint32_t sap = absp(S), fap = sap ^ 1;
+    const bool damaging = mv.bp() != 0;
     set_lm_counterable(sap, 0);
+    const uint32_t fs = status(F), ft = types(F);
+    const bool type_immune = chart(mtype, ft & 15) == 0 || chart(mtype, ft >> 4) == 0;
+    const bool fixed = eff == E_SpecialDamage || eff == E_SuperFang || move_id == M_Counter;
+    const bool ohko = eff == E_OHKO;
+    // deferred, single-site actions
+    uint32_t want_status = 0;
+    bool want_conf = false;
+    int ub_idx = -1, ub_n = 1, b_idx = -1, b_n = 1;
+    uint32_t sec_kind = SEC_NONE, sec_chance = 0, sec_status = 0;
+    int sec_idx = 0;
 
-    if (mv.bp() == 0) {
+    // -- stage 1: gates ----------------------------------------------------------------------------
+    bool go = true, need_hit = false;
+    if (!damaging) {
       last_damage = 0;
       switch (eff) {
-      case E_AttackUp1: case E_AttackUp2: case E_DefenseUp1: case E_DefenseUp2: case E_SpeedUp2: case E_SpecialUp1:
-      case E_SpecialUp2: case E_EvasionUp1: {
-        const int idx = (eff == E_AttackUp1 || eff == E_AttackUp2) ? 0 : (eff == E_DefenseUp1 || eff == E_DefenseUp2) ? 1
-                        : eff == E_SpeedUp2 ? 2 : eff == E_EvasionUp1 ? 5 : 3;
-        const int n = (eff == E_AttackUp2 || eff == E_DefenseUp2 || eff == E_SpeedUp2 || eff == E_SpecialUp2) ? 2 : 1;
-        boost_side(S, F, idx, n);
-        return;
+      case E_Confusion: go = !(F.vlo & V_SUBSTITUTE); need_hit = true; break;
+      case E_Conversion: case E_Transform: go = !(F.vlo & V_INVULNERABLE); break;
+      case E_LeechSeed: go = !has_type(ft, T_Grass); need_hit = true; break;
+      case E_Mimic: need_hit = true; break;
+      case E_Paralyze: go = fs == 0 && !type_immune; need_hit = true; break;
+      case E_Poison: go = fs == 0 && !has_type(ft, T_Poison) && !(F.vlo & V_SUBSTITUTE); need_hit = true; break;
+      case E_SwitchAndTeleport: need_hit = move_id != M_Teleport; break;
+      case E_AccuracyDown1: case E_AttackDown1: case E_DefenseDown1: case E_DefenseDown2: case E_SpeedDown1:
+        go = !(F.vlo & V_SUBSTITUTE); need_hit = true; break;
+      case E_Sleep:
+        if (F.vlo & V_RECHARGING) { F.vlo &= ~V_RECHARGING; go = !(fs & ST_SLP); } // always lands on a recharging target
+        else { go = fs == 0; need_hit = true; }
+        break;
+      case E_Disable: go = disable_move(F) == 0; need_hit = true; break;
+      default: break; // self-targeting effects
       }
+    } else {
+      bool immune = !fixed && type_immune;
+      if (eff == E_DreamEater && !(fs & ST_SLP)) immune = true;
+      if (ohko && spe(S) < spe(F)) immune = true;
+      if (move_id == M_Counter && (!lm_counterable(fap) || last_damage == 0)) immune = true;
+      go = !immune;
+      need_hit = true;
+    }
+    // -- stage 2: THE accuracy check ------------------------------------------------------------------
+    bool hit = true;
+    if (go && need_hit) hit = move_hit(mv);
+    if (!(go && hit)) {
+      if (damaging) {
+        last_damage = 0;
+        clear_binding(S);
+        if (eff == E_Explode) { set_hp(S, 0); set_status(S, 0); }
+        if (eff == E_JumpKick && go) { const uint32_t h = hp(S); if (h > 0) set_hp(S, h - 1); } // crash: 1 HP
+      }
+      return;
+    }
+    // -- stage 3: effect bodies (no accuracy checks, no shared machinery inside) ------------------------
+    if (!damaging) {
+      switch (eff) {
+      case E_Confusion: want_conf = !(F.vlo & V_CONFUSION); break;
+      case E_Conversion: S.a2 = (S.a2 & 0x00FFFFFFu) | (F.a2 & 0xFF000000u); break;
+      case E_FocusEnergy: S.vlo |= V_FOCUSENERGY; break;
+      case E_Haze: {
+        S.bo = 0;
+        F.bo = 0;
+        unmodified_to_active(S);
+        unmodified_to_active(F);
+        if (fs) {
+          if (fs & ST_SLP) dset(F, 0, 3, 0);
+          set_status(F, 0);
+        }
+        if (status(S) == ST_TOX) set_status(S, ST_PSN);
+        haze_clear(S);
+        haze_clear(F);
+        break;
+      }
+      case E_Heal: {
+        const uint32_t mx = maxhp(S), h = hp(S), delta = mx - h;
+        if (delta == 0 || (delta & 255) == 255) break; // gen-1 recovery failure glitch
+        if (move_id == M_Rest) {
+          set_status(S, ST_EXT | 2);
+          dset(S, 0, 3, 0);
+          set_hp(S, mx);
+          S.vlo &= ~V_TOXIC;
+          set_toxic_ctr(S, 0);
+        } else {
+          const uint32_t nh = h + mx / 2;
+          set_hp(S, nh > mx ? mx : nh);
+        }
+        break;
+      }
+      case E_LeechSeed: F.vlo |= V_LEECHSEED; break; // already seeded: no-op
+      case E_LightScreen: S.vlo |= V_LIGHTSCREEN; break;
+      case E_Reflect: S.vlo |= V_REFLECT; break;
+      case E_Mist: S.vlo |= V_MIST; break;
+      case E_Mimic: {
+        uint32_t n = 0;
+        for (uint32_t i = 1; i <= 4; ++i) n += (active_move(F, i) & 0xFF) != 0;
+        if (n == 0 || mslot == 0) break;
+        const uint32_t r = rng_range(0, n);
+        act_set(true, AC_MOVESLOT, 4, r + 1);
+        const uint64_t nid = active_move(F, r + 1) & 0xFF;
+        const uint32_t sh = 16 * (mslot - 1);
+        set_amoves(S, (amoves(S) & ~(0xFFull << sh)) | (nid << sh));
+        break;
+      }
+      case E_Paralyze: want_status = ST_PAR; break;
+      case E_Poison:
+        if (move_id == M_Toxic) { set_status(F, ST_TOX); F.vlo |= V_TOXIC; set_toxic_ctr(F, 0); }
+        else set_status(F, ST_PSN);
+        break;
+      case E_Substitute: {
+        if (S.vlo & V_SUBSTITUTE) break;
+        const uint32_t cost = maxhp(S) / 4, h = hp(S);
+        if (h < cost) break;
+        set_hp(S, h - cost); // exactly a quarter left: the user faints (gen-1 behaviour)
+        set_sub_hp(S, cost + 1);
+        S.vlo |= V_SUBSTITUTE;
+        break;
+      }
+      case E_Transform: {
+        const uint32_t id = (F.vlo & V_TRANSFORM) ? transform_id(F) : ((absp(F) << 3) | order0(F));
+        S.vlo |= V_TRANSFORM;
+        set_transform_id(S, id);
+        S.a0 = F.a0; S.a1 = F.a1; S.a2 = F.a2; S.bo = F.bo;
+        const uint64_t fm = amoves(F);
+        uint64_t nm = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const uint64_t mid = (fm >> (16 * i)) & 0xFF;
+          nm |= (mid | ((mid ? 5ull : 0ull) << 8)) << (16 * i);
+        }
+        set_amoves(S, nm);
+        break;
+      }
+      case E_AttackUp1: case E_AttackUp2: b_idx = 0; b_n = eff == E_AttackUp2 ? 2 : 1; break;
+      case E_DefenseUp1: case E_DefenseUp2: b_idx = 1; b_n = eff == E_DefenseUp2 ? 2 : 1; break;
+      case E_SpeedUp2: b_idx = 2; b_n = 2; break;
+      case E_SpecialUp1: case E_SpecialUp2: b_idx = 3; b_n = eff == E_SpecialUp2 ? 2 : 1; break;
+      case E_EvasionUp1: b_idx = 5; break;
       case E_Bide:
         S.vlo |= V_BIDE;
         set_vstate(S, 0);
         set_attacks(S, rng_range(2, 4));
         dset(S, 25, 3, 1);
         act_set(true, AC_ATTACKING, 2, OBS_STARTED);
-        return;
-      case E_AccuracyDown1: case E_AttackDown1: case E_DefenseDown1: case E_DefenseDown2: case E_SpeedDown1: {
-        if (F.vlo & V_SUBSTITUTE) return;
-        if (!move_hit(mv)) return;
-        const int idx = eff == E_AccuracyDown1 ? 4 : eff == E_AttackDown1 ? 0 : eff == E_SpeedDown1 ? 2 : 1;
-        unboost_foe(idx, eff == E_DefenseDown2 ? 2 : 1);
-        return;
-      }
-      case E_Sleep: {
-        const uint32_t fs = status(F);
-        if (F.vlo & V_RECHARGING) {
-          F.vlo &= ~V_RECHARGING;
-          if (fs & ST_SLP) return;
-        } else {
-          if (fs) return;
-          if (!move_hit(mv)) return;
-        }
+        break;
+      case E_AccuracyDown1: ub_idx = 4; break;
+      case E_AttackDown1: ub_idx = 0; break;
+      case E_DefenseDown1: ub_idx = 1; break;
+      case E_DefenseDown2: ub_idx = 1; ub_n = 2; break;
+      case E_SpeedDown1: ub_idx = 2; break;
+      case E_Sleep:
         set_status(F, rng_range(1, 8));
         dset(F, 0, 3, 1);
         act_set(false, AC_SLEEP, 2, OBS_STARTED);
-        return;
-      }
+        break;
       case E_Disable: {
-        if (disable_move(F) != 0) return;
-        if (!move_hit(mv)) return;
         uint32_t n = 0, packed = 0;
         for (uint32_t i = 1; i <= 4; ++i) {
           const uint32_t ms = active_move(F, i);
           if ((ms & 0xFF) && (ms >> 8)) { packed |= i << (4 * n); ++n; }
         }
-        if (n == 0) return;
+        if (n == 0) break;
         const uint32_t slot = (packed >> (4 * rng_range(0, n))) & 15;
         act_set(true, AC_MOVESLOT, 4, slot);
         set_disable_move(F, slot);
         set_disable_left(F, rng_range(1, 9));
         dset(F, 21, 4, 1);
         act_set(false, AC_DISABLE, 2, OBS_STARTED);
+        break;
+      }
+      default: break; // Splash, SwitchAndTeleport, unknown
+      }
+    } else {
+      // -- stage 4: damage ---------------------------------------------------------------------------
+      if (fixed) {
+        uint32_t dd;
+        if (move_id == M_Counter) { dd = last_damage * 2; if (dd > 65535) dd = 65535; }
+        else if (eff == E_SuperFang) { dd = hp(F) / 2; if (dd < 1) dd = 1; }
+        else if (move_id == M_SonicBoom) dd = 20;
+        else if (move_id == M_DragonRage) dd = 40;
+        else if (move_id == M_Psywave) {
+          const uint32_t max = level(S) * 3 / 2;
+          dd = max <= 1 ? 1 : rng_range(1, max);
+          act_set(true, AC_PSYWAVE, 8, dd);
+        } else dd = level(S); // SeismicToss, NightShade
+        last_damage = dd;
+      } else if (ohko) {
+        last_damage = 65535;
+      } else {
+        const bool crit = check_crit(mv);
+        if (!calc_damage(F, mv.bp(), mtype, eff == E_Explode, crit)) return;
+        adjust_damage(mv);
+        randomize_damage();
+        if (last_damage == 0) { clear_binding(S); return; } // rounded down to nothing
+      }
+      uint32_t hits = 1;
+      if (eff == E_DoubleHit || eff == E_Twineedle) hits = 2;
+      else if (eff == E_MultiHit) {
+        hits = (0x54333222u >> (4 * rng_range(0, 8))) & 15; // {2,2,2,3,3,3,4,5}
+        act_set(true, AC_MULTIHIT, 4, hits);
+      }
+      bool broke = false, hit_sub = false;
+      uint32_t dealt = 0, rage_hits = 0;
+      const uint32_t per_hit = last_damage;
+      for (uint32_t h = 0; h < hits; ++h) {
+        last_damage = per_hit;
+        broke = apply_damage(F, F, hit_sub);
+        dealt = last_damage;
+        if (!hit_sub) {
+          if (F.vlo & V_BIDE) set_vstate(F, (vstate(F) + dealt) & 0xFFFF);
+          if ((F.vlo & V_RAGE) && hp(F) > 0) ++rage_hits;
+        }
+        if (broke || hp(F) == 0) break;
+      }
+      // rage builds once per hit taken; nothing between the hits reads the attacker's stats, so the stage
+      // changes (and their stat-modification side effect on S) can be applied after the loop
+      for (uint32_t k = 0; k < rage_hits; ++k) (void)boost_side(F, S, 0, 1);
+      set_lm_counterable(sap, (mtype == T_Normal || mtype == T_Fighting) && move_id != M_Counter);
+      if (eff == E_Explode && !broke) { set_hp(S, 0); set_status(S, 0); }
+      if (eff == E_Recoil && !broke && dealt > 0) {
+        uint32_t r = dealt / (move_id == M_Struggle ? 2u : 4u); if (r < 1) r = 1;
+        const uint32_t h = hp(S);
+        set_hp(S, r > h ? 0 : h - r);
+      }
+      if ((eff == E_DrainHP || eff == E_DreamEater) && dealt > 0) {
+        uint32_t h = dealt / 2; if (h < 1) h = 1;
+        h += hp(S);
+        const uint32_t mx = maxhp(S);
+        set_hp(S, h > mx ? mx : h);
+      }
+      if (hp(F) == 0 || broke) return; // no secondary effects, no recharge, no binding
+      if (eff == E_HyperBeam) { S.vlo |= V_RECHARGING; return; }
+      if (eff == E_Binding) {
+        if (!(S.vlo & V_BINDING)) {
+          const uint32_t n = (0x54333222u >> (4 * rng_range(0, 8))) & 15;
+          S.vlo |= V_BINDING;
+          set_attacks(S, n - 1);
+          dset(S, 28, 3, 1);
+          act_set(true, AC_BINDING, 3, OBS_STARTED);
+        }
         return;
       }
-      default: return;
+      if (hit_sub) return; // a standing substitute blocks every secondary effect
+      // secondary-effect parameters; the roll itself happens at the shared site below
+      uint32_t st = 0, num = 0;
+      switch (eff) {
+      case E_BurnChance1: st = ST_BRN; num = 26; break;
+      case E_BurnChance2: st = ST_BRN; num = 77; break;
+      case E_FreezeChance: st = ST_FRZ; num = 26; break;
+      case E_ParalyzeChance1: st = ST_PAR; num = 26; break;
+      case E_ParalyzeChance2: st = ST_PAR; num = 77; break;
+      case E_PoisonChance1: case E_Twineedle: st = ST_PSN; num = 52; break;
+      case E_PoisonChance2: st = ST_PSN; num = 103; break;
+      case E_FlinchChance1: sec_kind = SEC_FLINCH; sec_chance = 26; break;
+      case E_FlinchChance2: sec_kind = SEC_FLINCH; sec_chance = 77; break;
+      case E_ConfusionChance: if (!(F.vlo & V_CONFUSION)) { sec_kind = SEC_CONF; sec_chance = 25; } break;
+      case E_AttackDownChance: case E_DefenseDownChance: case E_SpeedDownChance: case E_SpecialDownChance:
+        sec_kind = SEC_UNBOOST; sec_chance = 85; sec_idx = (int)eff - (int)E_AttackDownChance; break;
+      default: break;
+      }
+      if (st) {
+        const uint32_t fs2 = status(F);
+        if (st == ST_BRN && (fs2 & ST_FRZ)) set_status(F, 0); // fire thaws
+        else if (fs2 == 0 && !has_type(types(F), st == ST_PSN ? (uint32_t)T_Poison : mtype)) { sec_kind = SEC_STATUS; sec_status = st; sec_chance = num; }
       }
     }
-
-    const bool fixed = eff == E_SpecialDamage || eff == E_SuperFang || move_id == M_Counter;
-    const bool ohko = eff == E_OHKO;
-    const uint32_t ft = types(F);
-    bool immune = false;
-    if (!fixed) immune = chart(mv.type(), ft & 15) == 0 || chart(mv.type(), ft >> 4) == 0;
-    if (eff == E_DreamEater && !(status(F) & ST_SLP)) immune = true;
-    if (ohko && spe(S) < spe(F)) immune = true;
-    if (move_id == M_Counter && (!lm_counterable(fap) || last_damage == 0)) immune = true;
-    bool hit = false;
-    if (!immune) hit = move_hit(mv);
-    if (immune || !hit) {
-      last_damage = 0;
-      clear_binding(S);
-      if (eff == E_Explode) { set_hp(S, 0); set_status(S, 0); }
-      if (eff == E_JumpKick && !immune) { const uint32_t h = hp(S); if (h > 0) set_hp(S, h - 1); }
-      return;
-    }
-
-    if (fixed) {
-      uint32_t d;
-      if (move_id == M_Counter) { d = last_damage * 2; if (d > 65535) d = 65535; }
-      else if (eff == E_SuperFang) { d = hp(F) / 2; if (d < 1) d = 1; }
-      else if (move_id == M_SonicBoom) d = 20;
-      else if (move_id == M_DragonRage) d = 40;
-      else if (move_id == M_Psywave) {
-        const uint32_t max = level(S) * 3 / 2;
-        d = max <= 1 ? 1 : rng_range(1, max);
-        act_set(true, AC_PSYWAVE, 8, d);
-      } else d = level(S);
-      last_damage = d;
-    } else if (ohko) {
-      last_damage = 65535;
-    } else {
-      const bool crit = check_crit(mv);
-      if (!calc_damage(F, mv.bp(), mv.type(), eff == E_Explode, crit)) return;
-      adjust_damage(mv);
-      randomize_damage();
-      if (last_damage == 0) { clear_binding(S); return; }
-    }
-
-    uint32_t hits = 1;
-    if (eff == E_DoubleHit || eff == E_Twineedle) hits = 2;
-    else if (eff == E_MultiHit) {
-      hits = (0x54333222u >> (4 * rng_range(0, 8))) & 15;
-      act_set(true, AC_MULTIHIT, 4, hits);
-    }
-
-    bool broke = false, hit_sub = false;
-    uint32_t dealt = 0;
-    const uint32_t per_hit = last_damage;
-    for (uint32_t h = 0; h < hits; ++h) {
-      last_damage = per_hit;
-      broke = apply_damage(F, F, hit_sub);
-      dealt = last_damage;
-      if (!hit_sub) {
-        if (F.vlo & V_BIDE) set_vstate(F, (vstate(F) + dealt) & 0xFFFF);
-        if ((F.vlo & V_RAGE) && hp(F) > 0) (void)boost_side(F, S, 0, 1); // rage builds
+    // -- stage 5: THE secondary-effect roll ------------------------------------------------------------
+    if (sec_kind != SEC_NONE) {
+      const bool proc = rng_chance(sec_chance);
+      act_bool(true, AC_SECONDARY, proc);
+      if (proc) {
+        if (sec_kind == SEC_STATUS) want_status = sec_status;
+        else if (sec_kind == SEC_FLINCH) F.vlo |= V_FLINCH;
+        else if (sec_kind == SEC_CONF) want_conf = true;
+        else { ub_idx = sec_idx; ub_n = 1; }
       }
-      if (broke || hp(F) == 0) break;
     }
-    set_lm_counterable(sap, (mv.type() == T_Normal || mv.type() == T_Fighting) && move_id != M_Counter);
-
-    if (eff == E_Explode && !broke) { set_hp(S, 0); set_status(S, 0); }
-    if (eff == E_Recoil && !broke && dealt > 0) {
-      uint32_t r = dealt / (move_id == M_Struggle ? 2u : 4u); if (r < 1) r = 1;
-      const uint32_t h = hp(S);
-      set_hp(S, r > h ? 0 : h - r);
+    // -- stage 6: single sites for status / confusion / stat stages ---------------------------------------
+    if (want_status) {
+      set_status(F, want_status);
+      if (want_status == ST_PAR) { const uint32_t sp2 = spe(F) / 4; set_astat(F, 2, sp2 < 1 ? 1 : sp2); }
+      if (want_status == ST_BRN) { const uint32_t at2 = (F.a0 >> 16) / 2; set_astat(F, 0, at2 < 1 ? 1 : at2); }
     }
-    if ((eff == E_DrainHP || eff == E_DreamEater) && dealt > 0) {
-      uint32_t h = dealt / 2; if (h < 1) h = 1;
-      h += hp(S);
-      const uint32_t mx = maxhp(S);
-      set_hp(S, h > mx ? mx : h);
-    }
-    if (hp(F) == 0 || broke) return;
-    if (eff == E_HyperBeam) { S.vlo |= V_RECHARGING; return; }
-    if (eff == E_Binding) {
-      if (!(S.vlo & V_BINDING)) {
-        const uint32_t n = (0x54333222u >> (4 * rng_range(0, 8))) & 15;
-        S.vlo |= V_BINDING;
-        set_attacks(S, n - 1);
-        dset(S, 28, 3, 1);
-        act_set(true, AC_BINDING, 3, OBS_STARTED);
-      }
-      return;
-    }
-    if (hit_sub) return;
-    switch (eff) {
-    case E_BurnChance1: secondary_status(mv, ST_BRN, 26); break;
-    case E_BurnChance2: secondary_status(mv, ST_BRN, 77); break;
-    case E_FreezeChance: secondary_status(mv, ST_FRZ, 26); break;
-    case E_ParalyzeChance1: secondary_status(mv, ST_PAR, 26); break;
-    case E_ParalyzeChance2: secondary_status(mv, ST_PAR, 77); break;
-    case E_PoisonChance1: secondary_status(mv, ST_PSN, 52); break;
-    case E_PoisonChance2: secondary_status(mv, ST_PSN, 103); break;
-    case E_Twineedle: secondary_status(mv, ST_PSN, 52); break;
-    case E_FlinchChance1: case E_FlinchChance2: {
-      const bool proc = rng_chance(eff == E_FlinchChance1 ? 26 : 77);
-      act_bool(true, AC_SECONDARY, proc);
-      if (proc) F.vlo |= V_FLINCH;
-      break;
-    }
-    case E_ConfusionChance: {
-      if (F.vlo & V_CONFUSION) break;
-      const bool proc = rng_chance(25);
-      act_bool(true, AC_SECONDARY, proc);
-      if (proc) start_confusion(F, false);
-      break;
-    }
-    case E_AttackDownChance: case E_DefenseDownChance: case E_SpeedDownChance: case E_SpecialDownChance: {
-      const bool proc = rng_chance(85);
-      act_bool(true, AC_SECONDARY, proc);
-      if (proc) unboost_foe((int)eff - (int)E_AttackDownChance, 1);
-      break;
-    }
-    default: break;
-    }
+    if (want_conf) start_confusion(F, false);
+    if (ub_idx >= 0) (void)unboost_foe(ub_idx, ub_n);
+    if (b_idx >= 0) (void)boost_side(S, F, b_idx, b_n);
   }
 
   __device__ void execute_selected(uint32_t mslot, bool skip_can, bool skip_pp) {
@@ -996,7 +984,7 @@ struct EngineR {
           set_last_sel(S, mm);
           continue;
         }
-        if (eff >= E_Confusion && eff <= E_Transform) { on_begin(mv, move_id, mslot); return; }
+        if (eff >= E_Confusion && eff <= E_Transform) break;
         if (eff == E_Thrashing) {
           S.vlo |= V_THRASHING;
           set_attacks(S, rng_range(2, 4));
@@ -1008,7 +996,7 @@ struct EngineR {
         break;
       }
     }
-    do_move();
+    run_move(mslot);
   }
 
   __device__ bool execute_move(uint32_t choice, bool &err) {
