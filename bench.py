@@ -7,7 +7,7 @@ One *step* = one pass of the rollout kernel over one whole batch; inputs (battle
 durations, per-lane fast_prng state) are generated ON DEVICE before the timed region and
 stay resident in HBM; the per-lane choice-RNG stream continues from pass to pass, so every
 step plays different playouts.  Steps are independent batches (as in root-parallel MCTS), so
-they are issued round-robin on `--streams` HIP streams (default 12, each with its own batch
+they are issued round-robin on `--streams` HIP streams (default 20, each with its own batch
 buffers): a batch's long tail (0.1% of playouts run to the 1000-step cap on a handful of
 waves) then overlaps the next batches instead of idling the GPU.  `--streams 1` gives the
 strictly serial latency figure quoted in DESIGN.md.
@@ -30,7 +30,7 @@ import os
 import sys
 import time
 
-os.environ.setdefault("GPU_MAX_HW_QUEUES", os.environ.get("BENCH_HWQ", "24"))   # let every in-flight batch have its own hardware queue
+os.environ.setdefault("GPU_MAX_HW_QUEUES", os.environ.get("BENCH_HWQ", "32"))   # let every in-flight batch have its own hardware queue
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -44,10 +44,10 @@ MAX_STEPS = 1000
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=96)
-    ap.add_argument("--warmup", type=int, default=12)
+    ap.add_argument("--steps", type=int, default=160)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=65536, help="playouts per GPU")
-    ap.add_argument("--streams", type=int, default=12, help="independent batches in flight (HIP streams)")
+    ap.add_argument("--streams", type=int, default=20, help="independent batches in flight (HIP streams)")
     ap.add_argument("--playouts-per-lane", type=int, default=2,
                     help="k > 1: persistent n/k lanes per batch that refill from an atomic playout queue")
     ap.add_argument("--workload", choices=["rollout", "leaf"], default="rollout",

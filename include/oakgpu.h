@@ -41,10 +41,14 @@ int oakgpu_set_stream(oakgpu_ctx *ctx, void *hip_stream);
 /* The hipStream_t all *_dev launches of this context go to (own stream unless oakgpu_set_stream was called). */
 void *oakgpu_get_stream(oakgpu_ctx *ctx);
 int oakgpu_synchronize(oakgpu_ctx *ctx);
-/* Rollout scheduling: k = 1 (default) launches one lane per playout; k > 1 launches n/k persistent lanes
- * that refill from an atomic playout queue as playouts finish (same results, better lane utilisation
- * when several batches share the GPU). */
+/* Rollout scheduling (results never depend on it).  k = 1 launches one lane per playout; k > 1 (default 2)
+ * launches n/k persistent lanes that refill from an atomic playout queue as playouts finish. */
 int oakgpu_set_playouts_per_lane(oakgpu_ctx *ctx, int k);
+/* Regrouping of the queue schedule's long tail: the rollout runs as `rounds` dispatches (1..8, default 4); in
+ * every round but the last a wave whose queue is dry and that has fewer than `suspend_below` (0..64, default 32)
+ * playouts still running parks them (bit-exact state image) for the next round, which packs them 64 to a wave
+ * again on 1/`shrink` (>= 1, default 3) of the waves.  rounds = 1 or suspend_below = 0 disables it. */
+int oakgpu_set_regroup(oakgpu_ctx *ctx, int rounds, int suspend_below, int shrink);
 int oakgpu_device_count(void);
 
 /* ---- rollout: replaces MCTS::Search::init_stats_and_rollout (search/mcts.h:448-496) and,

@@ -8,7 +8,7 @@ LIB_PATH = os.path.join(_HERE, "liboakgpu.so")
 
 # every symbol include/oakgpu.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
-    "oakgpu_create", "oakgpu_destroy", "oakgpu_last_error", "oakgpu_set_stream", "oakgpu_get_stream", "oakgpu_synchronize", "oakgpu_set_playouts_per_lane",
+    "oakgpu_create", "oakgpu_destroy", "oakgpu_last_error", "oakgpu_set_stream", "oakgpu_get_stream", "oakgpu_synchronize", "oakgpu_set_playouts_per_lane", "oakgpu_set_regroup",
     "oakgpu_device_count", "oakgpu_rollout_dev", "oakgpu_rollout", "oakgpu_update_dev", "oakgpu_update",
     "oakgpu_choices_dev", "oakgpu_choices", "oakgpu_init_battles_dev", "oakgpu_init_battles",
     "oakgpu_set_ou_pools", "oakgpu_random_ou_battles_dev",
@@ -48,6 +48,7 @@ def load():
     lib.oakgpu_get_stream.restype = vp
     lib.oakgpu_synchronize.argtypes = [vp]
     lib.oakgpu_set_playouts_per_lane.argtypes = [vp, i32]
+    lib.oakgpu_set_regroup.argtypes = [vp, i32, i32, i32]
     lib.oakgpu_rollout_dev.argtypes = [vp, vp, vp, vp, vp, u32, u32, i32, vp, vp, vp, vp, vp]
     lib.oakgpu_rollout.argtypes = [vp, vp, vp, vp, vp, u32, u32, i32, vp, vp, vp, vp, vp]
     lib.oakgpu_update_dev.argtypes = [vp, vp, vp, vp, vp, vp, vp, u32, vp]

@@ -22,6 +22,60 @@
 
 namespace oak {
 
+// ---- optional region profile (tools/site_profile.sh builds a separate library with -DOAKGPU_SITE_PROFILE).
+// Per region: passes, active lanes summed over passes, wave cycles, lane-weighted cycles.  A "pass" is one
+// trip of (part of) a wave through the region, so lanes / (64 * passes) is the region's SIMT efficiency and
+// cycles its share of the wave's time.  Compiles to nothing in the product build.
+#ifdef OAKGPU_SITE_PROFILE
+static __device__ unsigned long long g_site_prof[32 * 4];
+// one wave per block in the profiled kernel: accumulate in LDS (cheap), flush once per wave at exit
+__device__ __forceinline__ unsigned long long *site_lds() {
+  __shared__ unsigned long long s_prof[32 * 4];
+  return s_prof;
+}
+__device__ __forceinline__ void site_zero() {
+  unsigned long long *p = site_lds();
+  for (int i = threadIdx.x; i < 32 * 4; i += blockDim.x) p[i] = 0;
+  __syncthreads();
+}
+__device__ __forceinline__ void site_flush() {
+  __syncthreads();
+  unsigned long long *p = site_lds();
+  for (int i = threadIdx.x; i < 32 * 4; i += blockDim.x) if (p[i]) atomicAdd(&g_site_prof[i], p[i]);
+}
+__device__ __forceinline__ void site_add(int id, long long dt) {
+  const uint64_t ex = __ballot(1);
+  const uint32_t lane = __lane_id();
+  if ((ex & ((1ull << lane) - 1)) == 0) {
+    unsigned long long *p = site_lds(); // ds_add_u64 without return: fire and forget
+    __hip_atomic_fetch_add(&p[id * 4 + 0], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __hip_atomic_fetch_add(&p[id * 4 + 1], (unsigned long long)__popcll(ex), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __hip_atomic_fetch_add(&p[id * 4 + 2], (unsigned long long)dt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __hip_atomic_fetch_add(&p[id * 4 + 3], (unsigned long long)dt * __popcll(ex), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  }
+}
+struct SiteScope {
+  int id; long long t0;
+  __device__ __forceinline__ SiteScope(int i) : id(i), t0(clock64()) {}
+  __device__ __forceinline__ ~SiteScope() { site_add(id, clock64() - t0); }
+};
+#define OAK_SCOPE(id) SiteScope oak_scope_##id(id)
+#define OAK_T0(v) long long v = clock64()
+#define OAK_T1(id, v) site_add(id, clock64() - v)
+#define OAK_PROF_ZERO() site_zero()
+#define OAK_PROF_FLUSH() site_flush()
+#else
+#define OAK_SCOPE(id)
+#define OAK_T0(v)
+#define OAK_T1(id, v)
+#define OAK_PROF_ZERO()
+#define OAK_PROF_FLUSH()
+#endif
+// region ids
+enum { PS_REFILL = 0, PS_STEP, PS_LEGAL_DRAW, PS_ORDER, PS_EXEC_MOVE, PS_SWITCH_IN, PS_BEFORE_MOVE, PS_EXEC_SELECTED_PRE,
+       PS_RUN_MOVE, PS_GATES_HIT, PS_STATUS_BODIES, PS_DAMAGE, PS_SECONDARY_APPLY, PS_FAINT_RESIDUAL, PS_PUBLISH,
+       PS_CALC_DAMAGE, PS_APPLY_HITS, PS_DAMAGE_TAIL, PS_COUNT };
+
 struct SideR {
   uint32_t a0, a1, a2; // active: hp|atk<<16, def|spe<<16, spc|species<<16|types<<24
   uint32_t bo;         // boosts nibbles: atk def | spe spc | acc eva
@@ -658,6 +712,8 @@ struct EngineR {
   enum : uint32_t { SEC_NONE = 0, SEC_STATUS = 1, SEC_FLINCH = 2, SEC_CONF = 3, SEC_UNBOOST = 4 };
 
   __device__ void run_move(uint32_t mslot) {
+    OAK_SCOPE(PS_RUN_MOVE);
+    OAK_T0(t_g);
     const uint32_t move_id = last_sel(S);
     const Move mv = move_data(move_id);
     const uint32_t eff = mv.effect(), mtype = mv.type();
@@ -707,6 +763,7 @@ struct EngineR {
     // -- stage 2: THE accuracy check ------------------------------------------------------------------
     bool hit = true;
     if (go && need_hit) hit = move_hit(mv);
+    OAK_T1(PS_GATES_HIT, t_g);
     if (!(go && hit)) {
       if (damaging) {
         last_damage = 0;
@@ -718,6 +775,7 @@ struct EngineR {
     }
     // -- stage 3: effect bodies (no accuracy checks, no shared machinery inside) ------------------------
     if (!damaging) {
+      OAK_SCOPE(PS_STATUS_BODIES);
       switch (eff) {
       case E_Confusion: want_conf = !(F.vlo & V_CONFUSION); break;
       case E_Conversion: S.a2 = (S.a2 & 0x00FFFFFFu) | (F.a2 & 0xFF000000u); break;
@@ -836,6 +894,8 @@ struct EngineR {
       }
     } else {
       // -- stage 4: damage ---------------------------------------------------------------------------
+      OAK_SCOPE(PS_DAMAGE);
+      OAK_T0(t_cd);
       if (fixed) {
         uint32_t dd;
         if (move_id == M_Counter) { dd = last_damage * 2; if (dd > 65535) dd = 65535; }
@@ -863,6 +923,8 @@ struct EngineR {
         hits = (0x54333222u >> (4 * rng_range(0, 8))) & 15; // {2,2,2,3,3,3,4,5}
         act_set(true, AC_MULTIHIT, 4, hits);
       }
+      OAK_T1(PS_CALC_DAMAGE, t_cd);
+      OAK_T0(t_ah);
       bool broke = false, hit_sub = false;
       uint32_t dealt = 0, rage_hits = 0;
       const uint32_t per_hit = last_damage;
@@ -878,6 +940,8 @@ struct EngineR {
       }
       // rage builds once per hit taken; nothing between the hits reads the attacker's stats, so the stage
       // changes (and their stat-modification side effect on S) can be applied after the loop
+      OAK_T1(PS_APPLY_HITS, t_ah);
+      OAK_SCOPE(PS_DAMAGE_TAIL);
       for (uint32_t k = 0; k < rage_hits; ++k) (void)boost_side(F, S, 0, 1);
       set_lm_counterable(sap, (mtype == T_Normal || mtype == T_Fighting) && move_id != M_Counter);
       if (eff == E_Explode && !broke) { set_hp(S, 0); set_status(S, 0); }
@@ -929,6 +993,7 @@ struct EngineR {
       }
     }
     // -- stage 5: THE secondary-effect roll ------------------------------------------------------------
+    OAK_SCOPE(PS_SECONDARY_APPLY);
     if (sec_kind != SEC_NONE) {
       const bool proc = rng_chance(sec_chance);
       act_bool(true, AC_SECONDARY, proc);
@@ -952,6 +1017,7 @@ struct EngineR {
 
   __device__ void execute_selected(uint32_t mslot, bool skip_can, bool skip_pp) {
     const uint32_t sap = absp(S);
+    OAK_T0(t_pre);
     if (!skip_can) {
 #pragma unroll 1
       for (int depth = 0; depth < 4; ++depth) {
@@ -996,21 +1062,8 @@ struct EngineR {
         break;
       }
     }
+    OAK_T1(PS_EXEC_SELECTED_PRE, t_pre);
     run_move(mslot);
-  }
-
-  __device__ bool execute_move(uint32_t choice, bool &err) {
-    const uint32_t type = choice & 3;
-    if (type == C_SWITCH) { switch_in(S, F, choice >> 2); return false; }
-    if (type == C_PASS) return false;
-    uint32_t mslot = choice >> 2;
-    if (last_sel(S) == M_Struggle) mslot = 0;
-    else if (mslot == 0) mslot = lm_index(absp(S));
-    const int r = before_move();
-    if (r == BM_ERR) { err = true; return true; }
-    if (r == BM_DONE) return true;
-    execute_selected(mslot, r == BM_SKIP_CAN, r == BM_SKIP_PP);
-    return true;
   }
 
   __device__ void handle_residual() {
@@ -1075,10 +1128,48 @@ struct EngineR {
     if constexpr (TRACK_ACTIONS) { uint64_t t = flipped ? actF : actS; actF = flipped ? actS : actF; actS = t; }
   }
 
+  // ---- one player's action = pre-state, the action itself, faint / residual checks.  Returns the turn's
+  // result if the action ended it (a faint -> forced switch or game over, or an engine error), else 0.
+  // Switches and passes are the cheap actions; moves go through before_move / execute_selected / run_move.
+  __device__ __forceinline__ uint32_t post_action(uint32_t choice, bool replace, bool residual) {
+    OAK_SCOPE(PS_FAINT_RESIDUAL);
+    if (replace) return 0;
+    uint32_t r = 0;
+    if ((choice & 3) != C_SWITCH) r = check_faint(F, S);
+    if (r == 0) {
+      if (residual) handle_residual();
+      r = check_faint(S, F);
+    }
+    return r;
+  }
+  __device__ __forceinline__ uint32_t act_cheap(uint32_t choice) { // C_SWITCH or C_PASS
+    const bool replace = hp(S) == 0;
+    if ((choice & 3) == C_SWITCH) { OAK_SCOPE(PS_SWITCH_IN); switch_in(S, F, choice >> 2); }
+    return post_action(choice, replace, false);
+  }
+  __device__ __forceinline__ uint32_t act_move(uint32_t choice) { // C_MOVE
+    OAK_T0(t_em);
+    const bool replace = hp(S) == 0;
+    uint32_t mslot = choice >> 2;
+    if (last_sel(S) == M_Struggle) mslot = 0;
+    else if (mslot == 0) mslot = lm_index(absp(S));
+    OAK_T0(t_bm);
+    const int r = before_move();
+    OAK_T1(PS_BEFORE_MOVE, t_bm);
+    if (r == BM_ERR) return mk_result(R_ERROR, 0, 0);
+    if (r != BM_DONE) execute_selected(mslot, r == BM_SKIP_CAN, r == BM_SKIP_PP);
+    OAK_T1(PS_EXEC_MOVE, t_em);
+    return post_action(choice, replace, true);
+  }
+
   // ---- pkmn_gen1_battle_update in FRAME terms: cS / cF are the choices of whoever currently sits in S / F
   // (absp() tells which player that is).  The frame is left wherever the turn ends -- callers that need
   // S = P1 call normalize().  Skipping the per-turn normalisation saves a 54-instruction conditional swap.
-  __device__ uint32_t update_frame(uint32_t cS, uint32_t cF) {
+  //
+  // turn_prologue: selection + who acts first; leaves the first actor in S and returns its choice in `pc`,
+  // the second actor's in `qc`.  A non-zero return value is the result of a turn that is already over
+  // (turn 0: both leads are sent out).
+  __device__ __forceinline__ uint32_t turn_prologue(uint32_t cS, uint32_t cF, uint32_t &pc, uint32_t &qc) {
     if constexpr (TRACK_ACTIONS) { actS = 0; actF = 0; }
     if (turn == 0) {
       const bool aS = (S.misc & 63) != 0, aF = (F.misc & 63) != 0;
@@ -1089,6 +1180,7 @@ struct EngineR {
       for (int k = 0; k < 2; ++k) { switch_in(S, F, 1); swap_sides(S, F); } // both leads, one copy of the code
       return end_turn();
     }
+    OAK_T0(t_ord);
     select_move(S, cS);
     select_move(F, cF);
     bool f_first;
@@ -1116,32 +1208,35 @@ struct EngineR {
         }
       }
     }
-    uint32_t pc = f_first ? cF : cS, qc = f_first ? cS : cF;
+    pc = f_first ? cF : cS;
+    qc = f_first ? cS : cF;
     cswap_sides(f_first, S, F);
     if constexpr (TRACK_ACTIONS) { uint64_t t = f_first ? actF : actS; actF = f_first ? actS : actF; actS = t; }
-#pragma unroll 1
-    for (int k = 0; k < 2; ++k) {
-      bool err = false;
-      const bool replace = hp(S) == 0;
-      const bool residual = execute_move(pc, err);
-      if (err) return mk_result(R_ERROR, 0, 0);
-      if (!replace) {
-        uint32_t r = 0;
-        if ((pc & 3) != C_SWITCH) r = check_faint(F, S);
-        if (r == 0) {
-          if (residual) handle_residual();
-          r = check_faint(S, F);
-        }
-        if (r) return r;
-      }
-      if ((qc & 3) == C_PASS) break;
-      swap_sides(S, F);
-      if constexpr (TRACK_ACTIONS) { uint64_t t = actS; actS = actF; actF = t; }
-      uint32_t t = pc; pc = qc; qc = t;
-    }
+    OAK_T1(PS_ORDER, t_ord);
+    return 0;
+  }
+  __device__ __forceinline__ uint32_t turn_epilogue() {
     if ((S.vlo & V_BINDING) && attacks(S) == 0) clear_binding(S);
     if ((F.vlo & V_BINDING) && attacks(F) == 0) clear_binding(F);
     return end_turn();
+  }
+  __device__ __forceinline__ void next_actor() {
+    swap_sides(S, F);
+    if constexpr (TRACK_ACTIONS) { uint64_t t = actS; actS = actF; actF = t; }
+  }
+
+  __device__ uint32_t update_frame(uint32_t cS, uint32_t cF) {
+    uint32_t pc = 0, qc = 0;
+    if (const uint32_t r0 = turn_prologue(cS, cF, pc, qc)) return r0;
+#pragma unroll 1
+    for (int k = 0; k < 2; ++k) {
+      const uint32_t r = (pc & 3) == C_MOVE ? act_move(pc) : act_cheap(pc);
+      if (r) return r;
+      if ((qc & 3) == C_PASS) break;
+      next_actor();
+      uint32_t t = pc; pc = qc; qc = t;
+    }
+    return turn_epilogue();
   }
   // normalised-frame form (S = P1, F = P2 before and after)
   __device__ __forceinline__ uint32_t update(uint32_t c1, uint32_t c2) {
@@ -1214,11 +1309,14 @@ struct EngineR {
   }
   // one random-policy turn-step of the rollout (choices x2 + update), frame-agnostic
   __device__ __forceinline__ uint32_t random_step(uint32_t result, uint32_t hi, uint32_t lo) {
+    OAK_SCOPE(PS_STEP);
+    OAK_T0(t_ld);
     const bool s_p1 = absp(S) == 0;
     const uint32_t req1 = (result >> 4) & 3, req2 = (result >> 6) & 3;
     const Legal LS = legal(S, s_p1 ? req1 : req2), LF = legal(F, s_p1 ? req2 : req1);
     const uint32_t cS = nth_choice(LS, draw_index(s_p1, hi, lo, LS.n));
     const uint32_t cF = nth_choice(LF, draw_index(!s_p1, hi, lo, LF.n));
+    OAK_T1(PS_LEGAL_DRAW, t_ld);
     return update_frame(cS, cF);
   }
 

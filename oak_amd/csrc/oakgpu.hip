@@ -257,8 +257,28 @@ __global__ __launch_bounds__(BLK, 2) void k_rollout_regs(RolloutArgs a) {
 // queue.  A lane that finishes its playout immediately starts the next unassigned one (wave ballot ->
 // one atomicAdd per wave -> prefix rank), so waves stay full instead of idling on their longest lane.
 // Results are indexed by playout, each playout owns its RNG streams: output is identical to k_rollout*.
+//
+// Regrouping rounds.  Playout lengths have a long tail (mean ~100 turn-steps, 0.1% reach the 1000-step cap),
+// so once the queue is dry every wave decays towards a single live lane that still pays a whole wave's issue
+// slots.  With `suspend_below` > 0 a wave whose queue is dry and that is down to fewer live lanes than that
+// SUSPENDS them: the full state goes to a per-playout scratch slot (the 384-byte battle image, durations,
+// PRNG, result, step count), the playout indices are appended to `list_out`, and the wave exits.  The next
+// launch (`list_in` = that list) packs the survivors 64 to a wave again.  The last round runs with
+// suspend_below = 0.  Serialisation is the engine's own bit-exact load/store, so results do not change.
+struct RoundArgs {
+  const uint32_t *list_in;  // nullptr: round 0, playout k of the caller's arrays
+  const uint32_t *n_in;     // device count of list_in
+  uint32_t *list_out;       // suspended playouts of this round
+  uint32_t *count_out;
+  uint8_t *sb;              // scratch: n x 384 battle images
+  uint8_t *sd;              // scratch: n x 8 durations
+  uint8_t *sres;            // scratch: n results
+  uint32_t suspend_below;
+  uint32_t *queue;          // this round's queue head
+};
+
 template <int BLK, int WPS>
-__global__ __launch_bounds__(BLK, WPS) void k_rollout_queue(RolloutArgs a, uint32_t *queue) {
+__global__ __launch_bounds__(BLK, WPS) void k_rollout_queue(RolloutArgs a, RoundArgs q) {
   extern __shared__ __align__(16) uint8_t smem[];
   lds_u32 *party = (lds_u32 *)smem;
   using ER = EngineR<BLK, false>;
@@ -266,64 +286,86 @@ __global__ __launch_bounds__(BLK, WPS) void k_rollout_queue(RolloutArgs a, uint3
   __syncthreads();
   const uint32_t tid = threadIdx.x, wl = tid & 63;
   constexpr uint32_t NONE = 0xFFFFFFFFu, DONE = 0xFFFFFFFEu;
+  const uint32_t total = q.list_in ? *q.n_in : a.n;
   ER e;
   e.m = party + tid;
   e.T = T;
   FastPrng g;
   g.s0 = g.s1 = 0;
   uint32_t idx = NONE, result = 0, steps = 0;
+  bool dry = false; // wave-uniform: the queue has handed out its last playout
+  OAK_PROF_ZERO();
   for (;;) {
     const bool need = idx == NONE;
     const uint64_t mask = __ballot(need);
     if (mask) { // wave-uniform
+      OAK_SCOPE(PS_REFILL);
       uint32_t base = 0;
-      if (wl == 0) base = atomicAdd(queue, (uint32_t)__popcll(mask));
+      if (wl == 0) base = atomicAdd(q.queue, (uint32_t)__popcll(mask));
       base = __shfl(base, 0, 64);
+      dry = base + (uint32_t)__popcll(mask) >= total;
       if (need) {
         const uint32_t my = base + (uint32_t)__popcll(mask & ((1ull << wl) - 1));
-        if (my < a.n) {
-          idx = my;
-          const uint32_t *dsrc = (const uint32_t *)a.durations + 2 * (size_t)my;
-          const uint32_t *psrc = (const uint32_t *)a.prng + 2 * (size_t)my;
+        if (my < total) {
+          const bool resume = q.list_in != nullptr; // uniform: a suspended playout of the previous round
+          idx = resume ? q.list_in[my] : my;
+          const uint32_t *dsrc = (const uint32_t *)(resume ? q.sd : a.durations) + 2 * (size_t)idx;
+          const uint32_t *psrc = (const uint32_t *)a.prng + 2 * (size_t)idx;
           g.s0 = psrc[0];
           g.s1 = psrc[1];
-          e.load_battle_global(a.battles + (size_t)my * 384, dsrc[0], dsrc[1]);
-          if (a.prep) { // mcts.h:254-259
+          e.load_battle_global((resume ? q.sb : a.battles) + (size_t)idx * 384, dsrc[0], dsrc[1]);
+          if (!resume && a.prep) { // mcts.h:254-259
             const uint32_t hi = g.next32(), lo = g.next32();
             e.rng = ((uint64_t)hi << 32) | lo;
             e.randomize_hidden();
           }
-          result = a.results_in[my];
-          steps = 0;
+          result = (resume ? q.sres : a.results_in)[idx];
+          steps = resume ? a.steps_out[idx] : 0;
         } else idx = DONE;
       }
     }
     if (__ballot(idx != DONE) == 0) break;
-    if (idx != DONE) {
-      if ((result & 15) == 0 && steps < a.max_steps) {
-        const uint32_t hi = g.next32(), lo = g.next32(); // uniform_64 = hi << 32 | lo
-        result = e.random_step(result, hi, lo);
-        ++steps;
+    bool playing = idx != DONE && (result & 15) == 0 && steps < a.max_steps;
+    if (playing) {
+      const uint32_t hi = g.next32(), lo = g.next32(); // uniform_64 = hi << 32 | lo
+      result = e.random_step(result, hi, lo);
+      ++steps;
+      playing = (result & 15) == 0 && steps < a.max_steps;
+    }
+    // wave-uniform: the queue is dry and too few lanes are still playing -> hand them to the next round
+    const uint64_t still = __ballot(playing);
+    const bool suspend = dry && still != 0 && (uint32_t)__popcll(still) < q.suspend_below;
+    if (idx != DONE && (!playing || suspend)) { // retire the lane: publish a finished playout / park a suspended one
+      OAK_SCOPE(PS_PUBLISH);
+      const bool fin = !playing;
+      e.normalize();
+      (fin ? a.results_out : q.sres)[idx] = (uint8_t)result;
+      a.steps_out[idx] = steps;
+      const uint32_t t = result & 15;
+      if (fin) a.values_out[idx] = t == R_WIN ? 1.0f : t == R_LOSE ? 0.0f : 0.5f;
+      uint32_t *pdst = (uint32_t *)a.prng + 2 * (size_t)idx;
+      pdst[0] = g.s0;
+      pdst[1] = g.s1;
+      uint8_t *ddst8 = fin ? a.durations_out : q.sd;
+      if (ddst8) {
+        uint32_t *ddst = (uint32_t *)ddst8 + 2 * (size_t)idx;
+        ddst[0] = e.S.dur;
+        ddst[1] = e.F.dur;
       }
-      if (!((result & 15) == 0 && steps < a.max_steps)) { // playout finished: publish and free the lane
-        e.normalize();
-        a.results_out[idx] = (uint8_t)result;
-        a.steps_out[idx] = steps;
-        const uint32_t t = result & 15;
-        a.values_out[idx] = t == R_WIN ? 1.0f : t == R_LOSE ? 0.0f : 0.5f;
-        uint32_t *pdst = (uint32_t *)a.prng + 2 * (size_t)idx;
-        pdst[0] = g.s0;
-        pdst[1] = g.s1;
-        if (a.durations_out) {
-          uint32_t *ddst = (uint32_t *)a.durations_out + 2 * (size_t)idx;
-          ddst[0] = e.S.dur;
-          ddst[1] = e.F.dur;
-        }
-        if (a.battles_out) e.store_battle_global(a.battles_out + (size_t)idx * 384);
-        idx = NONE;
-      }
+      uint8_t *bdst = fin ? a.battles_out : q.sb;
+      if (bdst) e.store_battle_global(bdst + (size_t)idx * 384);
+      idx = fin ? NONE : idx;
+    }
+    if (suspend) {
+      const uint32_t leader = (uint32_t)__ffsll((unsigned long long)still) - 1;
+      uint32_t base = 0;
+      if (wl == leader) base = atomicAdd(q.count_out, (uint32_t)__popcll(still));
+      base = __shfl(base, leader, 64);
+      if (playing) q.list_out[base + (uint32_t)__popcll(still & ((1ull << wl) - 1))] = idx;
+      break;
     }
   }
+  OAK_PROF_FLUSH();
 }
 
 // ---- batched single update -------------------------------------------------------------------
@@ -513,8 +555,13 @@ struct oakgpu_ctx {
   int rollout_block;  // threads per workgroup of the rollout kernel (64 or 256)
   int rollout_engine; // 2 = register-resident (default), 1 = LDS-resident
   int playouts_per_lane; // > 1: persistent grid of n / this lanes with queue refill (k_rollout_queue)
-  int waves_per_simd;    // register budget of the queue kernel: 2 (no spills), 3 or 4
-  uint32_t *d_queue;
+  int waves_per_simd;    // register budget of the queue kernel: 2, 3 or 4 waves per SIMD
+  uint32_t *d_queue;      // 64 counters: queue heads and suspended-playout counts of the regrouping rounds
+  int rounds;             // regrouping rounds of the queue kernel (1 = none)
+  int suspend_below;      // a dry wave with fewer live lanes than this hands them to the next round
+  int round_shrink;       // each round launches 1/round_shrink of the previous round's waves
+  uint8_t *d_scratch;     // suspended playout state: n x (384 + 8 + 1) bytes + two n-entry index lists
+  size_t scratch_n;
 };
 
 static thread_local std::string g_err;
@@ -547,9 +594,9 @@ static int set_lds_limits() {
   HIPCHK(hipFuncSetAttribute((const void *)oak::k_rollout<64>, hipFuncAttributeMaxDynamicSharedMemorySize, oak::STATE_WORDS * 64 * 4 + oak::TABLE_LDS_PAD));
   HIPCHK(hipFuncSetAttribute((const void *)oak::k_rollout_regs<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 24 * 128 * 4 + oak::TABLE_LDS_PAD));
   HIPCHK(hipFuncSetAttribute((const void *)oak::k_rollout_regs<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 24 * 64 * 4 + oak::TABLE_LDS_PAD));
-  HIPCHK(hipFuncSetAttribute((const void *)oak::k_rollout_queue<64, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 24 * 64 * 4 + oak::TABLE_LDS_PAD));
-  HIPCHK(hipFuncSetAttribute((const void *)oak::k_rollout_queue<64, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 24 * 64 * 4 + oak::TABLE_LDS_PAD));
-  HIPCHK(hipFuncSetAttribute((const void *)oak::k_rollout_queue<64, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 24 * 64 * 4 + oak::TABLE_LDS_PAD));
+#define OAK_LIM_Q(W) HIPCHK(hipFuncSetAttribute((const void *)oak::k_rollout_queue<64, W>, hipFuncAttributeMaxDynamicSharedMemorySize, 24 * 64 * 4 + oak::TABLE_LDS_PAD))
+  OAK_LIM_Q(2); OAK_LIM_Q(3); OAK_LIM_Q(4);
+#undef OAK_LIM_Q
   HIPCHK(hipFuncSetAttribute((const void *)oak::k_update, hipFuncAttributeMaxDynamicSharedMemorySize, oak::ENGINE_LDS_BYTES));
   HIPCHK(hipFuncSetAttribute((const void *)oak::k_choices, hipFuncAttributeMaxDynamicSharedMemorySize, oak::ENGINE_LDS_BYTES));
   HIPCHK(hipFuncSetAttribute((const void *)oak::k_init, hipFuncAttributeMaxDynamicSharedMemorySize, oak::ENGINE_LDS_BYTES));
@@ -572,10 +619,18 @@ int oakgpu_create(oakgpu_ctx **out, int device) {
   c->n_legal = 0;
   c->rollout_block = 64; // register engine: 64 (default: single-wave workgroups spread evenly over SIMDs) or 128; LDS engine: 64 or 256
   if (const char *env = getenv("OAKGPU_ROLLOUT_BLOCK")) c->rollout_block = atoi(env);
-  c->playouts_per_lane = 1;
+  c->playouts_per_lane = 2;
   if (const char *env = getenv("OAKGPU_PLAYOUTS_PER_LANE")) c->playouts_per_lane = atoi(env) > 0 ? atoi(env) : 1;
   c->d_queue = nullptr;
-  c->waves_per_simd = 3; // measured best on MI355X: 168 VGPRs (a dozen cold spills) beats 2 waves without spills
+  c->d_scratch = nullptr;
+  c->scratch_n = 0;
+  c->rounds = 4;
+  c->suspend_below = 32;
+  c->round_shrink = 3;
+  if (const char *env = getenv("OAKGPU_ROUNDS")) c->rounds = atoi(env) < 1 ? 1 : atoi(env) > 8 ? 8 : atoi(env);
+  if (const char *env = getenv("OAKGPU_SUSPEND_BELOW")) c->suspend_below = atoi(env) < 0 ? 0 : atoi(env) > 64 ? 64 : atoi(env);
+  if (const char *env = getenv("OAKGPU_ROUND_SHRINK")) c->round_shrink = atoi(env) < 1 ? 1 : atoi(env);
+  c->waves_per_simd = 4; // measured best on MI355X: the staged run_move fits 128 VGPRs without scratch
   if (const char *env = getenv("OAKGPU_WAVES_PER_SIMD")) c->waves_per_simd = atoi(env);
   c->rollout_engine = 2;
   if (const char *env = getenv("OAKGPU_ROLLOUT_ENGINE")) c->rollout_engine = atoi(env) == 1 ? 1 : 2;
@@ -594,6 +649,7 @@ void oakgpu_destroy(oakgpu_ctx *c) {
   if (c->d_pools) (void)hipFree(c->d_pools);
   if (c->d_sizes) (void)hipFree(c->d_sizes);
   if (c->d_queue) (void)hipFree(c->d_queue);
+  if (c->d_scratch) (void)hipFree(c->d_scratch);
   delete c;
 }
 
@@ -611,6 +667,15 @@ int oakgpu_set_playouts_per_lane(oakgpu_ctx *c, int k) {
   return 0;
 }
 
+int oakgpu_set_regroup(oakgpu_ctx *c, int rounds, int suspend_below, int shrink) {
+  if (!c || rounds < 1 || rounds > 8 || suspend_below < 0 || suspend_below > 64 || shrink < 1)
+    return bad("oakgpu_set_regroup: bad argument");
+  c->rounds = rounds;
+  c->suspend_below = suspend_below;
+  c->round_shrink = shrink;
+  return 0;
+}
+
 void *oakgpu_get_stream(oakgpu_ctx *c) { return c ? (void *)c->stream : nullptr; }
 
 int oakgpu_synchronize(oakgpu_ctx *c) {
@@ -618,6 +683,18 @@ int oakgpu_synchronize(oakgpu_ctx *c) {
   HIPCHK(hipStreamSynchronize(c->stream));
   return 0;
 }
+
+#ifdef OAKGPU_SITE_PROFILE
+// profile build only (tools/site_profile.sh): read-and-reset the region counters of gen1_regs.hpp
+extern "C" int oakgpu_site_profile(unsigned long long *out, int reset) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(oak::g_site_prof), sizeof(unsigned long long) * 32 * 4) != hipSuccess) return 1;
+  if (reset) {
+    unsigned long long z[32 * 4] = {};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(oak::g_site_prof), z, sizeof z) != hipSuccess) return 1;
+  }
+  return 0;
+}
+#endif
 
 static inline uint32_t grid_for(uint32_t n) { return (n + oak::BLOCK - 1) / oak::BLOCK; }
 
@@ -636,13 +713,35 @@ int oakgpu_rollout_dev(oakgpu_ctx *c, const uint8_t *battles, const uint8_t *dur
     else hipLaunchKernelGGL(oak::k_rollout<256>, dim3(grid_for(n)), dim3(256), oak::ENGINE_LDS_BYTES, c->stream, a);
   } else if (c->playouts_per_lane > 1) { // register engine + lane refill from an atomic playout queue
     if (!c->d_queue) HIPCHK(hipMalloc((void **)&c->d_queue, 256));
-    HIPCHK(hipMemsetAsync(c->d_queue, 0, 4, c->stream));
+    HIPCHK(hipMemsetAsync(c->d_queue, 0, 256, c->stream));
     uint32_t waves = ((n + 63) / 64 + c->playouts_per_lane - 1) / c->playouts_per_lane;
     if (waves < 1) waves = 1;
+    const int rounds = (c->suspend_below > 0 && waves >= 8) ? c->rounds : 1;
+    if (rounds > 1 && c->scratch_n < n) {
+      if (c->d_scratch) { HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipFree(c->d_scratch)); c->d_scratch = nullptr; }
+      HIPCHK(hipMalloc((void **)&c->d_scratch, (size_t)n * (384 + 8 + 4 + 4) + (((size_t)n + 15) & ~(size_t)15)));
+      c->scratch_n = n;
+    }
     const size_t lq = 24 * 64 * 4 + oak::TABLE_LDS_PAD;
-    if (c->waves_per_simd >= 4) hipLaunchKernelGGL((oak::k_rollout_queue<64, 4>), dim3(waves), dim3(64), lq, c->stream, a, c->d_queue);
-    else if (c->waves_per_simd == 3) hipLaunchKernelGGL((oak::k_rollout_queue<64, 3>), dim3(waves), dim3(64), lq, c->stream, a, c->d_queue);
-    else hipLaunchKernelGGL((oak::k_rollout_queue<64, 2>), dim3(waves), dim3(64), lq, c->stream, a, c->d_queue);
+    uint8_t *sb = c->d_scratch, *sd = sb ? sb + (size_t)c->scratch_n * 384 : nullptr;
+    uint32_t *lists[2] = {sd ? (uint32_t *)(sd + (size_t)c->scratch_n * 8) : nullptr, nullptr};
+    lists[1] = lists[0] ? lists[0] + c->scratch_n : nullptr;
+    uint8_t *sres = lists[1] ? (uint8_t *)(lists[1] + c->scratch_n) : nullptr;
+    for (int r = 0; r < rounds; ++r) {
+      oak::RoundArgs q{};
+      q.list_in = r ? lists[(r - 1) & 1] : nullptr;
+      q.n_in = r ? c->d_queue + 2 * r - 1 : nullptr; // = count_out of round r - 1
+      q.list_out = lists[r & 1];
+      q.count_out = c->d_queue + 2 * r + 1;
+      q.sb = sb; q.sd = sd; q.sres = sres;
+      q.suspend_below = r + 1 < rounds ? (uint32_t)c->suspend_below : 0u;
+      q.queue = c->d_queue + 2 * r;
+#define OAK_LAUNCH_Q(W) hipLaunchKernelGGL((oak::k_rollout_queue<64, W>), dim3(waves), dim3(64), lq, c->stream, a, q)
+      if (c->waves_per_simd >= 4) OAK_LAUNCH_Q(4); else if (c->waves_per_simd == 3) OAK_LAUNCH_Q(3); else OAK_LAUNCH_Q(2);
+#undef OAK_LAUNCH_Q
+      waves = (waves + c->round_shrink - 1) / c->round_shrink;
+      if (waves < 1) waves = 1;
+    }
   } else {                      // register-resident engine (gen1_regs.hpp): the default
     if (c->rollout_block == 64)
       hipLaunchKernelGGL(oak::k_rollout_regs<64>, dim3((n + 63) / 64), dim3(64), 24 * 64 * 4 + oak::TABLE_LDS_PAD, c->stream, a);

@@ -55,6 +55,10 @@ class Context:
     def set_playouts_per_lane(self, k):
         _lib.check(self.lib.oakgpu_set_playouts_per_lane(self.handle, int(k)))
 
+    def set_regroup(self, rounds=4, suspend_below=32, shrink=3):
+        """Tail regrouping of the queue schedule (include/oakgpu.h: oakgpu_set_regroup); results never change."""
+        _lib.check(self.lib.oakgpu_set_regroup(self.handle, int(rounds), int(suspend_below), int(shrink)))
+
     def stream_ptr(self):
         """hipStream_t of this context (wrap with torch.cuda.ExternalStream to share it with torch)."""
         return self.lib.oakgpu_get_stream(self.handle)

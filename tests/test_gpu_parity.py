@@ -166,13 +166,42 @@ def test_queue_refill_matches_plain_launch(gpu_ctx):
     """k_rollout_queue (persistent lanes refilled from an atomic playout queue) == one lane per playout."""
     n = 3000
     b, d, p, r = O.make_random_ou_batch(n, seed0=0x51515151)
+    gpu_ctx.set_playouts_per_lane(1)
     plain = gpu_ctx.rollout(b, d, r, p, max_steps=1000, return_state=True)
     for k in (2, 5, 64):
         gpu_ctx.set_playouts_per_lane(k)
         q = gpu_ctx.rollout(b, d, r, p, max_steps=1000, return_state=True)
         for key in ("results", "steps", "values", "battles", "durations", "prng"):
             assert (q[key] == plain[key]).all(), (k, key)
+    gpu_ctx.set_playouts_per_lane(2)
+
+
+def test_regrouping_rounds_do_not_change_results(gpu_ctx):
+    """Tail regrouping (suspended playouts parked as battle images, resumed 64 to a wave by later dispatches):
+    every schedule gives the byte-identical outputs of the plain one-lane-per-playout launch and of the oracle."""
+    n = 6000
+    b, d, p, r = O.make_random_ou_batch(n, seed0=0x7E57AB1E)
+    ob, od, op = b.copy(), d.copy(), p.copy()
+    oout, osteps = O.rollout_batch(ob, od, r, op, max_steps=1000, threads=8)
     gpu_ctx.set_playouts_per_lane(1)
+    plain = gpu_ctx.rollout(b, d, r, p, max_steps=1000, return_state=True)
+    assert (plain["steps"] == osteps).all() and (plain["battles"] == ob).all()
+    try:
+        for ppl, rounds, below, shrink in ((2, 1, 0, 1), (2, 2, 64, 2), (2, 4, 32, 3), (3, 8, 63, 1), (4, 3, 17, 5), (2, 4, 1, 2)):
+            gpu_ctx.set_playouts_per_lane(ppl)
+            gpu_ctx.set_regroup(rounds, below, shrink)
+            for prep in (False, True):
+                q = gpu_ctx.rollout(b, d, r, p, max_steps=1000, prep=prep, return_state=True)
+                ref = plain
+                if prep:
+                    gpu_ctx.set_playouts_per_lane(1)
+                    ref = gpu_ctx.rollout(b, d, r, p, max_steps=1000, prep=True, return_state=True)
+                    gpu_ctx.set_playouts_per_lane(ppl)
+                for key in ("results", "steps", "values", "battles", "durations", "prng"):
+                    assert (q[key] == ref[key]).all(), (ppl, rounds, below, shrink, prep, key)
+    finally:
+        gpu_ctx.set_playouts_per_lane(2)
+        gpu_ctx.set_regroup()
 
 
 def test_libpkmn_named_single_battle_abi(gpu_ctx):
@@ -220,9 +249,7 @@ def test_full_size_config2_bit_exact(gpu_ctx):
     """BASELINE configs[1] at its full size: all 65,536 random OU playouts, every output byte vs the oracle."""
     n = 65536
     b, d, p, r = O.make_random_ou_batch(n)
-    gpu_ctx.set_playouts_per_lane(2)          # the scheduling bench.py uses
-    got = gpu_ctx.rollout(b, d, r, p, max_steps=1000, return_state=True)
-    gpu_ctx.set_playouts_per_lane(1)
+    got = gpu_ctx.rollout(b, d, r, p, max_steps=1000, return_state=True)   # default schedule = the one bench.py uses
     ob, od, op = b.copy(), d.copy(), p.copy()
     oout, osteps = O.rollout_batch(ob, od, r, op, max_steps=1000, threads=16)
     assert (got["steps"] == osteps).all() and (got["results"] == oout).all()
