@@ -68,8 +68,76 @@ struct Tables {
   const lds_u8 *chart;   // [225]
   const lds_u16 *boost;  // [13] num | den<<8
   const lds_u32 *rcp;    // [256] floor((2^32-1)/d) + 1: exact x / d by one mul-hi for x < 2^24, d in 2..255
+  const lds_u16 *fx;     // [68] per-effect descriptor (fx_desc below): gate / action class / secondary effect
 };
-static constexpr int TABLE_LDS_BYTES = 166 * 4 + 168 + 152 * 4 + 152 * 4 + 228 + 28 + 256 * 4;
+static constexpr int TABLE_LDS_BYTES = 166 * 4 + 168 + 152 * 4 + 152 * 4 + 228 + 28 + 256 * 4 + 68 * 2;
+
+// ---- per-effect descriptors: what gen1_regs.hpp's run_move needs to know about a move effect, as data.
+// Lanes of a wave run different moves; a `switch (effect)` costs the wave every case any lane takes plus the
+// exec-mask bookkeeping of all of them, a table lookup costs one LDS read and a few selects for everybody.
+//   status moves (bp == 0):  bits 0-3 gate (can the move fail before / instead of its accuracy check),
+//                            bits 4-6 action class, bits 7-11 its parameter
+//   damaging moves:          bits 0-2 secondary-effect kind, 3-5 chance index, 6-8 parameter
+enum : uint32_t { G_NONE = 0, G_SUB, G_INVUL, G_GRASS, G_HIT, G_PAR, G_PSN, G_TELE, G_SLEEP, G_DISABLE };
+enum : uint32_t { A_NONE = 0, A_BOOST, A_UNBOOST, A_SVOL, A_FVOL, A_PAR, A_CONF, A_HEAVY };
+enum : uint32_t { SEC_NONE = 0, SEC_STATUS = 1, SEC_FLINCH = 2, SEC_CONF = 3, SEC_UNBOOST = 4 };
+// chance index -> x/256: 0: 26 (10%), 1: 77 (30%), 2: 52 (20%), 3: 103 (40%), 4: 25 (confusion), 5: 85 (stat drop)
+static constexpr uint64_t FX_CHANCES = 26ull | (77ull << 8) | (52ull << 16) | (103ull << 24) | (25ull << 32) | (85ull << 40);
+constexpr uint32_t fx_status(uint32_t gate, uint32_t cls, uint32_t par) { return gate | (cls << 4) | (par << 7); }
+constexpr uint32_t fx_stage(uint32_t idx, uint32_t n) { return idx | ((n - 1) << 3); } // stat idx 0 atk 1 def 2 spe 3 spc 4 acc 5 eva
+constexpr uint32_t fx_sec(uint32_t kind, uint32_t chance_idx, uint32_t par) { return kind | (chance_idx << 3) | (par << 6); }
+constexpr uint32_t fx_desc(uint32_t e) {
+  switch (e) {
+  case E_Confusion: return fx_status(G_SUB, A_CONF, 0);
+  case E_Conversion: case E_Transform: return fx_status(G_INVUL, A_HEAVY, 0);
+  case E_FocusEnergy: return fx_status(G_NONE, A_SVOL, 9);   // V_FOCUSENERGY
+  case E_LightScreen: return fx_status(G_NONE, A_SVOL, 15);  // V_LIGHTSCREEN
+  case E_Reflect: return fx_status(G_NONE, A_SVOL, 16);      // V_REFLECT
+  case E_Mist: return fx_status(G_NONE, A_SVOL, 8);          // V_MIST
+  case E_LeechSeed: return fx_status(G_GRASS, A_FVOL, 13);   // V_LEECHSEED
+  case E_Haze: case E_Heal: case E_Substitute: case E_Bide: return fx_status(G_NONE, A_HEAVY, 0);
+  case E_Mimic: return fx_status(G_HIT, A_HEAVY, 0);
+  case E_Paralyze: return fx_status(G_PAR, A_PAR, 0);
+  case E_Poison: return fx_status(G_PSN, A_HEAVY, 0);
+  case E_SwitchAndTeleport: return fx_status(G_TELE, A_NONE, 0);
+  case E_Sleep: return fx_status(G_SLEEP, A_HEAVY, 0);
+  case E_Disable: return fx_status(G_DISABLE, A_HEAVY, 0);
+  case E_AccuracyDown1: return fx_status(G_SUB, A_UNBOOST, fx_stage(4, 1));
+  case E_AttackDown1: return fx_status(G_SUB, A_UNBOOST, fx_stage(0, 1));
+  case E_DefenseDown1: return fx_status(G_SUB, A_UNBOOST, fx_stage(1, 1));
+  case E_DefenseDown2: return fx_status(G_SUB, A_UNBOOST, fx_stage(1, 2));
+  case E_SpeedDown1: return fx_status(G_SUB, A_UNBOOST, fx_stage(2, 1));
+  case E_AttackUp1: return fx_status(G_NONE, A_BOOST, fx_stage(0, 1));
+  case E_AttackUp2: return fx_status(G_NONE, A_BOOST, fx_stage(0, 2));
+  case E_DefenseUp1: return fx_status(G_NONE, A_BOOST, fx_stage(1, 1));
+  case E_DefenseUp2: return fx_status(G_NONE, A_BOOST, fx_stage(1, 2));
+  case E_SpeedUp2: return fx_status(G_NONE, A_BOOST, fx_stage(2, 2));
+  case E_SpecialUp1: return fx_status(G_NONE, A_BOOST, fx_stage(3, 1));
+  case E_SpecialUp2: return fx_status(G_NONE, A_BOOST, fx_stage(3, 2));
+  case E_EvasionUp1: return fx_status(G_NONE, A_BOOST, fx_stage(5, 1));
+  // damaging: secondary effects; the status parameter p means status byte 8 << p (PSN BRN FRZ PAR)
+  case E_PoisonChance1: case E_Twineedle: return fx_sec(SEC_STATUS, 2, 0);
+  case E_PoisonChance2: return fx_sec(SEC_STATUS, 3, 0);
+  case E_BurnChance1: return fx_sec(SEC_STATUS, 0, 1);
+  case E_BurnChance2: return fx_sec(SEC_STATUS, 1, 1);
+  case E_FreezeChance: return fx_sec(SEC_STATUS, 0, 2);
+  case E_ParalyzeChance1: return fx_sec(SEC_STATUS, 0, 3);
+  case E_ParalyzeChance2: return fx_sec(SEC_STATUS, 1, 3);
+  case E_FlinchChance1: return fx_sec(SEC_FLINCH, 0, 0);
+  case E_FlinchChance2: return fx_sec(SEC_FLINCH, 1, 0);
+  case E_ConfusionChance: return fx_sec(SEC_CONF, 4, 0);
+  case E_AttackDownChance: return fx_sec(SEC_UNBOOST, 5, 0);
+  case E_DefenseDownChance: return fx_sec(SEC_UNBOOST, 5, 1);
+  case E_SpeedDownChance: return fx_sec(SEC_UNBOOST, 5, 2);
+  case E_SpecialDownChance: return fx_sec(SEC_UNBOOST, 5, 3);
+  default: return 0; // Splash, plain damage, effects handled outside run_move
+  }
+}
+struct FxTable {
+  uint16_t d[68];
+  constexpr FxTable() : d{} { for (uint32_t e = 0; e < 68; ++e) d[e] = (uint16_t)fx_desc(e); }
+};
+static __device__ const FxTable OAK_FX{};
 
 // copies the packed table images into LDS; call with all threads of the workgroup, then barrier
 __device__ inline Tables stage_tables(lds_u8 *lds, const uint32_t *g_mv, const uint8_t *g_pp, const uint32_t *g_sp0,
@@ -81,12 +149,14 @@ __device__ inline Tables stage_tables(lds_u8 *lds, const uint32_t *g_mv, const u
   lds_u8 *chart = (lds_u8 *)(sp1 + 152);
   lds_u16 *boost = (lds_u16 *)(chart + 228);
   lds_u32 *rcp = (lds_u32 *)(chart + 228 + 28);
+  lds_u16 *fx = (lds_u16 *)(rcp + 256);
   for (int i = threadIdx.x; i < 256; i += blockDim.x) rcp[i] = i ? 0xFFFFFFFFu / (uint32_t)i + 1u : 0u;
+  for (int i = threadIdx.x; i < 68; i += blockDim.x) fx[i] = OAK_FX.d[i];
   for (int i = threadIdx.x; i < 166; i += blockDim.x) { mv[i] = g_mv[i]; pp[i] = g_pp[i]; }
   for (int i = threadIdx.x; i < 152; i += blockDim.x) { sp0[i] = g_sp0[i]; sp1[i] = g_sp1[i]; }
   for (int i = threadIdx.x; i < 225; i += blockDim.x) chart[i] = g_chart[i];
   for (int i = threadIdx.x; i < 13; i += blockDim.x) boost[i] = g_boost[i];
-  Tables t{mv, pp, sp0, sp1, chart, boost, rcp};
+  Tables t{mv, pp, sp0, sp1, chart, boost, rcp, fx};
   return t;
 }
 

@@ -709,8 +709,6 @@ struct EngineR {
   // accuracy site, ONE secondary-roll site, ONE status site, ONE confusion site, ONE stat-stage site.
   // Per-lane RNG order is unchanged (accuracy -> effect rolls -> crit -> damage -> counts -> secondary
   // chance -> secondary duration), so results stay bit-identical to gen1_device.hpp and the oracle.
-  enum : uint32_t { SEC_NONE = 0, SEC_STATUS = 1, SEC_FLINCH = 2, SEC_CONF = 3, SEC_UNBOOST = 4 };
-
   __device__ void run_move(uint32_t mslot) {
     OAK_SCOPE(PS_RUN_MOVE);
     OAK_T0(t_g);
@@ -733,25 +731,22 @@ struct EngineR {
 
     // -- stage 1: gates ----------------------------------------------------------------------------
     bool go = true, need_hit = false;
-    if (!damaging) {
+    const uint32_t fx = T.fx[eff]; // per-effect descriptor (gen1_device.hpp, fx_desc)
+    if (!damaging) { // branch-free: the gate kind selects among conditions every lane can evaluate
       last_damage = 0;
-      switch (eff) {
-      case E_Confusion: go = !(F.vlo & V_SUBSTITUTE); need_hit = true; break;
-      case E_Conversion: case E_Transform: go = !(F.vlo & V_INVULNERABLE); break;
-      case E_LeechSeed: go = !has_type(ft, T_Grass); need_hit = true; break;
-      case E_Mimic: need_hit = true; break;
-      case E_Paralyze: go = fs == 0 && !type_immune; need_hit = true; break;
-      case E_Poison: go = fs == 0 && !has_type(ft, T_Poison) && !(F.vlo & V_SUBSTITUTE); need_hit = true; break;
-      case E_SwitchAndTeleport: need_hit = move_id != M_Teleport; break;
-      case E_AccuracyDown1: case E_AttackDown1: case E_DefenseDown1: case E_DefenseDown2: case E_SpeedDown1:
-        go = !(F.vlo & V_SUBSTITUTE); need_hit = true; break;
-      case E_Sleep:
-        if (F.vlo & V_RECHARGING) { F.vlo &= ~V_RECHARGING; go = !(fs & ST_SLP); } // always lands on a recharging target
-        else { go = fs == 0; need_hit = true; }
-        break;
-      case E_Disable: go = disable_move(F) == 0; need_hit = true; break;
-      default: break; // self-targeting effects
-      }
+      const uint32_t gate = fx & 15;
+      const bool sub = (F.vlo & V_SUBSTITUTE) != 0;
+      const bool sure = gate == G_SLEEP && (F.vlo & V_RECHARGING); // sleep always lands on a recharging target
+      F.vlo &= sure ? ~V_RECHARGING : ~0u;
+      go = gate == G_SUB ? !sub
+         : gate == G_INVUL ? !(F.vlo & V_INVULNERABLE)
+         : gate == G_GRASS ? !has_type(ft, T_Grass)
+         : gate == G_PAR ? (fs == 0 && !type_immune)
+         : gate == G_PSN ? (fs == 0 && !has_type(ft, T_Poison) && !sub)
+         : gate == G_SLEEP ? (sure ? !(fs & ST_SLP) : fs == 0)
+         : gate == G_DISABLE ? disable_move(F) == 0
+         : true;
+      need_hit = gate == G_TELE ? move_id != M_Teleport : (gate != G_NONE && gate != G_INVUL && !sure);
     } else {
       bool immune = !fixed && type_immune;
       if (eff == E_DreamEater && !(fs & ST_SLP)) immune = true;
@@ -776,10 +771,16 @@ struct EngineR {
     // -- stage 3: effect bodies (no accuracy checks, no shared machinery inside) ------------------------
     if (!damaging) {
       OAK_SCOPE(PS_STATUS_BODIES);
-      switch (eff) {
-      case E_Confusion: want_conf = !(F.vlo & V_CONFUSION); break;
+      const uint32_t cls = (fx >> 4) & 7, par = fx >> 7;
+      // the light effects are pure data: a stage change, a volatile bit, paralysis, confusion
+      if (cls == A_BOOST) { b_idx = (int)(par & 7); b_n = (int)(par >> 3) + 1; }
+      if (cls == A_UNBOOST) { ub_idx = (int)(par & 7); ub_n = (int)(par >> 3) + 1; }
+      S.vlo |= cls == A_SVOL ? 1u << par : 0u; // FocusEnergy, LightScreen, Reflect, Mist
+      F.vlo |= cls == A_FVOL ? 1u << par : 0u; // LeechSeed (already seeded: no-op)
+      want_status = cls == A_PAR ? (uint32_t)ST_PAR : 0u;
+      want_conf = cls == A_CONF && !(F.vlo & V_CONFUSION);
+      if (cls == A_HEAVY) switch (eff) {
       case E_Conversion: S.a2 = (S.a2 & 0x00FFFFFFu) | (F.a2 & 0xFF000000u); break;
-      case E_FocusEnergy: S.vlo |= V_FOCUSENERGY; break;
       case E_Haze: {
         S.bo = 0;
         F.bo = 0;
@@ -809,10 +810,6 @@ struct EngineR {
         }
         break;
       }
-      case E_LeechSeed: F.vlo |= V_LEECHSEED; break; // already seeded: no-op
-      case E_LightScreen: S.vlo |= V_LIGHTSCREEN; break;
-      case E_Reflect: S.vlo |= V_REFLECT; break;
-      case E_Mist: S.vlo |= V_MIST; break;
       case E_Mimic: {
         uint32_t n = 0;
         for (uint32_t i = 1; i <= 4; ++i) n += (active_move(F, i) & 0xFF) != 0;
@@ -824,7 +821,6 @@ struct EngineR {
         set_amoves(S, (amoves(S) & ~(0xFFull << sh)) | (nid << sh));
         break;
       }
-      case E_Paralyze: want_status = ST_PAR; break;
       case E_Poison:
         if (move_id == M_Toxic) { set_status(F, ST_TOX); F.vlo |= V_TOXIC; set_toxic_ctr(F, 0); }
         else set_status(F, ST_PSN);
@@ -853,11 +849,6 @@ struct EngineR {
         set_amoves(S, nm);
         break;
       }
-      case E_AttackUp1: case E_AttackUp2: b_idx = 0; b_n = eff == E_AttackUp2 ? 2 : 1; break;
-      case E_DefenseUp1: case E_DefenseUp2: b_idx = 1; b_n = eff == E_DefenseUp2 ? 2 : 1; break;
-      case E_SpeedUp2: b_idx = 2; b_n = 2; break;
-      case E_SpecialUp1: case E_SpecialUp2: b_idx = 3; b_n = eff == E_SpecialUp2 ? 2 : 1; break;
-      case E_EvasionUp1: b_idx = 5; break;
       case E_Bide:
         S.vlo |= V_BIDE;
         set_vstate(S, 0);
@@ -865,11 +856,6 @@ struct EngineR {
         dset(S, 25, 3, 1);
         act_set(true, AC_ATTACKING, 2, OBS_STARTED);
         break;
-      case E_AccuracyDown1: ub_idx = 4; break;
-      case E_AttackDown1: ub_idx = 0; break;
-      case E_DefenseDown1: ub_idx = 1; break;
-      case E_DefenseDown2: ub_idx = 1; ub_n = 2; break;
-      case E_SpeedDown1: ub_idx = 2; break;
       case E_Sleep:
         set_status(F, rng_range(1, 8));
         dset(F, 0, 3, 1);
@@ -890,7 +876,7 @@ struct EngineR {
         act_set(false, AC_DISABLE, 2, OBS_STARTED);
         break;
       }
-      default: break; // Splash, SwitchAndTeleport, unknown
+      default: break;
       }
     } else {
       // -- stage 4: damage ---------------------------------------------------------------------------
@@ -969,28 +955,19 @@ struct EngineR {
         return;
       }
       if (hit_sub) return; // a standing substitute blocks every secondary effect
-      // secondary-effect parameters; the roll itself happens at the shared site below
-      uint32_t st = 0, num = 0;
-      switch (eff) {
-      case E_BurnChance1: st = ST_BRN; num = 26; break;
-      case E_BurnChance2: st = ST_BRN; num = 77; break;
-      case E_FreezeChance: st = ST_FRZ; num = 26; break;
-      case E_ParalyzeChance1: st = ST_PAR; num = 26; break;
-      case E_ParalyzeChance2: st = ST_PAR; num = 77; break;
-      case E_PoisonChance1: case E_Twineedle: st = ST_PSN; num = 52; break;
-      case E_PoisonChance2: st = ST_PSN; num = 103; break;
-      case E_FlinchChance1: sec_kind = SEC_FLINCH; sec_chance = 26; break;
-      case E_FlinchChance2: sec_kind = SEC_FLINCH; sec_chance = 77; break;
-      case E_ConfusionChance: if (!(F.vlo & V_CONFUSION)) { sec_kind = SEC_CONF; sec_chance = 25; } break;
-      case E_AttackDownChance: case E_DefenseDownChance: case E_SpeedDownChance: case E_SpecialDownChance:
-        sec_kind = SEC_UNBOOST; sec_chance = 85; sec_idx = (int)eff - (int)E_AttackDownChance; break;
-      default: break;
-      }
-      if (st) {
+      // secondary-effect parameters from the descriptor; the roll itself happens at the shared site below
+      const uint32_t sk = fx & 7, sp = (fx >> 6) & 7;
+      sec_chance = (uint32_t)(FX_CHANCES >> (8 * ((fx >> 3) & 7))) & 0xFF;
+      sec_idx = (int)sp;
+      sec_status = 8u << sp; // PSN BRN FRZ PAR
+      sec_kind = sk;
+      if (sk == SEC_STATUS) {
         const uint32_t fs2 = status(F);
-        if (st == ST_BRN && (fs2 & ST_FRZ)) set_status(F, 0); // fire thaws
-        else if (fs2 == 0 && !has_type(types(F), st == ST_PSN ? (uint32_t)T_Poison : mtype)) { sec_kind = SEC_STATUS; sec_status = st; sec_chance = num; }
+        const bool thaw = sec_status == ST_BRN && (fs2 & ST_FRZ); // fire thaws instead of burning
+        if (thaw) set_status(F, 0);
+        if (thaw || fs2 != 0 || has_type(types(F), sec_status == ST_PSN ? (uint32_t)T_Poison : mtype)) sec_kind = SEC_NONE;
       }
+      if (sk == SEC_CONF && (F.vlo & V_CONFUSION)) sec_kind = SEC_NONE;
     }
     // -- stage 5: THE secondary-effect roll ------------------------------------------------------------
     OAK_SCOPE(PS_SECONDARY_APPLY);
