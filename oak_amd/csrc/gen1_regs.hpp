@@ -90,7 +90,8 @@ struct SideR {
 #define OAK_FOR_SIDE_FIELDS(X) X(a0) X(a1) X(a2) X(bo) X(vlo) X(vhi) X(m01) X(m23) X(p0) X(p1) X(p2) X(p3) X(p4) X(p5) X(o0) X(o1) X(dur) X(misc)
 
 __device__ __forceinline__ void swap_sides(SideR &a, SideR &b) {
-#define X(f) { uint32_t t = a.f; a.f = b.f; b.f = t; }
+  // v_swap_b32: one instruction per field (the compiler's own lowering is three moves through a temporary)
+#define X(f) asm("v_swap_b32 %0, %1" : "+v"(a.f), "+v"(b.f));
   OAK_FOR_SIDE_FIELDS(X)
 #undef X
 }
@@ -1204,16 +1205,21 @@ struct EngineR {
 
   __device__ uint32_t update_frame(uint32_t cS, uint32_t cF) {
     uint32_t pc = 0, qc = 0;
-    if (const uint32_t r0 = turn_prologue(cS, cF, pc, qc)) return r0;
+    uint32_t r = turn_prologue(cS, cF, pc, qc);
+    if (r) return r;
+    // Both actions run through ONE copy of the action code.  The sides are swapped after EVERY action, whether
+    // or not a second one follows (the turn's end is frame-agnostic): an unconditional swap keeps the register
+    // roles of S and F identical on every path through the loop, where a conditional one makes the compiler
+    // copy the whole engine state at each merge point.
 #pragma unroll 1
     for (int k = 0; k < 2; ++k) {
-      const uint32_t r = (pc & 3) == C_MOVE ? act_move(pc) : act_cheap(pc);
-      if (r) return r;
-      if ((qc & 3) == C_PASS) break;
+      r = (pc & 3) == C_MOVE ? act_move(pc) : act_cheap(pc);
+      const bool last = r != 0 || (qc & 3) == C_PASS;
       next_actor();
-      uint32_t t = pc; pc = qc; qc = t;
+      const uint32_t t = pc; pc = qc; qc = t;
+      if (last) break;
     }
-    return turn_epilogue();
+    return r ? r : turn_epilogue();
   }
   // normalised-frame form (S = P1, F = P2 before and after)
   __device__ __forceinline__ uint32_t update(uint32_t c1, uint32_t c2) {
