@@ -277,16 +277,43 @@ struct RoundArgs {
   uint32_t *queue;          // this round's queue head
 };
 
+// The kernel's pointer arguments are needed only when a lane is (re)filled or retired, but as kernel arguments
+// they would sit in ~40 SGPRs for the whole turn loop, whose nested divergent control flow needs those SGPRs
+// for exec masks (the overflow is spilled to VGPR lanes: v_writelane / v_readlane in the hot path).  So thread 0
+// parks them in LDS once and the cold paths read them back (wave-uniform values in VGPRs).
+struct ColdArgs {
+  RolloutArgs a;
+  RoundArgs q;
+};
+constexpr int COLD_LDS_BYTES = (sizeof(ColdArgs) + 15) & ~15;
+template <class P>
+__device__ __forceinline__ P cold_ptr(const lds_u32 *cold, size_t byte_off) {
+  return (P)((uint64_t)cold[byte_off / 4] | ((uint64_t)cold[byte_off / 4 + 1] << 32));
+}
+#define COLD_A(field, type) cold_ptr<type>(cold, offsetof(ColdArgs, a) + offsetof(RolloutArgs, field))
+#define COLD_Q(field, type) cold_ptr<type>(cold, offsetof(ColdArgs, q) + offsetof(RoundArgs, field))
+
 template <int BLK, int WPS>
-__global__ __launch_bounds__(BLK, WPS) void k_rollout_queue(RolloutArgs a, RoundArgs q) {
+__global__ __launch_bounds__(BLK, WPS) void k_rollout_queue(RolloutArgs a_in, RoundArgs q_in) {
   extern __shared__ __align__(16) uint8_t smem[];
   lds_u32 *party = (lds_u32 *)smem;
   using ER = EngineR<BLK, false>;
   Tables T = stage_default_tables((lds_u8 *)smem + ER::PARTY_WORDS * BLK * 4);
+  lds_u32 *cold = (lds_u32 *)((lds_u8 *)smem + ER::PARTY_WORDS * BLK * 4 + TABLE_LDS_PAD);
+  if (threadIdx.x == 0) {
+    const ColdArgs c{a_in, q_in};
+    const uint32_t *src = (const uint32_t *)&c;
+#pragma unroll
+    for (uint32_t i = 0; i < sizeof(ColdArgs) / 4; ++i) cold[i] = src[i];
+  }
   __syncthreads();
   const uint32_t tid = threadIdx.x, wl = tid & 63;
   constexpr uint32_t NONE = 0xFFFFFFFFu, DONE = 0xFFFFFFFEu;
-  const uint32_t total = q.list_in ? *q.n_in : a.n;
+  // the few scalars the turn loop itself needs stay in SGPRs
+  const bool resume = q_in.list_in != nullptr; // a later round: playouts come from the previous round's suspended list
+  const uint32_t total = resume ? *q_in.n_in : a_in.n;
+  const uint32_t max_steps = a_in.max_steps, suspend_below = q_in.suspend_below;
+  const bool prep = !resume && a_in.prep;
   ER e;
   e.m = party + tid;
   e.T = T;
@@ -301,72 +328,73 @@ __global__ __launch_bounds__(BLK, WPS) void k_rollout_queue(RolloutArgs a, Round
     if (mask) { // wave-uniform
       OAK_SCOPE(PS_REFILL);
       uint32_t base = 0;
-      if (wl == 0) base = atomicAdd(q.queue, (uint32_t)__popcll(mask));
+      if (wl == 0) base = atomicAdd(COLD_Q(queue, uint32_t *), (uint32_t)__popcll(mask));
       base = __shfl(base, 0, 64);
       dry = base + (uint32_t)__popcll(mask) >= total;
       if (need) {
         const uint32_t my = base + (uint32_t)__popcll(mask & ((1ull << wl) - 1));
         if (my < total) {
-          const bool resume = q.list_in != nullptr; // uniform: a suspended playout of the previous round
-          idx = resume ? q.list_in[my] : my;
-          const uint32_t *dsrc = (const uint32_t *)(resume ? q.sd : a.durations) + 2 * (size_t)idx;
-          const uint32_t *psrc = (const uint32_t *)a.prng + 2 * (size_t)idx;
+          idx = resume ? COLD_Q(list_in, const uint32_t *)[my] : my;
+          const uint32_t *dsrc = (resume ? COLD_Q(sd, const uint32_t *) : COLD_A(durations, const uint32_t *)) + 2 * (size_t)idx;
+          const uint32_t *psrc = COLD_A(prng, const uint32_t *) + 2 * (size_t)idx;
           g.s0 = psrc[0];
           g.s1 = psrc[1];
-          e.load_battle_global((resume ? q.sb : a.battles) + (size_t)idx * 384, dsrc[0], dsrc[1]);
-          if (!resume && a.prep) { // mcts.h:254-259
+          e.load_battle_global((resume ? COLD_Q(sb, const uint8_t *) : COLD_A(battles, const uint8_t *)) + (size_t)idx * 384, dsrc[0], dsrc[1]);
+          if (prep) { // mcts.h:254-259
             const uint32_t hi = g.next32(), lo = g.next32();
             e.rng = ((uint64_t)hi << 32) | lo;
             e.randomize_hidden();
           }
-          result = (resume ? q.sres : a.results_in)[idx];
-          steps = resume ? a.steps_out[idx] : 0;
+          result = (resume ? COLD_Q(sres, const uint8_t *) : COLD_A(results_in, const uint8_t *))[idx];
+          steps = resume ? COLD_A(steps_out, const uint32_t *)[idx] : 0;
         } else idx = DONE;
       }
     }
     if (__ballot(idx != DONE) == 0) break;
-    bool playing = idx != DONE && (result & 15) == 0 && steps < a.max_steps;
+    bool playing = idx != DONE && (result & 15) == 0 && steps < max_steps;
     if (playing) {
       const uint32_t hi = g.next32(), lo = g.next32(); // uniform_64 = hi << 32 | lo
       result = e.random_step(result, hi, lo);
       ++steps;
-      playing = (result & 15) == 0 && steps < a.max_steps;
+      playing = (result & 15) == 0 && steps < max_steps;
     }
     // wave-uniform: the queue is dry and too few lanes are still playing -> hand them to the next round
     const uint64_t still = __ballot(playing);
-    const bool suspend = dry && still != 0 && (uint32_t)__popcll(still) < q.suspend_below;
+    const bool suspend = dry && still != 0 && (uint32_t)__popcll(still) < suspend_below;
     if (idx != DONE && (!playing || suspend)) { // retire the lane: publish a finished playout / park a suspended one
       OAK_SCOPE(PS_PUBLISH);
       const bool fin = !playing;
       e.normalize();
-      (fin ? a.results_out : q.sres)[idx] = (uint8_t)result;
-      a.steps_out[idx] = steps;
+      (fin ? COLD_A(results_out, uint8_t *) : COLD_Q(sres, uint8_t *))[idx] = (uint8_t)result;
+      COLD_A(steps_out, uint32_t *)[idx] = steps;
       const uint32_t t = result & 15;
-      if (fin) a.values_out[idx] = t == R_WIN ? 1.0f : t == R_LOSE ? 0.0f : 0.5f;
-      uint32_t *pdst = (uint32_t *)a.prng + 2 * (size_t)idx;
+      if (fin) COLD_A(values_out, float *)[idx] = t == R_WIN ? 1.0f : t == R_LOSE ? 0.0f : 0.5f;
+      uint32_t *pdst = COLD_A(prng, uint32_t *) + 2 * (size_t)idx;
       pdst[0] = g.s0;
       pdst[1] = g.s1;
-      uint8_t *ddst8 = fin ? a.durations_out : q.sd;
-      if (ddst8) {
-        uint32_t *ddst = (uint32_t *)ddst8 + 2 * (size_t)idx;
+      uint32_t *ddst = fin ? COLD_A(durations_out, uint32_t *) : COLD_Q(sd, uint32_t *);
+      if (ddst) {
+        ddst += 2 * (size_t)idx;
         ddst[0] = e.S.dur;
         ddst[1] = e.F.dur;
       }
-      uint8_t *bdst = fin ? a.battles_out : q.sb;
+      uint8_t *bdst = fin ? COLD_A(battles_out, uint8_t *) : COLD_Q(sb, uint8_t *);
       if (bdst) e.store_battle_global(bdst + (size_t)idx * 384);
       idx = fin ? NONE : idx;
     }
     if (suspend) {
       const uint32_t leader = (uint32_t)__ffsll((unsigned long long)still) - 1;
       uint32_t base = 0;
-      if (wl == leader) base = atomicAdd(q.count_out, (uint32_t)__popcll(still));
+      if (wl == leader) base = atomicAdd(COLD_Q(count_out, uint32_t *), (uint32_t)__popcll(still));
       base = __shfl(base, leader, 64);
-      if (playing) q.list_out[base + (uint32_t)__popcll(still & ((1ull << wl) - 1))] = idx;
+      if (playing) COLD_Q(list_out, uint32_t *)[base + (uint32_t)__popcll(still & ((1ull << wl) - 1))] = idx;
       break;
     }
   }
   OAK_PROF_FLUSH();
 }
+#undef COLD_A
+#undef COLD_Q
 
 // ---- batched single update -------------------------------------------------------------------
 __global__ __launch_bounds__(BLOCK) void k_update(uint8_t *battles, const uint8_t *c1, const uint8_t *c2,
@@ -594,7 +622,7 @@ static int set_lds_limits() {
   HIPCHK(hipFuncSetAttribute((const void *)oak::k_rollout<64>, hipFuncAttributeMaxDynamicSharedMemorySize, oak::STATE_WORDS * 64 * 4 + oak::TABLE_LDS_PAD));
   HIPCHK(hipFuncSetAttribute((const void *)oak::k_rollout_regs<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 24 * 128 * 4 + oak::TABLE_LDS_PAD));
   HIPCHK(hipFuncSetAttribute((const void *)oak::k_rollout_regs<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 24 * 64 * 4 + oak::TABLE_LDS_PAD));
-#define OAK_LIM_Q(W) HIPCHK(hipFuncSetAttribute((const void *)oak::k_rollout_queue<64, W>, hipFuncAttributeMaxDynamicSharedMemorySize, 24 * 64 * 4 + oak::TABLE_LDS_PAD))
+#define OAK_LIM_Q(W) HIPCHK(hipFuncSetAttribute((const void *)oak::k_rollout_queue<64, W>, hipFuncAttributeMaxDynamicSharedMemorySize, 24 * 64 * 4 + oak::TABLE_LDS_PAD + oak::COLD_LDS_BYTES))
   OAK_LIM_Q(2); OAK_LIM_Q(3); OAK_LIM_Q(4);
 #undef OAK_LIM_Q
   HIPCHK(hipFuncSetAttribute((const void *)oak::k_update, hipFuncAttributeMaxDynamicSharedMemorySize, oak::ENGINE_LDS_BYTES));
@@ -722,7 +750,7 @@ int oakgpu_rollout_dev(oakgpu_ctx *c, const uint8_t *battles, const uint8_t *dur
       HIPCHK(hipMalloc((void **)&c->d_scratch, (size_t)n * (384 + 8 + 4 + 4) + (((size_t)n + 15) & ~(size_t)15)));
       c->scratch_n = n;
     }
-    const size_t lq = 24 * 64 * 4 + oak::TABLE_LDS_PAD;
+    const size_t lq = 24 * 64 * 4 + oak::TABLE_LDS_PAD + oak::COLD_LDS_BYTES;
     uint8_t *sb = c->d_scratch, *sd = sb ? sb + (size_t)c->scratch_n * 384 : nullptr;
     uint32_t *lists[2] = {sd ? (uint32_t *)(sd + (size_t)c->scratch_n * 8) : nullptr, nullptr};
     lists[1] = lists[0] ? lists[0] + c->scratch_n : nullptr;
