@@ -169,11 +169,13 @@ def main():
         avg_kernel_s = (sum(kern_ms) / len(kern_ms)) / 1e3
         steps_per_launch = my_steps / args.steps
         achieved = steps_per_launch * ALGO_BYTES_PER_STEP / avg_kernel_s / 1e9
-        traffic = None
-        tp = os.path.join(ROOT, "profiles", "traffic.json")   # rocprofv3 --pmc result, bytes per launch
+        traffic, valu = None, None
+        tp = os.path.join(ROOT, "profiles", "traffic.json")   # rocprofv3 --pmc results, per step (tools/summarize_profile.py)
         if os.path.exists(tp):
             try:
-                traffic = json.load(open(tp)).get("k_rollout_hbm_bytes_per_launch")
+                tj = json.load(open(tp))
+                traffic = tj.get("k_rollout_hbm_bytes_per_launch")
+                valu = tj.get("valu_wave_insts_per_step")
             except Exception:
                 traffic = None
         out = {
@@ -203,7 +205,7 @@ def main():
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "oak::k_rollout",
+                "kernel": "oak::k_rollout_queue (one step = its regrouping dispatches on one stream)",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",
@@ -216,6 +218,12 @@ def main():
                 "turn_steps_per_launch": steps_per_launch,
             },
         }
+        if valu:
+            # the kernel is integer-VALU bound, not HBM bound: wave-instructions issued per step (PMC
+            # SQ_INSTS_VALU, committed in profiles/) against 1024 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction
+            peak = 1024 * 2.4e9 / 4
+            out["roofline"]["valu_issue"] = {"wave_insts_per_step": valu, "achieved_ginst_s": valu / (elapsed / args.steps) / 1e9,
+                                             "peak_ginst_s": peak / 1e9, "frac": valu / (elapsed / args.steps) / peak}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(n)
         print(json.dumps(out), flush=True)
