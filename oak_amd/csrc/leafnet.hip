@@ -417,6 +417,246 @@ __global__ __launch_bounds__(EMB_BLOCK) void k_embed_tile(EmbedTileArgs a) {
   }
 }
 
+// ---- K2, LDS-resident first layer (the default).  k_embed_tile's sparse first layer gathers ~210 weight rows of
+// 512 B per leaf from L2 (7 GB per 65,536-leaf batch) one item after the other, and that gather latency is
+// what it spends its time on.  Here one 512-thread workgroup per CU keeps the first-layer weights in LDS:
+//   party-slot kind : all 198 rows of W0^T (99 KB);
+//   active kind     : the 99 rows that are NOT move one-hots (stats, types, boosts, volatiles, durations and
+//                     the stored Pokemon's stats / status / types: 50 KB) -- they carry ~37 of an item's ~45
+//                     non-zeros; the <= 8 move rows still come from L2, prefetched for four items at once so
+//                     that their latency hides behind the LDS part.
+// The dense second layer stays on fp32 MFMA, with its B operand (W1, 64 values per lane) held in registers
+// instead of LDS.  Items per tile, tile layout and outputs are k_embed_tile's.
+constexpr int EL_BLOCK = 512;
+constexpr int EL_WAVES = EL_BLOCK / 64;
+constexpr int EL_ITEMS = ET / EL_WAVES; // 8 items per wave
+constexpr int EL_A_ROWS = 99;
+template <bool ACT> struct ELayout {
+  static constexpr int NROWS = ACT ? EL_A_ROWS : 198;
+  static constexpr int LCAP = ACT ? 48 : 16; // LDS-row features per item (<= 44 / 12), padded to a multiple of 4
+  static constexpr int NLEAF = ACT ? 34 : 9; // leaves a tile of 64 items can touch
+  static constexpr size_t BYTES = (size_t)(NROWS * 128 + ET * EHP + 2 * ET * LCAP + ET * 8 + 3 * ET + NLEAF * 98) * 4;
+};
+// LDS slot of row r of the active net's W0^T (move rows excluded), and its inverse
+__device__ __forceinline__ uint32_t active_lds_slot(uint32_t r) { return r < 45 ? r : r < 234 ? r - 164 : r - 328; }
+__device__ __forceinline__ uint32_t active_lds_row(uint32_t s) { return s < 45 ? s : s < 70 ? s + 164 : s + 328; }
+
+template <bool ACT>
+__global__ __launch_bounds__(EL_BLOCK) void k_embed_lds(EmbedTileArgs a) {
+  extern __shared__ __align__(16) float lds_f[];
+  using L = ELayout<ACT>;
+  const NetDev &N = a.net;
+  const int hidden = ACT ? N.a_hidden : N.p_hidden;
+  const int out_dim = ACT ? N.a_out : N.p_out;
+  const int NBo = (out_dim + 31) >> 5;
+  float *W0s = lds_f;                                   // NROWS x 128 (zero-padded beyond `hidden`)
+  float *Hs = W0s + L::NROWS * 128;                     // ET x EHP
+  uint32_t *Lidx = (uint32_t *)(Hs + ET * EHP);         // per item: LCAP LDS word offsets of W0s rows
+  float *Lval = (float *)(Lidx + ET * L::LCAP);         // ... and their feature values
+  uint32_t *Gidx = (uint32_t *)(Lval + ET * L::LCAP);   // per item: 8 global W0^T rows (move one-hots, ACT only)
+  uint32_t *meta = Gidx + ET * 8;                       // per item: countL | nG << 8
+  uint32_t *dst_off = meta + ET;                        // per item: float offset of its block in emb, or ~0
+  float *hp_ratio = (float *)(dst_off + ET);
+  uint32_t *Bs = (uint32_t *)(hp_ratio + ET);           // staged battles: 96 dwords + 2 duration dwords per leaf
+  const float *w0t = ACT ? N.a_w0t : N.p_w0t;
+  const float *W1 = ACT ? N.a_w1 : N.p_w1;
+  const float *b0 = ACT ? N.a_b0 : N.p_b0;
+  const float *b1 = ACT ? N.a_b1 : N.p_b1;
+  for (int i = threadIdx.x; i < L::NROWS * 128; i += EL_BLOCK) {
+    const uint32_t sl = (uint32_t)i >> 7, c = (uint32_t)i & 127;
+    const uint32_t r = ACT ? active_lds_row(sl) : sl;
+    W0s[i] = (int)c < hidden ? w0t[(size_t)r * hidden + c] : 0.0f;
+  }
+  const uint32_t lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+  const uint32_t c0 = lane, c1 = lane + 64;
+  const bool on0 = (int)c0 < hidden, on1 = (int)c1 < hidden;
+  const uint32_t cc0 = on0 ? c0 : 0, cc1 = on1 ? c1 : 0;
+  const float bias0 = on0 ? b0[c0] : 0.0f, bias1 = on1 ? b0[c1] : 0.0f;
+  // MFMA role of this wave: output block (mi, nb) of the 64 x out_pad tile; B fragments stay in registers
+  const int mi = wib & 1, nb = wib >> 1, r32 = lane & 31, hh = lane >> 5;
+  const bool mfma_wave = nb < NBo;
+  float bfrag[64];
+  {
+    const int o = nb * 32 + r32;
+#pragma unroll
+    for (int s2 = 0; s2 < 64; ++s2) {
+      const int c = 2 * s2 + hh;
+      bfrag[s2] = (mfma_wave && o < out_dim && c < hidden) ? W1[(size_t)o * hidden + c] : 0.0f;
+    }
+  }
+  const float obias = (mfma_wave && nb * 32 + r32 < out_dim) ? b1[nb * 32 + r32] : 0.0f;
+  const uint32_t per_leaf = ACT ? 2 : 10;
+  const uint32_t items = a.n * per_leaf;
+  const uint32_t ntiles = (items + ET - 1) / ET;
+  // The battles a tile touches are staged in LDS; the NEXT tile's are already on their way in registers while
+  // this one is processed (one workgroup per CU: nothing else would hide that latency).
+  constexpr uint32_t PF = (L::NLEAF * 98 + EL_BLOCK - 1) / EL_BLOCK; // staged dwords per thread
+  uint32_t pf[PF];
+  auto tile_leaves = [&](uint32_t tile, uint32_t &first_leaf) {
+    first_leaf = (tile * ET) / per_leaf;
+    uint32_t last_leaf = (tile * ET + ET - 1) / per_leaf;
+    if (last_leaf >= a.n) last_leaf = a.n - 1;
+    return last_leaf - first_leaf + 1;
+  };
+  auto prefetch = [&](uint32_t tile) {
+    uint32_t first_leaf;
+    const uint32_t nl = tile < ntiles ? tile_leaves(tile, first_leaf) : 0;
+#pragma unroll
+    for (uint32_t u = 0; u < PF; ++u) {
+      const uint32_t i = threadIdx.x + u * EL_BLOCK; // slot i of the staged image: leaf i / 98, dword i % 98
+      const uint32_t l = i / 98, d = i - l * 98;
+      pf[u] = 0;
+      if (l < nl) pf[u] = d < 96 ? ((const uint32_t *)a.battles)[(size_t)(first_leaf + l) * 96 + d]
+                                 : ((const uint32_t *)a.durations)[(size_t)(first_leaf + l) * 2 + (d - 96)];
+    }
+  };
+  prefetch(blockIdx.x);
+  for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    __syncthreads(); // previous tile fully consumed (also orders the one-time W0s staging)
+    uint32_t first_leaf;
+    (void)tile_leaves(tile, first_leaf);
+#pragma unroll
+    for (uint32_t u = 0; u < PF; ++u) { const uint32_t i = threadIdx.x + u * EL_BLOCK; if (i < (uint32_t)L::NLEAF * 98) Bs[i] = pf[u]; }
+    __syncthreads();
+    prefetch(tile + gridDim.x);
+    // ---- phase 1a: sparse feature lists of this wave's 8 items.  A lane evaluates ONE feature of one item:
+    // the 52 features of an active in one pass per item, the 12 features of a party slot five items per pass.
+    {
+      constexpr uint32_t FL = ACT ? 64 : 12, IPP = ACT ? 1 : 5, PASSES = (EL_ITEMS + IPP - 1) / IPP;
+      for (uint32_t k = lane; k < (uint32_t)(EL_ITEMS * L::LCAP); k += 64) { // padding entries: row 0 with weight 0
+        Lidx[wib * EL_ITEMS * L::LCAP + k] = 0;
+        Lval[wib * EL_ITEMS * L::LCAP + k] = 0.0f;
+      }
+      Gidx[wib * EL_ITEMS * 8 + lane] = 0;
+      const uint32_t sub = ACT ? 0 : lane / FL, j = ACT ? lane : lane - sub * FL;
+#pragma unroll 1
+      for (uint32_t pass = 0; pass < PASSES; ++pass) {
+        const uint32_t ii = pass * IPP + sub;
+        const bool mine = sub < IPP && ii < (uint32_t)EL_ITEMS;
+        const uint32_t i = wib * EL_ITEMS + (mine ? ii : 0);
+        const uint32_t g = tile * ET + i;
+        uint32_t fidx = 0, doff = 0xFFFFFFFFu, hp = 0, pk0 = 0;
+        float fval = 0.0f;
+        bool valid = false, is_move = false;
+        if (mine && g < items) {
+          const uint32_t leaf = g / per_leaf, q = g - leaf * per_leaf;
+          const uint32_t side = ACT ? q : q / 5, slot = ACT ? 0 : 1 + (q - side * 5);
+          const uint32_t *lb = Bs + (leaf - first_leaf) * 98;
+          const uint32_t *sb = lb + side * 46;
+          const uint32_t dur = lb[96 + side];
+          const uint32_t o0 = sb[44], o1 = sb[45];
+          const uint32_t id = slot < 4 ? (o0 >> (8 * slot)) & 0xFF : (o1 >> (8 * (slot - 4))) & 0xFF;
+          const uint32_t dd = leaf * N.emb_dim + side * N.side_dim + (ACT ? 0 : (1 + N.a_out) + (slot - 1) * (1 + N.p_out));
+          uint32_t pk1 = 0, pk2 = 0, pk3 = 0, pk4 = 0, pk5 = 0;
+          if (id != 0) {
+            const uint32_t *pk = sb + 6 * (id - 1);
+            pk0 = pk[0]; pk1 = pk[1]; pk2 = pk[2]; pk3 = pk[3]; pk4 = pk[4]; pk5 = pk[5];
+            hp = pk4 >> 16;
+          }
+          if (hp == 0) { // empty or fainted: zero block (network.h:142-143,153-160), kept out of phase 3
+            float *dst = a.emb + dd;
+            for (uint32_t o = j; o < (uint32_t)out_dim + 1; o += FL) dst[o] = 0.0f;
+          } else {
+            doff = dd;
+            if (ACT) {
+              const uint32_t *ac = sb + 36;
+              if (j < 40) { valid = active_feature(j, ac[0], ac[1], ac[2], ac[3], ac[4], ac[5], ac[6], ac[7], dur, fidx, fval); is_move = j >= 32 && j < 36; }
+              else if (j < 52) { valid = pokemon_feature(j - 40, pk0, pk1, pk2, pk3, pk4, pk5, dur & 7, fidx, fval); fidx += 229; is_move = j >= 45 && j < 49; }
+            } else {
+              valid = pokemon_feature(j, pk0, pk1, pk2, pk3, pk4, pk5, (dur >> (3 * slot)) & 7, fidx, fval);
+            }
+          }
+        }
+        const bool inL = valid && !is_move, inG = valid && is_move;
+        const uint64_t mL = __ballot(inL), mG = __ballot(inG);
+        const uint32_t sh = sub * FL; // this item's lanes are bits [sh, sh + FL)
+        const uint64_t item_bits = FL == 64 ? ~0ull : (((1ull << FL) - 1) << sh);
+        const uint64_t below = (1ull << lane) - 1;
+        if (inL) {
+          const uint32_t pos = (uint32_t)__popcll(mL & item_bits & below);
+          Lidx[i * L::LCAP + pos] = (ACT ? active_lds_slot(fidx) : fidx) * 128;
+          Lval[i * L::LCAP + pos] = fval;
+        }
+        if (inG) Gidx[i * 8 + (uint32_t)__popcll(mG & item_bits & below)] = fidx;
+        if (mine && j == 0) {
+          meta[i] = (uint32_t)__popcll(mL & item_bits) | ((uint32_t)__popcll(mG & item_bits) << 8);
+          dst_off[i] = doff;
+          if (doff != 0xFFFFFFFFu) hp_ratio[i] = (float)hp / (float)(pk0 & 0xFFFF);
+        }
+      }
+    }
+    // ---- phase 1b/c: first layer, four items at a time (their LDS reads interleave: fixed trip counts, padded
+    // lists); the active kind's move rows are prefetched from L2 first and added last ----
+#pragma unroll 1
+    for (uint32_t half = 0; half < 2; ++half) {
+      const uint32_t ibase = wib * EL_ITEMS + half * 4;
+      float gx0[4][8], gx1[4][8];
+      if (ACT) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const uint4 ra = *(const uint4 *)(Gidx + (ibase + t) * 8), rb = *(const uint4 *)(Gidx + (ibase + t) * 8 + 4);
+          const uint32_t rr[8] = {ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, rb.z, rb.w};
+#pragma unroll
+          for (int u = 0; u < 8; ++u) { const float *row = w0t + (size_t)rr[u] * hidden; gx0[t][u] = row[cc0]; gx1[t][u] = row[cc1]; }
+        }
+      }
+      float h0[4], h1[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) { h0[t] = bias0; h1[t] = bias1; }
+      uint32_t kmax = 12; // party slots: at most 12 features; actives: the longest of the four lists (<= 44)
+      if (ACT) {
+        kmax = 0;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { const uint32_t c = __builtin_amdgcn_readfirstlane(meta[ibase + t]) & 0xFF; kmax = c > kmax ? c : kmax; }
+      }
+#pragma unroll 1
+      for (uint32_t k = 0; k < kmax; k += 4) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const uint4 iv = *(const uint4 *)(Lidx + (ibase + t) * L::LCAP + k);
+          const float4 vv = *(const float4 *)(Lval + (ibase + t) * L::LCAP + k);
+          h0[t] = fmaf(W0s[iv.x + c0], vv.x, h0[t]); h1[t] = fmaf(W0s[iv.x + c1], vv.x, h1[t]);
+          h0[t] = fmaf(W0s[iv.y + c0], vv.y, h0[t]); h1[t] = fmaf(W0s[iv.y + c1], vv.y, h1[t]);
+          h0[t] = fmaf(W0s[iv.z + c0], vv.z, h0[t]); h1[t] = fmaf(W0s[iv.z + c1], vv.z, h1[t]);
+          h0[t] = fmaf(W0s[iv.w + c0], vv.w, h0[t]); h1[t] = fmaf(W0s[iv.w + c1], vv.w, h1[t]);
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const uint32_t i = ibase + t;
+        if (ACT) {
+          const uint32_t nG = __builtin_amdgcn_readfirstlane(meta[i]) >> 8;
+#pragma unroll
+          for (int u = 0; u < 8; ++u) { const float w = (uint32_t)u < nG ? 1.0f : 0.0f; h0[t] = fmaf(gx0[t][u], w, h0[t]); h1[t] = fmaf(gx1[t][u], w, h1[t]); }
+        }
+        const bool live = dst_off[i] != 0xFFFFFFFFu;
+        float *hrow = Hs + i * EHP;
+        hrow[c0] = (on0 && live) ? act_fn(h0[t], N.activation) : 0.0f;
+        hrow[c1] = (on1 && live) ? act_fn(h1[t], N.activation) : 0.0f;
+      }
+    }
+    __syncthreads();
+    // ---- phase 2: OUT[64][out_pad] = H[64][128] . W1^T on fp32 MFMA (one 32x32 block per wave) ----
+    if (mfma_wave) {
+      f32x16 acc;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[q] = 0.0f;
+      const float *arow = Hs + (mi * 32 + r32) * EHP + hh;
+#pragma unroll
+      for (int s2 = 0; s2 < 64; ++s2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(arow[2 * s2], bfrag[s2], acc, 0, 0, 0);
+      // ---- phase 3: bias + activation + scatter ----
+      const int o = nb * 32 + r32;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int row = (q & 3) + 8 * (q >> 2) + 4 * hh;
+        const uint32_t doff = dst_off[mi * 32 + row];
+        if (o < out_dim && doff != 0xFFFFFFFFu) a.emb[(size_t)doff + 1 + o] = act_fn(acc[q] + obias, N.activation);
+      }
+    }
+    if (threadIdx.x < ET && dst_off[threadIdx.x] != 0xFFFFFFFFu) a.emb[dst_off[threadIdx.x]] = hp_ratio[threadIdx.x];
+  }
+}
+
 // ---- K3: main net on fp32 MFMA ------------------------------------------------------------------
 constexpr int MN_BLOCK = 256; // 4 waves
 constexpr int TM = 64;        // leaves per workgroup tile
@@ -809,6 +1049,10 @@ static int lds_attrs_once() {
   if (e != hipSuccess) return oakgpu_fail_hip((int)e, "hipFuncSetAttribute(k_embed)");
   e = hipFuncSetAttribute((const void *)oak::k_embed_tile, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
   if (e != hipSuccess) return oakgpu_fail_hip((int)e, "hipFuncSetAttribute(k_embed_tile)");
+  e = hipFuncSetAttribute((const void *)oak::k_embed_lds<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)oak::ELayout<false>::BYTES);
+  if (e != hipSuccess) return oakgpu_fail_hip((int)e, "hipFuncSetAttribute(k_embed_lds<party>)");
+  e = hipFuncSetAttribute((const void *)oak::k_embed_lds<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)oak::ELayout<true>::BYTES);
+  if (e != hipSuccess) return oakgpu_fail_hip((int)e, "hipFuncSetAttribute(k_embed_lds<active>)");
   e = hipFuncSetAttribute((const void *)oak::k_policy, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
   if (e != hipSuccess) return oakgpu_fail_hip((int)e, "hipFuncSetAttribute(k_policy)");
   e = hipFuncSetAttribute((const void *)oak::k_mainnet, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
@@ -838,7 +1082,8 @@ static int leaf_eval_impl(oakgpu_ctx *ctx, oakgpu_net *net, const uint8_t *battl
     emb = net->emb_ws;
   }
   const oak::NetDev &D = net->dev;
-  if (getenv("OAKGPU_EMBED_V1")) { // first implementation (one wave per item, VALU second layer), kept for A/B
+  static const int embed_impl = getenv("OAKGPU_EMBED_IMPL") ? atoi(getenv("OAKGPU_EMBED_IMPL")) : 3;
+  if (embed_impl == 1) { // first implementation (one wave per item, VALU second layer), kept for A/B
     oak::EmbedArgs ea{D, battles, durations, n, emb};
     const size_t emb_lds = (size_t)(D.p_hidden * D.p_out + D.a_hidden * D.a_out + 4 * 256) * 4;
     uint32_t grid = (n * 12 + 3) / 4;
@@ -847,11 +1092,16 @@ static int leaf_eval_impl(oakgpu_ctx *ctx, oakgpu_net *net, const uint8_t *battl
   } else {
     for (int kind = 0; kind < 2; ++kind) {
       oak::EmbedTileArgs ta{D, battles, durations, n, emb, kind};
-      const int out_pad = ((kind ? D.a_out : D.p_out) + 31) & ~31;
-      const size_t lds = (size_t)(oak::ET * oak::EHP + out_pad * oak::EHP + 4 * 128 + 2 * oak::ET + (kind ? 34 : 9) * 98) * 4;
       const uint32_t ntiles = (n * (kind ? 2u : 10u) + oak::ET - 1) / oak::ET;
-      uint32_t grid = ntiles < 1024 ? ntiles : 1024;
-      hipLaunchKernelGGL(oak::k_embed_tile, dim3(grid), dim3(oak::EMB_BLOCK), lds, stream, ta);
+      if (embed_impl == 2) { // second implementation: first-layer rows gathered from L2 (A/B)
+        const int out_pad = ((kind ? D.a_out : D.p_out) + 31) & ~31;
+        const size_t lds = (size_t)(oak::ET * oak::EHP + out_pad * oak::EHP + 4 * 128 + 2 * oak::ET + (kind ? 34 : 9) * 98) * 4;
+        hipLaunchKernelGGL(oak::k_embed_tile, dim3(ntiles < 1024 ? ntiles : 1024), dim3(oak::EMB_BLOCK), lds, stream, ta);
+      } else {               // default: first-layer weights resident in LDS, one workgroup per CU
+        const uint32_t grid = ntiles < 256 ? ntiles : 256;
+        if (kind) hipLaunchKernelGGL(oak::k_embed_lds<true>, dim3(grid), dim3(oak::EL_BLOCK), oak::ELayout<true>::BYTES, stream, ta);
+        else hipLaunchKernelGGL(oak::k_embed_lds<false>, dim3(grid), dim3(oak::EL_BLOCK), oak::ELayout<false>::BYTES, stream, ta);
+      }
     }
   }
   float *h1 = nullptr;
