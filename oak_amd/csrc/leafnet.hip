@@ -17,6 +17,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/oakgpu.h"
@@ -660,7 +661,7 @@ __global__ __launch_bounds__(EL_BLOCK) void k_embed_lds(EmbedTileArgs a) {
 // ---- K3: main net on fp32 MFMA ------------------------------------------------------------------
 constexpr int MN_BLOCK = 256; // 4 waves
 constexpr int TM = 64;        // leaves per workgroup tile
-constexpr int KC = 32;        // K chunk staged per iteration
+constexpr int KC = 64;        // K chunk staged per iteration
 constexpr int KCP = KC + 1;   // padded LDS row stride (odd => conflict-free column reads)
 constexpr int MAXH = 256;
 
@@ -727,18 +728,28 @@ __device__ __forceinline__ void dense_layer(const float *a_global, int a_ld, uin
     const int kmax = (K - k0) < KC ? (K - k0) : KC;
     const float *arow = A_FROM_GLOBAL ? xs + (mi * 32 + r) * KCP + h : a_lds + (mi * 32 + r) * a_lds_ld + k0 + h;
     const float *brow = ws + (nb0 * 32 + r) * KCP + h; // n-block j of this wave sits 64 rows further per j
-    auto step = [&](int s) {
-      const float av = arow[2 * s];
+    // JN = how many of this wave's four n-blocks exist (wave-uniform).  The count is resolved ONCE per chunk, so
+    // that the k-steps below are straight-line code: with a per-MFMA `if (block exists)` every MFMA sits in its
+    // own basic block and the next step's LDS reads cannot be scheduled under the current step's MFMAs.
+    const int JN = NB - nb0 <= 0 ? 0 : (NB - nb0 + 1) / 2 > 4 ? 4 : (NB - nb0 + 1) / 2;
+    auto run = [&](auto jn_tag) {
+      constexpr int JNc = decltype(jn_tag)::value;
+      auto step = [&](int s) {
+        const float av = arow[2 * s];
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
-        if (nb0 + 2 * j < NB) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, brow[j * 64 * KCP + 2 * s], acc[j], 0, 0, 0);
+        for (int j = 0; j < JNc; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, brow[j * 64 * KCP + 2 * s], acc[j], 0, 0, 0);
+      };
+      if (kmax == KC) {
+#pragma unroll
+        for (int s = 0; s < KC / 2; ++s) step(s); // fully unrolled: next step's ds_reads issue under this step's MFMAs
+      } else {
+        for (int s = 0; s < kmax / 2; ++s) step(s);
+      }
     };
-    if (kmax == KC) {
-#pragma unroll
-      for (int s = 0; s < KC / 2; ++s) step(s); // fully unrolled: next step's ds_reads issue under this step's MFMAs
-    } else {
-      for (int s = 0; s < kmax / 2; ++s) step(s);
-    }
+    if (JN == 4) run(std::integral_constant<int, 4>{});
+    else if (JN == 3) run(std::integral_constant<int, 3>{});
+    else if (JN == 2) run(std::integral_constant<int, 2>{});
+    else if (JN == 1) run(std::integral_constant<int, 1>{});
   }
 }
 
