@@ -50,8 +50,9 @@ def main():
     ap.add_argument("--streams", type=int, default=20, help="independent batches in flight (HIP streams)")
     ap.add_argument("--playouts-per-lane", type=int, default=2,
                     help="k > 1: persistent n/k lanes per batch that refill from an atomic playout queue")
-    ap.add_argument("--workload", choices=["rollout", "leaf"], default="rollout",
-                    help="rollout = BASELINE configs[1] (headline); leaf = leaf-evals/s of the 768-256-256-256-1 net")
+    ap.add_argument("--workload", choices=["rollout", "leaf", "config3"], default="rollout",
+                    help="rollout = BASELINE configs[1] (headline); leaf = leaf-evals/s of the 768-256-256-256-1 net; "
+                         "config3 = configs[2]: one turn-step of the whole batch + a leaf eval of every lane, every turn")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -79,7 +80,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm
 
-    if args.workload == "leaf":
+    if args.workload in ("leaf", "config3"):
         return leaf_workload(args, torch, dev, rank, local_rank, world, dist)
 
     n = args.batch
@@ -269,10 +270,32 @@ def leaf_workload(args, torch, dev, rank, local_rank, world, dist):
         netfile.write_random_net(path, seed=7, hidden=256, value_hidden=256)
         net = Network(ctx, path=path)
 
+    config3 = args.workload == "config3"
+    live = torch.zeros((), dtype=torch.int64, device=dev)
+    turn = [0]
+    if config3:   # start every 40-turn episode from the turn-0 batch (restoring it is a 26 MB device copy)
+        b0, d0, p0, r0 = battles.clone(), durations.clone(), prng.clone(), rin.clone()
+
     def step():
-        _lib.check(lib.oakgpu_leaf_eval_dev(h, net.handle, P(mid), P(dur_mid), n, P(values), P(emb)))
+        if config3:
+            # BASELINE configs[2]: one random turn-step of all 65,536 lanes, in place (a rollout capped at one step),
+            # then a leaf evaluation of every lane's new state -- "MLP leaf eval every turn"
+            if turn[0] % 40 == 0:
+                with torch.cuda.stream(stream):
+                    battles.copy_(b0); durations.copy_(d0); prng.copy_(p0); rin.copy_(r0)
+            turn[0] += 1
+            _lib.check(lib.oakgpu_rollout_dev(h, P(battles), P(durations), P(rin), P(prng), n, 1, 0, P(rin), P(steps_out),
+                                              P(values), P(battles), P(durations)))
+            _lib.check(lib.oakgpu_leaf_eval_dev(h, net.handle, P(battles), P(durations), n, P(values), P(emb)))
+            with torch.cuda.stream(stream):
+                live.add_(steps_out.sum(dtype=torch.int64))
+        else:
+            _lib.check(lib.oakgpu_leaf_eval_dev(h, net.handle, P(mid), P(dur_mid), n, P(values), P(emb)))
     for _ in range(max(args.warmup, 1)):
         step()
+    turn[0] = 0
+    with torch.cuda.stream(stream):
+        live.zero_()
     ctx.synchronize()
     K = args.steps
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(K)]
@@ -298,7 +321,24 @@ def leaf_workload(args, torch, dev, rank, local_rank, world, dist):
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    if rank == 0:
+    if rank == 0 and config3:
+        main_f, emb_f = netfile.flops_per_leaf(256, 256)
+        avg_s = sum(a.elapsed_time(b) for a, b in ev) / K / 1e3
+        achieved = (main_f + emb_f) * n / avg_s / 1e12
+        steps_done = int(live.item())
+        print(json.dumps({
+            "metric": "turn-steps/s (rollout + leaf eval every turn)", "value": steps_done * world / elapsed, "unit": "turn-steps/s",
+            "n_gpus": world, "steps": K, "warmup": args.warmup, "ms_per_step": elapsed / K * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "configs[2]: batch=65536 random OU team pairs per GPU; every step = one random turn-step of the "
+                                   "whole batch (in place) + value_inference (768-256-256-256-1) of every lane; 40-turn episodes",
+                       "batch_per_gpu": n, "leaf_evals_per_s": n * world * K / elapsed,
+                       "live_lane_fraction": steps_done / (n * K)},
+            "roofline": {"bound": "mfma", "kernel": "oak::k_embed_lds (x2) + oak::k_mainnet (+ oak::k_rollout_queue, 1 step)",
+                         "achieved": achieved, "peak": 157.3, "unit": "TFLOP/s", "frac": achieved / 157.3, "traffic": None,
+                         "avg_step_ms": avg_s * 1e3, "algorithmic_flop_per_leaf": main_f + emb_f},
+        }), flush=True)
+    elif rank == 0:
         main_f, emb_f = netfile.flops_per_leaf(256, 256)
         avg_s = sum(a.elapsed_time(b) for a, b in ev) / K / 1e3
         achieved = (main_f + emb_f) * n / avg_s / 1e12

@@ -61,7 +61,9 @@ int oakgpu_device_count(void);
  *   results_out[i] : final pkmn_result byte (type 0 = hit the step cap)
  *   steps_out[i]   : number of pkmn_gen1_battle_update-equivalent turn-steps executed
  *   values_out[i]  : 1 / 0 / 0.5 for win / lose / (tie or capped)  (mcts.h:481-495)
- *   battles_out / durations_out (nullable): final state bytes, for parity checks. */
+ *   battles_out / durations_out (nullable): final state bytes (parity checks, stepping a resident batch).
+ * Every output may alias its input (battles_out == battles, durations_out == durations, results_out ==
+ * results_in): lane i only ever reads and writes row i. */
 int oakgpu_rollout_dev(oakgpu_ctx *ctx, const uint8_t *battles, const uint8_t *durations,
                        const uint8_t *results_in, uint8_t *prng_state, uint32_t n, uint32_t max_steps,
                        int prep, uint8_t *results_out, uint32_t *steps_out, float *values_out,

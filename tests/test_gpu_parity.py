@@ -204,6 +204,52 @@ def test_regrouping_rounds_do_not_change_results(gpu_ctx):
         gpu_ctx.set_regroup()
 
 
+def test_rollout_in_place_on_device_buffers(gpu_ctx):
+    """oakgpu_rollout_dev with battles_out == battles, durations_out == durations, results_out == results_in
+    (how bench.py --workload config3 steps a resident batch one turn at a time): same bytes as out of place.
+    Device buffers come straight from the HIP runtime the library already loaded (no torch in this process)."""
+    import ctypes as C
+    from oak_amd import _lib
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    hip.hipFree.argtypes = [C.c_void_p]
+    H2D, D2H = 1, 2
+
+    class Dev:
+        def __init__(self, arr):
+            self.shape, self.dtype, self.nbytes = arr.shape, arr.dtype, arr.nbytes
+            self.p = C.c_void_p()
+            assert hip.hipMalloc(C.byref(self.p), self.nbytes) == 0
+            a = np.ascontiguousarray(arr)
+            assert hip.hipMemcpy(self.p, a.ctypes.data_as(C.c_void_p), self.nbytes, H2D) == 0
+
+        def host(self):
+            out = np.empty(self.shape, dtype=self.dtype)
+            assert hip.hipMemcpy(out.ctypes.data_as(C.c_void_p), self.p, self.nbytes, D2H) == 0
+            return out
+
+        def free(self):
+            hip.hipFree(self.p)
+    n = 5000
+    b, d, p, r = O.make_random_ou_batch(n, seed0=0x1A2B3C)
+    lib, h = gpu_ctx.lib, gpu_ctx.handle
+    for max_steps, turns in ((1, 6), (1000, 1)):
+        gb, gd, gp, gr = Dev(b), Dev(d), Dev(p), Dev(r)
+        steps, vals = Dev(np.zeros(n, dtype=np.uint32)), Dev(np.zeros(n, dtype=np.float32))
+        hb, hd, hp, hr = b.copy(), d.copy(), p.copy(), r.copy()
+        for _ in range(turns):
+            _lib.check(lib.oakgpu_rollout_dev(h, gb.p, gd.p, gr.p, gp.p, n, max_steps, 0, gr.p, steps.p, vals.p, gb.p, gd.p))
+            gpu_ctx.synchronize()
+            ref = gpu_ctx.rollout(hb, hd, hr, hp, max_steps=max_steps, return_state=True)
+            hb, hd, hp, hr = ref["battles"], ref["durations"], ref["prng"], ref["results"]
+            assert (gb.host() == hb).all() and (gd.host() == hd).all()
+            assert (gr.host() == hr).all() and (gp.host() == hp).all()
+            assert (steps.host() == ref["steps"]).all() and (vals.host() == ref["values"]).all()
+        for x in (gb, gd, gp, gr, steps, vals):
+            x.free()
+
+
 def test_libpkmn_named_single_battle_abi(gpu_ctx):
     """include/pkmn.h: pkmn_gen1_battle_update / _choices / _options_* as batches of one on the GPU,
     driven exactly like the reference's rollout loop (mcts.h:448-496) and compared with the oracle."""
