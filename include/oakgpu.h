@@ -32,6 +32,7 @@ extern "C" {
 #define OAKGPU_TEAMS_SIZE 60 /* 2 sides x 6 sets x {species, move x4} */
 
 typedef struct oakgpu_ctx oakgpu_ctx;
+typedef struct oakgpu_net oakgpu_net; /* a loaded .battle.net (see oakgpu_net_load below) */
 
 int oakgpu_create(oakgpu_ctx **out, int device);
 void oakgpu_destroy(oakgpu_ctx *ctx);
@@ -91,6 +92,48 @@ int oakgpu_choices_dev(oakgpu_ctx *ctx, const uint8_t *battles, const uint8_t *r
 int oakgpu_choices(oakgpu_ctx *ctx, const uint8_t *battles, const uint8_t *results, int player, uint8_t *out,
                    uint8_t *counts, uint32_t n);
 
+/* ---- one tree level for a batch of descents (MCTS::Search::run_iteration, search/mcts.h:304-389): apply
+ * the joint action of every lane (c1[i] == 0xFF: lane i is finished, leave it untouched), in place, and
+ * report result, the 16-byte observation key (pkmn_gen1_battle_options_chance_actions; tree edge key,
+ * mcts.h:93-98,359) and BOTH players' legal choices in the new state (n x 9 + n counts each; counts are 0
+ * for terminal results).  rolls in {1, 2, 3, 20, 39}: damage-roll clamping of battle_options_set
+ * (mcts.h:569-604; 39 = off), override bytes derived from the last two bytes of battle.rng. */
+int oakgpu_tree_step_dev(oakgpu_ctx *ctx, uint8_t *battles, uint8_t *durations, uint8_t *results, const uint8_t *c1,
+                         const uint8_t *c2, uint32_t n, uint32_t rolls, uint8_t *actions, uint8_t *p1_choices,
+                         uint8_t *p1_counts, uint8_t *p2_choices, uint8_t *p2_counts);
+
+/* ---- tree search with batched leaves: MCTS::Search::run (search/mcts.h:154-247) with a Node heap
+ * (mcts.h:95-105), joint UCB / PUCB bandits (search/bandit/ucb.h:17-66, pucb.h:17-75) and the Monte-Carlo or
+ * network evaluator.  `batch` descents walk the host-side tree together, one oakgpu_tree_step_dev launch per
+ * level, all battle states resident on the device; lanes of a batch repel each other with a virtual loss.
+ * The root matrices come back as in MCTS::Output (mcts.h:68-90); the Nash solve of process_output
+ * (mcts.h:620-659) is host-side exact arithmetic and stays with the caller (oak_amd/search.py). */
+typedef struct {
+  uint64_t iterations;   /* root iterations (mcts.h:231-235, integer budget) */
+  uint32_t batch;        /* descents in flight (GPU lanes); 1 reproduces the reference's one-at-a-time order */
+  float ucb_c;           /* Bandit::Params.c */
+  int32_t bandit;        /* 0: UCB (bandit/ucb.h), 1: PUCB with network priors (bandit/pucb.h; needs eval = 1) */
+  int32_t eval;          /* 0: MCTS::MonteCarlo rollouts (mcts.h:448-496), 1: network value (network.h:72-123) */
+  uint32_t max_depth;    /* descent depth at which a node is evaluated even if already expanded (0 = 100) */
+  uint32_t root_rolls;   /* SearchOptions.root_rolls / other_rolls (mcts.h:107-131): 1, 2, 3, 20 or 39 (= no clamping) */
+  uint32_t other_rolls;
+  uint64_t seed;         /* seeds the per-lane fast_prng streams (root resampling draws + rollouts) */
+} oakgpu_search_params;
+typedef struct {
+  uint8_t m, n;                 /* legal choices per side at the root */
+  uint8_t p1_choices[9], p2_choices[9];
+  uint64_t visit_matrix[81];    /* [i * 9 + j] */
+  double value_matrix[81];      /* cumulative P1 values */
+  uint64_t iterations;
+  double empirical_value, initial_value;
+  double p1_empirical[9], p2_empirical[9];
+  uint64_t nodes, total_depth;
+  double duration_us;
+} oakgpu_search_output;
+int oakgpu_search(oakgpu_ctx *ctx, oakgpu_net *net /* nullable for eval = 0 */, const uint8_t *battle /* 384 */,
+                  const uint8_t *durations /* 8 */, uint8_t result, const oakgpu_search_params *params,
+                  oakgpu_search_output *out);
+
 /* ---- batched PKMN::battle(p1, p2, seed) (pkmn.h:50-57, init.h:90-154), level 100 sets.
  * teams: n x 60 bytes; seeds: n x u64; with first_update != 0 also performs the opening
  * update(battle, 0, 0) (benchmark.cc:29) and writes its result byte. */
@@ -119,7 +162,6 @@ int oakgpu_random_ou_battles_dev(oakgpu_ctx *ctx, uint64_t seed0, uint32_t n, ui
  * oakgpu_leaf_eval* = value_inference(battle, durations) for n leaves (network.h:72-79):
  * encode + both embedding nets + MainNet value path + sigmoid, fp32 throughout (dense layers on
  * fp32 MFMA).  embedding_out (nullable): the n x in_dim battle embeddings (network.h:131-175). */
-typedef struct oakgpu_net oakgpu_net;
 int oakgpu_net_load(oakgpu_ctx *ctx, const char *path, oakgpu_net **out);
 int oakgpu_net_load_memory(oakgpu_ctx *ctx, const void *bytes, size_t size, oakgpu_net **out);
 void oakgpu_net_free(oakgpu_ctx *ctx, oakgpu_net *net);

@@ -4,6 +4,7 @@
 //   OakGPU::Context            <- per-thread owner of device state (reference: per-thread Agent/Heap, util/search.h:17-64)
 //   OakGPU::Network            <- NN::Battle::Network (nn/battle/network.h:22-176): shape(), value_inference(batch)
 //   OakGPU::BatchedMonteCarlo  <- MCTS::MonteCarlo (mcts.h:21-23) + init_stats_and_rollout (mcts.h:448-496), batched
+//   OakGPU::TreeSearch         <- MCTS::Search::run (mcts.h:154-247): Node heap + joint UCB / PUCB, leaves batched on the GPU
 // Errors surface as std::runtime_error, like the reference's loaders (cpp/src/search.cc:81-146).
 #pragma once
 #include <cstdint>
@@ -97,9 +98,28 @@ public:
     return values;
   }
 
+  oakgpu_net *get() const noexcept { return net_; }
+
 private:
   Context &ctx_;
   oakgpu_net *net_{};
+};
+
+// MCTS::Search::run(device, budget, params, heap, eval, input) (mcts.h:154-155) with an integer budget: the heap is a
+// fresh Node tree per call, `params.bandit` picks UCB::Bandit / PUCB::Bandit, eval = Monte-Carlo (net == nullptr)
+// or the network.  Output carries MCTS::Output's root matrices (mcts.h:68-90).
+class TreeSearch {
+public:
+  explicit TreeSearch(Context &ctx) : ctx_{ctx} {}
+  oakgpu_search_output run(const Leaf &input, oakgpu_search_params params, Network *net = nullptr) {
+    params.eval = net ? 1 : 0;
+    oakgpu_search_output out{};
+    check(oakgpu_search(ctx_.get(), net ? net->get() : nullptr, input.battle, input.durations, input.result, &params, &out));
+    return out;
+  }
+
+private:
+  Context &ctx_;
 };
 
 } // namespace OakGPU

@@ -14,7 +14,22 @@ SYMBOLS = [
     "oakgpu_set_ou_pools", "oakgpu_random_ou_battles_dev",
     "oakgpu_net_load", "oakgpu_net_load_memory", "oakgpu_net_free", "oakgpu_net_shape",
     "oakgpu_leaf_eval_dev", "oakgpu_leaf_eval", "oakgpu_leaf_eval_policy_dev", "oakgpu_leaf_eval_policy",
+    "oakgpu_tree_step_dev", "oakgpu_search",
 ]
+
+
+class SearchParams(C.Structure):      # oakgpu_search_params (include/oakgpu.h)
+    _fields_ = [("iterations", C.c_uint64), ("batch", C.c_uint32), ("ucb_c", C.c_float), ("bandit", C.c_int32),
+                ("eval", C.c_int32), ("max_depth", C.c_uint32), ("root_rolls", C.c_uint32), ("other_rolls", C.c_uint32),
+                ("seed", C.c_uint64)]
+
+
+class SearchOutput(C.Structure):      # oakgpu_search_output
+    _fields_ = [("m", C.c_uint8), ("n", C.c_uint8), ("p1_choices", C.c_uint8 * 9), ("p2_choices", C.c_uint8 * 9),
+                ("visit_matrix", C.c_uint64 * 81), ("value_matrix", C.c_double * 81), ("iterations", C.c_uint64),
+                ("empirical_value", C.c_double), ("initial_value", C.c_double), ("p1_empirical", C.c_double * 9),
+                ("p2_empirical", C.c_double * 9), ("nodes", C.c_uint64), ("total_depth", C.c_uint64),
+                ("duration_us", C.c_double)]
 
 # include/pkmn.h: the libpkmn-named single-battle ABI (batch-of-one wrappers, pkmn_shim.hip)
 PKMN_SYMBOLS = [
@@ -51,6 +66,8 @@ def load():
     lib.oakgpu_set_regroup.argtypes = [vp, i32, i32, i32]
     lib.oakgpu_rollout_dev.argtypes = [vp, vp, vp, vp, vp, u32, u32, i32, vp, vp, vp, vp, vp]
     lib.oakgpu_rollout.argtypes = [vp, vp, vp, vp, vp, u32, u32, i32, vp, vp, vp, vp, vp]
+    lib.oakgpu_tree_step_dev.argtypes = [vp, vp, vp, vp, vp, vp, u32, u32, vp, vp, vp, vp, vp]
+    lib.oakgpu_search.argtypes = [vp, vp, vp, vp, C.c_uint8, C.POINTER(SearchParams), C.POINTER(SearchOutput)]
     lib.oakgpu_update_dev.argtypes = [vp, vp, vp, vp, vp, vp, vp, u32, vp]
     lib.oakgpu_update.argtypes = [vp, vp, vp, vp, vp, vp, vp, u32, vp]
     lib.oakgpu_choices_dev.argtypes = [vp, vp, vp, i32, vp, vp, u32]

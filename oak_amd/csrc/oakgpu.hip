@@ -448,6 +448,58 @@ __global__ __launch_bounds__(BLOCK) void k_choices(const uint8_t *battles, const
   }
 }
 
+// ---- one level of a batch of tree descents (MCTS::Search::run_iteration, mcts.h:304-389, per lane) --------
+// Applies the joint action the host-side bandits selected, reports the result, the 16-byte observation key
+// (pkmn_gen1_battle_options_chance_actions: the tree edge key, mcts.h:93-98,359) and the legal choices of BOTH
+// players in the new state, so that one device round trip per tree level is enough.  c1 == 0xFF: the lane's
+// descent has already ended (leaf or terminal) -- its state is left untouched.  `rolls` != 39 clamps the damage
+// rolls like battle_options_set (mcts.h:569-604): override bytes from the last two bytes of battle.rng.
+__device__ __forceinline__ uint32_t roll_byte(uint32_t rolls, uint32_t seed) {
+  if (rolls == 1) return 236;
+  return 217 + (38 / (rolls - 1)) * (seed % rolls);
+}
+__global__ __launch_bounds__(BLOCK) void k_tree_step(uint8_t *battles, uint8_t *durations, uint8_t *results, const uint8_t *c1,
+                                                     const uint8_t *c2, uint32_t n, uint32_t rolls, uint8_t *actions,
+                                                     uint8_t *ch1, uint8_t *cnt1, uint8_t *ch2, uint8_t *cnt2) {
+  extern __shared__ __align__(16) uint8_t smem[];
+  lds_u32 *state = (lds_u32 *)smem;
+  Tables T = stage_default_tables((lds_u8 *)smem + STATE_LDS_BYTES);
+  const uint32_t base = blockIdx.x * BLOCK;
+  const uint32_t count = min((uint32_t)BLOCK, n - base);
+  load_state(state, battles, base, count);
+  __syncthreads();
+  const uint32_t tid = threadIdx.x, lane = base + tid;
+  if (tid < count && c1[lane] != 0xFF) {
+    Engine<BLOCK, true> e;
+    e.m = state + tid;
+    e.T = T;
+    uint32_t *d = (uint32_t *)durations + 2 * (size_t)lane;
+    e.dur64 = (uint64_t)d[0] | ((uint64_t)d[1] << 32);
+    e.over16 = 0;
+    if (rolls != 39) {
+      const uint32_t hi = e.r32(B_RNG + 4);
+      e.over16 = roll_byte(rolls, (hi >> 16) & 0xFF) | (roll_byte(rolls, hi >> 24) << 8);
+    }
+    e.act0 = e.act1 = 0;
+    const uint32_t r = e.update(c1[lane], c2[lane]);
+    results[lane] = (uint8_t)r;
+    d[0] = e.dur_of(0);
+    d[1] = e.dur_of(1);
+    uint64_t *ad = (uint64_t *)actions + 2 * (size_t)lane;
+    ad[0] = e.act0;
+    ad[1] = e.act1;
+#pragma unroll 1
+    for (int pl = 0; pl < 2; ++pl) {
+      auto c = e.choices(pl, pl == 0 ? (r >> 4) & 3 : (r >> 6) & 3);
+      uint8_t *out = (pl ? ch2 : ch1) + (size_t)lane * OAKGPU_MAX_CHOICES;
+      (pl ? cnt2 : cnt1)[lane] = (r & 15) ? 0 : (uint8_t)c.n;
+      for (uint32_t i = 0; i < OAKGPU_MAX_CHOICES; ++i) out[i] = i < c.n ? (uint8_t)c.get(i) : 0;
+    }
+  }
+  __syncthreads();
+  store_state(state, battles, base, count);
+}
+
 // ---- PKMN::battle / Init::init_side (cpp/include/libpkmn/init.h:35-40,90-154) ---------------
 template <class E>
 __device__ void init_from_teams(E &e, const uint8_t *teams /* 60 B, this lane */, uint32_t seed_lo, uint32_t seed_hi) {
@@ -627,6 +679,7 @@ static int set_lds_limits() {
 #undef OAK_LIM_Q
   HIPCHK(hipFuncSetAttribute((const void *)oak::k_update, hipFuncAttributeMaxDynamicSharedMemorySize, oak::ENGINE_LDS_BYTES));
   HIPCHK(hipFuncSetAttribute((const void *)oak::k_choices, hipFuncAttributeMaxDynamicSharedMemorySize, oak::ENGINE_LDS_BYTES));
+  HIPCHK(hipFuncSetAttribute((const void *)oak::k_tree_step, hipFuncAttributeMaxDynamicSharedMemorySize, oak::ENGINE_LDS_BYTES));
   HIPCHK(hipFuncSetAttribute((const void *)oak::k_init, hipFuncAttributeMaxDynamicSharedMemorySize, oak::ENGINE_LDS_BYTES));
   HIPCHK(hipFuncSetAttribute((const void *)oak::k_random_ou, hipFuncAttributeMaxDynamicSharedMemorySize, oak::ENGINE_LDS_BYTES));
   return 0;
@@ -798,6 +851,20 @@ int oakgpu_choices_dev(oakgpu_ctx *c, const uint8_t *battles, const uint8_t *res
   if (!battles || !results || !out || !counts || player < 0 || player > 1) return bad("oakgpu_choices_dev: bad argument");
   hipLaunchKernelGGL(oak::k_choices, dim3(grid_for(n)), dim3(oak::BLOCK), oak::ENGINE_LDS_BYTES, c->stream, battles, results,
                      player, out, counts, n);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int oakgpu_tree_step_dev(oakgpu_ctx *c, uint8_t *battles, uint8_t *durations, uint8_t *results, const uint8_t *c1,
+                         const uint8_t *c2, uint32_t n, uint32_t rolls, uint8_t *actions, uint8_t *p1_choices,
+                         uint8_t *p1_counts, uint8_t *p2_choices, uint8_t *p2_counts) {
+  if (!c) return bad("null ctx");
+  if (n == 0) return 0;
+  if (!battles || !durations || !results || !c1 || !c2 || !actions || !p1_choices || !p1_counts || !p2_choices || !p2_counts)
+    return bad("oakgpu_tree_step_dev: null required pointer");
+  if (!(rolls == 1 || rolls == 2 || rolls == 3 || rolls == 20 || rolls == 39)) return bad("oakgpu_tree_step_dev: rolls must be 1, 2, 3, 20 or 39");
+  hipLaunchKernelGGL(oak::k_tree_step, dim3(grid_for(n)), dim3(oak::BLOCK), oak::ENGINE_LDS_BYTES, c->stream, battles, durations,
+                     results, c1, c2, n, rolls, actions, p1_choices, p1_counts, p2_choices, p2_counts);
   HIPCHK(hipGetLastError());
   return 0;
 }

@@ -1,0 +1,281 @@
+// oak_amd/csrc/search_host.hip -- batched-leaf tree search over the GPU hot path (host code of liboakgpu.so).
+//
+// the consumer of the leaf values.  Mirrors MCTS::Search::run / run_root_iteration /
+// run_iteration (cpp/include/search/mcts.h:154-389) with joint UCB / PUCB bandits (search/bandit/ucb.h:17-66,
+// pucb.h:17-75, search/joint.h:6-52) and a Node tree keyed (p1 index, p2 index, 16-byte observation)
+// (mcts.h:93-105).  The reference runs ONE descent at a time and calls libpkmn on the CPU at every tree edge;
+// here a batch of B descents walks the tree level by level:
+//   * the tree and the bandit statistics live on the host (pointer-chasing, a few bytes per visit);
+//   * every battle state lives on the GPU for the whole iteration: root prep (battle.rng = device draw,
+//     randomize_hidden_variables; mcts.h:250-263) is the rollout kernel's `prep`, one k_tree_step launch per tree
+//     level applies all lanes' joint actions and returns result + observation key + the child's legal choices
+//     (one device round trip per level), and the leaves are evaluated in place by the rollout kernel
+//     (MCTS::MonteCarlo, mcts.h:448-496) or the network kernels (value / value + policy logits);
+//   * lanes of one batch see each other's selections through a virtual loss (a visit without a score), the
+//     standard way to keep B simultaneous descents from all choosing the same path.
+// No battle arithmetic happens on the host: every state transition and evaluation above is a kernel launch.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+
+#include <array>
+#include <chrono>
+#include <cmath>
+#include <deque>
+#include <map>
+#include <vector>
+
+#include "../../include/oakgpu.h"
+#include "oakgpu_internal.h"
+
+namespace {
+
+struct Bandit { // UCB::Bandit / PUCB::Bandit (bandit/ucb.h:17-66, pucb.h:17-75)
+  float scores[9];
+  float priors[9];
+  uint32_t visits[9];
+  uint8_t k = 0;
+  void init(uint8_t kk) {
+    k = kk;
+    for (int i = 0; i < 9; ++i) { scores[i] = 0.5f; visits[i] = 1; priors[i] = kk ? 1.0f / kk : 0.0f; }
+  }
+  bool is_init() const { return k != 0; }
+  uint8_t select(float c, bool pucb) const {
+    if (k == 1) return 0;
+    uint64_t N = 0;
+    for (int i = 0; i < k; ++i) N += visits[i];
+    const float sqrtN = std::sqrt((float)N);
+    float best = 0;
+    uint8_t idx = 0;
+    for (int i = 0; i < k; ++i) {
+      const float e = pucb ? c * priors[i] * sqrtN : c * sqrtN / k;
+      const float a = (e + scores[i]) / visits[i];
+      if (a > best) { best = a; idx = (uint8_t)i; }
+    }
+    return idx;
+  }
+};
+
+using Key = std::array<uint8_t, 18>; // p1 index, p2 index, observation (mcts.h:95-105)
+struct Node {
+  Bandit p1, p2;
+  std::map<Key, Node *> children;
+  bool is_init() const { return p1.is_init(); }
+};
+
+void softmax(float *out, const float *logits, int k) { // search/util/softmax.h
+  float mx = logits[0];
+  for (int i = 1; i < k; ++i) mx = logits[i] > mx ? logits[i] : mx;
+  float sum = 0;
+  for (int i = 0; i < k; ++i) { out[i] = std::exp(logits[i] - mx); sum += out[i]; }
+  for (int i = 0; i < k; ++i) out[i] /= sum;
+}
+
+uint64_t splitmix64(uint64_t &x) {
+  uint64_t z = (x += 0x9E3779B97F4A7C15ull);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+
+struct Buffers { // device arrays + pinned host mirrors of what crosses PCIe every level
+  std::vector<void *> dev, pinned;
+  ~Buffers() {
+    for (void *p : dev) (void)hipFree(p);
+    for (void *p : pinned) (void)hipHostFree(p);
+  }
+  template <class T> int d(T **out, size_t count) {
+    void *p = nullptr;
+    hipError_t e = hipMalloc(&p, count * sizeof(T));
+    if (e != hipSuccess) return oakgpu_fail_hip((int)e, "hipMalloc(search buffers)");
+    dev.push_back(p);
+    *out = (T *)p;
+    return 0;
+  }
+  template <class T> int h(T **out, size_t count) {
+    void *p = nullptr;
+    hipError_t e = hipHostMalloc(&p, count * sizeof(T), hipHostMallocDefault);
+    if (e != hipSuccess) return oakgpu_fail_hip((int)e, "hipHostMalloc(search buffers)");
+    pinned.push_back(p);
+    *out = (T *)p;
+    return 0;
+  }
+};
+
+#define HIPRC(x) do { hipError_t _e = (x); if (_e != hipSuccess) return oakgpu_fail_hip((int)_e, #x); } while (0)
+#define RC(x) do { int _r = (x); if (_r) return _r; } while (0)
+
+} // namespace
+
+extern "C" int oakgpu_search(oakgpu_ctx *ctx, oakgpu_net *net, const uint8_t *battle, const uint8_t *durations, uint8_t result,
+                             const oakgpu_search_params *prm, oakgpu_search_output *out) {
+  if (!ctx || !battle || !durations || !prm || !out) return oakgpu_fail_msg("oakgpu_search: null argument");
+  const bool pucb = prm->bandit == 1, use_net = prm->eval == 1;
+  if (prm->bandit < 0 || prm->bandit > 1 || prm->eval < 0 || prm->eval > 1) return oakgpu_fail_msg("oakgpu_search: unknown bandit / eval");
+  if ((use_net || pucb) && !net) return oakgpu_fail_msg("oakgpu_search: network evaluation / PUCB priors need a network");
+  if (pucb && !use_net) return oakgpu_fail_msg("oakgpu_search: PUCB takes its priors from the network evaluator (eval = 1)");
+  if (prm->batch == 0 || prm->batch > (1u << 20)) return oakgpu_fail_msg("oakgpu_search: batch must be in 1..2^20");
+  auto rolls_ok = [](uint32_t r) { return r == 1 || r == 2 || r == 3 || r == 20 || r == 39; };
+  if (!rolls_ok(prm->root_rolls) || !rolls_ok(prm->other_rolls)) return oakgpu_fail_msg("oakgpu_search: rolls must be 1, 2, 3, 20 or 39");
+  HIPRC(hipSetDevice(oakgpu_ctx_device(ctx)));
+  hipStream_t stream = (hipStream_t)oakgpu_ctx_stream(ctx);
+  const uint32_t B = prm->batch;
+  const uint32_t max_depth = prm->max_depth ? prm->max_depth : 100;
+  memset(out, 0, sizeof *out);
+  const auto t_start = std::chrono::high_resolution_clock::now();
+
+  // root choices (mcts.h:160-166) through the batched choices kernel, batch of one
+  uint8_t root_c1[9], root_c2[9], m = 0, n = 0;
+  RC(oakgpu_choices(ctx, battle, &result, 0, root_c1, &m, 1));
+  RC(oakgpu_choices(ctx, battle, &result, 1, root_c2, &n, 1));
+  out->m = m;
+  out->n = n;
+  memcpy(out->p1_choices, root_c1, 9);
+  memcpy(out->p2_choices, root_c2, 9);
+  if ((result & 15) != 0 || m == 0 || n == 0) return oakgpu_fail_msg("oakgpu_search: the root position is terminal");
+
+  std::deque<Node> arena;
+  arena.emplace_back();
+  Node *root = &arena.back();
+  root->p1.init(m);
+  root->p2.init(n);
+  if (pucb) { // root priors from the policy heads (mcts.h:196-209)
+    float v, l1[9], l2[9];
+    RC(oakgpu_leaf_eval_policy(ctx, net, battle, durations, 1, root_c1, &m, root_c2, &n, &v, l1, l2));
+    softmax(root->p1.priors, l1, m);
+    softmax(root->p2.priors, l2, n);
+    out->initial_value = v;
+  }
+
+  Buffers buf;
+  uint8_t *d_root_b, *d_root_d, *d_root_r, *d_b, *d_d, *d_r, *d_prng, *d_c1, *d_c2, *d_act, *d_ch1, *d_cnt1, *d_ch2, *d_cnt2, *d_rout;
+  uint32_t *d_steps;
+  float *d_values, *d_l1 = nullptr, *d_l2 = nullptr;
+  RC(buf.d(&d_root_b, (size_t)B * 384)); RC(buf.d(&d_root_d, (size_t)B * 8)); RC(buf.d(&d_root_r, (size_t)B));
+  RC(buf.d(&d_b, (size_t)B * 384)); RC(buf.d(&d_d, (size_t)B * 8)); RC(buf.d(&d_r, (size_t)B)); RC(buf.d(&d_prng, (size_t)B * 8));
+  RC(buf.d(&d_c1, (size_t)B)); RC(buf.d(&d_c2, (size_t)B)); RC(buf.d(&d_act, (size_t)B * 16));
+  RC(buf.d(&d_ch1, (size_t)B * 9)); RC(buf.d(&d_cnt1, (size_t)B)); RC(buf.d(&d_ch2, (size_t)B * 9)); RC(buf.d(&d_cnt2, (size_t)B));
+  RC(buf.d(&d_rout, (size_t)B)); RC(buf.d(&d_steps, (size_t)B)); RC(buf.d(&d_values, (size_t)B));
+  if (pucb) { RC(buf.d(&d_l1, (size_t)B * 9)); RC(buf.d(&d_l2, (size_t)B * 9)); }
+  uint8_t *h_c1, *h_c2, *h_r, *h_act, *h_ch1, *h_cnt1, *h_ch2, *h_cnt2, *h_stage;
+  float *h_values, *h_l1 = nullptr, *h_l2 = nullptr;
+  RC(buf.h(&h_c1, (size_t)B)); RC(buf.h(&h_c2, (size_t)B)); RC(buf.h(&h_r, (size_t)B)); RC(buf.h(&h_act, (size_t)B * 16));
+  RC(buf.h(&h_ch1, (size_t)B * 9)); RC(buf.h(&h_cnt1, (size_t)B)); RC(buf.h(&h_ch2, (size_t)B * 9)); RC(buf.h(&h_cnt2, (size_t)B));
+  RC(buf.h(&h_values, (size_t)B)); RC(buf.h(&h_stage, (size_t)B * 384));
+  if (pucb) { RC(buf.h(&h_l1, (size_t)B * 9)); RC(buf.h(&h_l2, (size_t)B * 9)); }
+
+  // root template: B copies of the input; one fast_prng stream per lane (util/random.h:67-133), never all-zero
+  for (uint32_t l = 0; l < B; ++l) memcpy(h_stage + (size_t)l * 384, battle, 384);
+  HIPRC(hipMemcpyAsync(d_root_b, h_stage, (size_t)B * 384, hipMemcpyHostToDevice, stream));
+  HIPRC(hipStreamSynchronize(stream));
+  for (uint32_t l = 0; l < B; ++l) memcpy(h_stage + (size_t)l * 8, durations, 8);
+  HIPRC(hipMemcpyAsync(d_root_d, h_stage, (size_t)B * 8, hipMemcpyHostToDevice, stream));
+  HIPRC(hipStreamSynchronize(stream));
+  {
+    uint64_t sm = prm->seed;
+    for (uint32_t l = 0; l < B; ++l) { uint64_t s = splitmix64(sm) | 1; memcpy(h_stage + (size_t)l * 8, &s, 8); }
+    HIPRC(hipMemcpyAsync(d_prng, h_stage, (size_t)B * 8, hipMemcpyHostToDevice, stream));
+    HIPRC(hipMemsetAsync(d_root_r, result, B, stream));
+    HIPRC(hipStreamSynchronize(stream));
+  }
+
+  struct Step { Node *node; uint8_t i, j; };
+  std::vector<std::vector<Step>> path(B);
+  std::vector<Node *> cur(B), leaf(B);
+  std::vector<uint8_t> active(B);
+  double total_value = 0;
+  uint64_t done = 0, total_depth = 0;
+
+  while (done < prm->iterations) {
+    const uint32_t nb = (uint32_t)std::min<uint64_t>(B, prm->iterations - done);
+    // root prep on the device (mcts.h:254-259): rollout kernel with max_steps = 0
+    RC(oakgpu_rollout_dev(ctx, d_root_b, d_root_d, d_root_r, d_prng, nb, 0, 1, d_rout, d_steps, d_values, d_b, d_d));
+    HIPRC(hipMemcpyAsync(d_r, d_root_r, nb, hipMemcpyDeviceToDevice, stream));
+    for (uint32_t l = 0; l < nb; ++l) { path[l].clear(); cur[l] = root; leaf[l] = nullptr; active[l] = 1; }
+    uint32_t n_active = nb;
+    for (uint32_t depth = 0; n_active > 0; ++depth) {
+      for (uint32_t l = 0; l < nb; ++l) { // bandit selection, sequential: each lane sees the virtual losses before it
+        if (!active[l]) { h_c1[l] = 0xFF; h_c2[l] = 0xFF; continue; }
+        Node *nd = cur[l];
+        const uint8_t i = nd->p1.select(prm->ucb_c, pucb), j = nd->p2.select(prm->ucb_c, pucb);
+        ++nd->p1.visits[i];
+        ++nd->p2.visits[j];
+        path[l].push_back({nd, i, j});
+        h_c1[l] = depth == 0 ? root_c1[i] : h_ch1[(size_t)l * 9 + i];
+        h_c2[l] = depth == 0 ? root_c2[j] : h_ch2[(size_t)l * 9 + j];
+      }
+      HIPRC(hipMemcpyAsync(d_c1, h_c1, nb, hipMemcpyHostToDevice, stream));
+      HIPRC(hipMemcpyAsync(d_c2, h_c2, nb, hipMemcpyHostToDevice, stream));
+      RC(oakgpu_tree_step_dev(ctx, d_b, d_d, d_r, d_c1, d_c2, nb, depth == 0 ? prm->root_rolls : prm->other_rolls, d_act, d_ch1,
+                              d_cnt1, d_ch2, d_cnt2));
+      HIPRC(hipMemcpyAsync(h_r, d_r, nb, hipMemcpyDeviceToHost, stream));
+      HIPRC(hipMemcpyAsync(h_act, d_act, (size_t)nb * 16, hipMemcpyDeviceToHost, stream));
+      HIPRC(hipMemcpyAsync(h_ch1, d_ch1, (size_t)nb * 9, hipMemcpyDeviceToHost, stream));
+      HIPRC(hipMemcpyAsync(h_cnt1, d_cnt1, nb, hipMemcpyDeviceToHost, stream));
+      HIPRC(hipMemcpyAsync(h_ch2, d_ch2, (size_t)nb * 9, hipMemcpyDeviceToHost, stream));
+      HIPRC(hipMemcpyAsync(h_cnt2, d_cnt2, nb, hipMemcpyDeviceToHost, stream));
+      HIPRC(hipStreamSynchronize(stream));
+      for (uint32_t l = 0; l < nb; ++l) {
+        if (!active[l]) continue;
+        if ((h_r[l] & 15) != 0) { // terminal edge: the value comes from the result byte (mcts.h:427-441)
+          active[l] = 0; --n_active; total_depth += depth + 1;
+          continue;
+        }
+        Key key;
+        key[0] = path[l].back().i;
+        key[1] = path[l].back().j;
+        memcpy(key.data() + 2, h_act + (size_t)l * 16, 16);
+        Node *&child = cur[l]->children[key];
+        if (!child) { arena.emplace_back(); child = &arena.back(); }
+        if (child->is_init() && depth + 1 < max_depth) { cur[l] = child; continue; }
+        leaf[l] = child; // first visit (or depth cap): evaluate here (mcts.h:391-426)
+        active[l] = 0; --n_active; total_depth += depth + 1;
+      }
+    }
+    // leaf evaluation, in place on the device
+    if (!use_net) {
+      RC(oakgpu_rollout_dev(ctx, d_b, d_d, d_r, d_prng, nb, 1000, 0, d_rout, d_steps, d_values, nullptr, nullptr));
+    } else if (pucb) {
+      RC(oakgpu_leaf_eval_policy_dev(ctx, net, d_b, d_d, nb, d_ch1, d_cnt1, d_ch2, d_cnt2, d_values, d_l1, d_l2));
+      HIPRC(hipMemcpyAsync(h_l1, d_l1, (size_t)nb * 9 * 4, hipMemcpyDeviceToHost, stream));
+      HIPRC(hipMemcpyAsync(h_l2, d_l2, (size_t)nb * 9 * 4, hipMemcpyDeviceToHost, stream));
+    } else {
+      RC(oakgpu_leaf_eval_dev(ctx, net, d_b, d_d, nb, d_values, nullptr));
+    }
+    HIPRC(hipMemcpyAsync(h_values, d_values, (size_t)nb * 4, hipMemcpyDeviceToHost, stream));
+    HIPRC(hipStreamSynchronize(stream));
+    for (uint32_t l = 0; l < nb; ++l) {
+      float v1;
+      const uint32_t t = h_r[l] & 15;
+      if (t != 0) v1 = t == 1 ? 1.0f : t == 2 ? 0.0f : 0.5f;
+      else v1 = h_values[l];
+      Node *lf = leaf[l];
+      if (lf && !lf->is_init() && h_cnt1[l] && h_cnt2[l]) { // stats.init(m, n) (+ priors) on the first evaluation
+        lf->p1.init(h_cnt1[l]);
+        lf->p2.init(h_cnt2[l]);
+        if (pucb) { softmax(lf->p1.priors, h_l1 + (size_t)l * 9, h_cnt1[l]); softmax(lf->p2.priors, h_l2 + (size_t)l * 9, h_cnt2[l]); }
+      }
+      const float v2 = 1.0f - v1;
+      for (const Step &s : path[l]) { // Bandit::update, the visit was already counted as the virtual loss
+        s.node->p1.scores[s.i] += v1;
+        s.node->p2.scores[s.j] += v2;
+      }
+      const Step &s0 = path[l].front();
+      ++out->visit_matrix[s0.i * 9 + s0.j];
+      out->value_matrix[s0.i * 9 + s0.j] += v1;
+      total_value += v1;
+    }
+    done += nb;
+  }
+  out->iterations = done;
+  out->empirical_value = done ? total_value / (double)done : 0.0;
+  for (int i = 0; i < m; ++i)
+    for (int j = 0; j < n; ++j) {
+      out->p1_empirical[i] += (double)out->visit_matrix[i * 9 + j] / (double)done;
+      out->p2_empirical[j] += (double)out->visit_matrix[i * 9 + j] / (double)done;
+    }
+  out->nodes = arena.size();
+  out->total_depth = total_depth;
+  out->duration_us = std::chrono::duration<double, std::micro>(std::chrono::high_resolution_clock::now() - t_start).count();
+  return 0;
+}

@@ -9,6 +9,9 @@ Mirrors two pieces of the reference's search surface:
     counters (mcts.h:254-259), apply the joint action with ONE batched update on the GPU, evaluate the R x m x n
     children with GPU rollouts (or the GPU network), average into the value matrix and solve it.  Output fields
     follow MCTS::Output (mcts.h:68-90).
+  * `tree_search(...)`: the full tree search -- MCTS::Search::run (mcts.h:154-247) with a Node heap and joint
+    UCB / PUCB bandits -- as `oakgpu_search` runs it: batches of descents walking a host-side tree, every battle
+    state resident on the GPU (oak_amd/csrc/search_host.hip); this module adds process_output's Nash solve.
 All battle arithmetic runs through the C ABI (oak_amd.engine); this module only orchestrates and solves.
 """
 from fractions import Fraction
@@ -122,3 +125,43 @@ def root_matrix_search(ctx, battle, durations, result, replicas=256, seed=0x5EED
         "p1_nash": p1, "p2_nash": p2,
         "p1_empirical": np.full(m, 1.0 / m), "p2_empirical": np.full(n, 1.0 / n),
     }
+
+
+def process_output(out):
+    """MCTS::Search::process_output (mcts.h:620-659) on a dict holding m, n, visit_matrix, value_matrix, iterations:
+    adds nash_value / p1_nash / p2_nash (empirical matrix x 256 as integers, exact solve) and the empirical fields."""
+    m, n = out["m"], out["n"]
+    visits = np.asarray(out["visit_matrix"])[:m, :n].astype(np.int64)
+    values = np.asarray(out["value_matrix"])[:m, :n].astype(np.float64)
+    nn = np.where(visits == 0, 1, visits)
+    p1, p2, nash = solve_matrix((values / nn * 256).astype(np.int64), 256)   # C++ double -> int truncation
+    it = max(int(out["iterations"]), 1)
+    out.update(nash_value=nash, p1_nash=p1, p2_nash=p2, empirical_value=float(values.sum() / it),
+               p1_empirical=visits.sum(axis=1) / it, p2_empirical=visits.sum(axis=0) / it)
+    return out
+
+
+def tree_search(ctx, battle, durations, result, iterations=1 << 16, batch=4096, c=2.0, bandit="ucb", evaluator="mc",
+                root_rolls=3, other_rolls=1, max_depth=100, seed=0x5EED):
+    """Tree search with batched leaves on the GPU (include/oakgpu.h: oakgpu_search).  bandit: "ucb" | "pucb";
+    evaluator: "mc" or an oak_amd.engine.Network.  Defaults follow the reference's default_search{3, 1} damage-roll
+    clamping (mcts.h:131).  Returns a dict shaped like MCTS::Output (mcts.h:68-90)."""
+    import ctypes as C
+    from . import _lib
+    battle = np.ascontiguousarray(battle, dtype=np.uint8).reshape(384)
+    durations = np.ascontiguousarray(durations, dtype=np.uint8).reshape(8)
+    use_net = evaluator != "mc"
+    prm = _lib.SearchParams(iterations=int(iterations), batch=int(batch), ucb_c=float(c), bandit={"ucb": 0, "pucb": 1}[bandit],
+                            eval=1 if use_net else 0, max_depth=int(max_depth), root_rolls=int(root_rolls),
+                            other_rolls=int(other_rolls), seed=int(seed))
+    res = _lib.SearchOutput()
+    _lib.check(ctx.lib.oakgpu_search(ctx.handle, evaluator.handle if use_net else None, battle.ctypes.data_as(C.c_void_p),
+                                     durations.ctypes.data_as(C.c_void_p), int(result), C.byref(prm), C.byref(res)))
+    m, n = int(res.m), int(res.n)
+    out = {"m": m, "n": n, "p1_choices": np.array(res.p1_choices[:m], dtype=np.uint8),
+           "p2_choices": np.array(res.p2_choices[:n], dtype=np.uint8),
+           "visit_matrix": np.array(res.visit_matrix, dtype=np.int64).reshape(9, 9)[:m, :n].copy(),
+           "value_matrix": np.array(res.value_matrix, dtype=np.float64).reshape(9, 9)[:m, :n].copy(),
+           "iterations": int(res.iterations), "initial_value": float(res.initial_value), "nodes": int(res.nodes),
+           "mean_depth": res.total_depth / max(int(res.iterations), 1), "duration_ms": res.duration_us / 1e3}
+    return process_output(out)

@@ -14,6 +14,11 @@ int main() {
   std::vector<uint64_t> rng(4, 0x1234567ull);
   auto out = mc.rollout(leaves, rng);
   for (float v : out.value) if (v != 0.5f) { std::puts("unexpected value"); return 1; }
+  OakGPU::TreeSearch search{ctx};                 // a terminal root is refused, loudly (std::runtime_error)
+  bool threw = false;
+  leaves[0].result = 0x03;                        // PKMN_RESULT_TIE
+  try { (void)search.run(leaves[0], oakgpu_search_params{64, 64, 2.0f, 0, 0, 0, 3, 1, 1}); } catch (const std::runtime_error &) { threw = true; }
+  if (!threw) { std::puts("terminal root accepted"); return 1; }
   std::puts("ok");
   return 0;
 }

@@ -46,3 +46,66 @@ def test_full_position_with_network_evaluator(gpu_ctx):
         assert (M @ out["p2_nash"]).max() <= out["nash_value"] * 256 + 1e-6
         assert (out["p1_nash"] @ M).min() >= out["nash_value"] * 256 - 1e-6
     net.close()
+
+
+# ---- tree search with batched leaves (oakgpu_search: host tree + bandits, GPU states / steps / leaves) ----------
+def test_tree_search_single_action_positions(gpu_ctx):
+    """search-test.cc:80-108 through the full tree search: one legal joint action, value = wake-up probability."""
+    from oak_amd.search import tree_search
+    for k, expected in ((3, 1 / 4), (5, 1 / 2)):
+        b, d = parse_battle("starmie seismictoss 101hp slp%d | snorlax seismictoss 1hp" % k)
+        out = tree_search(gpu_ctx, b, d, result_from_state(b), iterations=1 << 15, batch=4096, seed=k)
+        assert out["m"] == 1 and out["n"] == 1 and out["iterations"] == 1 << 15
+        assert int(out["visit_matrix"].sum()) == 1 << 15
+        assert abs(out["empirical_value"] - expected) <= 0.03 and abs(out["nash_value"] - expected) <= 0.03
+
+
+def test_tree_search_finds_the_dominant_action(gpu_ctx):
+    from oak_amd.search import tree_search
+    b, d = parse_battle("starmie surf recover 1hp | rhydon earthquake 1hp")
+    out = tree_search(gpu_ctx, b, d, result_from_state(b), iterations=8192, batch=512, c=1.0)
+    surf = [i for i, c in enumerate(out["p1_choices"]) if int(c) == ((1 << 2) | 1)][0]
+    assert out["p1_nash"][surf] == 1.0 and out["nash_value"] == 1.0
+    assert out["visit_matrix"][surf, 0] > 0.9 * out["iterations"]           # UCB concentrates on the winning move
+    assert out["value_matrix"][surf, 0] == out["visit_matrix"][surf, 0]       # it always wins
+
+
+def test_tree_search_invariants_and_determinism(gpu_ctx):
+    """Full 9 x 9 root: bookkeeping invariants, same seed -> same tree, batch size changes the order not the sanity,
+    and the tree search agrees with the one-ply matrix search on the root's value within sampling noise."""
+    import oracle_lib as O
+    from oak_amd.search import tree_search
+    b, d, p, r = O.make_random_ou_batch(1, seed0=424242)
+    res = int(r[0])
+    a = tree_search(gpu_ctx, b[0], d[0], res, iterations=1 << 14, batch=2048, seed=7)
+    a2 = tree_search(gpu_ctx, b[0], d[0], res, iterations=1 << 14, batch=2048, seed=7)
+    assert a["m"] == 9 and a["n"] == 9
+    assert (a["visit_matrix"] == a2["visit_matrix"]).all() and (a["value_matrix"] == a2["value_matrix"]).all()
+    assert int(a["visit_matrix"].sum()) == a["iterations"] == 1 << 14
+    assert (a["value_matrix"] >= 0).all() and (a["value_matrix"] <= a["visit_matrix"] + 1e-9).all()
+    assert a["nodes"] > 81 and 1.0 <= a["mean_depth"] <= 100.0
+    assert abs(a["p1_nash"].sum() - 1) < 1e-9 and abs(a["p2_nash"].sum() - 1) < 1e-9 and 0 <= a["nash_value"] <= 1
+    one = tree_search(gpu_ctx, b[0], d[0], res, iterations=2048, batch=1, seed=7)      # the reference's sequential order
+    assert int(one["visit_matrix"].sum()) == 2048
+    assert abs(one["empirical_value"] - a["empirical_value"]) < 0.1
+    # unclamped rolls (39) are accepted too and give a similar value
+    full = tree_search(gpu_ctx, b[0], d[0], res, iterations=1 << 14, batch=2048, seed=8, root_rolls=39, other_rolls=39)
+    assert abs(full["empirical_value"] - a["empirical_value"]) < 0.1
+
+
+def test_tree_search_with_network_and_pucb(gpu_ctx):
+    import oracle_lib as O
+    from oak_amd.engine import Network
+    from oak_amd._lib import OakGpuError
+    from oak_amd.search import tree_search
+    b, d, p, r = O.make_random_ou_batch(1, seed0=777)
+    net = Network(gpu_ctx, path=os.path.join(ROOT, "tests", "golden", "net_default.battle.net"))
+    for bandit in ("ucb", "pucb"):
+        out = tree_search(gpu_ctx, b[0], d[0], int(r[0]), iterations=4096, batch=512, bandit=bandit, evaluator=net, c=1.5)
+        assert int(out["visit_matrix"].sum()) == 4096 and out["nodes"] > 81
+        assert 0 <= out["empirical_value"] <= 1 and abs(out["p1_nash"].sum() - 1) < 1e-9
+        if bandit == "pucb":
+            assert 0 < out["initial_value"] < 1      # root value_policy_inference (mcts.h:196-209)
+    with pytest.raises(OakGpuError):
+        tree_search(gpu_ctx, b[0], d[0], int(r[0]), iterations=64, batch=64, bandit="pucb", evaluator="mc")
+    net.close()
