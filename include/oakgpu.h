@@ -92,6 +92,14 @@ int oakgpu_choices_dev(oakgpu_ctx *ctx, const uint8_t *battles, const uint8_t *r
 int oakgpu_choices(oakgpu_ctx *ctx, const uint8_t *battles, const uint8_t *results, int player, uint8_t *out,
                    uint8_t *counts, uint32_t n);
 
+/* ---- PokeEngine::Eval (search/poke-engine-evaluate.h:9-204), batched: scores[i] = evaluate_battle(battle i)
+ * (Eval::get_root_score for a batch of one), values[i] = scaled_sigmoid(scores[i] - root_score) = Eval::evaluate.
+ * Either output may be null. */
+int oakgpu_poke_engine_eval_dev(oakgpu_ctx *ctx, const uint8_t *battles, uint32_t n, float root_score, float *values,
+                                float *scores);
+int oakgpu_poke_engine_eval(oakgpu_ctx *ctx, const uint8_t *battles, uint32_t n, float root_score, float *values,
+                            float *scores);
+
 /* ---- one tree level for a batch of descents (MCTS::Search::run_iteration, search/mcts.h:304-389): apply
  * the joint action of every lane (c1[i] == 0xFF: lane i is finished, leave it untouched), in place, and
  * report result, the 16-byte observation key (pkmn_gen1_battle_options_chance_actions; tree edge key,
@@ -113,7 +121,8 @@ typedef struct {
   uint32_t batch;        /* descents in flight (GPU lanes); 1 reproduces the reference's one-at-a-time order */
   float ucb_c;           /* Bandit::Params.c */
   int32_t bandit;        /* 0: UCB (bandit/ucb.h), 1: PUCB with network priors (bandit/pucb.h; needs eval = 1) */
-  int32_t eval;          /* 0: MCTS::MonteCarlo rollouts (mcts.h:448-496), 1: network value (network.h:72-123) */
+  int32_t eval;          /* 0: MCTS::MonteCarlo rollouts (mcts.h:448-496), 1: network value (network.h:72-123),
+                          * 2: PokeEngine::Eval (poke-engine-evaluate.h:186-202; root score taken at the root) */
   uint32_t max_depth;    /* descent depth at which a node is evaluated even if already expanded (0 = 100) */
   uint32_t root_rolls;   /* SearchOptions.root_rolls / other_rolls (mcts.h:107-131): 1, 2, 3, 20 or 39 (= no clamping) */
   uint32_t other_rolls;

@@ -14,7 +14,7 @@ SYMBOLS = [
     "oakgpu_set_ou_pools", "oakgpu_random_ou_battles_dev",
     "oakgpu_net_load", "oakgpu_net_load_memory", "oakgpu_net_free", "oakgpu_net_shape",
     "oakgpu_leaf_eval_dev", "oakgpu_leaf_eval", "oakgpu_leaf_eval_policy_dev", "oakgpu_leaf_eval_policy",
-    "oakgpu_tree_step_dev", "oakgpu_search",
+    "oakgpu_tree_step_dev", "oakgpu_search", "oakgpu_poke_engine_eval_dev", "oakgpu_poke_engine_eval",
 ]
 
 
@@ -66,6 +66,8 @@ def load():
     lib.oakgpu_set_regroup.argtypes = [vp, i32, i32, i32]
     lib.oakgpu_rollout_dev.argtypes = [vp, vp, vp, vp, vp, u32, u32, i32, vp, vp, vp, vp, vp]
     lib.oakgpu_rollout.argtypes = [vp, vp, vp, vp, vp, u32, u32, i32, vp, vp, vp, vp, vp]
+    lib.oakgpu_poke_engine_eval_dev.argtypes = [vp, vp, u32, C.c_float, vp, vp]
+    lib.oakgpu_poke_engine_eval.argtypes = [vp, vp, u32, C.c_float, vp, vp]
     lib.oakgpu_tree_step_dev.argtypes = [vp, vp, vp, vp, vp, vp, u32, u32, vp, vp, vp, vp, vp]
     lib.oakgpu_search.argtypes = [vp, vp, vp, vp, C.c_uint8, C.POINTER(SearchParams), C.POINTER(SearchOutput)]
     lib.oakgpu_update_dev.argtypes = [vp, vp, vp, vp, vp, vp, vp, u32, vp]

@@ -500,6 +500,72 @@ __global__ __launch_bounds__(BLOCK) void k_tree_step(uint8_t *battles, uint8_t *
   store_state(state, battles, base, count);
 }
 
+// ---- PokeEngine::Eval (cpp/include/search/poke-engine-evaluate.h:9-204): the hand-written fp32 position score the
+// reference uses as its default data-generation evaluator.  One lane per battle, straight from the AoS bytes.
+__device__ __forceinline__ float pe_boost(uint32_t nib) { // get_boost_multiplier (:52-85) of a 4-bit two's-complement stage
+  const int st = (int)((nib ^ 8) - 8);
+  const int a = st < 0 ? -st : st;
+  const float m = a == 0 ? 0.0f : a == 1 ? 1.0f : a == 2 ? 2.0f : a == 3 ? 2.5f : a == 4 ? 3.0f : a == 5 ? 3.15f : 3.3f;
+  return st < 0 ? -m : m;
+}
+__device__ __forceinline__ float pe_pokemon(const uint8_t *pk) { // evaluate_pokemon (:131-140), pk = 24 stored bytes
+  const uint32_t hp = pk[18] | (pk[19] << 8);
+  if (hp == 0) return 0.0f;
+  const uint32_t maxhp = pk[0] | (pk[1] << 8), status = pk[20];
+  float score = (100.0f * (float)hp) / (float)maxhp;
+  float st = 0.0f; // evaluate_status (:106-129)
+  if (status == ST_BRN) { // evaluate_burned (:87-104)
+    float mult = 0.0f;
+    for (int m = 0; m < 4; ++m) {
+      const uint32_t w = OAK_MOVE_WORDS[pk[10 + 2 * m]];
+      if (((w >> 8) & 0xFF) > 0 && ((w >> 16) & 0xFF) < 8) mult += 1.0f;
+    }
+    const uint32_t atk = pk[2] | (pk[3] << 8), spc = pk[8] | (pk[9] << 8);
+    if (spc > atk) mult *= 0.5f;
+    st = mult * -25.0f;
+  } else if (status == ST_FRZ) st = -40.0f;
+  else if (status == ST_PAR) st = -25.0f;
+  else if (status == ST_TOX) st = -30.0f;
+  else if (status == ST_PSN) st = -10.0f;
+  else if (status & 7) st = -25.0f;
+  score += st;
+  score = fmaxf(score, 0.0f);
+  return score + 30.0f;
+}
+__device__ __forceinline__ float pe_side(const uint8_t *side) { // evaluate_side / evaluate_active (:142-184)
+  float score = 0.0f;
+  const uint32_t aid = side[176];
+  const uint8_t *stored = side + 24 * (aid ? aid - 1 : 0); // Side::stored(): pokemon[order[0] - 1]
+  const uint32_t shp = aid ? (stored[18] | (stored[19] << 8)) : 0;
+  if (shp) {
+    score += pe_pokemon(stored);
+    const uint8_t *ac = side + 144;
+    const uint32_t vlo = ac[16] | (ac[17] << 8) | (ac[18] << 16);
+    if (vlo & V_LEECHSEED) score += -30.0f;
+    if (vlo & V_SUBSTITUTE) score += 40.0f;
+    if (vlo & V_CONFUSION) score += -20.0f;
+    if (vlo & V_REFLECT) score += 20.0f;
+    if (vlo & V_LIGHTSCREEN) score += 20.0f;
+    score += 30.0f * pe_boost(ac[12] & 15);   // atk
+    score += 15.0f * pe_boost(ac[12] >> 4);   // def
+    score += 30.0f * pe_boost(ac[13] >> 4);   // spc
+    score += 30.0f * pe_boost(ac[13] & 15);   // spe
+  }
+  for (int slot = 2; slot <= 6; ++slot) {
+    const uint32_t id = side[176 + slot - 1];
+    if (id != 0) score += pe_pokemon(side + 24 * (id - 1));
+  }
+  return score;
+}
+__global__ void k_poke_engine(const uint8_t *battles, uint32_t n, float root_score, float *values, float *scores) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint8_t *b = battles + (size_t)i * 384;
+  const float score = pe_side(b) - pe_side(b + 184);
+  if (scores) scores[i] = score;
+  if (values) values[i] = 1.0f / (1.0f + expf(-0.0125f * (score - root_score))); // scaled_sigmoid (:11-13), Eval::evaluate (:195-201)
+}
+
 // ---- PKMN::battle / Init::init_side (cpp/include/libpkmn/init.h:35-40,90-154) ---------------
 template <class E>
 __device__ void init_from_teams(E &e, const uint8_t *teams /* 60 B, this lane */, uint32_t seed_lo, uint32_t seed_hi) {
@@ -867,6 +933,38 @@ int oakgpu_tree_step_dev(oakgpu_ctx *c, uint8_t *battles, uint8_t *durations, ui
                      results, c1, c2, n, rolls, actions, p1_choices, p1_counts, p2_choices, p2_counts);
   HIPCHK(hipGetLastError());
   return 0;
+}
+
+int oakgpu_poke_engine_eval_dev(oakgpu_ctx *c, const uint8_t *battles, uint32_t n, float root_score, float *values, float *scores) {
+  if (!c) return bad("null ctx");
+  if (n == 0) return 0;
+  if (!battles || (!values && !scores)) return bad("oakgpu_poke_engine_eval_dev: null required pointer");
+  hipLaunchKernelGGL(oak::k_poke_engine, dim3((n + 255) / 256), dim3(256), 0, c->stream, battles, n, root_score, values, scores);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int oakgpu_poke_engine_eval(oakgpu_ctx *c, const uint8_t *battles, uint32_t n, float root_score, float *values, float *scores) {
+  if (!c) return bad("null ctx");
+  if (n == 0) return 0;
+  if (!battles || (!values && !scores)) return bad("oakgpu_poke_engine_eval: null required pointer");
+  HIPCHK(hipSetDevice(c->device));
+  uint8_t *db = nullptr;
+  float *dv = nullptr, *ds = nullptr;
+  HIPCHK(hipMalloc((void **)&db, (size_t)n * 384));
+  hipError_t e = hipMalloc((void **)&dv, (size_t)n * 8);
+  if (e != hipSuccess) { (void)hipFree(db); return fail(e, "hipMalloc"); }
+  ds = dv + n;
+  int rc = 0;
+  e = hipMemcpyAsync(db, battles, (size_t)n * 384, hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) rc = oakgpu_poke_engine_eval_dev(c, db, n, root_score, dv, ds);
+  if (e == hipSuccess && !rc && values) e = hipMemcpyAsync(values, dv, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess && !rc && scores) e = hipMemcpyAsync(scores, ds, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess && !rc) e = hipStreamSynchronize(c->stream);
+  (void)hipFree(db);
+  (void)hipFree(dv);
+  if (e != hipSuccess) return fail(e, "oakgpu_poke_engine_eval");
+  return rc;
 }
 
 int oakgpu_init_battles_dev(oakgpu_ctx *c, const uint8_t *teams, const uint64_t *seeds, uint32_t n, int first_update,

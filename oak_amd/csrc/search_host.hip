@@ -110,8 +110,8 @@ struct Buffers { // device arrays + pinned host mirrors of what crosses PCIe eve
 extern "C" int oakgpu_search(oakgpu_ctx *ctx, oakgpu_net *net, const uint8_t *battle, const uint8_t *durations, uint8_t result,
                              const oakgpu_search_params *prm, oakgpu_search_output *out) {
   if (!ctx || !battle || !durations || !prm || !out) return oakgpu_fail_msg("oakgpu_search: null argument");
-  const bool pucb = prm->bandit == 1, use_net = prm->eval == 1;
-  if (prm->bandit < 0 || prm->bandit > 1 || prm->eval < 0 || prm->eval > 1) return oakgpu_fail_msg("oakgpu_search: unknown bandit / eval");
+  const bool pucb = prm->bandit == 1, use_net = prm->eval == 1, use_pe = prm->eval == 2;
+  if (prm->bandit < 0 || prm->bandit > 1 || prm->eval < 0 || prm->eval > 2) return oakgpu_fail_msg("oakgpu_search: unknown bandit / eval");
   if ((use_net || pucb) && !net) return oakgpu_fail_msg("oakgpu_search: network evaluation / PUCB priors need a network");
   if (pucb && !use_net) return oakgpu_fail_msg("oakgpu_search: PUCB takes its priors from the network evaluator (eval = 1)");
   if (prm->batch == 0 || prm->batch > (1u << 20)) return oakgpu_fail_msg("oakgpu_search: batch must be in 1..2^20");
@@ -146,6 +146,9 @@ extern "C" int oakgpu_search(oakgpu_ctx *ctx, oakgpu_net *net, const uint8_t *ba
     softmax(root->p2.priors, l2, n);
     out->initial_value = v;
   }
+
+  float pe_root = 0.0f; // PokeEngine::Eval::get_root_score (mcts.h:172-174)
+  if (use_pe) RC(oakgpu_poke_engine_eval(ctx, battle, 1, 0.0f, nullptr, &pe_root));
 
   Buffers buf;
   uint8_t *d_root_b, *d_root_d, *d_root_r, *d_b, *d_d, *d_r, *d_prng, *d_c1, *d_c2, *d_act, *d_ch1, *d_cnt1, *d_ch2, *d_cnt2, *d_rout;
@@ -233,7 +236,9 @@ extern "C" int oakgpu_search(oakgpu_ctx *ctx, oakgpu_net *net, const uint8_t *ba
       }
     }
     // leaf evaluation, in place on the device
-    if (!use_net) {
+    if (use_pe) {
+      RC(oakgpu_poke_engine_eval_dev(ctx, d_b, nb, pe_root, d_values, nullptr));
+    } else if (!use_net) {
       RC(oakgpu_rollout_dev(ctx, d_b, d_d, d_r, d_prng, nb, 1000, 0, d_rout, d_steps, d_values, nullptr, nullptr));
     } else if (pucb) {
       RC(oakgpu_leaf_eval_policy_dev(ctx, net, d_b, d_d, nb, d_ch1, d_cnt1, d_ch2, d_cnt2, d_values, d_l1, d_l2));

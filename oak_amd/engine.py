@@ -55,6 +55,15 @@ class Context:
     def set_playouts_per_lane(self, k):
         _lib.check(self.lib.oakgpu_set_playouts_per_lane(self.handle, int(k)))
 
+    def poke_engine_eval(self, battles, root_score=0.0):
+        """PokeEngine::Eval on a batch (poke-engine-evaluate.h:186-202): returns (values, raw scores)."""
+        battles = _u8(battles)
+        n = battles.shape[0]
+        values = np.zeros(n, dtype=np.float32)
+        scores = np.zeros(n, dtype=np.float32)
+        _lib.check(self.lib.oakgpu_poke_engine_eval(self.handle, _p(battles), n, C.c_float(root_score), _p(values), _p(scores)))
+        return values, scores
+
     def set_regroup(self, rounds=4, suspend_below=32, shrink=3):
         """Tail regrouping of the queue schedule (include/oakgpu.h: oakgpu_set_regroup); results never change."""
         _lib.check(self.lib.oakgpu_set_regroup(self.handle, int(rounds), int(suspend_below), int(shrink)))

@@ -144,15 +144,15 @@ def process_output(out):
 def tree_search(ctx, battle, durations, result, iterations=1 << 16, batch=4096, c=2.0, bandit="ucb", evaluator="mc",
                 root_rolls=3, other_rolls=1, max_depth=100, seed=0x5EED):
     """Tree search with batched leaves on the GPU (include/oakgpu.h: oakgpu_search).  bandit: "ucb" | "pucb";
-    evaluator: "mc" or an oak_amd.engine.Network.  Defaults follow the reference's default_search{3, 1} damage-roll
+    evaluator: "mc", "poke-engine" (PokeEngine::Eval) or an oak_amd.engine.Network.  Defaults follow the reference's default_search{3, 1} damage-roll
     clamping (mcts.h:131).  Returns a dict shaped like MCTS::Output (mcts.h:68-90)."""
     import ctypes as C
     from . import _lib
     battle = np.ascontiguousarray(battle, dtype=np.uint8).reshape(384)
     durations = np.ascontiguousarray(durations, dtype=np.uint8).reshape(8)
-    use_net = evaluator != "mc"
+    use_net = not isinstance(evaluator, str)
     prm = _lib.SearchParams(iterations=int(iterations), batch=int(batch), ucb_c=float(c), bandit={"ucb": 0, "pucb": 1}[bandit],
-                            eval=1 if use_net else 0, max_depth=int(max_depth), root_rolls=int(root_rolls),
+                            eval=1 if use_net else {"mc": 0, "poke-engine": 2}[evaluator], max_depth=int(max_depth), root_rolls=int(root_rolls),
                             other_rolls=int(other_rolls), seed=int(seed))
     res = _lib.SearchOutput()
     _lib.check(ctx.lib.oakgpu_search(ctx.handle, evaluator.handle if use_net else None, battle.ctypes.data_as(C.c_void_p),

@@ -118,3 +118,16 @@ def test_value_policy_inference_matches_oracle(gpu_ctx, tag):
         assert (l1[i, n1[i]:] == 0).all() and (l2[i, n2[i]:] == 0).all()
     assert worst <= TOL
     net.close()
+
+
+def test_poke_engine_eval_matches_oracle(gpu_ctx):
+    """PokeEngine::Eval on the GPU (k_poke_engine) against the numpy restatement, on mid-game states with statuses,
+    boosts and volatiles in play: raw scores and sigmoid values."""
+    from oak_amd import gamedata
+    b, d = _midgame_states(400, 30, 2024)
+    root = 12.5
+    vals, scores = gpu_ctx.poke_engine_eval(b, root_score=root)
+    exp_s = np.array([float(NN.poke_engine_score(b[i], gamedata.MOVES)) for i in range(b.shape[0])])
+    exp_v = np.array([float(NN.poke_engine_value(b[i], gamedata.MOVES, root)) for i in range(b.shape[0])])
+    assert np.abs(scores - exp_s).max() <= 1e-3 and len(np.unique(np.round(exp_s))) > 50
+    assert np.abs(vals - exp_v).max() <= TOL

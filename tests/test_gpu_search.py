@@ -109,3 +109,12 @@ def test_tree_search_with_network_and_pucb(gpu_ctx):
     with pytest.raises(OakGpuError):
         tree_search(gpu_ctx, b[0], d[0], int(r[0]), iterations=64, batch=64, bandit="pucb", evaluator="mc")
     net.close()
+
+
+def test_tree_search_with_poke_engine_eval(gpu_ctx):
+    import oracle_lib as O
+    from oak_amd.search import tree_search
+    b, d, p, r = O.make_random_ou_batch(1, seed0=99)
+    out = tree_search(gpu_ctx, b[0], d[0], int(r[0]), iterations=8192, batch=1024, evaluator="poke-engine", c=1.0)
+    assert int(out["visit_matrix"].sum()) == 8192 and out["nodes"] > 81
+    assert 0.2 < out["empirical_value"] < 0.8      # values are sigmoids of score differences from the root: near 0.5

@@ -56,3 +56,24 @@ def test_encoder_dims_and_embedding_layout():
         assert emb.shape == (768,) and emb[0] == 1.0 and emb[384] == 1.0   # full-HP leads
         v = NN.value_inference(net, b[i], d[i])
         assert 0.0 < float(v) < 1.0
+
+
+def test_poke_engine_oracle_hand_computed_cases():
+    """PokeEngine::Eval restatement (poke-engine-evaluate.h): values worked out by hand from the header's constants."""
+    from oak_amd import gamedata
+    from oak_amd.parse import parse_battle
+    M = gamedata.MOVES
+    # full-health 1v1: each side 100 (hp) + 30 (alive) -> 0; sigmoid(0) = 0.5
+    b, d = parse_battle("starmie surf | snorlax bodyslam")
+    assert float(NN.poke_engine_score(b, M)) == 0.0 and float(NN.poke_engine_value(b, M, 0.0)) == 0.5
+    # a paralysed foe: -25 on its side -> +25 for P1
+    b, d = parse_battle("starmie surf | snorlax bodyslam par")
+    assert float(NN.poke_engine_score(b, M)) == 25.0
+    # burned physical attacker with two physical damaging moves (atk > spc): 2 * -25
+    b, d = parse_battle("starmie surf | snorlax bodyslam earthquake amnesia brn")
+    assert float(NN.poke_engine_score(b, M)) == 50.0
+    # sleeping P1 at 101 / 323 hp: 100 * 101 / 323 - 25 + 30 against 130
+    b, d = parse_battle("starmie seismictoss 101hp slp3 | snorlax seismictoss")
+    exp = np.float32(np.float32(np.float32(100) * np.float32(101)) / np.float32(323)) - np.float32(25) + np.float32(30) - np.float32(130)
+    assert abs(float(NN.poke_engine_score(b, M)) - float(exp)) < 1e-4
+    assert abs(float(NN.poke_engine_value(b, M, 0.0)) - 1 / (1 + np.exp(-0.0125 * float(exp)))) < 1e-6
