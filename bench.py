@@ -50,9 +50,10 @@ def main():
     ap.add_argument("--streams", type=int, default=20, help="independent batches in flight (HIP streams)")
     ap.add_argument("--playouts-per-lane", type=int, default=2,
                     help="k > 1: persistent n/k lanes per batch that refill from an atomic playout queue")
-    ap.add_argument("--workload", choices=["rollout", "leaf", "config3"], default="rollout",
+    ap.add_argument("--workload", choices=["rollout", "leaf", "config3", "search"], default="rollout",
                     help="rollout = BASELINE configs[1] (headline); leaf = leaf-evals/s of the 768-256-256-256-1 net; "
-                         "config3 = configs[2]: one turn-step of the whole batch + a leaf eval of every lane, every turn")
+                         "config3 = configs[2]: one turn-step of the whole batch + a leaf eval of every lane, every turn; "
+                         "search = tree search with batched leaves (oakgpu_search), iterations/s on one random OU root")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -82,6 +83,8 @@ def main():
 
     if args.workload in ("leaf", "config3"):
         return leaf_workload(args, torch, dev, rank, local_rank, world, dist)
+    if args.workload == "search":
+        return search_workload(args, torch, dev, rank, local_rank, world, dist)
 
     n = args.batch
     S = max(1, min(args.streams, args.steps if args.steps > 0 else 1))
@@ -354,6 +357,54 @@ def leaf_workload(args, torch, dev, rank, local_rank, world, dist):
                          "algorithmic_flop_per_leaf": main_f + emb_f, "mainnet_flop_per_leaf": main_f},
         }), flush=True)
     net.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def search_workload(args, torch, dev, rank, local_rank, world, dist):
+    """SURVEY 8(f) rank 1: MCTS::Search::run with batched leaves (oak_amd/csrc/search_host.hip).  One step = one search of
+    2^18 iterations (batch 16,384 descents, UCB c = 2, Monte-Carlo leaves, default_search{3, 1} roll clamping) from a
+    random OU turn-1 root; every rank searches its own root (root-parallel), nothing is exchanged."""
+    from oak_amd import _lib
+    from oak_amd import dist as oakdist
+    from oak_amd.engine import Context
+    from oak_amd.search import tree_search
+    ctx = Context(local_rank)
+    ctx.ensure_ou_pools()
+    ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+    tb, td, tp, tr = (torch.empty(s_, dtype=torch.uint8, device=dev) for s_ in ((1, 384), (1, 8), (1, 8), (1,)))
+
+    def P(t):
+        return C.c_void_p(t.data_ptr())
+    seed0 = oakdist.lane_seed0(SEED0, world, rank, world)
+    _lib.check(ctx.lib.oakgpu_random_ou_battles_dev(ctx.handle, C.c_uint64(seed0), 1, P(tb), P(td), P(tp), P(tr)))
+    torch.cuda.synchronize(dev)
+    b, d, r = tb.cpu().numpy()[0], td.cpu().numpy()[0], int(tr.cpu().numpy()[0])
+    iters, batch = 1 << 18, 16384
+    K = max(1, min(args.steps, 8))
+    tree_search(ctx, b, d, r, iterations=2 * batch, batch=batch)      # warm-up
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    outs = [tree_search(ctx, b, d, r, iterations=iters, batch=batch, seed=k) for k in range(K)]
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        print(json.dumps({
+            "metric": "search iterations/s (tree search, batched Monte-Carlo leaves)", "value": iters * K * world / elapsed,
+            "unit": "iterations/s", "n_gpus": world, "steps": K, "warmup": 1, "ms_per_step": elapsed / K * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u16", "data": "synthetic",
+            "config": {"workload": "SURVEY 8(f) rank 1: MCTS::Search::run, Node heap, joint UCB (c = 2), 2^18 iterations per search in "
+                                   "batches of 16384 descents, rollout leaves, roll clamping {3, 1}; one random OU turn-1 root per GPU",
+                       "nodes": outs[-1]["nodes"], "mean_depth": outs[-1]["mean_depth"], "nash_value": outs[-1]["nash_value"]},
+        }), flush=True)
     if world > 1:
         dist.destroy_process_group()
 

@@ -1,11 +1,11 @@
 // oak_amd/csrc/leafnet.hip -- fp32 leaf evaluator on gfx950 (K2 + K3) and its C ABI.
 //
 // Replaces NN::Battle::NetworkImpl::value_inference (cpp/include/nn/battle/network.h:72-79):
-//   K2  k_embed   : Encode::Battle::{Pokemon,ActivePokemon}::write (encode/battle/battle.h:208-214,
+//   K2  k_embed_lds : Encode::Battle::{Pokemon,ActivePokemon}::write (encode/battle/battle.h:208-214,
 //                   544-551) fused with EmbeddingNet::propagate (nn/ffn.h:47-51, affine.h:87-103)
-//                   and write_battle_embedding (network.h:131-175).  One wave per (leaf, party
-//                   slot); the sparse first layer is a gather-add over 512-byte weight rows driven
-//                   by wave-uniform control flow, the dense second layer streams W1^T from LDS.
+//                   and write_battle_embedding (network.h:131-175): 64-item tiles, one lane per sparse
+//                   feature, first-layer weights resident in LDS, dense second layer on fp32 MFMA
+//                   (k_embed_tile = the previous L2-gather form, OAKGPU_EMBED_IMPL=2, kept for A/B).
 //                   The reference's per-battle embedding caches (nn/battle/cache.h) are replaced
 //                   by recomputation.
 //   K3  k_mainnet : MainNet::propagate value path (nn/battle/main-net.h:57-64) + sigmoid, the three
@@ -26,9 +26,9 @@
 namespace oak {
 
 struct NetDev {
-  // embedding nets: W0t [in][128-ish hidden] (transposed for row gathers), b0, W1t [hidden][out], b1
-  const float *p_w0t, *p_b0, *p_w1t, *p_b1;
-  const float *a_w0t, *a_b0, *a_w1t, *a_b1;
+  // embedding nets: W0t [in][hidden <= 128] (transposed: one row per input feature), b0, b1
+  const float *p_w0t, *p_b0, *p_b1;
+  const float *a_w0t, *a_b0, *a_b1;
   const float *p_w1, *a_w1; // second layers in file layout [out][hidden] (MFMA B operand of k_embed_tile)
   int p_hidden, p_out, a_hidden, a_out;
   int side_dim, emb_dim;
@@ -49,15 +49,6 @@ __device__ __forceinline__ float act_fn(float x, int activation) {
 
 // ---- K2 ---------------------------------------------------------------------------------------
 constexpr int EMB_BLOCK = 256;
-constexpr int MAX_HIDDEN = 128; // embedding hidden width handled as 2 channels per lane
-
-struct EmbedArgs {
-  NetDev net;
-  const uint8_t *battles;
-  const uint8_t *durations;
-  uint32_t n;
-  float *emb; // n x emb_dim
-};
 
 __device__ __forceinline__ uint32_t status_index(uint32_t status, uint32_t sleeps) { // battle.h:103-123
   if (!(status & 7)) return (uint32_t)__builtin_ctz(status) - 3;
@@ -148,108 +139,6 @@ __device__ __forceinline__ bool active_feature(uint32_t j, uint32_t a0, uint32_t
   idx = (i == 0 ? 209 : i == 1 ? 214 : i == 2 ? 222 : 225) + v - 1;
   val = 1.0f;
   return v != 0;
-}
-
-// One wave per (leaf, party slot).  Lanes build the sparse feature list in parallel, compact it with a
-// ballot into LDS, then the wave streams the selected 512-byte rows of W0^T with 8 loads in flight
-// (2 channels per lane), and finishes with the dense second layer out of LDS.
-__global__ __launch_bounds__(EMB_BLOCK) void k_embed(EmbedArgs a) {
-  extern __shared__ __align__(16) float lds_f[];
-  const NetDev &N = a.net;
-  float *p_w1t = lds_f;                                   // [p_hidden][p_out]
-  float *a_w1t = p_w1t + N.p_hidden * N.p_out;            // [a_hidden][a_out]
-  float *scratch = a_w1t + N.a_hidden * N.a_out;          // per wave: 64 idx + 64 val + 128 h
-  for (int i = threadIdx.x; i < N.p_hidden * N.p_out; i += EMB_BLOCK) p_w1t[i] = N.p_w1t[i];
-  for (int i = threadIdx.x; i < N.a_hidden * N.a_out; i += EMB_BLOCK) a_w1t[i] = N.a_w1t[i];
-  __syncthreads();
-
-  const uint32_t lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
-  uint32_t *list_idx = (uint32_t *)(scratch + wib * 256);
-  float *list_val = scratch + wib * 256 + 64;
-  float *hbuf = scratch + wib * 256 + 128;
-  const uint32_t c0 = lane, c1 = lane + 64;
-  const uint32_t wave = __builtin_amdgcn_readfirstlane((blockIdx.x * EMB_BLOCK + threadIdx.x) >> 6);
-  const uint32_t n_waves = (gridDim.x * EMB_BLOCK) >> 6;
-  const uint32_t items = a.n * 12;
-  for (uint32_t item = wave; item < items; item += n_waves) {
-    const uint32_t leaf = item / 12, t = item - leaf * 12;
-    const uint32_t side = t / 6, slot = t - side * 6; // slot 0 = active
-    const uint32_t *sb = (const uint32_t *)(a.battles + (size_t)leaf * 384 + side * 184);
-    const uint32_t dur = ((const uint32_t *)a.durations)[(size_t)leaf * 2 + side];
-    const uint32_t o0 = sb[44], o1 = sb[45]; // order bytes at side offset 176
-    const uint32_t id = slot < 4 ? (o0 >> (8 * slot)) & 0xFF : (o1 >> (8 * (slot - 4))) & 0xFF;
-    const bool is_active = slot == 0;
-    const uint32_t out_dim = is_active ? N.a_out : N.p_out;
-    float *dst = a.emb + (size_t)leaf * N.emb_dim + side * N.side_dim + (is_active ? 0 : (1 + N.a_out) + (slot - 1) * (1 + N.p_out));
-    uint32_t pk0 = 0, pk1 = 0, pk2 = 0, pk3 = 0, pk4 = 0, pk5 = 0, hp = 0;
-    if (id != 0) {
-      const uint32_t *pk = sb + 6 * (id - 1);
-      pk0 = pk[0]; pk1 = pk[1]; pk2 = pk[2]; pk3 = pk[3]; pk4 = pk[4]; pk5 = pk[5];
-      hp = pk4 >> 16;
-    }
-    if (hp == 0) { // empty or fainted: zero block (network.h:142-143,153-160)
-      for (uint32_t o = lane; o < out_dim + 1; o += 64) dst[o] = 0.0f;
-      continue;
-    }
-    // 1. sparse feature list: lane j evaluates feature j
-    uint32_t fidx = 0;
-    float fval = 0.0f;
-    bool valid = false;
-    if (is_active) {
-      const uint32_t *ac = sb + 36; // active block at byte 144
-      if (lane < 40) valid = active_feature(lane, ac[0], ac[1], ac[2], ac[3], ac[4], ac[5], ac[6], ac[7], dur, fidx, fval);
-      else if (lane < 52) { valid = pokemon_feature(lane - 40, pk0, pk1, pk2, pk3, pk4, pk5, dur & 7, fidx, fval); fidx += 229; }
-    } else if (lane < 12) {
-      valid = pokemon_feature(lane, pk0, pk1, pk2, pk3, pk4, pk5, (dur >> (3 * slot)) & 7, fidx, fval);
-    }
-    const uint64_t mask = __ballot(valid);
-    const uint32_t count = (uint32_t)__popcll(mask);
-    list_idx[lane] = 0; // padding entries: row 0 with weight 0
-    list_val[lane] = 0.0f;
-    if (valid) {
-      const uint32_t pos = (uint32_t)__popcll(mask & ((1ull << lane) - 1));
-      list_idx[pos] = fidx;
-      list_val[pos] = fval;
-    }
-    // 2. first layer: h = b0 + sum_k W0t[idx_k][:] * val_k, 4 rows (8 loads) in flight
-    const uint32_t hidden = is_active ? N.a_hidden : N.p_hidden;
-    const float *w0t = is_active ? N.a_w0t : N.p_w0t;
-    const float *b0 = is_active ? N.a_b0 : N.p_b0;
-    const bool on0 = c0 < hidden, on1 = c1 < hidden;
-    float h0 = on0 ? b0[c0] : 0.0f, h1 = on1 ? b0[c1] : 0.0f;
-    const uint32_t cc0 = on0 ? c0 : 0, cc1 = on1 ? c1 : 0;
-    for (uint32_t k = 0; k < count; k += 4) {
-      const uint4 iv = *(const uint4 *)(list_idx + k);
-      const float4 vv = *(const float4 *)(list_val + k);
-      const float *r0 = w0t + (size_t)iv.x * hidden, *r1 = w0t + (size_t)iv.y * hidden, *r2 = w0t + (size_t)iv.z * hidden,
-                  *r3 = w0t + (size_t)iv.w * hidden;
-      const float x00 = r0[cc0], x01 = r0[cc1], x10 = r1[cc0], x11 = r1[cc1], x20 = r2[cc0], x21 = r2[cc1], x30 = r3[cc0], x31 = r3[cc1];
-      h0 = fmaf(x00, vv.x, h0); h1 = fmaf(x01, vv.x, h1);
-      h0 = fmaf(x10, vv.y, h0); h1 = fmaf(x11, vv.y, h1);
-      h0 = fmaf(x20, vv.z, h0); h1 = fmaf(x21, vv.z, h1);
-      h0 = fmaf(x30, vv.w, h0); h1 = fmaf(x31, vv.w, h1);
-    }
-    hbuf[c0] = on0 ? act_fn(h0, N.activation) : 0.0f;
-    hbuf[c1] = on1 ? act_fn(h1, N.activation) : 0.0f;
-    // 3. dense second layer: out[o] = b1[o] + sum_c W1t[c][o] * h[c]; h broadcast from LDS
-    const float *w1t = is_active ? a_w1t : p_w1t;
-    const float *b1 = is_active ? N.a_b1 : N.p_b1;
-    const uint32_t oa = lane, ob = lane + 64;
-    const bool ona = oa < out_dim, onb = ob < out_dim;
-    const uint32_t oca = ona ? oa : 0, ocb = onb ? ob : 0;
-    float ya = ona ? b1[oa] : 0.0f, yb = onb ? b1[ob] : 0.0f;
-    for (uint32_t c = 0; c < hidden; c += 4) {
-      const float4 hv = *(const float4 *)(hbuf + c);
-      const float *w = w1t + c * out_dim;
-      ya = fmaf(w[oca], hv.x, ya);                 yb = fmaf(w[ocb], hv.x, yb);
-      ya = fmaf(w[out_dim + oca], hv.y, ya);       yb = fmaf(w[out_dim + ocb], hv.y, yb);
-      ya = fmaf(w[2 * out_dim + oca], hv.z, ya);   yb = fmaf(w[2 * out_dim + ocb], hv.z, yb);
-      ya = fmaf(w[3 * out_dim + oca], hv.w, ya);   yb = fmaf(w[3 * out_dim + ocb], hv.w, yb);
-    }
-    if (lane == 0) dst[0] = (float)hp / (float)(pk0 & 0xFFFF);
-    if (ona) dst[1 + oa] = act_fn(ya, N.activation);
-    if (onb) dst[1 + ob] = act_fn(yb, N.activation);
-  }
 }
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
@@ -996,13 +885,11 @@ int oakgpu_net_load_memory(oakgpu_ctx *ctx, const void *bytes, size_t size, oakg
   int rc = 0;
   rc = rc ? rc : upload(net, transpose(p0), &D.p_w0t);
   rc = rc ? rc : upload(net, p0.b, &D.p_b0);
-  rc = rc ? rc : upload(net, transpose(p1), &D.p_w1t);
   rc = rc ? rc : upload(net, p1.w, &D.p_w1);
   rc = rc ? rc : upload(net, a1.w, &D.a_w1);
   rc = rc ? rc : upload(net, p1.b, &D.p_b1);
   rc = rc ? rc : upload(net, transpose(a0), &D.a_w0t);
   rc = rc ? rc : upload(net, a0.b, &D.a_b0);
-  rc = rc ? rc : upload(net, transpose(a1), &D.a_w1t);
   rc = rc ? rc : upload(net, a1.b, &D.a_b1);
   rc = rc ? rc : upload(net, pad_rows(fc0, H, fc0.in), &D.w0);
   rc = rc ? rc : upload(net, pad_vec(fc0.b, H), &D.b0);
@@ -1056,9 +943,7 @@ int oakgpu_net_shape(const oakgpu_net *net, int *in_dim, int *hidden, int *value
 static int lds_attrs_once() {
   static bool done = false;
   if (done) return 0;
-  hipError_t e = hipFuncSetAttribute((const void *)oak::k_embed, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-  if (e != hipSuccess) return oakgpu_fail_hip((int)e, "hipFuncSetAttribute(k_embed)");
-  e = hipFuncSetAttribute((const void *)oak::k_embed_tile, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+  hipError_t e = hipFuncSetAttribute((const void *)oak::k_embed_tile, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
   if (e != hipSuccess) return oakgpu_fail_hip((int)e, "hipFuncSetAttribute(k_embed_tile)");
   e = hipFuncSetAttribute((const void *)oak::k_embed_lds<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)oak::ELayout<false>::BYTES);
   if (e != hipSuccess) return oakgpu_fail_hip((int)e, "hipFuncSetAttribute(k_embed_lds<party>)");
@@ -1094,13 +979,7 @@ static int leaf_eval_impl(oakgpu_ctx *ctx, oakgpu_net *net, const uint8_t *battl
   }
   const oak::NetDev &D = net->dev;
   static const int embed_impl = getenv("OAKGPU_EMBED_IMPL") ? atoi(getenv("OAKGPU_EMBED_IMPL")) : 3;
-  if (embed_impl == 1) { // first implementation (one wave per item, VALU second layer), kept for A/B
-    oak::EmbedArgs ea{D, battles, durations, n, emb};
-    const size_t emb_lds = (size_t)(D.p_hidden * D.p_out + D.a_hidden * D.a_out + 4 * 256) * 4;
-    uint32_t grid = (n * 12 + 3) / 4;
-    if (grid > 256 * 8) grid = 256 * 8;
-    hipLaunchKernelGGL(oak::k_embed, dim3(grid), dim3(oak::EMB_BLOCK), emb_lds, stream, ea);
-  } else {
+  {
     for (int kind = 0; kind < 2; ++kind) {
       oak::EmbedTileArgs ta{D, battles, durations, n, emb, kind};
       const uint32_t ntiles = (n * (kind ? 2u : 10u) + oak::ET - 1) / oak::ET;
