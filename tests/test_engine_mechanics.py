@@ -236,3 +236,171 @@ def test_durations_follow_party_slots_on_switch():
     step(b, d, mv(b, 0, "Hypnosis"), (2 << 2) | 2)
     dw = int.from_bytes(bytes(d[4:8]), "little")
     assert dw & 7 == 0 and (dw >> 3) & 7 == 2                       # counter moved with the sleeper to slot 2
+
+
+# ---- second batch: formula-level and effect-level facts -------------------------------------------------------------
+def actions_of(pos, c1, c2, seed):
+    b, d = parse_battle(pos, seed)
+    opt = O.Options(d)
+    opt.set(None, MAXROLL)
+    r = O.update(b, c1(b), c2(b), opt)
+    return b, r, opt.actions.copy()
+
+
+def crit_flag(actions, side):           # critical_hit field: bit 10 of the side's 8 action bytes (layout.h:98-117)
+    return (int(actions[8 * side + 1]) >> 2) & 3 == 2
+
+
+def test_damage_formula_exact_number():
+    """L100 Tauros Body Slam into Starmie, max roll, no crit: floor(floor(floor(2*100/5+2) * 85 * atk / def) / 50) + 2,
+    x1.5 STAB, neutral, x255/255 -- the cartridge formula, worked out here from the two stats (both divided by 4
+    first because one of them exceeds 255)."""
+    b0, _ = parse_battle("tauros bodyslam | starmie recover")
+    atk, dfn = astat(b0, 0, 1), astat(b0, 1, 2)
+    assert atk > 255 or dfn > 255
+    atk, dfn = atk // 4, dfn // 4
+    base = (2 * 100 // 5 + 2) * 85 * atk // dfn // 50 + 2
+    expected = base + base // 2
+    seen = False
+    for s in range(60):
+        b, r, act = actions_of("tauros bodyslam | starmie recover", lambda b: mv(b, 0, "BodySlam"), lambda b: mv(b, 1, "Recover"), 7000 + s)
+        if not crit_flag(act, 0) and hp(b0, 1) - hp(b, 1) > 0:
+            # Starmie (faster) recovered nothing at full HP, then took the hit
+            assert hp(b0, 1) - hp(b, 1) == expected
+            seen = True
+    assert seen
+
+
+def test_critical_hits_double_level_and_ignore_stat_stages():
+    """Crit damage uses level x 2 and the UNMODIFIED stats: a -2 Attack Tauros crits for exactly what an unboosted one does."""
+    b0, _ = parse_battle("tauros bodyslam | starmie recover")
+    atk, dfn = astat(b0, 0, 1) // 4, astat(b0, 1, 2) // 4
+    base = (2 * 200 // 5 + 2) * 85 * atk // dfn // 50 + 2
+    expected = base + base // 2
+    hits = 0
+    for s in range(300):
+        b, r, act = actions_of("tauros bodyslam (atk-2) | starmie recover", lambda b: mv(b, 0, "BodySlam"), lambda b: mv(b, 1, "Recover"), 9000 + s)
+        if crit_flag(act, 0):
+            assert hp(b0, 1) - hp(b, 1) == expected
+            hits += 1
+    # crit chance = floor(base speed / 2) / 256 = 55 / 256 for Tauros (base 110)
+    assert 0.12 < hits / 300 < 0.32
+
+
+def test_high_critical_moves_and_rates():
+    n = 400
+    slash = sum(crit_flag(actions_of("persian slash | chansey softboiled", lambda b: mv(b, 0, "Slash"), lambda b: mv(b, 1, "SoftBoiled"), 100 + s)[2], 0)
+                for s in range(n))
+    assert slash / n > 0.97                 # min(8 * floor(115 / 2), 255) / 256
+    slow = sum(crit_flag(actions_of("snorlax bodyslam | chansey softboiled", lambda b: mv(b, 0, "BodySlam"), lambda b: mv(b, 1, "SoftBoiled"), 100 + s)[2], 0)
+               for s in range(n))
+    assert slow / n < 0.12                  # floor(30 / 2) / 256 = 5.9%
+
+
+def test_type_immunities():
+    b, d = parse_battle("snorlax bodyslam | gengar nightshade")
+    step(b, d, mv(b, 0, "BodySlam"), mv(b, 1, "NightShade"))
+    assert hp(b, 1) == hp(parse_battle("snorlax bodyslam | gengar nightshade")[0], 1)      # Normal vs Ghost
+    b, d = parse_battle("rhydon earthquake | zapdos thunderwave")
+    step(b, d, mv(b, 0, "Earthquake"), mv(b, 1, "ThunderWave"))
+    assert hp(b, 1) == hp(parse_battle("rhydon earthquake | zapdos thunderwave")[0], 1)    # Ground vs Flying
+    assert status(b, 0) == 0                                                                # Thunder Wave vs Ground
+    b, d = parse_battle("venusaur leechseed | exeggutor psychic")
+    step(b, d, mv(b, 0, "LeechSeed"), mv(b, 1, "Psychic"))
+    assert not (vol(b, 1) & (1 << 13))                                                      # Leech Seed vs Grass
+
+
+def test_multi_hit_distribution_and_fixed_two_hitters():
+    counts = {}
+    for s in range(800):
+        b, r, act = actions_of("cloyster spikecannon | chansey softboiled", lambda b: mv(b, 0, "SpikeCannon"), lambda b: mv(b, 1, "SoftBoiled"), s)
+        k = (int(act[5]) >> 4) & 15          # multi_hit field: bits 44-47
+        if k:
+            counts[k] = counts.get(k, 0) + 1
+    tot = sum(counts.values())
+    assert set(counts) == {2, 3, 4, 5}
+    assert abs(counts[2] / tot - 3 / 8) < 0.06 and abs(counts[3] / tot - 3 / 8) < 0.06
+    assert abs(counts[4] / tot - 1 / 8) < 0.05 and abs(counts[5] / tot - 1 / 8) < 0.05
+    # Double Kick: exactly two equal hits
+    b0, _ = parse_battle("hitmonlee doublekick | snorlax amnesia")
+    for s in range(40):
+        b, r, act = actions_of("hitmonlee doublekick | snorlax amnesia", lambda b: mv(b, 0, "DoubleKick"), lambda b: mv(b, 1, "Amnesia"), 300 + s)
+        lost = hp(b0, 1) - hp(b, 1)
+        assert lost % 2 == 0
+
+
+def test_counter_only_answers_normal_and_fighting():
+    b, d = parse_battle("chansey counter | starmie surf")
+    h1 = hp(b, 1)
+    step(b, d, mv(b, 0, "Counter"), mv(b, 1, "Surf"))
+    assert hp(b, 1) == h1                                           # Water damage cannot be countered
+    b, d = parse_battle("snorlax counter | chansey seismictoss")
+    h0, h1 = hp(b, 0), hp(b, 1)
+    step(b, d, mv(b, 0, "Counter"), mv(b, 1, "SeismicToss"))
+    assert h0 - hp(b, 0) == 100 and h1 - hp(b, 1) == 200            # Fighting-type damage comes back doubled
+
+
+def test_mirror_move_and_metronome():
+    b, d = parse_battle("pidgeot mirrormove | starmie surf")
+    h1 = hp(b, 1)
+    step(b, d, mv(b, 0, "MirrorMove"), mv(b, 1, "Surf"))           # Starmie is faster: its Surf is mirrored
+    assert hp(b, 1) < h1 and int(b[183]) == G.move_id("Surf")       # last_used_move = the copied move
+    b, d = parse_battle("pidgeot mirrormove | snorlax bodyslam")
+    h1 = hp(b, 1)
+    step(b, d, mv(b, 0, "MirrorMove"), mv(b, 1, "BodySlam"))       # Pidgeot is faster: nothing to mirror yet
+    assert hp(b, 1) == h1
+    picked = set()
+    for s in range(200):
+        b, r, act = actions_of("clefable metronome | chansey softboiled", lambda b: mv(b, 0, "Metronome"), lambda b: mv(b, 1, "SoftBoiled"), s)
+        picked.add(int(act[7]))                                      # metronome field: bits 56-63
+    assert len(picked) > 80 and G.move_id("Metronome") not in picked and 0 not in picked and 165 not in picked
+
+
+def test_disable_transform_and_mimic():
+    b, d, r = find_seed("alakazam disable | snorlax bodyslam amnesia", lambda b: mv(b, 0, "Disable"), lambda b: mv(b, 1, "Amnesia"),
+                        lambda b, r: (vol(b, 1) >> 56) & 7 != 0)
+    slot = (vol(b, 1) >> 56) & 7
+    legal = [int(c) for c in O.choices(b, 1, 1)]
+    assert ((slot << 2) | 1) not in legal and len(legal) == 1        # the disabled move cannot be selected
+    b, d = parse_battle("ditto transform | starmie surf recover")
+    step(b, d, mv(b, 0, "Transform"), mv(b, 1, "Recover"))
+    assert vol(b, 0) & (1 << 17)
+    assert [astat(b, 0, k) for k in range(1, 5)] == [astat(b, 1, k) for k in range(1, 5)]      # stats copied (not HP)
+    assert list(b[144 + 24:144 + 32:2]) == list(b[184 + 144 + 24:184 + 144 + 32:2])            # move ids copied
+    assert [int(x) for x in b[144 + 25:144 + 33:2]] == [5 if m else 0 for m in b[144 + 24:144 + 32:2]]   # 5 PP each
+    b, d, r = find_seed("clefable mimic | starmie surf", lambda b: mv(b, 0, "Mimic"), lambda b: mv(b, 1, "Surf"),
+                        lambda b, r: int(b[144 + 24]) == G.move_id("Surf"))
+    assert int(b[10]) == G.move_id("Mimic")                          # only the ACTIVE copy changes, the party slot keeps Mimic
+
+
+def test_haze_thrash_and_jump_kick_crash():
+    b, d = parse_battle("vaporeon haze (atk+2) brn | snorlax amnesia (spc+4) slp3")
+    step(b, d, mv(b, 0, "Haze"), mv(b, 1, "Amnesia"))
+    # both sides' stages reset; Snorlax, cured of sleep by the (faster) Haze, then moves: Amnesia from 0 to +2, not +6
+    assert b[144 + 12] == 0 and b[184 + 144 + 13] == (2 << 4)
+    assert status(b, 1) == 0 and status(b, 0) == 0x10                # the FOE's status is cured, the user's stays
+    b, d, r = find_seed("tauros thrash | chansey softboiled", lambda b: mv(b, 0, "Thrash"), lambda b: mv(b, 1, "SoftBoiled"),
+                        lambda b, r: bool(vol(b, 0) & 2))
+    turns = 1
+    while vol(b, 0) & 2:
+        assert len(O.choices(b, 0, 1)) == 1                          # locked in
+        step(b, d, int(O.choices(b, 0, 1)[0]), mv(b, 1, "SoftBoiled"))
+        turns += 1
+    assert turns in (3, 4) and (vol(b, 0) & (1 << 7))                # 3-4 turns of thrashing, then confusion
+    b, d = parse_battle("hitmonlee highjumpkick | gengar nightshade")
+    h0 = hp(b, 0)
+    step(b, d, mv(b, 0, "HighJumpKick"), mv(b, 1, "NightShade"))
+    assert hp(b, 0) == h0 - 100                                      # immune target: no crash damage (only Night Shade's 100)
+
+
+def test_ohko_speed_rule_and_swift_accuracy():
+    b, d = parse_battle("rhydon horndrill | starmie recover")
+    step(b, d, mv(b, 0, "HornDrill"), mv(b, 1, "Recover"))
+    assert hp(b, 1) == hp(parse_battle("rhydon horndrill | starmie recover")[0], 1)         # slower user: always fails
+    miss = 0
+    for s in range(200):
+        b, d = parse_battle("starmie swift | chansey softboiled (eva+6)", 50 + s)
+        h = hp(b, 1)
+        step(b, d, mv(b, 0, "Swift"), mv(b, 1, "SoftBoiled"))
+        miss += hp(b, 1) == h and h < 703
+    assert miss == 0                                                  # Swift ignores accuracy / evasion
