@@ -317,6 +317,17 @@ __global__ __launch_bounds__(EMB_BLOCK) void k_embed_tile(EmbedTileArgs a) {
 //                     that their latency hides behind the LDS part.
 // The dense second layer stays on fp32 MFMA, with its B operand (W1, 64 values per lane) held in registers
 // instead of LDS.  Items per tile, tile layout and outputs are k_embed_tile's.
+#ifdef OAKGPU_LEAF_PROFILE // tools/leaf_phase_profile.py: wave 0's cycles per phase of k_embed_lds, summed over tiles
+static __device__ unsigned long long g_leaf_prof[16];
+// accumulate in registers (a global atomic per mark would sit in vmcnt and distort the very waits being measured)
+#define EL_T0() long long el_t = clock64(); unsigned long long el_acc[8] = {}
+#define EL_MARK(id) do { const long long _t = clock64(); el_acc[id] += (unsigned long long)(_t - el_t); el_t = _t; } while (0)
+#define EL_FLUSH() do { if (threadIdx.x == 0) for (int _i = 0; _i < 8; ++_i) atomicAdd(&g_leaf_prof[_i], el_acc[_i]); } while (0)
+#else
+#define EL_MARK(id)
+#define EL_T0()
+#define EL_FLUSH()
+#endif
 constexpr int EL_BLOCK = 512;
 constexpr int EL_WAVES = EL_BLOCK / 64;
 constexpr int EL_ITEMS = ET / EL_WAVES; // 8 items per wave
@@ -358,8 +369,10 @@ __global__ __launch_bounds__(EL_BLOCK) void k_embed_lds(EmbedTileArgs a) {
     W0s[i] = (int)c < hidden ? w0t[(size_t)r * hidden + c] : 0.0f;
   }
   const uint32_t lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
-  const uint32_t c0 = lane, c1 = lane + 64;
+  // a lane owns the ADJACENT hidden channels 2*lane, 2*lane + 1: one 8-byte LDS / global read per weight row
+  const uint32_t c0 = 2 * lane, c1 = 2 * lane + 1;
   const bool on0 = (int)c0 < hidden, on1 = (int)c1 < hidden;
+  const bool pair_ok = (hidden & 1) == 0; // rows of W0^T in global memory are 8-byte aligned only for even widths
   const uint32_t cc0 = on0 ? c0 : 0, cc1 = on1 ? c1 : 0;
   const float bias0 = on0 ? b0[c0] : 0.0f, bias1 = on1 ? b0[c1] : 0.0f;
   // MFMA role of this wave: output block (mi, nb) of the 64 x out_pad tile; B fragments stay in registers
@@ -400,15 +413,19 @@ __global__ __launch_bounds__(EL_BLOCK) void k_embed_lds(EmbedTileArgs a) {
                                  : ((const uint32_t *)a.durations)[(size_t)(first_leaf + l) * 2 + (d - 96)];
     }
   };
-  prefetch(blockIdx.x);
-  for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    __syncthreads(); // previous tile fully consumed (also orders the one-time W0s staging)
-    uint32_t first_leaf;
-    (void)tile_leaves(tile, first_leaf);
+  auto stage = [&]() { // prefetched registers -> LDS image of the tile's battles
 #pragma unroll
     for (uint32_t u = 0; u < PF; ++u) { const uint32_t i = threadIdx.x + u * EL_BLOCK; if (i < (uint32_t)L::NLEAF * 98) Bs[i] = pf[u]; }
-    __syncthreads();
-    prefetch(tile + gridDim.x);
+  };
+  prefetch(blockIdx.x);
+  stage();
+  prefetch(blockIdx.x + gridDim.x);
+  EL_T0();
+  for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    __syncthreads(); // this tile's battles are staged, the previous tile's H is consumed (and W0s is staged, first time)
+    EL_MARK(0);
+    uint32_t first_leaf;
+    (void)tile_leaves(tile, first_leaf);
     // ---- phase 1a: sparse feature lists of this wave's 8 items.  A lane evaluates ONE feature of one item:
     // the 52 features of an active in one pass per item, the 12 features of a party slot five items per pass.
     {
@@ -419,7 +436,8 @@ __global__ __launch_bounds__(EL_BLOCK) void k_embed_lds(EmbedTileArgs a) {
       }
       Gidx[wib * EL_ITEMS * 8 + lane] = 0;
       const uint32_t sub = ACT ? 0 : lane / FL, j = ACT ? lane : lane - sub * FL;
-#pragma unroll 1
+      constexpr int PASS_UNROLL = ACT ? 1 : 2; // party slots: both passes' dependent LDS reads overlap
+#pragma unroll PASS_UNROLL
       for (uint32_t pass = 0; pass < PASSES; ++pass) {
         const uint32_t ii = pass * IPP + sub;
         const bool mine = sub < IPP && ii < (uint32_t)EL_ITEMS;
@@ -475,44 +493,52 @@ __global__ __launch_bounds__(EL_BLOCK) void k_embed_lds(EmbedTileArgs a) {
         }
       }
     }
-    // ---- phase 1b/c: first layer, four items at a time (their LDS reads interleave: fixed trip counts, padded
-    // lists); the active kind's move rows are prefetched from L2 first and added last ----
+    EL_MARK(3);
+    // ---- phase 1b/c: first layer, GI items at a time (their LDS reads interleave: common trip count, padded lists);
+    // the active kind's move rows are prefetched from L2 first and added last (two items at a time: 32 registers) ----
+    constexpr int GI = ACT ? 2 : 4;
 #pragma unroll 1
-    for (uint32_t half = 0; half < 2; ++half) {
-      const uint32_t ibase = wib * EL_ITEMS + half * 4;
-      float gx0[4][8], gx1[4][8];
+    for (uint32_t half = 0; half < (uint32_t)(EL_ITEMS / GI); ++half) {
+      const uint32_t ibase = wib * EL_ITEMS + half * GI;
+      float gx0[GI][8], gx1[GI][8];
       if (ACT) {
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
+        for (int t = 0; t < GI; ++t) {
           const uint4 ra = *(const uint4 *)(Gidx + (ibase + t) * 8), rb = *(const uint4 *)(Gidx + (ibase + t) * 8 + 4);
           const uint32_t rr[8] = {ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, rb.z, rb.w};
 #pragma unroll
-          for (int u = 0; u < 8; ++u) { const float *row = w0t + (size_t)rr[u] * hidden; gx0[t][u] = row[cc0]; gx1[t][u] = row[cc1]; }
+          for (int u = 0; u < 8; ++u) {
+            const float *row = w0t + (size_t)rr[u] * hidden;
+            if (pair_ok && on1) { const float2 v = *(const float2 *)(row + c0); gx0[t][u] = v.x; gx1[t][u] = v.y; }
+            else { gx0[t][u] = row[cc0]; gx1[t][u] = row[cc1]; }
+          }
         }
       }
-      float h0[4], h1[4];
+      float h0[GI], h1[GI];
 #pragma unroll
-      for (int t = 0; t < 4; ++t) { h0[t] = bias0; h1[t] = bias1; }
-      uint32_t kmax = 12; // party slots: at most 12 features; actives: the longest of the four lists (<= 44)
+      for (int t = 0; t < GI; ++t) { h0[t] = bias0; h1[t] = bias1; }
+      uint32_t kmax = 12; // party slots: at most 12 features; actives: the longest of the group's lists (<= 44)
       if (ACT) {
         kmax = 0;
 #pragma unroll
-        for (int t = 0; t < 4; ++t) { const uint32_t c = __builtin_amdgcn_readfirstlane(meta[ibase + t]) & 0xFF; kmax = c > kmax ? c : kmax; }
+        for (int t = 0; t < GI; ++t) { const uint32_t c = __builtin_amdgcn_readfirstlane(meta[ibase + t]) & 0xFF; kmax = c > kmax ? c : kmax; }
       }
 #pragma unroll 1
       for (uint32_t k = 0; k < kmax; k += 4) {
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
+        for (int t = 0; t < GI; ++t) {
           const uint4 iv = *(const uint4 *)(Lidx + (ibase + t) * L::LCAP + k);
           const float4 vv = *(const float4 *)(Lval + (ibase + t) * L::LCAP + k);
-          h0[t] = fmaf(W0s[iv.x + c0], vv.x, h0[t]); h1[t] = fmaf(W0s[iv.x + c1], vv.x, h1[t]);
-          h0[t] = fmaf(W0s[iv.y + c0], vv.y, h0[t]); h1[t] = fmaf(W0s[iv.y + c1], vv.y, h1[t]);
-          h0[t] = fmaf(W0s[iv.z + c0], vv.z, h0[t]); h1[t] = fmaf(W0s[iv.z + c1], vv.z, h1[t]);
-          h0[t] = fmaf(W0s[iv.w + c0], vv.w, h0[t]); h1[t] = fmaf(W0s[iv.w + c1], vv.w, h1[t]);
+          const float2 wx = *(const float2 *)(W0s + iv.x + c0), wy = *(const float2 *)(W0s + iv.y + c0);
+          const float2 wz = *(const float2 *)(W0s + iv.z + c0), ww = *(const float2 *)(W0s + iv.w + c0);
+          h0[t] = fmaf(wx.x, vv.x, h0[t]); h1[t] = fmaf(wx.y, vv.x, h1[t]);
+          h0[t] = fmaf(wy.x, vv.y, h0[t]); h1[t] = fmaf(wy.y, vv.y, h1[t]);
+          h0[t] = fmaf(wz.x, vv.z, h0[t]); h1[t] = fmaf(wz.y, vv.z, h1[t]);
+          h0[t] = fmaf(ww.x, vv.w, h0[t]); h1[t] = fmaf(ww.y, vv.w, h1[t]);
         }
       }
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
+      for (int t = 0; t < GI; ++t) {
         const uint32_t i = ibase + t;
         if (ACT) {
           const uint32_t nG = __builtin_amdgcn_readfirstlane(meta[i]) >> 8;
@@ -525,7 +551,15 @@ __global__ __launch_bounds__(EL_BLOCK) void k_embed_lds(EmbedTileArgs a) {
         hrow[c1] = (on1 && live) ? act_fn(h1[t], N.activation) : 0.0f;
       }
     }
+    EL_MARK(4);
     __syncthreads();
+    EL_MARK(5);
+    // Every wave is done with this tile's battles: stage the NEXT tile's (prefetched at least one whole phase 1 ago,
+    // so the wait is short -- and it is a wait on loads only: placed after the scatter stores below, the same
+    // s_waitcnt vmcnt(0) would also sit out this tile's stores) and start fetching the one after.
+    stage();
+    prefetch(tile + 2 * gridDim.x);
+    EL_MARK(1);
     // ---- phase 2: OUT[64][out_pad] = H[64][128] . W1^T on fp32 MFMA (one 32x32 block per wave) ----
     if (mfma_wave) {
       f32x16 acc;
@@ -534,6 +568,7 @@ __global__ __launch_bounds__(EL_BLOCK) void k_embed_lds(EmbedTileArgs a) {
       const float *arow = Hs + (mi * 32 + r32) * EHP + hh;
 #pragma unroll
       for (int s2 = 0; s2 < 64; ++s2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(arow[2 * s2], bfrag[s2], acc, 0, 0, 0);
+      EL_MARK(6);
       // ---- phase 3: bias + activation + scatter ----
       const int o = nb * 32 + r32;
 #pragma unroll
@@ -544,7 +579,9 @@ __global__ __launch_bounds__(EL_BLOCK) void k_embed_lds(EmbedTileArgs a) {
       }
     }
     if (threadIdx.x < ET && dst_off[threadIdx.x] != 0xFFFFFFFFu) a.emb[dst_off[threadIdx.x]] = hp_ratio[threadIdx.x];
+    EL_MARK(7);
   }
+  EL_FLUSH();
 }
 
 // ---- K3: main net on fp32 MFMA ------------------------------------------------------------------
@@ -1022,6 +1059,14 @@ static int leaf_eval_impl(oakgpu_ctx *ctx, oakgpu_net *net, const uint8_t *battl
   if (e != hipSuccess) return oakgpu_fail_hip((int)e, "leaf_eval launch");
   return 0;
 }
+
+#ifdef OAKGPU_LEAF_PROFILE
+int oakgpu_leaf_profile(unsigned long long *out, int reset) { // profile build only
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(oak::g_leaf_prof), sizeof(unsigned long long) * 16) != hipSuccess) return 1;
+  if (reset) { unsigned long long z[16] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(oak::g_leaf_prof), z, sizeof z) != hipSuccess) return 1; }
+  return 0;
+}
+#endif
 
 int oakgpu_leaf_eval_dev(oakgpu_ctx *ctx, oakgpu_net *net, const uint8_t *battles, const uint8_t *durations, uint32_t n,
                          float *values, float *embedding_out) {
