@@ -3,7 +3,7 @@
 set -e
 cd "$GRAFT_REPO_ROOT"; export TMPDIR=/tmp
 rm -rf gpurun_out/pmcv; mkdir -p gpurun_out/pmcv
-rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_LDS --kernel-trace --output-format csv -d gpurun_out/pmcv/a -- python3 tests/gpu_exp3.py 1000 > gpurun_out/pmcv/a.log 2>&1
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_LDS --kernel-trace --output-format csv -d gpurun_out/pmcv/a -- python3 tools/launch_caps.py 1000 > gpurun_out/pmcv/a.log 2>&1
 python3 - <<'PY'
 import csv, glob, collections
 f = glob.glob('gpurun_out/pmcv/a/**/*counter_collection.csv', recursive=True)[0]
