@@ -16,13 +16,13 @@
 // No battle arithmetic happens on the host: every state transition and evaluation above is a kernel launch.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <array>
 #include <chrono>
 #include <cmath>
-#include <deque>
-#include <map>
 #include <vector>
 
 #include "../../include/oakgpu.h"
@@ -56,11 +56,52 @@ struct Bandit { // UCB::Bandit / PUCB::Bandit (bandit/ucb.h:17-66, pucb.h:17-75)
   }
 };
 
-using Key = std::array<uint8_t, 18>; // p1 index, p2 index, observation (mcts.h:95-105)
-struct Node {
-  Bandit p1, p2;
-  std::map<Key, Node *> children;
-  bool is_init() const { return p1.is_init(); }
+// The tree.  The reference's Node owns a std::map<(i, j, Obs), Node> (mcts.h:95-105); nearly every iteration adds a
+// node (81 joint actions x the observation fan-out), so here nodes are indices into flat arrays and ALL edges live in
+// one open-addressing hash table keyed (parent, i, j, 16-byte observation): no per-node allocation, one probe per edge.
+struct Stats { Bandit p1, p2; bool is_init() const { return p1.is_init(); } };
+struct Edge { uint64_t hash; uint32_t parent, child; uint8_t key[18]; uint8_t used; };
+struct Tree {
+  std::vector<Stats> nodes;
+  std::vector<Edge> table;
+  size_t count = 0;
+  Tree() : table(1u << 16) { memset(table.data(), 0, table.size() * sizeof(Edge)); }
+  static uint64_t hash_of(uint32_t parent, const uint8_t *key) {
+    uint64_t a, b;
+    uint16_t c;
+    memcpy(&a, key, 8); memcpy(&b, key + 8, 8); memcpy(&c, key + 16, 2);
+    uint64_t h = (a ^ (uint64_t)parent * 0x9E3779B97F4A7C15ull) * 0xBF58476D1CE4E5B9ull;
+    h = (h ^ (h >> 29) ^ b) * 0x94D049BB133111EBull;
+    h = (h ^ (h >> 32) ^ c) * 0x9E3779B97F4A7C15ull;
+    return h ^ (h >> 31);
+  }
+  uint32_t new_node() { nodes.emplace_back(); return (uint32_t)nodes.size() - 1; }
+  void grow() {
+    std::vector<Edge> old;
+    old.swap(table);
+    table.resize(old.size() * 2);
+    memset(table.data(), 0, table.size() * sizeof(Edge));
+    const size_t mask = table.size() - 1;
+    for (const Edge &e : old)
+      if (e.used) { size_t i = e.hash & mask; while (table[i].used) i = (i + 1) & mask; table[i] = e; }
+  }
+  // child of `parent` along (i, j, obs) = key; created (uninitialised) when absent -- heap.children[{i, j, obs}] (mcts.h:359-361)
+  uint32_t child(uint32_t parent, const uint8_t *key) {
+    if ((count + 1) * 10 > table.size() * 6) grow();
+    const uint64_t h = hash_of(parent, key);
+    const size_t mask = table.size() - 1;
+    size_t i = h & mask;
+    for (;; i = (i + 1) & mask) {
+      Edge &e = table[i];
+      if (!e.used) {
+        e.used = 1; e.hash = h; e.parent = parent; memcpy(e.key, key, 18);
+        e.child = new_node();
+        ++count;
+        return e.child;
+      }
+      if (e.hash == h && e.parent == parent && memcmp(e.key, key, 18) == 0) return e.child;
+    }
+  }
 };
 
 void softmax(float *out, const float *logits, int k) { // search/util/softmax.h
@@ -134,16 +175,15 @@ extern "C" int oakgpu_search(oakgpu_ctx *ctx, oakgpu_net *net, const uint8_t *ba
   memcpy(out->p2_choices, root_c2, 9);
   if ((result & 15) != 0 || m == 0 || n == 0) return oakgpu_fail_msg("oakgpu_search: the root position is terminal");
 
-  std::deque<Node> arena;
-  arena.emplace_back();
-  Node *root = &arena.back();
-  root->p1.init(m);
-  root->p2.init(n);
+  Tree tree;
+  const uint32_t root = tree.new_node();
+  tree.nodes[root].p1.init(m);
+  tree.nodes[root].p2.init(n);
   if (pucb) { // root priors from the policy heads (mcts.h:196-209)
     float v, l1[9], l2[9];
     RC(oakgpu_leaf_eval_policy(ctx, net, battle, durations, 1, root_c1, &m, root_c2, &n, &v, l1, l2));
-    softmax(root->p1.priors, l1, m);
-    softmax(root->p2.priors, l2, n);
+    softmax(tree.nodes[root].p1.priors, l1, m);
+    softmax(tree.nodes[root].p2.priors, l2, n);
     out->initial_value = v;
   }
 
@@ -182,11 +222,16 @@ extern "C" int oakgpu_search(oakgpu_ctx *ctx, oakgpu_net *net, const uint8_t *ba
     HIPRC(hipStreamSynchronize(stream));
   }
 
-  struct Step { Node *node; uint8_t i, j; };
+  constexpr uint32_t NO_NODE = 0xFFFFFFFFu;
+  struct Step { uint32_t node; uint8_t i, j; };
   std::vector<std::vector<Step>> path(B);
-  std::vector<Node *> cur(B), leaf(B);
+  std::vector<uint32_t> cur(B), leaf(B);
   std::vector<uint8_t> active(B);
   double total_value = 0;
+  const bool timing = getenv("OAKGPU_SEARCH_TIMING") != nullptr;
+  double t_sel = 0, t_gpu = 0, t_proc = 0, t_eval = 0, t_back = 0;
+  auto now = [] { return std::chrono::high_resolution_clock::now(); };
+  auto us = [](auto a, auto b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
   uint64_t done = 0, total_depth = 0;
 
   while (done < prm->iterations) {
@@ -194,19 +239,21 @@ extern "C" int oakgpu_search(oakgpu_ctx *ctx, oakgpu_net *net, const uint8_t *ba
     // root prep on the device (mcts.h:254-259): rollout kernel with max_steps = 0
     RC(oakgpu_rollout_dev(ctx, d_root_b, d_root_d, d_root_r, d_prng, nb, 0, 1, d_rout, d_steps, d_values, d_b, d_d));
     HIPRC(hipMemcpyAsync(d_r, d_root_r, nb, hipMemcpyDeviceToDevice, stream));
-    for (uint32_t l = 0; l < nb; ++l) { path[l].clear(); cur[l] = root; leaf[l] = nullptr; active[l] = 1; }
+    for (uint32_t l = 0; l < nb; ++l) { path[l].clear(); cur[l] = root; leaf[l] = NO_NODE; active[l] = 1; }
     uint32_t n_active = nb;
     for (uint32_t depth = 0; n_active > 0; ++depth) {
+      const auto ta = now();
       for (uint32_t l = 0; l < nb; ++l) { // bandit selection, sequential: each lane sees the virtual losses before it
         if (!active[l]) { h_c1[l] = 0xFF; h_c2[l] = 0xFF; continue; }
-        Node *nd = cur[l];
-        const uint8_t i = nd->p1.select(prm->ucb_c, pucb), j = nd->p2.select(prm->ucb_c, pucb);
-        ++nd->p1.visits[i];
-        ++nd->p2.visits[j];
-        path[l].push_back({nd, i, j});
+        Stats &nd = tree.nodes[cur[l]];
+        const uint8_t i = nd.p1.select(prm->ucb_c, pucb), j = nd.p2.select(prm->ucb_c, pucb);
+        ++nd.p1.visits[i];
+        ++nd.p2.visits[j];
+        path[l].push_back({cur[l], i, j});
         h_c1[l] = depth == 0 ? root_c1[i] : h_ch1[(size_t)l * 9 + i];
         h_c2[l] = depth == 0 ? root_c2[j] : h_ch2[(size_t)l * 9 + j];
       }
+      const auto tb = now();
       HIPRC(hipMemcpyAsync(d_c1, h_c1, nb, hipMemcpyHostToDevice, stream));
       HIPRC(hipMemcpyAsync(d_c2, h_c2, nb, hipMemcpyHostToDevice, stream));
       RC(oakgpu_tree_step_dev(ctx, d_b, d_d, d_r, d_c1, d_c2, nb, depth == 0 ? prm->root_rolls : prm->other_rolls, d_act, d_ch1,
@@ -218,23 +265,26 @@ extern "C" int oakgpu_search(oakgpu_ctx *ctx, oakgpu_net *net, const uint8_t *ba
       HIPRC(hipMemcpyAsync(h_ch2, d_ch2, (size_t)nb * 9, hipMemcpyDeviceToHost, stream));
       HIPRC(hipMemcpyAsync(h_cnt2, d_cnt2, nb, hipMemcpyDeviceToHost, stream));
       HIPRC(hipStreamSynchronize(stream));
+      const auto tc = now();
       for (uint32_t l = 0; l < nb; ++l) {
         if (!active[l]) continue;
         if ((h_r[l] & 15) != 0) { // terminal edge: the value comes from the result byte (mcts.h:427-441)
           active[l] = 0; --n_active; total_depth += depth + 1;
           continue;
         }
-        Key key;
+        uint8_t key[18];
         key[0] = path[l].back().i;
         key[1] = path[l].back().j;
-        memcpy(key.data() + 2, h_act + (size_t)l * 16, 16);
-        Node *&child = cur[l]->children[key];
-        if (!child) { arena.emplace_back(); child = &arena.back(); }
-        if (child->is_init() && depth + 1 < max_depth) { cur[l] = child; continue; }
+        memcpy(key + 2, h_act + (size_t)l * 16, 16);
+        const uint32_t child = tree.child(cur[l], key);
+        if (tree.nodes[child].is_init() && depth + 1 < max_depth) { cur[l] = child; continue; }
         leaf[l] = child; // first visit (or depth cap): evaluate here (mcts.h:391-426)
         active[l] = 0; --n_active; total_depth += depth + 1;
       }
+      const auto td = now();
+      t_sel += us(ta, tb); t_gpu += us(tb, tc); t_proc += us(tc, td);
     }
+    const auto te = now();
     // leaf evaluation, in place on the device
     if (use_pe) {
       RC(oakgpu_poke_engine_eval_dev(ctx, d_b, nb, pe_root, d_values, nullptr));
@@ -249,29 +299,32 @@ extern "C" int oakgpu_search(oakgpu_ctx *ctx, oakgpu_net *net, const uint8_t *ba
     }
     HIPRC(hipMemcpyAsync(h_values, d_values, (size_t)nb * 4, hipMemcpyDeviceToHost, stream));
     HIPRC(hipStreamSynchronize(stream));
+    const auto tf = now();
     for (uint32_t l = 0; l < nb; ++l) {
       float v1;
       const uint32_t t = h_r[l] & 15;
       if (t != 0) v1 = t == 1 ? 1.0f : t == 2 ? 0.0f : 0.5f;
       else v1 = h_values[l];
-      Node *lf = leaf[l];
-      if (lf && !lf->is_init() && h_cnt1[l] && h_cnt2[l]) { // stats.init(m, n) (+ priors) on the first evaluation
-        lf->p1.init(h_cnt1[l]);
-        lf->p2.init(h_cnt2[l]);
-        if (pucb) { softmax(lf->p1.priors, h_l1 + (size_t)l * 9, h_cnt1[l]); softmax(lf->p2.priors, h_l2 + (size_t)l * 9, h_cnt2[l]); }
+      if (leaf[l] != NO_NODE && !tree.nodes[leaf[l]].is_init() && h_cnt1[l] && h_cnt2[l]) { // stats.init(m, n) (+ priors), first evaluation
+        Stats &lf = tree.nodes[leaf[l]];
+        lf.p1.init(h_cnt1[l]);
+        lf.p2.init(h_cnt2[l]);
+        if (pucb) { softmax(lf.p1.priors, h_l1 + (size_t)l * 9, h_cnt1[l]); softmax(lf.p2.priors, h_l2 + (size_t)l * 9, h_cnt2[l]); }
       }
       const float v2 = 1.0f - v1;
       for (const Step &s : path[l]) { // Bandit::update, the visit was already counted as the virtual loss
-        s.node->p1.scores[s.i] += v1;
-        s.node->p2.scores[s.j] += v2;
+        tree.nodes[s.node].p1.scores[s.i] += v1;
+        tree.nodes[s.node].p2.scores[s.j] += v2;
       }
       const Step &s0 = path[l].front();
       ++out->visit_matrix[s0.i * 9 + s0.j];
       out->value_matrix[s0.i * 9 + s0.j] += v1;
       total_value += v1;
     }
+    t_eval += us(te, tf); t_back += us(tf, now());
     done += nb;
   }
+  if (timing) fprintf(stderr, "oakgpu_search timing (ms): select %.1f  gpu-step %.1f  process %.1f  eval %.1f  backprop %.1f\n", t_sel / 1e3, t_gpu / 1e3, t_proc / 1e3, t_eval / 1e3, t_back / 1e3);
   out->iterations = done;
   out->empirical_value = done ? total_value / (double)done : 0.0;
   for (int i = 0; i < m; ++i)
@@ -279,7 +332,7 @@ extern "C" int oakgpu_search(oakgpu_ctx *ctx, oakgpu_net *net, const uint8_t *ba
       out->p1_empirical[i] += (double)out->visit_matrix[i * 9 + j] / (double)done;
       out->p2_empirical[j] += (double)out->visit_matrix[i * 9 + j] / (double)done;
     }
-  out->nodes = arena.size();
+  out->nodes = tree.nodes.size();
   out->total_depth = total_depth;
   out->duration_us = std::chrono::duration<double, std::micro>(std::chrono::high_resolution_clock::now() - t_start).count();
   return 0;
