@@ -159,7 +159,6 @@ extern "C" int oakgpu_search(oakgpu_ctx *ctx, oakgpu_net *net, const uint8_t *ba
   auto rolls_ok = [](uint32_t r) { return r == 1 || r == 2 || r == 3 || r == 20 || r == 39; };
   if (!rolls_ok(prm->root_rolls) || !rolls_ok(prm->other_rolls)) return oakgpu_fail_msg("oakgpu_search: rolls must be 1, 2, 3, 20 or 39");
   HIPRC(hipSetDevice(oakgpu_ctx_device(ctx)));
-  hipStream_t stream = (hipStream_t)oakgpu_ctx_stream(ctx);
   const uint32_t B = prm->batch;
   const uint32_t max_depth = prm->max_depth ? prm->max_depth : 100;
   memset(out, 0, sizeof *out);
@@ -190,139 +189,179 @@ extern "C" int oakgpu_search(oakgpu_ctx *ctx, oakgpu_net *net, const uint8_t *ba
   float pe_root = 0.0f; // PokeEngine::Eval::get_root_score (mcts.h:172-174)
   if (use_pe) RC(oakgpu_poke_engine_eval(ctx, battle, 1, 0.0f, nullptr, &pe_root));
 
-  Buffers buf;
-  uint8_t *d_root_b, *d_root_d, *d_root_r, *d_b, *d_d, *d_r, *d_prng, *d_c1, *d_c2, *d_act, *d_ch1, *d_cnt1, *d_ch2, *d_cnt2, *d_rout;
-  uint32_t *d_steps;
-  float *d_values, *d_l1 = nullptr, *d_l2 = nullptr;
-  RC(buf.d(&d_root_b, (size_t)B * 384)); RC(buf.d(&d_root_d, (size_t)B * 8)); RC(buf.d(&d_root_r, (size_t)B));
-  RC(buf.d(&d_b, (size_t)B * 384)); RC(buf.d(&d_d, (size_t)B * 8)); RC(buf.d(&d_r, (size_t)B)); RC(buf.d(&d_prng, (size_t)B * 8));
-  RC(buf.d(&d_c1, (size_t)B)); RC(buf.d(&d_c2, (size_t)B)); RC(buf.d(&d_act, (size_t)B * 16));
-  RC(buf.d(&d_ch1, (size_t)B * 9)); RC(buf.d(&d_cnt1, (size_t)B)); RC(buf.d(&d_ch2, (size_t)B * 9)); RC(buf.d(&d_cnt2, (size_t)B));
-  RC(buf.d(&d_rout, (size_t)B)); RC(buf.d(&d_steps, (size_t)B)); RC(buf.d(&d_values, (size_t)B));
-  if (pucb) { RC(buf.d(&d_l1, (size_t)B * 9)); RC(buf.d(&d_l2, (size_t)B * 9)); }
-  uint8_t *h_c1, *h_c2, *h_r, *h_act, *h_ch1, *h_cnt1, *h_ch2, *h_cnt2, *h_stage;
-  float *h_values, *h_l1 = nullptr, *h_l2 = nullptr;
-  RC(buf.h(&h_c1, (size_t)B)); RC(buf.h(&h_c2, (size_t)B)); RC(buf.h(&h_r, (size_t)B)); RC(buf.h(&h_act, (size_t)B * 16));
-  RC(buf.h(&h_ch1, (size_t)B * 9)); RC(buf.h(&h_cnt1, (size_t)B)); RC(buf.h(&h_ch2, (size_t)B * 9)); RC(buf.h(&h_cnt2, (size_t)B));
-  RC(buf.h(&h_values, (size_t)B)); RC(buf.h(&h_stage, (size_t)B * 384));
-  if (pucb) { RC(buf.h(&h_l1, (size_t)B * 9)); RC(buf.h(&h_l2, (size_t)B * 9)); }
-
-  // root template: B copies of the input; one fast_prng stream per lane (util/random.h:67-133), never all-zero
-  for (uint32_t l = 0; l < B; ++l) memcpy(h_stage + (size_t)l * 384, battle, 384);
-  HIPRC(hipMemcpyAsync(d_root_b, h_stage, (size_t)B * 384, hipMemcpyHostToDevice, stream));
-  HIPRC(hipStreamSynchronize(stream));
-  for (uint32_t l = 0; l < B; ++l) memcpy(h_stage + (size_t)l * 8, durations, 8);
-  HIPRC(hipMemcpyAsync(d_root_d, h_stage, (size_t)B * 8, hipMemcpyHostToDevice, stream));
-  HIPRC(hipStreamSynchronize(stream));
-  {
-    uint64_t sm = prm->seed;
-    for (uint32_t l = 0; l < B; ++l) { uint64_t s = splitmix64(sm) | 1; memcpy(h_stage + (size_t)l * 8, &s, 8); }
-    HIPRC(hipMemcpyAsync(d_prng, h_stage, (size_t)B * 8, hipMemcpyHostToDevice, stream));
-    HIPRC(hipMemsetAsync(d_root_r, result, B, stream));
-    HIPRC(hipStreamSynchronize(stream));
+  // Two batches are kept in flight ("slots", each with its own context = HIP stream and buffers): while the GPU
+  // evaluates the leaves of one batch (rollouts: milliseconds), the host walks the tree for the other.  The schedule
+  // is fixed (A descends, B descends, A finishes, A descends, B finishes, ...), so a search is reproducible.
+  struct Step { uint32_t node; uint8_t i, j; };
+  constexpr uint32_t NO_NODE = 0xFFFFFFFFu;
+  struct Slot {
+    oakgpu_ctx *ctx = nullptr;
+    bool own_ctx = false;
+    hipStream_t stream{};
+    Buffers buf;
+    uint8_t *d_root_b, *d_root_d, *d_root_r, *d_b, *d_d, *d_r, *d_prng, *d_c1, *d_c2, *d_act, *d_ch1, *d_cnt1, *d_ch2, *d_cnt2, *d_rout;
+    uint32_t *d_steps;
+    float *d_values, *d_l1 = nullptr, *d_l2 = nullptr, *d_emb = nullptr;
+    uint8_t *h_c1, *h_c2, *h_r, *h_act, *h_ch1, *h_cnt1, *h_ch2, *h_cnt2, *h_stage;
+    float *h_values, *h_l1 = nullptr, *h_l2 = nullptr;
+    std::vector<std::vector<Step>> path;
+    std::vector<uint32_t> cur, leaf;
+    std::vector<uint8_t> active;
+    uint32_t nb = 0;
+    bool busy = false;
+    ~Slot() { if (own_ctx && ctx) oakgpu_destroy(ctx); }
+  };
+  const int n_slots = (!pucb && prm->iterations > B) ? 2 : 1; // PUCB shares the network's policy workspace: one batch at a time
+  Slot slots[2];
+  for (int si = 0; si < n_slots; ++si) {
+    Slot &S = slots[si];
+    if (si == 0) S.ctx = ctx;
+    else { RC(oakgpu_create(&S.ctx, oakgpu_ctx_device(ctx))); S.own_ctx = true; }
+    S.stream = (hipStream_t)oakgpu_ctx_stream(S.ctx);
+    Buffers &buf = S.buf;
+    RC(buf.d(&S.d_root_b, (size_t)B * 384)); RC(buf.d(&S.d_root_d, (size_t)B * 8)); RC(buf.d(&S.d_root_r, (size_t)B));
+    RC(buf.d(&S.d_b, (size_t)B * 384)); RC(buf.d(&S.d_d, (size_t)B * 8)); RC(buf.d(&S.d_r, (size_t)B)); RC(buf.d(&S.d_prng, (size_t)B * 8));
+    RC(buf.d(&S.d_c1, (size_t)B)); RC(buf.d(&S.d_c2, (size_t)B)); RC(buf.d(&S.d_act, (size_t)B * 16));
+    RC(buf.d(&S.d_ch1, (size_t)B * 9)); RC(buf.d(&S.d_cnt1, (size_t)B)); RC(buf.d(&S.d_ch2, (size_t)B * 9)); RC(buf.d(&S.d_cnt2, (size_t)B));
+    RC(buf.d(&S.d_rout, (size_t)B)); RC(buf.d(&S.d_steps, (size_t)B)); RC(buf.d(&S.d_values, (size_t)B));
+    if (pucb) { RC(buf.d(&S.d_l1, (size_t)B * 9)); RC(buf.d(&S.d_l2, (size_t)B * 9)); }
+    if (use_net && n_slots > 1) { // per-slot embedding buffer: the network's own workspace serves one stream at a time
+      int emb_dim = 0;
+      RC(oakgpu_net_shape(net, &emb_dim, nullptr, nullptr, nullptr));
+      RC(buf.d(&S.d_emb, (size_t)B * emb_dim));
+    }
+    RC(buf.h(&S.h_c1, (size_t)B)); RC(buf.h(&S.h_c2, (size_t)B)); RC(buf.h(&S.h_r, (size_t)B)); RC(buf.h(&S.h_act, (size_t)B * 16));
+    RC(buf.h(&S.h_ch1, (size_t)B * 9)); RC(buf.h(&S.h_cnt1, (size_t)B)); RC(buf.h(&S.h_ch2, (size_t)B * 9)); RC(buf.h(&S.h_cnt2, (size_t)B));
+    RC(buf.h(&S.h_values, (size_t)B)); RC(buf.h(&S.h_stage, (size_t)B * 384));
+    if (pucb) { RC(buf.h(&S.h_l1, (size_t)B * 9)); RC(buf.h(&S.h_l2, (size_t)B * 9)); }
+    // root template: B copies of the input; one fast_prng stream per lane (util/random.h:67-133), never all-zero
+    for (uint32_t l = 0; l < B; ++l) memcpy(S.h_stage + (size_t)l * 384, battle, 384);
+    HIPRC(hipMemcpyAsync(S.d_root_b, S.h_stage, (size_t)B * 384, hipMemcpyHostToDevice, S.stream));
+    HIPRC(hipStreamSynchronize(S.stream));
+    for (uint32_t l = 0; l < B; ++l) memcpy(S.h_stage + (size_t)l * 8, durations, 8);
+    HIPRC(hipMemcpyAsync(S.d_root_d, S.h_stage, (size_t)B * 8, hipMemcpyHostToDevice, S.stream));
+    HIPRC(hipStreamSynchronize(S.stream));
+    uint64_t sm = prm->seed + 0x632BE59BD9B4E019ull * (uint64_t)si;
+    for (uint32_t l = 0; l < B; ++l) { uint64_t x = splitmix64(sm) | 1; memcpy(S.h_stage + (size_t)l * 8, &x, 8); }
+    HIPRC(hipMemcpyAsync(S.d_prng, S.h_stage, (size_t)B * 8, hipMemcpyHostToDevice, S.stream));
+    HIPRC(hipMemsetAsync(S.d_root_r, result, B, S.stream));
+    HIPRC(hipStreamSynchronize(S.stream));
+    S.path.resize(B); S.cur.resize(B); S.leaf.resize(B); S.active.resize(B);
   }
 
-  constexpr uint32_t NO_NODE = 0xFFFFFFFFu;
-  struct Step { uint32_t node; uint8_t i, j; };
-  std::vector<std::vector<Step>> path(B);
-  std::vector<uint32_t> cur(B), leaf(B);
-  std::vector<uint8_t> active(B);
   double total_value = 0;
   const bool timing = getenv("OAKGPU_SEARCH_TIMING") != nullptr;
   double t_sel = 0, t_gpu = 0, t_proc = 0, t_eval = 0, t_back = 0;
   auto now = [] { return std::chrono::high_resolution_clock::now(); };
   auto us = [](auto a, auto b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
-  uint64_t done = 0, total_depth = 0;
+  uint64_t done = 0, started = 0, total_depth = 0;
 
-  while (done < prm->iterations) {
-    const uint32_t nb = (uint32_t)std::min<uint64_t>(B, prm->iterations - done);
+  // one batch: root prep, level-synchronous descent (host selection <-> k_tree_step), then the leaf evaluation is
+  // LAUNCHED (not awaited)
+  auto descend = [&](Slot &S) -> int {
+    const uint32_t nb = (uint32_t)std::min<uint64_t>(B, prm->iterations - started);
+    S.nb = nb;
+    started += nb;
+    S.busy = true;
     // root prep on the device (mcts.h:254-259): rollout kernel with max_steps = 0
-    RC(oakgpu_rollout_dev(ctx, d_root_b, d_root_d, d_root_r, d_prng, nb, 0, 1, d_rout, d_steps, d_values, d_b, d_d));
-    HIPRC(hipMemcpyAsync(d_r, d_root_r, nb, hipMemcpyDeviceToDevice, stream));
-    for (uint32_t l = 0; l < nb; ++l) { path[l].clear(); cur[l] = root; leaf[l] = NO_NODE; active[l] = 1; }
+    RC(oakgpu_rollout_dev(S.ctx, S.d_root_b, S.d_root_d, S.d_root_r, S.d_prng, nb, 0, 1, S.d_rout, S.d_steps, S.d_values, S.d_b, S.d_d));
+    HIPRC(hipMemcpyAsync(S.d_r, S.d_root_r, nb, hipMemcpyDeviceToDevice, S.stream));
+    for (uint32_t l = 0; l < nb; ++l) { S.path[l].clear(); S.cur[l] = root; S.leaf[l] = NO_NODE; S.active[l] = 1; }
     uint32_t n_active = nb;
     for (uint32_t depth = 0; n_active > 0; ++depth) {
       const auto ta = now();
       for (uint32_t l = 0; l < nb; ++l) { // bandit selection, sequential: each lane sees the virtual losses before it
-        if (!active[l]) { h_c1[l] = 0xFF; h_c2[l] = 0xFF; continue; }
-        Stats &nd = tree.nodes[cur[l]];
+        if (!S.active[l]) { S.h_c1[l] = 0xFF; S.h_c2[l] = 0xFF; continue; }
+        Stats &nd = tree.nodes[S.cur[l]];
         const uint8_t i = nd.p1.select(prm->ucb_c, pucb), j = nd.p2.select(prm->ucb_c, pucb);
         ++nd.p1.visits[i];
         ++nd.p2.visits[j];
-        path[l].push_back({cur[l], i, j});
-        h_c1[l] = depth == 0 ? root_c1[i] : h_ch1[(size_t)l * 9 + i];
-        h_c2[l] = depth == 0 ? root_c2[j] : h_ch2[(size_t)l * 9 + j];
+        S.path[l].push_back({S.cur[l], i, j});
+        S.h_c1[l] = depth == 0 ? root_c1[i] : S.h_ch1[(size_t)l * 9 + i];
+        S.h_c2[l] = depth == 0 ? root_c2[j] : S.h_ch2[(size_t)l * 9 + j];
       }
       const auto tb = now();
-      HIPRC(hipMemcpyAsync(d_c1, h_c1, nb, hipMemcpyHostToDevice, stream));
-      HIPRC(hipMemcpyAsync(d_c2, h_c2, nb, hipMemcpyHostToDevice, stream));
-      RC(oakgpu_tree_step_dev(ctx, d_b, d_d, d_r, d_c1, d_c2, nb, depth == 0 ? prm->root_rolls : prm->other_rolls, d_act, d_ch1,
-                              d_cnt1, d_ch2, d_cnt2));
-      HIPRC(hipMemcpyAsync(h_r, d_r, nb, hipMemcpyDeviceToHost, stream));
-      HIPRC(hipMemcpyAsync(h_act, d_act, (size_t)nb * 16, hipMemcpyDeviceToHost, stream));
-      HIPRC(hipMemcpyAsync(h_ch1, d_ch1, (size_t)nb * 9, hipMemcpyDeviceToHost, stream));
-      HIPRC(hipMemcpyAsync(h_cnt1, d_cnt1, nb, hipMemcpyDeviceToHost, stream));
-      HIPRC(hipMemcpyAsync(h_ch2, d_ch2, (size_t)nb * 9, hipMemcpyDeviceToHost, stream));
-      HIPRC(hipMemcpyAsync(h_cnt2, d_cnt2, nb, hipMemcpyDeviceToHost, stream));
-      HIPRC(hipStreamSynchronize(stream));
+      HIPRC(hipMemcpyAsync(S.d_c1, S.h_c1, nb, hipMemcpyHostToDevice, S.stream));
+      HIPRC(hipMemcpyAsync(S.d_c2, S.h_c2, nb, hipMemcpyHostToDevice, S.stream));
+      RC(oakgpu_tree_step_dev(S.ctx, S.d_b, S.d_d, S.d_r, S.d_c1, S.d_c2, nb, depth == 0 ? prm->root_rolls : prm->other_rolls, S.d_act,
+                              S.d_ch1, S.d_cnt1, S.d_ch2, S.d_cnt2));
+      HIPRC(hipMemcpyAsync(S.h_r, S.d_r, nb, hipMemcpyDeviceToHost, S.stream));
+      HIPRC(hipMemcpyAsync(S.h_act, S.d_act, (size_t)nb * 16, hipMemcpyDeviceToHost, S.stream));
+      HIPRC(hipMemcpyAsync(S.h_ch1, S.d_ch1, (size_t)nb * 9, hipMemcpyDeviceToHost, S.stream));
+      HIPRC(hipMemcpyAsync(S.h_cnt1, S.d_cnt1, nb, hipMemcpyDeviceToHost, S.stream));
+      HIPRC(hipMemcpyAsync(S.h_ch2, S.d_ch2, (size_t)nb * 9, hipMemcpyDeviceToHost, S.stream));
+      HIPRC(hipMemcpyAsync(S.h_cnt2, S.d_cnt2, nb, hipMemcpyDeviceToHost, S.stream));
+      HIPRC(hipStreamSynchronize(S.stream));
       const auto tc = now();
       for (uint32_t l = 0; l < nb; ++l) {
-        if (!active[l]) continue;
-        if ((h_r[l] & 15) != 0) { // terminal edge: the value comes from the result byte (mcts.h:427-441)
-          active[l] = 0; --n_active; total_depth += depth + 1;
+        if (!S.active[l]) continue;
+        if ((S.h_r[l] & 15) != 0) { // terminal edge: the value comes from the result byte (mcts.h:427-441)
+          S.active[l] = 0; --n_active; total_depth += depth + 1;
           continue;
         }
         uint8_t key[18];
-        key[0] = path[l].back().i;
-        key[1] = path[l].back().j;
-        memcpy(key + 2, h_act + (size_t)l * 16, 16);
-        const uint32_t child = tree.child(cur[l], key);
-        if (tree.nodes[child].is_init() && depth + 1 < max_depth) { cur[l] = child; continue; }
-        leaf[l] = child; // first visit (or depth cap): evaluate here (mcts.h:391-426)
-        active[l] = 0; --n_active; total_depth += depth + 1;
+        key[0] = S.path[l].back().i;
+        key[1] = S.path[l].back().j;
+        memcpy(key + 2, S.h_act + (size_t)l * 16, 16);
+        const uint32_t child = tree.child(S.cur[l], key);
+        if (tree.nodes[child].is_init() && depth + 1 < max_depth) { S.cur[l] = child; continue; }
+        S.leaf[l] = child; // first visit (or depth cap): evaluate here (mcts.h:391-426)
+        S.active[l] = 0; --n_active; total_depth += depth + 1;
       }
       const auto td = now();
       t_sel += us(ta, tb); t_gpu += us(tb, tc); t_proc += us(tc, td);
     }
-    const auto te = now();
-    // leaf evaluation, in place on the device
+    // leaf evaluation, in place on the device; results are collected by finish()
     if (use_pe) {
-      RC(oakgpu_poke_engine_eval_dev(ctx, d_b, nb, pe_root, d_values, nullptr));
+      RC(oakgpu_poke_engine_eval_dev(S.ctx, S.d_b, nb, pe_root, S.d_values, nullptr));
     } else if (!use_net) {
-      RC(oakgpu_rollout_dev(ctx, d_b, d_d, d_r, d_prng, nb, 1000, 0, d_rout, d_steps, d_values, nullptr, nullptr));
+      RC(oakgpu_rollout_dev(S.ctx, S.d_b, S.d_d, S.d_r, S.d_prng, nb, 1000, 0, S.d_rout, S.d_steps, S.d_values, nullptr, nullptr));
     } else if (pucb) {
-      RC(oakgpu_leaf_eval_policy_dev(ctx, net, d_b, d_d, nb, d_ch1, d_cnt1, d_ch2, d_cnt2, d_values, d_l1, d_l2));
-      HIPRC(hipMemcpyAsync(h_l1, d_l1, (size_t)nb * 9 * 4, hipMemcpyDeviceToHost, stream));
-      HIPRC(hipMemcpyAsync(h_l2, d_l2, (size_t)nb * 9 * 4, hipMemcpyDeviceToHost, stream));
+      RC(oakgpu_leaf_eval_policy_dev(S.ctx, net, S.d_b, S.d_d, nb, S.d_ch1, S.d_cnt1, S.d_ch2, S.d_cnt2, S.d_values, S.d_l1, S.d_l2));
+      HIPRC(hipMemcpyAsync(S.h_l1, S.d_l1, (size_t)nb * 9 * 4, hipMemcpyDeviceToHost, S.stream));
+      HIPRC(hipMemcpyAsync(S.h_l2, S.d_l2, (size_t)nb * 9 * 4, hipMemcpyDeviceToHost, S.stream));
     } else {
-      RC(oakgpu_leaf_eval_dev(ctx, net, d_b, d_d, nb, d_values, nullptr));
+      RC(oakgpu_leaf_eval_dev(S.ctx, net, S.d_b, S.d_d, nb, S.d_values, S.d_emb));
     }
-    HIPRC(hipMemcpyAsync(h_values, d_values, (size_t)nb * 4, hipMemcpyDeviceToHost, stream));
-    HIPRC(hipStreamSynchronize(stream));
+    HIPRC(hipMemcpyAsync(S.h_values, S.d_values, (size_t)nb * 4, hipMemcpyDeviceToHost, S.stream));
+    return 0;
+  };
+  // wait for the batch's leaf values, initialise its new leaves and back the values up its paths
+  auto finish = [&](Slot &S) -> int {
+    const auto te = now();
+    HIPRC(hipStreamSynchronize(S.stream));
     const auto tf = now();
+    const uint32_t nb = S.nb;
     for (uint32_t l = 0; l < nb; ++l) {
       float v1;
-      const uint32_t t = h_r[l] & 15;
+      const uint32_t t = S.h_r[l] & 15;
       if (t != 0) v1 = t == 1 ? 1.0f : t == 2 ? 0.0f : 0.5f;
-      else v1 = h_values[l];
-      if (leaf[l] != NO_NODE && !tree.nodes[leaf[l]].is_init() && h_cnt1[l] && h_cnt2[l]) { // stats.init(m, n) (+ priors), first evaluation
-        Stats &lf = tree.nodes[leaf[l]];
-        lf.p1.init(h_cnt1[l]);
-        lf.p2.init(h_cnt2[l]);
-        if (pucb) { softmax(lf.p1.priors, h_l1 + (size_t)l * 9, h_cnt1[l]); softmax(lf.p2.priors, h_l2 + (size_t)l * 9, h_cnt2[l]); }
+      else v1 = S.h_values[l];
+      if (S.leaf[l] != NO_NODE && !tree.nodes[S.leaf[l]].is_init() && S.h_cnt1[l] && S.h_cnt2[l]) { // stats.init(m, n) (+ priors), first evaluation
+        Stats &lf = tree.nodes[S.leaf[l]];
+        lf.p1.init(S.h_cnt1[l]);
+        lf.p2.init(S.h_cnt2[l]);
+        if (pucb) { softmax(lf.p1.priors, S.h_l1 + (size_t)l * 9, S.h_cnt1[l]); softmax(lf.p2.priors, S.h_l2 + (size_t)l * 9, S.h_cnt2[l]); }
       }
       const float v2 = 1.0f - v1;
-      for (const Step &s : path[l]) { // Bandit::update, the visit was already counted as the virtual loss
-        tree.nodes[s.node].p1.scores[s.i] += v1;
-        tree.nodes[s.node].p2.scores[s.j] += v2;
+      for (const Step &st : S.path[l]) { // Bandit::update, the visit was already counted as the virtual loss
+        tree.nodes[st.node].p1.scores[st.i] += v1;
+        tree.nodes[st.node].p2.scores[st.j] += v2;
       }
-      const Step &s0 = path[l].front();
+      const Step &s0 = S.path[l].front();
       ++out->visit_matrix[s0.i * 9 + s0.j];
       out->value_matrix[s0.i * 9 + s0.j] += v1;
       total_value += v1;
     }
     t_eval += us(te, tf); t_back += us(tf, now());
     done += nb;
+    S.busy = false;
+    return 0;
+  };
+  for (int turn = 0; started < prm->iterations || slots[0].busy || slots[1].busy; turn = (turn + 1) % n_slots) {
+    Slot &S = slots[turn];
+    if (S.busy) RC(finish(S));
+    if (started < prm->iterations) RC(descend(S));
   }
   if (timing) fprintf(stderr, "oakgpu_search timing (ms): select %.1f  gpu-step %.1f  process %.1f  eval %.1f  backprop %.1f\n", t_sel / 1e3, t_gpu / 1e3, t_proc / 1e3, t_eval / 1e3, t_back / 1e3);
   out->iterations = done;
