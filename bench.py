@@ -16,8 +16,9 @@ strictly serial latency figure quoted in DESIGN.md.
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 N > 1: one process per GPU, lanes sharded by rank (weak scaling: 65,536 playouts per GPU,
-disjoint seeds), and every step ends with the path's single exchange: one RCCL all-gather of
-the fp32 leaf values (256 KiB per rank) back to every root.
+disjoint seeds); the path's single exchange is an RCCL all-gather of the fp32 leaf values
+(256 KiB per batch and rank) back to every root, issued as ONE collective per round of
+`--streams` batches on its own stream (class Exchange below).
 
 Prints ONE JSON line (rank 0).  `roofline` prices the rollout kernel against the HBM roof with
 the ALGORITHMIC bytes of SURVEY 8(d): 802 B per turn-step (401 read + 401 written of per-lane
@@ -122,9 +123,62 @@ def main():
         def finish(self):
             with torch.cuda.stream(self.stream):
                 self.total += self.steps_out.sum(dtype=torch.int64)   # tiny reduction kernel, inside the timed region
-                if world > 1 or force_dist:   # the path's single exchange: one RCCL all-gather of the fp32 leaf values
-                    self.gathered = oakdist.gather_values(self.values, n * world, force=force_dist)
+                if world > 1 or force_dist:
+                    exchange.add(self)
 
+    class Exchange:
+        """The path's single exchange: an RCCL all-gather of fp32 leaf values to every rank.  One collective carries the
+        values of ALL batches in flight (S x 256 KiB per rank: fewer, larger collectives): every batch copies its values
+        into its row of a staging buffer on its own stream, and when the last row of a round has been issued one
+        all-gather runs on a separate stream behind those copies.  Nothing waits for it but the end of the run -- a
+        batch stream that waited for a collective would wait for every earlier batch's rollout too (a process group's
+        collectives execute in issue order), the 20 batches would fall into lock-step and their tails would stop
+        overlapping; and a collective kernel launched once per batch has to squeeze into a saturated GPU 1,300 times a
+        second."""
+
+        def __init__(self):
+            self.stream = torch.cuda.Stream(device=dev)
+            self.ring = [(torch.empty((S, n), dtype=torch.float32, device=dev),
+                          torch.empty((world, S, n), dtype=torch.float32, device=dev)) for _ in range(3)]
+            self.works = [None, None, None]
+            self.round, self.filled, self.events = 0, 0, []
+            with torch.cuda.stream(self.stream):     # first use of a buffer pair by the collective library is slow
+                for stage, out in self.ring:        # (registration): pay it here, not in the timed region
+                    dist.all_gather_into_tensor(out.view(-1), stage.view(-1))
+            self.stream.synchronize()
+
+        def add(self, slot):            # called under the slot's stream context
+            stage, _ = self.ring[self.round % 3]
+            if self.filled == 0 and self.works[self.round % 3] is not None:
+                self.works[self.round % 3].wait()      # three rounds old: long finished
+            stage[self.filled].copy_(slot.values)
+            ev = torch.cuda.Event()
+            ev.record(slot.stream)
+            self.events.append(ev)
+            self.filled += 1
+            if self.filled == S:
+                self.flush()
+
+        def flush(self):
+            if self.filled == 0:
+                return
+            stage, out = self.ring[self.round % 3]
+            for ev in self.events:
+                self.stream.wait_event(ev)
+            with torch.cuda.stream(self.stream):
+                self.works[self.round % 3] = dist.all_gather_into_tensor(out.view(-1), stage.view(-1), async_op=True)
+            self.round += 1
+            self.filled, self.events = 0, []
+
+        def drain(self):
+            self.flush()
+            with torch.cuda.stream(self.stream):
+                for w in self.works:
+                    if w is not None:
+                        w.wait()
+            self.stream.synchronize()
+
+    exchange = Exchange() if (world > 1 or force_dist) else None
     slots = [Slot(i) for i in range(S)]
     torch.cuda.synchronize(dev)
     for sl in slots:   # loads torch's lazily-loaded reduce kernels up front
@@ -150,6 +204,8 @@ def main():
         sl.step()
         ev[k][1].record(sl.stream)
         sl.finish()
+    if exchange is not None:     # every gather of the timed region has completed before the clock stops
+        exchange.drain()
     torch.cuda.synchronize(dev)
     if world > 1:
         dist.barrier()
@@ -201,7 +257,7 @@ def main():
                 "batch_per_gpu": n,
                 "playouts_per_s": n * world * args.steps / elapsed,
                 "mean_turn_steps_per_playout": all_steps / (n * world * args.steps),
-                "parallelism": ("lanes sharded by rank; 1 RCCL all-gather of fp32 leaf values per step" if world > 1
+                "parallelism": ("lanes sharded by rank; RCCL all-gather of the fp32 leaf values, one collective per %d batches in flight" % S if world > 1
                                 else "single GPU") + "; %d independent batches in flight on %d HIP streams" % (S, S),
                 "streams": S,
                 "playouts_per_lane": args.playouts_per_lane,
