@@ -127,6 +127,14 @@ typedef struct {
   uint32_t root_rolls;   /* SearchOptions.root_rolls / other_rolls (mcts.h:107-131): 1, 2, 3, 20 or 39 (= no clamping) */
   uint32_t other_rolls;
   uint64_t seed;         /* seeds the per-lane fast_prng streams (root resampling draws + rollouts) */
+  /* MatrixUCBParams (mcts.h:107-113, 263-302, 498-566): once `mucb_delay` iterations are done the ROOT joint action is no
+   * longer picked by the bandits but sampled from the Nash strategies of the optimistic / pessimistic UCB matrices
+   * (cells below `mucb_minimum` visits are forced first).  The matrices are re-solved once per batch (the reference's
+   * `interval` = batch here).  matrix_ucb = 0 disables it. */
+  int32_t matrix_ucb;
+  uint32_t mucb_delay;
+  uint32_t mucb_minimum;
+  float mucb_c;
 } oakgpu_search_params;
 typedef struct {
   uint8_t m, n;                 /* legal choices per side at the root */

@@ -112,6 +112,52 @@ void softmax(float *out, const float *logits, int k) { // search/util/softmax.h
   for (int i = 0; i < k; ++i) out[i] /= sum;
 }
 
+// Equilibrium of a zero-sum matrix game (row player maximises A[i][j], m, n <= 9) by the simplex method in doubles,
+// Bland's rule.  Used only to SAMPLE root actions for MatrixUCB (the reference solves the same matrices exactly with
+// lrsnash, mcts.h:532-543); the reported Nash value of a search is solved exactly by the caller (oak_amd/search.py).
+void solve_zero_sum(const double *A, int m, int n, double *x, double *y) {
+  double lo = A[0];
+  for (int i = 0; i < m * n; ++i) lo = A[i] < lo ? A[i] : lo;
+  const double shift = 1.0 - lo; // every entry >= 1
+  // column player: maximise sum z s.t. B z <= 1, z >= 0; y = z / sum z; the duals (slack reduced costs) give x
+  const int W = n + m + 1;
+  double T[9][9 + 9 + 1], z[9 + 9 + 1];
+  int basis[9];
+  for (int i = 0; i < m; ++i) {
+    for (int j = 0; j < n; ++j) T[i][j] = A[i * n + j] + shift;
+    for (int k = 0; k < m; ++k) T[i][n + k] = i == k ? 1.0 : 0.0;
+    T[i][W - 1] = 1.0;
+    basis[i] = n + i;
+  }
+  for (int j = 0; j < W; ++j) z[j] = j < n ? -1.0 : 0.0;
+  for (int iter = 0; iter < 1000; ++iter) {
+    int col = -1;
+    for (int j = 0; j < n + m; ++j) if (z[j] < -1e-12) { col = j; break; }
+    if (col < 0) break;
+    int row = -1;
+    double best = 0;
+    for (int i = 0; i < m; ++i)
+      if (T[i][col] > 1e-12) {
+        const double ratio = T[i][W - 1] / T[i][col];
+        if (row < 0 || ratio < best - 1e-15 || (ratio <= best + 1e-15 && basis[i] < basis[row])) { best = ratio; row = i; }
+      }
+    if (row < 0) break;
+    const double piv = T[row][col];
+    for (int j = 0; j < W; ++j) T[row][j] /= piv;
+    for (int i = 0; i < m; ++i)
+      if (i != row && T[i][col] != 0.0) { const double f = T[i][col]; for (int j = 0; j < W; ++j) T[i][j] -= f * T[row][j]; }
+    const double f = z[col];
+    for (int j = 0; j < W; ++j) z[j] -= f * T[row][j];
+    basis[row] = col;
+  }
+  double zs[9] = {}, sum_y = 0, sum_x = 0;
+  for (int i = 0; i < m; ++i) if (basis[i] < n) zs[basis[i]] = T[i][W - 1];
+  for (int j = 0; j < n; ++j) sum_y += zs[j];
+  for (int i = 0; i < m; ++i) sum_x += z[n + i] > 0 ? z[n + i] : 0;
+  for (int j = 0; j < n; ++j) y[j] = sum_y > 0 ? zs[j] / sum_y : 1.0 / n;
+  for (int i = 0; i < m; ++i) x[i] = sum_x > 0 ? (z[n + i] > 0 ? z[n + i] : 0) / sum_x : 1.0 / m;
+}
+
 uint64_t splitmix64(uint64_t &x) {
   uint64_t z = (x += 0x9E3779B97F4A7C15ull);
   z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
@@ -207,6 +253,8 @@ extern "C" int oakgpu_search(oakgpu_ctx *ctx, oakgpu_net *net, const uint8_t *ba
     std::vector<std::vector<Step>> path;
     std::vector<uint32_t> cur, leaf;
     std::vector<uint8_t> active;
+    std::vector<uint8_t> forced;
+    double nash1[9], nash2[9];
     uint32_t nb = 0;
     bool busy = false;
     ~Slot() { if (own_ctx && ctx) oakgpu_destroy(ctx); }
@@ -255,6 +303,7 @@ extern "C" int oakgpu_search(oakgpu_ctx *ctx, oakgpu_net *net, const uint8_t *ba
   auto now = [] { return std::chrono::high_resolution_clock::now(); };
   auto us = [](auto a, auto b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
   uint64_t done = 0, started = 0, total_depth = 0;
+  uint64_t mucb_rng = prm->seed ^ 0xA0761D6478BD642Full;
 
   // one batch: root prep, level-synchronous descent (host selection <-> k_tree_step), then the leaf evaluation is
   // LAUNCHED (not awaited)
@@ -268,15 +317,56 @@ extern "C" int oakgpu_search(oakgpu_ctx *ctx, oakgpu_net *net, const uint8_t *ba
     HIPRC(hipMemcpyAsync(S.d_r, S.d_root_r, nb, hipMemcpyDeviceToDevice, S.stream));
     for (uint32_t l = 0; l < nb; ++l) { S.path[l].clear(); S.cur[l] = root; S.leaf[l] = NO_NODE; S.active[l] = 1; }
     uint32_t n_active = nb;
+    // MatrixUCB (mcts.h:263-302): the root's joint actions of this batch come from the UCB matrices, not the bandits
+    const bool mucb = prm->matrix_ucb && done >= prm->mucb_delay;
+    if (mucb) {
+      S.forced.clear();
+      uint64_t planned[81];
+      for (int q = 0; q < 81; ++q) planned[q] = out->visit_matrix[q];
+      for (int i = 0; i < m && S.forced.size() < nb; ++i) // cells under the minimum visit count go first (mcts.h:510-512)
+        for (int j = 0; j < n && S.forced.size() < nb; ++j)
+          while (planned[i * 9 + j] < prm->mucb_minimum && S.forced.size() < nb) { S.forced.push_back((uint8_t)(i * 9 + j)); ++planned[i * 9 + j]; }
+      if (S.forced.size() < nb) {
+        double up[81], dn[81];
+        const double log_T = std::log((double)(done ? done : 1)), w = std::log(2.0 * m * n);
+        for (int i = 0; i < m; ++i)
+          for (int j = 0; j < n; ++j) {
+            const uint64_t v = out->visit_matrix[i * 9 + j];
+            const double mean = v ? out->value_matrix[i * 9 + j] / (double)v : 0.0;
+            const double e = prm->mucb_c * std::sqrt(2.0 * (2.0 * log_T + w) / (double)(v + 1));
+            up[i * n + j] = std::floor(((v ? mean : 0.0) + e) * 256.0); // integer matrices x 256, like the reference's
+            dn[i * n + j] = std::floor(((v ? mean : 1.0) - e) * 256.0);
+          }
+        double dummy[9];
+        solve_zero_sum(up, m, n, S.nash1, dummy);
+        solve_zero_sum(dn, m, n, dummy, S.nash2);
+      }
+    }
     for (uint32_t depth = 0; n_active > 0; ++depth) {
       const auto ta = now();
       for (uint32_t l = 0; l < nb; ++l) { // bandit selection, sequential: each lane sees the virtual losses before it
         if (!S.active[l]) { S.h_c1[l] = 0xFF; S.h_c2[l] = 0xFF; continue; }
-        Stats &nd = tree.nodes[S.cur[l]];
-        const uint8_t i = nd.p1.select(prm->ucb_c, pucb), j = nd.p2.select(prm->ucb_c, pucb);
-        ++nd.p1.visits[i];
-        ++nd.p2.visits[j];
-        S.path[l].push_back({S.cur[l], i, j});
+        uint8_t i, j;
+        if (mucb && depth == 0) { // sampled / forced root action; the root bandits are neither consulted nor updated
+          if (l < S.forced.size()) { i = S.forced[l] / 9; j = S.forced[l] % 9; }
+          else {
+            auto sample = [&](const double *p, int k) {
+              double u = (double)(splitmix64(mucb_rng) >> 11) * (1.0 / 9007199254740992.0);
+              for (int q = 0; q < k; ++q) { u -= p[q]; if (u <= 0) return (uint8_t)q; }
+              return (uint8_t)(k - 1);
+            };
+            i = sample(S.nash1, m);
+            j = sample(S.nash2, n);
+          }
+          S.path[l].push_back({NO_NODE, i, j});
+        } else {
+          Stats &nd = tree.nodes[S.cur[l]];
+          i = nd.p1.select(prm->ucb_c, pucb);
+          j = nd.p2.select(prm->ucb_c, pucb);
+          ++nd.p1.visits[i];
+          ++nd.p2.visits[j];
+          S.path[l].push_back({S.cur[l], i, j});
+        }
         S.h_c1[l] = depth == 0 ? root_c1[i] : S.h_ch1[(size_t)l * 9 + i];
         S.h_c2[l] = depth == 0 ? root_c2[j] : S.h_ch2[(size_t)l * 9 + j];
       }
@@ -345,6 +435,7 @@ extern "C" int oakgpu_search(oakgpu_ctx *ctx, oakgpu_net *net, const uint8_t *ba
       }
       const float v2 = 1.0f - v1;
       for (const Step &st : S.path[l]) { // Bandit::update, the visit was already counted as the virtual loss
+        if (st.node == NO_NODE) continue;  // MatrixUCB root step: only the root matrices below are updated
         tree.nodes[st.node].p1.scores[st.i] += v1;
         tree.nodes[st.node].p2.scores[st.j] += v2;
       }

@@ -118,3 +118,25 @@ def test_tree_search_with_poke_engine_eval(gpu_ctx):
     out = tree_search(gpu_ctx, b[0], d[0], int(r[0]), iterations=8192, batch=1024, evaluator="poke-engine", c=1.0)
     assert int(out["visit_matrix"].sum()) == 8192 and out["nodes"] > 81
     assert 0.2 < out["empirical_value"] < 0.8      # values are sigmoids of score differences from the root: near 0.5
+
+
+def test_tree_search_matrix_ucb_root(gpu_ctx):
+    """MatrixUCBParams (mcts.h:107-113,263-302,498-566): after `delay` iterations the root joint action is sampled from the
+    Nash strategies of the UCB matrices; cells below `minimum` visits are forced first."""
+    import oracle_lib as O
+    from oak_amd.search import tree_search
+    # dominant action: the sampling must concentrate on it and the value must come out exact
+    b, d = parse_battle("starmie surf recover 1hp | rhydon earthquake 1hp")
+    out = tree_search(gpu_ctx, b, d, result_from_state(b), iterations=8192, batch=512, c=1.0, matrix_ucb=(512, 8, 1.0))
+    surf = [i for i, c in enumerate(out["p1_choices"]) if int(c) == ((1 << 2) | 1)][0]
+    assert out["nash_value"] == 1.0 and out["visit_matrix"][surf, 0] > 0.8 * out["iterations"]
+    assert (out["visit_matrix"] >= 8).all()                                  # the minimum-visits rule
+    # full 9 x 9 root: every cell reaches the minimum, bookkeeping holds, value agrees with the plain UCB search
+    bb, dd, pp, rr = O.make_random_ou_batch(1, seed0=424242)
+    res = int(rr[0])
+    plain = tree_search(gpu_ctx, bb[0], dd[0], res, iterations=1 << 15, batch=2048, seed=3)
+    mu = tree_search(gpu_ctx, bb[0], dd[0], res, iterations=1 << 15, batch=2048, seed=3, matrix_ucb=(4096, 32, 0.5))
+    assert int(mu["visit_matrix"].sum()) == 1 << 15 and (mu["visit_matrix"] >= 32).all()
+    assert abs(mu["nash_value"] - plain["nash_value"]) < 0.12
+    mu2 = tree_search(gpu_ctx, bb[0], dd[0], res, iterations=1 << 15, batch=2048, seed=3, matrix_ucb=(4096, 32, 0.5))
+    assert (mu["visit_matrix"] == mu2["visit_matrix"]).all()               # reproducible
