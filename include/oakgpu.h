@@ -119,8 +119,9 @@ int oakgpu_tree_step_dev(oakgpu_ctx *ctx, uint8_t *battles, uint8_t *durations, 
 typedef struct {
   uint64_t iterations;   /* root iterations (mcts.h:231-235, integer budget) */
   uint32_t batch;        /* descents in flight (GPU lanes); 1 reproduces the reference's one-at-a-time order */
-  float ucb_c;           /* Bandit::Params.c */
-  int32_t bandit;        /* 0: UCB (bandit/ucb.h), 1: PUCB with network priors (bandit/pucb.h; needs eval = 1) */
+  float ucb_c;           /* Bandit::Params.c (UCB, PUCB, UCB1) or gamma (Exp3, PExp3) */
+  int32_t bandit;        /* 0: UCB (bandit/ucb.h), 1: PUCB (pucb.h), 2: UCB1 (ucb1.h), 3: Exp3 (exp3.h), 4: PExp3 (pexp3.h);
+                          * PUCB / PExp3 take priors from the policy heads and need eval = 1 */
   int32_t eval;          /* 0: MCTS::MonteCarlo rollouts (mcts.h:448-496), 1: network value (network.h:72-123),
                           * 2: PokeEngine::Eval (poke-engine-evaluate.h:186-202; root score taken at the root) */
   uint32_t max_depth;    /* descent depth at which a node is evaluated even if already expanded (0 = 100) */
@@ -135,6 +136,7 @@ typedef struct {
   uint32_t mucb_delay;
   uint32_t mucb_minimum;
   float mucb_c;
+  float exp3_alpha;      /* Exp3 / PExp3 uniform mixing (search.cc:268-286); 0 = the reference's default 0.05 */
 } oakgpu_search_params;
 typedef struct {
   uint8_t m, n;                 /* legal choices per side at the root */

@@ -22,7 +22,7 @@ class SearchParams(C.Structure):      # oakgpu_search_params (include/oakgpu.h)
     _fields_ = [("iterations", C.c_uint64), ("batch", C.c_uint32), ("ucb_c", C.c_float), ("bandit", C.c_int32),
                 ("eval", C.c_int32), ("max_depth", C.c_uint32), ("root_rolls", C.c_uint32), ("other_rolls", C.c_uint32),
                 ("seed", C.c_uint64), ("matrix_ucb", C.c_int32), ("mucb_delay", C.c_uint32), ("mucb_minimum", C.c_uint32),
-                ("mucb_c", C.c_float)]
+                ("mucb_c", C.c_float), ("exp3_alpha", C.c_float)]
 
 
 class SearchOutput(C.Structure):      # oakgpu_search_output

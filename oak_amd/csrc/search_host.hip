@@ -30,29 +30,90 @@
 
 namespace {
 
-struct Bandit { // UCB::Bandit / PUCB::Bandit (bandit/ucb.h:17-66, pucb.h:17-75)
+uint64_t splitmix64(uint64_t &x) {
+  uint64_t z = (x += 0x9E3779B97F4A7C15ull);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+double uniform01(uint64_t &rng) { return (double)(splitmix64(rng) >> 11) * (1.0 / 9007199254740992.0); }
+
+enum BanditKind { B_UCB = 0, B_PUCB = 1, B_UCB1 = 2, B_EXP3 = 3, B_PEXP3 = 4 };
+struct BanditParams { int kind; float c; float alpha; }; // c: UCB c / Exp3 gamma; alpha: Exp3 uniform mixing (search.cc:268-286)
+
+// One player's bandit at a node: UCB::Bandit (bandit/ucb.h:17-66), PUCB::Bandit (pucb.h:17-75), UCB1::Bandit
+// (ucb1.h:16-67), Exp3::Bandit (exp3.h:17-79), PExp3::Bandit (pexp3.h:17-84).  `scores` doubles as Exp3's gains.
+struct Bandit {
   float scores[9];
   float priors[9];
   uint32_t visits[9];
   uint8_t k = 0;
-  void init(uint8_t kk) {
+  void init(uint8_t kk, int kind) {
     k = kk;
-    for (int i = 0; i < 9; ++i) { scores[i] = 0.5f; visits[i] = 1; priors[i] = kk ? 1.0f / kk : 0.0f; }
+    for (int i = 0; i < 9; ++i) {
+      priors[i] = kk ? 1.0f / kk : 0.0f;
+      if (kind == B_UCB1) { scores[i] = 0.0f; visits[i] = 0; }
+      else if (kind >= B_EXP3) { scores[i] = i < kk ? 0.0f : -INFINITY; visits[i] = 0; }
+      else { scores[i] = 0.5f; visits[i] = 1; }
+    }
   }
   bool is_init() const { return k != 0; }
-  uint8_t select(float c, bool pucb) const {
+  // network logits -> priors (PUCB::softmax_logits) or initial gains (PExp3::softmax_logits: logit / eta)
+  void set_logits(const BanditParams &P, const float *logits) {
+    if (P.kind == B_PUCB) {
+      float mx = logits[0], sum = 0;
+      for (int i = 1; i < k; ++i) mx = logits[i] > mx ? logits[i] : mx;
+      for (int i = 0; i < k; ++i) { priors[i] = std::exp(logits[i] - mx); sum += priors[i]; }
+      for (int i = 0; i < k; ++i) priors[i] /= sum;
+    } else if (P.kind == B_PEXP3) {
+      const float eta = P.c / k;
+      for (int i = 0; i < k; ++i) scores[i] = logits[i] / eta;
+    }
+  }
+  uint8_t select(const BanditParams &P, uint64_t &rng, float &prob) const {
+    prob = 1.0f;
     if (k == 1) return 0;
+    if (P.kind >= B_EXP3) {
+      const float eta = P.c / k, delta = P.alpha / k;
+      float policy[9], sum = 0;
+      for (int i = 0; i < 9; ++i) { policy[i] = std::exp(scores[i] * eta); sum += policy[i]; }
+      for (int i = 0; i < 9; ++i) policy[i] = (1.0f - P.alpha) * (policy[i] / sum) + delta;
+      double u = uniform01(rng); // device.sample_pdf (util/random.h:40-49)
+      uint8_t idx = 0;
+      for (int i = 0; i < 9; ++i) { u -= (double)policy[i]; if (u <= 0) { idx = (uint8_t)i; break; } }
+      idx = idx < k - 1 ? idx : (uint8_t)(k - 1);
+      prob = policy[idx];
+      return idx;
+    }
     uint64_t N = 0;
+    uint8_t idx = 0;
+    float best = 0;
+    if (P.kind == B_UCB1) {
+      for (int i = k - 1; i >= 0; --i) { if (visits[i] == 0) return (uint8_t)i; N += visits[i]; }
+      const float lnN = std::log((float)N);
+      for (int i = 0; i < k; ++i) {
+        const float a = std::sqrt(P.c * lnN / visits[i]) + scores[i] / visits[i];
+        if (a > best) { best = a; idx = (uint8_t)i; }
+      }
+      return idx;
+    }
     for (int i = 0; i < k; ++i) N += visits[i];
     const float sqrtN = std::sqrt((float)N);
-    float best = 0;
-    uint8_t idx = 0;
     for (int i = 0; i < k; ++i) {
-      const float e = pucb ? c * priors[i] * sqrtN : c * sqrtN / k;
+      const float e = P.kind == B_PUCB ? P.c * priors[i] * sqrtN : P.c * sqrtN / k;
       const float a = (e + scores[i]) / visits[i];
       if (a > best) { best = a; idx = (uint8_t)i; }
     }
     return idx;
+  }
+  // the visit of the counting bandits is booked at selection time (virtual loss), their score at back-up time
+  void visit(const BanditParams &P, uint8_t i) { if (P.kind < B_EXP3) ++visits[i]; }
+  void update(const BanditParams &P, uint8_t i, float value, float prob) {
+    if (P.kind < B_EXP3) { scores[i] += value; return; }
+    if ((scores[i] += (value - 0.5f) / prob) > 0) { // Exp3::update: keep the largest gain at 0
+      const float mx = scores[i];
+      for (int q = 0; q < 9; ++q) scores[q] -= mx;
+    }
   }
 };
 
@@ -104,14 +165,6 @@ struct Tree {
   }
 };
 
-void softmax(float *out, const float *logits, int k) { // search/util/softmax.h
-  float mx = logits[0];
-  for (int i = 1; i < k; ++i) mx = logits[i] > mx ? logits[i] : mx;
-  float sum = 0;
-  for (int i = 0; i < k; ++i) { out[i] = std::exp(logits[i] - mx); sum += out[i]; }
-  for (int i = 0; i < k; ++i) out[i] /= sum;
-}
-
 // Equilibrium of a zero-sum matrix game (row player maximises A[i][j], m, n <= 9) by the simplex method in doubles,
 // Bland's rule.  Used only to SAMPLE root actions for MatrixUCB (the reference solves the same matrices exactly with
 // lrsnash, mcts.h:532-543); the reported Nash value of a search is solved exactly by the caller (oak_amd/search.py).
@@ -158,13 +211,6 @@ void solve_zero_sum(const double *A, int m, int n, double *x, double *y) {
   for (int i = 0; i < m; ++i) x[i] = sum_x > 0 ? (z[n + i] > 0 ? z[n + i] : 0) / sum_x : 1.0 / m;
 }
 
-uint64_t splitmix64(uint64_t &x) {
-  uint64_t z = (x += 0x9E3779B97F4A7C15ull);
-  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-  return z ^ (z >> 31);
-}
-
 struct Buffers { // device arrays + pinned host mirrors of what crosses PCIe every level
   std::vector<void *> dev, pinned;
   ~Buffers() {
@@ -197,10 +243,12 @@ struct Buffers { // device arrays + pinned host mirrors of what crosses PCIe eve
 extern "C" int oakgpu_search(oakgpu_ctx *ctx, oakgpu_net *net, const uint8_t *battle, const uint8_t *durations, uint8_t result,
                              const oakgpu_search_params *prm, oakgpu_search_output *out) {
   if (!ctx || !battle || !durations || !prm || !out) return oakgpu_fail_msg("oakgpu_search: null argument");
-  const bool pucb = prm->bandit == 1, use_net = prm->eval == 1, use_pe = prm->eval == 2;
-  if (prm->bandit < 0 || prm->bandit > 1 || prm->eval < 0 || prm->eval > 2) return oakgpu_fail_msg("oakgpu_search: unknown bandit / eval");
-  if ((use_net || pucb) && !net) return oakgpu_fail_msg("oakgpu_search: network evaluation / PUCB priors need a network");
-  if (pucb && !use_net) return oakgpu_fail_msg("oakgpu_search: PUCB takes its priors from the network evaluator (eval = 1)");
+  const bool pucb = prm->bandit == B_PUCB || prm->bandit == B_PEXP3; // the bandits that take priors from the policy heads
+  const bool use_net = prm->eval == 1, use_pe = prm->eval == 2;
+  const BanditParams BP{prm->bandit, prm->ucb_c, prm->exp3_alpha > 0 ? prm->exp3_alpha : 0.05f};
+  if (prm->bandit < 0 || prm->bandit > 4 || prm->eval < 0 || prm->eval > 2) return oakgpu_fail_msg("oakgpu_search: unknown bandit / eval");
+  if ((use_net || pucb) && !net) return oakgpu_fail_msg("oakgpu_search: network evaluation / PUCB / PExp3 priors need a network");
+  if (pucb && !use_net) return oakgpu_fail_msg("oakgpu_search: PUCB / PExp3 take their priors from the network evaluator (eval = 1)");
   if (prm->batch == 0 || prm->batch > (1u << 20)) return oakgpu_fail_msg("oakgpu_search: batch must be in 1..2^20");
   auto rolls_ok = [](uint32_t r) { return r == 1 || r == 2 || r == 3 || r == 20 || r == 39; };
   if (!rolls_ok(prm->root_rolls) || !rolls_ok(prm->other_rolls)) return oakgpu_fail_msg("oakgpu_search: rolls must be 1, 2, 3, 20 or 39");
@@ -222,13 +270,13 @@ extern "C" int oakgpu_search(oakgpu_ctx *ctx, oakgpu_net *net, const uint8_t *ba
 
   Tree tree;
   const uint32_t root = tree.new_node();
-  tree.nodes[root].p1.init(m);
-  tree.nodes[root].p2.init(n);
+  tree.nodes[root].p1.init(m, BP.kind);
+  tree.nodes[root].p2.init(n, BP.kind);
   if (pucb) { // root priors from the policy heads (mcts.h:196-209)
     float v, l1[9], l2[9];
     RC(oakgpu_leaf_eval_policy(ctx, net, battle, durations, 1, root_c1, &m, root_c2, &n, &v, l1, l2));
-    softmax(tree.nodes[root].p1.priors, l1, m);
-    softmax(tree.nodes[root].p2.priors, l2, n);
+    tree.nodes[root].p1.set_logits(BP, l1);
+    tree.nodes[root].p2.set_logits(BP, l2);
     out->initial_value = v;
   }
 
@@ -238,7 +286,7 @@ extern "C" int oakgpu_search(oakgpu_ctx *ctx, oakgpu_net *net, const uint8_t *ba
   // Two batches are kept in flight ("slots", each with its own context = HIP stream and buffers): while the GPU
   // evaluates the leaves of one batch (rollouts: milliseconds), the host walks the tree for the other.  The schedule
   // is fixed (A descends, B descends, A finishes, A descends, B finishes, ...), so a search is reproducible.
-  struct Step { uint32_t node; uint8_t i, j; };
+  struct Step { uint32_t node; uint8_t i, j; float prob1, prob2; };
   constexpr uint32_t NO_NODE = 0xFFFFFFFFu;
   struct Slot {
     oakgpu_ctx *ctx = nullptr;
@@ -303,7 +351,7 @@ extern "C" int oakgpu_search(oakgpu_ctx *ctx, oakgpu_net *net, const uint8_t *ba
   auto now = [] { return std::chrono::high_resolution_clock::now(); };
   auto us = [](auto a, auto b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
   uint64_t done = 0, started = 0, total_depth = 0;
-  uint64_t mucb_rng = prm->seed ^ 0xA0761D6478BD642Full;
+  uint64_t mucb_rng = prm->seed ^ 0xA0761D6478BD642Full, bandit_rng = prm->seed ^ 0xE7037ED1A0B428DBull;
 
   // one batch: root prep, level-synchronous descent (host selection <-> k_tree_step), then the leaf evaluation is
   // LAUNCHED (not awaited)
@@ -351,21 +399,22 @@ extern "C" int oakgpu_search(oakgpu_ctx *ctx, oakgpu_net *net, const uint8_t *ba
           if (l < S.forced.size()) { i = S.forced[l] / 9; j = S.forced[l] % 9; }
           else {
             auto sample = [&](const double *p, int k) {
-              double u = (double)(splitmix64(mucb_rng) >> 11) * (1.0 / 9007199254740992.0);
+              double u = uniform01(mucb_rng);
               for (int q = 0; q < k; ++q) { u -= p[q]; if (u <= 0) return (uint8_t)q; }
               return (uint8_t)(k - 1);
             };
             i = sample(S.nash1, m);
             j = sample(S.nash2, n);
           }
-          S.path[l].push_back({NO_NODE, i, j});
+          S.path[l].push_back({NO_NODE, i, j, 1.0f, 1.0f});
         } else {
           Stats &nd = tree.nodes[S.cur[l]];
-          i = nd.p1.select(prm->ucb_c, pucb);
-          j = nd.p2.select(prm->ucb_c, pucb);
-          ++nd.p1.visits[i];
-          ++nd.p2.visits[j];
-          S.path[l].push_back({S.cur[l], i, j});
+          float pr1, pr2;
+          i = nd.p1.select(BP, bandit_rng, pr1);
+          j = nd.p2.select(BP, bandit_rng, pr2);
+          nd.p1.visit(BP, i);
+          nd.p2.visit(BP, j);
+          S.path[l].push_back({S.cur[l], i, j, pr1, pr2});
         }
         S.h_c1[l] = depth == 0 ? root_c1[i] : S.h_ch1[(size_t)l * 9 + i];
         S.h_c2[l] = depth == 0 ? root_c2[j] : S.h_ch2[(size_t)l * 9 + j];
@@ -429,15 +478,15 @@ extern "C" int oakgpu_search(oakgpu_ctx *ctx, oakgpu_net *net, const uint8_t *ba
       else v1 = S.h_values[l];
       if (S.leaf[l] != NO_NODE && !tree.nodes[S.leaf[l]].is_init() && S.h_cnt1[l] && S.h_cnt2[l]) { // stats.init(m, n) (+ priors), first evaluation
         Stats &lf = tree.nodes[S.leaf[l]];
-        lf.p1.init(S.h_cnt1[l]);
-        lf.p2.init(S.h_cnt2[l]);
-        if (pucb) { softmax(lf.p1.priors, S.h_l1 + (size_t)l * 9, S.h_cnt1[l]); softmax(lf.p2.priors, S.h_l2 + (size_t)l * 9, S.h_cnt2[l]); }
+        lf.p1.init(S.h_cnt1[l], BP.kind);
+        lf.p2.init(S.h_cnt2[l], BP.kind);
+        if (pucb) { lf.p1.set_logits(BP, S.h_l1 + (size_t)l * 9); lf.p2.set_logits(BP, S.h_l2 + (size_t)l * 9); }
       }
       const float v2 = 1.0f - v1;
       for (const Step &st : S.path[l]) { // Bandit::update, the visit was already counted as the virtual loss
         if (st.node == NO_NODE) continue;  // MatrixUCB root step: only the root matrices below are updated
-        tree.nodes[st.node].p1.scores[st.i] += v1;
-        tree.nodes[st.node].p2.scores[st.j] += v2;
+        tree.nodes[st.node].p1.update(BP, st.i, v1, st.prob1);
+        tree.nodes[st.node].p2.update(BP, st.j, v2, st.prob2);
       }
       const Step &s0 = S.path[l].front();
       ++out->visit_matrix[s0.i * 9 + s0.j];

@@ -142,8 +142,8 @@ def process_output(out):
 
 
 def tree_search(ctx, battle, durations, result, iterations=1 << 16, batch=4096, c=2.0, bandit="ucb", evaluator="mc",
-                root_rolls=3, other_rolls=1, max_depth=100, seed=0x5EED, matrix_ucb=None):
-    """Tree search with batched leaves on the GPU (include/oakgpu.h: oakgpu_search).  bandit: "ucb" | "pucb";
+                root_rolls=3, other_rolls=1, max_depth=100, seed=0x5EED, matrix_ucb=None, alpha=0.05):
+    """Tree search with batched leaves on the GPU (include/oakgpu.h: oakgpu_search).  bandit: "ucb" | "pucb" | "ucb1" | "exp3" | "pexp3" (c = gamma for the Exp3 family, alpha its uniform mixing);
     evaluator: "mc", "poke-engine" (PokeEngine::Eval) or an oak_amd.engine.Network.  Defaults follow the reference's default_search{3, 1} damage-roll
     clamping (mcts.h:131).  matrix_ucb: None or (delay, minimum, c) -- MatrixUCBParams with interval = batch (the
     reference's "delay-interval-minimum-c" agent string, search.cc:216-231).  Returns a dict shaped like MCTS::Output
@@ -153,11 +153,11 @@ def tree_search(ctx, battle, durations, result, iterations=1 << 16, batch=4096, 
     battle = np.ascontiguousarray(battle, dtype=np.uint8).reshape(384)
     durations = np.ascontiguousarray(durations, dtype=np.uint8).reshape(8)
     use_net = not isinstance(evaluator, str)
-    prm = _lib.SearchParams(iterations=int(iterations), batch=int(batch), ucb_c=float(c), bandit={"ucb": 0, "pucb": 1}[bandit],
+    prm = _lib.SearchParams(iterations=int(iterations), batch=int(batch), ucb_c=float(c), bandit={"ucb": 0, "pucb": 1, "ucb1": 2, "exp3": 3, "pexp3": 4}[bandit],
                             eval=1 if use_net else {"mc": 0, "poke-engine": 2}[evaluator], max_depth=int(max_depth), root_rolls=int(root_rolls),
                             other_rolls=int(other_rolls), seed=int(seed), matrix_ucb=1 if matrix_ucb else 0,
                             mucb_delay=int(matrix_ucb[0]) if matrix_ucb else 0, mucb_minimum=int(matrix_ucb[1]) if matrix_ucb else 0,
-                            mucb_c=float(matrix_ucb[2]) if matrix_ucb else 0.0)
+                            mucb_c=float(matrix_ucb[2]) if matrix_ucb else 0.0, exp3_alpha=float(alpha))
     res = _lib.SearchOutput()
     _lib.check(ctx.lib.oakgpu_search(ctx.handle, evaluator.handle if use_net else None, battle.ctypes.data_as(C.c_void_p),
                                      durations.ctypes.data_as(C.c_void_p), int(result), C.byref(prm), C.byref(res)))

@@ -140,3 +140,30 @@ def test_tree_search_matrix_ucb_root(gpu_ctx):
     assert abs(mu["nash_value"] - plain["nash_value"]) < 0.12
     mu2 = tree_search(gpu_ctx, bb[0], dd[0], res, iterations=1 << 15, batch=2048, seed=3, matrix_ucb=(4096, 32, 0.5))
     assert (mu["visit_matrix"] == mu2["visit_matrix"]).all()               # reproducible
+
+
+@pytest.mark.parametrize("bandit,c", [("ucb1", 2.0), ("exp3", 0.1)])
+def test_tree_search_other_bandits(gpu_ctx, bandit, c):
+    """UCB1::Bandit (ucb1.h) and Exp3::Bandit (exp3.h): the dominant action wins, bookkeeping holds, seeds reproduce."""
+    import oracle_lib as O
+    from oak_amd.search import tree_search
+    b, d = parse_battle("starmie surf recover 1hp | rhydon earthquake 1hp")
+    out = tree_search(gpu_ctx, b, d, result_from_state(b), iterations=8192, batch=256, c=c, bandit=bandit)
+    surf = [i for i, ch in enumerate(out["p1_choices"]) if int(ch) == ((1 << 2) | 1)][0]
+    assert out["nash_value"] == 1.0 and out["visit_matrix"][surf, 0] > 0.6 * out["iterations"]
+    bb, dd, pp, rr = O.make_random_ou_batch(1, seed0=555)
+    a1 = tree_search(gpu_ctx, bb[0], dd[0], int(rr[0]), iterations=1 << 14, batch=1024, c=c, bandit=bandit, seed=11)
+    a2 = tree_search(gpu_ctx, bb[0], dd[0], int(rr[0]), iterations=1 << 14, batch=1024, c=c, bandit=bandit, seed=11)
+    assert int(a1["visit_matrix"].sum()) == 1 << 14 and (a1["visit_matrix"] == a2["visit_matrix"]).all()
+    assert a1["nodes"] > 81 and 0 <= a1["nash_value"] <= 1
+
+
+def test_tree_search_pexp3_with_network(gpu_ctx):
+    import oracle_lib as O
+    from oak_amd.engine import Network
+    from oak_amd.search import tree_search
+    b, d, p, r = O.make_random_ou_batch(1, seed0=777)
+    net = Network(gpu_ctx, path=os.path.join(ROOT, "tests", "golden", "net_default.battle.net"))
+    out = tree_search(gpu_ctx, b[0], d[0], int(r[0]), iterations=4096, batch=512, bandit="pexp3", evaluator=net, c=0.1)
+    assert int(out["visit_matrix"].sum()) == 4096 and out["nodes"] > 81 and 0 < out["initial_value"] < 1
+    net.close()
