@@ -587,8 +587,8 @@ __global__ __launch_bounds__(EL_BLOCK) void k_embed_lds(EmbedTileArgs a) {
 // ---- K3: main net on fp32 MFMA ------------------------------------------------------------------
 constexpr int MN_BLOCK = 256; // 4 waves
 constexpr int TM = 64;        // leaves per workgroup tile
-constexpr int KC = 64;        // K chunk staged per iteration
-constexpr int KCP = KC + 1;   // padded LDS row stride (odd => conflict-free column reads)
+constexpr int KC_MAIN = 64;   // K chunk staged per iteration in k_mainnet (LDS: 16.6 + 66.6 KB staging + 65.8 KB activations)
+constexpr int KC_POLICY = 32; // ... in k_policy (two activation tiles: 8.4 + 33.8 KB staging)
 constexpr int MAXH = 256;
 
 struct MainArgs {
@@ -603,13 +603,17 @@ struct MainArgs {
 // A comes either from global (X, staged per K-chunk into xs) or from the LDS activation tile.
 // Staging is software-pipelined: the NEXT chunk's global loads are issued into registers before the
 // MFMAs of the current chunk, so L2 latency hides behind the matrix pipe (one wave per SIMD here).
-constexpr int WREG = MAXH * (KC / 4) / MN_BLOCK; // float4 per thread per W chunk (8)
-constexpr int XREG = TM * (KC / 4) / MN_BLOCK;   // float4 per thread per X chunk (2)
 
-template <bool A_FROM_GLOBAL>
+// KCT = K-chunk staged per iteration (k_mainnet: 64, half the barriers; k_policy: 32, its two activation tiles leave
+// no room for more).  Measured and rejected: double-buffering the chunks in LDS with KCT = 32 (one barrier per chunk,
+// staging under the previous chunk's MFMAs) -- 547 us against 473 us for single-buffered 64-wide chunks.
+template <bool A_FROM_GLOBAL, int KCT>
 __device__ __forceinline__ void dense_layer(const float *a_global, int a_ld, uint32_t row0, uint32_t n_rows, // global A
                                             const float *a_lds, int a_lds_ld,                               // LDS A
                                             const float *W, int K, int Hout, float *xs, float *ws, f32x16 (&acc)[4]) {
+  constexpr int KCPT = KCT + 1;                          // padded LDS row stride (odd => conflict-free column reads)
+  constexpr int WREGT = MAXH * (KCT / 4) / MN_BLOCK;     // float4 per thread per W chunk
+  constexpr int XREGT = TM * (KCT / 4) / MN_BLOCK;       // float4 per thread per X chunk
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int mi = wave & 1, nb0 = wave >> 1, NB = Hout / 32;
   const int r = lane & 31, h = lane >> 5;
@@ -617,57 +621,61 @@ __device__ __forceinline__ void dense_layer(const float *a_global, int a_ld, uin
   for (int j = 0; j < 4; ++j)
 #pragma unroll
     for (int q = 0; q < 16; ++q) acc[j][q] = 0.0f;
-  float4 wreg[WREG], xreg[XREG];
+  float4 wreg[WREGT], xreg[XREGT];
   auto prefetch = [&](int k0) {
+    const bool full = Hout == MAXH && k0 + KCT <= K; // the usual case: no per-load bounds branches
 #pragma unroll
-    for (int u = 0; u < WREG; ++u) {
-      const int i = tid + u * MN_BLOCK, row = i / (KC / 4), q = i - row * (KC / 4);
-      wreg[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (row < Hout && k0 + 4 * q < K) wreg[u] = *(const float4 *)(W + (size_t)row * K + k0 + 4 * q);
+    for (int u = 0; u < WREGT; ++u) {
+      const int i = tid + u * MN_BLOCK, row = i / (KCT / 4), q = i - row * (KCT / 4);
+      if (full) wreg[u] = *(const float4 *)(W + (size_t)row * K + k0 + 4 * q);
+      else {
+        wreg[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row < Hout && k0 + 4 * q < K) wreg[u] = *(const float4 *)(W + (size_t)row * K + k0 + 4 * q);
+      }
     }
     if (A_FROM_GLOBAL) {
 #pragma unroll
-      for (int u = 0; u < XREG; ++u) {
-        const int i = tid + u * MN_BLOCK, row = i / (KC / 4), q = i - row * (KC / 4);
+      for (int u = 0; u < XREGT; ++u) {
+        const int i = tid + u * MN_BLOCK, row = i / (KCT / 4), q = i - row * (KCT / 4);
         xreg[u] = make_float4(0.f, 0.f, 0.f, 0.f);
         if ((uint32_t)row < n_rows && k0 + 4 * q < K) xreg[u] = *(const float4 *)(a_global + (size_t)(row0 + row) * a_ld + k0 + 4 * q);
       }
     }
   };
+  // JN = how many of this wave's four n-blocks exist (wave-uniform).  The count is resolved ONCE, so that the k-steps
+  // below are straight-line code: with a per-MFMA `if (block exists)` every MFMA sits in its own basic block and the
+  // next step's LDS reads cannot be scheduled under the current step's MFMAs.
+  const int JN = NB - nb0 <= 0 ? 0 : (NB - nb0 + 1) / 2 > 4 ? 4 : (NB - nb0 + 1) / 2;
   prefetch(0);
-  for (int k0 = 0; k0 < K; k0 += KC) {
+  for (int k0 = 0; k0 < K; k0 += KCT) {
     __syncthreads(); // previous chunk fully consumed
 #pragma unroll
-    for (int u = 0; u < WREG; ++u) {
-      const int i = tid + u * MN_BLOCK, row = i / (KC / 4), q = i - row * (KC / 4);
-      if (row < Hout) { float *d = ws + row * KCP + 4 * q; d[0] = wreg[u].x; d[1] = wreg[u].y; d[2] = wreg[u].z; d[3] = wreg[u].w; }
+    for (int u = 0; u < WREGT; ++u) {
+      const int i = tid + u * MN_BLOCK, row = i / (KCT / 4), q = i - row * (KCT / 4);
+      if (row < Hout) { float *d = ws + row * KCPT + 4 * q; d[0] = wreg[u].x; d[1] = wreg[u].y; d[2] = wreg[u].z; d[3] = wreg[u].w; }
     }
     if (A_FROM_GLOBAL) {
 #pragma unroll
-      for (int u = 0; u < XREG; ++u) {
-        const int i = tid + u * MN_BLOCK, row = i / (KC / 4), q = i - row * (KC / 4);
-        float *d = xs + row * KCP + 4 * q; d[0] = xreg[u].x; d[1] = xreg[u].y; d[2] = xreg[u].z; d[3] = xreg[u].w;
+      for (int u = 0; u < XREGT; ++u) {
+        const int i = tid + u * MN_BLOCK, row = i / (KCT / 4), q = i - row * (KCT / 4);
+        float *d = xs + row * KCPT + 4 * q; d[0] = xreg[u].x; d[1] = xreg[u].y; d[2] = xreg[u].z; d[3] = xreg[u].w;
       }
     }
     __syncthreads();
-    if (k0 + KC < K) prefetch(k0 + KC); // in flight during the MFMAs below
-    const int kmax = (K - k0) < KC ? (K - k0) : KC;
-    const float *arow = A_FROM_GLOBAL ? xs + (mi * 32 + r) * KCP + h : a_lds + (mi * 32 + r) * a_lds_ld + k0 + h;
-    const float *brow = ws + (nb0 * 32 + r) * KCP + h; // n-block j of this wave sits 64 rows further per j
-    // JN = how many of this wave's four n-blocks exist (wave-uniform).  The count is resolved ONCE per chunk, so
-    // that the k-steps below are straight-line code: with a per-MFMA `if (block exists)` every MFMA sits in its
-    // own basic block and the next step's LDS reads cannot be scheduled under the current step's MFMAs.
-    const int JN = NB - nb0 <= 0 ? 0 : (NB - nb0 + 1) / 2 > 4 ? 4 : (NB - nb0 + 1) / 2;
+    if (k0 + KCT < K) prefetch(k0 + KCT); // in flight during the MFMAs below
+    const int kmax = (K - k0) < KCT ? (K - k0) : KCT;
+    const float *arow = A_FROM_GLOBAL ? xs + (mi * 32 + r) * KCPT + h : a_lds + (mi * 32 + r) * a_lds_ld + k0 + h;
+    const float *brow = ws + (nb0 * 32 + r) * KCPT + h; // n-block j of this wave sits 64 rows further per j
     auto run = [&](auto jn_tag) {
       constexpr int JNc = decltype(jn_tag)::value;
       auto step = [&](int s) {
         const float av = arow[2 * s];
 #pragma unroll
-        for (int j = 0; j < JNc; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, brow[j * 64 * KCP + 2 * s], acc[j], 0, 0, 0);
+        for (int j = 0; j < JNc; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, brow[j * 64 * KCPT + 2 * s], acc[j], 0, 0, 0);
       };
-      if (kmax == KC) {
+      if (kmax == KCT) {
 #pragma unroll
-        for (int s = 0; s < KC / 2; ++s) step(s); // fully unrolled: next step's ds_reads issue under this step's MFMAs
+        for (int s = 0; s < KCT / 2; ++s) step(s); // fully unrolled: next step's ds_reads issue under this step's MFMAs
       } else {
         for (int s = 0; s < kmax / 2; ++s) step(s);
       }
@@ -704,17 +712,17 @@ __global__ __launch_bounds__(MN_BLOCK) void k_mainnet(MainArgs a) {
   const NetDev &N = a.net;
   const int H = N.H, VH = N.VH;
   const int hld = (H > VH ? H : VH) + 1;
-  float *xs = lds_f;              // TM x KCP
-  float *ws = xs + TM * KCP;      // MAXH x KCP
-  float *hs = ws + MAXH * KCP;    // TM x hld
+  float *xs = lds_f;                          // TM x (KC_MAIN + 1)
+  float *ws = xs + TM * (KC_MAIN + 1);        // MAXH x (KC_MAIN + 1)
+  float *hs = ws + MAXH * (KC_MAIN + 1);      // TM x hld
   const uint32_t row0 = blockIdx.x * TM;
   const uint32_t n_rows = min((uint32_t)TM, a.n - row0);
   f32x16 acc[4];
-  dense_layer<true>(a.emb, N.emb_dim, row0, n_rows, nullptr, 0, N.w0, N.emb_dim, H, xs, ws, acc);
+  dense_layer<true, KC_MAIN>(a.emb, N.emb_dim, row0, n_rows, nullptr, 0, N.w0, N.emb_dim, H, xs, ws, acc);
   __syncthreads();
   store_act(acc, N.b0, H, N.activation, hs, hld);
   __syncthreads();
-  dense_layer<false>(nullptr, 0, 0, 0, hs, hld, N.w1, H, H, xs, ws, acc);
+  dense_layer<false, KC_MAIN>(nullptr, 0, 0, 0, hs, hld, N.w1, H, H, xs, ws, acc);
   __syncthreads(); // every wave done reading hs
   store_act(acc, N.b1, H, N.activation, hs, hld);
   __syncthreads();
@@ -724,7 +732,7 @@ __global__ __launch_bounds__(MN_BLOCK) void k_mainnet(MainArgs a) {
       a.h1_out[(size_t)(row0 + row) * H + c] = hs[row * hld + c];
     }
   }
-  dense_layer<false>(nullptr, 0, 0, 0, hs, hld, N.w2, H, VH, xs, ws, acc);
+  dense_layer<false, KC_MAIN>(nullptr, 0, 0, 0, hs, hld, N.w2, H, VH, xs, ws, acc);
   __syncthreads();
   store_act(acc, N.b2, VH, N.activation, hs, hld);
   __syncthreads();
@@ -769,8 +777,8 @@ __global__ __launch_bounds__(MN_BLOCK) void k_policy(PolicyArgs a) {
   const int H = N.H, PH = N.PH;
   const int hld = H + 1, old = PH + 1;
   float *xs = lds_f;              // unused staging slot of dense_layer<false> (kept for its signature)
-  float *ws = xs + TM * KCP;      // MAXH x KCP
-  float *hs = ws + MAXH * KCP;    // TM x hld : fc1 activations
+  float *ws = xs + TM * (KC_POLICY + 1);      // MAXH x (KC_POLICY + 1)
+  float *hs = ws + MAXH * (KC_POLICY + 1);    // TM x hld : fc1 activations
   float *os = hs + TM * hld;      // TM x old : policy fc2 activations
   const uint32_t row0 = blockIdx.x * TM;
   const uint32_t n_rows = min((uint32_t)TM, a.n - row0);
@@ -783,7 +791,7 @@ __global__ __launch_bounds__(MN_BLOCK) void k_policy(PolicyArgs a) {
   for (int head = 0; head < 2; ++head) {
     const float *Wa = head ? N.q2a : N.q1a, *ba = head ? N.q2a_b : N.q1a_b;
     const float *Wb = head ? N.q2b : N.q1b, *bb = head ? N.q2b_b : N.q1b_b;
-    dense_layer<false>(nullptr, 0, 0, 0, hs, hld, Wa, H, PH, xs, ws, acc);
+    dense_layer<false, KC_POLICY>(nullptr, 0, 0, 0, hs, hld, Wa, H, PH, xs, ws, acc);
     __syncthreads();
     store_act(acc, ba, PH, N.activation, os, old);
     __syncthreads();
@@ -1046,13 +1054,13 @@ static int leaf_eval_impl(oakgpu_ctx *ctx, oakgpu_net *net, const uint8_t *battl
   }
   oak::MainArgs ma{D, emb, n, values, h1};
   const int hld = (D.H > D.VH ? D.H : D.VH) + 1;
-  const size_t mn_lds = (size_t)(oak::TM * oak::KCP + oak::MAXH * oak::KCP + oak::TM * hld) * 4;
+  const size_t mn_lds = (size_t)((oak::TM + oak::MAXH) * (oak::KC_MAIN + 1) + oak::TM * hld) * 4;
   hipLaunchKernelGGL(oak::k_mainnet, dim3((n + oak::TM - 1) / oak::TM), dim3(oak::MN_BLOCK), mn_lds, stream, ma);
   if (pol) {
     oak::PolicyArgs pa = *pol;
     pa.net = D;
     pa.h1 = h1;
-    const size_t pl_lds = (size_t)(oak::TM * oak::KCP + oak::MAXH * oak::KCP + oak::TM * (D.H + 1) + oak::TM * (D.PH + 1)) * 4;
+    const size_t pl_lds = (size_t)((oak::TM + oak::MAXH) * (oak::KC_POLICY + 1) + oak::TM * (D.H + 1) + oak::TM * (D.PH + 1)) * 4;
     hipLaunchKernelGGL(oak::k_policy, dim3((n + oak::TM - 1) / oak::TM), dim3(oak::MN_BLOCK), pl_lds, stream, pa);
   }
   hipError_t e = hipGetLastError();

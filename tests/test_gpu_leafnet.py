@@ -131,3 +131,27 @@ def test_poke_engine_eval_matches_oracle(gpu_ctx):
     exp_v = np.array([float(NN.poke_engine_value(b[i], gamedata.MOVES, root)) for i in range(b.shape[0])])
     assert np.abs(scores - exp_s).max() <= 1e-3 and len(np.unique(np.round(exp_s))) > 50
     assert np.abs(vals - exp_v).max() <= TOL
+
+
+def test_value_policy_inference_config3_net(gpu_ctx, tmp_path):
+    """The policy heads behind the WIDEST main net the kernels take (768 -> 256 -> 256; policy fc2 64): k_policy's LDS
+    budget (two activation tiles next to the staged weight chunk) is only exercised at this width."""
+    import oracle_lib as O
+    from oak_amd.engine import Network
+    path = str(tmp_path / "c3p.battle.net")
+    NN.write_random_net(path, hidden=256, value_hidden=256, policy_hidden=64, seed=5)
+    net = Network(gpu_ctx, path=path)
+    onet = NN.Net(path)
+    b, d = _midgame_states(96, 15, 31337)
+    r = np.array([O.LIB.oracle_result_from_state(O.ptr(b[i])) for i in range(b.shape[0])], dtype=np.uint8)
+    keep = (r & 15) == 0
+    b, d, r = b[keep], d[keep], r[keep]
+    c1, n1 = gpu_ctx.choices(b, r, 0)
+    c2, n2 = gpu_ctx.choices(b, r, 1)
+    vals, l1, l2 = net.value_policy_inference(b, d, c1, n1, c2, n2)
+    worst = 0.0
+    for i in range(0, b.shape[0], 3):
+        ev, e1, e2 = NN.value_policy_inference(onet, b[i], d[i], c1[i, :n1[i]], c2[i, :n2[i]])
+        worst = max(worst, abs(float(vals[i]) - float(ev)), float(np.abs(l1[i, :n1[i]] - e1).max()), float(np.abs(l2[i, :n2[i]] - e2).max()))
+    assert worst <= 2e-5, worst
+    net.close()
