@@ -426,71 +426,79 @@ __global__ __launch_bounds__(EL_BLOCK) void k_embed_lds(EmbedTileArgs a) {
     EL_MARK(0);
     uint32_t first_leaf;
     (void)tile_leaves(tile, first_leaf);
-    // ---- phase 1a: sparse feature lists of this wave's 8 items.  A lane evaluates ONE feature of one item:
-    // the 52 features of an active in one pass per item, the 12 features of a party slot five items per pass.
+    // ---- phase 1a: sparse feature lists of this wave's 8 items, ONE LANE PER ITEM: lane t < 8 walks its item's 12 / 52
+    // candidate features in order and appends the present ones to the item's lists.  The feature index is a
+    // compile-time constant in the unrolled walk, so the encoders' branches on it fold away and all eight lanes run one
+    // straight-line instruction stream (the earlier lane-per-FEATURE form paid the encoder's whole branch ladder once
+    // per item).
     {
-      constexpr uint32_t FL = ACT ? 64 : 12, IPP = ACT ? 1 : 5, PASSES = (EL_ITEMS + IPP - 1) / IPP;
       for (uint32_t k = lane; k < (uint32_t)(EL_ITEMS * L::LCAP); k += 64) { // padding entries: row 0 with weight 0
         Lidx[wib * EL_ITEMS * L::LCAP + k] = 0;
         Lval[wib * EL_ITEMS * L::LCAP + k] = 0.0f;
       }
       Gidx[wib * EL_ITEMS * 8 + lane] = 0;
-      const uint32_t sub = ACT ? 0 : lane / FL, j = ACT ? lane : lane - sub * FL;
-      constexpr int PASS_UNROLL = ACT ? 1 : 2; // party slots: both passes' dependent LDS reads overlap
-#pragma unroll PASS_UNROLL
-      for (uint32_t pass = 0; pass < PASSES; ++pass) {
-        const uint32_t ii = pass * IPP + sub;
-        const bool mine = sub < IPP && ii < (uint32_t)EL_ITEMS;
-        const uint32_t i = wib * EL_ITEMS + (mine ? ii : 0);
-        const uint32_t g = tile * ET + i;
-        uint32_t fidx = 0, doff = 0xFFFFFFFFu, hp = 0, pk0 = 0;
-        float fval = 0.0f;
-        bool valid = false, is_move = false;
-        if (mine && g < items) {
-          const uint32_t leaf = g / per_leaf, q = g - leaf * per_leaf;
-          const uint32_t side = ACT ? q : q / 5, slot = ACT ? 0 : 1 + (q - side * 5);
-          const uint32_t *lb = Bs + (leaf - first_leaf) * 98;
-          const uint32_t *sb = lb + side * 46;
-          const uint32_t dur = lb[96 + side];
-          const uint32_t o0 = sb[44], o1 = sb[45];
-          const uint32_t id = slot < 4 ? (o0 >> (8 * slot)) & 0xFF : (o1 >> (8 * (slot - 4))) & 0xFF;
-          const uint32_t dd = leaf * N.emb_dim + side * N.side_dim + (ACT ? 0 : (1 + N.a_out) + (slot - 1) * (1 + N.p_out));
-          uint32_t pk1 = 0, pk2 = 0, pk3 = 0, pk4 = 0, pk5 = 0;
-          if (id != 0) {
-            const uint32_t *pk = sb + 6 * (id - 1);
-            pk0 = pk[0]; pk1 = pk[1]; pk2 = pk[2]; pk3 = pk[3]; pk4 = pk[4]; pk5 = pk[5];
-            hp = pk4 >> 16;
-          }
-          if (hp == 0) { // empty or fainted: zero block (network.h:142-143,153-160), kept out of phase 3
-            float *dst = a.emb + dd;
-            for (uint32_t o = j; o < (uint32_t)out_dim + 1; o += FL) dst[o] = 0.0f;
+      const bool mine = lane < (uint32_t)EL_ITEMS;
+      const uint32_t i = wib * EL_ITEMS + (mine ? lane : 0);
+      const uint32_t g = tile * ET + i;
+      uint32_t doff = 0xFFFFFFFFu, dead_off = 0xFFFFFFFFu, cntL = 0, cntG = 0;
+      if (mine && g < items) {
+        const uint32_t leaf = g / per_leaf, q = g - leaf * per_leaf;
+        const uint32_t side = ACT ? q : q / 5, slot = ACT ? 0 : 1 + (q - side * 5);
+        const uint32_t *lb = Bs + (leaf - first_leaf) * 98;
+        const uint32_t *sb = lb + side * 46;
+        const uint32_t dur = lb[96 + side];
+        const uint32_t o0 = sb[44], o1 = sb[45];
+        const uint32_t id = slot < 4 ? (o0 >> (8 * slot)) & 0xFF : (o1 >> (8 * (slot - 4))) & 0xFF;
+        const uint32_t dd = leaf * N.emb_dim + side * N.side_dim + (ACT ? 0 : (1 + N.a_out) + (slot - 1) * (1 + N.p_out));
+        uint32_t pk0 = 0, pk1 = 0, pk2 = 0, pk3 = 0, pk4 = 0, pk5 = 0, hp = 0;
+        if (id != 0) {
+          const uint32_t *pk = sb + 6 * (id - 1);
+          pk0 = pk[0]; pk1 = pk[1]; pk2 = pk[2]; pk3 = pk[3]; pk4 = pk[4]; pk5 = pk[5];
+          hp = pk4 >> 16;
+        }
+        if (hp == 0) dead_off = dd; // empty or fainted: zero block (network.h:142-143,153-160), kept out of phase 3
+        else {
+          doff = dd;
+          uint32_t *li = Lidx + i * L::LCAP;
+          float *lv = Lval + i * L::LCAP;
+          auto emit = [&](bool valid, uint32_t fidx, float fval, bool to_global) {
+            if (!valid) return;
+            if (to_global) { Gidx[i * 8 + cntG] = fidx; ++cntG; }
+            else { li[cntL] = (ACT ? active_lds_slot(fidx) : fidx) * 128; lv[cntL] = fval; ++cntL; }
+          };
+          if (ACT) {
+            const uint32_t *ac = sb + 36;
+            const uint32_t a0 = ac[0], a1 = ac[1], a2 = ac[2], a3 = ac[3], a4 = ac[4], a5 = ac[5], a6 = ac[6], a7 = ac[7];
+#pragma unroll
+            for (uint32_t j = 0; j < 40; ++j) {
+              uint32_t fidx = 0; float fval = 0.0f;
+              const bool v = active_feature(j, a0, a1, a2, a3, a4, a5, a6, a7, dur, fidx, fval);
+              emit(v, fidx, fval, j >= 32 && j < 36);
+            }
+#pragma unroll
+            for (uint32_t j = 0; j < 12; ++j) {
+              uint32_t fidx = 0; float fval = 0.0f;
+              const bool v = pokemon_feature(j, pk0, pk1, pk2, pk3, pk4, pk5, dur & 7, fidx, fval);
+              emit(v, fidx + 229, fval, j >= 5 && j < 9);
+            }
           } else {
-            doff = dd;
-            if (ACT) {
-              const uint32_t *ac = sb + 36;
-              if (j < 40) { valid = active_feature(j, ac[0], ac[1], ac[2], ac[3], ac[4], ac[5], ac[6], ac[7], dur, fidx, fval); is_move = j >= 32 && j < 36; }
-              else if (j < 52) { valid = pokemon_feature(j - 40, pk0, pk1, pk2, pk3, pk4, pk5, dur & 7, fidx, fval); fidx += 229; is_move = j >= 45 && j < 49; }
-            } else {
-              valid = pokemon_feature(j, pk0, pk1, pk2, pk3, pk4, pk5, (dur >> (3 * slot)) & 7, fidx, fval);
+#pragma unroll
+            for (uint32_t j = 0; j < 12; ++j) {
+              uint32_t fidx = 0; float fval = 0.0f;
+              const bool v = pokemon_feature(j, pk0, pk1, pk2, pk3, pk4, pk5, (dur >> (3 * slot)) & 7, fidx, fval);
+              emit(v, fidx, fval, false);
             }
           }
+          hp_ratio[i] = (float)hp / (float)(pk0 & 0xFFFF);
         }
-        const bool inL = valid && !is_move, inG = valid && is_move;
-        const uint64_t mL = __ballot(inL), mG = __ballot(inG);
-        const uint32_t sh = sub * FL; // this item's lanes are bits [sh, sh + FL)
-        const uint64_t item_bits = FL == 64 ? ~0ull : (((1ull << FL) - 1) << sh);
-        const uint64_t below = (1ull << lane) - 1;
-        if (inL) {
-          const uint32_t pos = (uint32_t)__popcll(mL & item_bits & below);
-          Lidx[i * L::LCAP + pos] = (ACT ? active_lds_slot(fidx) : fidx) * 128;
-          Lval[i * L::LCAP + pos] = fval;
-        }
-        if (inG) Gidx[i * 8 + (uint32_t)__popcll(mG & item_bits & below)] = fidx;
-        if (mine && j == 0) {
-          meta[i] = (uint32_t)__popcll(mL & item_bits) | ((uint32_t)__popcll(mG & item_bits) << 8);
-          dst_off[i] = doff;
-          if (doff != 0xFFFFFFFFu) hp_ratio[i] = (float)hp / (float)(pk0 & 0xFFFF);
-        }
+      }
+      if (mine) { meta[i] = cntL | (cntG << 8); dst_off[i] = doff; }
+      uint64_t dead = __ballot(dead_off != 0xFFFFFFFFu); // the wave zeroes the blocks of its dead items together
+      while (dead) {
+        const int src = __ffsll((unsigned long long)dead) - 1;
+        dead &= dead - 1;
+        float *dst = a.emb + __shfl(dead_off, src, 64);
+        for (uint32_t o = lane; o < (uint32_t)out_dim + 1; o += 64) dst[o] = 0.0f;
       }
     }
     EL_MARK(3);
