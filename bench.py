@@ -393,7 +393,7 @@ def leaf_workload(args, torch, dev, rank, local_rank, world, dist):
                                    "whole batch (in place) + value_inference (768-256-256-256-1) of every lane; 40-turn episodes",
                        "batch_per_gpu": n, "leaf_evals_per_s": n * world * K / elapsed,
                        "live_lane_fraction": steps_done / (n * K)},
-            "roofline": {"bound": "mfma", "kernel": "oak::k_embed_lds (x2) + oak::k_mainnet (+ oak::k_rollout_queue, 1 step)",
+            "roofline": {"bound": "mfma", "kernel": "oak::k_embed_lds (x2) + oak::k_mainnet_direct (+ oak::k_rollout_queue, 1 step)",
                          "achieved": achieved, "peak": 157.3, "unit": "TFLOP/s", "frac": achieved / 157.3, "traffic": None,
                          "avg_step_ms": avg_s * 1e3, "algorithmic_flop_per_leaf": main_f + emb_f},
         }), flush=True)
@@ -408,7 +408,7 @@ def leaf_workload(args, torch, dev, rank, local_rank, world, dist):
             "config": {"workload": "configs[2] leaf part: value_inference (encode + embeddings + 768-256-256-256-1 MainNet + "
                                    "sigmoid) over 65536 mid-game states per GPU", "batch_per_gpu": n,
                        "parity": "<= 1e-5 vs numpy oracle pinned by the reference torch mirror"},
-            "roofline": {"bound": "mfma", "kernel": "oak::k_embed_lds (x2) + oak::k_mainnet", "achieved": achieved, "peak": 157.3,
+            "roofline": {"bound": "mfma", "kernel": "oak::k_embed_lds (x2) + oak::k_mainnet_direct", "achieved": achieved, "peak": 157.3,
                          "unit": "TFLOP/s", "frac": achieved / 157.3, "traffic": None, "avg_launch_pair_ms": avg_s * 1e3,
                          "algorithmic_flop_per_leaf": main_f + emb_f, "mainnet_flop_per_leaf": main_f},
         }), flush=True)

@@ -35,6 +35,7 @@ struct NetDev {
   int activation; // 1 relu, 2 clamp
   // main net (value path), rows padded to multiples of 32 with zeros
   const float *w0, *b0, *w1, *b1, *w2, *b2, *w3;
+  const float *w0f, *w1f, *w2f; // the same three weight matrices in MFMA-fragment order (frag_order below), for k_mainnet_direct
   float b3;
   int H, VH; // padded dims
   // policy heads (main-net.h:67-107): fc2 [PHp][H] (rows padded to 32), fc3 [315][PHp] (+ biases)
@@ -323,7 +324,11 @@ static __device__ unsigned long long g_leaf_prof[16];
 #define EL_T0() long long el_t = clock64(); unsigned long long el_acc[8] = {}
 #define EL_MARK(id) do { const long long _t = clock64(); el_acc[id] += (unsigned long long)(_t - el_t); el_t = _t; } while (0)
 #define EL_FLUSH() do { if (threadIdx.x == 0) for (int _i = 0; _i < 8; ++_i) atomicAdd(&g_leaf_prof[_i], el_acc[_i]); } while (0)
+#define MN_T0() long long mn_t = clock64()
+#define MN_MARK(id) do { const long long _t = clock64(); if (threadIdx.x == 0) atomicAdd(&g_leaf_prof[id], (unsigned long long)(_t - mn_t)); mn_t = _t; } while (0)
 #else
+#define MN_T0()
+#define MN_MARK(id)
 #define EL_MARK(id)
 #define EL_T0()
 #define EL_FLUSH()
@@ -752,6 +757,151 @@ __global__ __launch_bounds__(MN_BLOCK) void k_mainnet(MainArgs a) {
   }
 }
 
+// ---- K3, direct-to-register weights (the default).  k_mainnet stages every 64-wide chunk of W through LDS (64 KB of
+// LDS writes, two barriers and a 4x re-read per chunk).  Here W is stored in MFMA-FRAGMENT ORDER on the device
+// (frag_order, done once at load time): for chunk c, n-block nb and float4 index q, lane (r, h) finds
+// W[nb*32 + r][c*64 + h*32 + 4q .. 4q+3] at float4 ((c*NB + nb)*8 + q)*64 + lane -- so a wave's operand load is one
+// fully coalesced 1 KB read straight into the registers the MFMAs consume, double-buffered one chunk ahead.  Within a
+// chunk the MFMA's two k-lanes take columns [0,32) and [32,64) instead of interleaved pairs (A and B agree, so the
+// products are the same).  A comes from LDS: the activation tile for fc1 / value_fc2, and for fc0 the embedding rows,
+// staged 256 columns at a time into the (still unused) activation tile.  Barriers per 64-leaf tile: ~12 instead of ~45.
+constexpr int XP = 256; // embedding columns staged per piece (= MAXH, the activation tile's width)
+
+template <int JNc, bool A_PIECE>
+__device__ __forceinline__ void direct_layer(const float4 *Wf, int K, int NB, const float *a_tile, int a_ld, int nb0, int mi, int r, int h,
+                                             const float *a_global, int a_gld, uint32_t row0, uint32_t n_rows, f32x16 (&acc)[4]) {
+  MN_T0();
+  // B operands of one chunk: JNc n-blocks x 8 float4 per lane
+  float4 b0[JNc][8], b1[JNc][8];
+  const int lane = r + 32 * h, tid = threadIdx.x;
+  const int nch = (K + 63) / 64;
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[j][q] = 0.0f;
+  auto load = [&](float4 (&b)[JNc][8], int c) {
+#pragma unroll
+    for (int j = 0; j < JNc; ++j)
+#pragma unroll
+      for (int q = 0; q < 8; ++q) b[j][q] = Wf[((size_t)(c * NB + nb0 + 2 * j) * 8 + q) * 64 + lane];
+  };
+  auto compute = [&](const float4 (&b)[JNc][8], int c, int piece_base) {
+    const bool half_ok = c * 64 + h * 32 < K; // K is a multiple of 32: the upper half of the last chunk may not exist
+    const float *arow = a_tile + (mi * 32 + r) * a_ld + (c * 64 - piece_base) + h * 32;
+    // all 32 A values of the chunk are read up front, UNCONDITIONALLY (the tile row is always addressable; a lane whose
+    // half of the chunk does not exist discards them below): a predicated LDS read is an exec-masked instruction the
+    // compiler can neither hoist nor batch, and every k-step then waits a full LDS round trip in front of its MFMAs
+    float av[32];
+#pragma unroll
+    for (int s = 0; s < 32; ++s) av[s] = arow[s];
+#pragma unroll
+    for (int s = 0; s < 32; ++s) {
+      const float a_s = half_ok ? av[s] : 0.0f;
+#pragma unroll
+      for (int j = 0; j < JNc; ++j) {
+        const float4 bq = b[j][s >> 2];
+        const float bv = (s & 3) == 0 ? bq.x : (s & 3) == 1 ? bq.y : (s & 3) == 2 ? bq.z : bq.w;
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_s, bv, acc[j], 0, 0, 0);
+      }
+    }
+  };
+  // fc0: the embedding rows go through the activation tile 256 columns at a time (prefetched one piece ahead)
+  constexpr int XR = TM * (XP / 4) / MN_BLOCK; // float4 per thread per piece (16)
+  float4 xr[A_PIECE ? XR : 1];
+  auto fetch_piece = [&](int base) {
+    if (A_PIECE) {
+#pragma unroll
+      for (int u = 0; u < XR; ++u) {
+        const int i = tid + u * MN_BLOCK, row = i / (XP / 4), q = i - row * (XP / 4);
+        xr[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if ((uint32_t)row < n_rows && base + 4 * q < K) xr[u] = *(const float4 *)(a_global + (size_t)(row0 + row) * a_gld + base + 4 * q);
+      }
+    }
+  };
+  auto store_piece = [&]() {
+    if (A_PIECE) {
+      float *xt = const_cast<float *>(a_tile);
+#pragma unroll
+      for (int u = 0; u < XR; ++u) {
+        const int i = tid + u * MN_BLOCK, row = i / (XP / 4), q = i - row * (XP / 4);
+        float *d = xt + row * a_ld + 4 * q; d[0] = xr[u].x; d[1] = xr[u].y; d[2] = xr[u].z; d[3] = xr[u].w;
+      }
+    }
+  };
+  if (A_PIECE) fetch_piece(0);
+  load(b0, 0);
+  int piece_base = 0;
+  for (int c = 0; c < nch; c += 2) {
+    if (A_PIECE && (c * 64) % XP == 0) { // a new piece starts with chunk c (XP / 64 = 4 chunks per piece: c is even, so no piece starts at c + 1)
+      piece_base = c * 64;
+      __syncthreads(); // everyone is done with the previous piece
+      store_piece();
+      __syncthreads();
+      if (piece_base + XP < K) fetch_piece(piece_base + XP); // lands during this piece's MFMAs
+    }
+    if (c + 1 < nch) load(b1, c + 1);
+    MN_MARK(8);
+    compute(b0, c, piece_base);
+    MN_MARK(9);
+    if (c + 1 < nch) {
+      if (c + 2 < nch) load(b0, c + 2);
+      MN_MARK(8);
+      compute(b1, c + 1, piece_base);
+      MN_MARK(9);
+    }
+  }
+  MN_MARK(8);
+}
+
+template <bool A_PIECE>
+__device__ __forceinline__ void direct_layer_jn(const float4 *Wf, int K, int Hout, const float *a_tile, int a_ld, const float *a_global, int a_gld,
+                                                uint32_t row0, uint32_t n_rows, f32x16 (&acc)[4]) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int mi = wave & 1, nb0 = wave >> 1, NB = Hout / 32, r = lane & 31, h = lane >> 5;
+  const int JN = NB - nb0 <= 0 ? 0 : (NB - nb0 + 1) / 2 > 4 ? 4 : (NB - nb0 + 1) / 2; // this wave's n-blocks: nb0, nb0 + 2, ...
+  // every wave takes part in the piece barriers, also one without an n-block of its own (JN = 0 -> runs the JNc = 1
+  // code on n-block nb0 clamped to an existing one and discards the result)
+  if (JN == 4) direct_layer<4, A_PIECE>(Wf, K, NB, a_tile, a_ld, nb0, mi, r, h, a_global, a_gld, row0, n_rows, acc);
+  else if (JN == 3) direct_layer<3, A_PIECE>(Wf, K, NB, a_tile, a_ld, nb0, mi, r, h, a_global, a_gld, row0, n_rows, acc);
+  else if (JN == 2) direct_layer<2, A_PIECE>(Wf, K, NB, a_tile, a_ld, nb0, mi, r, h, a_global, a_gld, row0, n_rows, acc);
+  else direct_layer<1, A_PIECE>(Wf, K, NB, a_tile, a_ld, JN == 1 ? nb0 : 0, mi, r, h, a_global, a_gld, row0, n_rows, acc);
+}
+
+__global__ __launch_bounds__(MN_BLOCK) void k_mainnet_direct(MainArgs a) {
+  extern __shared__ __align__(16) float lds_f[];
+  const NetDev &N = a.net;
+  const int H = N.H, VH = N.VH;
+  const int hld = MAXH + 1;      // the tile doubles as the 256-column staging area of fc0's input
+  float *hs = lds_f;             // TM x hld
+  const uint32_t row0 = blockIdx.x * TM;
+  const uint32_t n_rows = min((uint32_t)TM, a.n - row0);
+  f32x16 acc[4];
+  direct_layer_jn<true>((const float4 *)N.w0f, N.emb_dim, H, hs, hld, a.emb, N.emb_dim, row0, n_rows, acc);
+  __syncthreads(); // every wave done reading the last input piece
+  store_act(acc, N.b0, H, N.activation, hs, hld);
+  __syncthreads();
+  direct_layer_jn<false>((const float4 *)N.w1f, H, H, hs, hld, nullptr, 0, 0, 0, acc);
+  __syncthreads(); // every wave done reading hs
+  store_act(acc, N.b1, H, N.activation, hs, hld);
+  __syncthreads();
+  if (a.h1_out) { // keep fc1's activations for the policy heads
+    for (uint32_t i = threadIdx.x; i < n_rows * (uint32_t)H; i += MN_BLOCK) {
+      const uint32_t row = i / (uint32_t)H, c = i - row * (uint32_t)H;
+      a.h1_out[(size_t)(row0 + row) * H + c] = hs[row * hld + c];
+    }
+  }
+  direct_layer_jn<false>((const float4 *)N.w2f, H, VH, hs, hld, nullptr, 0, 0, 0, acc);
+  __syncthreads();
+  store_act(acc, N.b2, VH, N.activation, hs, hld);
+  __syncthreads();
+  if (threadIdx.x < n_rows) { // value_fc3 + sigmoid (network.h:14,75)
+    const float *hrow = hs + threadIdx.x * hld;
+    float y = N.b3;
+    for (int j = 0; j < VH; ++j) y = fmaf(hrow[j], N.w3[j], y);
+    a.values[row0 + threadIdx.x] = 1.0f / (1.0f + expf(-y));
+  }
+}
+
 // ---- policy heads: value_policy_inference's logits (network.h:102-123, main-net.h:67-107) ----------
 // Encode::Battle::Policy::get_index (encode/battle/policy.h:29-58) on the raw battle bytes
 __device__ __forceinline__ uint32_t policy_index(const uint8_t *side, uint32_t choice) {
@@ -877,6 +1027,22 @@ std::vector<float> pad_rows(const HostAffine &a, uint32_t out_pad, uint32_t in_p
     for (uint32_t i = 0; i < a.in; ++i) t[(size_t)o * in_pad + i] = a.w[(size_t)o * a.in + i];
   return t;
 }
+// MFMA-fragment order of a weight matrix for k_mainnet_direct: chunk c (64 columns), n-block nb (32 rows), float4 q,
+// lane (r, h) -> W[nb*32 + r][c*64 + h*32 + 4q .. 4q+3]; rows / columns beyond the matrix are zero.
+std::vector<float> frag_order(const HostAffine &a, uint32_t out_pad) {
+  const uint32_t nch = (a.in + 63) / 64, NB = out_pad / 32;
+  std::vector<float> f((size_t)nch * NB * 8 * 64 * 4, 0.0f);
+  for (uint32_t c = 0; c < nch; ++c)
+    for (uint32_t nb = 0; nb < NB; ++nb)
+      for (uint32_t q = 0; q < 8; ++q)
+        for (uint32_t lane = 0; lane < 64; ++lane)
+          for (uint32_t e = 0; e < 4; ++e) {
+            const uint32_t row = nb * 32 + (lane & 31), col = c * 64 + (lane >> 5) * 32 + 4 * q + e;
+            if (row < a.out && col < a.in) f[((((size_t)c * NB + nb) * 8 + q) * 64 + lane) * 4 + e] = a.w[(size_t)row * a.in + col];
+          }
+  return f;
+}
+
 std::vector<float> pad_vec(const std::vector<float> &v, uint32_t n) {
   std::vector<float> t(n, 0.0f);
   for (size_t i = 0; i < v.size(); ++i) t[i] = v[i];
@@ -951,6 +1117,9 @@ int oakgpu_net_load_memory(oakgpu_ctx *ctx, const void *bytes, size_t size, oakg
   rc = rc ? rc : upload(net, pad_rows(v2, VH, H), &D.w2);
   rc = rc ? rc : upload(net, pad_vec(v2.b, VH), &D.b2);
   rc = rc ? rc : upload(net, pad_vec(v3.w, VH), &D.w3);
+  rc = rc ? rc : upload(net, frag_order(fc0, H), &D.w0f);
+  rc = rc ? rc : upload(net, frag_order(fc1, H), &D.w1f);
+  rc = rc ? rc : upload(net, frag_order(v2, VH), &D.w2f);
   {
     const HostAffine &q1a = L[8], &q1b = L[9], &q2a = L[10], &q2b = L[11];
     if (q1a.in != fc1.out || q2a.in != fc1.out || q1b.in != q1a.out || q2b.in != q2a.out || q1a.out != q2a.out ||
@@ -1004,6 +1173,8 @@ static int lds_attrs_once() {
   if (e != hipSuccess) return oakgpu_fail_hip((int)e, "hipFuncSetAttribute(k_embed_lds<active>)");
   e = hipFuncSetAttribute((const void *)oak::k_policy, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
   if (e != hipSuccess) return oakgpu_fail_hip((int)e, "hipFuncSetAttribute(k_policy)");
+  e = hipFuncSetAttribute((const void *)oak::k_mainnet_direct, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+  if (e != hipSuccess) return oakgpu_fail_hip((int)e, "hipFuncSetAttribute(k_mainnet_direct)");
   e = hipFuncSetAttribute((const void *)oak::k_mainnet, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
   if (e != hipSuccess) return oakgpu_fail_hip((int)e, "hipFuncSetAttribute(k_mainnet)");
   done = true;
@@ -1063,7 +1234,11 @@ static int leaf_eval_impl(oakgpu_ctx *ctx, oakgpu_net *net, const uint8_t *battl
   oak::MainArgs ma{D, emb, n, values, h1};
   const int hld = (D.H > D.VH ? D.H : D.VH) + 1;
   const size_t mn_lds = (size_t)((oak::TM + oak::MAXH) * (oak::KC_MAIN + 1) + oak::TM * hld) * 4;
-  hipLaunchKernelGGL(oak::k_mainnet, dim3((n + oak::TM - 1) / oak::TM), dim3(oak::MN_BLOCK), mn_lds, stream, ma);
+  static const int main_impl = getenv("OAKGPU_MAINNET_IMPL") ? atoi(getenv("OAKGPU_MAINNET_IMPL")) : 2;
+  if (main_impl == 1) // LDS-staged weights (A/B)
+    hipLaunchKernelGGL(oak::k_mainnet, dim3((n + oak::TM - 1) / oak::TM), dim3(oak::MN_BLOCK), mn_lds, stream, ma);
+  else
+    hipLaunchKernelGGL(oak::k_mainnet_direct, dim3((n + oak::TM - 1) / oak::TM), dim3(oak::MN_BLOCK), (size_t)oak::TM * (oak::MAXH + 1) * 4, stream, ma);
   if (pol) {
     oak::PolicyArgs pa = *pol;
     pa.net = D;

@@ -36,6 +36,7 @@ for kind, env in (("both kinds", None),):
     torch.cuda.synchronize()
     lib.oakgpu_leaf_profile(buf, 0)
     names = ["barrier(prev tile)", "stage Bs + barrier", "issue prefetch", "1a feature lists", "1c first layer", "barrier", "2 mfma", "3 scatter"]
+    print("k_mainnet_direct wave 0: outside compute %d cycles, inside compute (MFMA streams) %d cycles" % (buf[8], buf[9]))
     tot = sum(buf[i] for i in range(8))
     for i, nm in enumerate(names):
         print("%-22s %12d cycles  %5.1f%%" % (nm, buf[i], 100.0 * buf[i] / tot))
