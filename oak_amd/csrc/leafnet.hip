@@ -785,7 +785,11 @@ __device__ __forceinline__ void direct_layer(const float4 *Wf, int K, int NB, co
 #pragma unroll
       for (int q = 0; q < 8; ++q) b[j][q] = Wf[((size_t)(c * NB + nb0 + 2 * j) * 8 + q) * 64 + lane];
   };
-  auto compute = [&](const float4 (&b)[JNc][8], int c, int piece_base) {
+  // the MFMAs of chunk c, with the loads of chunk c + 1 (into the other register set) spread between them one per
+  // k-step: an MFMA occupies the matrix pipe for 64 cycles but the wave for ~8, so everything else the wave has to
+  // issue belongs in those gaps, not in a clump between two MFMA streams during which the pipe runs dry
+  auto compute = [&](const float4 (&b)[JNc][8], float4 (&bn)[JNc][8], auto has_next_tag, int c, int piece_base) {
+    constexpr bool has_next = decltype(has_next_tag)::value;
     const bool half_ok = c * 64 + h * 32 < K; // K is a multiple of 32: the upper half of the last chunk may not exist
     const float *arow = a_tile + (mi * 32 + r) * a_ld + (c * 64 - piece_base) + h * 32;
     // all 32 A values of the chunk are read up front, UNCONDITIONALLY (the tile row is always addressable; a lane whose
@@ -794,8 +798,10 @@ __device__ __forceinline__ void direct_layer(const float4 *Wf, int K, int NB, co
     float av[32];
 #pragma unroll
     for (int s = 0; s < 32; ++s) av[s] = arow[s];
+    const float4 *wn = Wf + ((size_t)((c + 1) * NB + nb0) * 8) * 64 + lane;
 #pragma unroll
     for (int s = 0; s < 32; ++s) {
+      if (has_next && s < 8 * JNc) bn[s >> 3][s & 7] = wn[(size_t)((s >> 3) * 2 * 8 + (s & 7)) * 64];
       const float a_s = half_ok ? av[s] : 0.0f;
 #pragma unroll
       for (int j = 0; j < JNc; ++j) {
@@ -803,6 +809,7 @@ __device__ __forceinline__ void direct_layer(const float4 *Wf, int K, int NB, co
         const float bv = (s & 3) == 0 ? bq.x : (s & 3) == 1 ? bq.y : (s & 3) == 2 ? bq.z : bq.w;
         acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_s, bv, acc[j], 0, 0, 0);
       }
+      __builtin_amdgcn_sched_barrier(0); // keep this step's load next to this step's MFMAs
     }
   };
   // fc0: the embedding rows go through the activation tile 256 columns at a time (prefetched one piece ahead)
@@ -831,24 +838,29 @@ __device__ __forceinline__ void direct_layer(const float4 *Wf, int K, int NB, co
   if (A_PIECE) fetch_piece(0);
   load(b0, 0);
   int piece_base = 0;
-  for (int c = 0; c < nch; c += 2) {
-    if (A_PIECE && (c * 64) % XP == 0) { // a new piece starts with chunk c (XP / 64 = 4 chunks per piece: c is even, so no piece starts at c + 1)
+  auto new_piece = [&](int c) { // fc0 only: chunk c (a multiple of 4) opens the next 256 input columns
+    if (A_PIECE && (c * 64) % XP == 0) {
       piece_base = c * 64;
       __syncthreads(); // everyone is done with the previous piece
       store_piece();
       __syncthreads();
       if (piece_base + XP < K) fetch_piece(piece_base + XP); // lands during this piece's MFMAs
     }
-    if (c + 1 < nch) load(b1, c + 1);
-    MN_MARK(8);
-    compute(b0, c, piece_base);
-    MN_MARK(9);
-    if (c + 1 < nch) {
-      if (c + 2 < nch) load(b0, c + 2);
-      MN_MARK(8);
-      compute(b1, c + 1, piece_base);
-      MN_MARK(9);
-    }
+  };
+  using Yes = std::integral_constant<bool, true>;
+  using No = std::integral_constant<bool, false>;
+  int c = 0;
+  for (; c + 2 < nch; c += 2) { // both chunks of the pair have a successor to prefetch
+    new_piece(c);
+    compute(b0, b1, Yes{}, c, piece_base);
+    compute(b1, b0, Yes{}, c + 1, piece_base);
+  }
+  new_piece(c);
+  if (nch - c == 2) {
+    compute(b0, b1, Yes{}, c, piece_base);
+    compute(b1, b0, No{}, c + 1, piece_base);
+  } else {
+    compute(b0, b1, No{}, c, piece_base);
   }
   MN_MARK(8);
 }
