@@ -181,8 +181,10 @@ def main():
     exchange = Exchange() if (world > 1 or force_dist) else None
     slots = [Slot(i) for i in range(S)]
     torch.cuda.synchronize(dev)
-    for sl in slots:   # loads torch's lazily-loaded reduce kernels up front
+    for sl in slots:   # setup, not warm-up: every slot's first launch allocates its context's scratch buffers and loads
+        sl.step()      # torch's lazily-loaded reduce kernels -- whatever --warmup is, none of that is timed
         sl.finish()
+    torch.cuda.synchronize(dev)
     for k in range(args.warmup):
         slots[k % S].step()
         slots[k % S].finish()
