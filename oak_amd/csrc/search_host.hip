@@ -307,7 +307,9 @@ extern "C" int oakgpu_search(oakgpu_ctx *ctx, oakgpu_net *net, const uint8_t *ba
     bool busy = false;
     ~Slot() { if (own_ctx && ctx) oakgpu_destroy(ctx); }
   };
-  const int n_slots = (!pucb && prm->iterations > B) ? 2 : 1; // PUCB shares the network's policy workspace: one batch at a time
+  // one batch at a time for the bandits with network priors (they share the network's policy workspace) and for
+  // batch = 1, which is the reference's strictly sequential iteration order
+  const int n_slots = (!pucb && B > 1 && prm->iterations > B) ? 2 : 1;
   Slot slots[2];
   for (int si = 0; si < n_slots; ++si) {
     Slot &S = slots[si];
