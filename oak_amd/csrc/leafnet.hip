@@ -380,6 +380,11 @@ __global__ __launch_bounds__(EL_BLOCK) void k_embed_lds(EmbedTileArgs a) {
   const bool pair_ok = (hidden & 1) == 0; // rows of W0^T in global memory are 8-byte aligned only for even widths
   const uint32_t cc0 = on0 ? c0 : 0, cc1 = on1 ? c1 : 0;
   const float bias0 = on0 ? b0[c0] : 0.0f, bias1 = on1 ? b0[c1] : 0.0f;
+  // party slots: the five stat features are present in EVERY item, so their weight rows (W0^T rows 0..4) stay in
+  // registers for the whole kernel instead of being read from LDS 64 times per tile -- 5 of an item's ~11 row reads
+  float wst0[5], wst1[5];
+#pragma unroll
+  for (int k = 0; k < 5; ++k) { wst0[k] = (!ACT && on0) ? w0t[(size_t)k * hidden + c0] : 0.0f; wst1[k] = (!ACT && on1) ? w0t[(size_t)k * hidden + c1] : 0.0f; }
   // MFMA role of this wave: output block (mi, nb) of the 64 x out_pad tile; B fragments stay in registers
   const int mi = wib & 1, nb = wib >> 1, r32 = lane & 31, hh = lane >> 5;
   const bool mfma_wave = nb < NBo;
@@ -466,6 +471,7 @@ __global__ __launch_bounds__(EL_BLOCK) void k_embed_lds(EmbedTileArgs a) {
           doff = dd;
           uint32_t *li = Lidx + i * L::LCAP;
           float *lv = Lval + i * L::LCAP;
+          if (!ACT) cntL = 8; // party slots: list positions 0..4 carry the stat VALUES (rows in registers), rows start at 8
           auto emit = [&](bool valid, uint32_t fidx, float fval, bool to_global) {
             if (!valid) return;
             if (to_global) { Gidx[i * 8 + cntG] = fidx; ++cntG; }
@@ -491,7 +497,8 @@ __global__ __launch_bounds__(EL_BLOCK) void k_embed_lds(EmbedTileArgs a) {
             for (uint32_t j = 0; j < 12; ++j) {
               uint32_t fidx = 0; float fval = 0.0f;
               const bool v = pokemon_feature(j, pk0, pk1, pk2, pk3, pk4, pk5, (dur >> (3 * slot)) & 7, fidx, fval);
-              emit(v, fidx, fval, false);
+              if (j < 5) lv[j] = fval; // always present
+              else emit(v, fidx, fval, false);
             }
           }
           hp_ratio[i] = (float)hp / (float)(pk0 & 0xFFFF);
@@ -530,14 +537,27 @@ __global__ __launch_bounds__(EL_BLOCK) void k_embed_lds(EmbedTileArgs a) {
       float h0[GI], h1[GI];
 #pragma unroll
       for (int t = 0; t < GI; ++t) { h0[t] = bias0; h1[t] = bias1; }
-      uint32_t kmax = 12; // party slots: at most 12 features; actives: the longest of the group's lists (<= 44)
+      uint32_t kmin = 0, kmax = 16; // party slots: stat values at 0..4 (below), at most 7 row features at 8..14
+      if (!ACT) {
+        kmin = 8;
+#pragma unroll
+        for (int t = 0; t < GI; ++t) {
+          const float4 sv = *(const float4 *)(Lval + (ibase + t) * L::LCAP);
+          const float s4 = Lval[(ibase + t) * L::LCAP + 4];
+          h0[t] = fmaf(wst0[0], sv.x, h0[t]); h1[t] = fmaf(wst1[0], sv.x, h1[t]);
+          h0[t] = fmaf(wst0[1], sv.y, h0[t]); h1[t] = fmaf(wst1[1], sv.y, h1[t]);
+          h0[t] = fmaf(wst0[2], sv.z, h0[t]); h1[t] = fmaf(wst1[2], sv.z, h1[t]);
+          h0[t] = fmaf(wst0[3], sv.w, h0[t]); h1[t] = fmaf(wst1[3], sv.w, h1[t]);
+          h0[t] = fmaf(wst0[4], s4, h0[t]); h1[t] = fmaf(wst1[4], s4, h1[t]);
+        }
+      }
       if (ACT) {
         kmax = 0;
 #pragma unroll
         for (int t = 0; t < GI; ++t) { const uint32_t c = __builtin_amdgcn_readfirstlane(meta[ibase + t]) & 0xFF; kmax = c > kmax ? c : kmax; }
       }
 #pragma unroll 1
-      for (uint32_t k = 0; k < kmax; k += 4) {
+      for (uint32_t k = kmin; k < kmax; k += 4) {
 #pragma unroll
         for (int t = 0; t < GI; ++t) {
           const uint4 iv = *(const uint4 *)(Lidx + (ibase + t) * L::LCAP + k);
