@@ -40,6 +40,24 @@ def gather_values(values, n_total=None, force=False):
     return torch.cat([out[r * m:r * m + sizes[r]] for r in range(world)])
 
 
+def gather_round(stage, out=None, async_op=False):
+    """One collective for a whole ROUND of batches in flight: `stage` is [S, n] (row k = the leaf values of batch k of
+    this rank), the result is [world, S, n] on every rank (out[r, k] = rank r's batch k).  Returns (out, work); with
+    async_op the caller keeps `work` and waits for it later (bench.py never makes a batch stream wait for it)."""
+    world = dist.get_world_size()
+    S, n = stage.shape
+    if out is None:
+        out = torch.empty((world, S, n), dtype=stage.dtype, device=stage.device)
+    work = dist.all_gather_into_tensor(out.view(-1), stage.contiguous().view(-1), async_op=async_op)
+    return out, work
+
+
+def round_to_global(out):
+    """[world, S, n] from gather_round -> [S, world * n]: batch k's values in global lane order (rank-major blocks)."""
+    world, S, n = out.shape
+    return out.permute(1, 0, 2).reshape(S, world * n)
+
+
 def per_root_means(all_values, playouts_per_root):
     """Root-parallel MCTS (BASELINE config 4): mean leaf value per root from the gathered lane values."""
     return all_values.view(-1, playouts_per_root).mean(dim=1)

@@ -72,6 +72,39 @@ def test_two_ranks_equal_single_process_ragged():
     assert (_run(257) == _single(257)).all()
 
 
+def _round_worker(rank, world, port, S, n, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oak_amd import dist as D
+    # batch k of rank r holds the values of global lanes [r * n, (r + 1) * n) of batch k: value = 1000 k + global lane
+    stage = torch.stack([1000.0 * k + torch.arange(rank * n, (rank + 1) * n, dtype=torch.float32) for k in range(S)])
+    out, work = D.gather_round(stage, async_op=True)
+    work.wait()
+    if rank == 1:
+        q.put(D.round_to_global(out).numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_round_gather_puts_every_batch_in_global_lane_order():
+    """bench.py's exchange: ONE all-gather per round of S batches in flight ([S, n] per rank -> [world, S, n])."""
+    S, n, world = 5, 37, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_round_worker, args=(r, world, port, S, n, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    expect = np.stack([1000.0 * k + np.arange(world * n, dtype=np.float32) for k in range(S)])
+    assert got.shape == (S, world * n) and (got == expect).all()
+
+
 def test_shard_range_partition():
     from oak_amd.dist import shard_range
     for n in (0, 1, 7, 64, 65536, 65537):
