@@ -1007,14 +1007,15 @@ int oakgpu_random_ou_battles_dev(oakgpu_ctx *c, uint64_t seed0, uint32_t n, uint
 
 // ---- host-buffer conveniences (PCIe-inclusive; never the benchmarked path) ------------------
 namespace {
-struct DevBuf {
+struct DevBuf { // stream-ordered allocation from the device's memory pool: after the first call no hipMalloc / hipFree
   void *p = nullptr;
   size_t bytes = 0;
-  hipError_t alloc(size_t b) { bytes = b; return b ? hipMalloc(&p, b) : hipSuccess; }
-  ~DevBuf() { if (p) (void)hipFree(p); }
+  hipStream_t s = nullptr;
+  hipError_t alloc(size_t b, hipStream_t stream) { bytes = b; s = stream; return b ? hipMallocAsync(&p, b, stream) : hipSuccess; }
+  ~DevBuf() { if (p) (void)hipFreeAsync(p, s); }
 };
 } // namespace
-#define UP(buf, host, nbytes) do { HIPCHK((buf).alloc(nbytes)); if (host) HIPCHK(hipMemcpyAsync((buf).p, host, nbytes, hipMemcpyHostToDevice, c->stream)); } while (0)
+#define UP(buf, host, nbytes) do { HIPCHK((buf).alloc(nbytes, c->stream)); if (host) HIPCHK(hipMemcpyAsync((buf).p, host, nbytes, hipMemcpyHostToDevice, c->stream)); } while (0)
 #define DOWN(host, buf) do { if (host) HIPCHK(hipMemcpyAsync(host, (buf).p, (buf).bytes, hipMemcpyDeviceToHost, c->stream)); } while (0)
 
 int oakgpu_rollout(oakgpu_ctx *c, const uint8_t *battles, const uint8_t *durations, const uint8_t *results_in,
