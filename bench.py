@@ -48,7 +48,8 @@ def main():
     ap.add_argument("--steps", type=int, default=160)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=65536, help="playouts per GPU")
-    ap.add_argument("--streams", type=int, default=20, help="independent batches in flight (HIP streams)")
+    ap.add_argument("--group", type=int, default=20, help="batches per group launch (oakgpu_rollout_group_dev), <= 64")
+    ap.add_argument("--streams", type=int, default=2, help="groups in flight (contexts / HIP streams)")
     ap.add_argument("--playouts-per-lane", type=int, default=2,
                     help="k > 1: persistent n/k lanes per batch that refill from an atomic playout queue")
     ap.add_argument("--workload", choices=["rollout", "leaf", "config3", "search"], default="rollout",
@@ -87,112 +88,97 @@ def main():
     if args.workload == "search":
         return search_workload(args, torch, dev, rank, local_rank, world, dist)
 
+    out = rollout_workload(args, torch, dev, rank, local_rank, world, dist, force_dist)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1 or force_dist:
+        dist.destroy_process_group()
+
+
+def rollout_workload(args, torch, dev, rank, local_rank, world, dist, force_dist=False):
+    """BASELINE configs[1].  The K timed steps (= K independent 65,536-playout batches) are submitted in GROUPS of up to
+    `--group` batches: one oakgpu_rollout_group_dev launch drains a whole group through one playout queue, so a group has
+    ONE tail (its longest playout) instead of one per batch.  Groups alternate over `--streams` contexts (HIP streams,
+    each with its own batch buffers), so with more than one group the next group's launch fills the SIMDs the previous
+    group's tail leaves idle.  Returns the JSON record (rank 0; None elsewhere)."""
+    import numpy as np
+    from oak_amd import _lib
+    from oak_amd import dist as oakdist
+    from oak_amd.engine import Context
     n = args.batch
-    S = max(1, min(args.streams, args.steps if args.steps > 0 else 1))
+    G = max(1, min(args.group, 64))
     u8 = torch.uint8
 
-    def P(t):
-        return C.c_void_p(t.data_ptr())
+    def plan(k):   # k steps -> group sizes
+        return [G] * (k // G) + ([k % G] if k % G else [])
+    timed, warm = plan(args.steps), plan(args.warmup)
+    S = max(1, min(args.streams, len(timed)))
+    gmax = max(timed + warm + [1])
 
     class Slot:
-        """One batch in flight: its own context (HIP stream) and buffers."""
+        """One group in flight: a context (HIP stream) and the buffers of its `gmax` batches."""
 
         def __init__(self, idx):
             self.ctx = Context(local_rank)   # owns a dedicated non-blocking HIP stream
             self.stream = torch.cuda.ExternalStream(self.ctx.stream_ptr(), device=dev)
             self.ctx.ensure_ou_pools()
             self.ctx.set_playouts_per_lane(args.playouts_per_lane)
-            self.battles = torch.empty((n, 384), dtype=u8, device=dev)
-            self.durations = torch.empty((n, 8), dtype=u8, device=dev)
-            self.prng = torch.empty((n, 8), dtype=u8, device=dev)
-            self.results_in = torch.empty((n,), dtype=u8, device=dev)
-            self.results = torch.empty((n,), dtype=u8, device=dev)
-            self.steps_out = torch.zeros((n,), dtype=torch.int32, device=dev)
-            self.values = torch.empty((n,), dtype=torch.float32, device=dev)
+            self.battles = torch.empty((gmax, n, 384), dtype=u8, device=dev)
+            self.durations = torch.empty((gmax, n, 8), dtype=u8, device=dev)
+            self.prng = torch.empty((gmax, n, 8), dtype=u8, device=dev)
+            self.results_in = torch.empty((gmax, n), dtype=u8, device=dev)
+            self.results = torch.empty((gmax, n), dtype=u8, device=dev)
+            self.steps_out = torch.zeros((gmax, n), dtype=torch.int32, device=dev)
+            self.values = torch.empty((gmax, n), dtype=torch.float32, device=dev)
             self.total = torch.zeros((), dtype=torch.int64, device=dev)
-            # synthetic input, generated on device; lane seeds disjoint across ranks and slots
-            seed0 = oakdist.lane_seed0(SEED0 + idx * n * world, n * world, rank, world)
-            _lib.check(self.ctx.lib.oakgpu_random_ou_battles_dev(self.ctx.handle, C.c_uint64(seed0), n, P(self.battles),
-                                                                 P(self.durations), P(self.prng), P(self.results_in)))
+            self.gathered = torch.empty((world, gmax, n), dtype=torch.float32, device=dev) if exchange else None
+            self.gather_done = None
+            self.descs = (_lib.RolloutBatch * gmax)()
+            for k in range(gmax):
+                # synthetic input, generated on device; lane seeds disjoint across ranks, slots and batches
+                seed0 = oakdist.lane_seed0(SEED0 + (idx * gmax + k) * n * world, n * world, rank, world)
+                _lib.check(self.ctx.lib.oakgpu_random_ou_battles_dev(
+                    self.ctx.handle, C.c_uint64(seed0), n, C.c_void_p(self.battles[k].data_ptr()), C.c_void_p(self.durations[k].data_ptr()),
+                    C.c_void_p(self.prng[k].data_ptr()), C.c_void_p(self.results_in[k].data_ptr())))
+                self.descs[k] = _lib.RolloutBatch(self.battles[k].data_ptr(), self.durations[k].data_ptr(), self.results_in[k].data_ptr(),
+                                                  self.prng[k].data_ptr(), n, self.results[k].data_ptr(), self.steps_out[k].data_ptr(),
+                                                  self.values[k].data_ptr(), None, None)
 
-        def step(self):
-            _lib.check(self.ctx.lib.oakgpu_rollout_dev(self.ctx.handle, P(self.battles), P(self.durations), P(self.results_in),
-                                                       P(self.prng), n, MAX_STEPS, 0, P(self.results), P(self.steps_out),
-                                                       P(self.values), None, None))
+        def run(self, count):
+            if self.gather_done is not None:          # the previous gather of this slot still reads self.values
+                self.stream.wait_event(self.gather_done)
+            _lib.check(self.ctx.lib.oakgpu_rollout_group_dev(self.ctx.handle, self.descs, count, MAX_STEPS, 0))
 
-        def finish(self):
+        def finish(self, count):
             with torch.cuda.stream(self.stream):
-                self.total += self.steps_out.sum(dtype=torch.int64)   # tiny reduction kernel, inside the timed region
-                if exchange is not None:
-                    exchange.add(self)
+                self.total += self.steps_out[:count].sum(dtype=torch.int64)   # one small reduction kernel, inside the timed region
+            if exchange:
+                # the path's single exchange: ONE RCCL all-gather of the group's fp32 leaf values to every rank, on its
+                # own stream behind the group's launch; only the slot's NEXT group waits for it (buffer reuse)
+                ev = torch.cuda.Event()
+                ev.record(self.stream)
+                xstream.wait_event(ev)
+                with torch.cuda.stream(xstream):
+                    oakdist.gather_round(self.values[:count], self.gathered[:, :count] if count == gmax else None)
+                    self.gather_done = torch.cuda.Event()
+                    self.gather_done.record(xstream)
 
-    class Exchange:
-        """The path's single exchange: an RCCL all-gather of fp32 leaf values to every rank.  One collective carries the
-        values of ALL batches in flight (S x 256 KiB per rank: fewer, larger collectives): every batch copies its values
-        into its row of a staging buffer on its own stream, and when the last row of a round has been issued one
-        all-gather runs on a separate stream behind those copies.  Nothing waits for it but the end of the run -- a
-        batch stream that waited for a collective would wait for every earlier batch's rollout too (a process group's
-        collectives execute in issue order), the 20 batches would fall into lock-step and their tails would stop
-        overlapping; and a collective kernel launched once per batch has to squeeze into a saturated GPU 1,300 times a
-        second."""
-
-        def __init__(self):
-            self.stream = torch.cuda.Stream(device=dev)
-            self.ring = [(torch.empty((S, n), dtype=torch.float32, device=dev),
-                          torch.empty((world, S, n), dtype=torch.float32, device=dev)) for _ in range(3)]
-            self.works = [None, None, None]
-            self.round, self.filled, self.events = 0, 0, []
-            with torch.cuda.stream(self.stream):     # first use of a buffer pair by the collective library is slow
-                for stage, out in self.ring:        # (registration): pay it here, not in the timed region
-                    oakdist.gather_round(stage, out)
-            self.stream.synchronize()
-
-        def add(self, slot):            # called under the slot's stream context
-            stage, _ = self.ring[self.round % 3]
-            if self.filled == 0 and self.works[self.round % 3] is not None:
-                self.works[self.round % 3].wait()      # three rounds old: long finished
-            stage[self.filled].copy_(slot.values)
-            ev = torch.cuda.Event()
-            ev.record(slot.stream)
-            self.events.append(ev)
-            self.filled += 1
-            if self.filled == S:
-                self.flush()
-
-        def flush(self):
-            if self.filled == 0:
-                return
-            stage, out = self.ring[self.round % 3]
-            for ev in self.events:
-                self.stream.wait_event(ev)
-            with torch.cuda.stream(self.stream):
-                self.works[self.round % 3] = oakdist.gather_round(stage, out, async_op=True)[1]
-            self.round += 1
-            self.filled, self.events = 0, []
-
-        def drain(self):
-            self.flush()
-            with torch.cuda.stream(self.stream):
-                for w in self.works:
-                    if w is not None:
-                        w.wait()
-            self.stream.synchronize()
-
-    exchange = Exchange() if (world > 1 or force_dist) else None
+    exchange = world > 1 or force_dist
+    xstream = torch.cuda.Stream(device=dev) if exchange else None
     slots = [Slot(i) for i in range(S)]
     torch.cuda.synchronize(dev)
-    for sl in slots:   # setup, not warm-up: every slot's first launch allocates its context's scratch buffers and loads
-        sl.step()      # torch's lazily-loaded reduce kernels -- whatever --warmup is, none of that is timed
-        sl.finish()
+    for sl in slots:   # setup, not warm-up: every slot's first launch allocates its context's tables and loads torch's
+        sl.run(gmax)   # lazily-loaded reduce kernels (and the collective registers its buffers) -- none of that is timed
+        sl.finish(gmax)
     torch.cuda.synchronize(dev)
-    for k in range(args.warmup):
-        slots[k % S].step()
-        slots[k % S].finish()
+    for k, count in enumerate(warm):
+        slots[k % S].run(count)
+        slots[k % S].finish(count)
     torch.cuda.synchronize(dev)
     for sl in slots:
         sl.total.zero_()
 
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in timed]
     for k, (a, b) in enumerate(ev):   # force event creation outside the timed region
         a.record(slots[k % S].stream)
         b.record(slots[k % S].stream)
@@ -200,15 +186,13 @@ def main():
         dist.barrier()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
-    for k in range(args.steps):
+    for k, count in enumerate(timed):
         sl = slots[k % S]
         ev[k][0].record(sl.stream)
-        sl.step()
+        sl.run(count)
         ev[k][1].record(sl.stream)
-        sl.finish()
-    if exchange is not None:     # every gather of the timed region has completed before the clock stops
-        exchange.drain()
-    torch.cuda.synchronize(dev)
+        sl.finish(count)
+    torch.cuda.synchronize(dev)      # includes every gather of the timed region (xstream)
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
@@ -216,6 +200,12 @@ def main():
     total_steps = sum(sl.total for sl in slots)
     my_steps = int(total_steps.item())
     kern_ms = [a.elapsed_time(b) for a, b in ev]
+    if exchange and world > 1:       # one-off check of the exchange: rank r's rows of the last full gather are rank r's values
+        sl = slots[0]
+        mine = sl.values.clone()
+        probe = torch.empty((world, gmax, n), dtype=torch.float32, device=dev)
+        oakdist.gather_round(mine, probe)
+        assert torch.equal(probe[rank], mine), "all-gather returned a different row for this rank"
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -225,72 +215,73 @@ def main():
         all_steps = int(s.item())
     else:
         all_steps = my_steps
+    if rank != 0:
+        return None
 
-    if rank == 0:
-        value = all_steps / elapsed
-        avg_kernel_s = (sum(kern_ms) / len(kern_ms)) / 1e3
-        steps_per_launch = my_steps / args.steps
-        achieved = steps_per_launch * ALGO_BYTES_PER_STEP / avg_kernel_s / 1e9
-        traffic, valu = None, None
-        tp = os.path.join(ROOT, "profiles", "traffic.json")   # rocprofv3 --pmc results, per step (tools/summarize_profile.py)
-        if os.path.exists(tp):
-            try:
-                tj = json.load(open(tp))
-                traffic = tj.get("k_rollout_hbm_bytes_per_launch")
-                valu = tj.get("valu_wave_insts_per_step")
-            except Exception:
-                traffic = None
-        out = {
-            "metric": "turn-steps/s (batched playouts)",
-            "value": value,
-            "unit": "turn-steps/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "u16",
-            "data": "synthetic",
-            "config": {
-                "workload": "configs[1]: batch=65536 random OU team pairs per GPU, pure random-policy rollout to "
-                            "terminal (cap 1000 turn-steps)",
-                "batch_per_gpu": n,
-                "playouts_per_s": n * world * args.steps / elapsed,
-                "mean_turn_steps_per_playout": all_steps / (n * world * args.steps),
-                "parallelism": ("lanes sharded by rank; RCCL all-gather of the fp32 leaf values, one collective per %d batches in flight" % S if world > 1
-                                else "single GPU") + "; %d independent batches in flight on %d HIP streams" % (S, S),
-                "streams": S,
-                "playouts_per_lane": args.playouts_per_lane,
-                "parity": "bit-exact vs this repo's CPU oracle (libpkmn parity unpinned, see DESIGN.md)",
-            },
-            "roofline": {
-                "bound": "hbm",
-                "kernel": "oak::k_rollout_queue (one step = its regrouping dispatches on one stream)",
-                "achieved": achieved,
-                "peak": HBM_PEAK_GBPS,
-                "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBPS,
-                "traffic": traffic,
-                "avg_kernel_ms": avg_kernel_s * 1e3,
-                "concurrent_launches": S,
-                "achieved_aggregate": value / world * ALGO_BYTES_PER_STEP / 1e9,
-                "algorithmic_bytes_per_turn_step": ALGO_BYTES_PER_STEP,
-                "turn_steps_per_launch": steps_per_launch,
-            },
-        }
-        if valu:
-            # the kernel is integer-VALU bound, not HBM bound: wave-instructions issued per step (PMC
-            # SQ_INSTS_VALU, committed in profiles/) against 1024 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction
-            peak = 1024 * 2.4e9 / 4
-            out["roofline"]["valu_issue"] = {"wave_insts_per_step": valu, "achieved_ginst_s": valu / (elapsed / args.steps) / 1e9,
-                                             "peak_ginst_s": peak / 1e9, "frac": valu / (elapsed / args.steps) / peak}
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(n)
-        print(json.dumps(out), flush=True)
-    if world > 1 or force_dist:
-        dist.destroy_process_group()
+    value = all_steps / elapsed
+    # roofline of the dominant kernel: one launch = one group; algorithmic bytes = 802 B x the turn-steps the launch
+    # executed; duration = HIP events around the launch on its own stream
+    launch_s = sum(kern_ms) / 1e3
+    achieved = my_steps * ALGO_BYTES_PER_STEP / launch_s / 1e9
+    traffic, valu = None, None
+    tp = os.path.join(ROOT, "profiles", "traffic.json")   # rocprofv3 --pmc results (tools/summarize_profile.py)
+    if os.path.exists(tp):
+        try:
+            tj = json.load(open(tp))
+            per_step = tj.get("k_rollout_hbm_bytes_per_turn_step")
+            traffic = per_step * my_steps / len(timed) if per_step else None
+            valu = tj.get("valu_wave_insts_per_turn_step")
+        except Exception:
+            traffic = None
+    out = {
+        "metric": "turn-steps/s (batched playouts)",
+        "value": value,
+        "unit": "turn-steps/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "u16",
+        "data": "synthetic",
+        "config": {
+            "workload": "configs[1]: batch=65536 random OU team pairs per GPU, pure random-policy rollout to "
+                        "terminal (cap 1000 turn-steps)",
+            "batch_per_gpu": n,
+            "playouts_per_s": n * world * args.steps / elapsed,
+            "mean_turn_steps_per_playout": all_steps / (n * world * args.steps),
+            "parallelism": ("lanes sharded by rank; one RCCL all-gather of the fp32 leaf values per group; " if world > 1 else "single GPU; ") +
+                           "steps submitted as %d group launch(es) of up to %d batches over %d HIP stream(s)" % (len(timed), G, S),
+            "group": G, "groups": len(timed), "streams": S,
+            "playouts_per_lane": args.playouts_per_lane,
+            "parity": "bit-exact vs this repo's CPU oracle (libpkmn parity unpinned, see DESIGN.md)",
+        },
+        "roofline": {
+            "bound": "hbm",
+            "kernel": "oak::k_rollout_queue (one launch = one group of batches)",
+            "achieved": achieved,
+            "peak": HBM_PEAK_GBPS,
+            "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBPS,
+            "traffic": traffic,
+            "avg_launch_ms": launch_s / len(timed) * 1e3,
+            "launches": len(timed),
+            "algorithmic_bytes_per_turn_step": ALGO_BYTES_PER_STEP,
+            "turn_steps_per_launch": my_steps / len(timed),
+        },
+    }
+    if valu:
+        # the kernel is integer-VALU bound, not HBM bound: wave-instructions issued per turn-step (PMC
+        # SQ_INSTS_VALU, committed in profiles/) against 1024 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction
+        peak = 1024 * 2.4e9 / 4
+        ach = valu * my_steps / elapsed
+        out["roofline"]["valu_issue"] = {"wave_insts_per_turn_step": valu, "achieved_ginst_s": ach / 1e9,
+                                         "peak_ginst_s": peak / 1e9, "frac": ach / peak}
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(n)
+    return out
 
 
 def leaf_workload(args, torch, dev, rank, local_rank, world, dist):

@@ -48,7 +48,9 @@ int oakgpu_set_playouts_per_lane(oakgpu_ctx *ctx, int k);
 /* Regrouping of the queue schedule's long tail: the rollout runs as `rounds` dispatches (1..8, default 4); in
  * every round but the last a wave whose queue is dry and that has fewer than `suspend_below` (0..64, default 32)
  * playouts still running parks them (bit-exact state image) for the next round, which packs them 64 to a wave
- * again on 1/`shrink` (>= 1, default 3) of the waves.  rounds = 1 or suspend_below = 0 disables it. */
+ * again on 1/`shrink` (>= 1, default 3) of the waves.  rounds = 1 or suspend_below = 0 disables it.  By default a
+ * launch large enough to keep every SIMD's wave slots occupied runs as a single dispatch (its tail is bound by the
+ * longest playout, not by idle lanes); calling this function applies the given setting to every launch. */
 int oakgpu_set_regroup(oakgpu_ctx *ctx, int rounds, int suspend_below, int shrink);
 int oakgpu_device_count(void);
 
@@ -73,6 +75,23 @@ int oakgpu_rollout(oakgpu_ctx *ctx, const uint8_t *battles, const uint8_t *durat
                    const uint8_t *results_in, uint8_t *prng_state, uint32_t n, uint32_t max_steps, int prep,
                    uint8_t *results_out, uint32_t *steps_out, float *values_out, uint8_t *battles_out,
                    uint8_t *durations_out);
+
+/* Group launch: `count` (<= 64) independent batches drained by ONE launch through one playout queue, so the group has
+ * a single tail instead of one per batch (root-parallel MCTS submits its roots' batches together).  Same per-batch
+ * contract as oakgpu_rollout_dev (outputs may alias inputs; results never depend on the grouping); batches with
+ * n == 0 are skipped.  oakgpu_rollout_dev is the group of one. */
+typedef struct {
+  const uint8_t *battles, *durations, *results_in;
+  uint8_t *prng_state;
+  uint32_t n;
+  uint8_t *results_out;
+  uint32_t *steps_out;
+  float *values_out;
+  uint8_t *battles_out, *durations_out; /* nullable */
+} oakgpu_rollout_batch;
+int oakgpu_rollout_group_dev(oakgpu_ctx *ctx, const oakgpu_rollout_batch *batches, uint32_t count, uint32_t max_steps,
+                             int prep);
+int oakgpu_rollout_group(oakgpu_ctx *ctx, const oakgpu_rollout_batch *batches, uint32_t count, uint32_t max_steps, int prep);
 
 /* ---- batched pkmn_gen1_battle_update (call sites mcts.h:278,350,463,479; wrapper
  * libpkmn/pkmn.h:106-139).  In place on battles; durations in/out (chance options);

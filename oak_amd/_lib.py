@@ -9,13 +9,19 @@ LIB_PATH = os.path.join(_HERE, "liboakgpu.so")
 # every symbol include/oakgpu.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
     "oakgpu_create", "oakgpu_destroy", "oakgpu_last_error", "oakgpu_set_stream", "oakgpu_get_stream", "oakgpu_synchronize", "oakgpu_set_playouts_per_lane", "oakgpu_set_regroup",
-    "oakgpu_device_count", "oakgpu_rollout_dev", "oakgpu_rollout", "oakgpu_update_dev", "oakgpu_update",
+    "oakgpu_device_count", "oakgpu_rollout_dev", "oakgpu_rollout", "oakgpu_rollout_group_dev", "oakgpu_rollout_group", "oakgpu_update_dev", "oakgpu_update",
     "oakgpu_choices_dev", "oakgpu_choices", "oakgpu_init_battles_dev", "oakgpu_init_battles",
     "oakgpu_set_ou_pools", "oakgpu_random_ou_battles_dev",
     "oakgpu_net_load", "oakgpu_net_load_memory", "oakgpu_net_free", "oakgpu_net_shape",
     "oakgpu_leaf_eval_dev", "oakgpu_leaf_eval", "oakgpu_leaf_eval_policy_dev", "oakgpu_leaf_eval_policy",
     "oakgpu_tree_step_dev", "oakgpu_search", "oakgpu_poke_engine_eval_dev", "oakgpu_poke_engine_eval",
 ]
+
+
+class RolloutBatch(C.Structure):      # oakgpu_rollout_batch (include/oakgpu.h)
+    _fields_ = [("battles", C.c_void_p), ("durations", C.c_void_p), ("results_in", C.c_void_p), ("prng_state", C.c_void_p),
+                ("n", C.c_uint32), ("results_out", C.c_void_p), ("steps_out", C.c_void_p), ("values_out", C.c_void_p),
+                ("battles_out", C.c_void_p), ("durations_out", C.c_void_p)]
 
 
 class SearchParams(C.Structure):      # oakgpu_search_params (include/oakgpu.h)
@@ -67,6 +73,8 @@ def load():
     lib.oakgpu_set_regroup.argtypes = [vp, i32, i32, i32]
     lib.oakgpu_rollout_dev.argtypes = [vp, vp, vp, vp, vp, u32, u32, i32, vp, vp, vp, vp, vp]
     lib.oakgpu_rollout.argtypes = [vp, vp, vp, vp, vp, u32, u32, i32, vp, vp, vp, vp, vp]
+    lib.oakgpu_rollout_group_dev.argtypes = [vp, C.POINTER(RolloutBatch), u32, u32, i32]
+    lib.oakgpu_rollout_group.argtypes = [vp, C.POINTER(RolloutBatch), u32, u32, i32]
     lib.oakgpu_poke_engine_eval_dev.argtypes = [vp, vp, u32, C.c_float, vp, vp]
     lib.oakgpu_poke_engine_eval.argtypes = [vp, vp, u32, C.c_float, vp, vp]
     lib.oakgpu_tree_step_dev.argtypes = [vp, vp, vp, vp, vp, vp, u32, u32, vp, vp, vp, vp, vp]

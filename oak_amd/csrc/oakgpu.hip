@@ -15,6 +15,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <string>
+#include <vector>
 
 #include "../../include/oakgpu.h"
 #include "gen1_device.hpp"
@@ -266,54 +267,93 @@ __global__ __launch_bounds__(BLK, 2) void k_rollout_regs(RolloutArgs a) {
 // launch (`list_in` = that list) packs the survivors 64 to a wave again.  The last round runs with
 // suspend_below = 0.  Serialisation is the engine's own bit-exact load/store, so results do not change.
 struct RoundArgs {
-  const uint32_t *list_in;  // nullptr: round 0, playout k of the caller's arrays
+  const uint32_t *list_in;  // nullptr: round 0, playout k of the group
   const uint32_t *n_in;     // device count of list_in
   uint32_t *list_out;       // suspended playouts of this round
   uint32_t *count_out;
-  uint8_t *sb;              // scratch: n x 384 battle images
-  uint8_t *sd;              // scratch: n x 8 durations
-  uint8_t *sres;            // scratch: n results
+  uint8_t *sb;              // scratch: total x 384 battle images
+  uint8_t *sd;              // scratch: total x 8 durations
+  uint8_t *sres;            // scratch: total results
   uint32_t suspend_below;
   uint32_t *queue;          // this round's queue head
 };
 
+// One launch drains a GROUP of independent batches (oakgpu_rollout_group_dev): the queue hands out GLOBAL playout
+// indices 0 .. total-1, batch b owns [start_b, start_b + n_b).  A 20-batch group has ONE tail instead of twenty.
+struct BatchDesc {
+  const uint8_t *battles, *durations, *results_in;
+  uint8_t *prng;
+  uint8_t *results_out;
+  uint32_t *steps_out;
+  float *values_out;
+  uint8_t *battles_out, *durations_out;
+  uint32_t start, n;
+};
+constexpr int MAX_GROUP = 64;
+struct GroupArgs {
+  const BatchDesc *table; // device memory, `count` entries
+  uint32_t count, total, max_steps;
+  int prep;
+};
+
 // The kernel's pointer arguments are needed only when a lane is (re)filled or retired, but as kernel arguments
 // they would sit in ~40 SGPRs for the whole turn loop, whose nested divergent control flow needs those SGPRs
-// for exec masks (the overflow is spilled to VGPR lanes: v_writelane / v_readlane in the hot path).  So thread 0
-// parks them in LDS once and the cold paths read them back (wave-uniform values in VGPRs).
+// for exec masks (the overflow is spilled to VGPR lanes: v_writelane / v_readlane in the hot path).  So the cold
+// arguments are parked in LDS once (with the batches' start offsets) and the cold paths read them back.
 struct ColdArgs {
-  RolloutArgs a;
+  GroupArgs g;
   RoundArgs q;
+  uint32_t starts[MAX_GROUP];
 };
 constexpr int COLD_LDS_BYTES = (sizeof(ColdArgs) + 15) & ~15;
 template <class P>
 __device__ __forceinline__ P cold_ptr(const lds_u32 *cold, size_t byte_off) {
   return (P)((uint64_t)cold[byte_off / 4] | ((uint64_t)cold[byte_off / 4 + 1] << 32));
 }
-#define COLD_A(field, type) cold_ptr<type>(cold, offsetof(ColdArgs, a) + offsetof(RolloutArgs, field))
 #define COLD_Q(field, type) cold_ptr<type>(cold, offsetof(ColdArgs, q) + offsetof(RoundArgs, field))
+// batch of global playout idx: largest b with starts[b] <= idx (binary search over the LDS copy)
+__device__ __forceinline__ const BatchDesc *find_batch(const lds_u32 *cold, uint32_t idx) {
+  const uint32_t count = cold[(offsetof(ColdArgs, g) + offsetof(GroupArgs, count)) / 4];
+  const lds_u32 *starts = cold + offsetof(ColdArgs, starts) / 4;
+  uint32_t lo = 0, hi = count; // invariant: starts[lo] <= idx < starts[hi] (starts[count] = +inf)
+  while (hi - lo > 1) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (starts[mid] <= idx) lo = mid; else hi = mid;
+  }
+  return cold_ptr<const BatchDesc *>(cold, offsetof(ColdArgs, g) + offsetof(GroupArgs, table)) + lo;
+}
+
+#ifdef OAKGPU_TIMELINE
+// profile build only (tools/timeline.py): per wave of the queue kernel {start, first dry refill, exit} on the
+// 100 MHz wall clock + turn-steps executed
+static __device__ unsigned long long g_timeline[5 * 16384];
+#define OAK_TL(slot, v) do { const unsigned long long tl_v = (v); if (wl == 0 && blockIdx.x < 16384) g_timeline[5 * blockIdx.x + (slot)] = tl_v; } while (0)
+#else
+#define OAK_TL(slot, v)
+#endif
 
 template <int BLK, int WPS>
-__global__ __launch_bounds__(BLK, WPS) void k_rollout_queue(RolloutArgs a_in, RoundArgs q_in) {
+__global__ __launch_bounds__(BLK, WPS) void k_rollout_queue(GroupArgs g_in, RoundArgs q_in) {
   extern __shared__ __align__(16) uint8_t smem[];
   lds_u32 *party = (lds_u32 *)smem;
   using ER = EngineR<BLK, false>;
   Tables T = stage_default_tables((lds_u8 *)smem + ER::PARTY_WORDS * BLK * 4);
   lds_u32 *cold = (lds_u32 *)((lds_u8 *)smem + ER::PARTY_WORDS * BLK * 4 + TABLE_LDS_PAD);
   if (threadIdx.x == 0) {
-    const ColdArgs c{a_in, q_in};
+    struct { GroupArgs g; RoundArgs q; } c{g_in, q_in};
     const uint32_t *src = (const uint32_t *)&c;
 #pragma unroll
-    for (uint32_t i = 0; i < sizeof(ColdArgs) / 4; ++i) cold[i] = src[i];
+    for (uint32_t i = 0; i < offsetof(ColdArgs, starts) / 4; ++i) cold[i] = src[i];
   }
+  for (uint32_t i = threadIdx.x; i < g_in.count; i += BLK) cold[offsetof(ColdArgs, starts) / 4 + i] = g_in.table[i].start;
   __syncthreads();
   const uint32_t tid = threadIdx.x, wl = tid & 63;
   constexpr uint32_t NONE = 0xFFFFFFFFu, DONE = 0xFFFFFFFEu;
   // the few scalars the turn loop itself needs stay in SGPRs
   const bool resume = q_in.list_in != nullptr; // a later round: playouts come from the previous round's suspended list
-  const uint32_t total = resume ? *q_in.n_in : a_in.n;
-  const uint32_t max_steps = a_in.max_steps, suspend_below = q_in.suspend_below;
-  const bool prep = !resume && a_in.prep;
+  const uint32_t total = resume ? *q_in.n_in : g_in.total;
+  const uint32_t max_steps = g_in.max_steps, suspend_below = q_in.suspend_below;
+  const bool prep = !resume && g_in.prep;
   ER e;
   e.m = party + tid;
   e.T = T;
@@ -322,6 +362,11 @@ __global__ __launch_bounds__(BLK, WPS) void k_rollout_queue(RolloutArgs a_in, Ro
   uint32_t idx = NONE, result = 0, steps = 0;
   bool dry = false; // wave-uniform: the queue has handed out its last playout
   OAK_PROF_ZERO();
+  OAK_TL(0, wall_clock64());
+#ifdef OAKGPU_TIMELINE
+  bool tl_dry = false;
+  unsigned long long tl_steps = 0;
+#endif
   for (;;) {
     const bool need = idx == NONE;
     const uint64_t mask = __ballot(need);
@@ -331,27 +376,35 @@ __global__ __launch_bounds__(BLK, WPS) void k_rollout_queue(RolloutArgs a_in, Ro
       if (wl == 0) base = atomicAdd(COLD_Q(queue, uint32_t *), (uint32_t)__popcll(mask));
       base = __shfl(base, 0, 64);
       dry = base + (uint32_t)__popcll(mask) >= total;
+#ifdef OAKGPU_TIMELINE
+      if (dry && !tl_dry) { tl_dry = true; OAK_TL(1, wall_clock64()); }
+#endif
       if (need) {
         const uint32_t my = base + (uint32_t)__popcll(mask & ((1ull << wl) - 1));
         if (my < total) {
           idx = resume ? COLD_Q(list_in, const uint32_t *)[my] : my;
-          const uint32_t *dsrc = (resume ? COLD_Q(sd, const uint32_t *) : COLD_A(durations, const uint32_t *)) + 2 * (size_t)idx;
-          const uint32_t *psrc = COLD_A(prng, const uint32_t *) + 2 * (size_t)idx;
+          const BatchDesc *bd = find_batch(cold, idx);
+          const uint32_t k = idx - bd->start; // playout k of its batch
+          const uint32_t *dsrc = resume ? COLD_Q(sd, const uint32_t *) + 2 * (size_t)idx : (const uint32_t *)bd->durations + 2 * (size_t)k;
+          const uint32_t *psrc = (const uint32_t *)bd->prng + 2 * (size_t)k;
           g.s0 = psrc[0];
           g.s1 = psrc[1];
-          e.load_battle_global((resume ? COLD_Q(sb, const uint8_t *) : COLD_A(battles, const uint8_t *)) + (size_t)idx * 384, dsrc[0], dsrc[1]);
+          e.load_battle_global(resume ? COLD_Q(sb, const uint8_t *) + (size_t)idx * 384 : bd->battles + (size_t)k * 384, dsrc[0], dsrc[1]);
           if (prep) { // mcts.h:254-259
             const uint32_t hi = g.next32(), lo = g.next32();
             e.rng = ((uint64_t)hi << 32) | lo;
             e.randomize_hidden();
           }
-          result = (resume ? COLD_Q(sres, const uint8_t *) : COLD_A(results_in, const uint8_t *))[idx];
-          steps = resume ? COLD_A(steps_out, const uint32_t *)[idx] : 0;
+          result = resume ? COLD_Q(sres, const uint8_t *)[idx] : bd->results_in[k];
+          steps = resume ? bd->steps_out[k] : 0;
         } else idx = DONE;
       }
     }
     if (__ballot(idx != DONE) == 0) break;
     bool playing = idx != DONE && (result & 15) == 0 && steps < max_steps;
+#ifdef OAKGPU_TIMELINE
+    tl_steps += (unsigned long long)__popcll(__ballot(playing));
+#endif
     if (playing) {
       const uint32_t hi = g.next32(), lo = g.next32(); // uniform_64 = hi << 32 | lo
       result = e.random_step(result, hi, lo);
@@ -365,21 +418,22 @@ __global__ __launch_bounds__(BLK, WPS) void k_rollout_queue(RolloutArgs a_in, Ro
       OAK_SCOPE(PS_PUBLISH);
       const bool fin = !playing;
       e.normalize();
-      (fin ? COLD_A(results_out, uint8_t *) : COLD_Q(sres, uint8_t *))[idx] = (uint8_t)result;
-      COLD_A(steps_out, uint32_t *)[idx] = steps;
+      const BatchDesc *bd = find_batch(cold, idx);
+      const uint32_t k = idx - bd->start;
+      if (fin) bd->results_out[k] = (uint8_t)result; else COLD_Q(sres, uint8_t *)[idx] = (uint8_t)result;
+      bd->steps_out[k] = steps;
       const uint32_t t = result & 15;
-      if (fin) COLD_A(values_out, float *)[idx] = t == R_WIN ? 1.0f : t == R_LOSE ? 0.0f : 0.5f;
-      uint32_t *pdst = COLD_A(prng, uint32_t *) + 2 * (size_t)idx;
+      if (fin) bd->values_out[k] = t == R_WIN ? 1.0f : t == R_LOSE ? 0.0f : 0.5f;
+      uint32_t *pdst = (uint32_t *)bd->prng + 2 * (size_t)k;
       pdst[0] = g.s0;
       pdst[1] = g.s1;
-      uint32_t *ddst = fin ? COLD_A(durations_out, uint32_t *) : COLD_Q(sd, uint32_t *);
+      uint32_t *ddst = fin ? (bd->durations_out ? (uint32_t *)bd->durations_out + 2 * (size_t)k : nullptr) : COLD_Q(sd, uint32_t *) + 2 * (size_t)idx;
       if (ddst) {
-        ddst += 2 * (size_t)idx;
         ddst[0] = e.S.dur;
         ddst[1] = e.F.dur;
       }
-      uint8_t *bdst = fin ? COLD_A(battles_out, uint8_t *) : COLD_Q(sb, uint8_t *);
-      if (bdst) e.store_battle_global(bdst + (size_t)idx * 384);
+      uint8_t *bdst = fin ? (bd->battles_out ? bd->battles_out + (size_t)k * 384 : nullptr) : COLD_Q(sb, uint8_t *) + (size_t)idx * 384;
+      if (bdst) e.store_battle_global(bdst);
       idx = fin ? NONE : idx;
     }
     if (suspend) {
@@ -391,9 +445,12 @@ __global__ __launch_bounds__(BLK, WPS) void k_rollout_queue(RolloutArgs a_in, Ro
       break;
     }
   }
+  OAK_TL(2, wall_clock64());
+#ifdef OAKGPU_TIMELINE
+  OAK_TL(4, tl_steps);
+#endif
   OAK_PROF_FLUSH();
 }
-#undef COLD_A
 #undef COLD_Q
 
 // ---- batched single update -------------------------------------------------------------------
@@ -708,6 +765,12 @@ struct oakgpu_ctx {
   int round_shrink;       // each round launches 1/round_shrink of the previous round's waves
   uint8_t *d_scratch;     // suspended playout state: n x (384 + 8 + 1) bytes + two n-entry index lists
   size_t scratch_n;
+  int rounds_auto;        // a launch that saturates the device runs as one dispatch (no regrouping rounds)
+  int n_cu;               // compute units of the device
+  static constexpr int TABLE_SLOTS = 8;
+  void *h_table, *d_table; // batch tables of the group launches: pinned host ring -> device ring
+  hipEvent_t table_ev[TABLE_SLOTS];
+  uint64_t table_next;
 };
 
 static thread_local std::string g_err;
@@ -771,6 +834,16 @@ int oakgpu_create(oakgpu_ctx **out, int device) {
   c->d_queue = nullptr;
   c->d_scratch = nullptr;
   c->scratch_n = 0;
+  c->h_table = c->d_table = nullptr;
+  c->table_next = 0;
+  c->rounds_auto = 1;
+  if (const char *env = getenv("OAKGPU_ROUNDS_AUTO")) c->rounds_auto = atoi(env) != 0;
+  {
+    hipDeviceProp_t prop;
+    hipError_t pe = hipGetDeviceProperties(&prop, device);
+    if (pe != hipSuccess) { delete c; return fail(pe, "hipGetDeviceProperties"); }
+    c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  }
   c->rounds = 4;
   c->suspend_below = 32;
   c->round_shrink = 3;
@@ -797,6 +870,11 @@ void oakgpu_destroy(oakgpu_ctx *c) {
   if (c->d_sizes) (void)hipFree(c->d_sizes);
   if (c->d_queue) (void)hipFree(c->d_queue);
   if (c->d_scratch) (void)hipFree(c->d_scratch);
+  if (c->h_table) {
+    (void)hipHostFree(c->h_table);
+    (void)hipFree(c->d_table);
+    for (int i = 0; i < oakgpu_ctx::TABLE_SLOTS; ++i) (void)hipEventDestroy(c->table_ev[i]);
+  }
   delete c;
 }
 
@@ -820,6 +898,7 @@ int oakgpu_set_regroup(oakgpu_ctx *c, int rounds, int suspend_below, int shrink)
   c->rounds = rounds;
   c->suspend_below = suspend_below;
   c->round_shrink = shrink;
+  c->rounds_auto = 0; // an explicit setting applies to every launch, saturating or not
   return 0;
 }
 
@@ -843,53 +922,79 @@ extern "C" int oakgpu_site_profile(unsigned long long *out, int reset) {
 }
 #endif
 
+#ifdef OAKGPU_TIMELINE
+extern "C" int oakgpu_timeline(unsigned long long *out, int waves) { // profile build only (tools/timeline.py)
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(oak::g_timeline), sizeof(unsigned long long) * 5 * (size_t)waves) != hipSuccess;
+}
+#endif
+
 static inline uint32_t grid_for(uint32_t n) { return (n + oak::BLOCK - 1) / oak::BLOCK; }
 
-int oakgpu_rollout_dev(oakgpu_ctx *c, const uint8_t *battles, const uint8_t *durations, const uint8_t *results_in,
-                       uint8_t *prng_state, uint32_t n, uint32_t max_steps, int prep, uint8_t *results_out,
-                       uint32_t *steps_out, float *values_out, uint8_t *battles_out, uint8_t *durations_out) {
-  if (!c) return bad("null ctx");
-  if (n == 0) return 0;
-  if (!battles || !durations || !results_in || !prng_state || !results_out || !steps_out || !values_out)
-    return bad("oakgpu_rollout_dev: null required pointer");
-  oak::RolloutArgs a{battles, durations, results_in, prng_state, n, max_steps, prep, results_out, steps_out, values_out,
-                     battles_out, durations_out};
+// ---- group launch of the queue kernel --------------------------------------------------------------------------
+// The batch table travels through a small ring of pinned host slots -> device slots (async copy on the context's
+// stream; a slot is reused only after the event behind its previous copy has completed).
+static int launch_group(oakgpu_ctx *c, const oak::BatchDesc *descs, uint32_t count, uint32_t total, uint32_t max_steps, int prep) {
+  HIPCHK(hipSetDevice(c->device));
+  if (!c->d_queue) HIPCHK(hipMalloc((void **)&c->d_queue, 256));
+  if (!c->h_table) {
+    HIPCHK(hipHostMalloc((void **)&c->h_table, sizeof(oak::BatchDesc) * oak::MAX_GROUP * oakgpu_ctx::TABLE_SLOTS, hipHostMallocDefault));
+    HIPCHK(hipMalloc((void **)&c->d_table, sizeof(oak::BatchDesc) * oak::MAX_GROUP * oakgpu_ctx::TABLE_SLOTS));
+    for (int i = 0; i < oakgpu_ctx::TABLE_SLOTS; ++i) HIPCHK(hipEventCreateWithFlags(&c->table_ev[i], hipEventDisableTiming));
+  }
+  const int slot = (int)(c->table_next++ % oakgpu_ctx::TABLE_SLOTS);
+  HIPCHK(hipEventSynchronize(c->table_ev[slot])); // never-recorded events are complete
+  oak::BatchDesc *ht = (oak::BatchDesc *)c->h_table + (size_t)slot * oak::MAX_GROUP, *dt = (oak::BatchDesc *)c->d_table + (size_t)slot * oak::MAX_GROUP;
+  memcpy(ht, descs, sizeof(oak::BatchDesc) * count);
+  HIPCHK(hipMemcpyAsync(dt, ht, sizeof(oak::BatchDesc) * count, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipEventRecord(c->table_ev[slot], c->stream));
+  HIPCHK(hipMemsetAsync(c->d_queue, 0, 256, c->stream));
+  // grid: at least `playouts_per_lane` playouts per lane, and never more waves than the device keeps resident
+  const uint32_t n64 = (total + 63) / 64;
+  uint32_t waves = (n64 + c->playouts_per_lane - 1) / c->playouts_per_lane;
+  if (waves < 1) waves = 1;
+  const uint32_t resident = (uint32_t)c->n_cu * 4u * (uint32_t)(c->waves_per_simd >= 4 ? 4 : c->waves_per_simd == 3 ? 3 : 2);
+  const bool saturated = waves >= resident;
+  if (saturated) waves = resident;
+  // regrouping rounds pay off while the launch leaves SIMDs idle in its tail; a launch that saturates the device
+  // for most of its life (a group of batches) runs as a single dispatch (measured: DESIGN.md 3)
+  const int rounds = (c->suspend_below > 0 && waves >= 8 && !(saturated && c->rounds_auto)) ? c->rounds : 1;
+  if (rounds > 1 && c->scratch_n < total) {
+    if (c->d_scratch) { HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipFree(c->d_scratch)); c->d_scratch = nullptr; }
+    HIPCHK(hipMalloc((void **)&c->d_scratch, (size_t)total * (384 + 8 + 4 + 4) + (((size_t)total + 15) & ~(size_t)15)));
+    c->scratch_n = total;
+  }
+  const size_t lq = 24 * 64 * 4 + oak::TABLE_LDS_PAD + oak::COLD_LDS_BYTES;
+  uint8_t *sb = c->d_scratch, *sd = sb ? sb + (size_t)c->scratch_n * 384 : nullptr;
+  uint32_t *lists[2] = {sd ? (uint32_t *)(sd + (size_t)c->scratch_n * 8) : nullptr, nullptr};
+  lists[1] = lists[0] ? lists[0] + c->scratch_n : nullptr;
+  uint8_t *sres = lists[1] ? (uint8_t *)(lists[1] + c->scratch_n) : nullptr;
+  const oak::GroupArgs g{dt, count, total, max_steps, prep};
+  for (int r = 0; r < rounds; ++r) {
+    oak::RoundArgs q{};
+    q.list_in = r ? lists[(r - 1) & 1] : nullptr;
+    q.n_in = r ? c->d_queue + 2 * r - 1 : nullptr; // = count_out of round r - 1
+    q.list_out = lists[r & 1];
+    q.count_out = c->d_queue + 2 * r + 1;
+    q.sb = sb; q.sd = sd; q.sres = sres;
+    q.suspend_below = r + 1 < rounds ? (uint32_t)c->suspend_below : 0u;
+    q.queue = c->d_queue + 2 * r;
+#define OAK_LAUNCH_Q(W) hipLaunchKernelGGL((oak::k_rollout_queue<64, W>), dim3(waves), dim3(64), lq, c->stream, g, q)
+    if (c->waves_per_simd >= 4) OAK_LAUNCH_Q(4); else if (c->waves_per_simd == 3) OAK_LAUNCH_Q(3); else OAK_LAUNCH_Q(2);
+#undef OAK_LAUNCH_Q
+    waves = (waves + c->round_shrink - 1) / c->round_shrink;
+    if (waves < 1) waves = 1;
+  }
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+static int launch_single(oakgpu_ctx *c, const oak::RolloutArgs &a) { // one lane per playout, no queue
+  const uint32_t n = a.n;
   const size_t lds64 = oak::STATE_WORDS * 64 * 4 + oak::TABLE_LDS_PAD;
   if (c->rollout_engine == 1) { // LDS-resident engine (gen1_device.hpp), kept for A/B and as a second implementation
     if (c->rollout_block <= 64) hipLaunchKernelGGL(oak::k_rollout<64>, dim3((n + 63) / 64), dim3(64), lds64, c->stream, a);
     else hipLaunchKernelGGL(oak::k_rollout<256>, dim3(grid_for(n)), dim3(256), oak::ENGINE_LDS_BYTES, c->stream, a);
-  } else if (c->playouts_per_lane > 1) { // register engine + lane refill from an atomic playout queue
-    if (!c->d_queue) HIPCHK(hipMalloc((void **)&c->d_queue, 256));
-    HIPCHK(hipMemsetAsync(c->d_queue, 0, 256, c->stream));
-    uint32_t waves = ((n + 63) / 64 + c->playouts_per_lane - 1) / c->playouts_per_lane;
-    if (waves < 1) waves = 1;
-    const int rounds = (c->suspend_below > 0 && waves >= 8) ? c->rounds : 1;
-    if (rounds > 1 && c->scratch_n < n) {
-      if (c->d_scratch) { HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipFree(c->d_scratch)); c->d_scratch = nullptr; }
-      HIPCHK(hipMalloc((void **)&c->d_scratch, (size_t)n * (384 + 8 + 4 + 4) + (((size_t)n + 15) & ~(size_t)15)));
-      c->scratch_n = n;
-    }
-    const size_t lq = 24 * 64 * 4 + oak::TABLE_LDS_PAD + oak::COLD_LDS_BYTES;
-    uint8_t *sb = c->d_scratch, *sd = sb ? sb + (size_t)c->scratch_n * 384 : nullptr;
-    uint32_t *lists[2] = {sd ? (uint32_t *)(sd + (size_t)c->scratch_n * 8) : nullptr, nullptr};
-    lists[1] = lists[0] ? lists[0] + c->scratch_n : nullptr;
-    uint8_t *sres = lists[1] ? (uint8_t *)(lists[1] + c->scratch_n) : nullptr;
-    for (int r = 0; r < rounds; ++r) {
-      oak::RoundArgs q{};
-      q.list_in = r ? lists[(r - 1) & 1] : nullptr;
-      q.n_in = r ? c->d_queue + 2 * r - 1 : nullptr; // = count_out of round r - 1
-      q.list_out = lists[r & 1];
-      q.count_out = c->d_queue + 2 * r + 1;
-      q.sb = sb; q.sd = sd; q.sres = sres;
-      q.suspend_below = r + 1 < rounds ? (uint32_t)c->suspend_below : 0u;
-      q.queue = c->d_queue + 2 * r;
-#define OAK_LAUNCH_Q(W) hipLaunchKernelGGL((oak::k_rollout_queue<64, W>), dim3(waves), dim3(64), lq, c->stream, a, q)
-      if (c->waves_per_simd >= 4) OAK_LAUNCH_Q(4); else if (c->waves_per_simd == 3) OAK_LAUNCH_Q(3); else OAK_LAUNCH_Q(2);
-#undef OAK_LAUNCH_Q
-      waves = (waves + c->round_shrink - 1) / c->round_shrink;
-      if (waves < 1) waves = 1;
-    }
-  } else {                      // register-resident engine (gen1_regs.hpp): the default
+  } else {                      // register-resident engine (gen1_regs.hpp)
     if (c->rollout_block == 64)
       hipLaunchKernelGGL(oak::k_rollout_regs<64>, dim3((n + 63) / 64), dim3(64), 24 * 64 * 4 + oak::TABLE_LDS_PAD, c->stream, a);
     else
@@ -897,6 +1002,44 @@ int oakgpu_rollout_dev(oakgpu_ctx *c, const uint8_t *battles, const uint8_t *dur
   }
   HIPCHK(hipGetLastError());
   return 0;
+}
+
+int oakgpu_rollout_group_dev(oakgpu_ctx *c, const oakgpu_rollout_batch *batches, uint32_t count, uint32_t max_steps, int prep) {
+  if (!c) return bad("null ctx");
+  if (count == 0) return 0;
+  if (!batches) return bad("oakgpu_rollout_group_dev: null batches");
+  if (count > (uint32_t)oak::MAX_GROUP) return bad("oakgpu_rollout_group_dev: more than 64 batches in one group");
+  oak::BatchDesc descs[oak::MAX_GROUP];
+  uint32_t used = 0;
+  uint64_t total = 0;
+  for (uint32_t i = 0; i < count; ++i) {
+    const oakgpu_rollout_batch &b = batches[i];
+    if (b.n == 0) continue;
+    if (!b.battles || !b.durations || !b.results_in || !b.prng_state || !b.results_out || !b.steps_out || !b.values_out)
+      return bad("oakgpu_rollout_group_dev: null required pointer");
+    descs[used++] = oak::BatchDesc{b.battles, b.durations, b.results_in, b.prng_state, b.results_out, b.steps_out, b.values_out,
+                                   b.battles_out, b.durations_out, (uint32_t)total, b.n};
+    total += b.n;
+  }
+  if (used == 0) return 0;
+  if (total >= 0xFFFFFFF0ull) return bad("oakgpu_rollout_group_dev: more than 2^32 playouts in one group");
+  if (c->rollout_engine == 1 || c->playouts_per_lane <= 1) { // no queue: one launch per batch
+    HIPCHK(hipSetDevice(c->device));
+    for (uint32_t i = 0; i < used; ++i) {
+      const oak::BatchDesc &d = descs[i];
+      if (int r = launch_single(c, oak::RolloutArgs{d.battles, d.durations, d.results_in, d.prng, d.n, max_steps, prep, d.results_out,
+                                                    d.steps_out, d.values_out, d.battles_out, d.durations_out})) return r;
+    }
+    return 0;
+  }
+  return launch_group(c, descs, used, (uint32_t)total, max_steps, prep);
+}
+
+int oakgpu_rollout_dev(oakgpu_ctx *c, const uint8_t *battles, const uint8_t *durations, const uint8_t *results_in,
+                       uint8_t *prng_state, uint32_t n, uint32_t max_steps, int prep, uint8_t *results_out,
+                       uint32_t *steps_out, float *values_out, uint8_t *battles_out, uint8_t *durations_out) {
+  const oakgpu_rollout_batch b{battles, durations, results_in, prng_state, n, results_out, steps_out, values_out, battles_out, durations_out};
+  return oakgpu_rollout_group_dev(c, &b, 1, max_steps, prep);
 }
 
 int oakgpu_update_dev(oakgpu_ctx *c, uint8_t *battles, const uint8_t *c1, const uint8_t *c2, uint8_t *durations,
@@ -1018,33 +1161,64 @@ struct DevBuf { // stream-ordered allocation from the device's memory pool: afte
 #define UP(buf, host, nbytes) do { HIPCHK((buf).alloc(nbytes, c->stream)); if (host) HIPCHK(hipMemcpyAsync((buf).p, host, nbytes, hipMemcpyHostToDevice, c->stream)); } while (0)
 #define DOWN(host, buf) do { if (host) HIPCHK(hipMemcpyAsync(host, (buf).p, (buf).bytes, hipMemcpyDeviceToHost, c->stream)); } while (0)
 
+int oakgpu_rollout_group(oakgpu_ctx *c, const oakgpu_rollout_batch *batches, uint32_t count, uint32_t max_steps, int prep) {
+  if (!c) return bad("null ctx");
+  if (count == 0) return 0;
+  if (!batches) return bad("oakgpu_rollout_group: null batches");
+  if (count > (uint32_t)oak::MAX_GROUP) return bad("oakgpu_rollout_group: more than 64 batches in one group");
+  for (uint32_t i = 0; i < count; ++i) {
+    const oakgpu_rollout_batch &h = batches[i];
+    if (h.n && (!h.battles || !h.durations || !h.results_in || !h.prng_state || !h.results_out || !h.steps_out || !h.values_out))
+      return bad("oakgpu_rollout_group: null required pointer");
+  }
+  HIPCHK(hipSetDevice(c->device));
+  struct Bufs { DevBuf b, d, ri, pr, ro, st, va, bo, dd; };
+  std::vector<Bufs> bufs(count);
+  std::vector<oakgpu_rollout_batch> dev(count);
+  int rc = 0;
+  hipError_t e = hipSuccess;
+  auto up = [&](DevBuf &buf, const void *host, size_t nbytes) {
+    if (e != hipSuccess) return;
+    e = buf.alloc(nbytes, c->stream);
+    if (e == hipSuccess && host) e = hipMemcpyAsync(buf.p, host, nbytes, hipMemcpyHostToDevice, c->stream);
+  };
+  auto down = [&](void *host, DevBuf &buf) {
+    if (e == hipSuccess && host && buf.p) e = hipMemcpyAsync(host, buf.p, buf.bytes, hipMemcpyDeviceToHost, c->stream);
+  };
+  for (uint32_t i = 0; i < count; ++i) {
+    const oakgpu_rollout_batch &h = batches[i];
+    Bufs &B = bufs[i];
+    const size_t n = h.n;
+    dev[i] = oakgpu_rollout_batch{};
+    if (n == 0) continue;
+    up(B.b, h.battles, n * 384); up(B.d, h.durations, n * 8); up(B.ri, h.results_in, n); up(B.pr, h.prng_state, n * 8);
+    up(B.ro, nullptr, n); up(B.st, nullptr, n * 4); up(B.va, nullptr, n * 4);
+    if (h.battles_out) up(B.bo, nullptr, n * 384);
+    if (h.durations_out) up(B.dd, nullptr, n * 8);
+    dev[i] = oakgpu_rollout_batch{(uint8_t *)B.b.p, (uint8_t *)B.d.p, (uint8_t *)B.ri.p, (uint8_t *)B.pr.p, h.n, (uint8_t *)B.ro.p,
+                                  (uint32_t *)B.st.p, (float *)B.va.p, (uint8_t *)B.bo.p, (uint8_t *)B.dd.p};
+  }
+  if (e == hipSuccess) rc = oakgpu_rollout_group_dev(c, dev.data(), count, max_steps, prep);
+  if (e == hipSuccess && !rc)
+    for (uint32_t i = 0; i < count; ++i) {
+      const oakgpu_rollout_batch &h = batches[i];
+      Bufs &B = bufs[i];
+      down(h.results_out, B.ro); down(h.steps_out, B.st); down(h.values_out, B.va); down(h.prng_state, B.pr);
+      down(h.battles_out, B.bo); down(h.durations_out, B.dd);
+    }
+  // the copies to / from the caller's buffers (and the buffers' stream-ordered frees) must have finished on every exit
+  const hipError_t se = hipStreamSynchronize(c->stream);
+  if (e != hipSuccess) return fail(e, "oakgpu_rollout_group");
+  if (rc) return rc;
+  if (se != hipSuccess) return fail(se, "hipStreamSynchronize");
+  return 0;
+}
+
 int oakgpu_rollout(oakgpu_ctx *c, const uint8_t *battles, const uint8_t *durations, const uint8_t *results_in,
                    uint8_t *prng_state, uint32_t n, uint32_t max_steps, int prep, uint8_t *results_out, uint32_t *steps_out,
                    float *values_out, uint8_t *battles_out, uint8_t *durations_out) {
-  if (!c) return bad("null ctx");
-  if (n == 0) return 0;
-  HIPCHK(hipSetDevice(c->device));
-  DevBuf b, d, ri, pr, ro, st, va, bo, dd;
-  UP(b, battles, (size_t)n * 384);
-  UP(d, durations, (size_t)n * 8);
-  UP(ri, results_in, n);
-  UP(pr, prng_state, (size_t)n * 8);
-  UP(ro, (const void *)nullptr, n);
-  UP(st, (const void *)nullptr, (size_t)n * 4);
-  UP(va, (const void *)nullptr, (size_t)n * 4);
-  if (battles_out) UP(bo, (const void *)nullptr, (size_t)n * 384);
-  if (durations_out) UP(dd, (const void *)nullptr, (size_t)n * 8);
-  int r = oakgpu_rollout_dev(c, (uint8_t *)b.p, (uint8_t *)d.p, (uint8_t *)ri.p, (uint8_t *)pr.p, n, max_steps, prep,
-                             (uint8_t *)ro.p, (uint32_t *)st.p, (float *)va.p, (uint8_t *)bo.p, (uint8_t *)dd.p);
-  if (r) return r;
-  DOWN(results_out, ro);
-  DOWN(steps_out, st);
-  DOWN(values_out, va);
-  DOWN(prng_state, pr);
-  DOWN(battles_out, bo);
-  DOWN(durations_out, dd);
-  HIPCHK(hipStreamSynchronize(c->stream));
-  return 0;
+  const oakgpu_rollout_batch b{battles, durations, results_in, prng_state, n, results_out, steps_out, values_out, battles_out, durations_out};
+  return oakgpu_rollout_group(c, &b, 1, max_steps, prep);
 }
 
 int oakgpu_update(oakgpu_ctx *c, uint8_t *battles, const uint8_t *c1, const uint8_t *c2, uint8_t *durations, uint8_t *actions,

@@ -101,6 +101,27 @@ class Context:
             res.update(battles=bo, durations=do)
         return res
 
+    def rollout_group(self, batches, max_steps=1000, prep=False, return_state=False):
+        """Several independent batches [(battles, durations, results, prng), ...] drained by ONE launch
+        (oakgpu_rollout_group); returns one result dict per batch, identical to separate rollout() calls."""
+        descs = (_lib.RolloutBatch * len(batches))()
+        outs, keep = [], []
+        for k, (battles, durations, results, prng) in enumerate(batches):
+            battles = _u8(battles)
+            n = battles.shape[0]
+            durations, results, prng = _u8(durations, (n, 8)), _u8(results, (n,)), _u8(prng, (n, 8)).copy()
+            res = dict(results=np.zeros(n, dtype=np.uint8), steps=np.zeros(n, dtype=np.uint32),
+                       values=np.zeros(n, dtype=np.float32), prng=prng)
+            if return_state:
+                res.update(battles=np.zeros((n, 384), dtype=np.uint8), durations=np.zeros((n, 8), dtype=np.uint8))
+            keep.append((battles, durations, results))
+            a = lambda x: None if x is None or x.size == 0 else x.ctypes.data
+            descs[k] = _lib.RolloutBatch(a(battles), a(durations), a(results), a(prng), n, a(res["results"]), a(res["steps"]),
+                                         a(res["values"]), a(res.get("battles")), a(res.get("durations")))
+            outs.append(res)
+        _lib.check(self.lib.oakgpu_rollout_group(self.handle, descs, len(batches), max_steps, 1 if prep else 0))
+        return outs
+
     def update(self, battles, c1, c2, durations, overrides=None, want_actions=True):
         """In-place batched update; returns (results, actions or None)."""
         n = battles.shape[0]

@@ -327,3 +327,32 @@ def test_full_size_config4_properties_and_sampled_parity(gpu_ctx):
     oout, osteps = O.rollout_batch(ob, od, R[pick], op, max_steps=1000, prep=True, threads=16)
     assert (got["results"][pick] == oout).all() and (got["steps"][pick] == osteps).all()
     assert (got["battles"][pick] == ob).all() and (got["durations"][pick] == od).all() and (got["prng"][pick] == op).all()
+
+
+def test_group_launch_matches_separate_launches(gpu_ctx):
+    """oakgpu_rollout_group: several batches (ragged sizes, an empty one, a one-playout one) drained through ONE playout
+    queue give the byte-identical outputs of separate launches and of the oracle, with and without root prep, and
+    under regrouping rounds (suspended playouts of different batches share the scratch lists)."""
+    sizes = (1500, 0, 1, 777, 64, 2049)
+    batches = [O.make_random_ou_batch(n, seed0=0x6A0F0000 + 7919 * k) if n else
+               (np.zeros((0, 384), np.uint8), np.zeros((0, 8), np.uint8), np.zeros((0, 8), np.uint8), np.zeros(0, np.uint8))
+               for k, n in enumerate(sizes)]
+    try:
+        for ppl, rounds, below, shrink, max_steps in ((2, 1, 0, 1, 1000), (3, 4, 32, 3, 1000), (2, 3, 64, 2, 40)):
+            gpu_ctx.set_playouts_per_lane(ppl)
+            gpu_ctx.set_regroup(rounds, below, shrink)
+            for prep in (False, True):
+                got = gpu_ctx.rollout_group([(b, d, r, p) for b, d, p, r in batches], max_steps=max_steps, prep=prep, return_state=True)
+                for (b, d, p, r), g in zip(batches, got):
+                    if b.shape[0] == 0:
+                        assert g["steps"].size == 0
+                        continue
+                    ob, od, op = b.copy(), d.copy(), p.copy()
+                    oout, osteps = O.rollout_batch(ob, od, r, op, max_steps=max_steps, prep=prep, threads=4)
+                    assert (g["steps"] == osteps).all() and (g["results"] == oout).all()
+                    assert (g["battles"] == ob).all() and (g["durations"] == od).all() and (g["prng"] == op).all()
+                    t = oout & 15
+                    assert (g["values"] == np.where(t == 1, 1.0, np.where(t == 2, 0.0, 0.5)).astype(np.float32)).all()
+    finally:
+        gpu_ctx.set_playouts_per_lane(2)
+        gpu_ctx.set_regroup()

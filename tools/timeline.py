@@ -1,0 +1,51 @@
+"""Manual GPU tool: wave timeline of ONE big rollout launch (profile build with -DOAKGPU_TIMELINE).
+usage: timeline.py <lib.so> [n] [ppl] [rounds] -- prints when the queue ran dry and how the waves drain afterwards."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, ".")
+from oak_amd import _lib
+
+_lib.LIB_PATH = os.path.abspath(sys.argv[1])
+from oak_amd.engine import Context  # noqa: E402
+
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 20 * 65536
+ppl = int(sys.argv[3]) if len(sys.argv) > 3 else 5
+rounds = int(sys.argv[4]) if len(sys.argv) > 4 else 1
+ctx = Context(0)
+lib, h = ctx.lib, ctx.handle
+dev = torch.device("cuda", 0)
+ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+ctx.ensure_ou_pools()
+ctx.set_playouts_per_lane(ppl)
+ctx.set_regroup(rounds, 32 if rounds > 1 else 0, 3)
+T = lambda *s, dt=torch.uint8: torch.empty(s, dtype=dt, device=dev)
+battles, durations, prng, prng0, rin, rout = T(n, 384), T(n, 8), T(n, 8), T(n, 8), T(n), T(n)
+steps, values = T(n, dt=torch.int32), T(n, dt=torch.float32)
+P = lambda t: C.c_void_p(t.data_ptr())
+_lib.check(lib.oakgpu_random_ou_battles_dev(h, C.c_uint64(0x0A4B00000000), n, P(battles), P(durations), P(prng0), P(rin)))
+for rep in range(2):
+    prng.copy_(prng0)
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    _lib.check(lib.oakgpu_rollout_dev(h, P(battles), P(durations), P(rin), P(prng), n, 1000, 0, P(rout), P(steps), P(values), None, None))
+    b.record()
+    torch.cuda.synchronize()
+waves = ((n + 63) // 64 + ppl - 1) // ppl
+tl = np.zeros((waves, 5), dtype=np.uint64)
+lib.oakgpu_timeline.argtypes = [C.c_void_p, C.c_int]
+assert lib.oakgpu_timeline(tl.ctypes.data_as(C.c_void_p), waves) == 0
+t0 = tl[:, 0].min()
+us = lambda x: (x.astype(np.int64) - np.int64(t0)) / 100.0   # 100 MHz wall clock
+start, dry, end = us(tl[:, 0]), us(tl[:, 1]), us(tl[:, 2])
+print("launch %.3f ms, %d waves, total steps %d (kernel counted %d)" % (a.elapsed_time(b), waves, int(steps.sum().item()), int(tl[:, 4].sum())))
+print("wave start  us: min %.0f med %.0f max %.0f" % (start.min(), np.median(start), start.max()))
+print("dry seen    us: min %.0f med %.0f max %.0f; live lanes at dry: mean %.1f" % (dry.min(), np.median(dry), dry.max(), tl[:, 3].mean()))
+print("wave exit   us: min %.0f med %.0f p90 %.0f p99 %.0f max %.0f" % (end.min(), np.median(end), np.percentile(end, 90), np.percentile(end, 99), end.max()))
+for t in range(0, int(end.max()) + 1000, 1000):
+    print("  t=%5d us: waves still running %5d" % (t, int((end > t).sum())))
