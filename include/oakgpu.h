@@ -93,6 +93,29 @@ int oakgpu_rollout_group_dev(oakgpu_ctx *ctx, const oakgpu_rollout_batch *batche
                              int prep);
 int oakgpu_rollout_group(oakgpu_ctx *ctx, const oakgpu_rollout_batch *batches, uint32_t count, uint32_t max_steps, int prep);
 
+/* ---- rollouts driven by a caller-supplied draw stream (a SHARED sequential device generator).
+ * The reference's benchmark / search drive every playout from ONE std::mt19937 (benchmark.cc:24, search.cc:150), so
+ * playout i starts in the generator's output where playout i-1 stopped.  `draws` holds that output: one u64 per
+ * device.uniform_64() call (mcts.h:255-257: battle.rng of the root iteration when prep != 0; mcts.h:452: one per
+ * turn-step).
+ *   oakgpu_mt19937_fill           : std::mt19937{seed} -> uniform_64() values (util/random.h:10-65), host side.
+ *   oakgpu_rollout_draws_dev      : lane i plays from draws[offsets[i]] (offsets == NULL: from draws[i]); strides of 0
+ *                                   make every lane start from the same root; every output is nullable; used_out[i] =
+ *                                   draws consumed, 0xFFFFFFFF if the lane ran off the end of the stream.
+ *   oakgpu_rollout_shared_device  : (host pointers) n playouts from ONE root in the sequential order of the reference:
+ *                                   offsets resolved on the device by playing a playout from every start offset first.
+ *                                   Fails (-1) if the stream is too short.  offsets_out / draws_consumed nullable. */
+int oakgpu_mt19937_fill(uint32_t seed, uint64_t skip, uint64_t *out, size_t count);
+int oakgpu_rollout_draws_dev(oakgpu_ctx *ctx, const uint8_t *battles, uint32_t battle_stride, const uint8_t *durations,
+                             uint32_t durations_stride, const uint8_t *results_in, uint32_t results_stride,
+                             const uint64_t *draws, uint32_t n_draws, const uint32_t *offsets, uint32_t n,
+                             uint32_t max_steps, int prep, uint8_t *results_out, uint32_t *steps_out, float *values_out,
+                             uint8_t *battles_out, uint8_t *durations_out, uint32_t *used_out);
+int oakgpu_rollout_shared_device(oakgpu_ctx *ctx, const uint8_t *battle, const uint8_t *durations, uint8_t result,
+                                 const uint64_t *draws, uint32_t n_draws, uint32_t n, uint32_t max_steps, int prep,
+                                 uint8_t *results_out, uint32_t *steps_out, float *values_out, uint8_t *battles_out,
+                                 uint8_t *durations_out, uint32_t *offsets_out, uint64_t *draws_consumed);
+
 /* ---- batched pkmn_gen1_battle_update (call sites mcts.h:278,350,463,479; wrapper
  * libpkmn/pkmn.h:106-139).  In place on battles; durations in/out (chance options);
  * actions (nullable) receives the 16-byte chance-actions key of each update (mcts.h:93-98);

@@ -9,7 +9,8 @@ LIB_PATH = os.path.join(_HERE, "liboakgpu.so")
 # every symbol include/oakgpu.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
     "oakgpu_create", "oakgpu_destroy", "oakgpu_last_error", "oakgpu_set_stream", "oakgpu_get_stream", "oakgpu_synchronize", "oakgpu_set_playouts_per_lane", "oakgpu_set_regroup",
-    "oakgpu_device_count", "oakgpu_rollout_dev", "oakgpu_rollout", "oakgpu_rollout_group_dev", "oakgpu_rollout_group", "oakgpu_update_dev", "oakgpu_update",
+    "oakgpu_device_count", "oakgpu_rollout_dev", "oakgpu_rollout", "oakgpu_rollout_group_dev", "oakgpu_rollout_group",
+    "oakgpu_mt19937_fill", "oakgpu_rollout_draws_dev", "oakgpu_rollout_shared_device", "oakgpu_update_dev", "oakgpu_update",
     "oakgpu_choices_dev", "oakgpu_choices", "oakgpu_init_battles_dev", "oakgpu_init_battles",
     "oakgpu_set_ou_pools", "oakgpu_random_ou_battles_dev",
     "oakgpu_net_load", "oakgpu_net_load_memory", "oakgpu_net_free", "oakgpu_net_shape",
@@ -75,6 +76,9 @@ def load():
     lib.oakgpu_rollout.argtypes = [vp, vp, vp, vp, vp, u32, u32, i32, vp, vp, vp, vp, vp]
     lib.oakgpu_rollout_group_dev.argtypes = [vp, C.POINTER(RolloutBatch), u32, u32, i32]
     lib.oakgpu_rollout_group.argtypes = [vp, C.POINTER(RolloutBatch), u32, u32, i32]
+    lib.oakgpu_mt19937_fill.argtypes = [u32, u64, vp, C.c_size_t]
+    lib.oakgpu_rollout_draws_dev.argtypes = [vp, vp, u32, vp, u32, vp, u32, vp, u32, vp, u32, u32, i32, vp, vp, vp, vp, vp, vp]
+    lib.oakgpu_rollout_shared_device.argtypes = [vp, vp, vp, C.c_uint8, vp, u32, u32, u32, i32, vp, vp, vp, vp, vp, vp, vp]
     lib.oakgpu_poke_engine_eval_dev.argtypes = [vp, vp, u32, C.c_float, vp, vp]
     lib.oakgpu_poke_engine_eval.argtypes = [vp, vp, u32, C.c_float, vp, vp]
     lib.oakgpu_tree_step_dev.argtypes = [vp, vp, vp, vp, vp, vp, u32, u32, vp, vp, vp, vp, vp]

@@ -623,6 +623,9 @@ constexpr int TM = 64;        // leaves per workgroup tile
 constexpr int KC_MAIN = 64;   // K chunk staged per iteration in k_mainnet (LDS: 16.6 + 66.6 KB staging + 65.8 KB activations)
 constexpr int KC_POLICY = 32; // ... in k_policy (two activation tiles: 8.4 + 33.8 KB staging)
 constexpr int MAXH = 256;
+// dynamic LDS of k_policy: weight / input staging + a TM-leaf tile of the hidden and the policy-hidden activations
+constexpr int POLICY_LDS_LIMIT = 150 * 1024;
+constexpr int policy_lds_bytes(int H, int PH) { return ((TM + MAXH) * (KC_POLICY + 1) + TM * (H + 1) + TM * (PH + 1)) * 4; }
 
 struct MainArgs {
   NetDev net;
@@ -1009,10 +1012,7 @@ struct oakgpu_net {
   oak::NetDev dev;
   std::vector<void *> allocs;
   int in_dim, hidden, value_hidden, policy_hidden; // unpadded, as in the file
-  float *emb_ws;     // lazily grown workspace: n x emb_dim
-  size_t emb_ws_rows;
-  float *h1_ws;      // lazily grown workspace: n x H (policy path only)
-  size_t h1_ws_rows;
+  int device;        // the device the weights live on
 };
 
 namespace {
@@ -1088,9 +1088,8 @@ extern "C" {
 void oakgpu_net_free(oakgpu_ctx *ctx, oakgpu_net *net) {
   (void)ctx;
   if (!net) return;
+  (void)hipSetDevice(net->device);
   for (void *p : net->allocs) (void)hipFree(p);
-  if (net->emb_ws) (void)hipFree(net->emb_ws);
-  if (net->h1_ws) (void)hipFree(net->h1_ws);
   delete net;
 }
 
@@ -1119,10 +1118,7 @@ int oakgpu_net_load_memory(oakgpu_ctx *ctx, const void *bytes, size_t size, oakg
   hipError_t he = hipSetDevice(oakgpu_ctx_device(ctx));
   if (he != hipSuccess) return oakgpu_fail_hip((int)he, "hipSetDevice");
   oakgpu_net *net = new oakgpu_net();
-  net->emb_ws = nullptr;
-  net->emb_ws_rows = 0;
-  net->h1_ws = nullptr;
-  net->h1_ws_rows = 0;
+  net->device = oakgpu_ctx_device(ctx);
   net->in_dim = (int)fc0.in;
   net->hidden = (int)fc0.out;
   net->value_hidden = (int)v2.out;
@@ -1158,6 +1154,11 @@ int oakgpu_net_load_memory(oakgpu_ctx *ctx, const void *bytes, size_t size, oakg
         q1b.out != 315 || q2b.out != 315) { oakgpu_net_free(ctx, net); return oakgpu_fail_msg("network file: inconsistent policy-head dims"); }
     const uint32_t PH = up32(q1a.out);
     if (PH > (uint32_t)oak::MAXH) { oakgpu_net_free(ctx, net); return oakgpu_fail_msg("policy hidden width above 256 unsupported"); }
+    // k_policy keeps a 64-leaf tile of the hidden and policy-hidden activations in LDS next to its weight chunk
+    if (oak::policy_lds_bytes((int)H, (int)PH) > oak::POLICY_LDS_LIMIT) {
+      oakgpu_net_free(ctx, net);
+      return oakgpu_fail_msg("policy heads too wide for this hidden width (k_policy's LDS tile): at hidden 256 policy_hidden may be at most 160");
+    }
     D.PH = (int)PH;
     rc = rc ? rc : upload(net, pad_rows(q1a, PH, H), &D.q1a);
     rc = rc ? rc : upload(net, pad_vec(q1a.b, PH), &D.q1a_b);
@@ -1194,22 +1195,19 @@ int oakgpu_net_shape(const oakgpu_net *net, int *in_dim, int *hidden, int *value
   return 0;
 }
 
-static int lds_attrs_once() {
-  static bool done = false;
-  if (done) return 0;
+int oakgpu_leaf_set_lds_limits(void) { // per DEVICE (hipFuncSetAttribute applies to the current device): called by oakgpu_create
   hipError_t e = hipFuncSetAttribute((const void *)oak::k_embed_tile, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
   if (e != hipSuccess) return oakgpu_fail_hip((int)e, "hipFuncSetAttribute(k_embed_tile)");
   e = hipFuncSetAttribute((const void *)oak::k_embed_lds<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)oak::ELayout<false>::BYTES);
   if (e != hipSuccess) return oakgpu_fail_hip((int)e, "hipFuncSetAttribute(k_embed_lds<party>)");
   e = hipFuncSetAttribute((const void *)oak::k_embed_lds<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)oak::ELayout<true>::BYTES);
   if (e != hipSuccess) return oakgpu_fail_hip((int)e, "hipFuncSetAttribute(k_embed_lds<active>)");
-  e = hipFuncSetAttribute((const void *)oak::k_policy, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+  e = hipFuncSetAttribute((const void *)oak::k_policy, hipFuncAttributeMaxDynamicSharedMemorySize, oak::POLICY_LDS_LIMIT);
   if (e != hipSuccess) return oakgpu_fail_hip((int)e, "hipFuncSetAttribute(k_policy)");
   e = hipFuncSetAttribute((const void *)oak::k_mainnet_direct, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
   if (e != hipSuccess) return oakgpu_fail_hip((int)e, "hipFuncSetAttribute(k_mainnet_direct)");
   e = hipFuncSetAttribute((const void *)oak::k_mainnet, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
   if (e != hipSuccess) return oakgpu_fail_hip((int)e, "hipFuncSetAttribute(k_mainnet)");
-  done = true;
   return 0;
 }
 
@@ -1218,20 +1216,13 @@ static int leaf_eval_impl(oakgpu_ctx *ctx, oakgpu_net *net, const uint8_t *battl
   if (!ctx || !net) return oakgpu_fail_msg("oakgpu_leaf_eval_dev: null ctx/net");
   if (n == 0) return 0;
   if (!battles || !durations || !values) return oakgpu_fail_msg("oakgpu_leaf_eval_dev: null required pointer");
-  if (int rc = lds_attrs_once()) return rc;
+  if (net->device != oakgpu_ctx_device(ctx)) return oakgpu_fail_msg("oakgpu_leaf_eval_dev: the network was loaded on another device than the context's");
+  if (int rc = oakgpu_ctx_enter(ctx)) return rc;
   hipStream_t stream = (hipStream_t)oakgpu_ctx_stream(ctx);
   float *emb = embedding_out;
-  if (!emb) {
-    if (net->emb_ws_rows < n) {
-      hipError_t e = hipStreamSynchronize(stream);
-      if (e != hipSuccess) return oakgpu_fail_hip((int)e, "hipStreamSynchronize");
-      if (net->emb_ws) (void)hipFree(net->emb_ws);
-      net->emb_ws = nullptr;
-      e = hipMalloc((void **)&net->emb_ws, (size_t)n * net->dev.emb_dim * 4);
-      if (e != hipSuccess) return oakgpu_fail_hip((int)e, "hipMalloc(embedding workspace)");
-      net->emb_ws_rows = n;
-    }
-    emb = net->emb_ws;
+  if (!emb) { // per-context (= per-stream) workspace: contexts sharing a network never share scratch memory
+    emb = (float *)oakgpu_ctx_workspace(ctx, 0, (size_t)n * net->dev.emb_dim * 4);
+    if (!emb) return -1;
   }
   const oak::NetDev &D = net->dev;
   static const int embed_impl = getenv("OAKGPU_EMBED_IMPL") ? atoi(getenv("OAKGPU_EMBED_IMPL")) : 3;
@@ -1252,16 +1243,8 @@ static int leaf_eval_impl(oakgpu_ctx *ctx, oakgpu_net *net, const uint8_t *battl
   }
   float *h1 = nullptr;
   if (pol) {
-    if (net->h1_ws_rows < n) {
-      hipError_t e2 = hipStreamSynchronize(stream);
-      if (e2 != hipSuccess) return oakgpu_fail_hip((int)e2, "hipStreamSynchronize");
-      if (net->h1_ws) (void)hipFree(net->h1_ws);
-      net->h1_ws = nullptr;
-      e2 = hipMalloc((void **)&net->h1_ws, (size_t)n * D.H * 4);
-      if (e2 != hipSuccess) return oakgpu_fail_hip((int)e2, "hipMalloc(policy workspace)");
-      net->h1_ws_rows = n;
-    }
-    h1 = net->h1_ws;
+    h1 = (float *)oakgpu_ctx_workspace(ctx, 1, (size_t)n * D.H * 4);
+    if (!h1) return -1;
   }
   oak::MainArgs ma{D, emb, n, values, h1};
   const int hld = (D.H > D.VH ? D.H : D.VH) + 1;
@@ -1275,7 +1258,7 @@ static int leaf_eval_impl(oakgpu_ctx *ctx, oakgpu_net *net, const uint8_t *battl
     oak::PolicyArgs pa = *pol;
     pa.net = D;
     pa.h1 = h1;
-    const size_t pl_lds = (size_t)((oak::TM + oak::MAXH) * (oak::KC_POLICY + 1) + oak::TM * (D.H + 1) + oak::TM * (D.PH + 1)) * 4;
+    const size_t pl_lds = (size_t)oak::policy_lds_bytes(D.H, D.PH);
     hipLaunchKernelGGL(oak::k_policy, dim3((n + oak::TM - 1) / oak::TM), dim3(oak::MN_BLOCK), pl_lds, stream, pa);
   }
   hipError_t e = hipGetLastError();
@@ -1310,34 +1293,29 @@ int oakgpu_leaf_eval_policy_dev(oakgpu_ctx *ctx, oakgpu_net *net, const uint8_t 
   return leaf_eval_impl(ctx, net, battles, durations, n, values, nullptr, &pa);
 }
 
+#define TRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return oakgpu_fail_hip((int)e_, #x); } while (0)
+#define STAGE(var, bytes) void *var = hc.get(bytes); if (!var) return -1
+
 int oakgpu_leaf_eval(oakgpu_ctx *ctx, oakgpu_net *net, const uint8_t *battles, const uint8_t *durations, uint32_t n,
                      float *values, float *embedding_out) {
   if (!ctx || !net) return oakgpu_fail_msg("oakgpu_leaf_eval: null ctx/net");
   if (n == 0) return 0;
+  if (!battles || !durations || !values) return oakgpu_fail_msg("oakgpu_leaf_eval: null required pointer");
+  if (int rc = oakgpu_ctx_enter(ctx)) return rc;
   hipStream_t stream = (hipStream_t)oakgpu_ctx_stream(ctx);
-  void *db = nullptr, *dd = nullptr, *dv = nullptr, *de = nullptr;
-  int rc = 0;
-  hipError_t e;
-#define TRY(x) do { e = (x); if (e != hipSuccess) { rc = oakgpu_fail_hip((int)e, #x); goto done; } } while (0)
-  TRY(hipSetDevice(oakgpu_ctx_device(ctx)));
-  TRY(hipMalloc(&db, (size_t)n * 384));
-  TRY(hipMalloc(&dd, (size_t)n * 8));
-  TRY(hipMalloc(&dv, (size_t)n * 4));
-  if (embedding_out) TRY(hipMalloc(&de, (size_t)n * net->dev.emb_dim * 4));
+  OakHostCall hc(ctx); // staging buffers from the context's cache; synchronises the stream on every exit
+  STAGE(db, (size_t)n * 384);
+  STAGE(dd, (size_t)n * 8);
+  STAGE(dv, (size_t)n * 4);
+  void *de = nullptr;
+  if (embedding_out) { de = hc.get((size_t)n * net->dev.emb_dim * 4); if (!de) return -1; }
   TRY(hipMemcpyAsync(db, battles, (size_t)n * 384, hipMemcpyHostToDevice, stream));
   TRY(hipMemcpyAsync(dd, durations, (size_t)n * 8, hipMemcpyHostToDevice, stream));
-  rc = oakgpu_leaf_eval_dev(ctx, net, (const uint8_t *)db, (const uint8_t *)dd, n, (float *)dv, (float *)de);
-  if (rc) goto done;
+  if (int rc = oakgpu_leaf_eval_dev(ctx, net, (const uint8_t *)db, (const uint8_t *)dd, n, (float *)dv, (float *)de)) return rc;
   TRY(hipMemcpyAsync(values, dv, (size_t)n * 4, hipMemcpyDeviceToHost, stream));
   if (embedding_out) TRY(hipMemcpyAsync(embedding_out, de, (size_t)n * net->dev.emb_dim * 4, hipMemcpyDeviceToHost, stream));
   TRY(hipStreamSynchronize(stream));
-done:
-  if (db) (void)hipFree(db);
-  if (dd) (void)hipFree(dd);
-  if (dv) (void)hipFree(dv);
-  if (de) (void)hipFree(de);
-  return rc;
-#undef TRY
+  return 0;
 }
 
 int oakgpu_leaf_eval_policy(oakgpu_ctx *ctx, oakgpu_net *net, const uint8_t *battles, const uint8_t *durations, uint32_t n,
@@ -1345,32 +1323,29 @@ int oakgpu_leaf_eval_policy(oakgpu_ctx *ctx, oakgpu_net *net, const uint8_t *bat
                             float *values, float *p1_logits, float *p2_logits) {
   if (!ctx || !net) return oakgpu_fail_msg("oakgpu_leaf_eval_policy: null ctx/net");
   if (n == 0) return 0;
+  if (!battles || !durations || !values || !p1_choices || !p1_counts || !p2_choices || !p2_counts || !p1_logits || !p2_logits)
+    return oakgpu_fail_msg("oakgpu_leaf_eval_policy: null required pointer");
+  if (int rc = oakgpu_ctx_enter(ctx)) return rc;
   hipStream_t stream = (hipStream_t)oakgpu_ctx_stream(ctx);
-  void *db = nullptr, *dd = nullptr, *dv = nullptr, *dc1 = nullptr, *dc2 = nullptr, *dn1 = nullptr, *dn2 = nullptr, *dl1 = nullptr, *dl2 = nullptr;
-  int rc = 0;
-  hipError_t e;
-#define TRY(x) do { e = (x); if (e != hipSuccess) { rc = oakgpu_fail_hip((int)e, #x); goto done; } } while (0)
-  TRY(hipSetDevice(oakgpu_ctx_device(ctx)));
-  TRY(hipMalloc(&db, (size_t)n * 384)); TRY(hipMalloc(&dd, (size_t)n * 8)); TRY(hipMalloc(&dv, (size_t)n * 4));
-  TRY(hipMalloc(&dc1, (size_t)n * 9)); TRY(hipMalloc(&dc2, (size_t)n * 9)); TRY(hipMalloc(&dn1, n)); TRY(hipMalloc(&dn2, n));
-  TRY(hipMalloc(&dl1, (size_t)n * 36)); TRY(hipMalloc(&dl2, (size_t)n * 36));
+  OakHostCall hc(ctx);
+  STAGE(db, (size_t)n * 384); STAGE(dd, (size_t)n * 8); STAGE(dv, (size_t)n * 4);
+  STAGE(dc1, (size_t)n * 9); STAGE(dc2, (size_t)n * 9); STAGE(dn1, n); STAGE(dn2, n);
+  STAGE(dl1, (size_t)n * 36); STAGE(dl2, (size_t)n * 36);
   TRY(hipMemcpyAsync(db, battles, (size_t)n * 384, hipMemcpyHostToDevice, stream));
   TRY(hipMemcpyAsync(dd, durations, (size_t)n * 8, hipMemcpyHostToDevice, stream));
   TRY(hipMemcpyAsync(dc1, p1_choices, (size_t)n * 9, hipMemcpyHostToDevice, stream));
   TRY(hipMemcpyAsync(dc2, p2_choices, (size_t)n * 9, hipMemcpyHostToDevice, stream));
   TRY(hipMemcpyAsync(dn1, p1_counts, n, hipMemcpyHostToDevice, stream));
   TRY(hipMemcpyAsync(dn2, p2_counts, n, hipMemcpyHostToDevice, stream));
-  rc = oakgpu_leaf_eval_policy_dev(ctx, net, (const uint8_t *)db, (const uint8_t *)dd, n, (const uint8_t *)dc1, (const uint8_t *)dn1,
-                                   (const uint8_t *)dc2, (const uint8_t *)dn2, (float *)dv, (float *)dl1, (float *)dl2);
-  if (rc) goto done;
+  if (int rc = oakgpu_leaf_eval_policy_dev(ctx, net, (const uint8_t *)db, (const uint8_t *)dd, n, (const uint8_t *)dc1, (const uint8_t *)dn1,
+                                           (const uint8_t *)dc2, (const uint8_t *)dn2, (float *)dv, (float *)dl1, (float *)dl2)) return rc;
   TRY(hipMemcpyAsync(values, dv, (size_t)n * 4, hipMemcpyDeviceToHost, stream));
   TRY(hipMemcpyAsync(p1_logits, dl1, (size_t)n * 36, hipMemcpyDeviceToHost, stream));
   TRY(hipMemcpyAsync(p2_logits, dl2, (size_t)n * 36, hipMemcpyDeviceToHost, stream));
   TRY(hipStreamSynchronize(stream));
-done:
-  for (void *p : {db, dd, dv, dc1, dc2, dn1, dn2, dl1, dl2}) if (p) (void)hipFree(p);
-  return rc;
-#undef TRY
+  return 0;
 }
+#undef TRY
+#undef STAGE
 
 } // extern "C"

@@ -14,6 +14,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <random>
 #include <string>
 #include <vector>
 
@@ -246,6 +247,70 @@ __global__ __launch_bounds__(BLK, 2) void k_rollout_regs(RolloutArgs a) {
   uint32_t *pdst = (uint32_t *)a.prng + 2 * (size_t)lane;
   pdst[0] = g.s0;
   pdst[1] = g.s1;
+  if (a.durations_out) {
+    uint32_t *ddst = (uint32_t *)a.durations_out + 2 * (size_t)lane;
+    ddst[0] = e.S.dur;
+    ddst[1] = e.F.dur;
+  }
+  if (a.battles_out) e.store_battle_global(a.battles_out + (size_t)lane * 384);
+}
+
+// ---- K1 driven by a caller-supplied DRAW STREAM instead of per-lane fast_prng: lane i consumes
+// draws[offsets[i]], draws[offsets[i] + 1], ... -- one u64 per device.uniform_64() call of the reference loop (with
+// prep the first goes to battle.rng, mcts.h:255-257, then one per turn-step, mcts.h:452).  This is how a SHARED
+// sequential generator (benchmark.cc:24: one std::mt19937 for every playout) is replayed on the device: the host
+// generates the generator's output once, and playout i starts where playout i-1 stopped (oakgpu_rollout_shared_device).
+// stride 0 for battles / durations / results_in = every lane starts from the same root state.  A lane that would
+// read past the end of the stream stops there and reports used = 0xFFFFFFFF.
+struct DrawArgs {
+  const uint8_t *battles, *durations, *results_in;
+  uint32_t battle_stride, dur_stride, res_stride; // bytes (384 / 8 / 1) or 0
+  const uint64_t *draws;
+  uint32_t n_draws;
+  const uint32_t *offsets; // nullable: lane i starts at draw i
+  uint32_t n, max_steps;
+  int prep;
+  uint8_t *results_out;   // every output below is nullable
+  uint32_t *steps_out;
+  float *values_out;
+  uint8_t *battles_out, *durations_out;
+  uint32_t *used_out;     // draws consumed by lane i
+};
+template <int BLK>
+__global__ __launch_bounds__(BLK, 2) void k_rollout_draws(DrawArgs a) {
+  extern __shared__ __align__(16) uint8_t smem[];
+  lds_u32 *party = (lds_u32 *)smem;
+  using ER = EngineR<BLK, false>;
+  Tables T = stage_default_tables((lds_u8 *)smem + ER::PARTY_WORDS * BLK * 4);
+  __syncthreads();
+  const uint32_t tid = threadIdx.x, lane = blockIdx.x * BLK + tid;
+  if (lane >= a.n) return;
+  const uint32_t *dsrc = (const uint32_t *)(a.durations + (size_t)lane * a.dur_stride);
+  ER e;
+  e.m = party + tid;
+  e.T = T;
+  e.load_battle_global(a.battles + (size_t)lane * a.battle_stride, dsrc[0], dsrc[1]);
+  uint32_t pos = a.offsets ? a.offsets[lane] : lane;
+  const uint32_t first = pos;
+  bool over = false;
+  if (a.prep) { // mcts.h:254-259
+    if (pos < a.n_draws) { e.rng = a.draws[pos++]; e.randomize_hidden(); }
+    else over = true;
+  }
+  uint32_t result = a.results_in[(size_t)lane * a.res_stride];
+  uint32_t steps = 0;
+  while (!over && (result & 15) == 0 && steps < a.max_steps) {
+    if (pos >= a.n_draws) { over = true; break; }
+    const uint64_t dr = a.draws[pos++];
+    result = e.random_step(result, (uint32_t)(dr >> 32), (uint32_t)dr);
+    ++steps;
+  }
+  e.normalize();
+  if (a.used_out) a.used_out[lane] = over ? 0xFFFFFFFFu : pos - first;
+  if (a.results_out) a.results_out[lane] = (uint8_t)result;
+  if (a.steps_out) a.steps_out[lane] = steps;
+  const uint32_t t = result & 15;
+  if (a.values_out) a.values_out[lane] = t == R_WIN ? 1.0f : t == R_LOSE ? 0.0f : 0.5f;
   if (a.durations_out) {
     uint32_t *ddst = (uint32_t *)a.durations_out + 2 * (size_t)lane;
     ddst[0] = e.S.dur;
@@ -771,6 +836,10 @@ struct oakgpu_ctx {
   void *h_table, *d_table; // batch tables of the group launches: pinned host ring -> device ring
   hipEvent_t table_ev[TABLE_SLOTS];
   uint64_t table_next;
+  struct Block { void *p; size_t cap; };
+  std::vector<Block> stage; // staging buffers of the host-pointer entry points (oakgpu_internal.h)
+  size_t stage_cursor;
+  Block ws[2];              // leaf-evaluator workspaces
 };
 
 static thread_local std::string g_err;
@@ -785,8 +854,42 @@ static int bad(const char *what) {
 int oakgpu_fail_hip(int e, const char *what) { return fail((hipError_t)e, what); }
 int oakgpu_fail_msg(const char *what) { return bad(what); }
 int oakgpu_ctx_device(const oakgpu_ctx *c) { return c->device; }
+int oakgpu_ctx_enter(oakgpu_ctx *c) {
+  hipError_t e = hipSetDevice(c->device);
+  return e == hipSuccess ? 0 : fail(e, "hipSetDevice");
+}
+static void *grow_block(oakgpu_ctx *c, oakgpu_ctx::Block &b, size_t bytes) {
+  if (b.cap >= bytes && b.p) return b.p;
+  if (b.p) { // a launch on this context's stream may still use the old block
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipFree(b.p);
+    b.p = nullptr;
+    b.cap = 0;
+  }
+  const size_t cap = (bytes + (1u << 20) - 1) & ~(size_t)((1u << 20) - 1);
+  hipError_t e = hipMalloc(&b.p, cap);
+  if (e != hipSuccess) { b.p = nullptr; fail(e, "hipMalloc(context buffer)"); return nullptr; }
+  b.cap = cap;
+  return b.p;
+}
+void *oakgpu_ctx_workspace(oakgpu_ctx *c, int slot, size_t bytes) { return grow_block(c, c->ws[slot & 1], bytes ? bytes : 1); }
+void oakgpu_stage_begin(oakgpu_ctx *c) { c->stage_cursor = 0; }
+void oakgpu_stage_end(oakgpu_ctx *c) { (void)hipStreamSynchronize(c->stream); }
+void *oakgpu_stage_get(oakgpu_ctx *c, size_t bytes) {
+  if (c->stage_cursor >= c->stage.size()) c->stage.push_back(oakgpu_ctx::Block{nullptr, 0});
+  return grow_block(c, c->stage[c->stage_cursor++], bytes ? bytes : 1);
+}
 void *oakgpu_ctx_stream(const oakgpu_ctx *c) { return (void *)c->stream; }
 #define HIPCHK(x) do { hipError_t _e = (x); if (_e != hipSuccess) return fail(_e, #x); } while (0)
+
+// ---- host-buffer conveniences (PCIe-inclusive; never the benchmarked path) ------------------
+namespace {
+struct DevBuf { // one staging buffer of the current host call (owned by the context's grow-only cache)
+  void *p = nullptr;
+  size_t bytes = 0;
+  hipError_t alloc(size_t b, oakgpu_ctx *c) { bytes = b; p = oakgpu_stage_get(c, b); return p ? hipSuccess : hipErrorOutOfMemory; }
+};
+} // namespace
 
 extern "C" {
 
@@ -803,6 +906,7 @@ static int set_lds_limits() {
   HIPCHK(hipFuncSetAttribute((const void *)oak::k_rollout<64>, hipFuncAttributeMaxDynamicSharedMemorySize, oak::STATE_WORDS * 64 * 4 + oak::TABLE_LDS_PAD));
   HIPCHK(hipFuncSetAttribute((const void *)oak::k_rollout_regs<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 24 * 128 * 4 + oak::TABLE_LDS_PAD));
   HIPCHK(hipFuncSetAttribute((const void *)oak::k_rollout_regs<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 24 * 64 * 4 + oak::TABLE_LDS_PAD));
+  HIPCHK(hipFuncSetAttribute((const void *)oak::k_rollout_draws<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 24 * 64 * 4 + oak::TABLE_LDS_PAD));
 #define OAK_LIM_Q(W) HIPCHK(hipFuncSetAttribute((const void *)oak::k_rollout_queue<64, W>, hipFuncAttributeMaxDynamicSharedMemorySize, 24 * 64 * 4 + oak::TABLE_LDS_PAD + oak::COLD_LDS_BYTES))
   OAK_LIM_Q(2); OAK_LIM_Q(3); OAK_LIM_Q(4);
 #undef OAK_LIM_Q
@@ -821,7 +925,8 @@ int oakgpu_create(oakgpu_ctx **out, int device) {
   if (n <= 0) return bad("oakgpu_create: no HIP device (this library has no CPU fallback)");
   if (device < 0 || device >= n) return bad("oakgpu_create: device index out of range");
   HIPCHK(hipSetDevice(device));
-  if (int r = set_lds_limits()) return r;
+  if (int r = set_lds_limits()) return r;         // kernel attributes are per device: set for every context's device
+  if (int r = oakgpu_leaf_set_lds_limits()) return r;
   oakgpu_ctx *c = new oakgpu_ctx();
   c->device = device;
   c->own_stream = true;
@@ -836,6 +941,8 @@ int oakgpu_create(oakgpu_ctx **out, int device) {
   c->scratch_n = 0;
   c->h_table = c->d_table = nullptr;
   c->table_next = 0;
+  c->stage_cursor = 0;
+  c->ws[0] = c->ws[1] = oakgpu_ctx::Block{nullptr, 0};
   c->rounds_auto = 1;
   if (const char *env = getenv("OAKGPU_ROUNDS_AUTO")) c->rounds_auto = atoi(env) != 0;
   {
@@ -870,6 +977,8 @@ void oakgpu_destroy(oakgpu_ctx *c) {
   if (c->d_sizes) (void)hipFree(c->d_sizes);
   if (c->d_queue) (void)hipFree(c->d_queue);
   if (c->d_scratch) (void)hipFree(c->d_scratch);
+  for (auto &b : c->stage) if (b.p) (void)hipFree(b.p);
+  for (auto &b : c->ws) if (b.p) (void)hipFree(b.p);
   if (c->h_table) {
     (void)hipHostFree(c->h_table);
     (void)hipFree(c->d_table);
@@ -1042,11 +1151,116 @@ int oakgpu_rollout_dev(oakgpu_ctx *c, const uint8_t *battles, const uint8_t *dur
   return oakgpu_rollout_group_dev(c, &b, 1, max_steps, prep);
 }
 
+int oakgpu_rollout_draws_dev(oakgpu_ctx *c, const uint8_t *battles, uint32_t battle_stride, const uint8_t *durations,
+                             uint32_t durations_stride, const uint8_t *results_in, uint32_t results_stride, const uint64_t *draws,
+                             uint32_t n_draws, const uint32_t *offsets, uint32_t n, uint32_t max_steps, int prep,
+                             uint8_t *results_out, uint32_t *steps_out, float *values_out, uint8_t *battles_out,
+                             uint8_t *durations_out, uint32_t *used_out) {
+  if (!c) return bad("null ctx");
+  if (n == 0) return 0;
+  if (!battles || !durations || !results_in || !draws) return bad("oakgpu_rollout_draws_dev: null required pointer");
+  if ((battle_stride != 0 && battle_stride != 384) || (durations_stride != 0 && durations_stride != 8) || results_stride > 1)
+    return bad("oakgpu_rollout_draws_dev: strides must be 0 (one shared root) or the element size");
+  HIPCHK(hipSetDevice(c->device));
+  const oak::DrawArgs a{battles, durations, results_in, battle_stride, durations_stride, results_stride, draws, n_draws, offsets, n,
+                        max_steps, prep, results_out, steps_out, values_out, battles_out, durations_out, used_out};
+  hipLaunchKernelGGL(oak::k_rollout_draws<64>, dim3((n + 63) / 64), dim3(64), 24 * 64 * 4 + oak::TABLE_LDS_PAD, c->stream, a);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// std::mt19937 + the reference's uniform_64 (util/random.h:37: std::uniform_int_distribution<uint64_t> over the full
+// range = two 32-bit outputs, high word first -- pinned by tests/golden/rng_known_answers.json)
+int oakgpu_mt19937_fill(uint32_t seed, uint64_t skip, uint64_t *out, size_t count) {
+  if (!out && count) return bad("oakgpu_mt19937_fill: null out");
+  std::mt19937 g{seed};
+  g.discard(2 * skip);
+  for (size_t i = 0; i < count; ++i) {
+    const uint64_t hi = g(), lo = g();
+    out[i] = (hi << 32) | lo;
+  }
+  return 0;
+}
+
+// n playouts from ONE root driven by ONE sequential device generator (benchmark.cc:23-31 + mcts.h:250-263,448-496):
+// playout i consumes the generator's output right where playout i-1 stopped, so its start offset depends on every
+// earlier playout's length.  Resolved on the device without serialising the playouts: pass 1 plays a playout from
+// EVERY possible start offset (one lane per draw of the stream; only the number of draws it consumes is kept), the host
+// then follows the chain offset[i+1] = offset[i] + used[offset[i]], and pass 2 plays the n real playouts from their
+// resolved offsets with full outputs.
+int oakgpu_rollout_shared_device(oakgpu_ctx *c, const uint8_t *battle, const uint8_t *durations, uint8_t result,
+                                 const uint64_t *draws, uint32_t n_draws, uint32_t n, uint32_t max_steps, int prep,
+                                 uint8_t *results_out, uint32_t *steps_out, float *values_out, uint8_t *battles_out,
+                                 uint8_t *durations_out, uint32_t *offsets_out, uint64_t *draws_consumed) {
+  if (!c) return bad("null ctx");
+  if (!battle || !durations || (!draws && n_draws)) return bad("oakgpu_rollout_shared_device: null required pointer");
+  if (draws_consumed) *draws_consumed = 0;
+  if (n == 0) return 0;
+  HIPCHK(hipSetDevice(c->device));
+  OakHostCall hc(c);
+  DevBuf root, dr, used, off, ro, st, va, bo, dd;
+  hipError_t e = hipSuccess;
+  int rc = 0;
+  std::vector<uint32_t> h_used(n_draws), h_off(n);
+  uint8_t h_root[384 + 8 + 8] = {};
+  memcpy(h_root, battle, 384);
+  memcpy(h_root + 384, durations, 8);
+  h_root[392] = result;
+  auto ok = [&]() { return e == hipSuccess && rc == 0; };
+  e = root.alloc(sizeof h_root, c);
+  if (ok()) e = hipMemcpyAsync(root.p, h_root, sizeof h_root, hipMemcpyHostToDevice, c->stream);
+  if (ok()) e = dr.alloc((size_t)n_draws * 8 + 8, c);
+  if (ok() && n_draws) e = hipMemcpyAsync(dr.p, draws, (size_t)n_draws * 8, hipMemcpyHostToDevice, c->stream);
+  if (ok()) e = used.alloc((size_t)n_draws * 4 + 4, c);
+  const uint8_t *rb = (const uint8_t *)root.p;
+  // pass 1: draws consumed by a playout started at every offset
+  if (ok() && n_draws)
+    rc = oakgpu_rollout_draws_dev(c, rb, 0, rb + 384, 0, rb + 392, 0, (const uint64_t *)dr.p, n_draws, nullptr, n_draws, max_steps, prep,
+                                  nullptr, nullptr, nullptr, nullptr, nullptr, (uint32_t *)used.p);
+  if (ok() && n_draws) e = hipMemcpyAsync(h_used.data(), used.p, (size_t)n_draws * 4, hipMemcpyDeviceToHost, c->stream);
+  if (ok()) e = hipStreamSynchronize(c->stream);
+  bool short_stream = false;
+  if (ok()) { // the chain
+    uint64_t pos = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+      if (pos >= n_draws || h_used[pos] == 0xFFFFFFFFu) { short_stream = true; break; }
+      h_off[i] = (uint32_t)pos;
+      pos += h_used[pos];
+    }
+    if (!short_stream && draws_consumed) *draws_consumed = pos;
+  }
+  // pass 2: the n playouts themselves
+  if (ok() && !short_stream) {
+    e = off.alloc((size_t)n * 4, c);
+    if (ok()) e = hipMemcpyAsync(off.p, h_off.data(), (size_t)n * 4, hipMemcpyHostToDevice, c->stream);
+    if (ok()) e = ro.alloc(n, c);
+    if (ok()) e = st.alloc((size_t)n * 4, c);
+    if (ok()) e = va.alloc((size_t)n * 4, c);
+    if (ok() && battles_out) e = bo.alloc((size_t)n * 384, c);
+    if (ok() && durations_out) e = dd.alloc((size_t)n * 8, c);
+    if (ok())
+      rc = oakgpu_rollout_draws_dev(c, rb, 0, rb + 384, 0, rb + 392, 0, (const uint64_t *)dr.p, n_draws, (const uint32_t *)off.p, n, max_steps,
+                                    prep, (uint8_t *)ro.p, (uint32_t *)st.p, (float *)va.p, (uint8_t *)bo.p, (uint8_t *)dd.p, nullptr);
+    auto down = [&](void *host, DevBuf &buf) {
+      if (ok() && host && buf.p) e = hipMemcpyAsync(host, buf.p, buf.bytes, hipMemcpyDeviceToHost, c->stream);
+    };
+    down(results_out, ro); down(steps_out, st); down(values_out, va); down(battles_out, bo); down(durations_out, dd);
+    if (ok() && offsets_out) memcpy(offsets_out, h_off.data(), (size_t)n * 4);
+  }
+  const hipError_t se = hipStreamSynchronize(c->stream);
+  if (e != hipSuccess) return fail(e, "oakgpu_rollout_shared_device");
+  if (rc) return rc;
+  if (se != hipSuccess) return fail(se, "hipStreamSynchronize");
+  if (short_stream) return bad("oakgpu_rollout_shared_device: the draw stream is too short for n playouts");
+  return 0;
+}
+
 int oakgpu_update_dev(oakgpu_ctx *c, uint8_t *battles, const uint8_t *c1, const uint8_t *c2, uint8_t *durations,
                       uint8_t *actions, const uint8_t *overrides, uint32_t n, uint8_t *results) {
   if (!c) return bad("null ctx");
   if (n == 0) return 0;
   if (!battles || !c1 || !c2 || !durations || !results) return bad("oakgpu_update_dev: null required pointer");
+  HIPCHK(hipSetDevice(c->device));
   hipLaunchKernelGGL(oak::k_update, dim3(grid_for(n)), dim3(oak::BLOCK), oak::ENGINE_LDS_BYTES, c->stream, battles, c1, c2,
                      durations, actions, overrides, n, results);
   HIPCHK(hipGetLastError());
@@ -1058,6 +1272,7 @@ int oakgpu_choices_dev(oakgpu_ctx *c, const uint8_t *battles, const uint8_t *res
   if (!c) return bad("null ctx");
   if (n == 0) return 0;
   if (!battles || !results || !out || !counts || player < 0 || player > 1) return bad("oakgpu_choices_dev: bad argument");
+  HIPCHK(hipSetDevice(c->device));
   hipLaunchKernelGGL(oak::k_choices, dim3(grid_for(n)), dim3(oak::BLOCK), oak::ENGINE_LDS_BYTES, c->stream, battles, results,
                      player, out, counts, n);
   HIPCHK(hipGetLastError());
@@ -1072,6 +1287,7 @@ int oakgpu_tree_step_dev(oakgpu_ctx *c, uint8_t *battles, uint8_t *durations, ui
   if (!battles || !durations || !results || !c1 || !c2 || !actions || !p1_choices || !p1_counts || !p2_choices || !p2_counts)
     return bad("oakgpu_tree_step_dev: null required pointer");
   if (!(rolls == 1 || rolls == 2 || rolls == 3 || rolls == 20 || rolls == 39)) return bad("oakgpu_tree_step_dev: rolls must be 1, 2, 3, 20 or 39");
+  HIPCHK(hipSetDevice(c->device));
   hipLaunchKernelGGL(oak::k_tree_step, dim3(grid_for(n)), dim3(oak::BLOCK), oak::ENGINE_LDS_BYTES, c->stream, battles, durations,
                      results, c1, c2, n, rolls, actions, p1_choices, p1_counts, p2_choices, p2_counts);
   HIPCHK(hipGetLastError());
@@ -1082,6 +1298,7 @@ int oakgpu_poke_engine_eval_dev(oakgpu_ctx *c, const uint8_t *battles, uint32_t 
   if (!c) return bad("null ctx");
   if (n == 0) return 0;
   if (!battles || (!values && !scores)) return bad("oakgpu_poke_engine_eval_dev: null required pointer");
+  HIPCHK(hipSetDevice(c->device));
   hipLaunchKernelGGL(oak::k_poke_engine, dim3((n + 255) / 256), dim3(256), 0, c->stream, battles, n, root_score, values, scores);
   HIPCHK(hipGetLastError());
   return 0;
@@ -1092,22 +1309,17 @@ int oakgpu_poke_engine_eval(oakgpu_ctx *c, const uint8_t *battles, uint32_t n, f
   if (n == 0) return 0;
   if (!battles || (!values && !scores)) return bad("oakgpu_poke_engine_eval: null required pointer");
   HIPCHK(hipSetDevice(c->device));
-  uint8_t *db = nullptr;
-  float *dv = nullptr, *ds = nullptr;
-  HIPCHK(hipMalloc((void **)&db, (size_t)n * 384));
-  hipError_t e = hipMalloc((void **)&dv, (size_t)n * 8);
-  if (e != hipSuccess) { (void)hipFree(db); return fail(e, "hipMalloc"); }
-  ds = dv + n;
-  int rc = 0;
-  e = hipMemcpyAsync(db, battles, (size_t)n * 384, hipMemcpyHostToDevice, c->stream);
-  if (e == hipSuccess) rc = oakgpu_poke_engine_eval_dev(c, db, n, root_score, dv, ds);
-  if (e == hipSuccess && !rc && values) e = hipMemcpyAsync(values, dv, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream);
-  if (e == hipSuccess && !rc && scores) e = hipMemcpyAsync(scores, ds, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream);
-  if (e == hipSuccess && !rc) e = hipStreamSynchronize(c->stream);
-  (void)hipFree(db);
-  (void)hipFree(dv);
-  if (e != hipSuccess) return fail(e, "oakgpu_poke_engine_eval");
-  return rc;
+  OakHostCall hc(c);
+  DevBuf db, dv;
+  HIPCHK(db.alloc((size_t)n * 384, c));
+  HIPCHK(dv.alloc((size_t)n * 8, c));
+  float *fv = (float *)dv.p, *fs = fv + n;
+  HIPCHK(hipMemcpyAsync(db.p, battles, (size_t)n * 384, hipMemcpyHostToDevice, c->stream));
+  if (int rc = oakgpu_poke_engine_eval_dev(c, (const uint8_t *)db.p, n, root_score, fv, fs)) return rc;
+  if (values) HIPCHK(hipMemcpyAsync(values, fv, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+  if (scores) HIPCHK(hipMemcpyAsync(scores, fs, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return 0;
 }
 
 int oakgpu_init_battles_dev(oakgpu_ctx *c, const uint8_t *teams, const uint64_t *seeds, uint32_t n, int first_update,
@@ -1115,6 +1327,7 @@ int oakgpu_init_battles_dev(oakgpu_ctx *c, const uint8_t *teams, const uint64_t 
   if (!c) return bad("null ctx");
   if (n == 0) return 0;
   if (!teams || !seeds || !battles) return bad("oakgpu_init_battles_dev: null required pointer");
+  HIPCHK(hipSetDevice(c->device));
   hipLaunchKernelGGL(oak::k_init, dim3(grid_for(n)), dim3(oak::BLOCK), oak::ENGINE_LDS_BYTES, c->stream, teams, seeds, n,
                      first_update, battles, durations, results);
   HIPCHK(hipGetLastError());
@@ -1122,7 +1335,26 @@ int oakgpu_init_battles_dev(oakgpu_ctx *c, const uint8_t *teams, const uint64_t 
 }
 
 int oakgpu_set_ou_pools(oakgpu_ctx *c, const uint8_t *legal, int n_legal, const uint8_t *pools, const uint8_t *sizes) {
-  if (!c || !legal || !pools || !sizes || n_legal <= 0 || n_legal > 152) return bad("oakgpu_set_ou_pools: bad argument");
+  if (!c || !legal || !pools || !sizes || n_legal > 152) return bad("oakgpu_set_ou_pools: bad argument");
+  // k_random_ou draws 6 DISTINCT species per side and min(4, pool) distinct moves per species by rejection: with fewer
+  // than 6 distinct legal species, or a pool holding repeated / too few move ids, its loops would never terminate
+  if (n_legal < 6) return bad("oakgpu_set_ou_pools: at least 6 legal species are required");
+  {
+    bool seen[256] = {};
+    for (int i = 0; i < n_legal; ++i) {
+      const uint8_t sp = legal[i];
+      if (sp == 0 || sp >= 152 || seen[sp]) return bad("oakgpu_set_ou_pools: legal species must be distinct ids in 1..151");
+      seen[sp] = true;
+      const uint32_t psz = sizes[sp];
+      if (psz == 0 || psz > 48) return bad("oakgpu_set_ou_pools: every legal species needs a move pool of 1..48 moves");
+      bool mseen[256] = {};
+      for (uint32_t k = 0; k < psz; ++k) {
+        const uint8_t mv = pools[(size_t)sp * 48 + k];
+        if (mv == 0 || mv > 165 || mseen[mv]) return bad("oakgpu_set_ou_pools: move pools must hold distinct move ids in 1..165");
+        mseen[mv] = true;
+      }
+    }
+  }
   HIPCHK(hipSetDevice(c->device));
   if (!c->d_legal) {
     HIPCHK(hipMalloc((void **)&c->d_legal, 152));
@@ -1142,6 +1374,7 @@ int oakgpu_random_ou_battles_dev(oakgpu_ctx *c, uint64_t seed0, uint32_t n, uint
   if (!c->d_legal) return bad("oakgpu_random_ou_battles_dev: call oakgpu_set_ou_pools first");
   if (n == 0) return 0;
   if (!battles || !durations || !prng_state || !results) return bad("oakgpu_random_ou_battles_dev: null pointer");
+  HIPCHK(hipSetDevice(c->device));
   hipLaunchKernelGGL(oak::k_random_ou, dim3(grid_for(n)), dim3(oak::BLOCK), oak::ENGINE_LDS_BYTES, c->stream, seed0, n,
                      c->d_legal, c->n_legal, c->d_pools, c->d_sizes, battles, durations, prng_state, results);
   HIPCHK(hipGetLastError());
@@ -1149,16 +1382,7 @@ int oakgpu_random_ou_battles_dev(oakgpu_ctx *c, uint64_t seed0, uint32_t n, uint
 }
 
 // ---- host-buffer conveniences (PCIe-inclusive; never the benchmarked path) ------------------
-namespace {
-struct DevBuf { // stream-ordered allocation from the device's memory pool: after the first call no hipMalloc / hipFree
-  void *p = nullptr;
-  size_t bytes = 0;
-  hipStream_t s = nullptr;
-  hipError_t alloc(size_t b, hipStream_t stream) { bytes = b; s = stream; return b ? hipMallocAsync(&p, b, stream) : hipSuccess; }
-  ~DevBuf() { if (p) (void)hipFreeAsync(p, s); }
-};
-} // namespace
-#define UP(buf, host, nbytes) do { HIPCHK((buf).alloc(nbytes, c->stream)); if (host) HIPCHK(hipMemcpyAsync((buf).p, host, nbytes, hipMemcpyHostToDevice, c->stream)); } while (0)
+#define UP(buf, host, nbytes) do { HIPCHK((buf).alloc(nbytes, c)); if (host) HIPCHK(hipMemcpyAsync((buf).p, host, nbytes, hipMemcpyHostToDevice, c->stream)); } while (0)
 #define DOWN(host, buf) do { if (host) HIPCHK(hipMemcpyAsync(host, (buf).p, (buf).bytes, hipMemcpyDeviceToHost, c->stream)); } while (0)
 
 int oakgpu_rollout_group(oakgpu_ctx *c, const oakgpu_rollout_batch *batches, uint32_t count, uint32_t max_steps, int prep) {
@@ -1172,6 +1396,7 @@ int oakgpu_rollout_group(oakgpu_ctx *c, const oakgpu_rollout_batch *batches, uin
       return bad("oakgpu_rollout_group: null required pointer");
   }
   HIPCHK(hipSetDevice(c->device));
+  OakHostCall hc(c);
   struct Bufs { DevBuf b, d, ri, pr, ro, st, va, bo, dd; };
   std::vector<Bufs> bufs(count);
   std::vector<oakgpu_rollout_batch> dev(count);
@@ -1179,7 +1404,7 @@ int oakgpu_rollout_group(oakgpu_ctx *c, const oakgpu_rollout_batch *batches, uin
   hipError_t e = hipSuccess;
   auto up = [&](DevBuf &buf, const void *host, size_t nbytes) {
     if (e != hipSuccess) return;
-    e = buf.alloc(nbytes, c->stream);
+    e = buf.alloc(nbytes, c);
     if (e == hipSuccess && host) e = hipMemcpyAsync(buf.p, host, nbytes, hipMemcpyHostToDevice, c->stream);
   };
   auto down = [&](void *host, DevBuf &buf) {
@@ -1206,7 +1431,6 @@ int oakgpu_rollout_group(oakgpu_ctx *c, const oakgpu_rollout_batch *batches, uin
       down(h.results_out, B.ro); down(h.steps_out, B.st); down(h.values_out, B.va); down(h.prng_state, B.pr);
       down(h.battles_out, B.bo); down(h.durations_out, B.dd);
     }
-  // the copies to / from the caller's buffers (and the buffers' stream-ordered frees) must have finished on every exit
   const hipError_t se = hipStreamSynchronize(c->stream);
   if (e != hipSuccess) return fail(e, "oakgpu_rollout_group");
   if (rc) return rc;
@@ -1225,7 +1449,9 @@ int oakgpu_update(oakgpu_ctx *c, uint8_t *battles, const uint8_t *c1, const uint
                   const uint8_t *overrides, uint32_t n, uint8_t *results) {
   if (!c) return bad("null ctx");
   if (n == 0) return 0;
+  if (!battles || !c1 || !c2 || !durations || !results) return bad("oakgpu_update: null required pointer");
   HIPCHK(hipSetDevice(c->device));
+  OakHostCall hc(c);
   DevBuf b, a1, a2, d, ac, ov, rs;
   UP(b, battles, (size_t)n * 384);
   UP(a1, c1, n);
@@ -1249,7 +1475,9 @@ int oakgpu_choices(oakgpu_ctx *c, const uint8_t *battles, const uint8_t *results
                    uint32_t n) {
   if (!c) return bad("null ctx");
   if (n == 0) return 0;
+  if (!battles || !results || !out || !counts) return bad("oakgpu_choices: null required pointer");
   HIPCHK(hipSetDevice(c->device));
+  OakHostCall hc(c);
   DevBuf b, rs, o, cn;
   UP(b, battles, (size_t)n * 384);
   UP(rs, results, n);
@@ -1267,7 +1495,9 @@ int oakgpu_init_battles(oakgpu_ctx *c, const uint8_t *teams, const uint64_t *see
                         uint8_t *battles, uint8_t *durations, uint8_t *results) {
   if (!c) return bad("null ctx");
   if (n == 0) return 0;
+  if (!teams || !seeds || !battles) return bad("oakgpu_init_battles: null required pointer");
   HIPCHK(hipSetDevice(c->device));
+  OakHostCall hc(c);
   DevBuf t, s, b, d, rs;
   UP(t, teams, (size_t)n * 60);
   UP(s, seeds, (size_t)n * 8);

@@ -122,6 +122,23 @@ class Context:
         _lib.check(self.lib.oakgpu_rollout_group(self.handle, descs, len(batches), max_steps, 1 if prep else 0))
         return outs
 
+    def rollout_shared_device(self, battle, durations, result, draws, n, max_steps=1000, prep=True, return_state=False):
+        """n playouts from ONE root driven by ONE sequential device generator, in the reference's order
+        (benchmark.cc:23-31 + mcts.h:250-263,448-496).  `draws` = the generator's uniform_64() output
+        (mt19937_uniform_64 below).  Returns results / steps / values / offsets / consumed (+ final states)."""
+        draws = np.ascontiguousarray(draws, dtype=np.uint64)
+        res = dict(results=np.zeros(n, dtype=np.uint8), steps=np.zeros(n, dtype=np.uint32), values=np.zeros(n, dtype=np.float32),
+                   offsets=np.zeros(n, dtype=np.uint32))
+        if return_state:
+            res.update(battles=np.zeros((n, 384), dtype=np.uint8), durations=np.zeros((n, 8), dtype=np.uint8))
+        consumed = C.c_uint64(0)
+        _lib.check(self.lib.oakgpu_rollout_shared_device(
+            self.handle, _p(_u8(battle, (384,))), _p(_u8(durations, (8,))), int(result), _p(draws), len(draws), n, max_steps,
+            1 if prep else 0, _p(res["results"]), _p(res["steps"]), _p(res["values"]), _p(res.get("battles")),
+            _p(res.get("durations")), _p(res["offsets"]), C.cast(C.byref(consumed), C.c_void_p)))
+        res["consumed"] = consumed.value
+        return res
+
     def update(self, battles, c1, c2, durations, overrides=None, want_actions=True):
         """In-place batched update; returns (results, actions or None)."""
         n = battles.shape[0]
@@ -156,6 +173,13 @@ class Context:
         _lib.check(self.lib.oakgpu_init_battles(self.handle, _p(teams), _p(seeds), n, 1 if first_update else 0,
                                                 _p(b), _p(d), _p(r)))
         return b, d, r
+
+
+def mt19937_uniform_64(seed, count, skip=0):
+    """std::mt19937{seed} -> `count` uniform_64() values after skipping `skip` (util/random.h:10-65), host side."""
+    out = np.zeros(count, dtype=np.uint64)
+    _lib.check(_lib.load().oakgpu_mt19937_fill(int(seed), int(skip), _p(out), count))
+    return out
 
 
 class Network:

@@ -58,3 +58,14 @@ def test_cpp_host_layer_compiles_and_links(tmp_path):
                            "-Wl,-rpath," + os.path.join(ROOT, "oak_amd"), "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
     out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stdout + out.stderr
+
+
+def test_host_mt19937_fill_matches_reference_known_answers():
+    """oakgpu_mt19937_fill (host side of the shared-generator rollouts) against the std::mt19937 / uniform_64 values
+    dumped from the reference's util/random.h (tests/golden/rng_known_answers.json).  No GPU needed."""
+    import json
+    from oak_amd.engine import mt19937_uniform_64
+    ka = json.load(open(os.path.join(ROOT, "tests", "golden", "rng_known_answers.json")))["mt19937_uniform_64"]
+    for seed, want in ka.items():
+        assert [str(int(x)) for x in mt19937_uniform_64(int(seed), len(want))] == want
+        assert [str(int(x)) for x in mt19937_uniform_64(int(seed), 4, skip=3)] == want[3:7]

@@ -155,3 +155,55 @@ def test_value_policy_inference_config3_net(gpu_ctx, tmp_path):
         worst = max(worst, abs(float(vals[i]) - float(ev)), float(np.abs(l1[i, :n1[i]] - e1).max()), float(np.abs(l2[i, :n2[i]] - e2).max()))
     assert worst <= 2e-5, worst
     net.close()
+
+
+def test_policy_width_limits_are_enforced_at_load(gpu_ctx, tmp_path):
+    """k_policy keeps the hidden and policy-hidden activations of a 64-leaf tile in LDS: at hidden = 256 the widest policy
+    head that fits is 160.  160 must load and agree with the oracle; 192 must be refused by the loader (not fail at the
+    first value_policy_inference launch)."""
+    import oracle_lib as O
+    from oak_amd.engine import Network
+    ok = str(tmp_path / "p160.battle.net")
+    NN.write_random_net(ok, hidden=256, value_hidden=64, policy_hidden=160, seed=11)
+    net, onet = Network(gpu_ctx, path=ok), NN.Net(ok)
+    b, d = _midgame_states(70, 12, 4242)
+    r = np.array([O.LIB.oracle_result_from_state(O.ptr(b[i])) for i in range(b.shape[0])], dtype=np.uint8)
+    keep = (r & 15) == 0
+    b, d, r = b[keep], d[keep], r[keep]
+    c1, n1 = gpu_ctx.choices(b, r, 0)
+    c2, n2 = gpu_ctx.choices(b, r, 1)
+    vals, l1, l2 = net.value_policy_inference(b, d, c1, n1, c2, n2)
+    for i in range(0, b.shape[0], 5):
+        ev, e1, e2 = NN.value_policy_inference(onet, b[i], d[i], c1[i, :n1[i]], c2[i, :n2[i]])
+        assert abs(float(vals[i]) - float(ev)) <= TOL
+        assert np.abs(l1[i, :n1[i]] - e1).max() <= 2e-5 and np.abs(l2[i, :n2[i]] - e2).max() <= 2e-5
+    net.close()
+    bad = str(tmp_path / "p192.battle.net")
+    NN.write_random_net(bad, hidden=256, value_hidden=64, policy_hidden=192, seed=11)
+    with pytest.raises(RuntimeError, match="policy"):
+        Network(gpu_ctx, path=bad)
+
+
+def test_two_contexts_share_one_network(gpu_ctx):
+    """Workspaces (embeddings, policy activations) belong to the CONTEXT (one per stream), not to the network: two
+    contexts evaluating the same loaded network, interleaved and with different batch sizes, each get the oracle's values."""
+    from oak_amd.engine import Context, Network
+    other = Context(0)
+    DEFAULT_NET = os.path.join(ROOT, "tests", "golden", "net_default.battle.net")
+    net, onet = Network(gpu_ctx, path=DEFAULT_NET), NN.Net(DEFAULT_NET)
+    b1, d1 = _midgame_states(300, 10, 77)
+    b2, d2 = _midgame_states(90, 25, 78)
+    for _ in range(3):
+        import ctypes as C
+        v1 = net.value_inference(b1, d1)
+        # same network handle through the second context
+        v2 = np.zeros(b2.shape[0], dtype=np.float32)
+        from oak_amd import _lib
+        _lib.check(other.lib.oakgpu_leaf_eval(other.handle, net.handle, b2.ctypes.data_as(C.c_void_p), d2.ctypes.data_as(C.c_void_p),
+                                              b2.shape[0], v2.ctypes.data_as(C.c_void_p), None))
+        for i in range(0, 300, 37):
+            assert abs(float(v1[i]) - float(NN.value_inference(onet, b1[i], d1[i]))) <= TOL
+        for i in range(0, b2.shape[0], 11):
+            assert abs(float(v2[i]) - float(NN.value_inference(onet, b2[i], d2[i]))) <= TOL
+    net.close()
+    other.close()

@@ -356,3 +356,101 @@ def test_group_launch_matches_separate_launches(gpu_ctx):
     finally:
         gpu_ctx.set_playouts_per_lane(2)
         gpu_ctx.set_regroup()
+
+
+def test_config1_benchmark_playouts_on_the_gpu(gpu_ctx):
+    """BASELINE configs[0]: the two benchmark teams, 1,000 playouts driven by ONE shared std::mt19937{1111111}
+    (benchmark.cc:23-31 + mcts.h:250-263,448-496), through the HIP path: the generator's output is produced on the host
+    (oakgpu_mt19937_fill), start offsets are resolved on the device, and the (turn-steps, P1 wins, final-state digest)
+    triple must equal tests/golden/config1_digest.json byte for byte -- the same file the CPU oracle is held to."""
+    import json
+    import os
+    from oak_amd.engine import mt19937_uniform_64
+    from test_oracle_goldens import benchmark_teams, ROOT
+    teams = np.array(benchmark_teams(), dtype=np.uint8).reshape(1, 2, 6, 5)
+    b0, d0, r0 = gpu_ctx.battle(teams, np.array([1111111], dtype=np.uint64), first_update=True)   # PKMN::battle + update(0, 0)
+    ob = O.init_battle(benchmark_teams(), 1111111)
+    assert O.update(ob, 0, 0, O.Options()) == r0[0] and (ob == b0[0]).all()
+    draws = mt19937_uniform_64(1111111, 200000)
+    got = gpu_ctx.rollout_shared_device(b0[0], d0[0], int(r0[0]), draws, 1000, max_steps=100000, prep=True, return_state=True)
+    digest = 0xcbf29ce484222325
+    for i in range(1000):
+        digest = (digest ^ O.LIB.oracle_hash64(O.ptr(got["battles"][i]), 384)) * 0x100000001b3 % 2**64
+    triple = {"turn_steps": int(got["steps"].sum()), "p1_wins": int(((got["results"] & 15) == 1).sum()), "digest": "%016x" % digest}
+    assert triple == json.load(open(os.path.join(ROOT, "tests", "golden", "config1_digest.json")))
+    assert got["consumed"] == 1000 + triple["turn_steps"]          # one draw for battle.rng + one per turn-step
+    assert got["offsets"][0] == 0 and (np.diff(got["offsets"].astype(np.int64)) == got["steps"][:-1].astype(np.int64) + 1).all()
+    # a stream that is too short is refused, not truncated
+    with pytest.raises(RuntimeError):
+        gpu_ctx.rollout_shared_device(b0[0], d0[0], int(r0[0]), draws[:5000], 1000, max_steps=100000, prep=True)
+
+
+def test_rollout_draws_per_lane_roots_match_oracle(gpu_ctx):
+    """oakgpu_rollout_draws_dev with a different root per lane and explicit offsets: every lane equals the oracle's
+    mt19937-driven rollout started at that offset of the same stream (no prep, capped)."""
+    from oak_amd import _lib
+    from oak_amd.engine import mt19937_uniform_64
+    n = 300
+    b, d, p, r = O.make_random_ou_batch(n, seed0=0xD2A35000)
+    draws = mt19937_uniform_64(77, 4096)
+    offsets = (np.arange(n, dtype=np.uint32) * 7) % 3000
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    hip.hipFree.argtypes = [C.c_void_p]
+
+    def dev(a):
+        ptr = C.c_void_p()
+        assert hip.hipMalloc(C.byref(ptr), max(a.nbytes, 4)) == 0
+        assert hip.hipMemcpy(ptr, np.ascontiguousarray(a).ctypes.data_as(C.c_void_p), a.nbytes, 1) == 0
+        return ptr
+
+    def host(ptr, shape, dtype):
+        out = np.empty(shape, dtype=dtype)
+        assert hip.hipMemcpy(out.ctypes.data_as(C.c_void_p), ptr, out.nbytes, 2) == 0
+        return out
+    outs = dict(res=np.zeros(n, np.uint8), steps=np.zeros(n, np.uint32), vals=np.zeros(n, np.float32), bo=np.zeros((n, 384), np.uint8),
+                do=np.zeros((n, 8), np.uint8), used=np.zeros(n, np.uint32))
+    ptrs = {k: dev(v) for k, v in outs.items()}
+    gb, gd, gr, gdr, goff = dev(b), dev(d), dev(r), dev(draws), dev(offsets)
+    cap = 150
+    _lib.check(gpu_ctx.lib.oakgpu_rollout_draws_dev(gpu_ctx.handle, gb, 384, gd, 8, gr, 1, gdr, len(draws), goff, n, cap, 0, ptrs["res"],
+                                                     ptrs["steps"], ptrs["vals"], ptrs["bo"], ptrs["do"], ptrs["used"]))
+    gpu_ctx.synchronize()
+    got = {k: host(ptrs[k], v.shape, v.dtype) for k, v in outs.items()}
+    for x in list(ptrs.values()) + [gb, gd, gr, gdr, goff]:
+        hip.hipFree(x)
+    for i in range(n):
+        ob, od = b[i].copy(), d[i].copy()
+        opt = O.Options(od)
+        res, k = int(r[i]), 0
+        while (res & 15) == 0 and k < cap:
+            seed = int(draws[offsets[i] + k])
+            c1s, c2s = O.choices(ob, 0, (res >> 4) & 3), O.choices(ob, 1, (res >> 6) & 3)
+            opt.set()
+            res = O.update(ob, int(c1s[seed % len(c1s)]), int(c2s[(seed >> 32) % len(c2s)]), opt)
+            k += 1
+        assert got["steps"][i] == k and got["used"][i] == k and got["res"][i] == res, i
+        assert (got["bo"][i] == ob).all() and (got["do"][i] == opt.durations).all(), i
+
+
+def test_set_ou_pools_rejects_inputs_that_would_hang_the_generator():
+    """k_random_ou picks 6 distinct species per side and distinct moves per species by rejection: fewer than 6 legal
+    species, duplicates, or a pool with repeated moves would spin forever on the GPU -- the ABI refuses them."""
+    from oak_amd import _lib, gamedata
+    from oak_amd.engine import Context
+    ctx = Context(0)
+    legal, pools, sizes = gamedata.ou_pools()
+    pools = np.ascontiguousarray(pools)
+    P = lambda a: a.ctypes.data_as(C.c_void_p)
+    call = lambda l, n, p, s: ctx.lib.oakgpu_set_ou_pools(ctx.handle, P(l), n, P(p), P(s))
+    assert call(legal, len(legal), pools, sizes) == 0
+    assert call(legal, 5, pools, sizes) != 0                       # fewer than 6 species
+    dup = legal.copy(); dup[3] = dup[2]
+    assert call(dup, len(dup), pools, sizes) != 0                  # duplicate species
+    bad_pool = pools.copy(); bad_pool[int(legal[0]), 1] = bad_pool[int(legal[0]), 0]
+    if sizes[int(legal[0])] >= 2:
+        assert call(legal, len(legal), bad_pool, sizes) != 0       # repeated move in a pool
+    zero = sizes.copy(); zero[int(legal[1])] = 0
+    assert call(legal, len(legal), pools, zero) != 0               # empty pool
+    ctx.close()

@@ -30,13 +30,17 @@ T = lambda *s, dt=torch.uint8: torch.empty(s, dtype=dt, device=dev)
 battles, durations, prng, rin, rout = T(n, 384), T(n, 8), T(n, 8), T(n), T(n)
 steps, values = T(n, dt=torch.int32), T(n, dt=torch.float32)
 P = lambda t: C.c_void_p(t.data_ptr())
-_lib.check(lib.oakgpu_random_ou_battles_dev(h, C.c_uint64(0x0A4B00000000), n, P(battles), P(durations), P(prng), P(rin)))
+_lib.check(lib.oakgpu_random_ou_battles_dev(h, C.c_uint64(0x0A4B00000000 + int(os.environ.get("SEED_OFF", 0))), n, P(battles), P(durations), P(prng), P(rin)))
 torch.cuda.synchronize()
 buf = (C.c_ulonglong * 128)()
 lib.oakgpu_site_profile.argtypes = [C.c_void_p, C.c_int]
 lib.oakgpu_site_profile(buf, 1)
+ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+ev0.record()
 _lib.check(lib.oakgpu_rollout_dev(h, P(battles), P(durations), P(rin), P(prng), n, 1000, 0, P(rout), P(steps), P(values), None, None))
+ev1.record()
 torch.cuda.synchronize()
+print("launch ms", ev0.elapsed_time(ev1), file=sys.stderr)
 lib.oakgpu_site_profile(buf, 0)
 total_steps = int(steps.sum().item())
 rows = []
