@@ -1,28 +1,26 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the hot path on MI355X.
 
-Workload (BASELINE.json configs[1]): batch = 65,536 random OU team pairs per GPU, pure
-random-policy rollout to terminal (cap 1000 turn-steps, mirrors search/mcts.h:606-614).
-One *step* = one pass of the rollout kernel over one whole batch; inputs (battles,
-durations, per-lane fast_prng state) are generated ON DEVICE before the timed region and
-stay resident in HBM; the per-lane choice-RNG stream continues from pass to pass, so every
-step plays different playouts.  Steps are independent batches (as in root-parallel MCTS), so
-they are issued round-robin on `--streams` HIP streams (default 20, each with its own batch
-buffers): a batch's long tail (0.1% of playouts run to the 1000-step cap on a handful of
-waves) then overlaps the next batches instead of idling the GPU.  `--streams 1` gives the
-strictly serial latency figure quoted in DESIGN.md.
+Headline workload (BASELINE.json configs[1]): batch = 65,536 random OU team pairs per GPU, pure random-policy
+rollout to terminal (cap 1000 turn-steps, mirrors search/mcts.h:606-614).  One *step* = one pass of the rollout
+kernel over one whole batch; inputs (battles, durations, per-lane fast_prng state) are generated ON DEVICE before the
+timed region and stay resident in HBM; the per-lane choice-RNG stream continues from pass to pass, so every step
+plays different playouts.  Steps are independent batches (as in root-parallel MCTS) and are submitted in GROUPS of up
+to `--group` batches per launch (oakgpu_rollout_group_dev): one playout queue, one tail per group.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-N > 1: one process per GPU, lanes sharded by rank (weak scaling: 65,536 playouts per GPU,
-disjoint seeds); the path's single exchange is an RCCL all-gather of the fp32 leaf values
-(256 KiB per batch and rank) back to every root, issued as ONE collective per round of
-`--streams` batches on its own stream (class Exchange below).
+N > 1: one process per GPU, lanes sharded by rank (weak scaling: 65,536 playouts per GPU and step, disjoint seeds); the
+path's single exchange is an RCCL all-gather of the fp32 leaf values back to every root -- ONE collective per group
+launch (G x 256 KiB per rank), on its own stream.
 
-Prints ONE JSON line (rank 0).  `roofline` prices the rollout kernel against the HBM roof with
-the ALGORITHMIC bytes of SURVEY 8(d): 802 B per turn-step (401 read + 401 written of per-lane
-state); `cpu_baseline` times the CPU oracle (a restatement, not the Oak binary) on the host.
+Prints ONE JSON line (rank 0).  The line is the configs[1] record; with the default `--workload all` it also carries
+the rest of BASELINE.json's metric as sub-records with their own timed regions: `leaf` (leaf-evals/s of the
+768-256-256-256-1 network, fp32-MFMA roofline, per-kernel microseconds) and `config3` (configs[2]: turn-step + leaf
+evaluation every turn).  `roofline` of the headline record prices the rollout kernel against the HBM roof with the
+ALGORITHMIC bytes of SURVEY 8(d): 802 B per turn-step (401 read + 401 written of per-lane state); every record has a
+`cpu_baseline` at N = 1: the CPU oracle (a restatement, not the Oak binary) on all host cores.
 """
 import argparse
 import ctypes as C
@@ -52,10 +50,11 @@ def main():
     ap.add_argument("--streams", type=int, default=2, help="groups in flight (contexts / HIP streams)")
     ap.add_argument("--playouts-per-lane", type=int, default=2,
                     help="k > 1: persistent n/k lanes per batch that refill from an atomic playout queue")
-    ap.add_argument("--workload", choices=["rollout", "leaf", "config3", "search"], default="rollout",
-                    help="rollout = BASELINE configs[1] (headline); leaf = leaf-evals/s of the 768-256-256-256-1 net; "
-                         "config3 = configs[2]: one turn-step of the whole batch + a leaf eval of every lane, every turn; "
-                         "search = tree search with batched leaves (oakgpu_search), iterations/s on one random OU root")
+    ap.add_argument("--workload", choices=["all", "rollout", "leaf", "config3", "search"], default="all",
+                    help="all (default) = the configs[1] headline line + `leaf` and `config3` sub-records; rollout = configs[1] "
+                         "only; leaf = leaf-evals/s of the 768-256-256-256-1 net; config3 = configs[2]: one turn-step of the "
+                         "whole batch + a leaf eval of every lane, every turn; search = tree search with batched leaves "
+                         "(oakgpu_search), iterations/s on one random OU root")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -83,14 +82,24 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm
 
-    if args.workload in ("leaf", "config3"):
-        return leaf_workload(args, torch, dev, rank, local_rank, world, dist)
     if args.workload == "search":
         return search_workload(args, torch, dev, rank, local_rank, world, dist)
-
-    out = rollout_workload(args, torch, dev, rank, local_rank, world, dist, force_dist)
-    if rank == 0:
-        print(json.dumps(out), flush=True)
+    if args.workload in ("leaf", "config3"):      # one sub-record on its own, same JSON shape as the headline line
+        recs = leaf_records(args, torch, dev, rank, local_rank, world, dist, which=(args.workload,))
+        if rank == 0:
+            rec = recs[args.workload]
+            rec["vs_baseline"] = None
+            print(json.dumps(rec), flush=True)
+    else:
+        # default ("all"): the headline configs[1] line carries the whole BASELINE metric -- turn-steps/s of batched
+        # playouts plus, as sub-records with their own timed regions, leaf-evals/s and configs[2]
+        out = rollout_workload(args, torch, dev, rank, local_rank, world, dist, force_dist)
+        if args.workload == "all":
+            recs = leaf_records(args, torch, dev, rank, local_rank, world, dist)
+            if rank == 0:
+                out.update(recs)
+        if rank == 0:
+            print(json.dumps(out), flush=True)
     if world > 1 or force_dist:
         dist.destroy_process_group()
 
@@ -284,12 +293,14 @@ def rollout_workload(args, torch, dev, rank, local_rank, world, dist, force_dist
     return out
 
 
-def leaf_workload(args, torch, dev, rank, local_rank, world, dist):
-    """Second metric of BASELINE.json: leaf-evals/s.  One step = value_inference over one batch of 65,536
-    mid-game states (random OU battles advanced 20 random turn-steps on the device) with the config-3 network
-    (768 -> 256 -> 256 -> 256 -> 1, seeded synthetic weights).  Roofline: fp32 MFMA."""
+def leaf_records(args, torch, dev, rank, local_rank, world, dist, which=("leaf", "config3")):
+    """Second metric of BASELINE.json (leaf-evals/s) and configs[2], as sub-records of the one JSON line.
+    leaf    : one step = value_inference over one batch of 65,536 mid-game states (random OU battles advanced 20 random
+              turn-steps on the device) with the config-3 network (768 -> 256 -> 256 -> 256 -> 1, seeded synthetic weights).
+    config3 : one step = one random turn-step of the resident 65,536-lane batch, in place, + value_inference of every
+              lane (BASELINE configs[2]: "MLP leaf eval every turn"); 40-turn episodes.
+    Roofline: fp32 MFMA (157.3 TFLOP/s dense), algorithmic FLOP per leaf from SURVEY 8(d) (oak_amd.netfile.flops_per_leaf)."""
     import tempfile
-    import numpy as np
     from oak_amd import _lib, netfile
     from oak_amd import dist as oakdist
     from oak_amd.engine import Context, Network
@@ -310,104 +321,124 @@ def leaf_workload(args, torch, dev, rank, local_rank, world, dist):
     rout = torch.empty((n,), dtype=u8, device=dev)
     steps_out = torch.empty((n,), dtype=torch.int32, device=dev)
     values = torch.empty((n,), dtype=torch.float32, device=dev)
-    emb = torch.empty((n, 768), dtype=torch.float32, device=dev)
     lib, h = ctx.lib, ctx.handle
     seed0 = oakdist.lane_seed0(SEED0, n * world, rank, world)
     _lib.check(lib.oakgpu_random_ou_battles_dev(h, C.c_uint64(seed0), n, P(battles), P(durations), P(prng), P(rin)))
+    b0, d0, p0, r0 = battles.clone(), durations.clone(), prng.clone(), rin.clone()   # turn-0 batch (config3 episodes restart from it)
     _lib.check(lib.oakgpu_rollout_dev(h, P(battles), P(durations), P(rin), P(prng), n, 20, 0, P(rout), P(steps_out),
                                       P(values), P(mid), P(dur_mid)))
     ctx.synchronize()
-    with tempfile.TemporaryDirectory() as td:
-        path = os.path.join(td, "config3.battle.net")
-        netfile.write_random_net(path, seed=7, hidden=256, value_hidden=256)
-        net = Network(ctx, path=path)
-
-    config3 = args.workload == "config3"
+    td = tempfile.mkdtemp()
+    path = os.path.join(td, "config3.battle.net")
+    netfile.write_random_net(path, seed=7, hidden=256, value_hidden=256)
+    net = Network(ctx, path=path)
+    main_f, emb_f = netfile.flops_per_leaf(256, 256)
     live = torch.zeros((), dtype=torch.int64, device=dev)
     turn = [0]
-    if config3:   # start every 40-turn episode from the turn-0 batch (restoring it is a 26 MB device copy)
-        b0, d0, p0, r0 = battles.clone(), durations.clone(), prng.clone(), rin.clone()
 
-    def step():
-        if config3:
-            # BASELINE configs[2]: one random turn-step of all 65,536 lanes, in place (a rollout capped at one step),
-            # then a leaf evaluation of every lane's new state -- "MLP leaf eval every turn"
-            if turn[0] % 40 == 0:
-                with torch.cuda.stream(stream):
-                    battles.copy_(b0); durations.copy_(d0); prng.copy_(p0); rin.copy_(r0)
-            turn[0] += 1
-            _lib.check(lib.oakgpu_rollout_dev(h, P(battles), P(durations), P(rin), P(prng), n, 1, 0, P(rin), P(steps_out),
-                                              P(values), P(battles), P(durations)))
-            _lib.check(lib.oakgpu_leaf_eval_dev(h, net.handle, P(battles), P(durations), n, P(values), P(emb)))
+    def leaf_step():
+        _lib.check(lib.oakgpu_leaf_eval_dev(h, net.handle, P(mid), P(dur_mid), n, P(values), None))
+
+    def config3_step():
+        if turn[0] % 40 == 0:   # restoring the turn-0 batch is a 26 MB device copy
             with torch.cuda.stream(stream):
-                live.add_(steps_out.sum(dtype=torch.int64))
-        else:
-            _lib.check(lib.oakgpu_leaf_eval_dev(h, net.handle, P(mid), P(dur_mid), n, P(values), P(emb)))
-    for _ in range(max(args.warmup, 1)):
-        step()
-    turn[0] = 0
-    with torch.cuda.stream(stream):
-        live.zero_()
-    ctx.synchronize()
-    K = args.steps
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(K)]
-    for a, b in ev:
-        a.record(stream)
-        b.record(stream)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    for k in range(K):
-        ev[k][0].record(stream)
-        step()
-        ev[k][1].record(stream)
+                battles.copy_(b0); durations.copy_(d0); prng.copy_(p0); rin.copy_(r0)
+        turn[0] += 1
+        _lib.check(lib.oakgpu_rollout_dev(h, P(battles), P(durations), P(rin), P(prng), n, 1, 0, P(rin), P(steps_out),
+                                          P(values), P(battles), P(durations)))
+        _lib.check(lib.oakgpu_leaf_eval_dev(h, net.handle, P(battles), P(durations), n, P(values), None))
+        with torch.cuda.stream(stream):
+            live.add_(steps_out.sum(dtype=torch.int64))
+
+    def timed(step, K, W):
+        for _ in range(max(W, 1)):
+            step()
+        turn[0] = 0
+        with torch.cuda.stream(stream):
+            live.zero_()
+        ctx.synchronize()
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(K)]
+        for a, b in ev:
+            a.record(stream)
+            b.record(stream)
         if world > 1:
-            with torch.cuda.stream(stream):
-                oakdist.gather_values(values, n * world)
-    torch.cuda.synchronize(dev)
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    if rank == 0 and config3:
-        main_f, emb_f = netfile.flops_per_leaf(256, 256)
-        avg_s = sum(a.elapsed_time(b) for a, b in ev) / K / 1e3
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for k in range(K):
+            ev[k][0].record(stream)
+            step()
+            ev[k][1].record(stream)
+            if world > 1:   # the path's exchange: the batch's leaf values to every rank
+                with torch.cuda.stream(stream):
+                    oakdist.gather_values(values, n * world)
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        return elapsed, sum(a.elapsed_time(b) for a, b in ev) / K / 1e3
+
+    def kernel_us():   # diagnostic pass outside the timed regions: HIP events around each kernel of one call
+        _lib.check(lib.oakgpu_set_kernel_timing(h, 1))
+        acc = [0.0, 0.0, 0.0]
+        for _ in range(5):
+            leaf_step()
+            ms = (C.c_float * 3)()
+            _lib.check(lib.oakgpu_get_leaf_kernel_ms(h, ms))
+            acc = [x + y for x, y in zip(acc, ms)]
+        _lib.check(lib.oakgpu_set_kernel_timing(h, 0))
+        return {"k_embed_lds<party>": acc[0] / 5 * 1e3, "k_embed_lds<active>": acc[1] / 5 * 1e3, "k_mainnet_direct": acc[2] / 5 * 1e3}
+
+    out = {}
+    K, W = args.steps, args.warmup
+    if "leaf" in which:
+        elapsed, avg_s = timed(leaf_step, K, W)
+        achieved = (main_f + emb_f) * n / avg_s / 1e12
+        rec = {
+            "metric": "leaf-evals/s", "value": n * world * K / elapsed, "unit": "leaf-evals/s", "n_gpus": world, "steps": K,
+            "warmup": W, "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak", "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "leaf part of configs[2]: value_inference (encode + embeddings + 768-256-256-256-1 MainNet + "
+                                   "sigmoid) over 65536 mid-game states per GPU", "batch_per_gpu": n,
+                       "parity": "<= 1e-5 vs numpy oracle pinned by the reference torch mirror"},
+            "roofline": {"bound": "mfma", "kernel": "oak::k_embed_lds (x2) + oak::k_mainnet_direct (one value_inference call)",
+                         "achieved": achieved, "peak": 157.3, "unit": "TFLOP/s", "frac": achieved / 157.3, "traffic": None,
+                         "avg_call_ms": avg_s * 1e3, "algorithmic_flop_per_leaf": main_f + emb_f, "mainnet_flop_per_leaf": main_f,
+                         "kernel_us": kernel_us()},
+        }
+        if rank == 0 and world == 1 and not args.no_cpu_baseline:
+            rec["cpu_baseline"] = cpu_baseline_leaf(path, mid, dur_mid)
+        out["leaf"] = rec
+    if "config3" in which:
+        elapsed, avg_s = timed(config3_step, K, W)
         achieved = (main_f + emb_f) * n / avg_s / 1e12
         steps_done = int(live.item())
-        print(json.dumps({
-            "metric": "turn-steps/s (rollout + leaf eval every turn)", "value": steps_done * world / elapsed, "unit": "turn-steps/s",
-            "n_gpus": world, "steps": K, "warmup": args.warmup, "ms_per_step": elapsed / K * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        if world > 1:
+            s_ = torch.tensor([steps_done], dtype=torch.int64, device=dev)
+            dist.all_reduce(s_, op=dist.ReduceOp.SUM)
+            steps_done = int(s_.item())
+        rec = {
+            "metric": "turn-steps/s (rollout + leaf eval every turn)", "value": steps_done / elapsed, "unit": "turn-steps/s",
+            "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": elapsed / K * 1e3, "higher_is_better": True,
+            "scaling": "weak", "dtype": "f32", "data": "synthetic",
             "config": {"workload": "configs[2]: batch=65536 random OU team pairs per GPU; every step = one random turn-step of the "
                                    "whole batch (in place) + value_inference (768-256-256-256-1) of every lane; 40-turn episodes",
                        "batch_per_gpu": n, "leaf_evals_per_s": n * world * K / elapsed,
-                       "live_lane_fraction": steps_done / (n * K)},
-            "roofline": {"bound": "mfma", "kernel": "oak::k_embed_lds (x2) + oak::k_mainnet_direct (+ oak::k_rollout_queue, 1 step)",
+                       "live_lane_fraction": steps_done / (n * world * K)},
+            "roofline": {"bound": "mfma", "kernel": "oak::k_rollout_queue (1 step) + oak::k_embed_lds (x2) + oak::k_mainnet_direct",
                          "achieved": achieved, "peak": 157.3, "unit": "TFLOP/s", "frac": achieved / 157.3, "traffic": None,
                          "avg_step_ms": avg_s * 1e3, "algorithmic_flop_per_leaf": main_f + emb_f},
-        }), flush=True)
-    elif rank == 0:
-        main_f, emb_f = netfile.flops_per_leaf(256, 256)
-        avg_s = sum(a.elapsed_time(b) for a, b in ev) / K / 1e3
-        achieved = (main_f + emb_f) * n / avg_s / 1e12
-        print(json.dumps({
-            "metric": "leaf-evals/s", "value": n * world * K / elapsed, "unit": "leaf-evals/s", "n_gpus": world, "steps": K,
-            "warmup": args.warmup, "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "configs[2] leaf part: value_inference (encode + embeddings + 768-256-256-256-1 MainNet + "
-                                   "sigmoid) over 65536 mid-game states per GPU", "batch_per_gpu": n,
-                       "parity": "<= 1e-5 vs numpy oracle pinned by the reference torch mirror"},
-            "roofline": {"bound": "mfma", "kernel": "oak::k_embed_lds (x2) + oak::k_mainnet_direct", "achieved": achieved, "peak": 157.3,
-                         "unit": "TFLOP/s", "frac": achieved / 157.3, "traffic": None, "avg_launch_pair_ms": avg_s * 1e3,
-                         "algorithmic_flop_per_leaf": main_f + emb_f, "mainnet_flop_per_leaf": main_f},
-        }), flush=True)
+        }
+        if rank == 0 and world == 1 and not args.no_cpu_baseline:
+            rec["cpu_baseline"] = cpu_baseline_config3(path, n)
+        out["config3"] = rec
     net.close()
-    if world > 1:
-        dist.destroy_process_group()
+    ctx.close()
+    return out
 
 
 def search_workload(args, torch, dev, rank, local_rank, world, dist):
@@ -458,21 +489,44 @@ def search_workload(args, torch, dev, rank, local_rank, world, dist):
         dist.destroy_process_group()
 
 
+def host_threads():
+    """Threads the CPU baselines use: the cores this process may actually use = min(affinity mask, cgroup CPU quota)
+    (a one-GPU job on the GPU box sees every CPU of the host in its mask but is given a 16-CPU share)."""
+    try:
+        cores = max(1, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                quota, period = txt[0], float(txt[1])
+            else:
+                quota, period = txt[0], float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota not in ("max", "-1"):
+                cores = max(1, min(cores, int(round(float(quota) / period))))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    if cores > 64 and not os.environ.get("BENCH_CPU_THREADS"):
+        cores = 16   # no quota visible: assume the documented one-GPU share rather than oversubscribing a shared host
+    return int(os.environ.get("BENCH_CPU_THREADS", cores))
+
+
 def cpu_baseline(n):
     """The CPU oracle (kind "port": this repo's restatement, NOT the Oak binary) on the host cores,
     same lane seeds as the GPU batch, bounded to roughly 10-20 thread-seconds of work."""
-    import numpy as np
     import oracle_lib as O
-    cores = min(os.cpu_count() or 1, 16)
+    cores = host_threads()
     sample = min(n, 65536)
     b, d, p, r = O.make_random_ou_batch(sample, SEED0)
-    reps = 10
-    total = 0
+    reps, total = 0, 0
     t0 = time.perf_counter()
-    for _ in range(reps):
+    while reps < 40 and (reps < 3 or time.perf_counter() - t0 < 1.5):
         bb, dd = b.copy(), d.copy()
         _, steps = O.rollout_batch(bb, dd, r, p, max_steps=MAX_STEPS, threads=cores)  # p advances in place
         total += int(steps.sum())
+        reps += 1
     dt = time.perf_counter() - t0
     return {
         "value": total / dt,
@@ -482,6 +536,49 @@ def cpu_baseline(n):
         "sample": "%d passes over %d playouts (same lane seeds as the GPU batch), %d threads, oracle/liboracle.so "
                   "gcc -O3 -march=x86-64-v3" % (reps, sample, cores),
     }
+
+
+def cpu_baseline_leaf(net_path, mid, dur_mid):
+    """leaf-evals/s of oracle/nn_host.c (plain-C fp32 port of value_inference: sparse first layers, batch-1 GEMVs like
+    the reference's Eigen path, no embedding cache -- every battle is evaluated once) on the same mid-game states."""
+    import oracle_lib as O
+    cores = host_threads()
+    sample = min(mid.shape[0], 32768)
+    b, d = mid[:sample].cpu().numpy(), dur_mid[:sample].cpu().numpy()
+    net = O.CNet(net_path)
+    reps = 0
+    t0 = time.perf_counter()
+    while reps < 20 and (reps < 1 or time.perf_counter() - t0 < 2.0):
+        net.value_inference_batch(b, d, threads=cores)
+        reps += 1
+    dt = time.perf_counter() - t0
+    net.close()
+    return {"value": sample * reps / dt, "unit": "leaf-evals/s", "cores": cores, "kind": "port",
+            "sample": "%d passes over %d of the GPU batch's mid-game states, %d threads, oracle/nn_host.c gcc -O3 -march=x86-64-v3"
+                      % (reps, sample, cores)}
+
+
+def cpu_baseline_config3(net_path, n):
+    """configs[2] on the host: one random turn-step of every lane (oracle engine) + value_inference of every lane (C port),
+    episode of 10 turns from the turn-0 batch."""
+    import oracle_lib as O
+    cores = host_threads()
+    sample = min(n, 16384)
+    b, d, p, r = O.make_random_ou_batch(sample, SEED0)
+    net = O.CNet(net_path)
+    res = r.copy()
+    turns, total = 0, 0
+    t0 = time.perf_counter()
+    while turns < 10 and (turns < 2 or time.perf_counter() - t0 < 3.0):
+        res, steps = O.rollout_batch(b, d, res, p, max_steps=1, threads=cores)
+        net.value_inference_batch(b, d, threads=cores)
+        total += int(steps.sum())
+        turns += 1
+    dt = time.perf_counter() - t0
+    net.close()
+    return {"value": total / dt, "unit": "turn-steps/s", "cores": cores, "kind": "port",
+            "sample": "%d turns of %d lanes (turn-step by oracle/liboracle.so + value_inference by oracle/nn_host.c), %d threads"
+                      % (turns, sample, cores)}
 
 
 if __name__ == "__main__":

@@ -42,6 +42,11 @@ int oakgpu_set_stream(oakgpu_ctx *ctx, void *hip_stream);
 /* The hipStream_t all *_dev launches of this context go to (own stream unless oakgpu_set_stream was called). */
 void *oakgpu_get_stream(oakgpu_ctx *ctx);
 int oakgpu_synchronize(oakgpu_ctx *ctx);
+/* Diagnostics: with timing on, every oakgpu_leaf_eval*_dev call records HIP events around its three kernels on the
+ * context's stream; oakgpu_get_leaf_kernel_ms waits for the last call and returns {party-slot embedding pass, actives'
+ * embedding pass, main net} in milliseconds.  Off by default (the events cost a few microseconds per call). */
+int oakgpu_set_kernel_timing(oakgpu_ctx *ctx, int on);
+int oakgpu_get_leaf_kernel_ms(oakgpu_ctx *ctx, float ms[3]);
 /* Rollout scheduling (results never depend on it).  k = 1 launches one lane per playout; k > 1 (default 2)
  * launches n/k persistent lanes that refill from an atomic playout queue as playouts finish. */
 int oakgpu_set_playouts_per_lane(oakgpu_ctx *ctx, int k);

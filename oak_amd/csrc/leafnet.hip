@@ -1226,8 +1226,10 @@ static int leaf_eval_impl(oakgpu_ctx *ctx, oakgpu_net *net, const uint8_t *battl
   }
   const oak::NetDev &D = net->dev;
   static const int embed_impl = getenv("OAKGPU_EMBED_IMPL") ? atoi(getenv("OAKGPU_EMBED_IMPL")) : 3;
+  hipEvent_t *tev = (hipEvent_t *)oakgpu_ctx_timing_events(ctx); // diagnostic only (oakgpu_set_kernel_timing)
   {
     for (int kind = 0; kind < 2; ++kind) {
+      if (tev) (void)hipEventRecord(tev[kind], stream);
       oak::EmbedTileArgs ta{D, battles, durations, n, emb, kind};
       const uint32_t ntiles = (n * (kind ? 2u : 10u) + oak::ET - 1) / oak::ET;
       if (embed_impl == 2) { // second implementation: first-layer rows gathered from L2 (A/B)
@@ -1246,6 +1248,7 @@ static int leaf_eval_impl(oakgpu_ctx *ctx, oakgpu_net *net, const uint8_t *battl
     h1 = (float *)oakgpu_ctx_workspace(ctx, 1, (size_t)n * D.H * 4);
     if (!h1) return -1;
   }
+  if (tev) (void)hipEventRecord(tev[2], stream);
   oak::MainArgs ma{D, emb, n, values, h1};
   const int hld = (D.H > D.VH ? D.H : D.VH) + 1;
   const size_t mn_lds = (size_t)((oak::TM + oak::MAXH) * (oak::KC_MAIN + 1) + oak::TM * hld) * 4;
@@ -1254,6 +1257,7 @@ static int leaf_eval_impl(oakgpu_ctx *ctx, oakgpu_net *net, const uint8_t *battl
     hipLaunchKernelGGL(oak::k_mainnet, dim3((n + oak::TM - 1) / oak::TM), dim3(oak::MN_BLOCK), mn_lds, stream, ma);
   else
     hipLaunchKernelGGL(oak::k_mainnet_direct, dim3((n + oak::TM - 1) / oak::TM), dim3(oak::MN_BLOCK), (size_t)oak::TM * (oak::MAXH + 1) * 4, stream, ma);
+  if (tev) (void)hipEventRecord(tev[3], stream);
   if (pol) {
     oak::PolicyArgs pa = *pol;
     pa.net = D;

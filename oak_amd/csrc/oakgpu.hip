@@ -840,6 +840,9 @@ struct oakgpu_ctx {
   std::vector<Block> stage; // staging buffers of the host-pointer entry points (oakgpu_internal.h)
   size_t stage_cursor;
   Block ws[2];              // leaf-evaluator workspaces
+  int timing;               // oakgpu_set_kernel_timing
+  hipEvent_t tev[4];
+  bool tev_valid;
 };
 
 static thread_local std::string g_err;
@@ -872,6 +875,7 @@ static void *grow_block(oakgpu_ctx *c, oakgpu_ctx::Block &b, size_t bytes) {
   b.cap = cap;
   return b.p;
 }
+void **oakgpu_ctx_timing_events(oakgpu_ctx *c) { return c->timing && c->tev_valid ? (void **)c->tev : nullptr; }
 void *oakgpu_ctx_workspace(oakgpu_ctx *c, int slot, size_t bytes) { return grow_block(c, c->ws[slot & 1], bytes ? bytes : 1); }
 void oakgpu_stage_begin(oakgpu_ctx *c) { c->stage_cursor = 0; }
 void oakgpu_stage_end(oakgpu_ctx *c) { (void)hipStreamSynchronize(c->stream); }
@@ -943,6 +947,8 @@ int oakgpu_create(oakgpu_ctx **out, int device) {
   c->table_next = 0;
   c->stage_cursor = 0;
   c->ws[0] = c->ws[1] = oakgpu_ctx::Block{nullptr, 0};
+  c->timing = 0;
+  c->tev_valid = false;
   c->rounds_auto = 1;
   if (const char *env = getenv("OAKGPU_ROUNDS_AUTO")) c->rounds_auto = atoi(env) != 0;
   {
@@ -979,6 +985,7 @@ void oakgpu_destroy(oakgpu_ctx *c) {
   if (c->d_scratch) (void)hipFree(c->d_scratch);
   for (auto &b : c->stage) if (b.p) (void)hipFree(b.p);
   for (auto &b : c->ws) if (b.p) (void)hipFree(b.p);
+  if (c->tev_valid) for (auto &e : c->tev) (void)hipEventDestroy(e);
   if (c->h_table) {
     (void)hipHostFree(c->h_table);
     (void)hipFree(c->d_table);
@@ -1012,6 +1019,25 @@ int oakgpu_set_regroup(oakgpu_ctx *c, int rounds, int suspend_below, int shrink)
 }
 
 void *oakgpu_get_stream(oakgpu_ctx *c) { return c ? (void *)c->stream : nullptr; }
+
+int oakgpu_set_kernel_timing(oakgpu_ctx *c, int on) {
+  if (!c) return bad("null ctx");
+  HIPCHK(hipSetDevice(c->device));
+  if (on && !c->tev_valid) {
+    for (auto &e : c->tev) HIPCHK(hipEventCreate(&e));
+    c->tev_valid = true;
+  }
+  c->timing = on != 0;
+  return 0;
+}
+
+int oakgpu_get_leaf_kernel_ms(oakgpu_ctx *c, float ms[3]) {
+  if (!c || !ms) return bad("oakgpu_get_leaf_kernel_ms: null argument");
+  if (!c->timing || !c->tev_valid) return bad("oakgpu_get_leaf_kernel_ms: kernel timing is off (oakgpu_set_kernel_timing)");
+  HIPCHK(hipEventSynchronize(c->tev[3]));
+  for (int i = 0; i < 3; ++i) HIPCHK(hipEventElapsedTime(&ms[i], c->tev[i], c->tev[i + 1]));
+  return 0;
+}
 
 int oakgpu_synchronize(oakgpu_ctx *c) {
   if (!c) return bad("null ctx");

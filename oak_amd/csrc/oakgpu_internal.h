@@ -23,3 +23,6 @@ struct OakHostCall {
   void *get(size_t bytes) { return oakgpu_stage_get(c, bytes); }
 };
 extern "C" int oakgpu_leaf_set_lds_limits(void);                // leafnet.hip: per-device kernel attributes (called by oakgpu_create)
+// Optional per-kernel timing of the leaf evaluator (oakgpu_set_kernel_timing): 4 events = before the party-slot
+// embedding pass, before the actives' pass, before the main net, after it.  nullptr when timing is off.
+void **oakgpu_ctx_timing_events(oakgpu_ctx *ctx);

@@ -43,6 +43,13 @@ def _load():
     lib.oracle_set_ou_pools.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
     lib.oracle_make_random_ou_battle.restype = C.c_uint8
     lib.oracle_make_random_ou_battle.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
+    lib.oracle_nn_load.restype = C.c_void_p
+    lib.oracle_nn_load.argtypes = [C.c_char_p]
+    lib.oracle_nn_free.argtypes = [C.c_void_p]
+    lib.oracle_nn_embedding.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.oracle_nn_value_inference.restype = C.c_float
+    lib.oracle_nn_value_inference.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.oracle_nn_value_inference_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_int]
     lib.oracle_hash64.restype = C.c_uint64
     lib.oracle_hash64.argtypes = [C.c_void_p, C.c_size_t]
     return lib
@@ -128,3 +135,28 @@ def rollout_batch(battles, durs, results, prng, max_steps=1000, prep=False, thre
     LIB.oracle_rollout_batch(ptr(battles), ptr(durs), ptr(np.ascontiguousarray(results)), ptr(prng), n,
                              max_steps, 1 if prep else 0, ptr(out), ptr(steps), threads)
     return out, steps
+
+
+class CNet:
+    """oracle/nn_host.c: the plain-C fp32 leaf evaluator (second checker + bench.py's CPU baseline for leaf-evals/s)."""
+
+    def __init__(self, path):
+        self.h = LIB.oracle_nn_load(os.fsencode(path))
+        if not self.h:
+            raise RuntimeError("oracle_nn_load failed: %s" % path)
+
+    def embedding(self, battle, durations, dim=768):
+        out = np.zeros(dim, dtype=np.float32)
+        LIB.oracle_nn_embedding(self.h, ptr(np.ascontiguousarray(battle)), ptr(np.ascontiguousarray(durations)), ptr(out))
+        return out
+
+    def value_inference_batch(self, battles, durations, threads=1):
+        n = battles.shape[0]
+        out = np.zeros(n, dtype=np.float32)
+        LIB.oracle_nn_value_inference_batch(self.h, ptr(np.ascontiguousarray(battles)), ptr(np.ascontiguousarray(durations)), n, ptr(out), threads)
+        return out
+
+    def close(self):
+        if self.h:
+            LIB.oracle_nn_free(self.h)
+            self.h = None

@@ -77,3 +77,24 @@ def test_poke_engine_oracle_hand_computed_cases():
     exp = np.float32(np.float32(np.float32(100) * np.float32(101)) / np.float32(323)) - np.float32(25) + np.float32(30) - np.float32(130)
     assert abs(float(NN.poke_engine_score(b, M)) - float(exp)) < 1e-4
     assert abs(float(NN.poke_engine_value(b, M, 0.0)) - 1 / (1 + np.exp(-0.0125 * float(exp)))) < 1e-6
+
+
+def test_c_port_matches_numpy_oracle(tmp_path):
+    """oracle/nn_host.c (bench.py's CPU baseline for leaf-evals/s) against nn_oracle.py -- which the torch-mirror goldens
+    pin -- on mid-game states: embeddings and values, default (relu), tiny (clamp) and the 3x256 config-3 network."""
+    import oracle_lib as O
+    b, d, p, r = O.make_random_ou_batch(160, seed0=0xC0DE)
+    O.rollout_batch(b[:80], d[:80], r[:80], p[:80], max_steps=25, threads=2)
+    O.rollout_batch(b[80:], d[80:], r[80:], p[80:], max_steps=70, threads=2)
+    wide = str(tmp_path / "c3.battle.net")
+    NN.write_random_net(wide, hidden=256, value_hidden=256, seed=7)
+    for path in (os.path.join(ROOT, "tests", "golden", "net_default.battle.net"),
+                 os.path.join(ROOT, "tests", "golden", "net_tiny.battle.net"), wide):
+        net, cnet = NN.Net(path), O.CNet(path)
+        vals = cnet.value_inference_batch(b, d, threads=3)
+        for i in range(b.shape[0]):
+            e = NN.battle_embedding(net, b[i], d[i])
+            ce = cnet.embedding(b[i], d[i], dim=e.shape[0])
+            assert np.abs(e - ce).max() <= 2e-6, (path, i, int(np.abs(e - ce).argmax()))
+            assert abs(float(net.main_value(e)) - float(vals[i])) <= 1e-5
+        cnet.close()
