@@ -161,8 +161,8 @@ int oakgpu_tree_step_dev(oakgpu_ctx *ctx, uint8_t *battles, uint8_t *durations, 
  * (mcts.h:95-105), joint UCB / PUCB bandits (search/bandit/ucb.h:17-66, pucb.h:17-75) and the Monte-Carlo or
  * network evaluator.  `batch` descents walk the host-side tree together, one oakgpu_tree_step_dev launch per
  * level, all battle states resident on the device; lanes of a batch repel each other with a virtual loss.
- * The root matrices come back as in MCTS::Output (mcts.h:68-90); the Nash solve of process_output
- * (mcts.h:620-659) is host-side exact arithmetic and stays with the caller (oak_amd/search.py). */
+ * The root matrices come back as in MCTS::Output (mcts.h:68-90), with process_output's exact Nash solve
+ * (mcts.h:620-659) in nash_value / p1_nash / p2_nash. */
 typedef struct {
   uint64_t iterations;   /* root iterations (mcts.h:231-235, integer budget) */
   uint32_t batch;        /* descents in flight (GPU lanes); 1 reproduces the reference's one-at-a-time order */
@@ -195,7 +195,24 @@ typedef struct {
   double p1_empirical[9], p2_empirical[9];
   uint64_t nodes, total_depth;
   double duration_us;
+  /* MCTS::Search::process_output (mcts.h:620-659): equilibrium of the empirical root matrix (x 256 as integers, solved
+   * exactly, see oakgpu_solve_matrix) */
+  double nash_value, p1_nash[9], p2_nash[9];
 } oakgpu_search_output;
+/* LRSNash::solve_fast as the reference calls it (mcts.h:643-649, pyoak solve_matrix pyoak.cc:394-426): exact Nash
+ * equilibrium of the m x n (<= 9 x 9) zero-sum game whose ROW player maximises the integer payoffs[i * n + j]
+ * (|payoff| <= 2^20; the reference passes value * discretize_factor).  No floating point in the solve (integer-pivoting
+ * simplex on 512-bit integers; the reference's lrsnash + GMP is absent).  p1[m], p2[n] = equilibrium strategies, *value =
+ * game value / discretize_factor.  Host code: no GPU involved. */
+int oakgpu_solve_matrix(const int32_t *payoffs, int m, int n, int discretize_factor, double *p1, double *p2, double *value);
+/* Diagnostic (no GPU involved): ONE player's bandit of the search above replayed for `steps` rounds -- select, then
+ * update with values[t] -- so its arithmetic can be compared with the reference's search/bandit/*.h.  kind as in
+ * oakgpu_search_params.bandit; c = Params.c (UCB / PUCB / UCB1) or gamma (Exp3 / PExp3); logits (k floats): PUCB /
+ * PExp3 priors; uniforms: the device.uniform() draw of each sampled selection (Exp3 / PExp3, k > 1).  Outputs: selected
+ * index (and probability) per round, final stats_out[0..8] = scores / gains, [9..17] = priors, visits_out[0..8]. */
+int oakgpu_bandit_replay(int kind, float c, float alpha, uint32_t k, const float *logits, uint32_t steps,
+                         const double *uniforms, const float *values, uint8_t *index_out, float *prob_out,
+                         float *stats_out, uint32_t *visits_out);
 int oakgpu_search(oakgpu_ctx *ctx, oakgpu_net *net /* nullable for eval = 0 */, const uint8_t *battle /* 384 */,
                   const uint8_t *durations /* 8 */, uint8_t result, const oakgpu_search_params *params,
                   oakgpu_search_output *out);

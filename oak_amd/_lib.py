@@ -15,7 +15,7 @@ SYMBOLS = [
     "oakgpu_set_ou_pools", "oakgpu_random_ou_battles_dev",
     "oakgpu_net_load", "oakgpu_net_load_memory", "oakgpu_net_free", "oakgpu_net_shape",
     "oakgpu_leaf_eval_dev", "oakgpu_leaf_eval", "oakgpu_leaf_eval_policy_dev", "oakgpu_leaf_eval_policy",
-    "oakgpu_tree_step_dev", "oakgpu_search", "oakgpu_poke_engine_eval_dev", "oakgpu_poke_engine_eval",
+    "oakgpu_tree_step_dev", "oakgpu_search", "oakgpu_bandit_replay", "oakgpu_solve_matrix", "oakgpu_poke_engine_eval_dev", "oakgpu_poke_engine_eval",
 ]
 
 
@@ -37,7 +37,7 @@ class SearchOutput(C.Structure):      # oakgpu_search_output
                 ("visit_matrix", C.c_uint64 * 81), ("value_matrix", C.c_double * 81), ("iterations", C.c_uint64),
                 ("empirical_value", C.c_double), ("initial_value", C.c_double), ("p1_empirical", C.c_double * 9),
                 ("p2_empirical", C.c_double * 9), ("nodes", C.c_uint64), ("total_depth", C.c_uint64),
-                ("duration_us", C.c_double)]
+                ("duration_us", C.c_double), ("nash_value", C.c_double), ("p1_nash", C.c_double * 9), ("p2_nash", C.c_double * 9)]
 
 # include/pkmn.h: the libpkmn-named single-battle ABI (batch-of-one wrappers, pkmn_shim.hip)
 PKMN_SYMBOLS = [
@@ -85,6 +85,8 @@ def load():
     lib.oakgpu_poke_engine_eval.argtypes = [vp, vp, u32, C.c_float, vp, vp]
     lib.oakgpu_tree_step_dev.argtypes = [vp, vp, vp, vp, vp, vp, u32, u32, vp, vp, vp, vp, vp]
     lib.oakgpu_search.argtypes = [vp, vp, vp, vp, C.c_uint8, C.POINTER(SearchParams), C.POINTER(SearchOutput)]
+    lib.oakgpu_solve_matrix.argtypes = [vp, i32, i32, i32, vp, vp, vp]
+    lib.oakgpu_bandit_replay.argtypes = [i32, C.c_float, C.c_float, u32, vp, u32, vp, vp, vp, vp, vp, vp]
     lib.oakgpu_update_dev.argtypes = [vp, vp, vp, vp, vp, vp, vp, u32, vp]
     lib.oakgpu_update.argtypes = [vp, vp, vp, vp, vp, vp, vp, u32, vp]
     lib.oakgpu_choices_dev.argtypes = [vp, vp, vp, i32, vp, vp, u32]

@@ -1,0 +1,104 @@
+// oak_amd/csrc/bandit.hpp -- one player's bandit at a tree node, host side of the batched-leaf tree search.
+//
+// The arithmetic of the reference's five bandits, statement for statement (same float / double / integer types at every
+// step, so that select / update traces agree BIT FOR BIT with traces dumped from the reference's own headers:
+// tests/golden/bandit_traces.json):
+//   UCB::Bandit    cpp/include/search/bandit/ucb.h:17-66     PUCB::Bandit   pucb.h:17-75
+//   UCB1::Bandit   ucb1.h:16-67                              Exp3::Bandit   exp3.h:17-79      PExp3::Bandit  pexp3.h:17-84
+//   softmax        search/util/softmax.h:5-28                sample_pdf     util/random.h:40-49
+// One struct serves all five (`scores` doubles as Exp3's gains); the kind comes with the parameters.  The only
+// deliberate difference is WHEN the visit of the counting bandits is booked: at selection time (`visit`, the virtual
+// loss that keeps a batch of simultaneous descents apart) instead of inside update(); with one descent at a time
+// select -> visit -> update is exactly the reference's select -> update.
+#pragma once
+#include <stdint.h>
+
+#include <cmath>
+
+namespace oak_search {
+
+enum BanditKind { B_UCB = 0, B_PUCB = 1, B_UCB1 = 2, B_EXP3 = 3, B_PEXP3 = 4 };
+struct BanditParams { int kind; float c; float alpha; }; // c: UCB c / Exp3 gamma; alpha: Exp3 uniform mixing (search.cc:268-286)
+
+struct Bandit {
+  float scores[9];
+  float priors[9];
+  uint32_t visits[9];
+  uint8_t k = 0;
+  void init(uint8_t kk, int kind) {
+    k = kk;
+    for (int i = 0; i < 9; ++i) {
+      priors[i] = kk ? 1.0f / kk : 0.0f;
+      if (kind == B_UCB1) { scores[i] = 0.0f; visits[i] = 0; }
+      else if (kind >= B_EXP3) { scores[i] = i < kk ? 0.0f : -INFINITY; visits[i] = 0; }
+      else { scores[i] = 0.5f; visits[i] = 1; }
+    }
+  }
+  bool is_init() const { return k != 0; }
+  // network logits -> priors (PUCB::softmax_logits = softmax.h:5-15) or initial gains (PExp3::softmax_logits: logit / eta)
+  void set_logits(const BanditParams &P, const float *logits) {
+    if (P.kind == B_PUCB) {
+      float sum = 0;
+      for (int i = 0; i < k; ++i) { const float y = std::exp(logits[i]); priors[i] = y; sum += y; }
+      for (int i = 0; i < k; ++i) priors[i] /= sum;
+    } else if (P.kind == B_PEXP3) {
+      const float eta = P.c / k;
+      for (int i = 0; i < k; ++i) scores[i] = logits[i] / eta;
+    }
+  }
+  // `uniform` is called once per sampled selection (Exp3 / PExp3 with k > 1): the device's uniform() in (0, 1)
+  template <class U> uint8_t select(const BanditParams &P, U &&uniform, float &prob) const {
+    prob = 1.0f;
+    if (k == 1) return 0;
+    if (P.kind >= B_EXP3) {
+      const float eta = P.c / k, delta = P.alpha / k, one_minus_alpha = 1 - P.alpha;
+      float policy[9], sum = 0;
+      for (int i = 0; i < 9; ++i) { const float y = std::exp(scores[i] * eta); policy[i] = y; sum += y; }
+      for (int i = 0; i < 9; ++i) policy[i] /= sum;
+      for (int i = 0; i < 9; ++i) policy[i] = one_minus_alpha * policy[i] + delta;
+      double u = uniform();
+      uint32_t idx = 0;
+      for (uint32_t i = 0; i < 9; ++i) { u -= (double)policy[i]; if (u <= 0) { idx = i; break; } }
+      const uint8_t sel = (uint8_t)idx < (uint8_t)(k - 1) ? (uint8_t)idx : (uint8_t)(k - 1);
+      prob = policy[sel];
+      return sel;
+    }
+    uint64_t N = 0;
+    uint8_t idx = 0; // the reference leaves outcome.index at its initial 0 when no arm beats max = 0
+    float best = 0;
+    if (P.kind == B_UCB1) {
+      float q[9] = {};
+      for (int i = k - 1; i >= 0; --i) {
+        if (visits[i] == 0) return (uint8_t)i;
+        q[i] = scores[i] / visits[i];
+        N += visits[i];
+      }
+      const float lnN = (float)std::log((double)N);
+      for (int i = 0; i < k; ++i) {
+        const float e = std::sqrt(P.c * lnN / visits[i]);
+        const float a = e + q[i];
+        if (a > best) { best = a; idx = (uint8_t)i; }
+      }
+      return idx;
+    }
+    for (int i = 0; i < k; ++i) N += visits[i];
+    const float sqrtN = (float)std::sqrt((double)N);
+    for (int i = 0; i < k; ++i) {
+      const float e = P.kind == B_PUCB ? P.c * priors[i] * sqrtN : P.c * sqrtN / k;
+      const float a = (e + scores[i]) / visits[i];
+      if (a > best) { best = a; idx = (uint8_t)i; }
+    }
+    return idx;
+  }
+  // the visit of the counting bandits is booked at selection time (virtual loss), their score at back-up time
+  void visit(const BanditParams &P, uint8_t i) { if (P.kind < B_EXP3) ++visits[i]; }
+  void update(const BanditParams &P, uint8_t i, float value, float prob) {
+    if (P.kind < B_EXP3) { scores[i] += value; return; }
+    if ((scores[i] += (value - 0.5) / prob) > 0) { // Exp3::update (the reference's 0.5 is a double literal): keep the largest gain at 0
+      const float mx = scores[i];
+      for (int q = 0; q < 9; ++q) scores[q] -= mx;
+    }
+  }
+};
+
+} // namespace oak_search

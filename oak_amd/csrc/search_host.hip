@@ -27,6 +27,8 @@
 
 #include "../../include/oakgpu.h"
 #include "oakgpu_internal.h"
+#include "bandit.hpp"
+#include "nash.hpp"
 
 namespace {
 
@@ -37,85 +39,7 @@ uint64_t splitmix64(uint64_t &x) {
   return z ^ (z >> 31);
 }
 double uniform01(uint64_t &rng) { return (double)(splitmix64(rng) >> 11) * (1.0 / 9007199254740992.0); }
-
-enum BanditKind { B_UCB = 0, B_PUCB = 1, B_UCB1 = 2, B_EXP3 = 3, B_PEXP3 = 4 };
-struct BanditParams { int kind; float c; float alpha; }; // c: UCB c / Exp3 gamma; alpha: Exp3 uniform mixing (search.cc:268-286)
-
-// One player's bandit at a node: UCB::Bandit (bandit/ucb.h:17-66), PUCB::Bandit (pucb.h:17-75), UCB1::Bandit
-// (ucb1.h:16-67), Exp3::Bandit (exp3.h:17-79), PExp3::Bandit (pexp3.h:17-84).  `scores` doubles as Exp3's gains.
-struct Bandit {
-  float scores[9];
-  float priors[9];
-  uint32_t visits[9];
-  uint8_t k = 0;
-  void init(uint8_t kk, int kind) {
-    k = kk;
-    for (int i = 0; i < 9; ++i) {
-      priors[i] = kk ? 1.0f / kk : 0.0f;
-      if (kind == B_UCB1) { scores[i] = 0.0f; visits[i] = 0; }
-      else if (kind >= B_EXP3) { scores[i] = i < kk ? 0.0f : -INFINITY; visits[i] = 0; }
-      else { scores[i] = 0.5f; visits[i] = 1; }
-    }
-  }
-  bool is_init() const { return k != 0; }
-  // network logits -> priors (PUCB::softmax_logits) or initial gains (PExp3::softmax_logits: logit / eta)
-  void set_logits(const BanditParams &P, const float *logits) {
-    if (P.kind == B_PUCB) {
-      float mx = logits[0], sum = 0;
-      for (int i = 1; i < k; ++i) mx = logits[i] > mx ? logits[i] : mx;
-      for (int i = 0; i < k; ++i) { priors[i] = std::exp(logits[i] - mx); sum += priors[i]; }
-      for (int i = 0; i < k; ++i) priors[i] /= sum;
-    } else if (P.kind == B_PEXP3) {
-      const float eta = P.c / k;
-      for (int i = 0; i < k; ++i) scores[i] = logits[i] / eta;
-    }
-  }
-  uint8_t select(const BanditParams &P, uint64_t &rng, float &prob) const {
-    prob = 1.0f;
-    if (k == 1) return 0;
-    if (P.kind >= B_EXP3) {
-      const float eta = P.c / k, delta = P.alpha / k;
-      float policy[9], sum = 0;
-      for (int i = 0; i < 9; ++i) { policy[i] = std::exp(scores[i] * eta); sum += policy[i]; }
-      for (int i = 0; i < 9; ++i) policy[i] = (1.0f - P.alpha) * (policy[i] / sum) + delta;
-      double u = uniform01(rng); // device.sample_pdf (util/random.h:40-49)
-      uint8_t idx = 0;
-      for (int i = 0; i < 9; ++i) { u -= (double)policy[i]; if (u <= 0) { idx = (uint8_t)i; break; } }
-      idx = idx < k - 1 ? idx : (uint8_t)(k - 1);
-      prob = policy[idx];
-      return idx;
-    }
-    uint64_t N = 0;
-    uint8_t idx = 0;
-    float best = 0;
-    if (P.kind == B_UCB1) {
-      for (int i = k - 1; i >= 0; --i) { if (visits[i] == 0) return (uint8_t)i; N += visits[i]; }
-      const float lnN = std::log((float)N);
-      for (int i = 0; i < k; ++i) {
-        const float a = std::sqrt(P.c * lnN / visits[i]) + scores[i] / visits[i];
-        if (a > best) { best = a; idx = (uint8_t)i; }
-      }
-      return idx;
-    }
-    for (int i = 0; i < k; ++i) N += visits[i];
-    const float sqrtN = std::sqrt((float)N);
-    for (int i = 0; i < k; ++i) {
-      const float e = P.kind == B_PUCB ? P.c * priors[i] * sqrtN : P.c * sqrtN / k;
-      const float a = (e + scores[i]) / visits[i];
-      if (a > best) { best = a; idx = (uint8_t)i; }
-    }
-    return idx;
-  }
-  // the visit of the counting bandits is booked at selection time (virtual loss), their score at back-up time
-  void visit(const BanditParams &P, uint8_t i) { if (P.kind < B_EXP3) ++visits[i]; }
-  void update(const BanditParams &P, uint8_t i, float value, float prob) {
-    if (P.kind < B_EXP3) { scores[i] += value; return; }
-    if ((scores[i] += (value - 0.5f) / prob) > 0) { // Exp3::update: keep the largest gain at 0
-      const float mx = scores[i];
-      for (int q = 0; q < 9; ++q) scores[q] -= mx;
-    }
-  }
-};
+using namespace oak_search;
 
 // The tree.  The reference's Node owns a std::map<(i, j, Obs), Node> (mcts.h:95-105); nearly every iteration adds a
 // node (81 joint actions x the observation fan-out), so here nodes are indices into flat arrays and ALL edges live in
@@ -165,50 +89,14 @@ struct Tree {
   }
 };
 
-// Equilibrium of a zero-sum matrix game (row player maximises A[i][j], m, n <= 9) by the simplex method in doubles,
-// Bland's rule.  Used only to SAMPLE root actions for MatrixUCB (the reference solves the same matrices exactly with
-// lrsnash, mcts.h:532-543); the reported Nash value of a search is solved exactly by the caller (oak_amd/search.py).
-void solve_zero_sum(const double *A, int m, int n, double *x, double *y) {
-  double lo = A[0];
-  for (int i = 0; i < m * n; ++i) lo = A[i] < lo ? A[i] : lo;
-  const double shift = 1.0 - lo; // every entry >= 1
-  // column player: maximise sum z s.t. B z <= 1, z >= 0; y = z / sum z; the duals (slack reduced costs) give x
-  const int W = n + m + 1;
-  double T[9][9 + 9 + 1], z[9 + 9 + 1];
-  int basis[9];
-  for (int i = 0; i < m; ++i) {
-    for (int j = 0; j < n; ++j) T[i][j] = A[i * n + j] + shift;
-    for (int k = 0; k < m; ++k) T[i][n + k] = i == k ? 1.0 : 0.0;
-    T[i][W - 1] = 1.0;
-    basis[i] = n + i;
+// Equilibrium of an integer zero-sum matrix game (row player maximises): the exact solver of nash.hpp, as the reference
+// solves its root matrices exactly with lrsnash (mcts.h:532-543, 643-649).
+void solve_zero_sum(const int32_t *A, int m, int n, double *x, double *y) {
+  double v;
+  if (!oak_nash::solve(A, m, n, x, y, &v)) {
+    for (int i = 0; i < m; ++i) x[i] = 1.0 / m;
+    for (int j = 0; j < n; ++j) y[j] = 1.0 / n;
   }
-  for (int j = 0; j < W; ++j) z[j] = j < n ? -1.0 : 0.0;
-  for (int iter = 0; iter < 1000; ++iter) {
-    int col = -1;
-    for (int j = 0; j < n + m; ++j) if (z[j] < -1e-12) { col = j; break; }
-    if (col < 0) break;
-    int row = -1;
-    double best = 0;
-    for (int i = 0; i < m; ++i)
-      if (T[i][col] > 1e-12) {
-        const double ratio = T[i][W - 1] / T[i][col];
-        if (row < 0 || ratio < best - 1e-15 || (ratio <= best + 1e-15 && basis[i] < basis[row])) { best = ratio; row = i; }
-      }
-    if (row < 0) break;
-    const double piv = T[row][col];
-    for (int j = 0; j < W; ++j) T[row][j] /= piv;
-    for (int i = 0; i < m; ++i)
-      if (i != row && T[i][col] != 0.0) { const double f = T[i][col]; for (int j = 0; j < W; ++j) T[i][j] -= f * T[row][j]; }
-    const double f = z[col];
-    for (int j = 0; j < W; ++j) z[j] -= f * T[row][j];
-    basis[row] = col;
-  }
-  double zs[9] = {}, sum_y = 0, sum_x = 0;
-  for (int i = 0; i < m; ++i) if (basis[i] < n) zs[basis[i]] = T[i][W - 1];
-  for (int j = 0; j < n; ++j) sum_y += zs[j];
-  for (int i = 0; i < m; ++i) sum_x += z[n + i] > 0 ? z[n + i] : 0;
-  for (int j = 0; j < n; ++j) y[j] = sum_y > 0 ? zs[j] / sum_y : 1.0 / n;
-  for (int i = 0; i < m; ++i) x[i] = sum_x > 0 ? (z[n + i] > 0 ? z[n + i] : 0) / sum_x : 1.0 / m;
 }
 
 struct Buffers { // device arrays + pinned host mirrors of what crosses PCIe every level
@@ -239,6 +127,43 @@ struct Buffers { // device arrays + pinned host mirrors of what crosses PCIe eve
 #define RC(x) do { int _r = (x); if (_r) return _r; } while (0)
 
 } // namespace
+
+// Diagnostic: one player's bandit replayed over a supplied outcome sequence (select -> visit -> update per step), so that
+// the bandit arithmetic can be pinned against traces of the reference's own headers without a GPU.
+extern "C" int oakgpu_bandit_replay(int kind, float c, float alpha, uint32_t k, const float *logits, uint32_t steps,
+                                    const double *uniforms, const float *values, uint8_t *index_out, float *prob_out,
+                                    float *stats_out, uint32_t *visits_out) {
+  if (kind < 0 || kind > 4 || k < 1 || k > 9 || !values || !index_out) return oakgpu_fail_msg("oakgpu_bandit_replay: bad argument");
+  if ((kind == B_PUCB || kind == B_PEXP3) && !logits) return oakgpu_fail_msg("oakgpu_bandit_replay: PUCB / PExp3 need logits");
+  if (kind >= B_EXP3 && k > 1 && !uniforms) return oakgpu_fail_msg("oakgpu_bandit_replay: Exp3 / PExp3 need the uniform draws");
+  const BanditParams P{kind, c, alpha};
+  Bandit b;
+  b.init((uint8_t)k, kind);
+  if (logits) b.set_logits(P, logits);
+  uint32_t u = 0;
+  for (uint32_t t = 0; t < steps; ++t) {
+    float prob;
+    const uint8_t i = b.select(P, [&] { return uniforms[u++]; }, prob);
+    b.visit(P, i);
+    b.update(P, i, values[t], prob);
+    index_out[t] = i;
+    if (prob_out) prob_out[t] = prob;
+  }
+  if (stats_out) for (int i = 0; i < 9; ++i) { stats_out[i] = b.scores[i]; stats_out[9 + i] = b.priors[i]; }
+  if (visits_out) for (int i = 0; i < 9; ++i) visits_out[i] = b.visits[i];
+  return 0;
+}
+
+// pyoak solve_matrix / LRSNash::solve_fast (pyoak.cc:394-426, mcts.h:643-649): exact equilibrium of an integer matrix game
+extern "C" int oakgpu_solve_matrix(const int32_t *payoffs, int m, int n, int discretize_factor, double *p1, double *p2, double *value) {
+  if (!payoffs || !p1 || !p2 || !value) return oakgpu_fail_msg("oakgpu_solve_matrix: null argument");
+  if (m < 1 || n < 1 || m > 9 || n > 9) return oakgpu_fail_msg("oakgpu_solve_matrix: payoff matrix must be between 1x1 and 9x9");
+  if (discretize_factor < 1) return oakgpu_fail_msg("oakgpu_solve_matrix: discretize_factor must be positive");
+  double v = 0;
+  if (!oak_nash::solve(payoffs, m, n, p1, p2, &v)) return oakgpu_fail_msg("oakgpu_solve_matrix: payoffs out of range (|payoff| <= 2^20)");
+  *value = v / (double)discretize_factor;
+  return 0;
+}
 
 extern "C" int oakgpu_search(oakgpu_ctx *ctx, oakgpu_net *net, const uint8_t *battle, const uint8_t *durations, uint8_t result,
                              const oakgpu_search_params *prm, oakgpu_search_output *out) {
@@ -377,15 +302,15 @@ extern "C" int oakgpu_search(oakgpu_ctx *ctx, oakgpu_net *net, const uint8_t *ba
         for (int j = 0; j < n && S.forced.size() < nb; ++j)
           while (planned[i * 9 + j] < prm->mucb_minimum && S.forced.size() < nb) { S.forced.push_back((uint8_t)(i * 9 + j)); ++planned[i * 9 + j]; }
       if (S.forced.size() < nb) {
-        double up[81], dn[81];
+        int32_t up[81], dn[81];
         const double log_T = std::log((double)(done ? done : 1)), w = std::log(2.0 * m * n);
         for (int i = 0; i < m; ++i)
           for (int j = 0; j < n; ++j) {
             const uint64_t v = out->visit_matrix[i * 9 + j];
             const double mean = v ? out->value_matrix[i * 9 + j] / (double)v : 0.0;
             const double e = prm->mucb_c * std::sqrt(2.0 * (2.0 * log_T + w) / (double)(v + 1));
-            up[i * n + j] = std::floor(((v ? mean : 0.0) + e) * 256.0); // integer matrices x 256, like the reference's
-            dn[i * n + j] = std::floor(((v ? mean : 1.0) - e) * 256.0);
+            up[i * n + j] = (int32_t)(((v ? mean : 0.0) + e) * 256.0); // integer matrices x 256, truncated like the reference's (mcts.h:527-528)
+            dn[i * n + j] = (int32_t)(((v ? mean : 1.0) - e) * 256.0);
           }
         double dummy[9];
         solve_zero_sum(up, m, n, S.nash1, dummy);
@@ -412,8 +337,9 @@ extern "C" int oakgpu_search(oakgpu_ctx *ctx, oakgpu_net *net, const uint8_t *ba
         } else {
           Stats &nd = tree.nodes[S.cur[l]];
           float pr1, pr2;
-          i = nd.p1.select(BP, bandit_rng, pr1);
-          j = nd.p2.select(BP, bandit_rng, pr2);
+          auto draw = [&] { return uniform01(bandit_rng); }; // device.uniform() of sample_pdf (util/random.h:40-49)
+          i = nd.p1.select(BP, draw, pr1);
+          j = nd.p2.select(BP, draw, pr2);
           nd.p1.visit(BP, i);
           nd.p2.visit(BP, j);
           S.path[l].push_back({S.cur[l], i, j, pr1, pr2});
@@ -513,6 +439,17 @@ extern "C" int oakgpu_search(oakgpu_ctx *ctx, oakgpu_net *net, const uint8_t *ba
       out->p1_empirical[i] += (double)out->visit_matrix[i * 9 + j] / (double)done;
       out->p2_empirical[j] += (double)out->visit_matrix[i * 9 + j] / (double)done;
     }
+  { // MCTS::Search::process_output (mcts.h:620-659): empirical root matrix x 256 as integers, solved exactly
+    int32_t M[81];
+    for (int i = 0; i < m; ++i)
+      for (int j = 0; j < n; ++j) {
+        uint64_t v = out->visit_matrix[i * 9 + j];
+        v += !v;
+        M[i * n + j] = (int32_t)(out->value_matrix[i * 9 + j] / (double)v * 256.0);
+      }
+    double nv = 0;
+    if (oak_nash::solve(M, m, n, out->p1_nash, out->p2_nash, &nv)) out->nash_value = nv / 256.0;
+  }
   out->nodes = tree.nodes.size();
   out->total_depth = total_depth;
   out->duration_us = std::chrono::duration<double, std::micro>(std::chrono::high_resolution_clock::now() - t_start).count();

@@ -3,80 +3,37 @@
 Mirrors two pieces of the reference's search surface:
   * `solve_matrix(payoffs, discretize_factor) -> (p1, p2, value)`  (pyoak: cpp/src/pyoak.cc:394-426; used by
     MCTS::Search::process_output, cpp/include/search/mcts.h:620-659, through the absent lrsnash/GMP library):
-    exact Nash equilibrium of a <= 9 x 9 one-sum matrix game with integer payoffs.  Here: exact rational
-    simplex (fractions.Fraction, Bland's rule) -- no floating point in the solve, like the reference's GMP path.
+    exact Nash equilibrium of a <= 9 x 9 one-sum matrix game with integer payoffs -- a thin call into the C ABI
+    (oakgpu_solve_matrix: integer-pivoting simplex, Bland's rule, no floating point in the solve).
   * `root_matrix_search(...)`: for every joint action (i, j) of the root and R replicas, re-seed + resample hidden
     counters (mcts.h:254-259), apply the joint action with ONE batched update on the GPU, evaluate the R x m x n
     children with GPU rollouts (or the GPU network), average into the value matrix and solve it.  Output fields
     follow MCTS::Output (mcts.h:68-90).
   * `tree_search(...)`: the full tree search -- MCTS::Search::run (mcts.h:154-247) with a Node heap and joint
     UCB / PUCB bandits -- as `oakgpu_search` runs it: batches of descents walking a host-side tree, every battle
-    state resident on the GPU (oak_amd/csrc/search_host.hip); this module adds process_output's Nash solve.
+    state resident on the GPU (oak_amd/csrc/search_host.hip), process_output's Nash solve included.
 All battle arithmetic runs through the C ABI (oak_amd.engine); this module only orchestrates and solves.
 """
-from fractions import Fraction
+import ctypes as C
 
 import numpy as np
 
-
-def _simplex_max(A, b, c):
-    """maximise c.x s.t. A x <= b, x >= 0 with b > 0; exact Fractions; returns (x, dual y, value)."""
-    m, n = len(A), len(A[0])
-    T = [[Fraction(v) for v in A[i]] + [Fraction(int(i == k)) for k in range(m)] + [Fraction(b[i])] for i in range(m)]
-    z = [-Fraction(v) for v in c] + [Fraction(0)] * m + [Fraction(0)]
-    basis = [n + i for i in range(m)]
-    while True:
-        col = next((j for j in range(n + m) if z[j] < 0), None)       # Bland: lowest index with negative reduced cost
-        if col is None:
-            break
-        best, row = None, None
-        for i in range(m):
-            if T[i][col] > 0:
-                ratio = T[i][-1] / T[i][col]
-                if best is None or ratio < best or (ratio == best and basis[i] < basis[row]):
-                    best, row = ratio, i
-        if row is None:
-            raise ArithmeticError("unbounded LP")
-        piv = T[row][col]
-        T[row] = [v / piv for v in T[row]]
-        for i in range(m):
-            if i != row and T[i][col] != 0:
-                f = T[i][col]
-                T[i] = [a - f * p for a, p in zip(T[i], T[row])]
-        f = z[col]
-        z = [a - f * p for a, p in zip(z, T[row])]
-        basis[row] = col
-    x = [Fraction(0)] * n
-    for i, bi in enumerate(basis):
-        if bi < n:
-            x[bi] = T[i][-1]
-    y = [z[n + i] for i in range(m)]                                    # dual values = reduced costs of the slacks
-    return x, y, z[-1]
-
-
-def solve_matrix_exact(payoffs):
-    """Exact equilibrium of the zero-sum game where the row player maximises payoffs[i][j].
-    Returns (p1 [Fraction], p2 [Fraction], value Fraction)."""
-    A = [[Fraction(v) for v in row] for row in payoffs]
-    m, n = len(A), len(A[0])
-    shift = 1 - min(min(r) for r in A)                                  # make every entry >= 1
-    B = [[v + shift for v in row] for row in A]
-    # column player: maximise sum z s.t. B z <= 1  ->  p2 = z / sum z, value' = 1 / sum z; duals give p1
-    z, y, tot = _simplex_max(B, [1] * m, [1] * n)
-    v = 1 / tot
-    p2 = [zi * v for zi in z]
-    p1 = [yi * v for yi in y]
-    return p1, p2, v - shift
+from . import _lib
 
 
 def solve_matrix(payoffs, discretize_factor=256):
-    """pyoak `solve_matrix` (pyoak.cc:394-426).  payoffs: m x n integers = value * discretize_factor (the row
-    player's one-sum payoff).  Returns (p1 float[m], p2 float[n], value float in [0, 1])."""
+    """pyoak `solve_matrix` (pyoak.cc:394-426) over oakgpu_solve_matrix (exact integer-pivoting simplex in C++,
+    oak_amd/csrc/nash.hpp).  payoffs: m x n integers = value * discretize_factor (the row player's one-sum payoff).
+    Returns (p1 float[m], p2 float[n], value float)."""
     P = np.asarray(payoffs)
     if P.ndim != 2 or P.shape[0] < 1 or P.shape[1] < 1 or P.shape[0] > 9 or P.shape[1] > 9:
         raise RuntimeError("solve_matrix: payoff matrix must be between 1x1 and 9x9")
-    p1, p2, v = solve_matrix_exact([[int(x) for x in row] for row in P])
-    return (np.array([float(x) for x in p1]), np.array([float(x) for x in p2]), float(v / discretize_factor))
+    m, n = P.shape
+    M = np.ascontiguousarray(P, dtype=np.int32)
+    p1, p2, v = np.zeros(m), np.zeros(n), C.c_double(0)
+    _lib.check(_lib.load().oakgpu_solve_matrix(M.ctypes.data_as(C.c_void_p), m, n, int(discretize_factor), p1.ctypes.data_as(C.c_void_p),
+                                               p2.ctypes.data_as(C.c_void_p), C.cast(C.byref(v), C.c_void_p)))
+    return p1, p2, v.value
 
 
 def root_matrix_search(ctx, battle, durations, result, replicas=256, seed=0x5EED, evaluator="mc", max_steps=1000):
@@ -167,5 +124,9 @@ def tree_search(ctx, battle, durations, result, iterations=1 << 16, batch=4096, 
            "visit_matrix": np.array(res.visit_matrix, dtype=np.int64).reshape(9, 9)[:m, :n].copy(),
            "value_matrix": np.array(res.value_matrix, dtype=np.float64).reshape(9, 9)[:m, :n].copy(),
            "iterations": int(res.iterations), "initial_value": float(res.initial_value), "nodes": int(res.nodes),
-           "mean_depth": res.total_depth / max(int(res.iterations), 1), "duration_ms": res.duration_us / 1e3}
-    return process_output(out)
+           "mean_depth": res.total_depth / max(int(res.iterations), 1), "duration_ms": res.duration_us / 1e3,
+           # process_output ran in C++ (oakgpu_search_output: exact Nash of the empirical root matrix)
+           "nash_value": float(res.nash_value), "p1_nash": np.array(res.p1_nash[:m]), "p2_nash": np.array(res.p2_nash[:n]),
+           "empirical_value": float(res.empirical_value), "p1_empirical": np.array(res.p1_empirical[:m]),
+           "p2_empirical": np.array(res.p2_empirical[:n])}
+    return out

@@ -167,3 +167,53 @@ def test_tree_search_pexp3_with_network(gpu_ctx):
     out = tree_search(gpu_ctx, b[0], d[0], int(r[0]), iterations=4096, batch=512, bandit="pexp3", evaluator=net, c=0.1)
     assert int(out["visit_matrix"].sum()) == 4096 and out["nodes"] > 81 and 0 < out["initial_value"] < 1
     net.close()
+
+
+SEARCH_TEST_POSITIONS = (  # cpp/src/search-test.cc:50-109: (position, expected value, tolerance)
+    ("starmie seismictoss 1hp (conf:5) | snorlax bodyslam 1hp", 1.0, 0.0),
+    ("starmie seismictoss 1hp (conf:4) | snorlax bodyslam 1hp", .5 + .5 / 2, 0.03),
+    ("starmie seismictoss 1hp (conf:3) | snorlax bodyslam 1hp", .33 + .66 / 2, 0.03),
+    ("starmie seismictoss 1hp (conf:2) | snorlax bodyslam 1hp", .25 + .75 / 2, 0.03),
+    ("starmie seismictoss 1hp (conf:1) | snorlax bodyslam 1hp", .5, 0.03),
+    ("starmie seismictoss 1hp slp6 | snorlax seismictoss 1hp", 0.0, 0.0),
+    ("starmie seismictoss 101hp slp0 | snorlax seismictoss 1hp", 1.0 / 7, 0.03),
+    ("starmie seismictoss 101hp slp1 | snorlax seismictoss 1hp", 1.0 / 6, 0.03),
+    ("starmie seismictoss 101hp slp2 | snorlax seismictoss 1hp", 1.0 / 5, 0.03),
+    ("starmie seismictoss 101hp slp3 | snorlax seismictoss 1hp", 1.0 / 4, 0.03),
+    ("starmie seismictoss 101hp slp4 | snorlax seismictoss 1hp", 1.0 / 3, 0.03),
+    ("starmie seismictoss 101hp slp5 | snorlax seismictoss 1hp", 1.0 / 2, 0.03),
+    ("starmie seismictoss 101hp slp6 | snorlax seismictoss 1hp", 1.0, 0.0),
+)
+
+
+def test_search_test_cc_all_13_positions_through_the_tree_search(gpu_ctx):
+    """The reference's only runtime test, configured as the reference configures it (search-test.cc:27-31): bandit
+    "exp3-1.0-0.1", Monte-Carlo leaves, 2^20 iterations per position, abs(empirical_value - expected) <= 0.03 (exactly
+    0 for the three deterministic positions) -- through oakgpu_search (host tree + Exp3 bandits, GPU states and leaves)."""
+    from oak_amd.search import tree_search
+    for k, (position, expected, tol) in enumerate(SEARCH_TEST_POSITIONS):
+        b, d = parse_battle(position)
+        out = tree_search(gpu_ctx, b, d, result_from_state(b), iterations=1 << 20, batch=16384, bandit="exp3", c=1.0, alpha=0.1,
+                          seed=0xC0FFEE + k)
+        assert out["iterations"] == 1 << 20 and out["m"] == 1 and out["n"] == 1
+        assert abs(out["empirical_value"] - expected) <= tol, (position, out["empirical_value"], expected)
+        assert abs(out["nash_value"] - expected) <= tol + 1 / 256   # process_output's x256 integer matrix
+
+
+def test_tree_search_output_carries_the_exact_nash_solution(gpu_ctx):
+    """oakgpu_search_output.nash_* (process_output in C++, mcts.h:620-659) = oakgpu_solve_matrix of the empirical root
+    matrix x 256 truncated to integers, for all five bandits on a 9 x 9 root."""
+    import oracle_lib as O
+    from oak_amd.engine import Network
+    from oak_amd.search import solve_matrix, tree_search
+    b, d, p, r = O.make_random_ou_batch(1, seed0=777)
+    net = Network(gpu_ctx, path=os.path.join(ROOT, "tests", "golden", "net_default.battle.net"))
+    for bandit, ev, c in (("ucb", "mc", 2.0), ("ucb1", "mc", 2.0), ("exp3", "mc", 0.3), ("pucb", net, 1.5), ("pexp3", net, 0.5)):
+        out = tree_search(gpu_ctx, b[0], d[0], int(r[0]), iterations=1 << 13, batch=1024, bandit=bandit, c=c, evaluator=ev, seed=3)
+        v, n = out["value_matrix"], out["visit_matrix"]
+        M = (v / np.where(n == 0, 1, n) * 256).astype(np.int64)
+        p1, p2, nv = solve_matrix(M, 256)
+        assert np.allclose(p1, out["p1_nash"], atol=1e-12) and np.allclose(p2, out["p2_nash"], atol=1e-12)
+        assert abs(nv - out["nash_value"]) <= 1e-12 and abs(out["p1_nash"].sum() - 1) < 1e-9
+        assert (M @ p2).max() <= nv * 256 + 1e-6 and (p1 @ M).min() >= nv * 256 - 1e-6    # equilibrium of the matrix solved
+    net.close()

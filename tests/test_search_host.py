@@ -1,12 +1,57 @@
-"""CPU: the exact Nash solver behind oak_amd.search.solve_matrix (reference: LRSNash::solve_fast through
-pyoak.solve_matrix, cpp/src/pyoak.cc:394-426; no reference test pins it -> checked by LP optimality:
-with exact rationals the best-response gap must be exactly zero)."""
+"""CPU: the exact Nash solver behind oakgpu_solve_matrix / oak_amd.search.solve_matrix (reference: LRSNash::solve_fast
+through pyoak.solve_matrix, cpp/src/pyoak.cc:394-426; no reference test pins it).  Checked two ways: an independent
+exact-rational simplex written here (fractions.Fraction) must have a best-response gap of exactly zero, and the C++
+solver (integer pivoting on 512-bit integers, same pivoting rule) must return the same vertex and value."""
 from fractions import Fraction
 
 import numpy as np
 import pytest
 
-from oak_amd.search import solve_matrix, solve_matrix_exact
+from oak_amd.search import solve_matrix
+
+
+def _simplex_max(A, b, c):
+    """maximise c.x s.t. A x <= b, x >= 0 with b > 0; exact Fractions, Bland's rule; returns (x, dual y, value)."""
+    m, n = len(A), len(A[0])
+    T = [[Fraction(v) for v in A[i]] + [Fraction(int(i == k)) for k in range(m)] + [Fraction(b[i])] for i in range(m)]
+    z = [-Fraction(v) for v in c] + [Fraction(0)] * m + [Fraction(0)]
+    basis = [n + i for i in range(m)]
+    while True:
+        col = next((j for j in range(n + m) if z[j] < 0), None)
+        if col is None:
+            break
+        best, row = None, None
+        for i in range(m):
+            if T[i][col] > 0:
+                ratio = T[i][-1] / T[i][col]
+                if best is None or ratio < best or (ratio == best and basis[i] < basis[row]):
+                    best, row = ratio, i
+        assert row is not None
+        piv = T[row][col]
+        T[row] = [v / piv for v in T[row]]
+        for i in range(m):
+            if i != row and T[i][col] != 0:
+                f = T[i][col]
+                T[i] = [a - f * p for a, p in zip(T[i], T[row])]
+        f = z[col]
+        z = [a - f * p for a, p in zip(z, T[row])]
+        basis[row] = col
+    x = [Fraction(0)] * n
+    for i, bi in enumerate(basis):
+        if bi < n:
+            x[bi] = T[i][-1]
+    return x, [z[n + i] for i in range(m)], z[-1]
+
+
+def solve_matrix_exact(payoffs):
+    """Checker: exact equilibrium (Fractions) of the zero-sum game where the row player maximises payoffs[i][j]."""
+    A = [[Fraction(v) for v in row] for row in payoffs]
+    m, n = len(A), len(A[0])
+    shift = 1 - min(min(r) for r in A)
+    B = [[v + shift for v in row] for row in A]
+    z, y, tot = _simplex_max(B, [1] * m, [1] * n)
+    v = 1 / tot
+    return [yi * v for yi in y], [zi * v for zi in z], v - shift
 
 
 def _check_equilibrium(A):
@@ -16,6 +61,11 @@ def _check_equilibrium(A):
     row_payoffs = [sum(Fraction(A[i][j]) * p2[j] for j in range(n)) for i in range(m)]
     col_payoffs = [sum(Fraction(A[i][j]) * p1[i] for i in range(m)) for j in range(n)]
     assert max(row_payoffs) == v and min(col_payoffs) == v        # zero best-response gap, exactly
+    # the product solver (C++, exact integer pivoting, same rule): same vertex, same value, rounded to double only at the end
+    c1, c2, cv = solve_matrix(np.array(A), 1)
+    assert np.abs(c1 - np.array([float(x) for x in p1])).max() <= 1e-15
+    assert np.abs(c2 - np.array([float(x) for x in p2])).max() <= 1e-15
+    assert abs(cv - float(v)) <= 1e-12 * max(1.0, abs(float(v)))
     return p1, p2, v
 
 
@@ -40,6 +90,10 @@ def test_random_matrices_have_zero_best_response_gap():
         m, n = rng.integers(1, 10, 2)
         A = rng.integers(0, 3, (m, n)).tolist()
         _check_equilibrium(A)
+    for _ in range(40):                                             # the largest payoffs the ABI accepts, negatives included
+        m, n = rng.integers(1, 10, 2)
+        A = rng.integers(-(1 << 20), (1 << 20) + 1, (m, n)).tolist()
+        _check_equilibrium(A)
 
 
 def test_solve_matrix_api_and_errors():
@@ -47,3 +101,50 @@ def test_solve_matrix_api_and_errors():
     assert abs(value - 0.5) < 1e-12 and np.allclose(p1, [.5, .5]) and np.allclose(p2, [.5, .5])
     with pytest.raises(RuntimeError):
         solve_matrix(np.zeros((10, 2), dtype=int), 256)
+    with pytest.raises(RuntimeError):
+        solve_matrix(np.array([[1 << 21]]), 256)                    # beyond the exact solver's proven range
+
+
+def test_bandit_arithmetic_matches_reference_traces():
+    """SURVEY 8(f) rank 1 pin: select / update traces of all five bandits, dumped from the reference's OWN headers
+    (search/bandit/{ucb,pucb,ucb1,exp3,pexp3}.h via oracle/ref_bandit_dump.cc -> tests/golden/bandit_traces.json), replayed
+    through the product's bandit (oak_amd/csrc/bandit.hpp, oakgpu_bandit_replay): every selected index, every selection
+    probability and the final statistics must agree BIT FOR BIT.  Host-side code: no GPU needed."""
+    import ctypes as C
+    import json
+    import os
+    from oak_amd import _lib
+    lib = _lib.load()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    traces = json.load(open(os.path.join(root, "tests", "golden", "bandit_traces.json")))["traces"]
+    kinds = {"ucb": 0, "pucb": 1, "ucb1": 2, "exp3": 3, "pexp3": 4}
+    f32 = lambda xs: np.array([float(x) for x in xs], dtype=np.float32)   # "-inf" strings included
+    seen = set()
+    for t in traces:
+        kind, k, steps = kinds[t["kind"]], t["k"], t["steps"]
+        values = f32(t["values"])
+        logits = f32(t["logits"]) if "logits" in t else None
+        uniforms = np.array(t.get("uniforms", []), dtype=np.float64)
+        idx = np.zeros(steps, dtype=np.uint8)
+        prob = np.zeros(steps, dtype=np.float32)
+        stats = np.zeros(18, dtype=np.float32)
+        visits = np.zeros(9, dtype=np.uint32)
+        P = lambda a: None if a is None or a.size == 0 else a.ctypes.data_as(C.c_void_p)
+        rc = lib.oakgpu_bandit_replay(kind, C.c_float(t["c"]), C.c_float(t["alpha"]), k, P(logits), steps, P(uniforms), P(values),
+                                      P(idx), P(prob), P(stats), P(visits))
+        assert rc == 0
+        tag = (t["kind"], k, t["seed"])
+        assert list(idx) == t["index"], tag
+        if kind >= 3:
+            assert prob.tobytes() == f32(t["prob"]).tobytes(), tag
+            assert stats[:9].tobytes() == f32(t["gains"]).tobytes(), tag
+            assert len(uniforms) == (steps if k > 1 else 0)
+        else:
+            assert stats[:k].tobytes() == f32(t["scores"]).tobytes(), tag
+            assert list(visits[:k]) == t["visits"], tag
+            if "priors" in t:
+                assert stats[9:9 + k].tobytes() == f32(t["priors"]).tobytes(), tag
+        seen.add((t["kind"], k))
+    assert seen == {(n, k) for n in kinds for k in (1, 2, 4, 9)}
+    # the traces are not degenerate: every 9-armed one visits every arm
+    assert all(len(set(t["index"])) == 9 for t in traces if t["k"] == 9)
