@@ -217,6 +217,40 @@ int oakgpu_search(oakgpu_ctx *ctx, oakgpu_net *net /* nullable for eval = 0 */, 
                   const uint8_t *durations /* 8 */, uint8_t result, const oakgpu_search_params *params,
                   oakgpu_search_output *out);
 
+/* ---- `.battle.data` training frames + self-play on the GPU path.
+ * oakgpu_frames_write / _read = Train::Battle::CompressedFrames::write / read (train/battle/compressed-frame.h:37-243):
+ * one game = u32 record length, u16 frame count, the 384-byte battle after the opening update, the final result byte,
+ * then per turn {(m-1) | (n-1) << 4, c1, c2, u32 iterations, u16 empirical value, u16 nash value, m + m + n + n u16
+ * probabilities}; probabilities and values are stored as x * 65535 truncated to u16.  A `.battle.data` file is a plain
+ * concatenation of such records.  oakgpu_frames_size = the record's byte length. */
+typedef struct {
+  uint8_t m, n;          /* legal choices per side at this turn */
+  uint8_t c1, c2;        /* the pkmn_choices played */
+  uint32_t iterations;
+  double empirical_value, nash_value;
+  double p1_empirical[9], p1_nash[9], p2_empirical[9], p2_nash[9];
+} oakgpu_frame_update;
+size_t oakgpu_frames_size(const oakgpu_frame_update *updates, uint32_t count);
+int oakgpu_frames_write(const uint8_t *battle /* 384 */, uint8_t result, const oakgpu_frame_update *updates, uint32_t count,
+                        uint8_t *buffer, size_t capacity, size_t *written);
+int oakgpu_frames_read(const uint8_t *buffer, size_t size, uint8_t *battle /* 384, nullable */, uint8_t *result /* nullable */,
+                       oakgpu_frame_update *updates /* nullable */, uint32_t capacity, uint32_t *count, size_t *consumed);
+/* One self-play game, the per-game loop of the reference's data generator (cpp/src/generate.cc:238-322): PKMN::battle(teams,
+ * battle_seed) + opening update, then per turn oakgpu_search -> RuntimePolicy::process_and_sample for both sides
+ * (util/policy.h:22-106; mode words e / n / x with optional weights, e.g. "e0.9-x0.1") -> frame -> update, until the result
+ * is terminal; the finished record is written to `buffer`.  Every battle operation runs on the GPU.  Fails (no record
+ * written) when the game exceeds max_battle_length turns (0 = 1000), like the reference (generate.cc:268-271). */
+typedef struct {
+  oakgpu_search_params search; /* seed is replaced per turn from `seed` below */
+  char policy_mode[16];
+  double policy_temp, policy_min;
+  uint32_t max_battle_length;
+  uint64_t seed;
+} oakgpu_selfplay_params;
+int oakgpu_selfplay_game(oakgpu_ctx *ctx, oakgpu_net *net /* nullable for eval != 1 */, const uint8_t *teams /* 60 */,
+                         uint64_t battle_seed, const oakgpu_selfplay_params *params, uint8_t *buffer, size_t capacity,
+                         size_t *written, uint32_t *n_frames, uint8_t *result);
+
 /* ---- batched PKMN::battle(p1, p2, seed) (pkmn.h:50-57, init.h:90-154), level 100 sets.
  * teams: n x 60 bytes; seeds: n x u64; with first_update != 0 also performs the opening
  * update(battle, 0, 0) (benchmark.cc:29) and writes its result byte. */

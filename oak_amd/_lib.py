@@ -15,7 +15,8 @@ SYMBOLS = [
     "oakgpu_set_ou_pools", "oakgpu_random_ou_battles_dev",
     "oakgpu_net_load", "oakgpu_net_load_memory", "oakgpu_net_free", "oakgpu_net_shape",
     "oakgpu_leaf_eval_dev", "oakgpu_leaf_eval", "oakgpu_leaf_eval_policy_dev", "oakgpu_leaf_eval_policy",
-    "oakgpu_tree_step_dev", "oakgpu_search", "oakgpu_bandit_replay", "oakgpu_solve_matrix", "oakgpu_poke_engine_eval_dev", "oakgpu_poke_engine_eval",
+    "oakgpu_tree_step_dev", "oakgpu_search", "oakgpu_bandit_replay", "oakgpu_solve_matrix",
+    "oakgpu_frames_size", "oakgpu_frames_write", "oakgpu_frames_read", "oakgpu_selfplay_game", "oakgpu_poke_engine_eval_dev", "oakgpu_poke_engine_eval",
 ]
 
 
@@ -38,6 +39,17 @@ class SearchOutput(C.Structure):      # oakgpu_search_output
                 ("empirical_value", C.c_double), ("initial_value", C.c_double), ("p1_empirical", C.c_double * 9),
                 ("p2_empirical", C.c_double * 9), ("nodes", C.c_uint64), ("total_depth", C.c_uint64),
                 ("duration_us", C.c_double), ("nash_value", C.c_double), ("p1_nash", C.c_double * 9), ("p2_nash", C.c_double * 9)]
+
+class FrameUpdate(C.Structure):       # oakgpu_frame_update
+    _fields_ = [("m", C.c_uint8), ("n", C.c_uint8), ("c1", C.c_uint8), ("c2", C.c_uint8), ("iterations", C.c_uint32),
+                ("empirical_value", C.c_double), ("nash_value", C.c_double), ("p1_empirical", C.c_double * 9),
+                ("p1_nash", C.c_double * 9), ("p2_empirical", C.c_double * 9), ("p2_nash", C.c_double * 9)]
+
+
+class SelfplayParams(C.Structure):    # oakgpu_selfplay_params
+    _fields_ = [("search", SearchParams), ("policy_mode", C.c_char * 16), ("policy_temp", C.c_double), ("policy_min", C.c_double),
+                ("max_battle_length", C.c_uint32), ("seed", C.c_uint64)]
+
 
 # include/pkmn.h: the libpkmn-named single-battle ABI (batch-of-one wrappers, pkmn_shim.hip)
 PKMN_SYMBOLS = [
@@ -85,6 +97,12 @@ def load():
     lib.oakgpu_poke_engine_eval.argtypes = [vp, vp, u32, C.c_float, vp, vp]
     lib.oakgpu_tree_step_dev.argtypes = [vp, vp, vp, vp, vp, vp, u32, u32, vp, vp, vp, vp, vp]
     lib.oakgpu_search.argtypes = [vp, vp, vp, vp, C.c_uint8, C.POINTER(SearchParams), C.POINTER(SearchOutput)]
+    lib.oakgpu_frames_size.restype = C.c_size_t
+    lib.oakgpu_frames_size.argtypes = [C.POINTER(FrameUpdate), u32]
+    lib.oakgpu_frames_write.argtypes = [vp, C.c_uint8, C.POINTER(FrameUpdate), u32, vp, C.c_size_t, C.POINTER(C.c_size_t)]
+    lib.oakgpu_frames_read.argtypes = [vp, C.c_size_t, vp, C.POINTER(C.c_uint8), C.POINTER(FrameUpdate), u32, C.POINTER(u32), C.POINTER(C.c_size_t)]
+    lib.oakgpu_selfplay_game.argtypes = [vp, vp, vp, u64, C.POINTER(SelfplayParams), vp, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(u32),
+                                         C.POINTER(C.c_uint8)]
     lib.oakgpu_solve_matrix.argtypes = [vp, i32, i32, i32, vp, vp, vp]
     lib.oakgpu_bandit_replay.argtypes = [i32, C.c_float, C.c_float, u32, vp, u32, vp, vp, vp, vp, vp, vp]
     lib.oakgpu_update_dev.argtypes = [vp, vp, vp, vp, vp, vp, vp, u32, vp]

@@ -1,0 +1,201 @@
+// oak_amd/csrc/selfplay.hip -- `.battle.data` training frames and the self-play game loop over the GPU hot path (host code).
+//
+// the sink of the search results.  Two pieces of the reference are mirrored here:
+//   * Train::Battle::CompressedFrames (cpp/include/train/battle/compressed-frame.h:37-223): the on-disk record of one
+//     game -- u32 byte length, u16 frame count, the 384-byte battle after the opening update, the final result byte, then
+//     per turn an Update {mn byte = (m-1) | (n-1) << 4, both chosen pkmn_choices, u32 iterations, u16 empirical value,
+//     u16 nash value, m u16 empirical + m u16 nash probabilities of P1, n + n of P2}; probabilities and values are stored
+//     as `x * 65535` truncated to u16 (compress_probs, :11-25).  oakgpu_frames_write / _read are its write() / read().
+//   * the per-game loop of the data generator (cpp/src/generate.cc:238-322): PKMN::battle + opening update, then per turn
+//     RuntimeSearch::run -> RuntimePolicy::process_and_sample for both sides (cpp/include/util/policy.h:22-106) ->
+//     frame -> PKMN::update, until the result is terminal.  oakgpu_selfplay_game runs it with every battle operation on
+//     the GPU: oakgpu_init_battles, oakgpu_search (batched leaves), oakgpu_update.
+// The replay self-check of the reference (cpp/include/py/battle/frames.h:52-67: replaying the stored choices from the
+// stored battle must reproduce the stored result) is tests/test_gpu_frames.py.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <cmath>
+#include <string>
+#include <vector>
+
+#include "../../include/oakgpu.h"
+#include "oakgpu_internal.h"
+
+namespace {
+
+uint16_t compress_prob(double x) { // compress_probs<double, uint16_t> (compressed-frame.h:11-25)
+  const double v = x * 65535.0;
+  return v <= 0 ? 0 : v >= 65535.0 ? 65535 : (uint16_t)v;
+}
+size_t update_bytes(uint32_t m, uint32_t n) { return 1 + 2 + 4 + 2 * 2 + 2 * (m + n) * 2; } // Update::n_bytes_static (:77-82)
+
+template <class T> void put(uint8_t *&p, T v) { memcpy(p, &v, sizeof v); p += sizeof v; }
+template <class T> T get(const uint8_t *&p) { T v; memcpy(&v, p, sizeof v); p += sizeof v; return v; }
+
+uint64_t splitmix64(uint64_t &x) {
+  uint64_t z = (x += 0x9E3779B97F4A7C15ull);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+double uniform01(uint64_t &rng) { return (double)(splitmix64(rng) >> 11) * (1.0 / 9007199254740992.0); }
+
+// RuntimePolicy::get_policy (util/policy.h:22-98) for the modes the search output can feed: words of the mode string are
+// 'e' (empirical), 'n' (nash), 'x' (argmax of empirical), each optionally followed by a weight ("e0.9-x0.1"); then
+// temperature, the minimum-probability cut and renormalisation.  'p' (prior) and 'b' (beta) need fields this output
+// does not carry and are refused, like an unknown mode character.
+bool get_policy(const double *empirical, const double *nash, int k, const char *mode, double temp, double minp, double *policy) {
+  for (int i = 0; i < 9; ++i) policy[i] = 0;
+  const std::string s(mode && *mode ? mode : "e");
+  size_t pos = 0;
+  while (pos <= s.size()) {
+    size_t end = s.find('-', pos);
+    if (end == std::string::npos) end = s.size();
+    const std::string word = s.substr(pos, end - pos);
+    pos = end + 1;
+    if (word.empty()) continue;
+    const double w = word.size() > 1 ? atof(word.c_str() + 1) : 1.0;
+    if (word[0] == 'e') { for (int i = 0; i < k; ++i) policy[i] += w * empirical[i]; }
+    else if (word[0] == 'n') { for (int i = 0; i < k; ++i) policy[i] += w * nash[i]; }
+    else if (word[0] == 'x') { policy[std::max_element(empirical, empirical + k) - empirical] += w; }
+    else return false;
+  }
+  if (temp != 1) {
+    double sum = 0;
+    for (int i = 0; i < 9; ++i) { policy[i] = std::pow(policy[i], temp); sum += policy[i]; }
+    for (int i = 0; i < 9; ++i) policy[i] /= sum;
+  }
+  double sum = 0;
+  for (int i = 0; i < 9; ++i) { if (policy[i] < minp) policy[i] = 0; sum += policy[i]; }
+  if (!(sum > 0)) return false;
+  for (int i = 0; i < 9; ++i) policy[i] /= sum;
+  return true;
+}
+int sample_pdf(const double *p, int k, uint64_t &rng) { // device.sample_pdf (util/random.h:40-49)
+  double u = uniform01(rng);
+  for (int i = 0; i < k; ++i) { u -= p[i]; if (u <= 0) return i; }
+  return 0;
+}
+
+} // namespace
+
+extern "C" {
+
+size_t oakgpu_frames_size(const oakgpu_frame_update *updates, uint32_t count) { // CompressedFrames::n_bytes (:180-187)
+  size_t n = 4 + 2 + 384 + 1;
+  for (uint32_t i = 0; i < count; ++i) n += update_bytes(updates[i].m, updates[i].n);
+  return n;
+}
+
+int oakgpu_frames_write(const uint8_t *battle, uint8_t result, const oakgpu_frame_update *updates, uint32_t count, uint8_t *buffer,
+                        size_t capacity, size_t *written) {
+  if (!battle || (!updates && count) || !buffer) return oakgpu_fail_msg("oakgpu_frames_write: null argument");
+  if (count > 0xFFFF) return oakgpu_fail_msg("oakgpu_frames_write: more than 65535 frames in one game (FrameCount is u16)");
+  for (uint32_t i = 0; i < count; ++i)
+    if (updates[i].m < 1 || updates[i].m > 9 || updates[i].n < 1 || updates[i].n > 9) return oakgpu_fail_msg("oakgpu_frames_write: m, n must be in 1..9");
+  const size_t total = oakgpu_frames_size(updates, count);
+  if (total > capacity) return oakgpu_fail_msg("oakgpu_frames_write: buffer too small");
+  uint8_t *p = buffer;
+  put<uint32_t>(p, (uint32_t)total);          // Offset: byte length of this game's record (:190-191)
+  put<uint16_t>(p, (uint16_t)count);          // FrameCount
+  memcpy(p, battle, 384); p += 384;
+  *p++ = result;
+  for (uint32_t i = 0; i < count; ++i) {      // Update::write (:89-113)
+    const oakgpu_frame_update &u = updates[i];
+    *p++ = (uint8_t)((u.m - 1) | ((u.n - 1) << 4));
+    *p++ = u.c1;
+    *p++ = u.c2;
+    put<uint32_t>(p, u.iterations);
+    put<uint16_t>(p, compress_prob(u.empirical_value));
+    put<uint16_t>(p, compress_prob(u.nash_value));
+    for (int k = 0; k < u.m; ++k) put<uint16_t>(p, compress_prob(u.p1_empirical[k]));
+    for (int k = 0; k < u.m; ++k) put<uint16_t>(p, compress_prob(u.p1_nash[k]));
+    for (int k = 0; k < u.n; ++k) put<uint16_t>(p, compress_prob(u.p2_empirical[k]));
+    for (int k = 0; k < u.n; ++k) put<uint16_t>(p, compress_prob(u.p2_nash[k]));
+  }
+  if (written) *written = total;
+  return 0;
+}
+
+int oakgpu_frames_read(const uint8_t *buffer, size_t size, uint8_t *battle, uint8_t *result, oakgpu_frame_update *updates,
+                       uint32_t capacity, uint32_t *count, size_t *consumed) {
+  if (!buffer || !count) return oakgpu_fail_msg("oakgpu_frames_read: null argument");
+  if (size < 4 + 2 + 384 + 1) return oakgpu_fail_msg("oakgpu_frames_read: truncated record");
+  const uint8_t *p = buffer;
+  const uint32_t total = get<uint32_t>(p);
+  const uint16_t frames = get<uint16_t>(p);
+  if (total > size || total < 4 + 2 + 384 + 1) return oakgpu_fail_msg("oakgpu_frames_read: record length out of range");
+  if (battle) memcpy(battle, p, 384);
+  p += 384;
+  if (result) *result = *p;
+  ++p;
+  uint32_t n_read = 0;
+  while ((size_t)(p - buffer) < total) {      // CompressedFrames::read (:224-243)
+    if ((size_t)(buffer + total - p) < 3) return oakgpu_fail_msg("oakgpu_frames_read: truncated update");
+    const uint8_t mn = *p;
+    const uint32_t m = (mn & 15) + 1, n = (mn >> 4) + 1;
+    if (m > 9 || n > 9 || (size_t)(buffer + total - p) < update_bytes(m, n)) return oakgpu_fail_msg("oakgpu_frames_read: malformed update");
+    ++p;
+    oakgpu_frame_update u{};
+    u.m = (uint8_t)m; u.n = (uint8_t)n;
+    u.c1 = *p++; u.c2 = *p++;
+    u.iterations = get<uint32_t>(p);
+    u.empirical_value = get<uint16_t>(p) / 65535.0; // uncompress_probs (:27-35)
+    u.nash_value = get<uint16_t>(p) / 65535.0;
+    for (uint32_t k = 0; k < m; ++k) u.p1_empirical[k] = get<uint16_t>(p) / 65535.0;
+    for (uint32_t k = 0; k < m; ++k) u.p1_nash[k] = get<uint16_t>(p) / 65535.0;
+    for (uint32_t k = 0; k < n; ++k) u.p2_empirical[k] = get<uint16_t>(p) / 65535.0;
+    for (uint32_t k = 0; k < n; ++k) u.p2_nash[k] = get<uint16_t>(p) / 65535.0;
+    if (updates && n_read < capacity) updates[n_read] = u;
+    ++n_read;
+  }
+  if (n_read != frames) return oakgpu_fail_msg("oakgpu_frames_read: frame count does not match the record");
+  if (updates && n_read > capacity) return oakgpu_fail_msg("oakgpu_frames_read: more frames than the caller's capacity");
+  *count = n_read;
+  if (consumed) *consumed = total;
+  return 0;
+}
+
+int oakgpu_selfplay_game(oakgpu_ctx *ctx, oakgpu_net *net, const uint8_t *teams, uint64_t battle_seed, const oakgpu_selfplay_params *prm,
+                         uint8_t *buffer, size_t capacity, size_t *written, uint32_t *n_frames, uint8_t *result_out) {
+  if (!ctx || !teams || !prm || !buffer) return oakgpu_fail_msg("oakgpu_selfplay_game: null argument");
+  // PKMN::battle(p1, p2, seed) + the opening update(0, 0) (generate.cc:238-240), on the device
+  uint8_t battle[384], durations[8] = {}, result = 0;
+  if (int rc = oakgpu_init_battles(ctx, teams, &battle_seed, 1, 1, battle, durations, &result)) return rc;
+  uint8_t first[384];
+  memcpy(first, battle, 384); // CompressedFrames{battle_data.battle} (generate.cc:244)
+  std::vector<oakgpu_frame_update> frames;
+  uint64_t rng = prm->seed ^ 0x9FB21C651E98DF25ull;
+  const uint32_t max_len = prm->max_battle_length ? prm->max_battle_length : 1000;
+  oakgpu_search_params sp = prm->search;
+  while ((result & 15) == 0) {
+    if (frames.size() >= max_len) return oakgpu_fail_msg("oakgpu_selfplay_game: max battle length exceeded (generate.cc:268-271)");
+    oakgpu_search_output out;
+    sp.seed = splitmix64(rng);
+    if (int rc = oakgpu_search(ctx, net, battle, durations, result, &sp, &out)) return rc;
+    double pol1[9], pol2[9];
+    if (!get_policy(out.p1_empirical, out.p1_nash, out.m, prm->policy_mode, prm->policy_temp > 0 ? prm->policy_temp : 1.0, prm->policy_min, pol1) ||
+        !get_policy(out.p2_empirical, out.p2_nash, out.n, prm->policy_mode, prm->policy_temp > 0 ? prm->policy_temp : 1.0, prm->policy_min, pol2))
+      return oakgpu_fail_msg("oakgpu_selfplay_game: policy mode must be built from e / n / x words and leave a non-zero policy (util/policy.h:22-98)");
+    const int i = sample_pdf(pol1, out.m, rng), j = sample_pdf(pol2, out.n, rng);
+    oakgpu_frame_update u{};
+    u.m = out.m; u.n = out.n;
+    u.c1 = out.p1_choices[i]; u.c2 = out.p2_choices[j];
+    u.iterations = (uint32_t)out.iterations;
+    u.empirical_value = out.empirical_value;
+    u.nash_value = out.nash_value;
+    for (int k = 0; k < 9; ++k) { u.p1_empirical[k] = out.p1_empirical[k]; u.p1_nash[k] = out.p1_nash[k]; u.p2_empirical[k] = out.p2_empirical[k]; u.p2_nash[k] = out.p2_nash[k]; }
+    frames.push_back(u);
+    // PKMN::update(battle, c1, c2, options); durations <- options (generate.cc:319-322)
+    if (int rc = oakgpu_update(ctx, battle, &u.c1, &u.c2, durations, nullptr, nullptr, 1, &result)) return rc;
+  }
+  if (result_out) *result_out = result;
+  if (n_frames) *n_frames = (uint32_t)frames.size();
+  return oakgpu_frames_write(first, result, frames.data(), (uint32_t)frames.size(), buffer, capacity, written);
+}
+
+} // extern "C"
