@@ -184,6 +184,8 @@ typedef struct {
   uint32_t mucb_minimum;
   float mucb_c;
   float exp3_alpha;      /* Exp3 / PExp3 uniform mixing (search.cc:268-286); 0 = the reference's default 0.05 */
+  uint64_t duration_us;  /* time budget (search.cc:300-306): when non-zero, `iterations` is ignored and whole batches are
+                          * started until this much time has elapsed; output.iterations tells how many ran */
 } oakgpu_search_params;
 typedef struct {
   uint8_t m, n;                 /* legal choices per side at the root */
@@ -205,8 +207,22 @@ typedef struct {
  * simplex on 512-bit integers; the reference's lrsnash + GMP is absent).  p1[m], p2[n] = equilibrium strategies, *value =
  * game value / discretize_factor.  Host code: no GPU involved. */
 int oakgpu_solve_matrix(const int32_t *payoffs, int m, int n, int discretize_factor, double *p1, double *p2, double *value);
+/* RuntimeSearch::run (util/search.h:17-66, search.cc:150-313): the search configured by the Agent's strings, as the
+ * reference's binaries and pyoak.search configure it.  budget "4096" | "100ms" | "8s"; bandit "ucb-1.0" | "ucb1-2.0" |
+ * "pucb-1.5" | "exp3-<gamma>[-<alpha>]" | "pexp3-..."; eval "" / "mc" | "fp" | <.battle.net path> (loaded once per device
+ * and kept, like Agent::network_ptr); matrix_ucb "" | "<delay>-<interval>-<minimum>-<c>".  Unparsable strings fail with
+ * the reference's error texts (where it throws std::runtime_error); `table` and `discrete` agents are refused: those two
+ * components are not built.  batch = descents in flight, 0 = chosen from the budget. */
+typedef struct {
+  const char *budget, *bandit, *eval, *matrix_ucb;
+  int discrete, table;
+} oakgpu_agent;
+int oakgpu_search_agent(oakgpu_ctx *ctx, const uint8_t *battle, const uint8_t *durations, uint8_t result, const oakgpu_agent *agent,
+                        uint32_t batch, uint64_t seed, oakgpu_search_output *out);
+void oakgpu_agent_networks_clear(oakgpu_ctx *ctx);
+
 /* Diagnostic (no GPU involved): ONE player's bandit of the search above replayed for `steps` rounds -- select, then
- * update with values[t] -- so its arithmetic can be compared with the reference's search/bandit/*.h.  kind as in
+ * update with values[t] -- so its arithmetic can be compared with the reference's bandit headers.  kind as in
  * oakgpu_search_params.bandit; c = Params.c (UCB / PUCB / UCB1) or gamma (Exp3 / PExp3); logits (k floats): PUCB /
  * PExp3 priors; uniforms: the device.uniform() draw of each sampled selection (Exp3 / PExp3, k > 1).  Outputs: selected
  * index (and probability) per round, final stats_out[0..8] = scores / gains, [9..17] = priors, visits_out[0..8]. */

@@ -15,7 +15,7 @@ SYMBOLS = [
     "oakgpu_set_ou_pools", "oakgpu_random_ou_battles_dev",
     "oakgpu_net_load", "oakgpu_net_load_memory", "oakgpu_net_free", "oakgpu_net_shape",
     "oakgpu_leaf_eval_dev", "oakgpu_leaf_eval", "oakgpu_leaf_eval_policy_dev", "oakgpu_leaf_eval_policy",
-    "oakgpu_tree_step_dev", "oakgpu_search", "oakgpu_bandit_replay", "oakgpu_solve_matrix",
+    "oakgpu_tree_step_dev", "oakgpu_search", "oakgpu_search_agent", "oakgpu_agent_networks_clear", "oakgpu_bandit_replay", "oakgpu_solve_matrix",
     "oakgpu_frames_size", "oakgpu_frames_write", "oakgpu_frames_read", "oakgpu_selfplay_game", "oakgpu_poke_engine_eval_dev", "oakgpu_poke_engine_eval",
 ]
 
@@ -30,7 +30,12 @@ class SearchParams(C.Structure):      # oakgpu_search_params (include/oakgpu.h)
     _fields_ = [("iterations", C.c_uint64), ("batch", C.c_uint32), ("ucb_c", C.c_float), ("bandit", C.c_int32),
                 ("eval", C.c_int32), ("max_depth", C.c_uint32), ("root_rolls", C.c_uint32), ("other_rolls", C.c_uint32),
                 ("seed", C.c_uint64), ("matrix_ucb", C.c_int32), ("mucb_delay", C.c_uint32), ("mucb_minimum", C.c_uint32),
-                ("mucb_c", C.c_float), ("exp3_alpha", C.c_float)]
+                ("mucb_c", C.c_float), ("exp3_alpha", C.c_float), ("duration_us", C.c_uint64)]
+
+
+class Agent(C.Structure):             # oakgpu_agent
+    _fields_ = [("budget", C.c_char_p), ("bandit", C.c_char_p), ("eval", C.c_char_p), ("matrix_ucb", C.c_char_p),
+                ("discrete", C.c_int), ("table", C.c_int)]
 
 
 class SearchOutput(C.Structure):      # oakgpu_search_output
@@ -103,6 +108,9 @@ def load():
     lib.oakgpu_frames_read.argtypes = [vp, C.c_size_t, vp, C.POINTER(C.c_uint8), C.POINTER(FrameUpdate), u32, C.POINTER(u32), C.POINTER(C.c_size_t)]
     lib.oakgpu_selfplay_game.argtypes = [vp, vp, vp, u64, C.POINTER(SelfplayParams), vp, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(u32),
                                          C.POINTER(C.c_uint8)]
+    lib.oakgpu_search_agent.argtypes = [vp, vp, vp, C.c_uint8, C.POINTER(Agent), u32, u64, C.POINTER(SearchOutput)]
+    lib.oakgpu_agent_networks_clear.argtypes = [vp]
+    lib.oakgpu_agent_networks_clear.restype = None
     lib.oakgpu_solve_matrix.argtypes = [vp, i32, i32, i32, vp, vp, vp]
     lib.oakgpu_bandit_replay.argtypes = [i32, C.c_float, C.c_float, u32, vp, u32, vp, vp, vp, vp, vp, vp]
     lib.oakgpu_update_dev.argtypes = [vp, vp, vp, vp, vp, vp, vp, u32, vp]

@@ -175,6 +175,7 @@ extern "C" int oakgpu_search(oakgpu_ctx *ctx, oakgpu_net *net, const uint8_t *ba
   if ((use_net || pucb) && !net) return oakgpu_fail_msg("oakgpu_search: network evaluation / PUCB / PExp3 priors need a network");
   if (pucb && !use_net) return oakgpu_fail_msg("oakgpu_search: PUCB / PExp3 take their priors from the network evaluator (eval = 1)");
   if (prm->batch == 0 || prm->batch > (1u << 20)) return oakgpu_fail_msg("oakgpu_search: batch must be in 1..2^20");
+  if (prm->iterations == 0 && prm->duration_us == 0) return oakgpu_fail_msg("oakgpu_search: give an iteration or a time budget");
   auto rolls_ok = [](uint32_t r) { return r == 1 || r == 2 || r == 3 || r == 20 || r == 39; };
   if (!rolls_ok(prm->root_rolls) || !rolls_ok(prm->other_rolls)) return oakgpu_fail_msg("oakgpu_search: rolls must be 1, 2, 3, 20 or 39");
   HIPRC(hipSetDevice(oakgpu_ctx_device(ctx)));
@@ -234,7 +235,8 @@ extern "C" int oakgpu_search(oakgpu_ctx *ctx, oakgpu_net *net, const uint8_t *ba
   };
   // one batch at a time for the bandits with network priors (they share the network's policy workspace) and for
   // batch = 1, which is the reference's strictly sequential iteration order
-  const int n_slots = (!pucb && B > 1 && prm->iterations > B) ? 2 : 1;
+  const bool timed = prm->duration_us != 0; // time budget (search.cc:300-306): batches are started until it has elapsed
+  const int n_slots = (!pucb && B > 1 && (timed || prm->iterations > B)) ? 2 : 1;
   Slot slots[2];
   for (int si = 0; si < n_slots; ++si) {
     Slot &S = slots[si];
@@ -283,7 +285,7 @@ extern "C" int oakgpu_search(oakgpu_ctx *ctx, oakgpu_net *net, const uint8_t *ba
   // one batch: root prep, level-synchronous descent (host selection <-> k_tree_step), then the leaf evaluation is
   // LAUNCHED (not awaited)
   auto descend = [&](Slot &S) -> int {
-    const uint32_t nb = (uint32_t)std::min<uint64_t>(B, prm->iterations - started);
+    const uint32_t nb = timed ? B : (uint32_t)std::min<uint64_t>(B, prm->iterations - started);
     S.nb = nb;
     started += nb;
     S.busy = true;
@@ -426,10 +428,14 @@ extern "C" int oakgpu_search(oakgpu_ctx *ctx, oakgpu_net *net, const uint8_t *ba
     S.busy = false;
     return 0;
   };
-  for (int turn = 0; started < prm->iterations || slots[0].busy || slots[1].busy; turn = (turn + 1) % n_slots) {
+  auto more = [&] {
+    if (!timed) return started < prm->iterations;
+    return std::chrono::duration<double, std::micro>(std::chrono::high_resolution_clock::now() - t_start).count() < (double)prm->duration_us;
+  };
+  for (int turn = 0; more() || slots[0].busy || slots[1].busy; turn = (turn + 1) % n_slots) {
     Slot &S = slots[turn];
     if (S.busy) RC(finish(S));
-    if (started < prm->iterations) RC(descend(S));
+    if (more()) RC(descend(S));
   }
   if (timing) fprintf(stderr, "oakgpu_search timing (ms): select %.1f  gpu-step %.1f  process %.1f  eval %.1f  backprop %.1f\n", t_sel / 1e3, t_gpu / 1e3, t_proc / 1e3, t_eval / 1e3, t_back / 1e3);
   out->iterations = done;
@@ -454,4 +460,104 @@ extern "C" int oakgpu_search(oakgpu_ctx *ctx, oakgpu_net *net, const uint8_t *ba
   out->total_depth = total_depth;
   out->duration_us = std::chrono::duration<double, std::micro>(std::chrono::high_resolution_clock::now() - t_start).count();
   return 0;
+}
+
+
+// ---- RuntimeSearch::run (cpp/include/util/search.h:17-66, cpp/src/search.cc:150-313): the Agent's strings select budget,
+// bandit, evaluator and MatrixUCB at run time.  Same mini-languages and the same error texts as the reference, where it
+// throws std::runtime_error; what this build does not have (transposition-table heaps, the int8 "discrete" network) is
+// refused by name instead of being silently replaced.
+#include <map>
+#include <mutex>
+#include <string>
+namespace {
+std::vector<std::string> split(const std::string &s, char sep) {
+  std::vector<std::string> out;
+  size_t pos = 0;
+  for (;;) {
+    const size_t end = s.find(sep, pos);
+    out.push_back(s.substr(pos, end == std::string::npos ? std::string::npos : end - pos));
+    if (end == std::string::npos) break;
+    pos = end + 1;
+  }
+  return out;
+}
+bool to_float(const std::string &s, float &v) { char *e = nullptr; v = strtof(s.c_str(), &e); return e && e != s.c_str() && *e == 0; }
+bool to_u64(const std::string &s, uint64_t &v) { char *e = nullptr; v = strtoull(s.c_str(), &e, 10); return !s.empty() && e && *e == 0 && s[0] != '-'; }
+std::mutex g_net_mu;
+std::map<std::pair<int, std::string>, oakgpu_net *> g_nets; // Agent::network_ptr (search.cc:62-148), shared per (device, path)
+} // namespace
+
+extern "C" int oakgpu_search_agent(oakgpu_ctx *ctx, const uint8_t *battle, const uint8_t *durations, uint8_t result, const oakgpu_agent *agent,
+                                   uint32_t batch, uint64_t seed, oakgpu_search_output *out) {
+  if (!ctx || !battle || !durations || !agent || !out) return oakgpu_fail_msg("oakgpu_search_agent: null argument");
+  oakgpu_search_params P{};
+  P.root_rolls = 3; P.other_rolls = 1; // default_search (mcts.h:131)
+  P.seed = seed;
+  // budget: "4096" | "100ms" | "8s" (search.cc:292-310)
+  const std::string budget = agent->budget ? agent->budget : "";
+  const size_t pos = budget.find_first_not_of("0123456789");
+  uint64_t number = 0;
+  if (budget.empty() || pos == 0 || !to_u64(budget.substr(0, pos), number)) return oakgpu_fail_msg(("Invalid search duration specification: " + budget).c_str());
+  const std::string unit = pos == std::string::npos ? "" : budget.substr(pos);
+  if (unit.empty()) P.iterations = number;
+  else if (unit == "ms" || unit == "millisec" || unit == "milliseconds") P.duration_us = number * 1000;
+  else if (unit == "s" || unit == "sec" || unit == "seconds") P.duration_us = number * 1000000;
+  else return oakgpu_fail_msg(("Invalid search duration specification: " + budget).c_str());
+  if (P.iterations == 0 && P.duration_us == 0) return oakgpu_fail_msg(("Invalid search duration specification: " + budget).c_str());
+  // evaluator: "" / "mc" / "montecarlo" / "monte-carlo" | "fp" | <network path> (util/search.h:56-61)
+  const std::string eval = agent->eval ? agent->eval : "";
+  const bool mc = eval.empty() || eval == "mc" || eval == "montecarlo" || eval == "monte-carlo", fp = eval == "fp";
+  P.eval = mc ? 0 : fp ? 2 : 1;
+  // bandit: "ucb-1.0" | "ucb1-2.0" | "pucb-1.5" | "exp3-<gamma>[-<alpha>]" | "pexp3-..." (search.cc:237-290)
+  const std::string bandit = agent->bandit ? agent->bandit : "";
+  const std::vector<std::string> bs = split(bandit, '-');
+  if (bs.size() < 2 || !to_float(bs[1], P.ucb_c)) return oakgpu_fail_msg(("Could not parse bandit string: " + bandit).c_str());
+  const std::string &name = bs[0];
+  if (name == "ucb") P.bandit = 0;
+  else if (name == "pucb") P.bandit = 1;
+  else if (name == "ucb1") P.bandit = 2;
+  else if (name == "exp3") P.bandit = 3;
+  else if (name == "pexp3") P.bandit = 4;
+  else return oakgpu_fail_msg(("Could not parse bandit string: " + name).c_str());
+  if ((P.bandit == 1 || P.bandit == 4) && (mc || fp)) return oakgpu_fail_msg("Contextual bandit specified with eval that does not produce policy priors.");
+  P.exp3_alpha = 0.05f;
+  if (P.bandit >= 3 && bs.size() >= 3 && !to_float(bs[2], P.exp3_alpha)) return oakgpu_fail_msg(("Could not parse bandit string: " + bandit).c_str());
+  // matrix_ucb: "" | "delay-interval-minimum-c" (search.cc:216-235); the interval is the batch here
+  const std::string mu = agent->matrix_ucb ? agent->matrix_ucb : "";
+  if (!mu.empty()) {
+    const std::vector<std::string> ms = split(mu, '-');
+    uint64_t delay = 0, interval = 0, minimum = 0;
+    if (ms.size() != 4 || !to_u64(ms[0], delay) || !to_u64(ms[1], interval) || !to_u64(ms[2], minimum) || !to_float(ms[3], P.mucb_c))
+      return oakgpu_fail_msg(("Could not parse MatrixUCB name: " + mu).c_str());
+    P.matrix_ucb = 1;
+    P.mucb_delay = (uint32_t)delay;
+    P.mucb_minimum = (uint32_t)minimum;
+  }
+  if (agent->table) return oakgpu_fail_msg("RuntimeSearch: transposition-table heaps (search/hash.h) are not built in this library");
+  if (agent->discrete) return oakgpu_fail_msg("RuntimeSearch: the int8 (discrete) network (nn/battle/quantized) is not built in this library; use the fp32 network");
+  // descents in flight: the caller's choice, or a size that keeps the GPU busy without starving the tree of feedback
+  if (batch) P.batch = batch;
+  else if (P.duration_us) P.batch = 4096;
+  else P.batch = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(16384, P.iterations / 16));
+  oakgpu_net *net = nullptr;
+  if (P.eval == 1) { // Agent::initialize_network (search.cc:62-148): read once, keep
+    std::lock_guard<std::mutex> lock(g_net_mu);
+    const auto key = std::make_pair(oakgpu_ctx_device(ctx), eval);
+    auto it = g_nets.find(key);
+    if (it == g_nets.end()) {
+      oakgpu_net *n = nullptr;
+      if (int rc = oakgpu_net_load(ctx, eval.c_str(), &n)) return rc;
+      it = g_nets.emplace(key, n).first;
+    }
+    net = it->second;
+  }
+  return oakgpu_search(ctx, net, battle, durations, result, &P, out);
+}
+
+extern "C" void oakgpu_agent_networks_clear(oakgpu_ctx *ctx) { // drops the networks oakgpu_search_agent loaded on this context's device
+  if (!ctx) return;
+  std::lock_guard<std::mutex> lock(g_net_mu);
+  for (auto it = g_nets.begin(); it != g_nets.end();)
+    if (it->first.first == oakgpu_ctx_device(ctx)) { oakgpu_net_free(ctx, it->second); it = g_nets.erase(it); } else ++it;
 }
