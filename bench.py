@@ -50,7 +50,10 @@ def main():
     ap.add_argument("--streams", type=int, default=2, help="groups in flight (contexts / HIP streams)")
     ap.add_argument("--playouts-per-lane", type=int, default=2,
                     help="k > 1: persistent n/k lanes per batch that refill from an atomic playout queue")
-    ap.add_argument("--workload", choices=["all", "rollout", "leaf", "config3", "search"], default="all",
+    ap.add_argument("--exchange", choices=["torch", "rccl"], default="torch",
+                    help="config4: the all-gather of the per-root means through torch.distributed (RCCL underneath) or through "
+                         "the library's own ncclAllGather call site (oakgpu_all_gather_dev)")
+    ap.add_argument("--workload", choices=["all", "rollout", "leaf", "config3", "config4", "search"], default="all",
                     help="all (default) = the configs[1] headline line + `leaf` and `config3` sub-records; rollout = configs[1] "
                          "only; leaf = leaf-evals/s of the 768-256-256-256-1 net; config3 = configs[2]: one turn-step of the "
                          "whole batch + a leaf eval of every lane, every turn; search = tree search with batched leaves "
@@ -84,6 +87,8 @@ def main():
 
     if args.workload == "search":
         return search_workload(args, torch, dev, rank, local_rank, world, dist)
+    if args.workload == "config4":
+        return config4_workload(args, torch, dev, rank, local_rank, world, dist)
     if args.workload in ("leaf", "config3"):      # one sub-record on its own, same JSON shape as the headline line
         recs = leaf_records(args, torch, dev, rank, local_rank, world, dist, which=(args.workload,))
         if rank == 0:
@@ -439,6 +444,136 @@ def leaf_records(args, torch, dev, rank, local_rank, world, dist, which=("leaf",
     net.close()
     ctx.close()
     return out
+
+
+def config4_workload(args, torch, dev, rank, local_rank, world, dist):
+    """BASELINE configs[3]: root-parallel MCTS, 256 roots x 4096 playouts per search step, STRONG scaling: the roots are
+    sharded contiguous-by-root over the ranks (oak_amd.dist.root_shard), every rank rolls out its roots' playouts with root
+    prep (battle.rng from the lane's stream + randomize_hidden_variables, mcts.h:250-263), reduces them to one mean per root
+    on the device (oakgpu_segment_mean_dev) and ONE all-gather of those means (256 floats in total) gives every rank every
+    root's value.  A search step ends when the means are on the HOST (the tree update that consumes them is sequential), so
+    steps do not overlap: each pays its own tail."""
+    import numpy as np
+    from oak_amd import _lib
+    from oak_amd import dist as oakdist
+    from oak_amd.engine import Context
+    n_roots, reps = 256, 4096
+    lo, hi = oakdist.root_shard(n_roots, rank, world)
+    mine = hi - lo
+    n = mine * reps
+    ctx = Context(local_rank)
+    stream = torch.cuda.ExternalStream(ctx.stream_ptr(), device=dev)
+    ctx.ensure_ou_pools()
+    lib, h = ctx.lib, ctx.handle
+    u8 = torch.uint8
+
+    def P(t):
+        return C.c_void_p(t.data_ptr())
+    # the 256 roots = the first 256 lanes of config 2 after update(0, 0) (SURVEY 8d), identical on every rank
+    rb, rd, rp, rr = (torch.empty(s_, dtype=u8, device=dev) for s_ in ((n_roots, 384), (n_roots, 8), (n_roots, 8), (n_roots,)))
+    _lib.check(lib.oakgpu_random_ou_battles_dev(h, C.c_uint64(SEED0), n_roots, P(rb), P(rd), P(rp), P(rr)))
+    ctx.synchronize()
+    battles = rb[lo:hi].repeat_interleave(reps, 0).contiguous()
+    durations = rd[lo:hi].repeat_interleave(reps, 0).contiguous()
+    rin = rr[lo:hi].repeat_interleave(reps, 0).contiguous()
+    # one fast_prng stream per replica, seeded by its GLOBAL lane index (results do not depend on the number of ranks)
+    prng = torch.empty((n, 8), dtype=u8, device=dev)
+    with torch.no_grad():
+        tb, tdur, tr = torch.empty((n, 384), dtype=u8, device=dev), torch.empty((n, 8), dtype=u8, device=dev), torch.empty((n,), dtype=u8, device=dev)
+        _lib.check(lib.oakgpu_random_ou_battles_dev(h, C.c_uint64(0xC40000000000 + lo * reps), n, P(tb), P(tdur), P(prng), P(tr)))
+        ctx.synchronize()
+        del tb, tdur, tr
+    results = torch.empty((n,), dtype=u8, device=dev)
+    steps_out = torch.zeros((n,), dtype=torch.int32, device=dev)
+    values = torch.empty((n,), dtype=torch.float32, device=dev)
+    per = -(-n_roots // world)                                     # padded shard size (ragged splits)
+    means = torch.zeros((per,), dtype=torch.float32, device=dev)
+    allm = torch.empty((world * per,), dtype=torch.float32, device=dev)
+    host = torch.empty((world * per,), dtype=torch.float32).pin_memory()
+    total = torch.zeros((), dtype=torch.int64, device=dev)
+    comm = None
+    if args.exchange == "rccl":      # the library's own ncclAllGather call site; the id travels through torch.distributed
+        idt = torch.zeros(128, dtype=u8)
+        if rank == 0:
+            buf = (C.c_uint8 * 128)()
+            _lib.check(lib.oakgpu_comm_unique_id(buf))
+            idt = torch.tensor(list(buf), dtype=u8)
+        if world > 1:
+            idt = idt.to(dev)
+            dist.broadcast(idt, 0)
+            idt = idt.cpu()
+        idb = (C.c_uint8 * 128)(*idt.tolist())
+        comm = C.c_void_p()
+        _lib.check(lib.oakgpu_comm_create(h, idb, rank, world, C.byref(comm)))
+
+    def step():
+        _lib.check(lib.oakgpu_rollout_dev(h, P(battles), P(durations), P(rin), P(prng), n, MAX_STEPS, 1, P(results), P(steps_out),
+                                          P(values), None, None))
+        _lib.check(lib.oakgpu_segment_mean_dev(h, P(values), mine, reps, P(means)))
+        with torch.cuda.stream(stream):
+            total.add_(steps_out.sum(dtype=torch.int64))
+            if comm is not None:
+                _lib.check(lib.oakgpu_all_gather_dev(h, comm, P(means), P(allm), per))
+            elif world > 1:
+                dist.all_gather_into_tensor(allm, means)
+            else:
+                allm.copy_(means)
+            host.copy_(allm, non_blocking=True)
+        ctx.synchronize()                                           # the host now holds all 256 means: the step is over
+
+    for _ in range(max(args.warmup, 1)):
+        step()
+    with torch.cuda.stream(stream):
+        total.zero_()
+    ctx.synchronize()
+    K = args.steps
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(K):
+        step()
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    my_steps = int(total.item())
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        s_ = torch.tensor([my_steps], dtype=torch.int64, device=dev)
+        dist.all_reduce(s_, op=dist.ReduceOp.SUM)
+        my_steps = int(s_.item())
+    got = np.concatenate([host.numpy()[r * per:r * per + (oakdist.root_shard(n_roots, r, world)[1] - oakdist.root_shard(n_roots, r, world)[0])]
+                          for r in range(world)])
+    assert got.shape == (n_roots,) and ((got >= 0) & (got <= 1)).all()
+    if rank == 0:
+        print(json.dumps({
+            "metric": "turn-steps/s (root-parallel MCTS step: 256 roots x 4096 playouts)", "value": my_steps / elapsed, "unit": "turn-steps/s",
+            "n_gpus": world, "steps": K, "warmup": args.warmup, "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "u16", "data": "synthetic",
+            "config": {"workload": "configs[3]: root-parallel MCTS, 256 roots x 4096 playouts per search step, roots sharded contiguous-by-root, "
+                                   "per-root means reduced on the device, ONE all-gather of 256 floats per step, means on the host before the next step",
+                       "roots": n_roots, "playouts_per_root": reps, "roots_per_gpu": mine, "playouts_per_s": n_roots * reps * K / elapsed,
+                       "exchange": ("oakgpu_all_gather_dev (ncclAllGather)" if comm is not None else "torch.distributed all_gather_into_tensor" if world > 1 else "none (one rank)"),
+                       "mean_root_value": float(got.mean())},
+        }), flush=True)
+    dbg = (lambda m: print(m, file=sys.stderr, flush=True)) if os.environ.get("BENCH_DEBUG") else (lambda m: None)
+    torch.cuda.synchronize(dev)
+    if comm is not None:
+        lib.oakgpu_comm_destroy(comm)
+        dbg("comm destroyed")
+    del host
+    dbg("host freed")
+    del battles, durations, rin, prng, results, steps_out, values, means, allm, total, rb, rd, rp, rr
+    dbg("tensors freed")
+    del stream
+    dbg("stream wrapper freed")
+    ctx.close()
+    dbg("ctx closed")
+    if world > 1:
+        dist.destroy_process_group()
 
 
 def search_workload(args, torch, dev, rank, local_rank, world, dist):

@@ -233,6 +233,21 @@ int oakgpu_search(oakgpu_ctx *ctx, oakgpu_net *net /* nullable for eval = 0 */, 
                   const uint8_t *durations /* 8 */, uint8_t result, const oakgpu_search_params *params,
                   oakgpu_search_output *out);
 
+/* ---- the path's one exchange step: per-root pre-reduction on the device + RCCL all-gather over xGMI.
+ * Root-parallel MCTS shards its roots contiguously over the GPUs of a node; each rank reduces its playouts' leaf values to
+ * one mean per root (oakgpu_segment_mean_dev: out[s] = mean(values[s * per_segment .. (s + 1) * per_segment))) and ONE
+ * ncclAllGather of `count` floats per rank (oakgpu_all_gather_dev, on the context's stream) gives every rank all means:
+ * recv = world x count floats, rank-major.  One process per GPU: rank 0 makes the 128-byte id (oakgpu_comm_unique_id),
+ * hands it to the others out of band, and every rank calls oakgpu_comm_create.  RCCL is bound at run time (dlopen);
+ * without it these calls fail with a message.  The reference has no collective: its playouts are unrelated threads
+ * (cpp/src/generate.cc:527-536). */
+typedef struct oakgpu_comm oakgpu_comm;
+int oakgpu_segment_mean_dev(oakgpu_ctx *ctx, const float *values, uint32_t segments, uint32_t per_segment, float *out);
+int oakgpu_comm_unique_id(uint8_t *id128);
+int oakgpu_comm_create(oakgpu_ctx *ctx, const uint8_t *id128, int rank, int world, oakgpu_comm **out);
+void oakgpu_comm_destroy(oakgpu_comm *comm);
+int oakgpu_all_gather_dev(oakgpu_ctx *ctx, oakgpu_comm *comm, const float *send, float *recv, size_t count);
+
 /* ---- `.battle.data` training frames + self-play on the GPU path.
  * oakgpu_frames_write / _read = Train::Battle::CompressedFrames::write / read (train/battle/compressed-frame.h:37-243):
  * one game = u32 record length, u16 frame count, the 384-byte battle after the opening update, the final result byte,

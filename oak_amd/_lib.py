@@ -16,6 +16,7 @@ SYMBOLS = [
     "oakgpu_net_load", "oakgpu_net_load_memory", "oakgpu_net_free", "oakgpu_net_shape",
     "oakgpu_leaf_eval_dev", "oakgpu_leaf_eval", "oakgpu_leaf_eval_policy_dev", "oakgpu_leaf_eval_policy",
     "oakgpu_tree_step_dev", "oakgpu_search", "oakgpu_search_agent", "oakgpu_agent_networks_clear", "oakgpu_bandit_replay", "oakgpu_solve_matrix",
+    "oakgpu_segment_mean_dev", "oakgpu_comm_unique_id", "oakgpu_comm_create", "oakgpu_comm_destroy", "oakgpu_all_gather_dev",
     "oakgpu_frames_size", "oakgpu_frames_write", "oakgpu_frames_read", "oakgpu_selfplay_game", "oakgpu_poke_engine_eval_dev", "oakgpu_poke_engine_eval",
 ]
 
@@ -102,6 +103,12 @@ def load():
     lib.oakgpu_poke_engine_eval.argtypes = [vp, vp, u32, C.c_float, vp, vp]
     lib.oakgpu_tree_step_dev.argtypes = [vp, vp, vp, vp, vp, vp, u32, u32, vp, vp, vp, vp, vp]
     lib.oakgpu_search.argtypes = [vp, vp, vp, vp, C.c_uint8, C.POINTER(SearchParams), C.POINTER(SearchOutput)]
+    lib.oakgpu_segment_mean_dev.argtypes = [vp, vp, u32, u32, vp]
+    lib.oakgpu_comm_unique_id.argtypes = [vp]
+    lib.oakgpu_comm_create.argtypes = [vp, vp, i32, i32, C.POINTER(vp)]
+    lib.oakgpu_comm_destroy.argtypes = [vp]
+    lib.oakgpu_comm_destroy.restype = None
+    lib.oakgpu_all_gather_dev.argtypes = [vp, vp, vp, vp, C.c_size_t]
     lib.oakgpu_frames_size.restype = C.c_size_t
     lib.oakgpu_frames_size.argtypes = [C.POINTER(FrameUpdate), u32]
     lib.oakgpu_frames_write.argtypes = [vp, C.c_uint8, C.POINTER(FrameUpdate), u32, vp, C.c_size_t, C.POINTER(C.c_size_t)]

@@ -61,3 +61,18 @@ def round_to_global(out):
 def per_root_means(all_values, playouts_per_root):
     """Root-parallel MCTS (BASELINE config 4): mean leaf value per root from the gathered lane values."""
     return all_values.view(-1, playouts_per_root).mean(dim=1)
+
+
+# ---- BASELINE config 4: root-parallel MCTS, roots sharded contiguous-by-root, per-root pre-reduction on the device,
+# ONE all-gather of one float per root (256 floats: latency-bound) -------------------------------------------------
+def root_shard(n_roots, rank, world):
+    """Roots of `rank`: [lo, hi) -- contiguous, so a root's playouts stay on one device and are reduced there."""
+    return shard_range(n_roots, rank, world)
+
+
+def gather_root_means(local_means, n_roots):
+    """All-gather the per-root mean leaf values: `local_means` holds this rank's roots (root_shard order); returns the
+    n_roots means in global root order on every rank.  One collective of at most ceil(n_roots / world) floats per rank."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return local_means
+    return gather_values(local_means, n_roots)

@@ -112,3 +112,55 @@ def test_shard_range_partition():
             edges = [shard_range(n, r, w) for r in range(w)]
             assert edges[0][0] == 0 and edges[-1][1] == n
             assert all(edges[i][1] == edges[i + 1][0] for i in range(w - 1))
+
+
+def _config4_worker(rank, world, port, n_roots, reps, q):
+    """BASELINE config 4 on two ranks: roots sharded contiguous-by-root, every root replicated `reps` times with its own
+    playout streams, rolled out with root prep, reduced to one mean per root locally, ONE all-gather of the means."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oak_amd import dist as D
+    lo, hi = D.root_shard(n_roots, rank, world)
+    means = torch.from_numpy(_config4_means(n_roots, reps, lo, hi))
+    allm = D.gather_root_means(means, n_roots)
+    if rank == world - 1:
+        q.put(allm.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _config4_means(n_roots, reps, lo, hi):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import ctypes as C
+    import oracle_lib as O
+    rb, rd, rp, rr = O.make_random_ou_batch(n_roots, seed0=4000)      # the roots are global: root g is the same on any rank
+    out = np.zeros(hi - lo, dtype=np.float32)
+    for g in range(lo, hi):
+        b, d, r = np.repeat(rb[g:g + 1], reps, 0), np.repeat(rd[g:g + 1], reps, 0), np.repeat(rr[g:g + 1], reps)
+        p = np.zeros((reps, 8), dtype=np.uint8)
+        for k in range(reps):                                          # replica k of root g: its own fast_prng stream
+            O.LIB.oracle_fast_prng_seed(O.ptr(p[k]), C.c_uint64(0xC4000000 + g * reps + k))
+        res, _ = O.rollout_batch(b, d, r, p, max_steps=150, prep=True)
+        t = res & 15
+        out[g - lo] = np.where(t == 1, 1.0, np.where(t == 2, 0.0, 0.5)).astype(np.float32).mean()
+    return out
+
+
+def test_config4_root_sharding_and_mean_gather():
+    """256 roots x 4096 playouts in miniature (13 roots x 6, ragged over 2 ranks): the gathered per-root means equal the
+    single-process result in global root order."""
+    n_roots, reps, world = 13, 6, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_config4_worker, args=(r, world, port, n_roots, reps, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=180)
+    for p in procs:
+        p.join(timeout=180)
+        assert p.exitcode == 0
+    assert got.shape == (n_roots,) and (got == _config4_means(n_roots, reps, 0, n_roots)).all()

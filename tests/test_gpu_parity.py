@@ -454,3 +454,43 @@ def test_set_ou_pools_rejects_inputs_that_would_hang_the_generator():
     zero = sizes.copy(); zero[int(legal[1])] = 0
     assert call(legal, len(legal), pools, zero) != 0               # empty pool
     ctx.close()
+
+
+def test_segment_mean_and_direct_rccl_all_gather(gpu_ctx):
+    """The C++ host layer's exchange step: per-root means on the device (oakgpu_segment_mean_dev) and the library's own
+    ncclAllGather call site (oakgpu_comm_* / oakgpu_all_gather_dev) -- here with a one-rank communicator on the one GPU."""
+    from oak_amd import _lib
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    hip.hipFree.argtypes = [C.c_void_p]
+    lib, h = gpu_ctx.lib, gpu_ctx.handle
+    rng = np.random.default_rng(3)
+    for segs, per in ((256, 4096), (7, 100), (1, 1), (32, 333)):
+        vals = rng.random((segs, per)).astype(np.float32)
+        dv, do = C.c_void_p(), C.c_void_p()
+        assert hip.hipMalloc(C.byref(dv), vals.nbytes) == 0 and hip.hipMalloc(C.byref(do), segs * 4) == 0
+        assert hip.hipMemcpy(dv, vals.ctypes.data_as(C.c_void_p), vals.nbytes, 1) == 0
+        _lib.check(lib.oakgpu_segment_mean_dev(h, dv, segs, per, do))
+        gpu_ctx.synchronize()
+        out = np.zeros(segs, dtype=np.float32)
+        assert hip.hipMemcpy(out.ctypes.data_as(C.c_void_p), do, segs * 4, 2) == 0
+        assert np.abs(out - vals.astype(np.float64).mean(axis=1)).max() <= 2e-6
+        hip.hipFree(dv)
+        hip.hipFree(do)
+    ident = (C.c_uint8 * 128)()
+    _lib.check(lib.oakgpu_comm_unique_id(ident))
+    comm = C.c_void_p()
+    _lib.check(lib.oakgpu_comm_create(h, ident, 0, 1, C.byref(comm)))
+    send = rng.random(256).astype(np.float32)
+    ds, dr = C.c_void_p(), C.c_void_p()
+    assert hip.hipMalloc(C.byref(ds), 1024) == 0 and hip.hipMalloc(C.byref(dr), 1024) == 0
+    assert hip.hipMemcpy(ds, send.ctypes.data_as(C.c_void_p), 1024, 1) == 0
+    _lib.check(lib.oakgpu_all_gather_dev(h, comm, ds, dr, 256))
+    gpu_ctx.synchronize()
+    recv = np.zeros(256, dtype=np.float32)
+    assert hip.hipMemcpy(recv.ctypes.data_as(C.c_void_p), dr, 1024, 2) == 0
+    assert (recv == send).all()
+    lib.oakgpu_comm_destroy(comm)
+    hip.hipFree(ds)
+    hip.hipFree(dr)

@@ -6,7 +6,7 @@ set -e
 cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
 if [ "$1" = build ] || [ ! -f prof_build/liboakgpu_prof.so ]; then
   mkdir -p prof_build
-  hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -DOAKGPU_SITE_PROFILE -o prof_build/liboakgpu_prof.so oak_amd/csrc/oakgpu.hip oak_amd/csrc/leafnet.hip oak_amd/csrc/pkmn_shim.hip oak_amd/csrc/search_host.hip oak_amd/csrc/selfplay.hip
+  hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -DOAKGPU_SITE_PROFILE -o prof_build/liboakgpu_prof.so oak_amd/csrc/oakgpu.hip oak_amd/csrc/leafnet.hip oak_amd/csrc/pkmn_shim.hip oak_amd/csrc/search_host.hip oak_amd/csrc/selfplay.hip oak_amd/csrc/collective.hip
   [ "$1" = build ] && exit 0
 fi
 mkdir -p gpurun_out
