@@ -74,7 +74,8 @@ struct SiteScope {
 // region ids
 enum { PS_REFILL = 0, PS_STEP, PS_LEGAL_DRAW, PS_ORDER, PS_EXEC_MOVE, PS_SWITCH_IN, PS_BEFORE_MOVE, PS_EXEC_SELECTED_PRE,
        PS_RUN_MOVE, PS_GATES_HIT, PS_STATUS_BODIES, PS_DAMAGE, PS_SECONDARY_APPLY, PS_FAINT_RESIDUAL, PS_PUBLISH,
-       PS_CALC_DAMAGE, PS_APPLY_HITS, PS_DAMAGE_TAIL, PS_COUNT };
+       PS_CALC_DAMAGE, PS_APPLY_HITS, PS_DAMAGE_TAIL, PS_HEAVY, PS_H_CONVERSION, PS_H_HAZE, PS_H_HEAL, PS_H_MIMIC,
+       PS_H_POISON, PS_H_SUBSTITUTE, PS_H_TRANSFORM, PS_H_BIDE, PS_H_SLEEP, PS_H_DISABLE, PS_COUNT };
 
 struct SideR {
   uint32_t a0, a1, a2; // active: hp|atk<<16, def|spe<<16, spc|species<<16|types<<24
@@ -780,9 +781,10 @@ struct EngineR {
       F.vlo |= cls == A_FVOL ? 1u << par : 0u; // LeechSeed (already seeded: no-op)
       want_status = cls == A_PAR ? (uint32_t)ST_PAR : 0u;
       want_conf = cls == A_CONF && !(F.vlo & V_CONFUSION);
-      if (cls == A_HEAVY) switch (eff) {
-      case E_Conversion: S.a2 = (S.a2 & 0x00FFFFFFu) | (F.a2 & 0xFF000000u); break;
+      if (cls == A_HEAVY) { OAK_SCOPE(PS_HEAVY); switch (eff) {
+      case E_Conversion: { OAK_SCOPE(PS_H_CONVERSION); } S.a2 = (S.a2 & 0x00FFFFFFu) | (F.a2 & 0xFF000000u); break;
       case E_Haze: {
+        OAK_SCOPE(PS_H_HAZE);
         S.bo = 0;
         F.bo = 0;
         unmodified_to_active(S);
@@ -797,6 +799,7 @@ struct EngineR {
         break;
       }
       case E_Heal: {
+        OAK_SCOPE(PS_H_HEAL);
         const uint32_t mx = maxhp(S), h = hp(S), delta = mx - h;
         if (delta == 0 || (delta & 255) == 255) break; // gen-1 recovery failure glitch
         if (move_id == M_Rest) {
@@ -812,6 +815,7 @@ struct EngineR {
         break;
       }
       case E_Mimic: {
+        OAK_SCOPE(PS_H_MIMIC);
         uint32_t n = 0;
         for (uint32_t i = 1; i <= 4; ++i) n += (active_move(F, i) & 0xFF) != 0;
         if (n == 0 || mslot == 0) break;
@@ -822,11 +826,14 @@ struct EngineR {
         set_amoves(S, (amoves(S) & ~(0xFFull << sh)) | (nid << sh));
         break;
       }
-      case E_Poison:
+      case E_Poison: {
+        OAK_SCOPE(PS_H_POISON);
         if (move_id == M_Toxic) { set_status(F, ST_TOX); F.vlo |= V_TOXIC; set_toxic_ctr(F, 0); }
         else set_status(F, ST_PSN);
         break;
+      }
       case E_Substitute: {
+        OAK_SCOPE(PS_H_SUBSTITUTE);
         if (S.vlo & V_SUBSTITUTE) break;
         const uint32_t cost = maxhp(S) / 4, h = hp(S);
         if (h < cost) break;
@@ -836,6 +843,7 @@ struct EngineR {
         break;
       }
       case E_Transform: {
+        OAK_SCOPE(PS_H_TRANSFORM);
         const uint32_t id = (F.vlo & V_TRANSFORM) ? transform_id(F) : ((absp(F) << 3) | order0(F));
         S.vlo |= V_TRANSFORM;
         set_transform_id(S, id);
@@ -850,19 +858,24 @@ struct EngineR {
         set_amoves(S, nm);
         break;
       }
-      case E_Bide:
+      case E_Bide: {
+        OAK_SCOPE(PS_H_BIDE);
         S.vlo |= V_BIDE;
         set_vstate(S, 0);
         set_attacks(S, rng_range(2, 4));
         dset(S, 25, 3, 1);
         act_set(true, AC_ATTACKING, 2, OBS_STARTED);
         break;
-      case E_Sleep:
+      }
+      case E_Sleep: {
+        OAK_SCOPE(PS_H_SLEEP);
         set_status(F, rng_range(1, 8));
         dset(F, 0, 3, 1);
         act_set(false, AC_SLEEP, 2, OBS_STARTED);
         break;
+      }
       case E_Disable: {
+        OAK_SCOPE(PS_H_DISABLE);
         uint32_t n = 0, packed = 0;
         for (uint32_t i = 1; i <= 4; ++i) {
           const uint32_t ms = active_move(F, i);
@@ -878,7 +891,7 @@ struct EngineR {
         break;
       }
       default: break;
-      }
+      } }
     } else {
       // -- stage 4: damage ---------------------------------------------------------------------------
       OAK_SCOPE(PS_DAMAGE);

@@ -1228,8 +1228,10 @@ static int leaf_eval_impl(oakgpu_ctx *ctx, oakgpu_net *net, const uint8_t *battl
   static const int embed_impl = getenv("OAKGPU_EMBED_IMPL") ? atoi(getenv("OAKGPU_EMBED_IMPL")) : 3;
   hipEvent_t *tev = (hipEvent_t *)oakgpu_ctx_timing_events(ctx); // diagnostic only (oakgpu_set_kernel_timing)
   {
+    static const int kinds = getenv("OAKGPU_EMBED_KINDS") ? atoi(getenv("OAKGPU_EMBED_KINDS")) : 3; // diagnostics: 1 party, 2 actives
     for (int kind = 0; kind < 2; ++kind) {
       if (tev) (void)hipEventRecord(tev[kind], stream);
+      if (!((kinds >> kind) & 1)) continue;
       oak::EmbedTileArgs ta{D, battles, durations, n, emb, kind};
       const uint32_t ntiles = (n * (kind ? 2u : 10u) + oak::ET - 1) / oak::ET;
       if (embed_impl == 2) { // second implementation: first-layer rows gathered from L2 (A/B)

@@ -30,11 +30,12 @@ buf = (C.c_ulonglong * 16)()
 lib.oakgpu_leaf_profile.argtypes = [C.c_void_p, C.c_int]
 _lib.check(lib.oakgpu_leaf_eval_dev(h, net.handle, P(mid), P(dmid), n, P(values), None))
 torch.cuda.synchronize()
-for kind, env in (("both kinds", None),):
+for kind, env in ((os.environ.get("OAKGPU_EMBED_KINDS", "both kinds"), None),):
     lib.oakgpu_leaf_profile(buf, 1)
     _lib.check(lib.oakgpu_leaf_eval_dev(h, net.handle, P(mid), P(dmid), n, P(values), None))
     torch.cuda.synchronize()
     lib.oakgpu_leaf_profile(buf, 0)
+    print("== kinds", kind)
     names = ["barrier(prev tile)", "stage Bs + barrier", "issue prefetch", "1a feature lists", "1c first layer", "barrier", "2 mfma", "3 scatter"]
     print("k_mainnet_direct wave 0: outside compute %d cycles, inside compute (MFMA streams) %d cycles" % (buf[8], buf[9]))
     tot = sum(buf[i] for i in range(8))

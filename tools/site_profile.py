@@ -19,7 +19,8 @@ from oak_amd.engine import Context  # noqa: E402
 
 NAMES = ["refill", "step", "legal_draw", "order", "exec_move", "switch_in", "before_move", "exec_selected_pre",
          "run_move", "gates_hit", "status_bodies", "damage", "secondary_apply", "faint_residual", "publish",
-         "calc_damage", "apply_hits", "damage_tail"]
+         "calc_damage", "apply_hits", "damage_tail", "heavy_switch", "h_conversion", "h_haze", "h_heal", "h_mimic", "h_poison",
+         "h_substitute", "h_transform", "h_bide", "h_sleep", "h_disable"]
 ctx = Context(0)
 lib, h = ctx.lib, ctx.handle
 dev = torch.device("cuda", 0)
