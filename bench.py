@@ -329,7 +329,9 @@ def leaf_records(args, torch, dev, rank, local_rank, world, dist, which=("leaf",
     lib, h = ctx.lib, ctx.handle
     seed0 = oakdist.lane_seed0(SEED0, n * world, rank, world)
     _lib.check(lib.oakgpu_random_ou_battles_dev(h, C.c_uint64(seed0), n, P(battles), P(durations), P(prng), P(rin)))
+    ctx.synchronize()   # the generator ran on the context's stream; torch copies below run on torch's
     b0, d0, p0, r0 = battles.clone(), durations.clone(), prng.clone(), rin.clone()   # turn-0 batch (config3 episodes restart from it)
+    torch.cuda.synchronize(dev)
     _lib.check(lib.oakgpu_rollout_dev(h, P(battles), P(durations), P(rin), P(prng), n, 20, 0, P(rout), P(steps_out),
                                       P(values), P(mid), P(dur_mid)))
     ctx.synchronize()
@@ -340,6 +342,10 @@ def leaf_records(args, torch, dev, rank, local_rank, world, dist, which=("leaf",
     main_f, emb_f = netfile.flops_per_leaf(256, 256)
     live = torch.zeros((), dtype=torch.int64, device=dev)
     turn = [0]
+    # configs[2] evaluates the SAME resident lanes every turn: the party-slot embeddings are cached by exact identity tags
+    # (oakgpu_leaf_eval_cached_dev, the GPU form of the reference's PokemonCache) -- buffers the caller keeps between calls
+    emb = torch.empty((n, 768), dtype=torch.float32, device=dev)
+    tags = torch.full((n, 10, 6), -1, dtype=torch.int32, device=dev)
 
     def leaf_step():
         _lib.check(lib.oakgpu_leaf_eval_dev(h, net.handle, P(mid), P(dur_mid), n, P(values), None))
@@ -351,7 +357,7 @@ def leaf_records(args, torch, dev, rank, local_rank, world, dist, which=("leaf",
         turn[0] += 1
         _lib.check(lib.oakgpu_rollout_dev(h, P(battles), P(durations), P(rin), P(prng), n, 1, 0, P(rin), P(steps_out),
                                           P(values), P(battles), P(durations)))
-        _lib.check(lib.oakgpu_leaf_eval_dev(h, net.handle, P(battles), P(durations), n, P(values), None))
+        _lib.check(lib.oakgpu_leaf_eval_cached_dev(h, net.handle, P(battles), P(durations), n, P(values), P(emb), P(tags)))
         with torch.cuda.stream(stream):
             live.add_(steps_out.sum(dtype=torch.int64))
 
@@ -431,12 +437,15 @@ def leaf_records(args, torch, dev, rank, local_rank, world, dist, which=("leaf",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": elapsed / K * 1e3, "higher_is_better": True,
             "scaling": "weak", "dtype": "f32", "data": "synthetic",
             "config": {"workload": "configs[2]: batch=65536 random OU team pairs per GPU; every step = one random turn-step of the "
-                                   "whole batch (in place) + value_inference (768-256-256-256-1) of every lane; 40-turn episodes",
+                                   "whole batch (in place) + value_inference (768-256-256-256-1) of every lane, party-slot embeddings cached by identity "
+                                   "tags (PokemonCache analogue); 40-turn episodes",
                        "batch_per_gpu": n, "leaf_evals_per_s": n * world * K / elapsed,
                        "live_lane_fraction": steps_done / (n * world * K)},
-            "roofline": {"bound": "mfma", "kernel": "oak::k_rollout_queue (1 step) + oak::k_embed_lds (x2) + oak::k_mainnet_direct",
+            "roofline": {"bound": "mfma", "kernel": "oak::k_rollout_queue (1 step) + oak::k_party_tags + oak::k_embed_lds (changed party slots; "
+                                                     "actives) + oak::k_mainnet_direct",
                          "achieved": achieved, "peak": 157.3, "unit": "TFLOP/s", "frac": achieved / 157.3, "traffic": None,
-                         "avg_step_ms": avg_s * 1e3, "algorithmic_flop_per_leaf": main_f + emb_f},
+                         "avg_step_ms": avg_s * 1e3, "algorithmic_flop_per_leaf": main_f + emb_f,
+                         "note": "algorithmic FLOP count every embedding (SURVEY 8d: recomputed per leaf); the cache skips the unchanged party slots"},
         }
         if rank == 0 and world == 1 and not args.no_cpu_baseline:
             rec["cpu_baseline"] = cpu_baseline_config3(path, n)

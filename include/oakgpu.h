@@ -320,6 +320,17 @@ int oakgpu_leaf_eval_dev(oakgpu_ctx *ctx, oakgpu_net *net, const uint8_t *battle
 int oakgpu_leaf_eval(oakgpu_ctx *ctx, oakgpu_net *net, const uint8_t *battles, const uint8_t *durations, uint32_t n,
                      float *values, float *embedding_out);
 
+/* value_inference for a RESIDENT batch evaluated again and again (BASELINE configs[2]: every lane, every turn), with the
+ * party-slot embeddings cached like NN::Battle::PokemonCache (nn/battle/cache.h:18-131, key encode/battle/key.h:65-71):
+ * the caller keeps `embedding` (n x in_dim floats) and `slot_tags` (n x 10 x OAKGPU_SLOT_TAG_WORDS u32) between calls; a
+ * bench slot is re-embedded only when what its embedding depends on changed -- the stored Pokemon's bytes with PP reduced
+ * to has-PP bits and the status to its encoder index, compared exactly (no hashing).  Fill slot_tags with 0xFF bytes before
+ * the first call; after that nothing needs resetting, not even when other battles are put into the lanes (a tag holds the
+ * slot's whole identity).  Results are identical to oakgpu_leaf_eval_dev. */
+#define OAKGPU_SLOT_TAG_WORDS 6
+int oakgpu_leaf_eval_cached_dev(oakgpu_ctx *ctx, oakgpu_net *net, const uint8_t *battles, const uint8_t *durations, uint32_t n,
+                                float *values, float *embedding, uint32_t *slot_tags);
+
 /* value_policy_inference (network.h:102-123): value plus, per side, the logits of the <= 9 legal choices
  * (choices n x 9 bytes + counts n bytes per side, as produced by oakgpu_choices*; logits n x 9 floats,
  * entries past the count are 0).  Choice -> policy row via Encode::Battle::Policy::get_index

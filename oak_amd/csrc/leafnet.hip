@@ -159,7 +159,11 @@ struct EmbedTileArgs {
   uint32_t n;
   float *emb;
   int kind; // 0: party slots (10 per leaf), 1: actives (2 per leaf)
+  // LIST mode of the party-slot pass (oakgpu_leaf_eval_cached*): only the slots k_party_tags found changed
+  const struct PartyWork *work;
+  const uint32_t *work_count;
 };
+struct PartyWork { uint32_t item, pk[6], sleep; }; // item = leaf * 10 + q; the slot's stored Pokemon; its public sleep turns
 
 __global__ __launch_bounds__(EMB_BLOCK) void k_embed_tile(EmbedTileArgs a) {
   extern __shared__ __align__(16) float lds_f[];
@@ -347,8 +351,9 @@ template <bool ACT> struct ELayout {
 __device__ __forceinline__ uint32_t active_lds_slot(uint32_t r) { return r < 45 ? r : r < 234 ? r - 164 : r - 328; }
 __device__ __forceinline__ uint32_t active_lds_row(uint32_t s) { return s < 45 ? s : s < 70 ? s + 164 : s + 328; }
 
-template <bool ACT>
+template <bool ACT, bool LIST = false>
 __global__ __launch_bounds__(EL_BLOCK) void k_embed_lds(EmbedTileArgs a) {
+  static_assert(!(ACT && LIST), "the work-list form exists for the party-slot pass only");
   extern __shared__ __align__(16) float lds_f[];
   using L = ELayout<ACT>;
   const NetDev &N = a.net;
@@ -399,7 +404,7 @@ __global__ __launch_bounds__(EL_BLOCK) void k_embed_lds(EmbedTileArgs a) {
   }
   const float obias = (mfma_wave && nb * 32 + r32 < out_dim) ? b1[nb * 32 + r32] : 0.0f;
   const uint32_t per_leaf = ACT ? 2 : 10;
-  const uint32_t items = a.n * per_leaf;
+  const uint32_t items = LIST ? *a.work_count : a.n * per_leaf;
   const uint32_t ntiles = (items + ET - 1) / ET;
   // The battles a tile touches are staged in LDS; the NEXT tile's are already on their way in registers while
   // this one is processed (one workgroup per CU: nothing else would hide that latency).
@@ -412,6 +417,11 @@ __global__ __launch_bounds__(EL_BLOCK) void k_embed_lds(EmbedTileArgs a) {
     return last_leaf - first_leaf + 1;
   };
   auto prefetch = [&](uint32_t tile) {
+    if constexpr (LIST) { // the tile's 64 work records (8 dwords each) instead of whole battles
+      const uint32_t g = tile * ET + (threadIdx.x >> 3);
+      pf[0] = (tile < ntiles && g < items) ? ((const uint32_t *)a.work)[(size_t)g * 8 + (threadIdx.x & 7)] : 0;
+      return;
+    }
     uint32_t first_leaf;
     const uint32_t nl = tile < ntiles ? tile_leaves(tile, first_leaf) : 0;
 #pragma unroll
@@ -424,6 +434,7 @@ __global__ __launch_bounds__(EL_BLOCK) void k_embed_lds(EmbedTileArgs a) {
     }
   };
   auto stage = [&]() { // prefetched registers -> LDS image of the tile's battles
+    if constexpr (LIST) { Bs[threadIdx.x] = pf[0]; return; }
 #pragma unroll
     for (uint32_t u = 0; u < PF; ++u) { const uint32_t i = threadIdx.x + u * EL_BLOCK; if (i < (uint32_t)L::NLEAF * 98) Bs[i] = pf[u]; }
   };
@@ -452,17 +463,19 @@ __global__ __launch_bounds__(EL_BLOCK) void k_embed_lds(EmbedTileArgs a) {
       const uint32_t g = tile * ET + i;
       uint32_t doff = 0xFFFFFFFFu, dead_off = 0xFFFFFFFFu, cntL = 0, cntG = 0;
       if (mine && g < items) {
-        const uint32_t leaf = g / per_leaf, q = g - leaf * per_leaf;
+        const uint32_t *rec = Bs + i * 8; // LIST: this item's work record
+        const uint32_t gi = LIST ? rec[0] : g;
+        const uint32_t leaf = gi / per_leaf, q = gi - leaf * per_leaf;
         const uint32_t side = ACT ? q : q / 5, slot = ACT ? 0 : 1 + (q - side * 5);
-        const uint32_t *lb = Bs + (leaf - first_leaf) * 98;
+        const uint32_t *lb = Bs + (LIST ? 0 : (leaf - first_leaf) * 98);
         const uint32_t *sb = lb + side * 46;
-        const uint32_t dur = lb[96 + side];
-        const uint32_t o0 = sb[44], o1 = sb[45];
-        const uint32_t id = slot < 4 ? (o0 >> (8 * slot)) & 0xFF : (o1 >> (8 * (slot - 4))) & 0xFF;
+        const uint32_t dur = LIST ? rec[7] << (3 * slot) : lb[96 + side]; // LIST: only the slot's sleep turns are needed
+        const uint32_t o0 = LIST ? 0 : sb[44], o1 = LIST ? 0 : sb[45];
+        const uint32_t id = LIST ? 1 : slot < 4 ? (o0 >> (8 * slot)) & 0xFF : (o1 >> (8 * (slot - 4))) & 0xFF;
         const uint32_t dd = leaf * N.emb_dim + side * N.side_dim + (ACT ? 0 : (1 + N.a_out) + (slot - 1) * (1 + N.p_out));
         uint32_t pk0 = 0, pk1 = 0, pk2 = 0, pk3 = 0, pk4 = 0, pk5 = 0, hp = 0;
         if (id != 0) {
-          const uint32_t *pk = sb + 6 * (id - 1);
+          const uint32_t *pk = LIST ? rec + 1 : sb + 6 * (id - 1);
           pk0 = pk[0]; pk1 = pk[1]; pk2 = pk[2]; pk3 = pk[3]; pk4 = pk[4]; pk5 = pk[5];
           hp = pk4 >> 16;
         }
@@ -615,6 +628,96 @@ __global__ __launch_bounds__(EL_BLOCK) void k_embed_lds(EmbedTileArgs a) {
     EL_MARK(7);
   }
   EL_FLUSH();
+}
+
+// ---- party-slot embedding cache (the GPU form of NN::Battle::PokemonCache, cpp/include/nn/battle/cache.h:18-131) ------------
+// A bench Pokemon's embedding depends only on its stored bytes minus hp, with the PP bytes reduced to "has PP" bits and the
+// status reduced to its encoder index (Encode::Battle::pokemon_key, encode/battle/key.h:65-71) -- the reference fills 240
+// embeddings per Pokemon once per search and looks them up.  For a RESIDENT batch that is evaluated again and again
+// (BASELINE configs[2]: a leaf evaluation of every lane every turn) the analogue is: the caller keeps the batch's embedding
+// buffer and a TAG per (leaf, bench slot) -- the canonicalised 24 stored bytes, exact, no hashing -- and only the slots
+// whose tag changed since the last call are recomputed.  k_party_tags does the comparison for all n x 10 slots (one lane
+// each), refreshes the slot's hp ratio (hp is not part of the embedding input, network.h:153-160), zeroes the block of a
+// slot that became empty / fainted and appends the changed live slots -- with their Pokemon bytes -- to a work list that
+// k_embed_lds<party, LIST> then embeds.
+constexpr uint32_t TAG_DEAD = 0xFFFFFFFEu, TAG_WORDS = 6;
+constexpr int TAG_R = 8; // slots per lane: ONE atomic on the work counter per 2048 slots (one per wave serialised 10,000 of them)
+__global__ __launch_bounds__(256) void k_party_tags(NetDev N, const uint8_t *battles, const uint8_t *durations, uint32_t n, float *emb,
+                                                    uint32_t *tags, PartyWork *work, uint32_t *work_count) {
+  __shared__ uint32_t cnt[TAG_R * 4 + 1];
+  const uint32_t lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+  uint32_t pk[TAG_R][6], sleep[TAG_R];
+  uint32_t changed = 0; // bit r: the slot of round r is live and its tag changed
+#pragma unroll
+  for (int r = 0; r < TAG_R; ++r) {
+    const uint32_t item = (blockIdx.x * TAG_R + r) * 256 + threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) pk[r][k] = 0;
+    sleep[r] = 0;
+    bool live_change = false;
+    if (item < n * 10) {
+      const uint32_t leaf = item / 10, q = item - leaf * 10, side = q / 5, slot = 1 + (q - side * 5);
+      const uint32_t *sb = (const uint32_t *)battles + (size_t)leaf * 96 + side * 46;
+      const uint32_t dur = ((const uint32_t *)durations)[(size_t)leaf * 2 + side];
+      const uint32_t o0 = sb[44], o1 = sb[45];
+      const uint32_t id = slot < 4 ? (o0 >> (8 * slot)) & 0xFF : (o1 >> (8 * (slot - 4))) & 0xFF;
+      const uint32_t doff = leaf * N.emb_dim + side * N.side_dim + (1 + N.a_out) + (slot - 1) * (1 + N.p_out);
+      uint32_t hp = 0;
+      if (id != 0) {
+        const uint32_t *p = sb + 6 * (id - 1);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) pk[r][k] = p[k];
+        hp = pk[r][4] >> 16;
+      }
+      sleep[r] = (dur >> (3 * slot)) & 7;
+      uint32_t c[TAG_WORDS];
+      if (hp == 0) {
+#pragma unroll
+        for (uint32_t k = 0; k < TAG_WORDS; ++k) c[k] = TAG_DEAD;
+      } else { // canonical form: everything Encode::Battle::Pokemon::write reads (battle.h:197-214), nothing else
+        const uint32_t st = pk[r][5] & 0xFF;
+        const uint32_t skey = st ? status_index(st, sleep[r]) + 1 : 0;
+        c[0] = pk[r][0];                                                                   // hp max | atk
+        c[1] = pk[r][1];                                                                   // def | spe
+        c[2] = (pk[r][2] & 0x00FFFFFFu) | ((pk[r][2] >> 24) ? 1u << 24 : 0u);                // spc | move 1 id | has-pp 1
+        c[3] = (pk[r][3] & 0x00FF00FFu) | (((pk[r][3] >> 8) & 0xFF) ? 1u << 8 : 0u) | ((pk[r][3] >> 24) ? 1u << 24 : 0u); // ids 2, 3 | has-pp 2, 3
+        c[4] = (pk[r][4] & 0xFFu) | (((pk[r][4] >> 8) & 0xFF) ? 1u << 8 : 0u) | (skey << 16); // id 4 | has-pp 4 | status index + 1
+        c[5] = pk[r][5] & 0xFFFFFF00u;                                                     // species | types | level
+      }
+      uint32_t *t = tags + (size_t)item * TAG_WORDS;
+      bool same = true;
+#pragma unroll
+      for (uint32_t k = 0; k < TAG_WORDS; ++k) same = same && t[k] == c[k];
+      if (!same) {
+#pragma unroll
+        for (uint32_t k = 0; k < TAG_WORDS; ++k) t[k] = c[k];
+        if (hp == 0) { for (int o = 0; o <= N.p_out; ++o) emb[(size_t)doff + o] = 0.0f; } // network.h:153-160: empty / fainted slot
+        else live_change = true;
+      }
+      if (hp != 0) emb[doff] = (float)hp / (float)(pk[r][0] & 0xFFFF); // the hp ratio changes without the tag changing
+    }
+    const uint64_t mask = __ballot(live_change);
+    if (lane == 0) cnt[r * 4 + wib] = (uint32_t)__popcll(mask);
+    changed |= live_change ? 1u << r : 0u;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) { // exclusive prefix over the block's (round, wave) counts + ONE atomic for the block
+    uint32_t run = 0;
+    for (int k = 0; k < TAG_R * 4; ++k) { const uint32_t c = cnt[k]; cnt[k] = run; run += c; }
+    cnt[TAG_R * 4] = run ? atomicAdd(work_count, run) : 0u;
+  }
+  __syncthreads();
+  const uint32_t base = cnt[TAG_R * 4];
+#pragma unroll
+  for (int r = 0; r < TAG_R; ++r) {
+    const bool mine = (changed >> r) & 1;
+    const uint64_t mask = __ballot(mine);
+    if (mine) {
+      const uint32_t item = (blockIdx.x * TAG_R + r) * 256 + threadIdx.x;
+      PartyWork w{item, {pk[r][0], pk[r][1], pk[r][2], pk[r][3], pk[r][4], pk[r][5]}, sleep[r]};
+      work[base + cnt[r * 4 + wib] + (uint32_t)__popcll(mask & ((1ull << lane) - 1))] = w;
+    }
+  }
 }
 
 // ---- K3: main net on fp32 MFMA ------------------------------------------------------------------
@@ -1200,6 +1303,8 @@ int oakgpu_leaf_set_lds_limits(void) { // per DEVICE (hipFuncSetAttribute applie
   if (e != hipSuccess) return oakgpu_fail_hip((int)e, "hipFuncSetAttribute(k_embed_tile)");
   e = hipFuncSetAttribute((const void *)oak::k_embed_lds<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)oak::ELayout<false>::BYTES);
   if (e != hipSuccess) return oakgpu_fail_hip((int)e, "hipFuncSetAttribute(k_embed_lds<party>)");
+  e = hipFuncSetAttribute((const void *)oak::k_embed_lds<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)oak::ELayout<false>::BYTES);
+  if (e != hipSuccess) return oakgpu_fail_hip((int)e, "hipFuncSetAttribute(k_embed_lds<party, list>)");
   e = hipFuncSetAttribute((const void *)oak::k_embed_lds<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)oak::ELayout<true>::BYTES);
   if (e != hipSuccess) return oakgpu_fail_hip((int)e, "hipFuncSetAttribute(k_embed_lds<active>)");
   e = hipFuncSetAttribute((const void *)oak::k_policy, hipFuncAttributeMaxDynamicSharedMemorySize, oak::POLICY_LDS_LIMIT);
@@ -1212,7 +1317,7 @@ int oakgpu_leaf_set_lds_limits(void) { // per DEVICE (hipFuncSetAttribute applie
 }
 
 static int leaf_eval_impl(oakgpu_ctx *ctx, oakgpu_net *net, const uint8_t *battles, const uint8_t *durations, uint32_t n,
-                          float *values, float *embedding_out, const oak::PolicyArgs *pol) {
+                          float *values, float *embedding_out, const oak::PolicyArgs *pol, uint32_t *slot_tags = nullptr) {
   if (!ctx || !net) return oakgpu_fail_msg("oakgpu_leaf_eval_dev: null ctx/net");
   if (n == 0) return 0;
   if (!battles || !durations || !values) return oakgpu_fail_msg("oakgpu_leaf_eval_dev: null required pointer");
@@ -1232,8 +1337,21 @@ static int leaf_eval_impl(oakgpu_ctx *ctx, oakgpu_net *net, const uint8_t *battl
     for (int kind = 0; kind < 2; ++kind) {
       if (tev) (void)hipEventRecord(tev[kind], stream);
       if (!((kinds >> kind) & 1)) continue;
-      oak::EmbedTileArgs ta{D, battles, durations, n, emb, kind};
+      oak::EmbedTileArgs ta{D, battles, durations, n, emb, kind, nullptr, nullptr};
       const uint32_t ntiles = (n * (kind ? 2u : 10u) + oak::ET - 1) / oak::ET;
+      if (kind == 0 && slot_tags) { // cached party-slot pass: tag comparison, then only the changed slots (work list)
+        uint8_t *ws = (uint8_t *)oakgpu_ctx_workspace(ctx, 2, (size_t)n * 10 * sizeof(oak::PartyWork) + 16);
+        if (!ws) return -1;
+        uint32_t *count = (uint32_t *)ws;
+        oak::PartyWork *work = (oak::PartyWork *)(ws + 16);
+        hipError_t me = hipMemsetAsync(count, 0, 4, stream);
+        if (me != hipSuccess) return oakgpu_fail_hip((int)me, "hipMemsetAsync(work count)");
+        hipLaunchKernelGGL(oak::k_party_tags, dim3((n * 10 + 256 * oak::TAG_R - 1) / (256 * oak::TAG_R)), dim3(256), 0, stream, D, battles, durations, n, emb, slot_tags, work, count);
+        ta.work = work;
+        ta.work_count = count;
+        hipLaunchKernelGGL((oak::k_embed_lds<false, true>), dim3(ntiles < 256 ? ntiles : 256), dim3(oak::EL_BLOCK), oak::ELayout<false>::BYTES, stream, ta);
+        continue;
+      }
       if (embed_impl == 2) { // second implementation: first-layer rows gathered from L2 (A/B)
         const int out_pad = ((kind ? D.a_out : D.p_out) + 31) & ~31;
         const size_t lds = (size_t)(oak::ET * oak::EHP + out_pad * oak::EHP + 4 * 128 + 2 * oak::ET + (kind ? 34 : 9) * 98) * 4;
@@ -1283,6 +1401,12 @@ int oakgpu_leaf_profile(unsigned long long *out, int reset) { // profile build o
 int oakgpu_leaf_eval_dev(oakgpu_ctx *ctx, oakgpu_net *net, const uint8_t *battles, const uint8_t *durations, uint32_t n,
                          float *values, float *embedding_out) {
   return leaf_eval_impl(ctx, net, battles, durations, n, values, embedding_out, nullptr);
+}
+
+int oakgpu_leaf_eval_cached_dev(oakgpu_ctx *ctx, oakgpu_net *net, const uint8_t *battles, const uint8_t *durations, uint32_t n,
+                                float *values, float *embedding, uint32_t *slot_tags) {
+  if (!embedding || !slot_tags) return oakgpu_fail_msg("oakgpu_leaf_eval_cached_dev: the persistent embedding and tag buffers are required");
+  return leaf_eval_impl(ctx, net, battles, durations, n, values, embedding, nullptr, slot_tags);
 }
 
 int oakgpu_leaf_eval_policy_dev(oakgpu_ctx *ctx, oakgpu_net *net, const uint8_t *battles, const uint8_t *durations, uint32_t n,

@@ -839,7 +839,7 @@ struct oakgpu_ctx {
   struct Block { void *p; size_t cap; };
   std::vector<Block> stage; // staging buffers of the host-pointer entry points (oakgpu_internal.h)
   size_t stage_cursor;
-  Block ws[2];              // leaf-evaluator workspaces
+  Block ws[3];              // leaf-evaluator workspaces: embeddings, policy activations, party work list
   int timing;               // oakgpu_set_kernel_timing
   hipEvent_t tev[4];
   bool tev_valid;
@@ -876,7 +876,7 @@ static void *grow_block(oakgpu_ctx *c, oakgpu_ctx::Block &b, size_t bytes) {
   return b.p;
 }
 void **oakgpu_ctx_timing_events(oakgpu_ctx *c) { return c->timing && c->tev_valid ? (void **)c->tev : nullptr; }
-void *oakgpu_ctx_workspace(oakgpu_ctx *c, int slot, size_t bytes) { return grow_block(c, c->ws[slot & 1], bytes ? bytes : 1); }
+void *oakgpu_ctx_workspace(oakgpu_ctx *c, int slot, size_t bytes) { return grow_block(c, c->ws[slot % 3], bytes ? bytes : 1); }
 void oakgpu_stage_begin(oakgpu_ctx *c) { c->stage_cursor = 0; }
 void oakgpu_stage_end(oakgpu_ctx *c) { (void)hipStreamSynchronize(c->stream); }
 void *oakgpu_stage_get(oakgpu_ctx *c, size_t bytes) {
@@ -946,7 +946,7 @@ int oakgpu_create(oakgpu_ctx **out, int device) {
   c->h_table = c->d_table = nullptr;
   c->table_next = 0;
   c->stage_cursor = 0;
-  c->ws[0] = c->ws[1] = oakgpu_ctx::Block{nullptr, 0};
+  c->ws[0] = c->ws[1] = c->ws[2] = oakgpu_ctx::Block{nullptr, 0};
   c->timing = 0;
   c->tev_valid = false;
   c->rounds_auto = 1;
@@ -1092,7 +1092,8 @@ static int launch_group(oakgpu_ctx *c, const oak::BatchDesc *descs, uint32_t cou
   if (saturated) waves = resident;
   // regrouping rounds pay off while the launch leaves SIMDs idle in its tail; a launch that saturates the device
   // for most of its life (a group of batches) runs as a single dispatch (measured: DESIGN.md 3)
-  const int rounds = (c->suspend_below > 0 && waves >= 8 && !(saturated && c->rounds_auto)) ? c->rounds : 1;
+  // ... and so does a launch capped at a few steps (stepping a resident batch turn by turn): there is no tail to regroup
+  const int rounds = (c->suspend_below > 0 && waves >= 8 && !(c->rounds_auto && (saturated || max_steps <= 64))) ? c->rounds : 1;
   if (rounds > 1 && c->scratch_n < total) {
     if (c->d_scratch) { HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipFree(c->d_scratch)); c->d_scratch = nullptr; }
     HIPCHK(hipMalloc((void **)&c->d_scratch, (size_t)total * (384 + 8 + 4 + 4) + (((size_t)total + 15) & ~(size_t)15)));

@@ -7,7 +7,7 @@ int oakgpu_fail_msg(const char *what);                 // records the message, r
 int oakgpu_ctx_device(const oakgpu_ctx *ctx);
 void *oakgpu_ctx_stream(const oakgpu_ctx *ctx);        // hipStream_t
 int oakgpu_ctx_enter(oakgpu_ctx *ctx);                 // hipSetDevice(ctx->device): first line of every entry point that launches or allocates
-// Per-context device workspaces (slot 0: battle embeddings, 1: policy activations): grow-only, one per context = one
+// Per-context device workspaces (slot 0: battle embeddings, 1: policy activations, 2: party-slot work list): grow-only, one per context = one
 // per stream, so two contexts evaluating the same network never share scratch memory.  nullptr on failure (error recorded).
 void *oakgpu_ctx_workspace(oakgpu_ctx *ctx, int slot, size_t bytes);
 // Staging buffers of the host-pointer entry points: a grow-only cache owned by the context (slot k of a call = the k-th

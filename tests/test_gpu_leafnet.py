@@ -207,3 +207,44 @@ def test_two_contexts_share_one_network(gpu_ctx):
             assert abs(float(v2[i]) - float(NN.value_inference(onet, b2[i], d2[i]))) <= TOL
     net.close()
     other.close()
+
+
+def test_cached_leaf_eval_equals_plain_eval_over_a_resident_batch(gpu_ctx, tmp_path):
+    """oakgpu_leaf_eval_cached_dev (party-slot embeddings cached by exact identity tags, the GPU form of PokemonCache): a
+    resident batch stepped turn by turn on the device -- values AND embeddings are bit-identical to the uncached evaluator
+    every turn; then other battles are loaded into the same lanes WITHOUT resetting the tags, and it is still exact."""
+    from hipmem import Dev
+    from oak_amd import _lib
+    from oak_amd.engine import Network
+    path = str(tmp_path / "c3.battle.net")
+    NN.write_random_net(path, hidden=256, value_hidden=256, seed=7)
+    net = Network(gpu_ctx, path=path)
+    lib, h = gpu_ctx.lib, gpu_ctx.handle
+    n = 3001
+    b, d, p, r = O.make_random_ou_batch(n, seed0=0xCAC4E)
+    gb, gd, gp, gr = Dev(b), Dev(d), Dev(p), Dev(r)
+    steps, vals = Dev(np.zeros(n, np.uint32)), Dev(np.zeros(n, np.float32))
+    v_plain, v_cached = Dev(np.zeros(n, np.float32)), Dev(np.zeros(n, np.float32))
+    e_plain, e_cached = Dev(np.zeros((n, 768), np.float32)), Dev(np.zeros((n, 768), np.float32), fill=0x7F)   # garbage: every slot must get written
+    tags = Dev(np.zeros((n, 10, 6), np.uint32), fill=0xFF)
+    for turn in range(45):
+        if turn == 30:      # new battles in the same lanes, tags NOT reset: a tag is the slot's whole identity
+            b2, d2, p2, r2 = O.make_random_ou_batch(n, seed0=0xBEEF00)
+            gb.put(b2); gd.put(d2); gp.put(p2); gr.put(r2)
+        _lib.check(lib.oakgpu_rollout_dev(h, gb.p, gd.p, gr.p, gp.p, n, 1, 0, gr.p, steps.p, vals.p, gb.p, gd.p))   # one turn, in place
+        _lib.check(lib.oakgpu_leaf_eval_dev(h, net.handle, gb.p, gd.p, n, v_plain.p, e_plain.p))
+        _lib.check(lib.oakgpu_leaf_eval_cached_dev(h, net.handle, gb.p, gd.p, n, v_cached.p, e_cached.p, tags.p))
+        gpu_ctx.synchronize()
+        ep, ec = e_plain.host(), e_cached.host()
+        bad = np.nonzero((ep != ec).any(axis=1))[0]
+        assert bad.size == 0, (turn, int(bad[0]), np.nonzero(ep[bad[0]] != ec[bad[0]])[0][:8])
+        assert (v_plain.host() == v_cached.host()).all(), turn
+    # and both agree with the oracle on the final states
+    fb, fd = gb.host(), gd.host()
+    onet = NN.Net(path)
+    vc = v_cached.host()
+    for i in range(0, n, 97):
+        assert abs(float(vc[i]) - float(NN.value_inference(onet, fb[i], fd[i]))) <= TOL
+    for x in (gb, gd, gp, gr, steps, vals, v_plain, v_cached, e_plain, e_cached, tags):
+        x.free()
+    net.close()
