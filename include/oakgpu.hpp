@@ -4,7 +4,12 @@
 //   OakGPU::Context            <- per-thread owner of device state (reference: per-thread Agent/Heap, util/search.h:17-64)
 //   OakGPU::Network            <- NN::Battle::Network (nn/battle/network.h:22-176): shape(), value_inference(batch)
 //   OakGPU::BatchedMonteCarlo  <- MCTS::MonteCarlo (mcts.h:21-23) + init_stats_and_rollout (mcts.h:448-496), batched
-//   OakGPU::TreeSearch         <- MCTS::Search::run (mcts.h:154-247): Node heap + joint UCB / PUCB, leaves batched on the GPU
+//   OakGPU::TreeSearch         <- MCTS::Search::run (mcts.h:154-247): Node heap + the five joint bandits, leaves batched on the GPU
+//   OakGPU::run                <- RuntimeSearch::run (util/search.h:66, search.cc:150-313): the Agent's strings pick everything
+//   OakGPU::solve_matrix       <- LRSNash::solve_fast as called at mcts.h:643-649 / pyoak.cc:394-426 (exact)
+//   OakGPU::SharedDeviceRollout<- benchmark.cc:23-31: n playouts from one root driven by ONE sequential std::mt19937
+//   OakGPU::Frames             <- Train::Battle::CompressedFrames (train/battle/compressed-frame.h:37-243)
+//   OakGPU::Exchange           <- the path's one collective: per-root means on the device + RCCL all-gather (no reference analogue)
 // Errors surface as std::runtime_error, like the reference's loaders (cpp/src/search.cc:81-146).
 #pragma once
 #include <cstdint>
@@ -51,6 +56,11 @@ struct RolloutResult {
 class BatchedMonteCarlo {
 public:
   explicit BatchedMonteCarlo(Context &ctx) : ctx_{ctx} {}
+  // Several independent batches (e.g. the leaf batches of many roots) drained by ONE launch through one playout queue:
+  // a group has one tail instead of one per batch.  Device pointers; asynchronous on the context's stream.
+  void rollout_group_dev(const std::vector<oakgpu_rollout_batch> &batches, bool prep = false, uint32_t max_steps = 1000) {
+    check(oakgpu_rollout_group_dev(ctx_.get(), batches.data(), static_cast<uint32_t>(batches.size()), max_steps, prep ? 1 : 0));
+  }
   // device_rng: one fast_prng state (8 bytes, util/random.h:67-133) per leaf, advanced in place.
   // prep = true performs run_root_iteration's re-seed + randomize_hidden_variables per leaf (mcts.h:254-259).
   RolloutResult rollout(const std::vector<Leaf> &leaves, std::vector<uint64_t> &device_rng, bool prep = false,
@@ -98,6 +108,14 @@ public:
     return values;
   }
 
+  // A RESIDENT batch evaluated every turn (device pointers): party-slot embeddings cached by exact identity tags, the GPU
+  // form of NN::Battle::PokemonCache (nn/battle/cache.h:18-131).  `embedding` (n x in_dim floats) and `slot_tags`
+  // (n x 10 x OAKGPU_SLOT_TAG_WORDS u32, initialised to 0xFF bytes) are the caller's, kept between calls.
+  void value_inference_cached_dev(const uint8_t *battles, const uint8_t *durations, uint32_t n, float *values, float *embedding,
+                                  uint32_t *slot_tags) {
+    check(oakgpu_leaf_eval_cached_dev(ctx_.get(), net_, battles, durations, n, values, embedding, slot_tags));
+  }
+
   oakgpu_net *get() const noexcept { return net_; }
 
 private:
@@ -120,6 +138,106 @@ public:
 
 private:
   Context &ctx_;
+};
+
+// RuntimeSearch::Agent (util/search.h:34-64) and RuntimeSearch::run: budget "4096" | "100ms" | "8s", bandit "ucb-1.0" |
+// "exp3-0.1-0.05" | ..., eval "mc" | "fp" | <.battle.net path>, matrix_ucb "" | "delay-interval-minimum-c".  Unparsable
+// strings throw std::runtime_error with the reference's texts (search.cc:200-307).
+struct Agent {
+  std::string budget{"4096"}, bandit{"ucb-1.0"}, eval{"mc"}, matrix_ucb{};
+  bool discrete{false}, table{false};
+};
+inline oakgpu_search_output run(Context &ctx, const Leaf &input, const Agent &agent, uint64_t seed, uint32_t batch = 0) {
+  const oakgpu_agent a{agent.budget.c_str(), agent.bandit.c_str(), agent.eval.c_str(), agent.matrix_ucb.c_str(), agent.discrete, agent.table};
+  oakgpu_search_output out{};
+  check(oakgpu_search_agent(ctx.get(), input.battle, input.durations, input.result, &a, batch, seed, &out));
+  return out;
+}
+
+// Exact Nash equilibrium of an integer m x n (<= 9 x 9) matrix game, row player maximising: {p1, p2, value / discretize}.
+inline std::tuple<std::vector<double>, std::vector<double>, double> solve_matrix(const std::vector<int32_t> &payoffs, int m, int n,
+                                                                                 int discretize_factor = 256) {
+  if (m < 1 || n < 1 || payoffs.size() != static_cast<size_t>(m) * static_cast<size_t>(n)) throw std::runtime_error{"oakgpu: payoff matrix shape"};
+  std::vector<double> p1(static_cast<size_t>(m)), p2(static_cast<size_t>(n));
+  double value = 0;
+  check(oakgpu_solve_matrix(payoffs.data(), m, n, discretize_factor, p1.data(), p2.data(), &value));
+  return {p1, p2, value};
+}
+
+// benchmark.cc:23-31 + mcts.h:250-263,448-496 on the device: `n` playouts from one root, every draw taken from ONE
+// std::mt19937{seed} in the reference's sequential order (playout i starts where playout i - 1 stopped).
+class SharedDeviceRollout {
+public:
+  explicit SharedDeviceRollout(Context &ctx) : ctx_{ctx} {}
+  RolloutResult run(const Leaf &root, uint32_t seed, uint32_t n, uint32_t max_steps = 100000, std::vector<uint8_t> *final_battles = nullptr) {
+    RolloutResult out{std::vector<float>(n), std::vector<uint32_t>(n), std::vector<uint8_t>(n)};
+    if (final_battles) final_battles->assign(size_t{n} * OAKGPU_BATTLE_SIZE, 0);
+    for (size_t draws = size_t{n} * 160 + 4096;; draws *= 2) { // grow the generator's output until n playouts fit
+      std::vector<uint64_t> stream(draws);
+      check(oakgpu_mt19937_fill(seed, 0, stream.data(), stream.size()));
+      uint64_t used = 0;
+      const int rc = oakgpu_rollout_shared_device(ctx_.get(), root.battle, root.durations, root.result, stream.data(), static_cast<uint32_t>(draws), n,
+                                                  max_steps, 1, out.result.data(), out.steps.data(), out.value.data(),
+                                                  final_battles ? final_battles->data() : nullptr, nullptr, nullptr, &used);
+      if (rc == 0) return out;
+      if (draws > (size_t{1} << 30) || std::string{oakgpu_last_error()}.find("too short") == std::string::npos) check(rc);
+    }
+  }
+
+private:
+  Context &ctx_;
+};
+
+// One game's `.battle.data` record under construction (CompressedFrames: battle after the opening update, one Update per
+// turn, the final result byte); bytes() serialises it in the reference's on-disk layout.
+class Frames {
+public:
+  explicit Frames(const uint8_t *first_battle) { std::memcpy(battle_, first_battle, OAKGPU_BATTLE_SIZE); }
+  void push(const oakgpu_search_output &o, uint8_t c1, uint8_t c2) { // Update{search_output, c1, c2} (compressed-frame.h:66-75)
+    oakgpu_frame_update u{};
+    u.m = o.m; u.n = o.n; u.c1 = c1; u.c2 = c2;
+    u.iterations = static_cast<uint32_t>(o.iterations);
+    u.empirical_value = o.empirical_value;
+    u.nash_value = o.nash_value;
+    for (int k = 0; k < 9; ++k) { u.p1_empirical[k] = o.p1_empirical[k]; u.p1_nash[k] = o.p1_nash[k]; u.p2_empirical[k] = o.p2_empirical[k]; u.p2_nash[k] = o.p2_nash[k]; }
+    updates_.push_back(u);
+  }
+  std::vector<uint8_t> bytes(uint8_t result) const {
+    std::vector<uint8_t> out(oakgpu_frames_size(updates_.data(), static_cast<uint32_t>(updates_.size())));
+    size_t written = 0;
+    check(oakgpu_frames_write(battle_, result, updates_.data(), static_cast<uint32_t>(updates_.size()), out.data(), out.size(), &written));
+    out.resize(written);
+    return out;
+  }
+
+private:
+  uint8_t battle_[OAKGPU_BATTLE_SIZE];
+  std::vector<oakgpu_frame_update> updates_;
+};
+
+// The path's one exchange step for root-parallel search sharded over the GPUs of a node (one process per GPU): reduce the
+// rank's leaf values to one mean per root on the device, then ONE ncclAllGather (RCCL over xGMI) of those means.
+class Exchange {
+public:
+  // id128: made by rank 0 with Exchange::unique_id() and handed to the other ranks out of band
+  Exchange(Context &ctx, const uint8_t *id128, int rank, int world) : ctx_{ctx} { check(oakgpu_comm_create(ctx_.get(), id128, rank, world, &comm_)); }
+  ~Exchange() { oakgpu_comm_destroy(comm_); }
+  Exchange(const Exchange &) = delete;
+  Exchange &operator=(const Exchange &) = delete;
+  static std::vector<uint8_t> unique_id() {
+    std::vector<uint8_t> id(128);
+    check(oakgpu_comm_unique_id(id.data()));
+    return id;
+  }
+  // device pointers, asynchronous on the context's stream: means[r] = mean(values[r * per_root ...]); all = world x roots
+  void root_means_all_gather_dev(const float *values, uint32_t roots, uint32_t per_root, float *means, float *all) {
+    check(oakgpu_segment_mean_dev(ctx_.get(), values, roots, per_root, means));
+    check(oakgpu_all_gather_dev(ctx_.get(), comm_, means, all, roots));
+  }
+
+private:
+  Context &ctx_;
+  oakgpu_comm *comm_{};
 };
 
 } // namespace OakGPU
