@@ -630,6 +630,173 @@ __global__ __launch_bounds__(EL_BLOCK) void k_embed_lds(EmbedTileArgs a) {
   EL_FLUSH();
 }
 
+// ---- K2, third form of the party-slot pass (the default): every wave is its own pipeline, no workgroup barrier per tile.
+// k_embed_lds runs five phases back to back per 64-item tile (feature lists with 8 of 64 lanes busy, first layer, barrier,
+// MFMA on four of its eight waves, scatter) because its first layer leaves each item's hidden row spread over a wave
+// (a lane owns two channels) and the MFMA wants it the other way round (a lane owns a row) -- so the rows go through an LDS
+// tile, and a second tile to overlap the phases does not fit next to 99 KB of weights.  Here a lane owns a ROW from the
+// start: lane (r, hh) of a wave computes, for item r of the wave's 32-item mini-tile, the 64 hidden channels k = 2j + hh --
+// exactly the A operand sequence of v_mfma_f32_32x32x2_f32 -- straight into registers, 16 channels at a time:
+//   first layer : the item's 13 fixed (row, value) pairs {bias, 5 stats, 4 move slots, status, 2 types; absent ones are
+//                 (row 0, value 0)}; per pair 4 ds_read_b128 of the lane's part of the de-interleaved weight row + 16 FMAs;
+//   second layer: 16 k-steps x 2 output blocks of MFMA with W1 in registers, accumulating over the four channel quarters;
+// so the activation tile, its barrier and the idle waves are gone, and the two waves of a SIMD overlap by themselves:
+// one sits in its MFMA block (the wave stalls, the matrix pipe runs) while the other reads LDS and issues FMAs.
+// LDS: 199 weight rows (198 + the bias as a row) x 132 floats, rows de-interleaved [even channels | odd channels] and
+// padded so that lanes on different rows spread over the banks (105 KB), + 5.6 KB per wave (staged battles, pair lists).
+constexpr int ER_BLOCK = 512, ER_WAVES = 8, ER_ITEMS = 32, ER_RS = 132, ER_ROWS = 199, ER_PAIRS = 13;
+constexpr int ER_STAGE = 512;                                  // dwords of staged input per wave (5 leaves x 98, or 32 records x 8)
+constexpr int ER_WAVE_WORDS = ER_STAGE + 2 * ER_ITEMS * ER_PAIRS + 2 * ER_ITEMS; // + pair rows, pair values, dst offsets, hp ratios
+constexpr size_t ER_BYTES = (size_t)(ER_ROWS * ER_RS + ER_WAVES * ER_WAVE_WORDS) * 4;
+template <bool LIST>
+__global__ __launch_bounds__(ER_BLOCK) void k_embed_rows(EmbedTileArgs a) {
+  extern __shared__ __align__(16) float lds_f[];
+  const NetDev &N = a.net;
+  const int hidden = N.p_hidden, out_dim = N.p_out;
+  float *W0s = lds_f;
+  for (int i = threadIdx.x; i < ER_ROWS * 128; i += ER_BLOCK) { // row r, slot hh * 64 + j  <-  channel 2j + hh (row 198 = bias)
+    const int r = i >> 7, sl = i & 127, c = 2 * (sl & 63) + (sl >> 6);
+    W0s[r * ER_RS + sl] = c < hidden ? (r < 198 ? N.p_w0t[(size_t)r * hidden + c] : N.p_b0[c]) : 0.0f;
+  }
+  const uint32_t lane = threadIdx.x & 63, wib = threadIdx.x >> 6, r32 = lane & 31, hh = lane >> 5;
+  uint32_t *wl = (uint32_t *)(W0s + ER_ROWS * ER_RS) + wib * ER_WAVE_WORDS; // this wave's private LDS
+  uint32_t *Bs = wl, *prow = Bs + ER_STAGE, *dst_off = prow + 2 * ER_ITEMS * ER_PAIRS;
+  float *pval = (float *)(prow + ER_ITEMS * ER_PAIRS), *hp_ratio = (float *)(dst_off + ER_ITEMS);
+  // B operands of both 32-wide output blocks stay in registers: lane (r32, hh) holds W1[o = nb * 32 + r32][k = 2s + hh]
+  float bf0[64], bf1[64];
+#pragma unroll
+  for (int s2 = 0; s2 < 64; ++s2) {
+    const int c = 2 * s2 + (int)hh, o0 = (int)r32, o1 = 32 + (int)r32;
+    bf0[s2] = (o0 < out_dim && c < hidden) ? N.p_w1[(size_t)o0 * hidden + c] : 0.0f;
+    bf1[s2] = (o1 < out_dim && c < hidden) ? N.p_w1[(size_t)o1 * hidden + c] : 0.0f;
+  }
+  const float ob0 = (int)r32 < out_dim ? N.p_b1[r32] : 0.0f, ob1 = 32 + (int)r32 < out_dim ? N.p_b1[32 + r32] : 0.0f;
+  const uint32_t items = LIST ? *a.work_count : a.n * 10;
+  const uint32_t nmt = (items + ER_ITEMS - 1) / ER_ITEMS;
+  const uint32_t stride = gridDim.x * ER_WAVES;
+  // staged input of a mini-tile, prefetched one mini-tile ahead in registers (8 dwords per lane)
+  uint32_t pf[ER_STAGE / 64];
+  auto prefetch = [&](uint32_t mt) {
+#pragma unroll
+    for (int u = 0; u < ER_STAGE / 64; ++u) {
+      const uint32_t i = lane + 64 * u;
+      pf[u] = 0;
+      if (mt >= nmt) continue;
+      if (LIST) {
+        const uint32_t g = mt * ER_ITEMS + (i >> 3);
+        if (i < ER_ITEMS * 8 && g < items) pf[u] = ((const uint32_t *)a.work)[(size_t)g * 8 + (i & 7)];
+      } else {
+        const uint32_t first_leaf = (mt * ER_ITEMS) / 10;
+        uint32_t last_leaf = (mt * ER_ITEMS + ER_ITEMS - 1) / 10;
+        if (last_leaf >= a.n) last_leaf = a.n - 1;
+        const uint32_t l = i / 98, d = i - l * 98;
+        if (first_leaf + l <= last_leaf) pf[u] = d < 96 ? ((const uint32_t *)a.battles)[(size_t)(first_leaf + l) * 96 + d]
+                                                        : ((const uint32_t *)a.durations)[(size_t)(first_leaf + l) * 2 + (d - 96)];
+      }
+    }
+  };
+  __syncthreads(); // W0s staged (the only workgroup barrier of the kernel)
+  uint32_t mt = blockIdx.x * ER_WAVES + wib;
+  prefetch(mt);
+  EL_T0();
+  EL_MARK(0); // prologue (up to here, wave 0 of every workgroup)
+  for (; mt < nmt; mt += stride) {
+#pragma unroll
+    for (int u = 0; u < ER_STAGE / 64; ++u) Bs[lane + 64 * u] = pf[u];
+    __builtin_amdgcn_wave_barrier();
+    prefetch(mt + stride);
+    EL_MARK(1);
+    // ---- pair lists: lane r (hh = 0) encodes item r ----
+    if (hh == 0) {
+      const uint32_t g = mt * ER_ITEMS + r32;
+      uint32_t doff = 0xFFFFFFFFu, dead_off = 0xFFFFFFFFu;
+      uint32_t *pr = prow + r32 * ER_PAIRS;
+      float *pv = pval + r32 * ER_PAIRS;
+#pragma unroll
+      for (int e = 0; e < ER_PAIRS; ++e) { pr[e] = 0; pv[e] = 0.0f; }
+      if (g < items) {
+        const uint32_t *rec = Bs + r32 * 8;
+        const uint32_t gi = LIST ? rec[0] : g;
+        const uint32_t leaf = gi / 10, q = gi - leaf * 10, side = q / 5, slot = 1 + (q - side * 5);
+        const uint32_t first_leaf = (mt * ER_ITEMS) / 10;
+        const uint32_t *sb = Bs + (LIST ? 0 : (leaf - first_leaf) * 98) + side * 46;
+        const uint32_t sleep = LIST ? rec[7] : (Bs[(leaf - first_leaf) * 98 + 96 + side] >> (3 * slot)) & 7;
+        const uint32_t o0 = LIST ? 0 : sb[44], o1 = LIST ? 0 : sb[45];
+        const uint32_t id = LIST ? 1 : slot < 4 ? (o0 >> (8 * slot)) & 0xFF : (o1 >> (8 * (slot - 4))) & 0xFF;
+        const uint32_t dd = leaf * N.emb_dim + side * N.side_dim + (1 + N.a_out) + (slot - 1) * (1 + N.p_out);
+        uint32_t pk0 = 0, pk1 = 0, pk2 = 0, pk3 = 0, pk4 = 0, pk5 = 0, hp = 0;
+        if (id != 0) {
+          const uint32_t *pk = LIST ? rec + 1 : sb + 6 * (id - 1);
+          pk0 = pk[0]; pk1 = pk[1]; pk2 = pk[2]; pk3 = pk[3]; pk4 = pk[4]; pk5 = pk[5];
+          hp = pk4 >> 16;
+        }
+        if (hp == 0) dead_off = dd; // empty or fainted: zero block (network.h:153-160), kept out of the scatter
+        else {
+          doff = dd;
+          pr[0] = 198 * ER_RS; pv[0] = 1.0f; // the bias, as a row
+#pragma unroll
+          for (uint32_t j = 0; j < 12; ++j) { // fixed positions; an absent feature stays (row 0, value 0): fma(w, 0, h) = h
+            uint32_t fidx = 0; float fval = 0.0f;
+            const bool v = pokemon_feature(j, pk0, pk1, pk2, pk3, pk4, pk5, sleep, fidx, fval);
+            pr[1 + j] = v ? fidx * ER_RS : 0u;
+            pv[1 + j] = v ? fval : 0.0f;
+          }
+          hp_ratio[r32] = (float)hp / (float)(pk0 & 0xFFFF);
+        }
+      }
+      dst_off[r32] = doff;
+      if (dead_off != 0xFFFFFFFFu) for (int o = 0; o <= out_dim; ++o) a.emb[(size_t)dead_off + o] = 0.0f;
+    }
+    __builtin_amdgcn_wave_barrier();
+    EL_MARK(3);
+    // ---- both layers, 16 hidden channels at a time (a quarter of the lane's 64: keeps the live registers under 256) ----
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) { acc0[q] = 0.0f; acc1[q] = 0.0f; }
+    const uint32_t *pr = prow + r32 * ER_PAIRS;
+    const float *pv = pval + r32 * ER_PAIRS;
+#pragma unroll
+    for (int part = 0; part < 4; ++part) {
+      float h[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) h[j] = 0.0f;
+#pragma unroll
+      for (int e = 0; e < ER_PAIRS; ++e) {
+        const float v = pv[e];
+        const float4 *w = (const float4 *)(W0s + pr[e] + hh * 64 + part * 16);
+#pragma unroll
+        for (int j4 = 0; j4 < 4; ++j4) {
+          const float4 x = w[j4];
+          h[4 * j4 + 0] = fmaf(x.x, v, h[4 * j4 + 0]); h[4 * j4 + 1] = fmaf(x.y, v, h[4 * j4 + 1]);
+          h[4 * j4 + 2] = fmaf(x.z, v, h[4 * j4 + 2]); h[4 * j4 + 3] = fmaf(x.w, v, h[4 * j4 + 3]);
+        }
+      }
+      EL_MARK(4);
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const float av = act_fn(h[j], N.activation);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bf0[part * 16 + j], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bf1[part * 16 + j], acc1, 0, 0, 0);
+      }
+      EL_MARK(6);
+    }
+    // ---- bias + activation + scatter: acc[q] is row (q & 3) + 8 (q >> 2) + 4 hh of the mini-tile, column nb * 32 + r32 ----
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int row = (q & 3) + 8 * (q >> 2) + 4 * (int)hh;
+      const uint32_t doff = dst_off[row];
+      if (doff != 0xFFFFFFFFu) {
+        if ((int)r32 < out_dim) a.emb[(size_t)doff + 1 + r32] = act_fn(acc0[q] + ob0, N.activation);
+        if (32 + (int)r32 < out_dim) a.emb[(size_t)doff + 1 + 32 + r32] = act_fn(acc1[q] + ob1, N.activation);
+      }
+    }
+    if (hh == 0 && dst_off[r32] != 0xFFFFFFFFu) a.emb[dst_off[r32]] = hp_ratio[r32];
+    __builtin_amdgcn_wave_barrier(); // the wave's LDS is rewritten by the next mini-tile
+    EL_MARK(7);
+  }
+  EL_FLUSH();
+}
+
 // ---- party-slot embedding cache (the GPU form of NN::Battle::PokemonCache, cpp/include/nn/battle/cache.h:18-131) ------------
 // A bench Pokemon's embedding depends only on its stored bytes minus hp, with the PP bytes reduced to "has PP" bits and the
 // status reduced to its encoder index (Encode::Battle::pokemon_key, encode/battle/key.h:65-71) -- the reference fills 240
@@ -1305,6 +1472,10 @@ int oakgpu_leaf_set_lds_limits(void) { // per DEVICE (hipFuncSetAttribute applie
   if (e != hipSuccess) return oakgpu_fail_hip((int)e, "hipFuncSetAttribute(k_embed_lds<party>)");
   e = hipFuncSetAttribute((const void *)oak::k_embed_lds<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)oak::ELayout<false>::BYTES);
   if (e != hipSuccess) return oakgpu_fail_hip((int)e, "hipFuncSetAttribute(k_embed_lds<party, list>)");
+  e = hipFuncSetAttribute((const void *)oak::k_embed_rows<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)oak::ER_BYTES);
+  if (e != hipSuccess) return oakgpu_fail_hip((int)e, "hipFuncSetAttribute(k_embed_rows)");
+  e = hipFuncSetAttribute((const void *)oak::k_embed_rows<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)oak::ER_BYTES);
+  if (e != hipSuccess) return oakgpu_fail_hip((int)e, "hipFuncSetAttribute(k_embed_rows<list>)");
   e = hipFuncSetAttribute((const void *)oak::k_embed_lds<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)oak::ELayout<true>::BYTES);
   if (e != hipSuccess) return oakgpu_fail_hip((int)e, "hipFuncSetAttribute(k_embed_lds<active>)");
   e = hipFuncSetAttribute((const void *)oak::k_policy, hipFuncAttributeMaxDynamicSharedMemorySize, oak::POLICY_LDS_LIMIT);
@@ -1330,7 +1501,8 @@ static int leaf_eval_impl(oakgpu_ctx *ctx, oakgpu_net *net, const uint8_t *battl
     if (!emb) return -1;
   }
   const oak::NetDev &D = net->dev;
-  static const int embed_impl = getenv("OAKGPU_EMBED_IMPL") ? atoi(getenv("OAKGPU_EMBED_IMPL")) : 3;
+  static const int embed_impl = getenv("OAKGPU_EMBED_IMPL") ? atoi(getenv("OAKGPU_EMBED_IMPL")) : 4;
+  const bool rows_ok = D.p_hidden <= 128 && D.p_out <= 64; // k_embed_rows: two 32-wide output blocks
   hipEvent_t *tev = (hipEvent_t *)oakgpu_ctx_timing_events(ctx); // diagnostic only (oakgpu_set_kernel_timing)
   {
     static const int kinds = getenv("OAKGPU_EMBED_KINDS") ? atoi(getenv("OAKGPU_EMBED_KINDS")) : 3; // diagnostics: 1 party, 2 actives
@@ -1349,7 +1521,15 @@ static int leaf_eval_impl(oakgpu_ctx *ctx, oakgpu_net *net, const uint8_t *battl
         hipLaunchKernelGGL(oak::k_party_tags, dim3((n * 10 + 256 * oak::TAG_R - 1) / (256 * oak::TAG_R)), dim3(256), 0, stream, D, battles, durations, n, emb, slot_tags, work, count);
         ta.work = work;
         ta.work_count = count;
-        hipLaunchKernelGGL((oak::k_embed_lds<false, true>), dim3(ntiles < 256 ? ntiles : 256), dim3(oak::EL_BLOCK), oak::ELayout<false>::BYTES, stream, ta);
+        // the work list is short (~10% of the slots): the tile kernel's lighter prologue wins there (measured: 0.789 vs 0.802 ms per
+        // configs[2] step); OAKGPU_EMBED_IMPL=5 selects the row kernel for the list as well (A/B)
+        if (embed_impl == 5 && rows_ok) hipLaunchKernelGGL(oak::k_embed_rows<true>, dim3(256), dim3(oak::ER_BLOCK), oak::ER_BYTES, stream, ta);
+        else hipLaunchKernelGGL((oak::k_embed_lds<false, true>), dim3(ntiles < 256 ? ntiles : 256), dim3(oak::EL_BLOCK), oak::ELayout<false>::BYTES, stream, ta);
+        continue;
+      }
+      if (kind == 0 && embed_impl >= 4 && rows_ok) { // default party-slot pass: every wave its own pipeline
+        const uint32_t nmt = (n * 10 + oak::ER_ITEMS - 1) / oak::ER_ITEMS, wg = (nmt + oak::ER_WAVES - 1) / oak::ER_WAVES;
+        hipLaunchKernelGGL(oak::k_embed_rows<false>, dim3(wg < 256 ? wg : 256), dim3(oak::ER_BLOCK), oak::ER_BYTES, stream, ta);
         continue;
       }
       if (embed_impl == 2) { // second implementation: first-layer rows gathered from L2 (A/B)
