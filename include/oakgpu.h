@@ -57,6 +57,12 @@ int oakgpu_set_playouts_per_lane(oakgpu_ctx *ctx, int k);
  * launch large enough to keep every SIMD's wave slots occupied runs as a single dispatch (its tail is bound by the
  * longest playout, not by idle lanes); calling this function applies the given setting to every launch. */
 int oakgpu_set_regroup(oakgpu_ctx *ctx, int rounds, int suspend_below, int shrink);
+/* Rollout engine (results never depend on it; all three are bit-identical): 2 = register-resident engine, one wave per
+ * workgroup, queue refill (default); 1 = LDS-resident engine (first implementation, kept as a second opinion); 3 =
+ * register-resident engine in 256-lane workgroups that re-bin their playouts by action class {move, switch / pass,
+ * nothing} before each of a turn's two action slots (per-turn branch compaction through LDS), `workgroups_per_cu` of
+ * them per CU (2..4, 0 = keep). */
+int oakgpu_set_rollout_engine(oakgpu_ctx *ctx, int engine, int workgroups_per_cu);
 int oakgpu_device_count(void);
 
 /* ---- rollout: replaces MCTS::Search::init_stats_and_rollout (search/mcts.h:448-496) and,

@@ -68,6 +68,10 @@ class Context:
         """Tail regrouping of the queue schedule (include/oakgpu.h: oakgpu_set_regroup); results never change."""
         _lib.check(self.lib.oakgpu_set_regroup(self.handle, int(rounds), int(suspend_below), int(shrink)))
 
+    def set_rollout_engine(self, engine=2, workgroups_per_cu=0):
+        """2: register engine + queue (default); 1: LDS engine; 3: register engine with per-turn action-class compaction."""
+        _lib.check(self.lib.oakgpu_set_rollout_engine(self.handle, int(engine), int(workgroups_per_cu)))
+
     def stream_ptr(self):
         """hipStream_t of this context (wrap with torch.cuda.ExternalStream to share it with torch)."""
         return self.lib.oakgpu_get_stream(self.handle)

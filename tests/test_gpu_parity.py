@@ -494,3 +494,32 @@ def test_segment_mean_and_direct_rccl_all_gather(gpu_ctx):
     lib.oakgpu_comm_destroy(comm)
     hip.hipFree(ds)
     hip.hipFree(dr)
+
+
+def test_action_class_compaction_engine_is_bit_identical(gpu_ctx):
+    """Engine 3 (k_rollout_bins: 256-lane workgroups that re-bin their playouts by action class before each action slot,
+    the whole playout state travelling between lanes through LDS) against the oracle: every output byte, with and without
+    root prep, capped, ragged, and as a group launch."""
+    try:
+        gpu_ctx.set_rollout_engine(3, 3)
+        for n, ppl, max_steps, seed0 in ((3000, 2, 1000, 0xB1A50000), (700, 1, 23, 0xB1A51000), (9000, 5, 1000, 0xB1A52000), (1, 2, 1000, 0xB1A53000)):
+            gpu_ctx.set_playouts_per_lane(ppl)
+            b, d, p, r = O.make_random_ou_batch(n, seed0=seed0)
+            for prep in (False, True):
+                got = gpu_ctx.rollout(b, d, r, p, max_steps=max_steps, prep=prep, return_state=True)
+                ob, od, op = b.copy(), d.copy(), p.copy()
+                oout, osteps = O.rollout_batch(ob, od, r, op, max_steps=max_steps, prep=prep, threads=8)
+                assert (got["steps"] == osteps).all() and (got["results"] == oout).all(), (n, prep)
+                bad = np.nonzero((got["battles"] != ob).any(axis=1))[0]
+                assert bad.size == 0, (n, prep, int(bad[0]))
+                assert (got["durations"] == od).all() and (got["prng"] == op).all()
+        gpu_ctx.set_playouts_per_lane(3)
+        batches = [O.make_random_ou_batch(n, seed0=0xB1A60000 + 1000 * k) for k, n in enumerate((1200, 77, 2500))]
+        got = gpu_ctx.rollout_group([(b, d, r, p) for b, d, p, r in batches], return_state=True)
+        for (b, d, p, r), g in zip(batches, got):
+            ob, od, op = b.copy(), d.copy(), p.copy()
+            oout, osteps = O.rollout_batch(ob, od, r, op, max_steps=1000, threads=8)
+            assert (g["steps"] == osteps).all() and (g["results"] == oout).all() and (g["battles"] == ob).all() and (g["prng"] == op).all()
+    finally:
+        gpu_ctx.set_rollout_engine(2)
+        gpu_ctx.set_playouts_per_lane(2)
