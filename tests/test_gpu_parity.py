@@ -523,3 +523,21 @@ def test_action_class_compaction_engine_is_bit_identical(gpu_ctx):
     finally:
         gpu_ctx.set_rollout_engine(2)
         gpu_ctx.set_playouts_per_lane(2)
+
+
+def test_group_launch_limits(gpu_ctx):
+    """64 batches per group is the documented maximum (the batch table lives in LDS): 64 tiny batches work and agree with
+    the oracle, 65 are refused with a message, and a null required pointer is refused before anything is launched."""
+    from oak_amd import _lib
+    batches = [O.make_random_ou_batch(3 + (k % 5), seed0=0x64000000 + 97 * k) for k in range(64)]
+    got = gpu_ctx.rollout_group([(b, d, r, p) for b, d, p, r in batches], max_steps=300, return_state=True)
+    for (b, d, p, r), g in zip(batches, got):
+        ob, od, op = b.copy(), d.copy(), p.copy()
+        oout, osteps = O.rollout_batch(ob, od, r, op, max_steps=300)
+        assert (g["steps"] == osteps).all() and (g["results"] == oout).all() and (g["battles"] == ob).all()
+    with pytest.raises(RuntimeError, match="more than 64 batches"):
+        gpu_ctx.rollout_group([(b, d, r, p) for b, d, p, r in batches] + [(batches[0][0], batches[0][1], batches[0][3], batches[0][2])])
+    descs = (_lib.RolloutBatch * 1)()
+    descs[0] = _lib.RolloutBatch(None, None, None, None, 5, None, None, None, None, None)
+    assert gpu_ctx.lib.oakgpu_rollout_group_dev(gpu_ctx.handle, descs, 1, 10, 0) != 0
+    assert b"null required pointer" in gpu_ctx.lib.oakgpu_last_error()
