@@ -531,7 +531,8 @@ __global__ __launch_bounds__(BLK, WPS) void k_rollout_queue(GroupArgs g_in, Roun
 // party slots stay put in LDS, addressed by the `home` index that travels with it.
 constexpr int BINS_BLK = 256, BINS_NW = 48, BINS_ROUND = 12;
 constexpr int BINS_LDS_BYTES = 24 * BINS_BLK * 4 + TABLE_LDS_PAD + COLD_LDS_BYTES + BINS_ROUND * BINS_BLK * 4 + 64;
-template <int WPS>
+static_assert(4 * 3 * 4 <= 64, "class counters fit the tail of the exchange area");
+template <int WPS, bool ONE_EXCHANGE = false>
 __global__ __launch_bounds__(BINS_BLK, WPS) void k_rollout_bins(GroupArgs g_in, RoundArgs q_in) {
   extern __shared__ __align__(16) uint8_t smem[];
   lds_u32 *party = (lds_u32 *)smem;
@@ -539,7 +540,7 @@ __global__ __launch_bounds__(BINS_BLK, WPS) void k_rollout_bins(GroupArgs g_in, 
   Tables T = stage_default_tables((lds_u8 *)smem + ER::PARTY_WORDS * BINS_BLK * 4);
   lds_u32 *cold = (lds_u32 *)((lds_u8 *)smem + ER::PARTY_WORDS * BINS_BLK * 4 + TABLE_LDS_PAD);
   lds_u32 *xch = (lds_u32 *)((lds_u8 *)cold + COLD_LDS_BYTES);          // BINS_ROUND x 256 dwords
-  lds_u32 *counts = xch + BINS_ROUND * BINS_BLK;                         // 4 waves x {moves, cheap}
+  lds_u32 *counts = xch + BINS_ROUND * BINS_BLK;                         // 4 waves x 3 class counts (the fourth is the rest)
   if (threadIdx.x == 0) {
     struct { GroupArgs g; RoundArgs q; } c{g_in, q_in};
     const uint32_t *src = (const uint32_t *)&c;
@@ -598,22 +599,23 @@ __global__ __launch_bounds__(BINS_BLK, WPS) void k_rollout_bins(GroupArgs g_in, 
     home = st[k++];
     e.m = party + home;
   };
-  // re-bin the workgroup's 256 playouts by class (0: move, 1: switch / pass, 2: nothing to do in this slot)
+  // re-bin the workgroup's 256 playouts by class 0..3 (classes are a scheduling hint only: any permutation is correct)
   auto exchange = [&](uint32_t cls, uint32_t &pc, uint32_t &qc, uint32_t &flags) {
-    const uint64_t mA = __ballot(cls == 0), mB = __ballot(cls == 1);
-    if (wl == 0) { counts[2 * wib] = (uint32_t)__popcll(mA); counts[2 * wib + 1] = (uint32_t)__popcll(mB); }
+    const uint64_t mA = __ballot(cls == 0), mB = __ballot(cls == 1), mC = __ballot(cls == 2);
+    if (wl == 0) { counts[3 * wib] = (uint32_t)__popcll(mA); counts[3 * wib + 1] = (uint32_t)__popcll(mB); counts[3 * wib + 2] = (uint32_t)__popcll(mC); }
     __syncthreads();
-    uint32_t totA = 0, totB = 0, preA = 0, preB = 0, preC = 0;
+    uint32_t totA = 0, totB = 0, totC = 0, preA = 0, preB = 0, preC = 0, preD = 0;
 #pragma unroll
     for (uint32_t w = 0; w < 4; ++w) {
-      const uint32_t a = counts[2 * w], b = counts[2 * w + 1];
-      preA += w < wib ? a : 0; preB += w < wib ? b : 0; preC += w < wib ? 64 - a - b : 0;
-      totA += a; totB += b;
+      const uint32_t a = counts[3 * w], b = counts[3 * w + 1], cc = counts[3 * w + 2];
+      preA += w < wib ? a : 0; preB += w < wib ? b : 0; preC += w < wib ? cc : 0; preD += w < wib ? 64 - a - b - cc : 0;
+      totA += a; totB += b; totC += cc;
     }
-    const uint64_t below = (1ull << wl) - 1, mC = ~(mA | mB);
+    const uint64_t below = (1ull << wl) - 1, mD = ~(mA | mB | mC);
     const uint32_t dest = cls == 0 ? preA + (uint32_t)__popcll(mA & below)
                         : cls == 1 ? totA + preB + (uint32_t)__popcll(mB & below)
-                                   : totA + totB + preC + (uint32_t)__popcll(mC & below);
+                        : cls == 2 ? totA + totB + preC + (uint32_t)__popcll(mC & below)
+                                   : totA + totB + totC + preD + (uint32_t)__popcll(mD & below);
     uint32_t st[BINS_NW];
     pack(st, pc, qc, flags);
 #pragma unroll
@@ -671,10 +673,16 @@ __global__ __launch_bounds__(BINS_BLK, WPS) void k_rollout_bins(GroupArgs g_in, 
     }
     // flags: bit 0 playing this turn, bit 1 an action is pending in the coming slot, bits 8-15 the turn's result so far
     uint32_t flags = (playing ? 1u : 0u) | ((playing && r == 0) ? 2u : 0u) | (r << 8);
+    if constexpr (ONE_EXCHANGE) { // bin once per turn by the PAIR of pending actions: {move first, switch then move, switches only, nothing}
+      const bool act = (flags & 2) != 0;
+      exchange(!act ? 3u : (pc & 3) == C_MOVE ? 0u : (qc & 3) == C_MOVE ? 1u : 2u, pc, qc, flags);
+    }
 #pragma unroll 1
     for (int slot = 0; slot < 2; ++slot) {
-      const bool act = (flags & 2) != 0;
-      exchange(!act ? 2u : (pc & 3) == C_MOVE ? 0u : 1u, pc, qc, flags);
+      if constexpr (!ONE_EXCHANGE) {
+        const bool act = (flags & 2) != 0;
+        exchange(!act ? 3u : (pc & 3) == C_MOVE ? 0u : 1u, pc, qc, flags);
+      }
       if (flags & 2) {
         r = (pc & 3) == C_MOVE ? e.act_move(pc) : e.act_cheap(pc);
         const bool last = r != 0 || (qc & 3) == C_PASS;
@@ -1109,6 +1117,7 @@ static int set_lds_limits() {
   HIPCHK(hipFuncSetAttribute((const void *)oak::k_rollout_bins<2>, hipFuncAttributeMaxDynamicSharedMemorySize, oak::BINS_LDS_BYTES));
   HIPCHK(hipFuncSetAttribute((const void *)oak::k_rollout_bins<3>, hipFuncAttributeMaxDynamicSharedMemorySize, oak::BINS_LDS_BYTES));
   HIPCHK(hipFuncSetAttribute((const void *)oak::k_rollout_bins<4>, hipFuncAttributeMaxDynamicSharedMemorySize, oak::BINS_LDS_BYTES));
+  HIPCHK(hipFuncSetAttribute((const void *)(oak::k_rollout_bins<3, true>), hipFuncAttributeMaxDynamicSharedMemorySize, oak::BINS_LDS_BYTES));
 #define OAK_LIM_Q(W) HIPCHK(hipFuncSetAttribute((const void *)oak::k_rollout_queue<64, W>, hipFuncAttributeMaxDynamicSharedMemorySize, 24 * 64 * 4 + oak::TABLE_LDS_PAD + oak::COLD_LDS_BYTES))
   OAK_LIM_Q(2); OAK_LIM_Q(3); OAK_LIM_Q(4);
 #undef OAK_LIM_Q
@@ -1299,7 +1308,9 @@ static int launch_group(oakgpu_ctx *c, const oak::BatchDesc *descs, uint32_t cou
     const oak::GroupArgs gb{dt, count, total, max_steps, prep};
     oak::RoundArgs qb{};
     qb.queue = c->d_queue;
-    if (wps >= 4) hipLaunchKernelGGL(oak::k_rollout_bins<4>, dim3(blocks), dim3(oak::BINS_BLK), oak::BINS_LDS_BYTES, c->stream, gb, qb);
+    static const bool one = getenv("OAKGPU_BINS_ONE") && atoi(getenv("OAKGPU_BINS_ONE")); // A/B: one exchange per turn (by action pair)
+    if (one) hipLaunchKernelGGL((oak::k_rollout_bins<3, true>), dim3(blocks), dim3(oak::BINS_BLK), oak::BINS_LDS_BYTES, c->stream, gb, qb);
+    else if (wps >= 4) hipLaunchKernelGGL(oak::k_rollout_bins<4>, dim3(blocks), dim3(oak::BINS_BLK), oak::BINS_LDS_BYTES, c->stream, gb, qb);
     else if (wps == 3) hipLaunchKernelGGL(oak::k_rollout_bins<3>, dim3(blocks), dim3(oak::BINS_BLK), oak::BINS_LDS_BYTES, c->stream, gb, qb);
     else hipLaunchKernelGGL(oak::k_rollout_bins<2>, dim3(blocks), dim3(oak::BINS_BLK), oak::BINS_LDS_BYTES, c->stream, gb, qb);
     HIPCHK(hipGetLastError());
