@@ -233,10 +233,10 @@ extern "C" int oakgpu_search(oakgpu_ctx *ctx, oakgpu_net *net, const uint8_t *ba
     bool busy = false;
     ~Slot() { if (own_ctx && ctx) oakgpu_destroy(ctx); }
   };
-  // one batch at a time for the bandits with network priors (they share the network's policy workspace) and for
-  // batch = 1, which is the reference's strictly sequential iteration order
+  // one batch at a time only for batch = 1, which is the reference's strictly sequential iteration order (the evaluator's
+  // workspaces belong to the context, so two slots -- two contexts -- can evaluate the same network concurrently)
   const bool timed = prm->duration_us != 0; // time budget (search.cc:300-306): batches are started until it has elapsed
-  const int n_slots = (!pucb && B > 1 && (timed || prm->iterations > B)) ? 2 : 1;
+  const int n_slots = (B > 1 && (timed || prm->iterations > B)) ? 2 : 1;
   Slot slots[2];
   for (int si = 0; si < n_slots; ++si) {
     Slot &S = slots[si];
@@ -250,7 +250,7 @@ extern "C" int oakgpu_search(oakgpu_ctx *ctx, oakgpu_net *net, const uint8_t *ba
     RC(buf.d(&S.d_ch1, (size_t)B * 9)); RC(buf.d(&S.d_cnt1, (size_t)B)); RC(buf.d(&S.d_ch2, (size_t)B * 9)); RC(buf.d(&S.d_cnt2, (size_t)B));
     RC(buf.d(&S.d_rout, (size_t)B)); RC(buf.d(&S.d_steps, (size_t)B)); RC(buf.d(&S.d_values, (size_t)B));
     if (pucb) { RC(buf.d(&S.d_l1, (size_t)B * 9)); RC(buf.d(&S.d_l2, (size_t)B * 9)); }
-    if (use_net && n_slots > 1) { // per-slot embedding buffer: the network's own workspace serves one stream at a time
+    if (use_net && n_slots > 1) { // per-slot embedding buffer (kept from round 1; the context's own workspace would do as well)
       int emb_dim = 0;
       RC(oakgpu_net_shape(net, &emb_dim, nullptr, nullptr, nullptr));
       RC(buf.d(&S.d_emb, (size_t)B * emb_dim));

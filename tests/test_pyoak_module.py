@@ -11,7 +11,17 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _mod():
-    from oak_amd import pyoak
+    try:
+        from oak_amd import pyoak
+    except ImportError:      # a fresh checkout: build the module like __graft_entry__.build() does (host-only C++, no GPU needed)
+        import sys
+        sys.path.insert(0, ROOT)
+        import __graft_entry__ as G
+        lib = os.path.join(ROOT, "oak_amd", "liboakgpu.so")
+        if not os.path.exists(lib):
+            G.build()
+        G.build_pyoak(lib, [os.path.join(ROOT, "include", f) for f in sorted(os.listdir(os.path.join(ROOT, "include")))])
+        from oak_amd import pyoak
     return pyoak
 
 
