@@ -21,6 +21,7 @@
 
 #include <cstring>
 #include <fstream>
+#include <mutex>
 #include <random>
 #include <stdexcept>
 #include <string>
@@ -53,6 +54,7 @@ void check(int rc) {
   if (rc != 0) throw std::runtime_error(oakgpu_last_error());
 }
 
+std::mutex g_ctx_mu; // a context serves one caller at a time; search() drops the GIL, so two Python threads could meet here
 oakgpu_ctx *context() { // one context per process, created on first use (device from OAKGPU_DEVICE, default 0)
   static oakgpu_ctx *ctx = nullptr;
   if (!ctx) {
@@ -112,6 +114,7 @@ PYBIND11_MODULE(pyoak, m) {
   m.def(
       "update",
       [](Input &input, uint8_t c1, uint8_t c2) { // options <- durations; PKMN::update; durations <- options (pyoak.cc:468-478)
+        std::lock_guard<std::mutex> lock(g_ctx_mu);
         check(oakgpu_update(context(), input.battle, &c1, &c2, input.durations, nullptr, nullptr, 1, &input.result));
       },
       py::arg("input"), py::arg("c1"), py::arg("c2"));
@@ -120,6 +123,7 @@ PYBIND11_MODULE(pyoak, m) {
       "choices",
       [](const Input &input) { // not in pyoak: PKMN::choices(battle, result) (pkmn.h:141-156) for both players
         uint8_t c1[9], c2[9], n1 = 0, n2 = 0;
+        std::lock_guard<std::mutex> lock(g_ctx_mu);
         check(oakgpu_choices(context(), input.battle, &input.result, 0, c1, &n1, 1));
         check(oakgpu_choices(context(), input.battle, &input.result, 1, c2, &n2, 1));
         return py::make_tuple(std::vector<int>(c1, c1 + n1), std::vector<int>(c2, c2 + n2));
@@ -178,6 +182,7 @@ PYBIND11_MODULE(pyoak, m) {
         int rc;
         {
           py::gil_scoped_release release; // the search is long and touches no Python state
+          std::lock_guard<std::mutex> lock(g_ctx_mu);
           rc = oakgpu_search_agent(context(), input.battle, input.durations, input.result, &a, batch, s, &out.raw);
         }
         check(rc);
