@@ -30,6 +30,9 @@ struct NetDev {
   const float *p_w0t, *p_b0, *p_b1;
   const float *a_w0t, *a_b0, *a_b1;
   const float *p_w1, *a_w1; // second layers in file layout [out][hidden] (MFMA B operand of k_embed_tile)
+  // k_embed_arows: the active net's W0^T with every row de-interleaved [even channels | odd channels] and padded to 128
+  // floats, + an all-zero row 427 (absent move slots point at it); W1 in MFMA-fragment order [n-block][k-step][lane]
+  const float *a_w0d, *a_w1f;
   int p_hidden, p_out, a_hidden, a_out;
   int side_dim, emb_dim;
   int activation; // 1 relu, 2 clamp
@@ -797,6 +800,193 @@ __global__ __launch_bounds__(ER_BLOCK) void k_embed_rows(EmbedTileArgs a) {
   EL_FLUSH();
 }
 
+// ---- K2, the actives' pass in the same row-per-lane form as k_embed_rows (the default).  An active's ~45 non-zero
+// features fall into three kinds, and each gets the cheapest treatment that its structure allows:
+//   36 FIXED rows  (bias, the 5 active stats, 6 boosts, 19 volatile features, the stored Pokemon's 5 stats): the row is known
+//                  at compile time, only the VALUE differs per item -- constant LDS offsets, no index, and a row whose value
+//                  is 0 for every item of the wave (most volatile flags) is skipped with one ballot;
+//    9 ONE-HOT rows in LDS (2 types, 4 durations, status, 2 stored types): a 16-bit LDS offset per item, absent = the zero row;
+//    8 MOVE rows   (4 active + 4 stored move slots, 328 possible rows): read from the de-interleaved copy in L2
+//                  (`a_w0d`, 219 KB), absent = its zero row.
+// A lane accumulates all 64 of its hidden channels (k = 2j + hh) in registers, then runs the <= 4 output blocks one after
+// the other with that block's W1 fragment streamed from L2 (`a_w1f`, coalesced 256 B per k-step) 16 k-steps at a time, the
+// next chunk's loads issued ahead of the current chunk's MFMAs.  No activation tile, no workgroup barrier per tile, every
+// wave on the MFMA; the kernel fits 128 registers so that a CU holds ONE 16-wave workgroup (4 waves per SIMD, 149 KB of
+// LDS): with 8 waves of 256 registers the two waves of a SIMD sat in the same phase at the same time (157 us vs 144 us).
+constexpr int AR_SLOTS = 101;                 // 99 LDS-resident rows (active_lds_slot) + the bias + a zero row
+constexpr int AR_BIAS = 99, AR_ZERO = 100;
+constexpr int AR_FIXED = 36, AR_HOT = 9, AR_MOVES = 8;
+constexpr int AR_ITEM_WORDS = AR_FIXED + 5 + 4; // 36 values, 9 u16 LDS offsets (5 words), 8 u16 global rows (4 words)
+constexpr int AR_WAVE_WORDS = ER_ITEMS * AR_ITEM_WORDS + 2 * ER_ITEMS;
+constexpr int AR_BLOCK = 1024, AR_WAVES = 16; // 16 waves = 4 per SIMD at <= 128 registers: the phases of different waves overlap
+constexpr size_t AR_BYTES = (size_t)(AR_SLOTS * ER_RS + AR_WAVES * AR_WAVE_WORDS) * 4;
+// LDS slot of fixed pair f (0..35): bias, active stats, boosts, volatiles, stored stats (rows 229..233 -> slots 65..69)
+__host__ __device__ constexpr int ar_fixed_slot(int f) { return f == 0 ? AR_BIAS : f < 6 ? f - 1 : f < 12 ? 20 + (f - 6) : f < 31 ? 26 + (f - 12) : 65 + (f - 31); }
+__global__ __launch_bounds__(AR_BLOCK) void k_embed_arows(EmbedTileArgs a) {
+  extern __shared__ __align__(16) float lds_f[];
+  const NetDev &N = a.net;
+  const int hidden = N.a_hidden, out_dim = N.a_out;
+  const int NBo = (out_dim + 31) >> 5;
+  float *W0s = lds_f;
+  for (int i = threadIdx.x; i < AR_SLOTS * 128; i += AR_BLOCK) { // slot, position hh * 64 + j  <-  channel 2j + hh
+    const int sl = i >> 7, pos = i & 127, c = 2 * (pos & 63) + (pos >> 6);
+    float v = 0.0f;
+    if (c < hidden) v = sl < 99 ? N.a_w0t[(size_t)active_lds_row(sl) * hidden + c] : sl == AR_BIAS ? N.a_b0[c] : 0.0f;
+    W0s[sl * ER_RS + pos] = v;
+  }
+  const uint32_t lane = threadIdx.x & 63, wib = threadIdx.x >> 6, r32 = lane & 31, hh = lane >> 5;
+  uint32_t *wl = (uint32_t *)(W0s + AR_SLOTS * ER_RS) + wib * AR_WAVE_WORDS; // this wave's private LDS
+  uint32_t *dst_off = wl + ER_ITEMS * AR_ITEM_WORDS;
+  float *hp_ratio = (float *)(dst_off + ER_ITEMS);
+  const uint32_t items = a.n * 2;
+  const uint32_t nmt = (items + ER_ITEMS - 1) / ER_ITEMS;
+  const uint32_t stride = gridDim.x * AR_WAVES;
+  __syncthreads(); // W0s staged (the only workgroup barrier of the kernel)
+  EL_T0();
+  EL_MARK(0);
+  for (uint32_t mt = blockIdx.x * AR_WAVES + wib; mt < nmt; mt += stride) {
+    // ---- lists: lane r (hh = 0) encodes item r straight from global memory (two dependent loads: order -> stored Pokemon) ----
+    if (hh == 0) {
+      const uint32_t g = mt * ER_ITEMS + r32;
+      uint32_t *it = wl + r32 * AR_ITEM_WORDS;
+      float *fv = (float *)it;                          // 36 fixed-row values
+      uint16_t *hot = (uint16_t *)(it + AR_FIXED);      // 9 LDS offsets (in floats / 4: slot * ER_RS fits 16 bits)
+      uint16_t *mv = (uint16_t *)(it + AR_FIXED + 5);   // 8 global rows
+      uint32_t doff = 0xFFFFFFFFu, dead_off = 0xFFFFFFFFu;
+#pragma unroll
+      for (int f = 0; f < AR_FIXED; ++f) fv[f] = 0.0f;
+#pragma unroll
+      for (int k = 0; k < AR_HOT; ++k) hot[k] = (uint16_t)(AR_ZERO * ER_RS / 4);
+#pragma unroll
+      for (int k = 0; k < AR_MOVES; ++k) mv[k] = 427;
+      if (g < items) {
+        const uint32_t leaf = g >> 1, side = g & 1;
+        const uint32_t *sb = (const uint32_t *)a.battles + (size_t)leaf * 96 + side * 46;
+        const uint32_t dur = ((const uint32_t *)a.durations)[(size_t)leaf * 2 + side];
+        const uint4 av0 = *(const uint4 *)(sb + 36), av1 = *(const uint4 *)(sb + 40);
+        const uint32_t id = sb[44] & 0xFF;
+        const uint32_t dd = leaf * N.emb_dim + side * N.side_dim;
+        uint32_t pk0 = 0, pk1 = 0, pk2 = 0, pk3 = 0, pk4 = 0, pk5 = 0, hp = 0;
+        if (id != 0) {
+          const uint32_t *pk = sb + 6 * (id - 1);
+          pk0 = pk[0]; pk1 = pk[1]; pk2 = pk[2]; pk3 = pk[3]; pk4 = pk[4]; pk5 = pk[5];
+          hp = pk4 >> 16;
+        }
+        if (hp == 0) dead_off = dd; // no active / fainted active: zero block (network.h:142-143)
+        else {
+          doff = dd;
+          fv[0] = 1.0f; // the bias
+          int nh = 0, nm = 0;
+#pragma unroll
+          for (uint32_t j = 0; j < 40; ++j) { // Encode::Battle::Active (battle.h:229-489)
+            uint32_t fidx = 0; float fval = 0.0f;
+            const bool v = active_feature(j, av0.x, av0.y, av0.z, av0.w, av1.x, av1.y, av1.z, av1.w, dur, fidx, fval);
+            if (j < 5) fv[1 + j] = fval;                                   // stats: always present
+            else if (j < 7) { hot[nh++] = v ? (uint16_t)(active_lds_slot(fidx) * ER_RS / 4) : (uint16_t)(AR_ZERO * ER_RS / 4); } // types
+            else if (j < 13) fv[6 + (j - 7)] = fval;                       // boosts: always present
+            else if (j < 32) fv[12 + (j - 13)] = v ? fval : 0.0f;          // volatiles: fixed rows, value 0 when absent
+            else if (j < 36) { mv[nm++] = v ? (uint16_t)fidx : (uint16_t)427; } // move slots: rows in L2
+            else { hot[nh++] = v ? (uint16_t)(active_lds_slot(fidx) * ER_RS / 4) : (uint16_t)(AR_ZERO * ER_RS / 4); } // durations
+          }
+#pragma unroll
+          for (uint32_t j = 0; j < 12; ++j) { // Encode::Battle::Pokemon of the stored active (battle.h:197-214), rows + 229
+            uint32_t fidx = 0; float fval = 0.0f;
+            const bool v = pokemon_feature(j, pk0, pk1, pk2, pk3, pk4, pk5, dur & 7, fidx, fval);
+            if (j < 5) fv[31 + j] = fval;
+            else if (j < 9) { mv[nm++] = v ? (uint16_t)(fidx + 229) : (uint16_t)427; }
+            else { hot[nh++] = v ? (uint16_t)(active_lds_slot(fidx + 229) * ER_RS / 4) : (uint16_t)(AR_ZERO * ER_RS / 4); }
+          }
+          hp_ratio[r32] = (float)hp / (float)(pk0 & 0xFFFF);
+        }
+      }
+      dst_off[r32] = doff;
+      if (dead_off != 0xFFFFFFFFu) for (int o = 0; o <= out_dim; ++o) a.emb[(size_t)dead_off + o] = 0.0f;
+    }
+    __builtin_amdgcn_wave_barrier();
+    EL_MARK(3);
+    // ---- first layer: this lane's 64 hidden channels of item r32 ----
+    const uint32_t *it = wl + r32 * AR_ITEM_WORDS;
+    const float *fv = (const float *)it;
+    const uint16_t *hot = (const uint16_t *)(it + AR_FIXED);
+    const uint16_t *mvr = (const uint16_t *)(it + AR_FIXED + 5);
+    float h[64];
+#pragma unroll
+    for (int j = 0; j < 64; ++j) h[j] = 0.0f;
+    // one weight row at a time, a quarter row (4 x ds_read_b128 = 16 registers) in flight: the loops below are NOT unrolled
+    // over the rows on purpose -- the kernel has to fit 128 registers (4 waves per SIMD)
+    auto axpy = [&](const float4 *w, float v) {
+#pragma unroll
+      for (int part = 0; part < 4; ++part) {
+        float4 x[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) x[u] = w[4 * part + u];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int j = 16 * part + 4 * u;
+          h[j + 0] = fmaf(x[u].x, v, h[j + 0]); h[j + 1] = fmaf(x[u].y, v, h[j + 1]);
+          h[j + 2] = fmaf(x[u].z, v, h[j + 2]); h[j + 3] = fmaf(x[u].w, v, h[j + 3]);
+        }
+      }
+    };
+#pragma unroll 1
+    for (int f = 0; f < AR_FIXED; ++f) {
+      const float v = fv[f];
+      if (f >= 12 && f < 31 && __ballot(v != 0.0f) == 0) continue; // a volatile feature nobody in this wave has
+      axpy((const float4 *)(W0s + ar_fixed_slot(f) * ER_RS + hh * 64), v);
+    }
+#pragma unroll 1
+    for (int k = 0; k < AR_HOT; ++k) axpy((const float4 *)(W0s + (uint32_t)hot[k] * 4 + hh * 64), 1.0f);
+#pragma unroll 1
+    for (int k = 0; k < AR_MOVES; ++k) axpy((const float4 *)(N.a_w0d + (size_t)mvr[k] * 128 + hh * 64), 1.0f); // rows in L2
+#pragma unroll
+    for (int j = 0; j < 64; ++j) h[j] = act_fn(h[j], N.activation);
+    __builtin_amdgcn_sched_barrier(0);
+    EL_MARK(4);
+    // ---- second layer: one 32-wide output block after the other; the W1 fragments stream from L2 in chunks of 16 k-steps,
+    // the next chunk's loads issued before the current chunk's MFMAs ----
+    float bfa[16], bfb[16];
+    const float *wf = N.a_w1f + lane;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) bfa[s] = wf[(size_t)s * 64];
+#pragma unroll 1
+    for (int nb = 0; nb < NBo; ++nb) {
+      f32x16 acc;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[q] = 0.0f;
+      const float *wc = wf + (size_t)nb * 64 * 64;
+      const float *wnext = wf + (size_t)(nb + 1 < NBo ? nb + 1 : nb) * 64 * 64; // the last block re-reads itself: no branch
+#pragma unroll
+      for (int s = 0; s < 16; ++s) bfb[s] = wc[(size_t)(16 + s) * 64];
+#pragma unroll
+      for (int s = 0; s < 16; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(h[s], bfa[s], acc, 0, 0, 0);
+#pragma unroll
+      for (int s = 0; s < 16; ++s) bfa[s] = wc[(size_t)(32 + s) * 64];
+#pragma unroll
+      for (int s = 0; s < 16; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(h[16 + s], bfb[s], acc, 0, 0, 0);
+#pragma unroll
+      for (int s = 0; s < 16; ++s) bfb[s] = wc[(size_t)(48 + s) * 64];
+#pragma unroll
+      for (int s = 0; s < 16; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(h[32 + s], bfa[s], acc, 0, 0, 0);
+#pragma unroll
+      for (int s = 0; s < 16; ++s) bfa[s] = wnext[(size_t)s * 64];
+#pragma unroll
+      for (int s = 0; s < 16; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(h[48 + s], bfb[s], acc, 0, 0, 0);
+      const int o = nb * 32 + (int)r32;
+      const float ob = o < out_dim ? N.a_b1[o] : 0.0f;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int row = (q & 3) + 8 * (q >> 2) + 4 * (int)hh;
+        const uint32_t doff = dst_off[row];
+        if (o < out_dim && doff != 0xFFFFFFFFu) a.emb[(size_t)doff + 1 + o] = act_fn(acc[q] + ob, N.activation);
+      }
+    }
+    if (hh == 0 && dst_off[r32] != 0xFFFFFFFFu) a.emb[dst_off[r32]] = hp_ratio[r32];
+    __builtin_amdgcn_wave_barrier(); // the wave's LDS is rewritten by the next mini-tile
+    EL_MARK(7);
+  }
+  EL_FLUSH();
+}
+
 // ---- party-slot embedding cache (the GPU form of NN::Battle::PokemonCache, cpp/include/nn/battle/cache.h:18-131) ------------
 // A bench Pokemon's embedding depends only on its stored bytes minus hp, with the PP bytes reduced to "has PP" bits and the
 // status reduced to its encoder index (Encode::Battle::pokemon_key, encode/battle/key.h:65-71) -- the reference fills 240
@@ -1345,6 +1535,26 @@ std::vector<float> frag_order(const HostAffine &a, uint32_t out_pad) {
   return f;
 }
 
+// k_embed_arows: W0^T rows de-interleaved [even channels | odd channels], 128 floats per row, + an all-zero last row
+std::vector<float> deinterleave_rows(const HostAffine &a) { // a.w is [out = hidden][in]; row r of W0^T = column r of W
+  std::vector<float> d((size_t)(a.in + 1) * 128, 0.0f);
+  for (uint32_t r = 0; r < a.in; ++r)
+    for (uint32_t c = 0; c < a.out && c < 128; ++c) d[(size_t)r * 128 + (c & 1) * 64 + (c >> 1)] = a.w[(size_t)c * a.in + r];
+  return d;
+}
+// ... and W1 [out][hidden] in MFMA-fragment order: [n-block][k-step s2][lane (r32, hh)] = W1[nb * 32 + r32][2 s2 + hh]
+std::vector<float> embed_frag_order(const HostAffine &a) {
+  const uint32_t NB = (a.out + 31) / 32;
+  std::vector<float> f((size_t)NB * 64 * 64, 0.0f);
+  for (uint32_t nb = 0; nb < NB; ++nb)
+    for (uint32_t s2 = 0; s2 < 64; ++s2)
+      for (uint32_t lane = 0; lane < 64; ++lane) {
+        const uint32_t o = nb * 32 + (lane & 31), c = 2 * s2 + (lane >> 5);
+        if (o < a.out && c < a.in) f[((size_t)nb * 64 + s2) * 64 + lane] = a.w[(size_t)o * a.in + c];
+      }
+  return f;
+}
+
 std::vector<float> pad_vec(const std::vector<float> &v, uint32_t n) {
   std::vector<float> t(n, 0.0f);
   for (size_t i = 0; i < v.size(); ++i) t[i] = v[i];
@@ -1408,6 +1618,8 @@ int oakgpu_net_load_memory(oakgpu_ctx *ctx, const void *bytes, size_t size, oakg
   rc = rc ? rc : upload(net, transpose(a0), &D.a_w0t);
   rc = rc ? rc : upload(net, a0.b, &D.a_b0);
   rc = rc ? rc : upload(net, a1.b, &D.a_b1);
+  rc = rc ? rc : upload(net, deinterleave_rows(a0), &D.a_w0d);
+  rc = rc ? rc : upload(net, embed_frag_order(a1), &D.a_w1f);
   rc = rc ? rc : upload(net, pad_rows(fc0, H, fc0.in), &D.w0);
   rc = rc ? rc : upload(net, pad_vec(fc0.b, H), &D.b0);
   rc = rc ? rc : upload(net, pad_rows(fc1, H, H), &D.w1);
@@ -1476,6 +1688,8 @@ int oakgpu_leaf_set_lds_limits(void) { // per DEVICE (hipFuncSetAttribute applie
   if (e != hipSuccess) return oakgpu_fail_hip((int)e, "hipFuncSetAttribute(k_embed_rows)");
   e = hipFuncSetAttribute((const void *)oak::k_embed_rows<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)oak::ER_BYTES);
   if (e != hipSuccess) return oakgpu_fail_hip((int)e, "hipFuncSetAttribute(k_embed_rows<list>)");
+  e = hipFuncSetAttribute((const void *)oak::k_embed_arows, hipFuncAttributeMaxDynamicSharedMemorySize, (int)oak::AR_BYTES);
+  if (e != hipSuccess) return oakgpu_fail_hip((int)e, "hipFuncSetAttribute(k_embed_arows)");
   e = hipFuncSetAttribute((const void *)oak::k_embed_lds<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)oak::ELayout<true>::BYTES);
   if (e != hipSuccess) return oakgpu_fail_hip((int)e, "hipFuncSetAttribute(k_embed_lds<active>)");
   e = hipFuncSetAttribute((const void *)oak::k_policy, hipFuncAttributeMaxDynamicSharedMemorySize, oak::POLICY_LDS_LIMIT);
@@ -1525,6 +1739,11 @@ static int leaf_eval_impl(oakgpu_ctx *ctx, oakgpu_net *net, const uint8_t *battl
         // configs[2] step); OAKGPU_EMBED_IMPL=5 selects the row kernel for the list as well (A/B)
         if (embed_impl == 5 && rows_ok) hipLaunchKernelGGL(oak::k_embed_rows<true>, dim3(256), dim3(oak::ER_BLOCK), oak::ER_BYTES, stream, ta);
         else hipLaunchKernelGGL((oak::k_embed_lds<false, true>), dim3(ntiles < 256 ? ntiles : 256), dim3(oak::EL_BLOCK), oak::ELayout<false>::BYTES, stream, ta);
+        continue;
+      }
+      if (kind == 1 && embed_impl >= 4 && D.a_hidden <= 128 && D.a_out <= 128 && !getenv("OAKGPU_ACTIVE_TILE")) { // default actives' pass
+        const uint32_t nmt = (n * 2 + oak::ER_ITEMS - 1) / oak::ER_ITEMS, wg = (nmt + oak::AR_WAVES - 1) / oak::AR_WAVES;
+        hipLaunchKernelGGL(oak::k_embed_arows, dim3(wg < 256 ? wg : 256), dim3(oak::AR_BLOCK), oak::AR_BYTES, stream, ta);
         continue;
       }
       if (kind == 0 && embed_impl >= 4 && rows_ok) { // default party-slot pass: every wave its own pipeline
