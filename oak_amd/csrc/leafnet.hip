@@ -1397,6 +1397,186 @@ __global__ __launch_bounds__(MN_BLOCK) void k_mainnet_direct(MainArgs a) {
   }
 }
 
+// ---- K3, wave-independent form (the default).  k_mainnet_direct runs one wave per SIMD (its double-buffered weight
+// fragments take the whole register file), so nothing overlaps with anything: every workgroup barrier (fc0's three
+// 256-column input pieces, the layer hand-overs), every piece's trip through registers into LDS and every wait for the
+// slowest of the four waves is time the matrix pipe stands still (MFMA busy 0.71).  Here a WAVE owns 32 leaves and all (up
+// to 8) 32-wide output blocks of a layer: fc0's A operands come straight from the embedding rows in global memory (lane
+// (r, h) reads 32 B of row r per 8 k-steps, prefetched one sub-chunk ahead like the weights), the hand-over between layers
+// goes through the wave's PRIVATE 32 x 257 LDS tile (C layout -> A layout) and needs no workgroup barrier at all.  Weight
+// fragments are the same arrays as k_mainnet_direct's (frag_order), read 8 k-steps at a time: 2 x 64 registers of B
+// fragments + 128 accumulators.  L2 traffic is unchanged (there, the two waves of a row-half pair read the same fragments).
+constexpr int MW_LD = MAXH + 1;
+constexpr size_t MW_BYTES = (size_t)4 * 32 * MW_LD * 4;
+
+__device__ __forceinline__ float f4_pick(const float4 &v, int i) { return i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w; }
+
+template <int NBc, bool A_GLOBAL>
+__device__ __forceinline__ void wave_layer(const float4 *Wf, int K, int NB, const float *arow, f32x16 (&acc)[8]) {
+  const int lane = threadIdx.x & 63, h = lane >> 5;
+  const int nch = (K + 63) / 64;
+  float4 bA[NBc][2], bB[NBc][2]; // B fragments of one sub-chunk (8 k-steps), double-buffered
+  float4 aC[8], aN[8];           // the lane's 32 A values of the current / the next chunk (fc0: one 128-byte line of its row)
+#pragma unroll
+  for (int j = 0; j < NBc; ++j)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[j][q] = 0.0f;
+  // sub-chunk (c, u): k-steps 8u .. 8u+7 of chunk c = float4 q = 2u, 2u+1 of every n-block's fragment
+  auto wptr = [&](int c, int u) { return Wf + ((size_t)c * NB * 8 + 2 * u) * 64 + lane; };
+  auto load_a = [&](float4 (&av)[8], int c) {
+    const int col = c * 64 + h * 32;
+    if (A_GLOBAL) { // columns past K: the address is clamped instead of the load predicated (a predicated load cannot be hoisted)
+#pragma unroll
+      for (int q = 0; q < 8; ++q) av[q] = *(const float4 *)(arow + (col + 4 * q < K ? col + 4 * q : 0));
+    } else {        // the LDS tile row is addressable up to column 256 whatever K is
+      const float *p = arow + col;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) av[q] = make_float4(p[4 * q], p[4 * q + 1], p[4 * q + 2], p[4 * q + 3]);
+    }
+  };
+  // columns past K contribute nothing (K is a multiple of 4; stale tile columns may hold anything).  Applied where the
+  // values are first USED, not where they are loaded: a select right behind the load makes the wave wait for it on the spot
+  auto mask_a = [&](float4 (&av)[8], int c) {
+    const int col = c * 64 + h * 32;
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+      if (col + 4 * q >= K) av[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+  };
+  auto load_b = [&](float4 (&bv)[NBc][2], int c, int u) {
+    const float4 *w = wptr(c, u);
+#pragma unroll
+    for (int j = 0; j < NBc; ++j) {
+      const int nb = j < NB ? j : NB - 1;
+      bv[j][0] = w[(size_t)nb * 8 * 64]; bv[j][1] = w[(size_t)nb * 8 * 64 + 64];
+    }
+  };
+  // the MFMAs of one sub-chunk; the next one's weight loads are issued in front of its FIRST k-step: the wave's instruction
+  // stream advances at the matrix pipe's pace, so a load placed in front of step s is issued (8 - s) x 512 cycles before
+  // the next sub-chunk needs it.  Measured (main net, us): two loads per k-step 385, four 366, all sixteen up front 356-361,
+  // one behind each MFMA of the first two k-steps 367.
+  auto compute = [&](const float4 (&bv)[NBc][2], float4 (&bn)[NBc][2], int u, int cn, int un, int ca) {
+    const float4 *wn = wptr(cn, un);
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      if (s == 0) {
+#pragma unroll
+        for (int j = 0; j < NBc; ++j) {
+          const int nb = j < NB ? j : NB - 1;
+          bn[j][0] = wn[(size_t)nb * 8 * 64]; bn[j][1] = wn[(size_t)nb * 8 * 64 + 64];
+        }
+      }
+      // the next chunk's A values, a whole chunk ahead -- issued BEHIND this sub-chunk's weight loads: the vector-memory
+      // counter retires in order, so the wait for those weights (one sub-chunk from now) would otherwise cover these too
+      if (ca >= 0 && s == 1) load_a(aN, ca);
+      const float a_s = f4_pick(aC[2 * u + (s >> 2)], s & 3);
+#pragma unroll
+      for (int j = 0; j < NBc; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_s, f4_pick(bv[j][s >> 2], s & 3), acc[j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  load_b(bA, 0, 0);
+  load_a(aC, 0);
+  mask_a(aC, 0);
+#pragma unroll 1
+  for (int c = 0; c < nch; ++c) {
+    const int cn = c + 1 < nch ? c + 1 : c; // the last chunk prefetches itself again: straight-line code, the loads are dropped
+    compute(bA, bB, 0, c, 1, cn);
+    compute(bB, bA, 1, c, 2, -1);
+    compute(bA, bB, 2, c, 3, -1);
+    compute(bB, bA, 3, cn, 0, -1);
+    mask_a(aN, cn);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) aC[q] = aN[q];
+  }
+}
+
+template <bool A_GLOBAL>
+__device__ __forceinline__ void wave_layer_nb(const float *Wf, int K, int NB, const float *arow, f32x16 (&acc)[8]) {
+  if (NB > 4) wave_layer<8, A_GLOBAL>((const float4 *)Wf, K, NB, arow, acc);
+  else if (NB > 2) wave_layer<4, A_GLOBAL>((const float4 *)Wf, K, NB, arow, acc);
+  else if (NB == 2) wave_layer<2, A_GLOBAL>((const float4 *)Wf, K, NB, arow, acc);
+  else wave_layer<1, A_GLOBAL>((const float4 *)Wf, K, NB, arow, acc);
+}
+
+// bias + activation, accumulators (C layout: lane = column, registers = rows) -> the wave's tile (row-major)
+__device__ __forceinline__ void wave_store_act(const f32x16 (&acc)[8], const float *bias, int NB, int activation, float *tile) {
+  const int lane = threadIdx.x & 63, col = lane & 31, hh = lane >> 5;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    if (j < NB) {
+      const int nn = j * 32 + col;
+      const float b = bias[nn];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) tile[((q & 3) + 8 * (q >> 2) + 4 * hh) * MW_LD + nn] = act_fn(acc[j][q] + b, activation);
+    }
+  }
+}
+
+// value_fc2's bias + activation, value_fc3 and the sigmoid (network.h:14,75) straight from the accumulators: lane (col, hh)
+// holds column j * 32 + col of 16 rows per block, so its share of a row's dot product is sum_j act(acc[j][q] + b2) * w3, and
+// a butterfly over the 32 lanes of its half finishes the rows -- no trip through the tile, no 256-long serial chain
+__device__ __forceinline__ void wave_value_head(const f32x16 (&acc)[8], const float *b2, const float *w3, float b3, int NB, int activation,
+                                                float *values, uint32_t row0, uint32_t n_rows) {
+  const int lane = threadIdx.x & 63, col = lane & 31, hh = lane >> 5;
+  float part[16];
+#pragma unroll
+  for (int q = 0; q < 16; ++q) part[q] = 0.0f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    if (j < NB) {
+      const float b = b2[j * 32 + col], w = w3[j * 32 + col];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) part[q] = fmaf(act_fn(acc[j][q] + b, activation), w, part[q]);
+    }
+  }
+#pragma unroll
+  for (int off = 1; off < 32; off <<= 1)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) part[q] += __shfl_xor(part[q], off, 64);
+  float y = part[0];
+#pragma unroll
+  for (int q = 1; q < 16; ++q) y = (col & 15) == q ? part[q] : y;
+  const uint32_t row = (uint32_t)((col & 3) + 8 * ((col & 15) >> 2) + 4 * hh);
+  if (col < 16 && row < n_rows) values[row0 + row] = 1.0f / (1.0f + expf(-(y + b3)));
+}
+
+__global__ __launch_bounds__(MN_BLOCK) void k_mainnet_wave(MainArgs a) {
+  extern __shared__ __align__(16) float lds_f[];
+  const NetDev &N = a.net;
+  const int H = N.H, VH = N.VH;
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
+  float *tile = lds_f + wave * 32 * MW_LD;
+  const float *trow = tile + r * MW_LD;
+  const uint32_t ntiles = (a.n + 31) / 32;
+  for (uint32_t wt = blockIdx.x * 4 + wave; wt < ntiles; wt += gridDim.x * 4) {
+    const uint32_t row0 = wt * 32;
+    const uint32_t n_rows = min(32u, a.n - row0);
+    const uint32_t grow = row0 + (r < n_rows ? r : n_rows - 1); // rows past the batch repeat the last one and are dropped below
+    f32x16 acc[8];
+    MN_T0();
+    wave_layer_nb<true>(N.w0f, N.emb_dim, H / 32, a.emb + (size_t)grow * N.emb_dim, acc);
+    MN_MARK(10);
+    __builtin_amdgcn_wave_barrier(); // (the previous tile's value_fc2 reads of the tile come first)
+    wave_store_act(acc, N.b0, H / 32, N.activation, tile);
+    __builtin_amdgcn_wave_barrier();
+    MN_MARK(11);
+    wave_layer_nb<false>(N.w1f, H, H / 32, trow, acc);
+    MN_MARK(12);
+    __builtin_amdgcn_wave_barrier();
+    wave_store_act(acc, N.b1, H / 32, N.activation, tile);
+    __builtin_amdgcn_wave_barrier();
+    if (a.h1_out) { // keep fc1's activations for the policy heads
+      for (uint32_t row = 0; row < n_rows; ++row)
+        for (uint32_t c = lane; c < (uint32_t)H; c += 64) a.h1_out[(size_t)(row0 + row) * H + c] = tile[row * MW_LD + c];
+    }
+    MN_MARK(13);
+    wave_layer_nb<false>(N.w2f, H, VH / 32, trow, acc);
+    MN_MARK(14);
+    wave_value_head(acc, N.b2, N.w3, N.b3, VH / 32, N.activation, a.values, row0, n_rows);
+    MN_MARK(15);
+  }
+}
+
 // ---- policy heads: value_policy_inference's logits (network.h:102-123, main-net.h:67-107) ----------
 // Encode::Battle::Policy::get_index (encode/battle/policy.h:29-58) on the raw battle bytes
 __device__ __forceinline__ uint32_t policy_index(const uint8_t *side, uint32_t choice) {
@@ -1694,6 +1874,8 @@ int oakgpu_leaf_set_lds_limits(void) { // per DEVICE (hipFuncSetAttribute applie
   if (e != hipSuccess) return oakgpu_fail_hip((int)e, "hipFuncSetAttribute(k_embed_lds<active>)");
   e = hipFuncSetAttribute((const void *)oak::k_policy, hipFuncAttributeMaxDynamicSharedMemorySize, oak::POLICY_LDS_LIMIT);
   if (e != hipSuccess) return oakgpu_fail_hip((int)e, "hipFuncSetAttribute(k_policy)");
+  e = hipFuncSetAttribute((const void *)oak::k_mainnet_wave, hipFuncAttributeMaxDynamicSharedMemorySize, (int)oak::MW_BYTES);
+  if (e != hipSuccess) return oakgpu_fail_hip((int)e, "hipFuncSetAttribute(k_mainnet_wave)");
   e = hipFuncSetAttribute((const void *)oak::k_mainnet_direct, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
   if (e != hipSuccess) return oakgpu_fail_hip((int)e, "hipFuncSetAttribute(k_mainnet_direct)");
   e = hipFuncSetAttribute((const void *)oak::k_mainnet, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
@@ -1771,11 +1953,15 @@ static int leaf_eval_impl(oakgpu_ctx *ctx, oakgpu_net *net, const uint8_t *battl
   oak::MainArgs ma{D, emb, n, values, h1};
   const int hld = (D.H > D.VH ? D.H : D.VH) + 1;
   const size_t mn_lds = (size_t)((oak::TM + oak::MAXH) * (oak::KC_MAIN + 1) + oak::TM * hld) * 4;
-  static const int main_impl = getenv("OAKGPU_MAINNET_IMPL") ? atoi(getenv("OAKGPU_MAINNET_IMPL")) : 2;
+  static const int main_impl = getenv("OAKGPU_MAINNET_IMPL") ? atoi(getenv("OAKGPU_MAINNET_IMPL")) : 3;
   if (main_impl == 1) // LDS-staged weights (A/B)
     hipLaunchKernelGGL(oak::k_mainnet, dim3((n + oak::TM - 1) / oak::TM), dim3(oak::MN_BLOCK), mn_lds, stream, ma);
-  else
+  else if (main_impl == 2) // four-wave tiles with workgroup barriers (A/B)
     hipLaunchKernelGGL(oak::k_mainnet_direct, dim3((n + oak::TM - 1) / oak::TM), dim3(oak::MN_BLOCK), (size_t)oak::TM * (oak::MAXH + 1) * 4, stream, ma);
+  else {
+    const uint32_t wgs = ((n + 31) / 32 + 3) / 4;
+    hipLaunchKernelGGL(oak::k_mainnet_wave, dim3(wgs < 256 ? wgs : 256), dim3(oak::MN_BLOCK), oak::MW_BYTES, stream, ma);
+  }
   if (tev) (void)hipEventRecord(tev[3], stream);
   if (pol) {
     oak::PolicyArgs pa = *pol;
