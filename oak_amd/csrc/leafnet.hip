@@ -32,13 +32,14 @@ struct NetDev {
   const float *p_w1, *a_w1; // second layers in file layout [out][hidden] (MFMA B operand of k_embed_tile)
   // k_embed_arows: the active net's W0^T with every row de-interleaved [even channels | odd channels] and padded to 128
   // floats, + an all-zero row 427 (absent move slots point at it); W1 in MFMA-fragment order [n-block][k-step][lane]
-  const float *a_w0d, *a_w1f;
+  const float *a_w0d, *a_w1f, *a_wdf;
   int p_hidden, p_out, a_hidden, a_out;
   int side_dim, emb_dim;
   int activation; // 1 relu, 2 clamp
   // main net (value path), rows padded to multiples of 32 with zeros
   const float *w0, *b0, *w1, *b1, *w2, *b2, *w3;
   const float *w0f, *w1f, *w2f; // the same three weight matrices in MFMA-fragment order (frag_order below), for k_mainnet_direct
+  const float *w0g, *w1g, *w2g; // ... and in k_mainnet_wave's order (frag_order_wave): a sub-chunk's fragments contiguous
   float b3;
   int H, VH; // padded dims
   // policy heads (main-net.h:67-107): fc2 [PHp][H] (rows padded to 32), fc3 [315][PHp] (+ biases)
@@ -800,63 +801,77 @@ __global__ __launch_bounds__(ER_BLOCK) void k_embed_rows(EmbedTileArgs a) {
   EL_FLUSH();
 }
 
-// ---- K2, the actives' pass in the same row-per-lane form as k_embed_rows (the default).  An active's ~45 non-zero
-// features fall into three kinds, and each gets the cheapest treatment that its structure allows:
-//   36 FIXED rows  (bias, the 5 active stats, 6 boosts, 19 volatile features, the stored Pokemon's 5 stats): the row is known
-//                  at compile time, only the VALUE differs per item -- constant LDS offsets, no index, and a row whose value
-//                  is 0 for every item of the wave (most volatile flags) is skipped with one ballot;
-//    9 ONE-HOT rows in LDS (2 types, 4 durations, status, 2 stored types): a 16-bit LDS offset per item, absent = the zero row;
-//    8 MOVE rows   (4 active + 4 stored move slots, 328 possible rows): read from the de-interleaved copy in L2
+// ---- K2, the actives' pass (the default): row-per-lane like k_embed_rows, with the DENSE part of the first layer on the
+// matrix pipe.  An active's ~53 candidate features fall into three kinds:
+//   36 DENSE features (bias, the 5 active stats, 6 boosts, 19 volatile features, the stored Pokemon's 5 stats): the weight
+//                  row is the same for every item, only the VALUE differs -- a 32-item x 36 x 128 GEMM.  It runs as
+//                  H^T = W0d^T . X^T on v_mfma_f32_32x32x2_f32 (A = the weight fragment, B = the items' values), because in
+//                  THAT orientation the result lands as "lane = item, registers = channels": lane (r, hh) receives channels
+//                  32 blk + (q & 3) + 8 (q >> 2) + 4 hh of item r -- already the A operand of the second layer's MFMAs, if W1's
+//                  fragments and the sparse rows use the same channel order (ar_channel).  18 k-steps x 4 blocks = 72 MFMAs
+//                  replace 36 x 16 ds_read_b128 + 36 x 64 FMAs per lane;
+//    9 ONE-HOT rows in LDS (2 types, 4 durations, status, 2 stored types; 64 possible rows): a 16-bit LDS offset per item,
+//                  absent = the zero row; added to the MFMA result with FMAs as in k_embed_rows;
+//    8 MOVE rows   (4 active + 4 stored move slots, 328 possible rows): read from a copy in L2 in the same channel order
 //                  (`a_w0d`, 219 KB), absent = its zero row.
-// A lane accumulates all 64 of its hidden channels (k = 2j + hh) in registers, then runs the <= 4 output blocks one after
-// the other with that block's W1 fragment streamed from L2 (`a_w1f`, coalesced 256 B per k-step) 16 k-steps at a time, the
-// next chunk's loads issued ahead of the current chunk's MFMAs.  No activation tile, no workgroup barrier per tile, every
-// wave on the MFMA; the kernel fits 128 registers so that a CU holds ONE 16-wave workgroup (4 waves per SIMD, 149 KB of
-// LDS): with 8 waves of 256 registers the two waves of a SIMD sat in the same phase at the same time (157 us vs 144 us).
-constexpr int AR_SLOTS = 101;                 // 99 LDS-resident rows (active_lds_slot) + the bias + a zero row
-constexpr int AR_BIAS = 99, AR_ZERO = 100;
-constexpr int AR_FIXED = 36, AR_HOT = 9, AR_MOVES = 8;
-constexpr int AR_ITEM_WORDS = AR_FIXED + 5 + 4; // 36 values, 9 u16 LDS offsets (5 words), 8 u16 global rows (4 words)
+// Then the <= 4 output blocks one after the other with that block's W1 fragment streamed from L2 (`a_w1f`, coalesced 256 B
+// per k-step) 16 k-steps at a time, the next chunk's loads issued ahead of the current chunk's MFMAs.  No activation tile,
+// no workgroup barrier per tile, every wave on the MFMA; the kernel fits 128 registers so that a CU holds ONE 16-wave
+// workgroup (4 waves per SIMD, 149 KB of LDS).
+constexpr int AR_SPARSE = 64, AR_ZERO = 64;   // LDS-resident one-hot rows (ar_sparse_slot) + a zero row
+constexpr int AR_FIXED = 36, AR_HOT = 9, AR_MOVES = 8, AR_KSTEPS = AR_FIXED / 2;
+constexpr int AR_ITEM_WORDS = 5 + 4;            // 9 u16 LDS offsets (5 words), 8 u16 global rows (4 words)
 constexpr int AR_WAVE_WORDS = ER_ITEMS * AR_ITEM_WORDS + 2 * ER_ITEMS;
 constexpr int AR_BLOCK = 1024, AR_WAVES = 16; // 16 waves = 4 per SIMD at <= 128 registers: the phases of different waves overlap
-constexpr size_t AR_BYTES = (size_t)(AR_SLOTS * ER_RS + AR_WAVES * AR_WAVE_WORDS) * 4;
-// LDS slot of fixed pair f (0..35): bias, active stats, boosts, volatiles, stored stats (rows 229..233 -> slots 65..69)
-__host__ __device__ constexpr int ar_fixed_slot(int f) { return f == 0 ? AR_BIAS : f < 6 ? f - 1 : f < 12 ? 20 + (f - 6) : f < 31 ? 26 + (f - 12) : 65 + (f - 31); }
+constexpr int AR_DENSE_WORDS = AR_KSTEPS * 4 * 64; // the dense weight fragment: [k-step][channel block][lane]
+constexpr size_t ar_bytes(int nbo) { return (size_t)((AR_SPARSE + 1) * ER_RS + AR_DENSE_WORDS + nbo * 64 * 64 + AR_WAVES * AR_WAVE_WORDS) * 4; }
+// channel held by register s (0..63) of a lane in half hh: the C layout of four 32x32 MFMA blocks, block b's row i being
+// channel 4 i + b (so that a lane's float4 of a weight row feeds the four blocks)
+__host__ __device__ constexpr int ar_channel(int s, int hh) { return 4 * ((s & 3) + 8 * ((s & 15) >> 2) + 4 * hh) + (s >> 4); }
+// W0^T row of dense feature d (1..35; 0 is the bias): active stats, boosts, volatiles, the stored Pokemon's stats
+__host__ __device__ constexpr int ar_dense_row(int d) { return d < 6 ? d - 1 : d < 12 ? 20 + (d - 6) : d < 31 ? 26 + (d - 12) : 229 + (d - 31); }
+// compact LDS slot of a one-hot row (types 5..19, rows 209..228, rows 398..426) and back
+__device__ __forceinline__ uint32_t ar_sparse_slot(uint32_t row) { return row < 20 ? row - 5 : row < 229 ? row - 209 + 15 : row - 398 + 35; }
+__host__ __device__ constexpr int ar_sparse_row(int slot) { return slot < 15 ? slot + 5 : slot < 35 ? slot - 15 + 209 : slot - 35 + 398; }
 __global__ __launch_bounds__(AR_BLOCK) void k_embed_arows(EmbedTileArgs a) {
   extern __shared__ __align__(16) float lds_f[];
   const NetDev &N = a.net;
   const int hidden = N.a_hidden, out_dim = N.a_out;
   const int NBo = (out_dim + 31) >> 5;
-  float *W0s = lds_f;
-  for (int i = threadIdx.x; i < AR_SLOTS * 128; i += AR_BLOCK) { // slot, position hh * 64 + j  <-  channel 2j + hh
-    const int sl = i >> 7, pos = i & 127, c = 2 * (pos & 63) + (pos >> 6);
-    float v = 0.0f;
-    if (c < hidden) v = sl < 99 ? N.a_w0t[(size_t)active_lds_row(sl) * hidden + c] : sl == AR_BIAS ? N.a_b0[c] : 0.0f;
-    W0s[sl * ER_RS + pos] = v;
+  float *W0s = lds_f;                                   // sparse rows, channels in natural order
+  float *Wd = W0s + (AR_SPARSE + 1) * ER_RS;            // dense fragment (a_wdf, built at load time)
+  for (int i = threadIdx.x; i < (AR_SPARSE + 1) * 128; i += AR_BLOCK) {
+    const int sl = i >> 7, c = i & 127;
+    W0s[sl * ER_RS + c] = (sl < AR_SPARSE && c < hidden) ? N.a_w0t[(size_t)ar_sparse_row(sl) * hidden + c] : 0.0f;
   }
+  for (int i = threadIdx.x; i < AR_DENSE_WORDS; i += AR_BLOCK) Wd[i] = N.a_wdf[i];
+  float *W1s = Wd + AR_DENSE_WORDS;                     // the second layer's fragments (a_w1f): [block][k-step][lane]
+  for (int i = threadIdx.x; i < NBo * 64 * 64; i += AR_BLOCK) W1s[i] = N.a_w1f[i];
   const uint32_t lane = threadIdx.x & 63, wib = threadIdx.x >> 6, r32 = lane & 31, hh = lane >> 5;
-  uint32_t *wl = (uint32_t *)(W0s + AR_SLOTS * ER_RS) + wib * AR_WAVE_WORDS; // this wave's private LDS
+  uint32_t *wl = (uint32_t *)(W1s + NBo * 64 * 64) + wib * AR_WAVE_WORDS; // this wave's private LDS
   uint32_t *dst_off = wl + ER_ITEMS * AR_ITEM_WORDS;
   float *hp_ratio = (float *)(dst_off + ER_ITEMS);
   const uint32_t items = a.n * 2;
   const uint32_t nmt = (items + ER_ITEMS - 1) / ER_ITEMS;
   const uint32_t stride = gridDim.x * AR_WAVES;
-  __syncthreads(); // W0s staged (the only workgroup barrier of the kernel)
+  __syncthreads(); // weights staged (the only workgroup barrier of the kernel)
   EL_T0();
   EL_MARK(0);
   for (uint32_t mt = blockIdx.x * AR_WAVES + wib; mt < nmt; mt += stride) {
-    // ---- lists: lane r (hh = 0) encodes item r straight from global memory (two dependent loads: order -> stored Pokemon) ----
-    if (hh == 0) {
+    // ---- encode: BOTH lanes (r, 0) and (r, 1) encode item r straight from global memory (two dependent loads: order ->
+    // stored Pokemon) -- the same instructions for the whole wave; each keeps the dense values of its own k-half in
+    // registers (x[t] = value 2t + hh, the B operand below) and lane (r, 0) writes the row indices to the wave's LDS ----
+    float x[AR_KSTEPS];
+    {
       const uint32_t g = mt * ER_ITEMS + r32;
-      uint32_t *it = wl + r32 * AR_ITEM_WORDS;
-      float *fv = (float *)it;                          // 36 fixed-row values
-      uint16_t *hot = (uint16_t *)(it + AR_FIXED);      // 9 LDS offsets (in floats / 4: slot * ER_RS fits 16 bits)
-      uint16_t *mv = (uint16_t *)(it + AR_FIXED + 5);   // 8 global rows
+      float fv[AR_FIXED];
+      uint32_t hot[AR_HOT], mv[AR_MOVES];
       uint32_t doff = 0xFFFFFFFFu, dead_off = 0xFFFFFFFFu;
+      float hpr = 0.0f;
 #pragma unroll
       for (int f = 0; f < AR_FIXED; ++f) fv[f] = 0.0f;
 #pragma unroll
-      for (int k = 0; k < AR_HOT; ++k) hot[k] = (uint16_t)(AR_ZERO * ER_RS / 4);
+      for (int k = 0; k < AR_HOT; ++k) hot[k] = AR_ZERO * ER_RS / 4;
 #pragma unroll
       for (int k = 0; k < AR_MOVES; ++k) mv[k] = 427;
       if (g < items) {
@@ -882,95 +897,97 @@ __global__ __launch_bounds__(AR_BLOCK) void k_embed_arows(EmbedTileArgs a) {
             uint32_t fidx = 0; float fval = 0.0f;
             const bool v = active_feature(j, av0.x, av0.y, av0.z, av0.w, av1.x, av1.y, av1.z, av1.w, dur, fidx, fval);
             if (j < 5) fv[1 + j] = fval;                                   // stats: always present
-            else if (j < 7) { hot[nh++] = v ? (uint16_t)(active_lds_slot(fidx) * ER_RS / 4) : (uint16_t)(AR_ZERO * ER_RS / 4); } // types
+            else if (j < 7) { hot[nh++] = v ? ar_sparse_slot(fidx) * ER_RS / 4 : AR_ZERO * ER_RS / 4; } // types
             else if (j < 13) fv[6 + (j - 7)] = fval;                       // boosts: always present
-            else if (j < 32) fv[12 + (j - 13)] = v ? fval : 0.0f;          // volatiles: fixed rows, value 0 when absent
-            else if (j < 36) { mv[nm++] = v ? (uint16_t)fidx : (uint16_t)427; } // move slots: rows in L2
-            else { hot[nh++] = v ? (uint16_t)(active_lds_slot(fidx) * ER_RS / 4) : (uint16_t)(AR_ZERO * ER_RS / 4); } // durations
+            else if (j < 32) fv[12 + (j - 13)] = v ? fval : 0.0f;          // volatiles: dense, value 0 when absent
+            else if (j < 36) { mv[nm++] = v ? fidx : 427u; }               // move slots: rows in L2
+            else { hot[nh++] = v ? ar_sparse_slot(fidx) * ER_RS / 4 : AR_ZERO * ER_RS / 4; } // durations
           }
 #pragma unroll
           for (uint32_t j = 0; j < 12; ++j) { // Encode::Battle::Pokemon of the stored active (battle.h:197-214), rows + 229
             uint32_t fidx = 0; float fval = 0.0f;
             const bool v = pokemon_feature(j, pk0, pk1, pk2, pk3, pk4, pk5, dur & 7, fidx, fval);
             if (j < 5) fv[31 + j] = fval;
-            else if (j < 9) { mv[nm++] = v ? (uint16_t)(fidx + 229) : (uint16_t)427; }
-            else { hot[nh++] = v ? (uint16_t)(active_lds_slot(fidx + 229) * ER_RS / 4) : (uint16_t)(AR_ZERO * ER_RS / 4); }
+            else if (j < 9) { mv[nm++] = v ? fidx + 229 : 427u; }
+            else { hot[nh++] = v ? ar_sparse_slot(fidx + 229) * ER_RS / 4 : AR_ZERO * ER_RS / 4; }
           }
-          hp_ratio[r32] = (float)hp / (float)(pk0 & 0xFFFF);
+          hpr = (float)hp / (float)(pk0 & 0xFFFF);
         }
       }
-      dst_off[r32] = doff;
-      if (dead_off != 0xFFFFFFFFu) for (int o = 0; o <= out_dim; ++o) a.emb[(size_t)dead_off + o] = 0.0f;
+#pragma unroll
+      for (int t = 0; t < AR_KSTEPS; ++t) x[t] = hh ? fv[2 * t + 1] : fv[2 * t];
+      if (hh == 0) {
+        uint32_t *it = wl + r32 * AR_ITEM_WORDS;
+        it[0] = hot[0] | hot[1] << 16; it[1] = hot[2] | hot[3] << 16; it[2] = hot[4] | hot[5] << 16; it[3] = hot[6] | hot[7] << 16; it[4] = hot[8];
+        it[5] = mv[0] | mv[1] << 16; it[6] = mv[2] | mv[3] << 16; it[7] = mv[4] | mv[5] << 16; it[8] = mv[6] | mv[7] << 16;
+        dst_off[r32] = doff;
+        hp_ratio[r32] = hpr;
+        if (dead_off != 0xFFFFFFFFu) for (int o = 0; o <= out_dim; ++o) a.emb[(size_t)dead_off + o] = 0.0f;
+      }
     }
     __builtin_amdgcn_wave_barrier();
     EL_MARK(3);
-    // ---- first layer: this lane's 64 hidden channels of item r32 ----
-    const uint32_t *it = wl + r32 * AR_ITEM_WORDS;
-    const float *fv = (const float *)it;
-    const uint16_t *hot = (const uint16_t *)(it + AR_FIXED);
-    const uint16_t *mvr = (const uint16_t *)(it + AR_FIXED + 5);
-    float h[64];
+    // ---- first layer, dense part on the matrix pipe: hb[blk] = this lane's 16 channels of block blk of item r32 ----
+    f32x16 hb[4];
 #pragma unroll
-    for (int j = 0; j < 64; ++j) h[j] = 0.0f;
-    // one weight row at a time, a quarter row (4 x ds_read_b128 = 16 registers) in flight: the loops below are NOT unrolled
-    // over the rows on purpose -- the kernel has to fit 128 registers (4 waves per SIMD)
-    auto axpy = [&](const float4 *w, float v) {
+    for (int b = 0; b < 4; ++b)
 #pragma unroll
-      for (int part = 0; part < 4; ++part) {
-        float4 x[4];
+      for (int q = 0; q < 16; ++q) hb[b][q] = 0.0f;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) x[u] = w[4 * part + u];
+    for (int t = 0; t < AR_KSTEPS; ++t) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int j = 16 * part + 4 * u;
-          h[j + 0] = fmaf(x[u].x, v, h[j + 0]); h[j + 1] = fmaf(x[u].y, v, h[j + 1]);
-          h[j + 2] = fmaf(x[u].z, v, h[j + 2]); h[j + 3] = fmaf(x[u].w, v, h[j + 3]);
-        }
-      }
-    };
-#pragma unroll 1
-    for (int f = 0; f < AR_FIXED; ++f) {
-      const float v = fv[f];
-      if (f >= 12 && f < 31 && __ballot(v != 0.0f) == 0) continue; // a volatile feature nobody in this wave has
-      axpy((const float4 *)(W0s + ar_fixed_slot(f) * ER_RS + hh * 64), v);
+      for (int b = 0; b < 4; ++b) hb[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(Wd[(t * 4 + b) * 64 + lane], x[t], hb[b], 0, 0, 0);
     }
-#pragma unroll 1
-    for (int k = 0; k < AR_HOT; ++k) axpy((const float4 *)(W0s + (uint32_t)hot[k] * 4 + hh * 64), 1.0f);
-#pragma unroll 1
-    for (int k = 0; k < AR_MOVES; ++k) axpy((const float4 *)(N.a_w0d + (size_t)mvr[k] * 128 + hh * 64), 1.0f); // rows in L2
+    // ---- the one-hot and move rows.  Read "lane = item" they cost a 16-byte piece of 64 different cache lines per load
+    // instruction (8,192 line requests per mini-tile: the L1 was the bottleneck of the whole kernel).  So they are read
+    // "lane = channels": in k-step t the half-wave hh sums the 17 rows of item 2t + hh, lane (i, hh) taking channels
+    // 4i .. 4i+3 (one float4: a half-wave reads a whole 512-byte row per instruction), and an MFMA against the identity
+    // (B[k][j] = [k == j]) transposes-and-accumulates the sums into the "lane = item" registers: D[channel][item j] +=
+    // sum[item k][channel] [k == j] -- exact in fp32, 64 more MFMAs per mini-tile.
+#pragma unroll 2
+    for (int t = 0; t < 16; ++t) {
+      const uint32_t *ip = wl + (2 * t + hh) * AR_ITEM_WORDS;
+      uint32_t iw[9];
 #pragma unroll
-    for (int j = 0; j < 64; ++j) h[j] = act_fn(h[j], N.activation);
+      for (int k = 0; k < 9; ++k) iw[k] = ip[k];
+      float4 g[AR_MOVES];
+#pragma unroll
+      for (int k = 0; k < AR_MOVES; ++k) {
+        const uint32_t row = (iw[5 + (k >> 1)] >> (16 * (k & 1))) & 0xFFFF;
+        g[k] = *(const float4 *)(N.a_w0d + (size_t)row * 128 + 4 * r32); // rows in L2
+      }
+      float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int k = 0; k < AR_HOT; ++k) {
+        const uint32_t off = (iw[k >> 1] >> (16 * (k & 1))) & 0xFFFF;
+        const float4 x = *(const float4 *)(W0s + off * 4 + 4 * r32);
+        sum.x += x.x; sum.y += x.y; sum.z += x.z; sum.w += x.w;
+      }
+#pragma unroll
+      for (int k = 0; k < AR_MOVES; ++k) { sum.x += g[k].x; sum.y += g[k].y; sum.z += g[k].z; sum.w += g[k].w; }
+      const float ident = (uint32_t)(2 * t) + hh == r32 ? 1.0f : 0.0f;
+      hb[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(sum.x, ident, hb[0], 0, 0, 0);
+      hb[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(sum.y, ident, hb[1], 0, 0, 0);
+      hb[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(sum.z, ident, hb[2], 0, 0, 0);
+      hb[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(sum.w, ident, hb[3], 0, 0, 0);
+    }
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) hb[b][q] = act_fn(hb[b][q], N.activation);
     __builtin_amdgcn_sched_barrier(0);
     EL_MARK(4);
-    // ---- second layer: one 32-wide output block after the other; the W1 fragments stream from L2 in chunks of 16 k-steps,
-    // the next chunk's loads issued before the current chunk's MFMAs ----
-    float bfa[16], bfb[16];
-    const float *wf = N.a_w1f + lane;
-#pragma unroll
-    for (int s = 0; s < 16; ++s) bfa[s] = wf[(size_t)s * 64];
+    // ---- second layer: one 32-wide output block after the other, W1 fragments from LDS (256 B per k-step, conflict-free) ----
 #pragma unroll 1
     for (int nb = 0; nb < NBo; ++nb) {
       f32x16 acc;
 #pragma unroll
       for (int q = 0; q < 16; ++q) acc[q] = 0.0f;
-      const float *wc = wf + (size_t)nb * 64 * 64;
-      const float *wnext = wf + (size_t)(nb + 1 < NBo ? nb + 1 : nb) * 64 * 64; // the last block re-reads itself: no branch
+      const float *wc = W1s + nb * 64 * 64 + lane;
 #pragma unroll
-      for (int s = 0; s < 16; ++s) bfb[s] = wc[(size_t)(16 + s) * 64];
+      for (int b = 0; b < 4; ++b)
 #pragma unroll
-      for (int s = 0; s < 16; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(h[s], bfa[s], acc, 0, 0, 0);
-#pragma unroll
-      for (int s = 0; s < 16; ++s) bfa[s] = wc[(size_t)(32 + s) * 64];
-#pragma unroll
-      for (int s = 0; s < 16; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(h[16 + s], bfb[s], acc, 0, 0, 0);
-#pragma unroll
-      for (int s = 0; s < 16; ++s) bfb[s] = wc[(size_t)(48 + s) * 64];
-#pragma unroll
-      for (int s = 0; s < 16; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(h[32 + s], bfa[s], acc, 0, 0, 0);
-#pragma unroll
-      for (int s = 0; s < 16; ++s) bfa[s] = wnext[(size_t)s * 64];
-#pragma unroll
-      for (int s = 0; s < 16; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(h[48 + s], bfb[s], acc, 0, 0, 0);
+        for (int s2 = 0; s2 < 16; ++s2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(hb[b][s2], wc[(b * 16 + s2) * 64], acc, 0, 0, 0);
       const int o = nb * 32 + (int)r32;
       const float ob = o < out_dim ? N.a_b1[o] : 0.0f;
 #pragma unroll
@@ -1404,8 +1421,8 @@ __global__ __launch_bounds__(MN_BLOCK) void k_mainnet_direct(MainArgs a) {
 // to 8) 32-wide output blocks of a layer: fc0's A operands come straight from the embedding rows in global memory (lane
 // (r, h) reads 32 B of row r per 8 k-steps, prefetched one sub-chunk ahead like the weights), the hand-over between layers
 // goes through the wave's PRIVATE 32 x 257 LDS tile (C layout -> A layout) and needs no workgroup barrier at all.  Weight
-// fragments are the same arrays as k_mainnet_direct's (frag_order), read 8 k-steps at a time: 2 x 64 registers of B
-// fragments + 128 accumulators.  L2 traffic is unchanged (there, the two waves of a row-half pair read the same fragments).
+// fragments as in k_mainnet_direct but ordered by sub-chunk (frag_order_wave), read 8 k-steps at a time: 2 x 64 registers
+// of B fragments + 128 accumulators.  L2 traffic is unchanged (there, the two waves of a row-half pair read the same fragments).
 constexpr int MW_LD = MAXH + 1;
 constexpr size_t MW_BYTES = (size_t)4 * 32 * MW_LD * 4;
 
@@ -1422,7 +1439,7 @@ __device__ __forceinline__ void wave_layer(const float4 *Wf, int K, int NB, cons
 #pragma unroll
     for (int q = 0; q < 16; ++q) acc[j][q] = 0.0f;
   // sub-chunk (c, u): k-steps 8u .. 8u+7 of chunk c = float4 q = 2u, 2u+1 of every n-block's fragment
-  auto wptr = [&](int c, int u) { return Wf + ((size_t)c * NB * 8 + 2 * u) * 64 + lane; };
+  auto wptr = [&](int t) { return Wf + (size_t)t * NBc * 128; }; // sub-chunk t = 4c + u; wave-uniform: a scalar base
   auto load_a = [&](float4 (&av)[8], int c) {
     const int col = c * 64 + h * 32;
     if (A_GLOBAL) { // columns past K: the address is clamped instead of the load predicated (a predicated load cannot be hoisted)
@@ -1442,48 +1459,52 @@ __device__ __forceinline__ void wave_layer(const float4 *Wf, int K, int NB, cons
     for (int q = 0; q < 8; ++q)
       if (col + 4 * q >= K) av[q] = make_float4(0.f, 0.f, 0.f, 0.f);
   };
-  auto load_b = [&](float4 (&bv)[NBc][2], int c, int u) {
-    const float4 *w = wptr(c, u);
-#pragma unroll
-    for (int j = 0; j < NBc; ++j) {
-      const int nb = j < NB ? j : NB - 1;
-      bv[j][0] = w[(size_t)nb * 8 * 64]; bv[j][1] = w[(size_t)nb * 8 * 64 + 64];
-    }
-  };
-  // the MFMAs of one sub-chunk; the next one's weight loads are issued in front of its FIRST k-step: the wave's instruction
-  // stream advances at the matrix pipe's pace, so a load placed in front of step s is issued (8 - s) x 512 cycles before
-  // the next sub-chunk needs it.  Measured (main net, us): two loads per k-step 385, four 366, all sixteen up front 356-361,
-  // one behind each MFMA of the first two k-steps 367.
-  auto compute = [&](const float4 (&bv)[NBc][2], float4 (&bn)[NBc][2], int u, int cn, int un, int ca) {
-    const float4 *wn = wptr(cn, un);
+  // The MFMAs of one sub-chunk (flat index t, fragments in P; Q holds sub-chunk t + 1).  Every half of a fragment buffer is
+  // refilled right after its last use: Q's second halves (k-steps 4..7 of t - 1) in front of step 0 with those of t + 1, P's
+  // first halves (k-steps 0..3 of t) in front of step 4 with those of t + 2 -- each load is issued 12 k-steps (6 k cycles of
+  // MFMA) before its first use, out of the same 128 registers as plain double-buffering (8 k-steps).  Measured with plain
+  // double-buffering (main net, us): two loads per k-step 385, four 366, all sixteen in front of step 0 356-361.
+  const int nsc = 4 * nch;
+  auto compute = [&](float4 (&P)[NBc][2], float4 (&Q)[NBc][2], int u, int t, int ca) {
+    const float4 *w1 = wptr(t + 1 < nsc ? t + 1 : nsc - 1) + 64 + lane; // past the end: the last sub-chunk again, dropped
+    const float4 *w2 = wptr(t + 2 < nsc ? t + 2 : nsc - 1) + lane;
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
+#ifndef OAKGPU_MW_EXPERIMENT_NO_B
       if (s == 0) {
 #pragma unroll
-        for (int j = 0; j < NBc; ++j) {
-          const int nb = j < NB ? j : NB - 1;
-          bn[j][0] = wn[(size_t)nb * 8 * 64]; bn[j][1] = wn[(size_t)nb * 8 * 64 + 64];
-        }
+        for (int j = 0; j < NBc; ++j) Q[j][1] = w1[j * 128];
       }
-      // the next chunk's A values, a whole chunk ahead -- issued BEHIND this sub-chunk's weight loads: the vector-memory
-      // counter retires in order, so the wait for those weights (one sub-chunk from now) would otherwise cover these too
+      if (s == 4) {
+#pragma unroll
+        for (int j = 0; j < NBc; ++j) P[j][0] = w2[j * 128];
+      }
+#endif
+      // the next chunk's A values, a whole chunk ahead -- issued BEHIND this sub-chunk's first weight loads: the vector-memory
+      // counter retires in order, so the next waits for weights would otherwise cover these (HBM latency) too
+#ifndef OAKGPU_MW_EXPERIMENT_NO_A
       if (ca >= 0 && s == 1) load_a(aN, ca);
+#endif
       const float a_s = f4_pick(aC[2 * u + (s >> 2)], s & 3);
 #pragma unroll
-      for (int j = 0; j < NBc; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_s, f4_pick(bv[j][s >> 2], s & 3), acc[j], 0, 0, 0);
+      for (int j = 0; j < NBc; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_s, f4_pick(P[j][s >> 2], s & 3), acc[j], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
   };
-  load_b(bA, 0, 0);
+  {
+    const float4 *w0 = wptr(0) + lane, *w1 = wptr(1) + lane; // (nsc >= 4)
+#pragma unroll
+    for (int j = 0; j < NBc; ++j) { bA[j][0] = w0[j * 128]; bA[j][1] = w0[j * 128 + 64]; bB[j][0] = w1[j * 128]; }
+  }
   load_a(aC, 0);
   mask_a(aC, 0);
 #pragma unroll 1
   for (int c = 0; c < nch; ++c) {
     const int cn = c + 1 < nch ? c + 1 : c; // the last chunk prefetches itself again: straight-line code, the loads are dropped
-    compute(bA, bB, 0, c, 1, cn);
-    compute(bB, bA, 1, c, 2, -1);
-    compute(bA, bB, 2, c, 3, -1);
-    compute(bB, bA, 3, cn, 0, -1);
+    compute(bA, bB, 0, 4 * c, cn);
+    compute(bB, bA, 1, 4 * c + 1, -1);
+    compute(bA, bB, 2, 4 * c + 2, -1);
+    compute(bB, bA, 3, 4 * c + 3, -1);
     mask_a(aN, cn);
 #pragma unroll
     for (int q = 0; q < 8; ++q) aC[q] = aN[q];
@@ -1554,13 +1575,13 @@ __global__ __launch_bounds__(MN_BLOCK) void k_mainnet_wave(MainArgs a) {
     const uint32_t grow = row0 + (r < n_rows ? r : n_rows - 1); // rows past the batch repeat the last one and are dropped below
     f32x16 acc[8];
     MN_T0();
-    wave_layer_nb<true>(N.w0f, N.emb_dim, H / 32, a.emb + (size_t)grow * N.emb_dim, acc);
+    wave_layer_nb<true>(N.w0g, N.emb_dim, H / 32, a.emb + (size_t)grow * N.emb_dim, acc);
     MN_MARK(10);
     __builtin_amdgcn_wave_barrier(); // (the previous tile's value_fc2 reads of the tile come first)
     wave_store_act(acc, N.b0, H / 32, N.activation, tile);
     __builtin_amdgcn_wave_barrier();
     MN_MARK(11);
-    wave_layer_nb<false>(N.w1f, H, H / 32, trow, acc);
+    wave_layer_nb<false>(N.w1g, H, H / 32, trow, acc);
     MN_MARK(12);
     __builtin_amdgcn_wave_barrier();
     wave_store_act(acc, N.b1, H / 32, N.activation, tile);
@@ -1570,7 +1591,7 @@ __global__ __launch_bounds__(MN_BLOCK) void k_mainnet_wave(MainArgs a) {
         for (uint32_t c = lane; c < (uint32_t)H; c += 64) a.h1_out[(size_t)(row0 + row) * H + c] = tile[row * MW_LD + c];
     }
     MN_MARK(13);
-    wave_layer_nb<false>(N.w2f, H, VH / 32, trow, acc);
+    wave_layer_nb<false>(N.w2g, H, VH / 32, trow, acc);
     MN_MARK(14);
     wave_value_head(acc, N.b2, N.w3, N.b3, VH / 32, N.activation, a.values, row0, n_rows);
     MN_MARK(15);
@@ -1715,21 +1736,53 @@ std::vector<float> frag_order(const HostAffine &a, uint32_t out_pad) {
   return f;
 }
 
-// k_embed_arows: W0^T rows de-interleaved [even channels | odd channels], 128 floats per row, + an all-zero last row
-std::vector<float> deinterleave_rows(const HostAffine &a) { // a.w is [out = hidden][in]; row r of W0^T = column r of W
+// k_mainnet_wave's order: the same fragments, but the 2 float4 x NB n-blocks of one SUB-chunk (8 k-steps) are contiguous:
+// float4 (((c*4 + u)*NB + nb)*2 + qq)*64 + lane -> W[nb*32 + r][c*64 + h*32 + 8u + 4qq .. +3], so the 16 loads of a sub-chunk
+// are one scalar base + the lane's offset + small constants (no per-block vector address arithmetic).  NB is rounded up to
+// the kernel's template width (1, 2, 4, 8) with all-zero blocks, so that every block index is a compile-time constant.
+std::vector<float> frag_order_wave(const HostAffine &a, uint32_t out_pad) {
+  const uint32_t nch = (a.in + 63) / 64, nb_real = out_pad / 32;
+  const uint32_t NB = nb_real > 4 ? 8 : nb_real > 2 ? 4 : nb_real; // the kernel's block count (wave_layer_nb): absent blocks are zeros
+  std::vector<float> f((size_t)nch * NB * 8 * 64 * 4, 0.0f);
+  for (uint32_t c = 0; c < nch; ++c)
+    for (uint32_t u = 0; u < 4; ++u)
+      for (uint32_t nb = 0; nb < NB; ++nb)
+        for (uint32_t qq = 0; qq < 2; ++qq)
+          for (uint32_t lane = 0; lane < 64; ++lane)
+            for (uint32_t e = 0; e < 4; ++e) {
+              const uint32_t row = nb * 32 + (lane & 31), col = c * 64 + (lane >> 5) * 32 + 8 * u + 4 * qq + e;
+              if (row < a.out && col < a.in) f[(((((size_t)c * 4 + u) * NB + nb) * 2 + qq) * 64 + lane) * 4 + e] = a.w[(size_t)row * a.in + col];
+            }
+  return f;
+}
+
+// k_embed_arows: W0^T padded to 128 floats per row, + an all-zero last row (the move rows are read from this copy)
+std::vector<float> arows_rows(const HostAffine &a) { // a.w is [out = hidden][in]; row r of W0^T = column r of W
   std::vector<float> d((size_t)(a.in + 1) * 128, 0.0f);
   for (uint32_t r = 0; r < a.in; ++r)
-    for (uint32_t c = 0; c < a.out && c < 128; ++c) d[(size_t)r * 128 + (c & 1) * 64 + (c >> 1)] = a.w[(size_t)c * a.in + r];
+    for (uint32_t c = 0; c < a.out && c < 128; ++c) d[(size_t)r * 128 + c] = a.w[(size_t)c * a.in + r];
   return d;
 }
-// ... and W1 [out][hidden] in MFMA-fragment order: [n-block][k-step s2][lane (r32, hh)] = W1[nb * 32 + r32][2 s2 + hh]
+// ... the dense part of W0 as the A operand of H^T = W0d^T . X^T: [k-step t][channel block][lane (i, hh)] =
+// W0[channel 4 i + blk][row of dense feature d = 2t + hh]  (d = 0: the bias)
+std::vector<float> arows_dense_frag(const HostAffine &a) {
+  std::vector<float> f((size_t)oak::AR_DENSE_WORDS, 0.0f);
+  for (uint32_t t = 0; t < (uint32_t)oak::AR_KSTEPS; ++t)
+    for (uint32_t blk = 0; blk < 4; ++blk)
+      for (uint32_t lane = 0; lane < 64; ++lane) {
+        const uint32_t d = 2 * t + (lane >> 5), c = 4 * (lane & 31) + blk;
+        if (c < a.out) f[((size_t)t * 4 + blk) * 64 + lane] = d == 0 ? a.b[c] : a.w[(size_t)c * a.in + (uint32_t)oak::ar_dense_row((int)d)];
+      }
+  return f;
+}
+// ... and W1 [out][hidden] in MFMA-fragment order: [n-block][k-step s][lane (r32, hh)] = W1[nb * 32 + r32][ar_channel(s, hh)]
 std::vector<float> embed_frag_order(const HostAffine &a) {
   const uint32_t NB = (a.out + 31) / 32;
   std::vector<float> f((size_t)NB * 64 * 64, 0.0f);
   for (uint32_t nb = 0; nb < NB; ++nb)
     for (uint32_t s2 = 0; s2 < 64; ++s2)
       for (uint32_t lane = 0; lane < 64; ++lane) {
-        const uint32_t o = nb * 32 + (lane & 31), c = 2 * s2 + (lane >> 5);
+        const uint32_t o = nb * 32 + (lane & 31), c = (uint32_t)oak::ar_channel((int)s2, (int)(lane >> 5));
         if (o < a.out && c < a.in) f[((size_t)nb * 64 + s2) * 64 + lane] = a.w[(size_t)o * a.in + c];
       }
   return f;
@@ -1798,7 +1851,8 @@ int oakgpu_net_load_memory(oakgpu_ctx *ctx, const void *bytes, size_t size, oakg
   rc = rc ? rc : upload(net, transpose(a0), &D.a_w0t);
   rc = rc ? rc : upload(net, a0.b, &D.a_b0);
   rc = rc ? rc : upload(net, a1.b, &D.a_b1);
-  rc = rc ? rc : upload(net, deinterleave_rows(a0), &D.a_w0d);
+  rc = rc ? rc : upload(net, arows_rows(a0), &D.a_w0d);
+  rc = rc ? rc : upload(net, arows_dense_frag(a0), &D.a_wdf);
   rc = rc ? rc : upload(net, embed_frag_order(a1), &D.a_w1f);
   rc = rc ? rc : upload(net, pad_rows(fc0, H, fc0.in), &D.w0);
   rc = rc ? rc : upload(net, pad_vec(fc0.b, H), &D.b0);
@@ -1810,6 +1864,9 @@ int oakgpu_net_load_memory(oakgpu_ctx *ctx, const void *bytes, size_t size, oakg
   rc = rc ? rc : upload(net, frag_order(fc0, H), &D.w0f);
   rc = rc ? rc : upload(net, frag_order(fc1, H), &D.w1f);
   rc = rc ? rc : upload(net, frag_order(v2, VH), &D.w2f);
+  rc = rc ? rc : upload(net, frag_order_wave(fc0, H), &D.w0g);
+  rc = rc ? rc : upload(net, frag_order_wave(fc1, H), &D.w1g);
+  rc = rc ? rc : upload(net, frag_order_wave(v2, VH), &D.w2g);
   {
     const HostAffine &q1a = L[8], &q1b = L[9], &q2a = L[10], &q2b = L[11];
     if (q1a.in != fc1.out || q2a.in != fc1.out || q1b.in != q1a.out || q2b.in != q2a.out || q1a.out != q2a.out ||
@@ -1868,7 +1925,7 @@ int oakgpu_leaf_set_lds_limits(void) { // per DEVICE (hipFuncSetAttribute applie
   if (e != hipSuccess) return oakgpu_fail_hip((int)e, "hipFuncSetAttribute(k_embed_rows)");
   e = hipFuncSetAttribute((const void *)oak::k_embed_rows<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)oak::ER_BYTES);
   if (e != hipSuccess) return oakgpu_fail_hip((int)e, "hipFuncSetAttribute(k_embed_rows<list>)");
-  e = hipFuncSetAttribute((const void *)oak::k_embed_arows, hipFuncAttributeMaxDynamicSharedMemorySize, (int)oak::AR_BYTES);
+  e = hipFuncSetAttribute((const void *)oak::k_embed_arows, hipFuncAttributeMaxDynamicSharedMemorySize, (int)oak::ar_bytes(4));
   if (e != hipSuccess) return oakgpu_fail_hip((int)e, "hipFuncSetAttribute(k_embed_arows)");
   e = hipFuncSetAttribute((const void *)oak::k_embed_lds<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)oak::ELayout<true>::BYTES);
   if (e != hipSuccess) return oakgpu_fail_hip((int)e, "hipFuncSetAttribute(k_embed_lds<active>)");
@@ -1925,7 +1982,7 @@ static int leaf_eval_impl(oakgpu_ctx *ctx, oakgpu_net *net, const uint8_t *battl
       }
       if (kind == 1 && embed_impl >= 4 && D.a_hidden <= 128 && D.a_out <= 128 && !getenv("OAKGPU_ACTIVE_TILE")) { // default actives' pass
         const uint32_t nmt = (n * 2 + oak::ER_ITEMS - 1) / oak::ER_ITEMS, wg = (nmt + oak::AR_WAVES - 1) / oak::AR_WAVES;
-        hipLaunchKernelGGL(oak::k_embed_arows, dim3(wg < 256 ? wg : 256), dim3(oak::AR_BLOCK), oak::AR_BYTES, stream, ta);
+        hipLaunchKernelGGL(oak::k_embed_arows, dim3(wg < 256 ? wg : 256), dim3(oak::AR_BLOCK), oak::ar_bytes((D.a_out + 31) / 32), stream, ta);
         continue;
       }
       if (kind == 0 && embed_impl >= 4 && rows_ok) { // default party-slot pass: every wave its own pipeline
