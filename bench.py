@@ -402,7 +402,7 @@ def leaf_records(args, torch, dev, rank, local_rank, world, dist, which=("leaf",
             _lib.check(lib.oakgpu_get_leaf_kernel_ms(h, ms))
             acc = [x + y for x, y in zip(acc, ms)]
         _lib.check(lib.oakgpu_set_kernel_timing(h, 0))
-        return {"k_embed_rows (party slots)": acc[0] / 5 * 1e3, "k_embed_arows (actives)": acc[1] / 5 * 1e3, "k_mainnet_wave": acc[2] / 5 * 1e3}
+        return {"k_embed_prows (party slots)": acc[0] / 5 * 1e3, "k_embed_arows (actives)": acc[1] / 5 * 1e3, "k_mainnet_wave": acc[2] / 5 * 1e3}
 
     out = {}
     K, W = args.steps, args.warmup
@@ -416,7 +416,7 @@ def leaf_records(args, torch, dev, rank, local_rank, world, dist, which=("leaf",
             "config": {"workload": "leaf part of configs[2]: value_inference (encode + embeddings + 768-256-256-256-1 MainNet + "
                                    "sigmoid) over 65536 mid-game states per GPU", "batch_per_gpu": n,
                        "parity": "<= 1e-5 vs numpy oracle pinned by the reference torch mirror"},
-            "roofline": {"bound": "mfma", "kernel": "oak::k_embed_rows + oak::k_embed_arows + oak::k_mainnet_wave (one value_inference call)",
+            "roofline": {"bound": "mfma", "kernel": "oak::k_embed_prows + oak::k_embed_arows + oak::k_mainnet_wave (one value_inference call)",
                          "achieved": achieved, "peak": 157.3, "unit": "TFLOP/s", "frac": achieved / 157.3, "traffic": None,
                          "avg_call_ms": avg_s * 1e3, "algorithmic_flop_per_leaf": main_f + emb_f, "mainnet_flop_per_leaf": main_f,
                          "kernel_us": kernel_us()},
@@ -441,7 +441,7 @@ def leaf_records(args, torch, dev, rank, local_rank, world, dist, which=("leaf",
                                    "tags (PokemonCache analogue); 40-turn episodes",
                        "batch_per_gpu": n, "leaf_evals_per_s": n * world * K / elapsed,
                        "live_lane_fraction": steps_done / (n * world * K)},
-            "roofline": {"bound": "mfma", "kernel": "oak::k_rollout_queue (1 step) + oak::k_party_tags + oak::k_embed_lds (changed party slots) + "
+            "roofline": {"bound": "mfma", "kernel": "oak::k_rollout_queue (1 step) + oak::k_party_tags + oak::k_embed_prows<list> (changed party slots) + "
                                                      "oak::k_embed_arows (actives) + oak::k_mainnet_wave",
                          "achieved": achieved, "peak": 157.3, "unit": "TFLOP/s", "frac": achieved / 157.3, "traffic": None,
                          "avg_step_ms": avg_s * 1e3, "algorithmic_flop_per_leaf": main_f + emb_f,

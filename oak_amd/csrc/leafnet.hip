@@ -32,7 +32,8 @@ struct NetDev {
   const float *p_w1, *a_w1; // second layers in file layout [out][hidden] (MFMA B operand of k_embed_tile)
   // k_embed_arows: the active net's W0^T with every row de-interleaved [even channels | odd channels] and padded to 128
   // floats, + an all-zero row 427 (absent move slots point at it); W1 in MFMA-fragment order [n-block][k-step][lane]
-  const float *a_w0d, *a_w1f, *a_wdf;
+  const float *a_w0d, *a_img; // k_embed_arows: padded W0^T (move rows), and the image of its LDS weights (arows_image)
+  const float *p_img;         // k_embed_prows: the image of its LDS weights (prows_image)
   int p_hidden, p_out, a_hidden, a_out;
   int side_dim, emb_dim;
   int activation; // 1 relu, 2 clamp
@@ -801,6 +802,25 @@ __global__ __launch_bounds__(ER_BLOCK) void k_embed_rows(EmbedTileArgs a) {
   EL_FLUSH();
 }
 
+// Copy a prebuilt image of the kernel's LDS weights (built once at load time in exactly the LDS layout) with every load of
+// a thread in flight at once.  The obvious `lds[i] = cond ? global[f(i)] : 0` loop compiles to load -> wait -> store per
+// iteration: ~30 serialized L2 round trips per workgroup, 20-50 us in front of every embedding kernel.
+template <int BLOCK, int MAXR>
+__device__ __forceinline__ void stage_image(float *lds, const float *img, int words) {
+  const int n4 = words >> 2; // (images are padded to a multiple of 4 floats)
+  float4 t[MAXR];
+#pragma unroll
+  for (int u = 0; u < MAXR; ++u) {
+    const int i = (int)threadIdx.x + u * BLOCK;
+    if (i < n4) t[u] = ((const float4 *)img)[i];
+  }
+#pragma unroll
+  for (int u = 0; u < MAXR; ++u) {
+    const int i = (int)threadIdx.x + u * BLOCK;
+    if (i < n4) ((float4 *)lds)[i] = t[u];
+  }
+}
+
 // ---- K2, the actives' pass (the default): row-per-lane like k_embed_rows, with the DENSE part of the first layer on the
 // matrix pipe.  An active's ~53 candidate features fall into three kinds:
 //   36 DENSE features (bias, the 5 active stats, 6 boosts, 19 volatile features, the stored Pokemon's 5 stats): the weight
@@ -814,10 +834,10 @@ __global__ __launch_bounds__(ER_BLOCK) void k_embed_rows(EmbedTileArgs a) {
 //                  absent = the zero row; added to the MFMA result with FMAs as in k_embed_rows;
 //    8 MOVE rows   (4 active + 4 stored move slots, 328 possible rows): read from a copy in L2 in the same channel order
 //                  (`a_w0d`, 219 KB), absent = its zero row.
-// Then the <= 4 output blocks one after the other with that block's W1 fragment streamed from L2 (`a_w1f`, coalesced 256 B
-// per k-step) 16 k-steps at a time, the next chunk's loads issued ahead of the current chunk's MFMAs.  No activation tile,
-// no workgroup barrier per tile, every wave on the MFMA; the kernel fits 128 registers so that a CU holds ONE 16-wave
-// workgroup (4 waves per SIMD, 149 KB of LDS).
+// Then the <= 4 output blocks one after the other with W1's fragments from LDS (256 B per k-step, conflict-free).  No
+// activation tile, no workgroup barrier per tile, every wave on the MFMA; the kernel fits 128 registers so that a CU holds
+// ONE 16-wave workgroup (4 waves per SIMD).  LDS: 65 x 528 B rows + 18 KB dense fragment + <= 64 KB W1 fragments + 1.4 KB
+// per wave (row indices) = <= 141 KB, staged from one prebuilt image (stage_image).
 constexpr int AR_SPARSE = 64, AR_ZERO = 64;   // LDS-resident one-hot rows (ar_sparse_slot) + a zero row
 constexpr int AR_FIXED = 36, AR_HOT = 9, AR_MOVES = 8, AR_KSTEPS = AR_FIXED / 2;
 constexpr int AR_ITEM_WORDS = 5 + 4;            // 9 u16 LDS offsets (5 words), 8 u16 global rows (4 words)
@@ -835,18 +855,14 @@ __device__ __forceinline__ uint32_t ar_sparse_slot(uint32_t row) { return row < 
 __host__ __device__ constexpr int ar_sparse_row(int slot) { return slot < 15 ? slot + 5 : slot < 35 ? slot - 15 + 209 : slot - 35 + 398; }
 __global__ __launch_bounds__(AR_BLOCK) void k_embed_arows(EmbedTileArgs a) {
   extern __shared__ __align__(16) float lds_f[];
+  EL_T0();
   const NetDev &N = a.net;
   const int hidden = N.a_hidden, out_dim = N.a_out;
   const int NBo = (out_dim + 31) >> 5;
-  float *W0s = lds_f;                                   // sparse rows, channels in natural order
-  float *Wd = W0s + (AR_SPARSE + 1) * ER_RS;            // dense fragment (a_wdf, built at load time)
-  for (int i = threadIdx.x; i < (AR_SPARSE + 1) * 128; i += AR_BLOCK) {
-    const int sl = i >> 7, c = i & 127;
-    W0s[sl * ER_RS + c] = (sl < AR_SPARSE && c < hidden) ? N.a_w0t[(size_t)ar_sparse_row(sl) * hidden + c] : 0.0f;
-  }
-  for (int i = threadIdx.x; i < AR_DENSE_WORDS; i += AR_BLOCK) Wd[i] = N.a_wdf[i];
-  float *W1s = Wd + AR_DENSE_WORDS;                     // the second layer's fragments (a_w1f): [block][k-step][lane]
-  for (int i = threadIdx.x; i < NBo * 64 * 64; i += AR_BLOCK) W1s[i] = N.a_w1f[i];
+  float *W0s = lds_f;                                   // sparse rows, channels in natural order, + a zero row
+  float *Wd = W0s + (AR_SPARSE + 1) * ER_RS;            // dense fragment: [k-step][channel block][lane]
+  float *W1s = Wd + AR_DENSE_WORDS;                     // the second layer's fragments: [block][k-step][lane]
+  stage_image<AR_BLOCK, 8>(lds_f, N.a_img, (AR_SPARSE + 1) * ER_RS + AR_DENSE_WORDS + NBo * 64 * 64);
   const uint32_t lane = threadIdx.x & 63, wib = threadIdx.x >> 6, r32 = lane & 31, hh = lane >> 5;
   uint32_t *wl = (uint32_t *)(W1s + NBo * 64 * 64) + wib * AR_WAVE_WORDS; // this wave's private LDS
   uint32_t *dst_off = wl + ER_ITEMS * AR_ITEM_WORDS;
@@ -855,7 +871,6 @@ __global__ __launch_bounds__(AR_BLOCK) void k_embed_arows(EmbedTileArgs a) {
   const uint32_t nmt = (items + ER_ITEMS - 1) / ER_ITEMS;
   const uint32_t stride = gridDim.x * AR_WAVES;
   __syncthreads(); // weights staged (the only workgroup barrier of the kernel)
-  EL_T0();
   EL_MARK(0);
   for (uint32_t mt = blockIdx.x * AR_WAVES + wib; mt < nmt; mt += stride) {
     // ---- encode: BOTH lanes (r, 0) and (r, 1) encode item r straight from global memory (two dependent loads: order ->
@@ -990,6 +1005,164 @@ __global__ __launch_bounds__(AR_BLOCK) void k_embed_arows(EmbedTileArgs a) {
         for (int s2 = 0; s2 < 16; ++s2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(hb[b][s2], wc[(b * 16 + s2) * 64], acc, 0, 0, 0);
       const int o = nb * 32 + (int)r32;
       const float ob = o < out_dim ? N.a_b1[o] : 0.0f;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int row = (q & 3) + 8 * (q >> 2) + 4 * (int)hh;
+        const uint32_t doff = dst_off[row];
+        if (o < out_dim && doff != 0xFFFFFFFFu) a.emb[(size_t)doff + 1 + o] = act_fn(acc[q] + ob, N.activation);
+      }
+    }
+    if (hh == 0 && dst_off[r32] != 0xFFFFFFFFu) a.emb[dst_off[r32]] = hp_ratio[r32];
+    __builtin_amdgcn_wave_barrier(); // the wave's LDS is rewritten by the next mini-tile
+    EL_MARK(7);
+  }
+  EL_FLUSH();
+}
+
+// ---- K2, the party-slot pass in the same form as k_embed_arows (the default).  A bench Pokemon has 6 DENSE features (bias,
+// 5 stats: 3 k-steps x 4 blocks = 12 MFMAs in the "lane = item" orientation) and 7 ONE-HOT rows (4 move slots, status, 2
+// types; 193 possible rows, all LDS-resident in natural channel order): in k-step t the half-wave hh sums the 7 rows of
+// item 2t + hh, a whole 512-byte row per ds_read_b128 and so free of the bank conflicts of k_embed_rows (every lane another
+// row at the same column), and an identity MFMA transposes the sums into the item lanes.  Second layer (<= 2 output
+// blocks) with W1 fragments from LDS.  The input is read straight from global memory (the encode of a Pokemon is 12
+// features; no staging).  LDS: 194 x 528 B rows + 3 KB dense fragment + 32 KB W1 fragments + 768 B per wave = 147 KB.
+constexpr int PR_SPARSE = 193, PR_ZERO = 193, PR_KSTEPS = 3, PR_HOT = 7;
+constexpr int PR_ITEM_WORDS = 4;                 // 7 u16 LDS offsets
+constexpr int PR_WAVE_WORDS = ER_ITEMS * PR_ITEM_WORDS + 2 * ER_ITEMS;
+constexpr int PR_BLOCK = 1024, PR_WAVES = 16;
+constexpr int PR_DENSE_WORDS = PR_KSTEPS * 4 * 64;
+constexpr size_t PR_BYTES = (size_t)((PR_SPARSE + 1) * ER_RS + PR_DENSE_WORDS + 2 * 64 * 64 + PR_WAVES * PR_WAVE_WORDS) * 4;
+template <bool LIST>
+__global__ __launch_bounds__(PR_BLOCK) void k_embed_prows(EmbedTileArgs a) {
+  extern __shared__ __align__(16) float lds_f[];
+  EL_T0();
+  const NetDev &N = a.net;
+  const int hidden = N.p_hidden, out_dim = N.p_out;
+  const int NBo = (out_dim + 31) >> 5;
+  const uint32_t items = LIST ? *a.work_count : a.n * 10;
+  const uint32_t nmt = (items + ER_ITEMS - 1) / ER_ITEMS;
+  if (blockIdx.x * PR_WAVES >= nmt) return; // (a short work list: most workgroups have nothing to stage weights for)
+  float *W0s = lds_f;                                   // rows 5..197 of W0^T, channels in natural order, + a zero row
+  float *Wd = W0s + (PR_SPARSE + 1) * ER_RS;            // dense fragment
+  float *W1s = Wd + PR_DENSE_WORDS;                     // second layer's fragments: [block][k-step][lane]
+  stage_image<PR_BLOCK, 9>(lds_f, N.p_img, (PR_SPARSE + 1) * ER_RS + PR_DENSE_WORDS + NBo * 64 * 64);
+  const uint32_t lane = threadIdx.x & 63, wib = threadIdx.x >> 6, r32 = lane & 31, hh = lane >> 5;
+  uint32_t *wl = (uint32_t *)(W1s + 2 * 64 * 64) + wib * PR_WAVE_WORDS; // this wave's private LDS
+  uint32_t *dst_off = wl + ER_ITEMS * PR_ITEM_WORDS;
+  float *hp_ratio = (float *)(dst_off + ER_ITEMS);
+  const uint32_t stride = gridDim.x * PR_WAVES;
+  __syncthreads(); // weights staged (the only workgroup barrier of the kernel)
+  EL_MARK(0);
+  for (uint32_t mt = blockIdx.x * PR_WAVES + wib; mt < nmt; mt += stride) {
+    // ---- encode: both lanes (r, 0) and (r, 1) encode item r; each keeps the dense values of its own k-half.  (Fetching
+    // the raw input one mini-tile ahead, order bytes first and the Pokemon they point to after the first layer, was
+    // measured and rejected: 240 us against 226 us -- the encode is not what the kernel waits for.) ----
+    float x[PR_KSTEPS];
+    {
+      const uint32_t g = mt * ER_ITEMS + r32;
+      uint32_t gi = g, pk0 = 0, pk1 = 0, pk2 = 0, pk3 = 0, pk4 = 0, pk5 = 0, sleep = 0;
+      if (g < items) {
+        if (LIST) {
+          const uint32_t *rec = (const uint32_t *)a.work + (size_t)g * 8;
+          const uint4 r0 = *(const uint4 *)rec, r1 = *(const uint4 *)(rec + 4);
+          gi = r0.x; pk0 = r0.y; pk1 = r0.z; pk2 = r0.w; pk3 = r1.x; pk4 = r1.y; pk5 = r1.z; sleep = r1.w;
+        } else {
+          const uint32_t leaf = g / 10, q = g - leaf * 10, side = q / 5, slot = 1 + (q - side * 5);
+          const uint32_t *sb = (const uint32_t *)a.battles + (size_t)leaf * 96 + side * 46;
+          const uint32_t o0 = sb[44], o1 = sb[45];
+          const uint32_t dur = ((const uint32_t *)a.durations)[(size_t)leaf * 2 + side];
+          const uint32_t id = slot < 4 ? (o0 >> (8 * slot)) & 0xFF : (o1 >> (8 * (slot - 4))) & 0xFF;
+          sleep = (dur >> (3 * slot)) & 7;
+          if (id != 0) {
+            const uint2 *pk = (const uint2 *)(sb + 6 * (id - 1));
+            const uint2 a0 = pk[0], a1 = pk[1], a2 = pk[2];
+            pk0 = a0.x; pk1 = a0.y; pk2 = a1.x; pk3 = a1.y; pk4 = a2.x; pk5 = a2.y;
+          }
+        }
+      }
+      float fv[6];
+      uint32_t hot[8];
+      uint32_t doff = 0xFFFFFFFFu, dead_off = 0xFFFFFFFFu;
+      float hpr = 0.0f;
+#pragma unroll
+      for (int f = 0; f < 6; ++f) fv[f] = 0.0f;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) hot[k] = PR_ZERO * ER_RS / 4;
+      if (g < items) {
+        const uint32_t leaf = gi / 10, q = gi - leaf * 10, side = q / 5, slot = 1 + (q - side * 5);
+        const uint32_t hp = pk4 >> 16;
+        const uint32_t dd = leaf * N.emb_dim + side * N.side_dim + (1 + N.a_out) + (slot - 1) * (1 + N.p_out);
+        if (hp == 0) dead_off = dd; // empty or fainted: zero block (network.h:153-160), kept out of the scatter
+        else {
+          doff = dd;
+          fv[0] = 1.0f; // the bias
+#pragma unroll
+          for (uint32_t j = 0; j < 12; ++j) { // Encode::Battle::Pokemon (battle.h:197-214)
+            uint32_t fidx = 0; float fval = 0.0f;
+            const bool v = pokemon_feature(j, pk0, pk1, pk2, pk3, pk4, pk5, sleep, fidx, fval);
+            if (j < 5) fv[1 + j] = fval;
+            else hot[j - 5] = v ? (fidx - 5) * ER_RS / 4 : PR_ZERO * ER_RS / 4;
+          }
+          hpr = (float)hp / (float)(pk0 & 0xFFFF);
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < PR_KSTEPS; ++t) x[t] = hh ? fv[2 * t + 1] : fv[2 * t];
+      if (hh == 0) {
+        uint32_t *it = wl + r32 * PR_ITEM_WORDS;
+        it[0] = hot[0] | hot[1] << 16; it[1] = hot[2] | hot[3] << 16; it[2] = hot[4] | hot[5] << 16; it[3] = hot[6];
+        dst_off[r32] = doff;
+        hp_ratio[r32] = hpr;
+        if (dead_off != 0xFFFFFFFFu) for (int o = 0; o <= out_dim; ++o) a.emb[(size_t)dead_off + o] = 0.0f;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    EL_MARK(3);
+    // ---- first layer: dense part, then the one-hot rows through the identity transposition (see k_embed_arows) ----
+    f32x16 hb[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) hb[b][q] = 0.0f;
+#pragma unroll
+    for (int t = 0; t < PR_KSTEPS; ++t)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) hb[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(Wd[(t * 4 + b) * 64 + lane], x[t], hb[b], 0, 0, 0);
+#pragma unroll 4
+    for (int t = 0; t < 16; ++t) {
+      const uint4 iw = *(const uint4 *)(wl + (2 * t + hh) * PR_ITEM_WORDS);
+      const uint32_t w[4] = {iw.x, iw.y, iw.z, iw.w};
+      float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int k = 0; k < PR_HOT; ++k) {
+        const uint32_t off = (w[k >> 1] >> (16 * (k & 1))) & 0xFFFF;
+        const float4 r = *(const float4 *)(W0s + off * 4 + 4 * r32);
+        sum.x += r.x; sum.y += r.y; sum.z += r.z; sum.w += r.w;
+      }
+      const float ident = (uint32_t)(2 * t) + hh == r32 ? 1.0f : 0.0f;
+      hb[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(sum.x, ident, hb[0], 0, 0, 0);
+      hb[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(sum.y, ident, hb[1], 0, 0, 0);
+      hb[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(sum.z, ident, hb[2], 0, 0, 0);
+      hb[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(sum.w, ident, hb[3], 0, 0, 0);
+    }
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) hb[b][q] = act_fn(hb[b][q], N.activation);
+    EL_MARK(4);
+    // ---- second layer ----
+#pragma unroll 1
+    for (int nb = 0; nb < NBo; ++nb) {
+      f32x16 acc;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[q] = 0.0f;
+      const float *wc = W1s + nb * 64 * 64 + lane;
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int s2 = 0; s2 < 16; ++s2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(hb[b][s2], wc[(b * 16 + s2) * 64], acc, 0, 0, 0);
+      const int o = nb * 32 + (int)r32;
+      const float ob = o < out_dim ? N.p_b1[o] : 0.0f;
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
         const int row = (q & 3) + 8 * (q >> 2) + 4 * (int)hh;
@@ -1470,7 +1643,6 @@ __device__ __forceinline__ void wave_layer(const float4 *Wf, int K, int NB, cons
     const float4 *w2 = wptr(t + 2 < nsc ? t + 2 : nsc - 1) + lane;
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
-#ifndef OAKGPU_MW_EXPERIMENT_NO_B
       if (s == 0) {
 #pragma unroll
         for (int j = 0; j < NBc; ++j) Q[j][1] = w1[j * 128];
@@ -1479,12 +1651,9 @@ __device__ __forceinline__ void wave_layer(const float4 *Wf, int K, int NB, cons
 #pragma unroll
         for (int j = 0; j < NBc; ++j) P[j][0] = w2[j * 128];
       }
-#endif
       // the next chunk's A values, a whole chunk ahead -- issued BEHIND this sub-chunk's first weight loads: the vector-memory
       // counter retires in order, so the next waits for weights would otherwise cover these (HBM latency) too
-#ifndef OAKGPU_MW_EXPERIMENT_NO_A
       if (ca >= 0 && s == 1) load_a(aN, ca);
-#endif
       const float a_s = f4_pick(aC[2 * u + (s >> 2)], s & 3);
 #pragma unroll
       for (int j = 0; j < NBc; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_s, f4_pick(P[j][s >> 2], s & 3), acc[j], 0, 0, 0);
@@ -1775,6 +1944,17 @@ std::vector<float> arows_dense_frag(const HostAffine &a) {
       }
   return f;
 }
+// the same for k_embed_prows: dense feature d = 0 is the bias, d = 1..5 are W0^T rows 0..4 (the stats)
+std::vector<float> prows_dense_frag(const HostAffine &a) {
+  std::vector<float> f((size_t)oak::PR_DENSE_WORDS, 0.0f);
+  for (uint32_t t = 0; t < (uint32_t)oak::PR_KSTEPS; ++t)
+    for (uint32_t blk = 0; blk < 4; ++blk)
+      for (uint32_t lane = 0; lane < 64; ++lane) {
+        const uint32_t d = 2 * t + (lane >> 5), c = 4 * (lane & 31) + blk;
+        if (c < a.out) f[((size_t)t * 4 + blk) * 64 + lane] = d == 0 ? a.b[c] : a.w[(size_t)c * a.in + (d - 1)];
+      }
+  return f;
+}
 // ... and W1 [out][hidden] in MFMA-fragment order: [n-block][k-step s][lane (r32, hh)] = W1[nb * 32 + r32][ar_channel(s, hh)]
 std::vector<float> embed_frag_order(const HostAffine &a) {
   const uint32_t NB = (a.out + 31) / 32;
@@ -1786,6 +1966,26 @@ std::vector<float> embed_frag_order(const HostAffine &a) {
         if (o < a.out && c < a.in) f[((size_t)nb * 64 + s2) * 64 + lane] = a.w[(size_t)o * a.in + c];
       }
   return f;
+}
+
+// the images of the two kernels' LDS weights: [one-hot rows (stride ER_RS) + a zero row | dense fragment | W1 fragments]
+std::vector<float> arows_image(const HostAffine &a0, const HostAffine &a1) {
+  std::vector<float> img((size_t)(oak::AR_SPARSE + 1) * oak::ER_RS, 0.0f);
+  for (int sl = 0; sl < oak::AR_SPARSE; ++sl)
+    for (uint32_t c = 0; c < a0.out && c < 128; ++c) img[(size_t)sl * oak::ER_RS + c] = a0.w[(size_t)c * a0.in + (uint32_t)oak::ar_sparse_row(sl)];
+  const std::vector<float> d = arows_dense_frag(a0), f = embed_frag_order(a1);
+  img.insert(img.end(), d.begin(), d.end());
+  img.insert(img.end(), f.begin(), f.end());
+  return img;
+}
+std::vector<float> prows_image(const HostAffine &p0, const HostAffine &p1) {
+  std::vector<float> img((size_t)(oak::PR_SPARSE + 1) * oak::ER_RS, 0.0f);
+  for (int sl = 0; sl < oak::PR_SPARSE; ++sl)
+    for (uint32_t c = 0; c < p0.out && c < 128; ++c) img[(size_t)sl * oak::ER_RS + c] = p0.w[(size_t)c * p0.in + (uint32_t)(sl + 5)];
+  const std::vector<float> d = prows_dense_frag(p0), f = embed_frag_order(p1);
+  img.insert(img.end(), d.begin(), d.end());
+  img.insert(img.end(), f.begin(), f.end());
+  return img;
 }
 
 std::vector<float> pad_vec(const std::vector<float> &v, uint32_t n) {
@@ -1852,8 +2052,8 @@ int oakgpu_net_load_memory(oakgpu_ctx *ctx, const void *bytes, size_t size, oakg
   rc = rc ? rc : upload(net, a0.b, &D.a_b0);
   rc = rc ? rc : upload(net, a1.b, &D.a_b1);
   rc = rc ? rc : upload(net, arows_rows(a0), &D.a_w0d);
-  rc = rc ? rc : upload(net, arows_dense_frag(a0), &D.a_wdf);
-  rc = rc ? rc : upload(net, embed_frag_order(a1), &D.a_w1f);
+  rc = rc ? rc : upload(net, arows_image(a0, a1), &D.a_img);
+  rc = rc ? rc : upload(net, prows_image(p0, p1), &D.p_img);
   rc = rc ? rc : upload(net, pad_rows(fc0, H, fc0.in), &D.w0);
   rc = rc ? rc : upload(net, pad_vec(fc0.b, H), &D.b0);
   rc = rc ? rc : upload(net, pad_rows(fc1, H, H), &D.w1);
@@ -1927,6 +2127,10 @@ int oakgpu_leaf_set_lds_limits(void) { // per DEVICE (hipFuncSetAttribute applie
   if (e != hipSuccess) return oakgpu_fail_hip((int)e, "hipFuncSetAttribute(k_embed_rows<list>)");
   e = hipFuncSetAttribute((const void *)oak::k_embed_arows, hipFuncAttributeMaxDynamicSharedMemorySize, (int)oak::ar_bytes(4));
   if (e != hipSuccess) return oakgpu_fail_hip((int)e, "hipFuncSetAttribute(k_embed_arows)");
+  e = hipFuncSetAttribute((const void *)oak::k_embed_prows<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)oak::PR_BYTES);
+  if (e != hipSuccess) return oakgpu_fail_hip((int)e, "hipFuncSetAttribute(k_embed_prows)");
+  e = hipFuncSetAttribute((const void *)oak::k_embed_prows<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)oak::PR_BYTES);
+  if (e != hipSuccess) return oakgpu_fail_hip((int)e, "hipFuncSetAttribute(k_embed_prows<list>)");
   e = hipFuncSetAttribute((const void *)oak::k_embed_lds<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)oak::ELayout<true>::BYTES);
   if (e != hipSuccess) return oakgpu_fail_hip((int)e, "hipFuncSetAttribute(k_embed_lds<active>)");
   e = hipFuncSetAttribute((const void *)oak::k_policy, hipFuncAttributeMaxDynamicSharedMemorySize, oak::POLICY_LDS_LIMIT);
@@ -1974,9 +2178,9 @@ static int leaf_eval_impl(oakgpu_ctx *ctx, oakgpu_net *net, const uint8_t *battl
         hipLaunchKernelGGL(oak::k_party_tags, dim3((n * 10 + 256 * oak::TAG_R - 1) / (256 * oak::TAG_R)), dim3(256), 0, stream, D, battles, durations, n, emb, slot_tags, work, count);
         ta.work = work;
         ta.work_count = count;
-        // the work list is short (~10% of the slots): the tile kernel's lighter prologue wins there (measured: 0.789 vs 0.802 ms per
-        // configs[2] step); OAKGPU_EMBED_IMPL=5 selects the row kernel for the list as well (A/B)
-        if (embed_impl == 5 && rows_ok) hipLaunchKernelGGL(oak::k_embed_rows<true>, dim3(256), dim3(oak::ER_BLOCK), oak::ER_BYTES, stream, ta);
+        // the same kernel as the plain pass (so that cached and plain embeddings are bit-identical); workgroups beyond the
+        // list's length leave before staging any weights
+        if (embed_impl >= 4 && rows_ok) hipLaunchKernelGGL(oak::k_embed_prows<true>, dim3(256), dim3(oak::PR_BLOCK), oak::PR_BYTES, stream, ta);
         else hipLaunchKernelGGL((oak::k_embed_lds<false, true>), dim3(ntiles < 256 ? ntiles : 256), dim3(oak::EL_BLOCK), oak::ELayout<false>::BYTES, stream, ta);
         continue;
       }
@@ -1986,8 +2190,13 @@ static int leaf_eval_impl(oakgpu_ctx *ctx, oakgpu_net *net, const uint8_t *battl
         continue;
       }
       if (kind == 0 && embed_impl >= 4 && rows_ok) { // default party-slot pass: every wave its own pipeline
-        const uint32_t nmt = (n * 10 + oak::ER_ITEMS - 1) / oak::ER_ITEMS, wg = (nmt + oak::ER_WAVES - 1) / oak::ER_WAVES;
-        hipLaunchKernelGGL(oak::k_embed_rows<false>, dim3(wg < 256 ? wg : 256), dim3(oak::ER_BLOCK), oak::ER_BYTES, stream, ta);
+        if (embed_impl == 6) { // the previous form: every lane its own weight rows (A/B)
+          const uint32_t nmt = (n * 10 + oak::ER_ITEMS - 1) / oak::ER_ITEMS, wg = (nmt + oak::ER_WAVES - 1) / oak::ER_WAVES;
+          hipLaunchKernelGGL(oak::k_embed_rows<false>, dim3(wg < 256 ? wg : 256), dim3(oak::ER_BLOCK), oak::ER_BYTES, stream, ta);
+        } else {
+          const uint32_t nmt = (n * 10 + oak::ER_ITEMS - 1) / oak::ER_ITEMS, wg = (nmt + oak::PR_WAVES - 1) / oak::PR_WAVES;
+          hipLaunchKernelGGL(oak::k_embed_prows<false>, dim3(wg < 256 ? wg : 256), dim3(oak::PR_BLOCK), oak::PR_BYTES, stream, ta);
+        }
         continue;
       }
       if (embed_impl == 2) { // second implementation: first-layer rows gathered from L2 (A/B)

@@ -36,7 +36,7 @@ for kind, env in ((os.environ.get("OAKGPU_EMBED_KINDS", "both kinds"), None),):
     torch.cuda.synchronize()
     lib.oakgpu_leaf_profile(buf, 0)
     print("== kinds", kind)
-    names = ["barrier(prev tile)", "stage Bs + barrier", "issue prefetch", "1a feature lists", "1c first layer", "barrier", "2 mfma", "3 scatter"]
+    names = ["prologue (weights -> LDS)", "stage Bs + barrier", "issue prefetch", "1a feature lists", "1c first layer", "barrier", "2 mfma", "3 scatter"]
     print("k_mainnet_direct wave 0: outside compute %d cycles, inside compute (MFMA streams) %d cycles" % (buf[8], buf[9]))
     wn = ["fc0 (196,608 MFMA cycles per tile)", "store 0", "fc1 (65,536)", "store 1 (+ h1)", "value_fc2 (65,536)", "store 2 + value_fc3"]
     wt = sum(buf[10 + i] for i in range(6))
