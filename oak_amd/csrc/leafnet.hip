@@ -821,6 +821,19 @@ __device__ __forceinline__ void stage_image(float *lds, const float *img, int wo
   }
 }
 
+// The embedding blocks of empty / fainted slots are all-zero (network.h:142-143,153-160).  The lanes that found one hand it to
+// the whole wave: one coalesced store per dead item instead of `len` four-byte stores by a single lane.
+__device__ __forceinline__ void zero_blocks(float *emb, uint32_t dead_off, int len) {
+  const int lane = threadIdx.x & 63;
+  unsigned long long m = __ballot(dead_off != 0xFFFFFFFFu);
+  while (m) {
+    const int l = __builtin_ctzll(m);
+    m &= m - 1;
+    const uint32_t off = (uint32_t)__builtin_amdgcn_readlane((int)dead_off, l);
+    for (int o = lane; o < len; o += 64) emb[(size_t)off + o] = 0.0f;
+  }
+}
+
 // ---- K2, the actives' pass (the default): row-per-lane like k_embed_rows, with the DENSE part of the first layer on the
 // matrix pipe.  An active's ~53 candidate features fall into three kinds:
 //   36 DENSE features (bias, the 5 active stats, 6 boosts, 19 volatile features, the stored Pokemon's 5 stats): the weight
@@ -937,8 +950,8 @@ __global__ __launch_bounds__(AR_BLOCK) void k_embed_arows(EmbedTileArgs a) {
         it[5] = mv[0] | mv[1] << 16; it[6] = mv[2] | mv[3] << 16; it[7] = mv[4] | mv[5] << 16; it[8] = mv[6] | mv[7] << 16;
         dst_off[r32] = doff;
         hp_ratio[r32] = hpr;
-        if (dead_off != 0xFFFFFFFFu) for (int o = 0; o <= out_dim; ++o) a.emb[(size_t)dead_off + o] = 0.0f;
       }
+      zero_blocks(a.emb, hh == 0 ? dead_off : 0xFFFFFFFFu, out_dim + 1);
     }
     __builtin_amdgcn_wave_barrier();
     EL_MARK(3);
@@ -1113,8 +1126,8 @@ __global__ __launch_bounds__(PR_BLOCK) void k_embed_prows(EmbedTileArgs a) {
         it[0] = hot[0] | hot[1] << 16; it[1] = hot[2] | hot[3] << 16; it[2] = hot[4] | hot[5] << 16; it[3] = hot[6];
         dst_off[r32] = doff;
         hp_ratio[r32] = hpr;
-        if (dead_off != 0xFFFFFFFFu) for (int o = 0; o <= out_dim; ++o) a.emb[(size_t)dead_off + o] = 0.0f;
       }
+      zero_blocks(a.emb, hh == 0 ? dead_off : 0xFFFFFFFFu, out_dim + 1);
     }
     __builtin_amdgcn_wave_barrier();
     EL_MARK(3);

@@ -25,7 +25,7 @@ rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES
 rocprofv3 --pmc SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d $O/pmc_sq2 -- $R > $O/pmc_sq2.log 2>&1 || echo "sq2 pmc pass failed"
 echo "rollout pmc done"
 L="python3 bench.py --workload leaf --steps 10 --warmup 2 --no-cpu-baseline"
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_LDS_BANK_CONFLICT SQ_INSTS_LDS SQ_ACTIVE_INST_LDS --kernel-trace --output-format csv -d $O/pmc_leaf -- $L > $O/pmc_leaf.log 2>&1 || echo "leaf pmc pass failed"
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_LDS_BANK_CONFLICT SQ_WAIT_ANY GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc_leaf -- $L > $O/pmc_leaf.log 2>&1 || echo "leaf pmc pass failed"
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_leaf_fetch -- $L > $O/pmc_leaf_fetch.log 2>&1 || echo "leaf fetch pass failed"
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_leaf_write -- $L > $O/pmc_leaf_write.log 2>&1 || echo "leaf write pass failed"
 echo "leaf pmc done"

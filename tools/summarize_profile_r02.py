@@ -80,6 +80,9 @@ for k, v in leaf.items():
         # MFMA_BUSY counts cycles per SIMD summed over the chip; BUSY_CYCLES counts per SE/XCD: report the raw pair and the
         # per-kernel duration-based fraction computed in DESIGN.md from the kernel's duration and 1024 SIMDs
         v["mfma_busy_cycles_per_simd"] = v["SQ_VALU_MFMA_BUSY_CYCLES"]["mean"] / 1024.0
+        if "GRBM_GUI_ACTIVE" in v:  # GRBM_GUI_ACTIVE is summed over the 8 XCDs: / 8 = the kernel's duration in GPU cycles (under the profiler)
+            v["kernel_cycles"] = v["GRBM_GUI_ACTIVE"]["mean"] / 8.0
+            v["mfma_busy_frac"] = v["mfma_busy_cycles_per_simd"] / v["kernel_cycles"]
 json.dump(leaf, open(os.path.join(dst, "r02_leaf_pmc.json"), "w"), indent=1)
 
 # the group launch (largest grid) is the headline's dominant kernel: per-launch traffic and instruction counts
