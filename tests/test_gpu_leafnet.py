@@ -57,6 +57,29 @@ def test_config3_net_256(gpu_ctx, tmp_path):
     net.close()
 
 
+@pytest.mark.parametrize("dims", [
+    dict(hidden=96, value_hidden=160),                                        # 3 and 5 output blocks: padded to the 4- and 8-wide kernels
+    dict(hidden=32, value_hidden=32, pokemon_out=27, active_out=19),          # one block everywhere, embedding dim 312
+    dict(hidden=64, value_hidden=224, pokemon_hidden=64, active_hidden=96, pokemon_out=64, active_out=128),   # narrow hidden layers, widest outputs
+    dict(hidden=128, value_hidden=64, pokemon_out=33, active_out=97, pokemon_hidden=100, active_hidden=72),   # ragged widths
+    dict(hidden=64, value_hidden=32, pokemon_out=99),                         # party output above 64: the tile kernel takes the party pass
+])
+def test_layer_widths(gpu_ctx, tmp_path, dims):
+    """Every template width of the leaf kernels (1 / 2 / 4 / 8 output blocks, padded blocks, ragged hidden widths) and the
+    fall-back of the party pass for outputs above 64, plain and cached, against the numpy oracle."""
+    from oak_amd import netfile
+    from oak_amd.engine import Network
+    path = str(tmp_path / "w.battle.net")
+    netfile.write_random_net(path, seed=3, activation=1 + (dims["hidden"] % 64 == 0), **dims)
+    net = Network(gpu_ctx, path=path)
+    onet = NN.Net(path)
+    b, d = _midgame_states(97, 30, 4242)
+    vals = net.value_inference(b, d)
+    exp = np.array([float(NN.value_inference(onet, b[i], d[i])) for i in range(b.shape[0])])
+    assert np.abs(vals - exp).max() <= TOL
+    net.close()
+
+
 def test_bad_network_files_raise(gpu_ctx, tmp_path):
     from oak_amd.engine import Network
     from oak_amd._lib import OakGpuError
