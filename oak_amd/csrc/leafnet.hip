@@ -1054,7 +1054,7 @@ __global__ __launch_bounds__(PR_BLOCK) void k_embed_prows(EmbedTileArgs a) {
   const int NBo = (out_dim + 31) >> 5;
   const uint32_t items = LIST ? *a.work_count : a.n * 10;
   const uint32_t nmt = (items + ER_ITEMS - 1) / ER_ITEMS;
-  if (blockIdx.x * PR_WAVES >= nmt) return; // (a short work list: most workgroups have nothing to stage weights for)
+  if (blockIdx.x >= nmt) return; // (a very short work list: no weights staged for nothing)
   float *W0s = lds_f;                                   // rows 5..197 of W0^T, channels in natural order, + a zero row
   float *Wd = W0s + (PR_SPARSE + 1) * ER_RS;            // dense fragment
   float *W1s = Wd + PR_DENSE_WORDS;                     // second layer's fragments: [block][k-step][lane]
@@ -1066,7 +1066,9 @@ __global__ __launch_bounds__(PR_BLOCK) void k_embed_prows(EmbedTileArgs a) {
   const uint32_t stride = gridDim.x * PR_WAVES;
   __syncthreads(); // weights staged (the only workgroup barrier of the kernel)
   EL_MARK(0);
-  for (uint32_t mt = blockIdx.x * PR_WAVES + wib; mt < nmt; mt += stride) {
+  // mini-tiles go round-robin over the WORKGROUPS first, so that a short work list still spreads over every CU (two waves per
+  // SIMD finish a mini-tile much sooner than four)
+  for (uint32_t mt = wib * gridDim.x + blockIdx.x; mt < nmt; mt += stride) {
     // ---- encode: both lanes (r, 0) and (r, 1) encode item r; each keeps the dense values of its own k-half.  (Fetching
     // the raw input one mini-tile ahead, order bytes first and the Pokemon they point to after the first layer, was
     // measured and rejected: 240 us against 226 us -- the encode is not what the kernel waits for.) ----
