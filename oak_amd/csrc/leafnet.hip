@@ -1143,17 +1143,25 @@ __global__ __launch_bounds__(PR_BLOCK) void k_embed_prows(EmbedTileArgs a) {
     for (int t = 0; t < PR_KSTEPS; ++t)
 #pragma unroll
       for (int b = 0; b < 4; ++b) hb[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(Wd[(t * 4 + b) * 64 + lane], x[t], hb[b], 0, 0, 0);
-#pragma unroll 4
+    // (not unrolled, all seven row reads of a k-step issued before the first add: unrolled, the register allocator -- 128
+    // registers, 64 of them accumulators -- gave every read the same four registers and a full LDS round trip each)
+    uint4 iw = *(const uint4 *)(wl + hh * PR_ITEM_WORDS);
+#pragma unroll 1
     for (int t = 0; t < 16; ++t) {
-      const uint4 iw = *(const uint4 *)(wl + (2 * t + hh) * PR_ITEM_WORDS);
       const uint32_t w[4] = {iw.x, iw.y, iw.z, iw.w};
-      float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+      float4 r[PR_HOT];
 #pragma unroll
       for (int k = 0; k < PR_HOT; ++k) {
         const uint32_t off = (w[k >> 1] >> (16 * (k & 1))) & 0xFFFF;
-        const float4 r = *(const float4 *)(W0s + off * 4 + 4 * r32);
-        sum.x += r.x; sum.y += r.y; sum.z += r.z; sum.w += r.w;
+        r[k] = *(const float4 *)(W0s + off * 4 + 4 * r32);
       }
+      iw = *(const uint4 *)(wl + (2 * (t < 15 ? t + 1 : t) + hh) * PR_ITEM_WORDS); // the next k-step's row indices
+      __builtin_amdgcn_sched_barrier(0);
+      float4 sum;
+      sum.x = ((r[0].x + r[1].x) + (r[2].x + r[3].x)) + ((r[4].x + r[5].x) + r[6].x);
+      sum.y = ((r[0].y + r[1].y) + (r[2].y + r[3].y)) + ((r[4].y + r[5].y) + r[6].y);
+      sum.z = ((r[0].z + r[1].z) + (r[2].z + r[3].z)) + ((r[4].z + r[5].z) + r[6].z);
+      sum.w = ((r[0].w + r[1].w) + (r[2].w + r[3].w)) + ((r[4].w + r[5].w) + r[6].w);
       const float ident = (uint32_t)(2 * t) + hh == r32 ? 1.0f : 0.0f;
       hb[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(sum.x, ident, hb[0], 0, 0, 0);
       hb[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(sum.y, ident, hb[1], 0, 0, 0);
