@@ -1083,15 +1083,25 @@ __global__ __launch_bounds__(PR_BLOCK) void k_embed_prows(EmbedTileArgs a) {
           gi = r0.x; pk0 = r0.y; pk1 = r0.z; pk2 = r0.w; pk3 = r1.x; pk4 = r1.y; pk5 = r1.z; sleep = r1.w;
         } else {
           const uint32_t leaf = g / 10, q = g - leaf * 10, side = q / 5, slot = 1 + (q - side * 5);
+          // the side's whole party (36 dwords) is asked for together with its order bytes and the right Pokemon selected
+          // afterwards: ONE round trip to memory instead of two dependent ones (the five lanes of a side read the same lines)
           const uint32_t *sb = (const uint32_t *)a.battles + (size_t)leaf * 96 + side * 46;
-          const uint32_t o0 = sb[44], o1 = sb[45];
+          uint4 pw[9];
+#pragma unroll
+          for (int u = 0; u < 9; ++u) pw[u] = ((const uint4 *)sb)[u];
+          const uint2 ow = *(const uint2 *)(sb + 44);
+          const uint32_t o0 = ow.x, o1 = ow.y;
           const uint32_t dur = ((const uint32_t *)a.durations)[(size_t)leaf * 2 + side];
           const uint32_t id = slot < 4 ? (o0 >> (8 * slot)) & 0xFF : (o1 >> (8 * (slot - 4))) & 0xFF;
           sleep = (dur >> (3 * slot)) & 7;
-          if (id != 0) {
-            const uint2 *pk = (const uint2 *)(sb + 6 * (id - 1));
-            const uint2 a0 = pk[0], a1 = pk[1], a2 = pk[2];
-            pk0 = a0.x; pk1 = a0.y; pk2 = a1.x; pk3 = a1.y; pk4 = a2.x; pk5 = a2.y;
+          const uint32_t w[36] = {pw[0].x, pw[0].y, pw[0].z, pw[0].w, pw[1].x, pw[1].y, pw[1].z, pw[1].w, pw[2].x, pw[2].y, pw[2].z, pw[2].w,
+                                  pw[3].x, pw[3].y, pw[3].z, pw[3].w, pw[4].x, pw[4].y, pw[4].z, pw[4].w, pw[5].x, pw[5].y, pw[5].z, pw[5].w,
+                                  pw[6].x, pw[6].y, pw[6].z, pw[6].w, pw[7].x, pw[7].y, pw[7].z, pw[7].w, pw[8].x, pw[8].y, pw[8].z, pw[8].w};
+#pragma unroll
+          for (uint32_t k = 0; k < 6; ++k) {
+            const bool m = id == k + 1;
+            pk0 = m ? w[6 * k + 0] : pk0; pk1 = m ? w[6 * k + 1] : pk1; pk2 = m ? w[6 * k + 2] : pk2;
+            pk3 = m ? w[6 * k + 3] : pk3; pk4 = m ? w[6 * k + 4] : pk4; pk5 = m ? w[6 * k + 5] : pk5;
           }
         }
       }
