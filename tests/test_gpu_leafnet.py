@@ -80,6 +80,21 @@ def test_layer_widths(gpu_ctx, tmp_path, dims):
     net.close()
 
 
+@pytest.mark.parametrize("n", [1, 31, 32, 33, 65])
+def test_ragged_batch_sizes(gpu_ctx, tmp_path, n):
+    """Batches around the kernels' 32-item mini-tiles (1 leaf = 10 party items + 2 actives; 33 leaves = a second main-net tile of one row)."""
+    from oak_amd.engine import Network
+    path = str(tmp_path / "c3.battle.net")
+    NN.write_random_net(path, hidden=256, value_hidden=256, seed=9)
+    net = Network(gpu_ctx, path=path)
+    onet = NN.Net(path)
+    b, d = _midgame_states(n, 40, 900 + n)
+    vals = net.value_inference(b, d)
+    exp = np.array([float(NN.value_inference(onet, b[i], d[i])) for i in range(n)])
+    assert vals.shape == (n,) and np.abs(vals - exp).max() <= TOL
+    net.close()
+
+
 def test_bad_network_files_raise(gpu_ctx, tmp_path):
     from oak_amd.engine import Network
     from oak_amd._lib import OakGpuError
