@@ -805,15 +805,21 @@ __global__ __launch_bounds__(ER_BLOCK) void k_embed_rows(EmbedTileArgs a) {
 // Copy a prebuilt image of the kernel's LDS weights (built once at load time in exactly the LDS layout) with every load of
 // a thread in flight at once.  The obvious `lds[i] = cond ? global[f(i)] : 0` loop compiles to load -> wait -> store per
 // iteration: ~30 serialized L2 round trips per workgroup, 20-50 us in front of every embedding kernel.
+// The copy is split in two: the loads are issued at the top of the kernel, the LDS writes (and the workgroup barrier behind
+// them) come after the wave's FIRST encode, which needs no weights -- the image's round trip runs under it.
 template <int BLOCK, int MAXR>
-__device__ __forceinline__ void stage_image(float *lds, const float *img, int words) {
+__device__ __forceinline__ void stage_image_load(float4 (&t)[MAXR], const float *img, int words) {
   const int n4 = words >> 2; // (images are padded to a multiple of 4 floats)
-  float4 t[MAXR];
 #pragma unroll
   for (int u = 0; u < MAXR; ++u) {
     const int i = (int)threadIdx.x + u * BLOCK;
+    t[u] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (i < n4) t[u] = ((const float4 *)img)[i];
   }
+}
+template <int BLOCK, int MAXR>
+__device__ __forceinline__ void stage_image_store(float *lds, const float4 (&t)[MAXR], int words) {
+  const int n4 = words >> 2;
 #pragma unroll
   for (int u = 0; u < MAXR; ++u) {
     const int i = (int)threadIdx.x + u * BLOCK;
@@ -850,7 +856,7 @@ __device__ __forceinline__ void zero_blocks(float *emb, uint32_t dead_off, int l
 // Then the <= 4 output blocks one after the other with W1's fragments from LDS (256 B per k-step, conflict-free).  No
 // activation tile, no workgroup barrier per tile, every wave on the MFMA; the kernel fits 128 registers so that a CU holds
 // ONE 16-wave workgroup (4 waves per SIMD).  LDS: 65 x 528 B rows + 18 KB dense fragment + <= 64 KB W1 fragments + 1.4 KB
-// per wave (row indices) = <= 141 KB, staged from one prebuilt image (stage_image).
+// per wave (row indices) = <= 141 KB, staged from one prebuilt image (stage_image_load / _store).
 constexpr int AR_SPARSE = 64, AR_ZERO = 64;   // LDS-resident one-hot rows (ar_sparse_slot) + a zero row
 constexpr int AR_FIXED = 36, AR_HOT = 9, AR_MOVES = 8, AR_KSTEPS = AR_FIXED / 2;
 constexpr int AR_ITEM_WORDS = 5 + 4;            // 9 u16 LDS offsets (5 words), 8 u16 global rows (4 words)
@@ -875,7 +881,9 @@ __global__ __launch_bounds__(AR_BLOCK) void k_embed_arows(EmbedTileArgs a) {
   float *W0s = lds_f;                                   // sparse rows, channels in natural order, + a zero row
   float *Wd = W0s + (AR_SPARSE + 1) * ER_RS;            // dense fragment: [k-step][channel block][lane]
   float *W1s = Wd + AR_DENSE_WORDS;                     // the second layer's fragments: [block][k-step][lane]
-  stage_image<AR_BLOCK, 8>(lds_f, N.a_img, (AR_SPARSE + 1) * ER_RS + AR_DENSE_WORDS + NBo * 64 * 64);
+  const int img_words = (AR_SPARSE + 1) * ER_RS + AR_DENSE_WORDS + NBo * 64 * 64;
+  float4 img_t[8];
+  stage_image_load<AR_BLOCK, 8>(img_t, N.a_img, img_words);
   const uint32_t lane = threadIdx.x & 63, wib = threadIdx.x >> 6, r32 = lane & 31, hh = lane >> 5;
   uint32_t *wl = (uint32_t *)(W1s + NBo * 64 * 64) + wib * AR_WAVE_WORDS; // this wave's private LDS
   uint32_t *dst_off = wl + ER_ITEMS * AR_ITEM_WORDS;
@@ -883,76 +891,81 @@ __global__ __launch_bounds__(AR_BLOCK) void k_embed_arows(EmbedTileArgs a) {
   const uint32_t items = a.n * 2;
   const uint32_t nmt = (items + ER_ITEMS - 1) / ER_ITEMS;
   const uint32_t stride = gridDim.x * AR_WAVES;
-  __syncthreads(); // weights staged (the only workgroup barrier of the kernel)
   EL_MARK(0);
-  for (uint32_t mt = blockIdx.x * AR_WAVES + wib; mt < nmt; mt += stride) {
-    // ---- encode: BOTH lanes (r, 0) and (r, 1) encode item r straight from global memory (two dependent loads: order ->
-    // stored Pokemon) -- the same instructions for the whole wave; each keeps the dense values of its own k-half in
-    // registers (x[t] = value 2t + hh, the B operand below) and lane (r, 0) writes the row indices to the wave's LDS ----
-    float x[AR_KSTEPS];
-    {
-      const uint32_t g = mt * ER_ITEMS + r32;
-      float fv[AR_FIXED];
-      uint32_t hot[AR_HOT], mv[AR_MOVES];
-      uint32_t doff = 0xFFFFFFFFu, dead_off = 0xFFFFFFFFu;
-      float hpr = 0.0f;
+  // ---- encode: BOTH lanes (r, 0) and (r, 1) encode item r straight from global memory (two dependent loads: order ->
+  // stored Pokemon) -- the same instructions for the whole wave; each keeps the dense values of its own k-half in
+  // registers (x[t] = value 2t + hh, the B operand below) and lane (r, 0) writes the row indices to the wave's LDS.  The
+  // wave's first encode runs BEFORE the weights are written to LDS (it needs none): the image's round trip hides under it ----
+  float x[AR_KSTEPS];
+  auto encode = [&](uint32_t mt)
+  {
+    const uint32_t g = mt * ER_ITEMS + r32;
+    float fv[AR_FIXED];
+    uint32_t hot[AR_HOT], mv[AR_MOVES];
+    uint32_t doff = 0xFFFFFFFFu, dead_off = 0xFFFFFFFFu;
+    float hpr = 0.0f;
 #pragma unroll
-      for (int f = 0; f < AR_FIXED; ++f) fv[f] = 0.0f;
+    for (int f = 0; f < AR_FIXED; ++f) fv[f] = 0.0f;
 #pragma unroll
-      for (int k = 0; k < AR_HOT; ++k) hot[k] = AR_ZERO * ER_RS / 4;
+    for (int k = 0; k < AR_HOT; ++k) hot[k] = AR_ZERO * ER_RS / 4;
 #pragma unroll
-      for (int k = 0; k < AR_MOVES; ++k) mv[k] = 427;
-      if (g < items) {
-        const uint32_t leaf = g >> 1, side = g & 1;
-        const uint32_t *sb = (const uint32_t *)a.battles + (size_t)leaf * 96 + side * 46;
-        const uint32_t dur = ((const uint32_t *)a.durations)[(size_t)leaf * 2 + side];
-        const uint4 av0 = *(const uint4 *)(sb + 36), av1 = *(const uint4 *)(sb + 40);
-        const uint32_t id = sb[44] & 0xFF;
-        const uint32_t dd = leaf * N.emb_dim + side * N.side_dim;
-        uint32_t pk0 = 0, pk1 = 0, pk2 = 0, pk3 = 0, pk4 = 0, pk5 = 0, hp = 0;
-        if (id != 0) {
-          const uint32_t *pk = sb + 6 * (id - 1);
-          pk0 = pk[0]; pk1 = pk[1]; pk2 = pk[2]; pk3 = pk[3]; pk4 = pk[4]; pk5 = pk[5];
-          hp = pk4 >> 16;
-        }
-        if (hp == 0) dead_off = dd; // no active / fainted active: zero block (network.h:142-143)
-        else {
-          doff = dd;
-          fv[0] = 1.0f; // the bias
-          int nh = 0, nm = 0;
-#pragma unroll
-          for (uint32_t j = 0; j < 40; ++j) { // Encode::Battle::Active (battle.h:229-489)
-            uint32_t fidx = 0; float fval = 0.0f;
-            const bool v = active_feature(j, av0.x, av0.y, av0.z, av0.w, av1.x, av1.y, av1.z, av1.w, dur, fidx, fval);
-            if (j < 5) fv[1 + j] = fval;                                   // stats: always present
-            else if (j < 7) { hot[nh++] = v ? ar_sparse_slot(fidx) * ER_RS / 4 : AR_ZERO * ER_RS / 4; } // types
-            else if (j < 13) fv[6 + (j - 7)] = fval;                       // boosts: always present
-            else if (j < 32) fv[12 + (j - 13)] = v ? fval : 0.0f;          // volatiles: dense, value 0 when absent
-            else if (j < 36) { mv[nm++] = v ? fidx : 427u; }               // move slots: rows in L2
-            else { hot[nh++] = v ? ar_sparse_slot(fidx) * ER_RS / 4 : AR_ZERO * ER_RS / 4; } // durations
-          }
-#pragma unroll
-          for (uint32_t j = 0; j < 12; ++j) { // Encode::Battle::Pokemon of the stored active (battle.h:197-214), rows + 229
-            uint32_t fidx = 0; float fval = 0.0f;
-            const bool v = pokemon_feature(j, pk0, pk1, pk2, pk3, pk4, pk5, dur & 7, fidx, fval);
-            if (j < 5) fv[31 + j] = fval;
-            else if (j < 9) { mv[nm++] = v ? fidx + 229 : 427u; }
-            else { hot[nh++] = v ? ar_sparse_slot(fidx + 229) * ER_RS / 4 : AR_ZERO * ER_RS / 4; }
-          }
-          hpr = (float)hp / (float)(pk0 & 0xFFFF);
-        }
+    for (int k = 0; k < AR_MOVES; ++k) mv[k] = 427;
+    if (g < items) {
+      const uint32_t leaf = g >> 1, side = g & 1;
+      const uint32_t *sb = (const uint32_t *)a.battles + (size_t)leaf * 96 + side * 46;
+      const uint32_t dur = ((const uint32_t *)a.durations)[(size_t)leaf * 2 + side];
+      const uint4 av0 = *(const uint4 *)(sb + 36), av1 = *(const uint4 *)(sb + 40);
+      const uint32_t id = sb[44] & 0xFF;
+      const uint32_t dd = leaf * N.emb_dim + side * N.side_dim;
+      uint32_t pk0 = 0, pk1 = 0, pk2 = 0, pk3 = 0, pk4 = 0, pk5 = 0, hp = 0;
+      if (id != 0) {
+        const uint32_t *pk = sb + 6 * (id - 1);
+        pk0 = pk[0]; pk1 = pk[1]; pk2 = pk[2]; pk3 = pk[3]; pk4 = pk[4]; pk5 = pk[5];
+        hp = pk4 >> 16;
       }
+      if (hp == 0) dead_off = dd; // no active / fainted active: zero block (network.h:142-143)
+      else {
+        doff = dd;
+        fv[0] = 1.0f; // the bias
+        int nh = 0, nm = 0;
 #pragma unroll
-      for (int t = 0; t < AR_KSTEPS; ++t) x[t] = hh ? fv[2 * t + 1] : fv[2 * t];
-      if (hh == 0) {
-        uint32_t *it = wl + r32 * AR_ITEM_WORDS;
-        it[0] = hot[0] | hot[1] << 16; it[1] = hot[2] | hot[3] << 16; it[2] = hot[4] | hot[5] << 16; it[3] = hot[6] | hot[7] << 16; it[4] = hot[8];
-        it[5] = mv[0] | mv[1] << 16; it[6] = mv[2] | mv[3] << 16; it[7] = mv[4] | mv[5] << 16; it[8] = mv[6] | mv[7] << 16;
-        dst_off[r32] = doff;
-        hp_ratio[r32] = hpr;
+        for (uint32_t j = 0; j < 40; ++j) { // Encode::Battle::Active (battle.h:229-489)
+          uint32_t fidx = 0; float fval = 0.0f;
+          const bool v = active_feature(j, av0.x, av0.y, av0.z, av0.w, av1.x, av1.y, av1.z, av1.w, dur, fidx, fval);
+          if (j < 5) fv[1 + j] = fval;                                   // stats: always present
+          else if (j < 7) { hot[nh++] = v ? ar_sparse_slot(fidx) * ER_RS / 4 : AR_ZERO * ER_RS / 4; } // types
+          else if (j < 13) fv[6 + (j - 7)] = fval;                       // boosts: always present
+          else if (j < 32) fv[12 + (j - 13)] = v ? fval : 0.0f;          // volatiles: dense, value 0 when absent
+          else if (j < 36) { mv[nm++] = v ? fidx : 427u; }               // move slots: rows in L2
+          else { hot[nh++] = v ? ar_sparse_slot(fidx) * ER_RS / 4 : AR_ZERO * ER_RS / 4; } // durations
+        }
+#pragma unroll
+        for (uint32_t j = 0; j < 12; ++j) { // Encode::Battle::Pokemon of the stored active (battle.h:197-214), rows + 229
+          uint32_t fidx = 0; float fval = 0.0f;
+          const bool v = pokemon_feature(j, pk0, pk1, pk2, pk3, pk4, pk5, dur & 7, fidx, fval);
+          if (j < 5) fv[31 + j] = fval;
+          else if (j < 9) { mv[nm++] = v ? fidx + 229 : 427u; }
+          else { hot[nh++] = v ? ar_sparse_slot(fidx + 229) * ER_RS / 4 : AR_ZERO * ER_RS / 4; }
+        }
+        hpr = (float)hp / (float)(pk0 & 0xFFFF);
       }
-      zero_blocks(a.emb, hh == 0 ? dead_off : 0xFFFFFFFFu, out_dim + 1);
     }
+#pragma unroll
+    for (int t = 0; t < AR_KSTEPS; ++t) x[t] = hh ? fv[2 * t + 1] : fv[2 * t];
+    if (hh == 0) {
+      uint32_t *it = wl + r32 * AR_ITEM_WORDS;
+      it[0] = hot[0] | hot[1] << 16; it[1] = hot[2] | hot[3] << 16; it[2] = hot[4] | hot[5] << 16; it[3] = hot[6] | hot[7] << 16; it[4] = hot[8];
+      it[5] = mv[0] | mv[1] << 16; it[6] = mv[2] | mv[3] << 16; it[7] = mv[4] | mv[5] << 16; it[8] = mv[6] | mv[7] << 16;
+      dst_off[r32] = doff;
+      hp_ratio[r32] = hpr;
+    }
+    zero_blocks(a.emb, hh == 0 ? dead_off : 0xFFFFFFFFu, out_dim + 1);
+  };
+  uint32_t mt = blockIdx.x * AR_WAVES + wib;
+  if (mt < nmt) encode(mt); // needs no weights: the image's round trip runs under it
+  stage_image_store<AR_BLOCK, 8>(lds_f, img_t, img_words);
+  __syncthreads(); // weights staged (the only workgroup barrier of the kernel)
+  while (mt < nmt) {
     __builtin_amdgcn_wave_barrier();
     EL_MARK(3);
     // ---- first layer, dense part on the matrix pipe: hb[blk] = this lane's 16 channels of block blk of item r32 ----
@@ -1028,6 +1041,8 @@ __global__ __launch_bounds__(AR_BLOCK) void k_embed_arows(EmbedTileArgs a) {
     if (hh == 0 && dst_off[r32] != 0xFFFFFFFFu) a.emb[dst_off[r32]] = hp_ratio[r32];
     __builtin_amdgcn_wave_barrier(); // the wave's LDS is rewritten by the next mini-tile
     EL_MARK(7);
+    mt += stride;
+    if (mt < nmt) encode(mt);
   }
   EL_FLUSH();
 }
@@ -1058,89 +1073,95 @@ __global__ __launch_bounds__(PR_BLOCK) void k_embed_prows(EmbedTileArgs a) {
   float *W0s = lds_f;                                   // rows 5..197 of W0^T, channels in natural order, + a zero row
   float *Wd = W0s + (PR_SPARSE + 1) * ER_RS;            // dense fragment
   float *W1s = Wd + PR_DENSE_WORDS;                     // second layer's fragments: [block][k-step][lane]
-  stage_image<PR_BLOCK, 9>(lds_f, N.p_img, (PR_SPARSE + 1) * ER_RS + PR_DENSE_WORDS + NBo * 64 * 64);
+  const int img_words = (PR_SPARSE + 1) * ER_RS + PR_DENSE_WORDS + NBo * 64 * 64;
+  float4 img_t[9];
+  stage_image_load<PR_BLOCK, 9>(img_t, N.p_img, img_words);
   const uint32_t lane = threadIdx.x & 63, wib = threadIdx.x >> 6, r32 = lane & 31, hh = lane >> 5;
   uint32_t *wl = (uint32_t *)(W1s + 2 * 64 * 64) + wib * PR_WAVE_WORDS; // this wave's private LDS
   uint32_t *dst_off = wl + ER_ITEMS * PR_ITEM_WORDS;
   float *hp_ratio = (float *)(dst_off + ER_ITEMS);
   const uint32_t stride = gridDim.x * PR_WAVES;
-  __syncthreads(); // weights staged (the only workgroup barrier of the kernel)
   EL_MARK(0);
+  // ---- encode: both lanes (r, 0) and (r, 1) encode item r; each keeps the dense values of its own k-half.  The loop below
+  // is rotated: a mini-tile's encode runs at the END of the previous one's body (the first one before the weights are
+  // written to LDS -- it needs none, so the image's round trip and the workgroup barrier hide under it). ----
+  float x[PR_KSTEPS];
+  auto encode = [&](uint32_t mt)
+  {
+    const uint32_t g = mt * ER_ITEMS + r32;
+    uint32_t gi = g, pk0 = 0, pk1 = 0, pk2 = 0, pk3 = 0, pk4 = 0, pk5 = 0, sleep = 0;
+    if (g < items) {
+      if (LIST) {
+        const uint32_t *rec = (const uint32_t *)a.work + (size_t)g * 8;
+        const uint4 r0 = *(const uint4 *)rec, r1 = *(const uint4 *)(rec + 4);
+        gi = r0.x; pk0 = r0.y; pk1 = r0.z; pk2 = r0.w; pk3 = r1.x; pk4 = r1.y; pk5 = r1.z; sleep = r1.w;
+      } else {
+        const uint32_t leaf = g / 10, q = g - leaf * 10, side = q / 5, slot = 1 + (q - side * 5);
+        // the side's whole party (36 dwords) is asked for together with its order bytes and the right Pokemon selected
+        // afterwards: ONE round trip to memory instead of two dependent ones (the five lanes of a side read the same lines)
+        const uint32_t *sb = (const uint32_t *)a.battles + (size_t)leaf * 96 + side * 46;
+        uint4 pw[9];
+#pragma unroll
+        for (int u = 0; u < 9; ++u) pw[u] = ((const uint4 *)sb)[u];
+        const uint2 ow = *(const uint2 *)(sb + 44);
+        const uint32_t o0 = ow.x, o1 = ow.y;
+        const uint32_t dur = ((const uint32_t *)a.durations)[(size_t)leaf * 2 + side];
+        const uint32_t id = slot < 4 ? (o0 >> (8 * slot)) & 0xFF : (o1 >> (8 * (slot - 4))) & 0xFF;
+        sleep = (dur >> (3 * slot)) & 7;
+        const uint32_t w[36] = {pw[0].x, pw[0].y, pw[0].z, pw[0].w, pw[1].x, pw[1].y, pw[1].z, pw[1].w, pw[2].x, pw[2].y, pw[2].z, pw[2].w,
+                                pw[3].x, pw[3].y, pw[3].z, pw[3].w, pw[4].x, pw[4].y, pw[4].z, pw[4].w, pw[5].x, pw[5].y, pw[5].z, pw[5].w,
+                                pw[6].x, pw[6].y, pw[6].z, pw[6].w, pw[7].x, pw[7].y, pw[7].z, pw[7].w, pw[8].x, pw[8].y, pw[8].z, pw[8].w};
+#pragma unroll
+        for (uint32_t k = 0; k < 6; ++k) {
+          const bool m = id == k + 1;
+          pk0 = m ? w[6 * k + 0] : pk0; pk1 = m ? w[6 * k + 1] : pk1; pk2 = m ? w[6 * k + 2] : pk2;
+          pk3 = m ? w[6 * k + 3] : pk3; pk4 = m ? w[6 * k + 4] : pk4; pk5 = m ? w[6 * k + 5] : pk5;
+        }
+      }
+    }
+    float fv[6];
+    uint32_t hot[8];
+    uint32_t doff = 0xFFFFFFFFu, dead_off = 0xFFFFFFFFu;
+    float hpr = 0.0f;
+#pragma unroll
+    for (int f = 0; f < 6; ++f) fv[f] = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) hot[k] = PR_ZERO * ER_RS / 4;
+    if (g < items) {
+      const uint32_t leaf = gi / 10, q = gi - leaf * 10, side = q / 5, slot = 1 + (q - side * 5);
+      const uint32_t hp = pk4 >> 16;
+      const uint32_t dd = leaf * N.emb_dim + side * N.side_dim + (1 + N.a_out) + (slot - 1) * (1 + N.p_out);
+      if (hp == 0) dead_off = dd; // empty or fainted: zero block (network.h:153-160), kept out of the scatter
+      else {
+        doff = dd;
+        fv[0] = 1.0f; // the bias
+#pragma unroll
+        for (uint32_t j = 0; j < 12; ++j) { // Encode::Battle::Pokemon (battle.h:197-214)
+          uint32_t fidx = 0; float fval = 0.0f;
+          const bool v = pokemon_feature(j, pk0, pk1, pk2, pk3, pk4, pk5, sleep, fidx, fval);
+          if (j < 5) fv[1 + j] = fval;
+          else hot[j - 5] = v ? (fidx - 5) * ER_RS / 4 : PR_ZERO * ER_RS / 4;
+        }
+        hpr = (float)hp / (float)(pk0 & 0xFFFF);
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < PR_KSTEPS; ++t) x[t] = hh ? fv[2 * t + 1] : fv[2 * t];
+    if (hh == 0) {
+      uint32_t *it = wl + r32 * PR_ITEM_WORDS;
+      it[0] = hot[0] | hot[1] << 16; it[1] = hot[2] | hot[3] << 16; it[2] = hot[4] | hot[5] << 16; it[3] = hot[6];
+      dst_off[r32] = doff;
+      hp_ratio[r32] = hpr;
+    }
+    zero_blocks(a.emb, hh == 0 ? dead_off : 0xFFFFFFFFu, out_dim + 1);
+  };
   // mini-tiles go round-robin over the WORKGROUPS first, so that a short work list still spreads over every CU (two waves per
   // SIMD finish a mini-tile much sooner than four)
-  for (uint32_t mt = wib * gridDim.x + blockIdx.x; mt < nmt; mt += stride) {
-    // ---- encode: both lanes (r, 0) and (r, 1) encode item r; each keeps the dense values of its own k-half.  (Fetching
-    // the raw input one mini-tile ahead, order bytes first and the Pokemon they point to after the first layer, was
-    // measured and rejected: 240 us against 226 us -- the encode is not what the kernel waits for.) ----
-    float x[PR_KSTEPS];
-    {
-      const uint32_t g = mt * ER_ITEMS + r32;
-      uint32_t gi = g, pk0 = 0, pk1 = 0, pk2 = 0, pk3 = 0, pk4 = 0, pk5 = 0, sleep = 0;
-      if (g < items) {
-        if (LIST) {
-          const uint32_t *rec = (const uint32_t *)a.work + (size_t)g * 8;
-          const uint4 r0 = *(const uint4 *)rec, r1 = *(const uint4 *)(rec + 4);
-          gi = r0.x; pk0 = r0.y; pk1 = r0.z; pk2 = r0.w; pk3 = r1.x; pk4 = r1.y; pk5 = r1.z; sleep = r1.w;
-        } else {
-          const uint32_t leaf = g / 10, q = g - leaf * 10, side = q / 5, slot = 1 + (q - side * 5);
-          // the side's whole party (36 dwords) is asked for together with its order bytes and the right Pokemon selected
-          // afterwards: ONE round trip to memory instead of two dependent ones (the five lanes of a side read the same lines)
-          const uint32_t *sb = (const uint32_t *)a.battles + (size_t)leaf * 96 + side * 46;
-          uint4 pw[9];
-#pragma unroll
-          for (int u = 0; u < 9; ++u) pw[u] = ((const uint4 *)sb)[u];
-          const uint2 ow = *(const uint2 *)(sb + 44);
-          const uint32_t o0 = ow.x, o1 = ow.y;
-          const uint32_t dur = ((const uint32_t *)a.durations)[(size_t)leaf * 2 + side];
-          const uint32_t id = slot < 4 ? (o0 >> (8 * slot)) & 0xFF : (o1 >> (8 * (slot - 4))) & 0xFF;
-          sleep = (dur >> (3 * slot)) & 7;
-          const uint32_t w[36] = {pw[0].x, pw[0].y, pw[0].z, pw[0].w, pw[1].x, pw[1].y, pw[1].z, pw[1].w, pw[2].x, pw[2].y, pw[2].z, pw[2].w,
-                                  pw[3].x, pw[3].y, pw[3].z, pw[3].w, pw[4].x, pw[4].y, pw[4].z, pw[4].w, pw[5].x, pw[5].y, pw[5].z, pw[5].w,
-                                  pw[6].x, pw[6].y, pw[6].z, pw[6].w, pw[7].x, pw[7].y, pw[7].z, pw[7].w, pw[8].x, pw[8].y, pw[8].z, pw[8].w};
-#pragma unroll
-          for (uint32_t k = 0; k < 6; ++k) {
-            const bool m = id == k + 1;
-            pk0 = m ? w[6 * k + 0] : pk0; pk1 = m ? w[6 * k + 1] : pk1; pk2 = m ? w[6 * k + 2] : pk2;
-            pk3 = m ? w[6 * k + 3] : pk3; pk4 = m ? w[6 * k + 4] : pk4; pk5 = m ? w[6 * k + 5] : pk5;
-          }
-        }
-      }
-      float fv[6];
-      uint32_t hot[8];
-      uint32_t doff = 0xFFFFFFFFu, dead_off = 0xFFFFFFFFu;
-      float hpr = 0.0f;
-#pragma unroll
-      for (int f = 0; f < 6; ++f) fv[f] = 0.0f;
-#pragma unroll
-      for (int k = 0; k < 8; ++k) hot[k] = PR_ZERO * ER_RS / 4;
-      if (g < items) {
-        const uint32_t leaf = gi / 10, q = gi - leaf * 10, side = q / 5, slot = 1 + (q - side * 5);
-        const uint32_t hp = pk4 >> 16;
-        const uint32_t dd = leaf * N.emb_dim + side * N.side_dim + (1 + N.a_out) + (slot - 1) * (1 + N.p_out);
-        if (hp == 0) dead_off = dd; // empty or fainted: zero block (network.h:153-160), kept out of the scatter
-        else {
-          doff = dd;
-          fv[0] = 1.0f; // the bias
-#pragma unroll
-          for (uint32_t j = 0; j < 12; ++j) { // Encode::Battle::Pokemon (battle.h:197-214)
-            uint32_t fidx = 0; float fval = 0.0f;
-            const bool v = pokemon_feature(j, pk0, pk1, pk2, pk3, pk4, pk5, sleep, fidx, fval);
-            if (j < 5) fv[1 + j] = fval;
-            else hot[j - 5] = v ? (fidx - 5) * ER_RS / 4 : PR_ZERO * ER_RS / 4;
-          }
-          hpr = (float)hp / (float)(pk0 & 0xFFFF);
-        }
-      }
-#pragma unroll
-      for (int t = 0; t < PR_KSTEPS; ++t) x[t] = hh ? fv[2 * t + 1] : fv[2 * t];
-      if (hh == 0) {
-        uint32_t *it = wl + r32 * PR_ITEM_WORDS;
-        it[0] = hot[0] | hot[1] << 16; it[1] = hot[2] | hot[3] << 16; it[2] = hot[4] | hot[5] << 16; it[3] = hot[6];
-        dst_off[r32] = doff;
-        hp_ratio[r32] = hpr;
-      }
-      zero_blocks(a.emb, hh == 0 ? dead_off : 0xFFFFFFFFu, out_dim + 1);
-    }
+  uint32_t mt = wib * gridDim.x + blockIdx.x;
+  if (mt < nmt) encode(mt); // needs no weights: the image's round trip runs under it
+  stage_image_store<PR_BLOCK, 9>(lds_f, img_t, img_words);
+  __syncthreads(); // weights staged (the only workgroup barrier of the kernel)
+  while (mt < nmt) {
     __builtin_amdgcn_wave_barrier();
     EL_MARK(3);
     // ---- first layer: dense part, then the one-hot rows through the identity transposition (see k_embed_arows) ----
@@ -1206,6 +1227,8 @@ __global__ __launch_bounds__(PR_BLOCK) void k_embed_prows(EmbedTileArgs a) {
     if (hh == 0 && dst_off[r32] != 0xFFFFFFFFu) a.emb[dst_off[r32]] = hp_ratio[r32];
     __builtin_amdgcn_wave_barrier(); // the wave's LDS is rewritten by the next mini-tile
     EL_MARK(7);
+    mt += stride;
+    if (mt < nmt) encode(mt);
   }
   EL_FLUSH();
 }
