@@ -1653,7 +1653,7 @@ __global__ __launch_bounds__(MN_BLOCK) void k_mainnet_direct(MainArgs a) {
 // fragments as in k_mainnet_direct but ordered by sub-chunk (frag_order_wave), read 8 k-steps at a time: 2 x 64 registers
 // of B fragments + 128 accumulators.  L2 traffic is unchanged (there, the two waves of a row-half pair read the same fragments).
 constexpr int MW_LD = MAXH + 1;
-constexpr size_t MW_BYTES = (size_t)4 * 32 * MW_LD * 4;
+constexpr size_t MW_BYTES = (size_t)(4 * 32 * MW_LD + 4 * MAXH) * 4; // four wave tiles + the bias / value_fc3 vectors
 
 __device__ __forceinline__ float f4_pick(const float4 &v, int i) { return i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w; }
 
@@ -1793,6 +1793,14 @@ __global__ __launch_bounds__(MN_BLOCK) void k_mainnet_wave(MainArgs a) {
   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
   float *tile = lds_f + wave * 32 * MW_LD;
   const float *trow = tile + r * MW_LD;
+  // the three bias vectors and value_fc3's weights, once per workgroup: read from LDS at the layer hand-overs instead of from
+  // global memory in front of them (a round trip the lone wave of a SIMD cannot hide)
+  float *vec = lds_f + 4 * 32 * MW_LD; // [b0 | b1 | b2 | w3], MAXH each
+  for (int i = threadIdx.x; i < MAXH; i += MN_BLOCK) {
+    vec[i] = i < H ? N.b0[i] : 0.0f; vec[MAXH + i] = i < H ? N.b1[i] : 0.0f;
+    vec[2 * MAXH + i] = i < VH ? N.b2[i] : 0.0f; vec[3 * MAXH + i] = i < VH ? N.w3[i] : 0.0f;
+  }
+  __syncthreads();
   const uint32_t ntiles = (a.n + 31) / 32;
   for (uint32_t wt = blockIdx.x * 4 + wave; wt < ntiles; wt += gridDim.x * 4) {
     const uint32_t row0 = wt * 32;
@@ -1803,13 +1811,13 @@ __global__ __launch_bounds__(MN_BLOCK) void k_mainnet_wave(MainArgs a) {
     wave_layer_nb<true>(N.w0g, N.emb_dim, H / 32, a.emb + (size_t)grow * N.emb_dim, acc);
     MN_MARK(10);
     __builtin_amdgcn_wave_barrier(); // (the previous tile's value_fc2 reads of the tile come first)
-    wave_store_act(acc, N.b0, H / 32, N.activation, tile);
+    wave_store_act(acc, vec, H / 32, N.activation, tile);
     __builtin_amdgcn_wave_barrier();
     MN_MARK(11);
     wave_layer_nb<false>(N.w1g, H, H / 32, trow, acc);
     MN_MARK(12);
     __builtin_amdgcn_wave_barrier();
-    wave_store_act(acc, N.b1, H / 32, N.activation, tile);
+    wave_store_act(acc, vec + MAXH, H / 32, N.activation, tile);
     __builtin_amdgcn_wave_barrier();
     if (a.h1_out) { // keep fc1's activations for the policy heads
       for (uint32_t row = 0; row < n_rows; ++row)
@@ -1818,7 +1826,7 @@ __global__ __launch_bounds__(MN_BLOCK) void k_mainnet_wave(MainArgs a) {
     MN_MARK(13);
     wave_layer_nb<false>(N.w2g, H, VH / 32, trow, acc);
     MN_MARK(14);
-    wave_value_head(acc, N.b2, N.w3, N.b3, VH / 32, N.activation, a.values, row0, n_rows);
+    wave_value_head(acc, vec + 2 * MAXH, vec + 3 * MAXH, N.b3, VH / 32, N.activation, a.values, row0, n_rows);
     MN_MARK(15);
   }
 }
