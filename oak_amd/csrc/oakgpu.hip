@@ -1392,7 +1392,10 @@ int oakgpu_rollout_group_dev(oakgpu_ctx *c, const oakgpu_rollout_batch *batches,
   }
   if (used == 0) return 0;
   if (total >= 0xFFFFFFF0ull) return bad("oakgpu_rollout_group_dev: more than 2^32 playouts in one group");
-  if (c->rollout_engine == 1 || c->playouts_per_lane <= 1) { // no queue: one launch per batch
+  // no queue: one launch per batch -- also for launches capped at a few turn-steps (stepping a resident batch turn by turn,
+  // BASELINE configs[2]): there is no tail for a queue to fill, and twice the waves hide twice the latency (measured, one
+  // turn-step of 65,536 battles: 61 us against 99 us; tools/onestep_latency.py)
+  if (c->rollout_engine == 1 || c->playouts_per_lane <= 1 || max_steps <= 16) {
     HIPCHK(hipSetDevice(c->device));
     for (uint32_t i = 0; i < used; ++i) {
       const oak::BatchDesc &d = descs[i];
