@@ -343,7 +343,7 @@ def leaf_records(args, torch, dev, rank, local_rank, world, dist, which=("leaf",
     netfile.write_random_net(path, seed=7, hidden=256, value_hidden=256)
     net = Network(ctx, path=path)
     main_f, emb_f = netfile.flops_per_leaf(256, 256)
-    live = torch.zeros((), dtype=torch.int64, device=dev)
+    live = torch.zeros((n,), dtype=torch.int32, device=dev)   # turn-steps done per lane (summed after the timed region)
     turn = [0]
     # configs[2] evaluates the SAME resident lanes every turn: the party-slot embeddings are cached by exact identity tags
     # (oakgpu_leaf_eval_cached_dev, the GPU form of the reference's PokemonCache) -- buffers the caller keeps between calls
@@ -362,7 +362,7 @@ def leaf_records(args, torch, dev, rank, local_rank, world, dist, which=("leaf",
                                           P(values), P(battles), P(durations)))
         _lib.check(lib.oakgpu_leaf_eval_cached_dev(h, net.handle, P(battles), P(durations), n, P(values), P(emb), P(tags)))
         with torch.cuda.stream(stream):
-            live.add_(steps_out.sum(dtype=torch.int64))
+            live.add_(steps_out)
 
     def timed(step, K, W):
         for _ in range(max(W, 1)):
@@ -430,7 +430,7 @@ def leaf_records(args, torch, dev, rank, local_rank, world, dist, which=("leaf",
     if "config3" in which:
         elapsed, avg_s = timed(config3_step, K, W)
         achieved = (main_f + emb_f) * n / avg_s / 1e12
-        steps_done = int(live.item())
+        steps_done = int(live.sum(dtype=torch.int64).item())
         if world > 1:
             s_ = torch.tensor([steps_done], dtype=torch.int64, device=dev)
             dist.all_reduce(s_, op=dist.ReduceOp.SUM)

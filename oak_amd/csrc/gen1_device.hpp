@@ -139,7 +139,22 @@ struct FxTable {
 };
 static __device__ const FxTable OAK_FX{};
 
-// copies the packed table images into LDS; call with all threads of the workgroup, then barrier
+// where each table sits in the workgroup's LDS table area (TABLE_LDS_BYTES)
+__device__ __forceinline__ Tables tables_at(lds_u8 *lds) {
+  lds_u32 *mv = (lds_u32 *)lds;
+  lds_u8 *pp = lds + 166 * 4;
+  lds_u32 *sp0 = (lds_u32 *)(pp + 168);
+  lds_u32 *sp1 = sp0 + 152;
+  lds_u8 *chart = (lds_u8 *)(sp1 + 152);
+  lds_u16 *boost = (lds_u16 *)(chart + 228);
+  lds_u32 *rcp = (lds_u32 *)(chart + 228 + 28);
+  lds_u16 *fx = (lds_u16 *)(rcp + 256);
+  Tables t{mv, pp, sp0, sp1, chart, boost, rcp, fx};
+  return t;
+}
+
+// builds the tables in LDS from the packed images; call with all threads of the workgroup, then barrier.  (Only the
+// table-image builder does this: the rollout kernels copy the finished image, see stage_default_tables.)
 __device__ inline Tables stage_tables(lds_u8 *lds, const uint32_t *g_mv, const uint8_t *g_pp, const uint32_t *g_sp0,
                                       const uint32_t *g_sp1, const uint8_t *g_chart, const uint16_t *g_boost) {
   lds_u32 *mv = (lds_u32 *)lds;

@@ -31,8 +31,37 @@ constexpr int STATE_LDS_BYTES = STATE_WORDS * BLOCK * 4;
 constexpr int TABLE_LDS_PAD = (TABLE_LDS_BYTES + 15) & ~15;
 constexpr int ENGINE_LDS_BYTES = STATE_LDS_BYTES + TABLE_LDS_PAD;
 
+// The engine's tables (moves, species, type chart, boosts, reciprocals, effect descriptors: 3.4 KB) as ONE image in exactly
+// their LDS layout, built once per device by k_build_table_image (oakgpu_create).  A kernel's prologue is then a straight
+// copy with all of a thread's loads in flight at once -- built table by table it was a dozen load -> wait -> store round
+// trips plus four integer divisions per thread in front of every launch (~10 us of the 61 us a one-turn launch takes).
+constexpr int TABLE_IMAGE_WORDS = TABLE_LDS_PAD / 4;
+__device__ uint32_t g_table_image[TABLE_IMAGE_WORDS];
+
+__global__ __launch_bounds__(64) void k_build_table_image() {
+  extern __shared__ __align__(16) uint8_t smem[];
+  for (int i = threadIdx.x; i < TABLE_IMAGE_WORDS; i += 64) ((lds_u32 *)smem)[i] = 0;
+  __syncthreads();
+  (void)stage_tables((lds_u8 *)smem, OAK_MOVE_WORDS, OAK_MOVE_MAXPP, OAK_SPECIES_W0, OAK_SPECIES_W1, OAK_TYPE_CHART, OAK_BOOSTS);
+  __syncthreads();
+  for (int i = threadIdx.x; i < TABLE_IMAGE_WORDS; i += 64) g_table_image[i] = ((lds_u32 *)smem)[i];
+}
+
+// call with all threads of the workgroup, then barrier (the table area is 16-byte aligned in every kernel's LDS layout)
 __device__ __forceinline__ Tables stage_default_tables(lds_u8 *lds) {
-  return stage_tables(lds, OAK_MOVE_WORDS, OAK_MOVE_MAXPP, OAK_SPECIES_W0, OAK_SPECIES_W1, OAK_TYPE_CHART, OAK_BOOSTS);
+  constexpr int N4 = TABLE_IMAGE_WORDS / 4;
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  typedef OAK_LDS u32x4 lds_u128;
+  const u32x4 *src = (const u32x4 *)g_table_image;
+  lds_u128 *dst = (lds_u128 *)lds;
+  for (int base = threadIdx.x; base < N4; base += 4 * (int)blockDim.x) {
+    u32x4 t[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { const int i = base + u * (int)blockDim.x; t[u] = src[i < N4 ? i : N4 - 1]; }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { const int i = base + u * (int)blockDim.x; if (i < N4) dst[i] = t[u]; }
+  }
+  return tables_at(lds);
 }
 
 // AoS (n x 384 B, 4-byte aligned) <-> lane-interleaved LDS, whole workgroup cooperating.
@@ -1138,6 +1167,10 @@ int oakgpu_create(oakgpu_ctx **out, int device) {
   HIPCHK(hipSetDevice(device));
   if (int r = set_lds_limits()) return r;         // kernel attributes are per device: set for every context's device
   if (int r = oakgpu_leaf_set_lds_limits()) return r;
+  // the engine's table image of this device (idempotent: every context of a device writes the same bytes)
+  hipLaunchKernelGGL(oak::k_build_table_image, dim3(1), dim3(64), oak::TABLE_LDS_PAD, 0);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(0));
   oakgpu_ctx *c = new oakgpu_ctx();
   c->device = device;
   c->own_stream = true;
