@@ -284,6 +284,81 @@ __global__ __launch_bounds__(BLK, 2) void k_rollout_regs(RolloutArgs a) {
   if (a.battles_out) e.store_battle_global(a.battles_out + (size_t)lane * 384);
 }
 
+// The same, for launches of a FEW turn-steps over a resident batch (BASELINE configs[2]: one turn-step, then a leaf
+// evaluation, every turn).  There the launch is all load / decode / encode / store: a lane reading its own 384-byte
+// battle touches a 16-byte piece of 64 different lines per instruction, and writes it back the same way (45 us for a
+// launch with ZERO steps; the HBM traffic is worth 12).  Here the wave moves its 64 battles (24 KB, contiguous) between
+// global memory and LDS with fully coalesced 1 KB accesses, and the engine reads / writes the LDS copy through `gin`
+// (a generic pointer: the flat loads resolve to LDS).
+constexpr int STAGE_STRIDE = 100; // words per staged battle: 96 + 4 (16-byte aligned rows that spread over the banks)
+constexpr int STAGED_LDS_BYTES = 24 * 64 * 4 + TABLE_LDS_PAD + 64 * STAGE_STRIDE * 4;
+__global__ __launch_bounds__(64, 2) void k_rollout_staged(RolloutArgs a) {
+  extern __shared__ __align__(16) uint8_t smem[];
+  lds_u32 *party = (lds_u32 *)smem;
+  using ER = EngineR<64, false>;
+  Tables T = stage_default_tables((lds_u8 *)smem + ER::PARTY_WORDS * 64 * 4);
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  typedef OAK_LDS u32x4 lds_u128;
+  lds_u32 *stage = (lds_u32 *)((lds_u8 *)smem + ER::PARTY_WORDS * 64 * 4 + TABLE_LDS_PAD);
+  const uint32_t tid = threadIdx.x, base = blockIdx.x * 64, lane = base + tid;
+  const uint32_t cnt = a.n - base < 64 ? a.n - base : 64; // battles of this wave
+  {
+    const u32x4 *src = (const u32x4 *)(a.battles + (size_t)base * 384);
+    u32x4 t[24];
+#pragma unroll
+    for (int k = 0; k < 24; ++k) { const uint32_t i = k * 64 + tid; t[k] = src[i < cnt * 24 ? i : 0]; } // float4 i = battle i / 24, piece i % 24
+#pragma unroll
+    for (int k = 0; k < 24; ++k) { const uint32_t i = k * 64 + tid, b = i / 24, w = i - b * 24; *(lds_u128 *)(stage + b * STAGE_STRIDE + 4 * w) = t[k]; }
+  }
+  __syncthreads();
+  uint32_t result = 0, steps = 0;
+  FastPrng g;
+  g.s0 = g.s1 = 0;
+  ER e;
+  e.m = party + tid;
+  e.T = T;
+  if (lane < a.n) {
+    const uint32_t *dsrc = (const uint32_t *)a.durations + 2 * (size_t)lane;
+    const uint32_t *psrc = (const uint32_t *)a.prng + 2 * (size_t)lane;
+    g.s0 = psrc[0];
+    g.s1 = psrc[1];
+    e.load_battle_global((const uint8_t *)(stage + tid * STAGE_STRIDE), dsrc[0], dsrc[1]);
+    if (a.prep) { // mcts.h:254-259
+      const uint32_t hi = g.next32(), lo = g.next32();
+      e.rng = ((uint64_t)hi << 32) | lo;
+      e.randomize_hidden();
+    }
+    result = a.results_in[lane];
+    while ((result & 15) == 0 && steps < a.max_steps) {
+      const uint32_t hi = g.next32(), lo = g.next32(); // uniform_64 = hi << 32 | lo
+      result = e.random_step(result, hi, lo);
+      ++steps;
+    }
+    e.normalize();
+    a.results_out[lane] = (uint8_t)result;
+    a.steps_out[lane] = steps;
+    const uint32_t t = result & 15;
+    a.values_out[lane] = t == R_WIN ? 1.0f : t == R_LOSE ? 0.0f : 0.5f;
+    uint32_t *pdst = (uint32_t *)a.prng + 2 * (size_t)lane;
+    pdst[0] = g.s0;
+    pdst[1] = g.s1;
+    if (a.durations_out) {
+      uint32_t *ddst = (uint32_t *)a.durations_out + 2 * (size_t)lane;
+      ddst[0] = e.S.dur;
+      ddst[1] = e.F.dur;
+    }
+    if (a.battles_out) e.store_battle_global((uint8_t *)(stage + tid * STAGE_STRIDE));
+  }
+  if (!a.battles_out) return;
+  __syncthreads();
+  u32x4 *dst = (u32x4 *)(a.battles_out + (size_t)base * 384);
+#pragma unroll
+  for (int k = 0; k < 24; ++k) {
+    const uint32_t i = k * 64 + tid, b = i / 24, w = i - b * 24;
+    if (i < cnt * 24) dst[i] = *(const lds_u128 *)(stage + b * STAGE_STRIDE + 4 * w);
+  }
+}
+
 // ---- K1 driven by a caller-supplied DRAW STREAM instead of per-lane fast_prng: lane i consumes
 // draws[offsets[i]], draws[offsets[i] + 1], ... -- one u64 per device.uniform_64() call of the reference loop (with
 // prep the first goes to battle.rng, mcts.h:255-257, then one per turn-step, mcts.h:452).  This is how a SHARED
@@ -1142,6 +1217,7 @@ static int set_lds_limits() {
   HIPCHK(hipFuncSetAttribute((const void *)oak::k_rollout<64>, hipFuncAttributeMaxDynamicSharedMemorySize, oak::STATE_WORDS * 64 * 4 + oak::TABLE_LDS_PAD));
   HIPCHK(hipFuncSetAttribute((const void *)oak::k_rollout_regs<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 24 * 128 * 4 + oak::TABLE_LDS_PAD));
   HIPCHK(hipFuncSetAttribute((const void *)oak::k_rollout_regs<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 24 * 64 * 4 + oak::TABLE_LDS_PAD));
+  HIPCHK(hipFuncSetAttribute((const void *)oak::k_rollout_staged, hipFuncAttributeMaxDynamicSharedMemorySize, oak::STAGED_LDS_BYTES));
   HIPCHK(hipFuncSetAttribute((const void *)oak::k_rollout_draws<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 24 * 64 * 4 + oak::TABLE_LDS_PAD));
   HIPCHK(hipFuncSetAttribute((const void *)oak::k_rollout_bins<2>, hipFuncAttributeMaxDynamicSharedMemorySize, oak::BINS_LDS_BYTES));
   HIPCHK(hipFuncSetAttribute((const void *)oak::k_rollout_bins<3>, hipFuncAttributeMaxDynamicSharedMemorySize, oak::BINS_LDS_BYTES));
@@ -1397,7 +1473,10 @@ static int launch_single(oakgpu_ctx *c, const oak::RolloutArgs &a) { // one lane
     if (c->rollout_block <= 64) hipLaunchKernelGGL(oak::k_rollout<64>, dim3((n + 63) / 64), dim3(64), lds64, c->stream, a);
     else hipLaunchKernelGGL(oak::k_rollout<256>, dim3(grid_for(n)), dim3(256), oak::ENGINE_LDS_BYTES, c->stream, a);
   } else {                      // register-resident engine (gen1_regs.hpp)
-    if (c->rollout_block == 64)
+    static const bool no_staged = getenv("OAKGPU_NO_STAGED") != nullptr; // (A/B)
+    if (a.max_steps <= 16 && !no_staged && ((uintptr_t)a.battles & 15) == 0 && (!a.battles_out || ((uintptr_t)a.battles_out & 15) == 0))
+      hipLaunchKernelGGL(oak::k_rollout_staged, dim3((n + 63) / 64), dim3(64), oak::STAGED_LDS_BYTES, c->stream, a);
+    else if (c->rollout_block == 64)
       hipLaunchKernelGGL(oak::k_rollout_regs<64>, dim3((n + 63) / 64), dim3(64), 24 * 64 * 4 + oak::TABLE_LDS_PAD, c->stream, a);
     else
       hipLaunchKernelGGL(oak::k_rollout_regs<128>, dim3((n + 127) / 128), dim3(128), 24 * 128 * 4 + oak::TABLE_LDS_PAD, c->stream, a);

@@ -45,6 +45,21 @@ def test_rollout_ragged_and_capped(gpu_ctx):
     assert (got["battles"] == ob).all() and (got["durations"] == od).all() and (got["prng"] == op).all()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,max_steps,prep", [(1, 1, False), (63, 1, True), (64, 2, False), (65, 3, True), (4099, 1, False), (4099, 16, True)])
+def test_short_launches_staged_kernel(gpu_ctx, n, max_steps, prep):
+    """Launches capped at <= 16 turn-steps take k_rollout_staged (battles staged through LDS with coalesced accesses,
+    BASELINE configs[2]'s turn-by-turn stepping): ragged wave counts, root prep, several turns in a row, against the oracle."""
+    b, d, p, r = O.make_random_ou_batch(n, seed0=0x57A6ED00 + n)
+    ob, od, op, orr = b.copy(), d.copy(), p.copy(), r.copy()
+    for turn in range(3):
+        got = gpu_ctx.rollout(b, d, r, p, max_steps=max_steps, prep=prep and turn == 0, return_state=True)
+        oout, osteps = O.rollout_batch(ob, od, orr, op, max_steps=max_steps, prep=prep and turn == 0, threads=4)
+        assert (got["steps"] == osteps).all() and (got["results"] == oout).all()
+        assert (got["battles"] == ob).all() and (got["durations"] == od).all() and (got["prng"] == op).all()
+        b, d, p, r, orr = got["battles"], got["durations"], got["prng"], got["results"], oout
+
+
 def test_rollout_empty(gpu_ctx):
     got = gpu_ctx.rollout(np.zeros((0, 384), np.uint8), np.zeros((0, 8), np.uint8), np.zeros(0, np.uint8),
                           np.zeros((0, 8), np.uint8))
