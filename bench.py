@@ -421,7 +421,7 @@ def leaf_records(args, torch, dev, rank, local_rank, world, dist, which=("leaf",
             "config": {"workload": "leaf part of configs[2]: value_inference (encode + embeddings + 768-256-256-256-1 MainNet + "
                                    "sigmoid) over 65536 mid-game states per GPU", "batch_per_gpu": n,
                        "parity": "<= 1e-5 vs numpy oracle pinned by the reference torch mirror"},
-            "roofline": {"bound": "mfma", "kernel": "oak::k_embed_prows + oak::k_embed_arows + oak::k_mainnet_wave (one value_inference call)",
+            "roofline": {"bound": "mfma", "kernel": "oak::k_embed_both (k_embed_prows + k_embed_arows in one launch) + oak::k_mainnet_wave (one value_inference call)",
                          "achieved": achieved, "peak": 157.3, "unit": "TFLOP/s", "frac": achieved / 157.3, "traffic": None,
                          "avg_call_ms": avg_s * 1e3, "algorithmic_flop_per_leaf": main_f + emb_f, "mainnet_flop_per_leaf": main_f,
                          "kernel_us": kernel_us()},
@@ -444,8 +444,8 @@ def leaf_records(args, torch, dev, rank, local_rank, world, dist, which=("leaf",
                                    "tags (PokemonCache analogue); 40-turn episodes",
                        "batch_per_gpu": n, "leaf_evals_per_s": n * world * K / elapsed,
                        "live_lane_fraction": steps_done / (n * world * K)},
-            "roofline": {"bound": "mfma", "kernel": "oak::k_rollout_queue (1 step) + oak::k_party_tags + oak::k_embed_prows<list> (changed party slots) + "
-                                                     "oak::k_embed_arows (actives) + oak::k_mainnet_wave",
+            "roofline": {"bound": "mfma", "kernel": "oak::k_rollout_staged (1 turn-step) + oak::k_party_tags + oak::k_embed_both<list> (changed party slots + "
+                                                     "actives) + oak::k_mainnet_wave",
                          "achieved": achieved, "peak": 157.3, "unit": "TFLOP/s", "frac": achieved / 157.3, "traffic": None,
                          "avg_step_ms": avg_s * 1e3, "algorithmic_flop_per_leaf": main_f + emb_f,
                          "note": "algorithmic FLOP count every embedding (SURVEY 8d: recomputed per leaf); the cache skips the unchanged party slots"},

@@ -872,8 +872,7 @@ __host__ __device__ constexpr int ar_dense_row(int d) { return d < 6 ? d - 1 : d
 // compact LDS slot of a one-hot row (types 5..19, rows 209..228, rows 398..426) and back
 __device__ __forceinline__ uint32_t ar_sparse_slot(uint32_t row) { return row < 20 ? row - 5 : row < 229 ? row - 209 + 15 : row - 398 + 35; }
 __host__ __device__ constexpr int ar_sparse_row(int slot) { return slot < 15 ? slot + 5 : slot < 35 ? slot - 15 + 209 : slot - 35 + 398; }
-__global__ __launch_bounds__(AR_BLOCK) void k_embed_arows(EmbedTileArgs a) {
-  extern __shared__ __align__(16) float lds_f[];
+__device__ __forceinline__ void embed_arows_body(const EmbedTileArgs &a, float *lds_f, const uint32_t bid, const uint32_t nblocks) {
   EL_T0();
   const NetDev &N = a.net;
   const int hidden = N.a_hidden, out_dim = N.a_out;
@@ -890,7 +889,7 @@ __global__ __launch_bounds__(AR_BLOCK) void k_embed_arows(EmbedTileArgs a) {
   float *hp_ratio = (float *)(dst_off + ER_ITEMS);
   const uint32_t items = a.n * 2;
   const uint32_t nmt = (items + ER_ITEMS - 1) / ER_ITEMS;
-  const uint32_t stride = gridDim.x * AR_WAVES;
+  const uint32_t stride = nblocks * AR_WAVES;
   EL_MARK(0);
   // ---- encode: BOTH lanes (r, 0) and (r, 1) encode item r straight from global memory (two dependent loads: order ->
   // stored Pokemon) -- the same instructions for the whole wave; each keeps the dense values of its own k-half in
@@ -961,7 +960,7 @@ __global__ __launch_bounds__(AR_BLOCK) void k_embed_arows(EmbedTileArgs a) {
     }
     zero_blocks(a.emb, hh == 0 ? dead_off : 0xFFFFFFFFu, out_dim + 1);
   };
-  uint32_t mt = blockIdx.x * AR_WAVES + wib;
+  uint32_t mt = bid * AR_WAVES + wib;
   if (mt < nmt) encode(mt); // needs no weights: the image's round trip runs under it
   stage_image_store<AR_BLOCK, 8>(lds_f, img_t, img_words);
   __syncthreads(); // weights staged (the only workgroup barrier of the kernel)
@@ -1047,6 +1046,11 @@ __global__ __launch_bounds__(AR_BLOCK) void k_embed_arows(EmbedTileArgs a) {
   EL_FLUSH();
 }
 
+__global__ __launch_bounds__(AR_BLOCK) void k_embed_arows(EmbedTileArgs a) {
+  extern __shared__ __align__(16) float lds_f[];
+  embed_arows_body(a, lds_f, blockIdx.x, gridDim.x);
+}
+
 // ---- K2, the party-slot pass in the same form as k_embed_arows (the default).  A bench Pokemon has 6 DENSE features (bias,
 // 5 stats: 3 k-steps x 4 blocks = 12 MFMAs in the "lane = item" orientation) and 7 ONE-HOT rows (4 move slots, status, 2
 // types; 193 possible rows, all LDS-resident in natural channel order): in k-step t the half-wave hh sums the 7 rows of
@@ -1061,15 +1065,14 @@ constexpr int PR_BLOCK = 1024, PR_WAVES = 16;
 constexpr int PR_DENSE_WORDS = PR_KSTEPS * 4 * 64;
 constexpr size_t PR_BYTES = (size_t)((PR_SPARSE + 1) * ER_RS + PR_DENSE_WORDS + 2 * 64 * 64 + PR_WAVES * PR_WAVE_WORDS) * 4;
 template <bool LIST>
-__global__ __launch_bounds__(PR_BLOCK) void k_embed_prows(EmbedTileArgs a) {
-  extern __shared__ __align__(16) float lds_f[];
+__device__ __forceinline__ void embed_prows_body(const EmbedTileArgs &a, float *lds_f, const uint32_t bid, const uint32_t nblocks) {
   EL_T0();
   const NetDev &N = a.net;
   const int hidden = N.p_hidden, out_dim = N.p_out;
   const int NBo = (out_dim + 31) >> 5;
   const uint32_t items = LIST ? *a.work_count : a.n * 10;
   const uint32_t nmt = (items + ER_ITEMS - 1) / ER_ITEMS;
-  if (blockIdx.x >= nmt) return; // (a very short work list: no weights staged for nothing)
+  if (bid >= nmt) return; // (a very short work list: no weights staged for nothing)
   float *W0s = lds_f;                                   // rows 5..197 of W0^T, channels in natural order, + a zero row
   float *Wd = W0s + (PR_SPARSE + 1) * ER_RS;            // dense fragment
   float *W1s = Wd + PR_DENSE_WORDS;                     // second layer's fragments: [block][k-step][lane]
@@ -1080,7 +1083,7 @@ __global__ __launch_bounds__(PR_BLOCK) void k_embed_prows(EmbedTileArgs a) {
   uint32_t *wl = (uint32_t *)(W1s + 2 * 64 * 64) + wib * PR_WAVE_WORDS; // this wave's private LDS
   uint32_t *dst_off = wl + ER_ITEMS * PR_ITEM_WORDS;
   float *hp_ratio = (float *)(dst_off + ER_ITEMS);
-  const uint32_t stride = gridDim.x * PR_WAVES;
+  const uint32_t stride = nblocks * PR_WAVES;
   EL_MARK(0);
   // ---- encode: both lanes (r, 0) and (r, 1) encode item r; each keeps the dense values of its own k-half.  The loop below
   // is rotated: a mini-tile's encode runs at the END of the previous one's body (the first one before the weights are
@@ -1157,7 +1160,7 @@ __global__ __launch_bounds__(PR_BLOCK) void k_embed_prows(EmbedTileArgs a) {
   };
   // mini-tiles go round-robin over the WORKGROUPS first, so that a short work list still spreads over every CU (two waves per
   // SIMD finish a mini-tile much sooner than four)
-  uint32_t mt = wib * gridDim.x + blockIdx.x;
+  uint32_t mt = wib * nblocks + bid;
   if (mt < nmt) encode(mt); // needs no weights: the image's round trip runs under it
   stage_image_store<PR_BLOCK, 9>(lds_f, img_t, img_words);
   __syncthreads(); // weights staged (the only workgroup barrier of the kernel)
@@ -1231,6 +1234,24 @@ __global__ __launch_bounds__(PR_BLOCK) void k_embed_prows(EmbedTileArgs a) {
     if (mt < nmt) encode(mt);
   }
   EL_FLUSH();
+}
+
+template <bool LIST>
+__global__ __launch_bounds__(PR_BLOCK) void k_embed_prows(EmbedTileArgs a) {
+  extern __shared__ __align__(16) float lds_f[];
+  embed_prows_body<LIST>(a, lds_f, blockIdx.x, gridDim.x);
+}
+
+// Both embedding passes in ONE launch (the default): workgroups [0, np) run the party-slot pass, the rest the actives'
+// pass.  A CU holds one of these workgroups at a time (LDS), so the actives' workgroups start where the party pass's finish:
+// one kernel boundary less, and the slow tail of the first pass (the last waves of 256 CUs finishing one by one) is filled
+// by the second instead of standing between two launches.
+static_assert(PR_BLOCK == AR_BLOCK, "the merged launch uses one workgroup size");
+template <bool LIST>
+__global__ __launch_bounds__(PR_BLOCK) void k_embed_both(EmbedTileArgs party, EmbedTileArgs actives, uint32_t np) {
+  extern __shared__ __align__(16) float lds_f[];
+  if (blockIdx.x < np) embed_prows_body<LIST>(party, lds_f, blockIdx.x, np);
+  else embed_arows_body(actives, lds_f, blockIdx.x - np, gridDim.x - np);
 }
 
 // ---- party-slot embedding cache (the GPU form of NN::Battle::PokemonCache, cpp/include/nn/battle/cache.h:18-131) ------------
@@ -2206,6 +2227,13 @@ int oakgpu_leaf_set_lds_limits(void) { // per DEVICE (hipFuncSetAttribute applie
   if (e != hipSuccess) return oakgpu_fail_hip((int)e, "hipFuncSetAttribute(k_embed_arows)");
   e = hipFuncSetAttribute((const void *)oak::k_embed_prows<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)oak::PR_BYTES);
   if (e != hipSuccess) return oakgpu_fail_hip((int)e, "hipFuncSetAttribute(k_embed_prows)");
+  {
+    const int both_bytes = (int)(oak::PR_BYTES > oak::ar_bytes(4) ? oak::PR_BYTES : oak::ar_bytes(4));
+    e = hipFuncSetAttribute((const void *)oak::k_embed_both<false>, hipFuncAttributeMaxDynamicSharedMemorySize, both_bytes);
+    if (e != hipSuccess) return oakgpu_fail_hip((int)e, "hipFuncSetAttribute(k_embed_both)");
+    e = hipFuncSetAttribute((const void *)oak::k_embed_both<true>, hipFuncAttributeMaxDynamicSharedMemorySize, both_bytes);
+    if (e != hipSuccess) return oakgpu_fail_hip((int)e, "hipFuncSetAttribute(k_embed_both<list>)");
+  }
   e = hipFuncSetAttribute((const void *)oak::k_embed_prows<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)oak::PR_BYTES);
   if (e != hipSuccess) return oakgpu_fail_hip((int)e, "hipFuncSetAttribute(k_embed_prows<list>)");
   e = hipFuncSetAttribute((const void *)oak::k_embed_lds<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)oak::ELayout<true>::BYTES);
@@ -2240,7 +2268,32 @@ static int leaf_eval_impl(oakgpu_ctx *ctx, oakgpu_net *net, const uint8_t *battl
   hipEvent_t *tev = (hipEvent_t *)oakgpu_ctx_timing_events(ctx); // diagnostic only (oakgpu_set_kernel_timing)
   {
     static const int kinds = getenv("OAKGPU_EMBED_KINDS") ? atoi(getenv("OAKGPU_EMBED_KINDS")) : 3; // diagnostics: 1 party, 2 actives
-    for (int kind = 0; kind < 2; ++kind) {
+    static const bool split = getenv("OAKGPU_EMBED_SPLIT") != nullptr; // A/B: the two passes as two launches
+    // default: both embedding passes in one launch (k_embed_both).  Not while the per-kernel timing diagnostic is on (it
+    // wants an event between the passes), nor for layer widths the row kernels do not take.
+    const bool both = embed_impl >= 4 && embed_impl != 6 && rows_ok && D.a_hidden <= 128 && D.a_out <= 128 && kinds == 3 && !split && !tev &&
+                      !getenv("OAKGPU_ACTIVE_TILE");
+    if (both) {
+      oak::EmbedTileArgs tp{D, battles, durations, n, emb, 0, nullptr, nullptr}, tact{D, battles, durations, n, emb, 1, nullptr, nullptr};
+      const uint32_t nmt_a = (n * 2 + oak::ER_ITEMS - 1) / oak::ER_ITEMS, wg_a0 = (nmt_a + oak::AR_WAVES - 1) / oak::AR_WAVES, wg_a = wg_a0 < 256 ? wg_a0 : 256;
+      const size_t lds = oak::PR_BYTES > oak::ar_bytes((D.a_out + 31) / 32) ? oak::PR_BYTES : oak::ar_bytes((D.a_out + 31) / 32);
+      if (slot_tags) { // cached party-slot pass: tag comparison, then only the changed slots (work list)
+        uint8_t *ws = (uint8_t *)oakgpu_ctx_workspace(ctx, 2, (size_t)n * 10 * sizeof(oak::PartyWork) + 16);
+        if (!ws) return -1;
+        uint32_t *count = (uint32_t *)ws;
+        oak::PartyWork *work = (oak::PartyWork *)(ws + 16);
+        hipError_t me = hipMemsetAsync(count, 0, 4, stream);
+        if (me != hipSuccess) return oakgpu_fail_hip((int)me, "hipMemsetAsync(work count)");
+        hipLaunchKernelGGL(oak::k_party_tags, dim3((n * 10 + 256 * oak::TAG_R - 1) / (256 * oak::TAG_R)), dim3(256), 0, stream, D, battles, durations, n, emb, slot_tags, work, count);
+        tp.work = work;
+        tp.work_count = count;
+        hipLaunchKernelGGL(oak::k_embed_both<true>, dim3(256 + wg_a), dim3(oak::PR_BLOCK), lds, stream, tp, tact, 256u);
+      } else {
+        const uint32_t nmt_p = (n * 10 + oak::ER_ITEMS - 1) / oak::ER_ITEMS, wg_p0 = (nmt_p + oak::PR_WAVES - 1) / oak::PR_WAVES, wg_p = wg_p0 < 256 ? wg_p0 : 256;
+        hipLaunchKernelGGL(oak::k_embed_both<false>, dim3(wg_p + wg_a), dim3(oak::PR_BLOCK), lds, stream, tp, tact, wg_p);
+      }
+    }
+    for (int kind = 0; kind < 2 && !both; ++kind) {
       if (tev) (void)hipEventRecord(tev[kind], stream);
       if (!((kinds >> kind) & 1)) continue;
       oak::EmbedTileArgs ta{D, battles, durations, n, emb, kind, nullptr, nullptr};
