@@ -626,8 +626,40 @@ def search_workload(args, torch, dev, rank, local_rank, world, dist):
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    # BASELINE configs[4]: the same search fed by batched network leaf evaluations (768-256-256-256-1) instead of rollouts,
+    # exact Nash of the root matrix solved on the host (oakgpu_search_output.nash_value, csrc/nash.hpp) after every search
+    import tempfile
+    from oak_amd import netfile
+    from oak_amd.engine import Network
+    path = os.path.join(tempfile.mkdtemp(), "config5.battle.net")
+    netfile.write_random_net(path, seed=7, hidden=256, value_hidden=256)
+    net = Network(ctx, path=path)
+    tree_search(ctx, b, d, r, iterations=2 * batch, batch=batch, evaluator=net)      # warm-up
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    outs_nn = [tree_search(ctx, b, d, r, iterations=iters, batch=batch, seed=k, evaluator=net) for k in range(K)]
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    elapsed_nn = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed_nn], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed_nn = float(t.item())
+    nn_rec = {"metric": "search iterations/s (tree search, batched network leaf evaluations, exact Nash at the root)",
+              "value": iters * K * world / elapsed_nn, "unit": "iterations/s", "n_gpus": world, "steps": K, "warmup": 1,
+              "ms_per_step": elapsed_nn / K * 1e3, "higher_is_better": True, "scaling": "weak", "dtype": "f32", "data": "synthetic",
+              "config": {"workload": "configs[4]: MCTS::Search::run with NN::Battle::Network leaves (768-256-256-256-1, seeded synthetic "
+                                     "weights), joint UCB (c = 2), 2^18 iterations per search in batches of 16384 descents, exact Nash "
+                                     "of the root's empirical matrix on the host; one random OU turn-1 root per GPU",
+                         "nodes": outs_nn[-1]["nodes"], "mean_depth": outs_nn[-1]["mean_depth"], "nash_value": outs_nn[-1]["nash_value"],
+                         "leaf_evals_per_s": iters * K * world / elapsed_nn}}
+    net.close()
     if rank == 0:
         print(json.dumps({
+            "config5_network_leaves": nn_rec,
             "metric": "search iterations/s (tree search, batched Monte-Carlo leaves)", "value": iters * K * world / elapsed,
             "unit": "iterations/s", "n_gpus": world, "steps": K, "warmup": 1, "ms_per_step": elapsed / K * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u16", "data": "synthetic",

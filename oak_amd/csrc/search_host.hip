@@ -61,6 +61,17 @@ struct Tree {
     return h ^ (h >> 31);
   }
   uint32_t new_node() { nodes.emplace_back(); return (uint32_t)nodes.size() - 1; }
+  // start a new search in the memory of the previous one (a search adds a node per iteration: tens of MB whose first touch
+  // -- page faults, vector regrowth, table rehashes -- cost a third of the host time of a 2^18-iteration search)
+  void reset(size_t expected_nodes) {
+    nodes.clear();
+    if (nodes.capacity() < expected_nodes + 16) nodes.reserve(expected_nodes + 16);
+    size_t want = 1u << 16;
+    while (want * 6 < (expected_nodes + 16) * 10) want *= 2;
+    if (table.size() < want) table.resize(want);
+    memset(table.data(), 0, table.size() * sizeof(Edge));
+    count = 0;
+  }
   void grow() {
     std::vector<Edge> old;
     old.swap(table);
@@ -70,6 +81,10 @@ struct Tree {
     for (const Edge &e : old)
       if (e.used) { size_t i = e.hash & mask; while (table[i].used) i = (i + 1) & mask; table[i] = e; }
   }
+  // the host loops over a batch's lanes are bound by cache misses on this table and on `nodes` (tens of MB per search):
+  // they ask for a later lane's lines while working on the current one
+  void prefetch_edge(uint32_t parent, const uint8_t *key) const { __builtin_prefetch(&table[hash_of(parent, key) & (table.size() - 1)]); }
+  void prefetch_node(uint32_t node) const { if (node < nodes.size()) { __builtin_prefetch(&nodes[node]); __builtin_prefetch((const char *)&nodes[node] + 64); } }
   // child of `parent` along (i, j, obs) = key; created (uninitialised) when absent -- heap.children[{i, j, obs}] (mcts.h:359-361)
   uint32_t child(uint32_t parent, const uint8_t *key) {
     if ((count + 1) * 10 > table.size() * 6) grow();
@@ -194,7 +209,9 @@ extern "C" int oakgpu_search(oakgpu_ctx *ctx, oakgpu_net *net, const uint8_t *ba
   memcpy(out->p2_choices, root_c2, 9);
   if ((result & 15) != 0 || m == 0 || n == 0) return oakgpu_fail_msg("oakgpu_search: the root position is terminal");
 
-  Tree tree;
+  static thread_local Tree tree_storage; // (kept between searches of a thread: see Tree::reset)
+  Tree &tree = tree_storage;
+  tree.reset(prm->duration_us != 0 ? (size_t)1 << 20 : (size_t)std::min<uint64_t>(prm->iterations, (uint64_t)1 << 24));
   const uint32_t root = tree.new_node();
   tree.nodes[root].p1.init(m, BP.kind);
   tree.nodes[root].p2.init(n, BP.kind);
@@ -322,6 +339,7 @@ extern "C" int oakgpu_search(oakgpu_ctx *ctx, oakgpu_net *net, const uint8_t *ba
     for (uint32_t depth = 0; n_active > 0; ++depth) {
       const auto ta = now();
       for (uint32_t l = 0; l < nb; ++l) { // bandit selection, sequential: each lane sees the virtual losses before it
+        if (l + 12 < nb && S.active[l + 12]) tree.prefetch_node(S.cur[l + 12]);
         if (!S.active[l]) { S.h_c1[l] = 0xFF; S.h_c2[l] = 0xFF; continue; }
         uint8_t i, j;
         if (mucb && depth == 0) { // sampled / forced root action; the root bandits are neither consulted nor updated
@@ -363,6 +381,13 @@ extern "C" int oakgpu_search(oakgpu_ctx *ctx, oakgpu_net *net, const uint8_t *ba
       HIPRC(hipStreamSynchronize(S.stream));
       const auto tc = now();
       for (uint32_t l = 0; l < nb; ++l) {
+        if (l + 16 < nb && S.active[l + 16] && (S.h_r[l + 16] & 15) == 0) {
+          uint8_t pk[18];
+          pk[0] = S.path[l + 16].back().i;
+          pk[1] = S.path[l + 16].back().j;
+          memcpy(pk + 2, S.h_act + (size_t)(l + 16) * 16, 16);
+          tree.prefetch_edge(S.cur[l + 16], pk);
+        }
         if (!S.active[l]) continue;
         if ((S.h_r[l] & 15) != 0) { // terminal edge: the value comes from the result byte (mcts.h:427-441)
           S.active[l] = 0; --n_active; total_depth += depth + 1;
@@ -402,6 +427,7 @@ extern "C" int oakgpu_search(oakgpu_ctx *ctx, oakgpu_net *net, const uint8_t *ba
     const auto tf = now();
     const uint32_t nb = S.nb;
     for (uint32_t l = 0; l < nb; ++l) {
+      if (l + 8 < nb) { for (const Step &st : S.path[l + 8]) if (st.node != NO_NODE) tree.prefetch_node(st.node); if (S.leaf[l + 8] != NO_NODE) tree.prefetch_node(S.leaf[l + 8]); }
       float v1;
       const uint32_t t = S.h_r[l] & 15;
       if (t != 0) v1 = t == 1 ? 1.0f : t == 2 ? 0.0f : 0.5f;
