@@ -1,15 +1,13 @@
 // oak_amd/csrc/leafnet.hip -- fp32 leaf evaluator on gfx950 (K2 + K3) and its C ABI.
 //
 // Replaces NN::Battle::NetworkImpl::value_inference (cpp/include/nn/battle/network.h:72-79):
-//   K2  k_embed_lds : Encode::Battle::{Pokemon,ActivePokemon}::write (encode/battle/battle.h:208-214,
-//                   544-551) fused with EmbeddingNet::propagate (nn/ffn.h:47-51, affine.h:87-103)
-//                   and write_battle_embedding (network.h:131-175): 64-item tiles, one lane per sparse
-//                   feature, first-layer weights resident in LDS, dense second layer on fp32 MFMA
-//                   (k_embed_tile = the previous L2-gather form, OAKGPU_EMBED_IMPL=2, kept for A/B).
-//                   The reference's per-battle embedding caches (nn/battle/cache.h) are replaced
-//                   by recomputation.
-//   K3  k_mainnet : MainNet::propagate value path (nn/battle/main-net.h:57-64) + sigmoid, the three
-//                   dense layers on v_mfma_f32_32x32x2_f32 (exact fp32), activations never leave LDS.
+//   K2  k_embed_both (k_embed_prows + k_embed_arows; k_embed_lds for embedding widths those do not take):
+//                   Encode::Battle::{Pokemon,ActivePokemon}::write (encode/battle/battle.h:208-214, 544-551) fused with
+//                   EmbeddingNet::propagate (nn/ffn.h:47-51, affine.h:87-103) and write_battle_embedding
+//                   (network.h:131-175): first-layer weights resident in LDS, dense parts on fp32 MFMA.  The reference's
+//                   per-battle embedding cache (nn/battle/cache.h) is oakgpu_leaf_eval_cached_dev (k_party_tags).
+//   K3  k_mainnet_wave : MainNet::propagate value path (nn/battle/main-net.h:57-64) + sigmoid, the three dense layers on
+//                   v_mfma_f32_32x32x2_f32 (exact fp32); k_policy: the policy heads (main-net.h:67-107).
 // Parameter file reader: nn/affine.h:35-70, network.h:52-70, main-net.h:36-55, search.cc:127-131.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -29,18 +27,15 @@ struct NetDev {
   // embedding nets: W0t [in][hidden <= 128] (transposed: one row per input feature), b0, b1
   const float *p_w0t, *p_b0, *p_b1;
   const float *a_w0t, *a_b0, *a_b1;
-  const float *p_w1, *a_w1; // second layers in file layout [out][hidden] (MFMA B operand of k_embed_tile)
-  // k_embed_arows: the active net's W0^T with every row de-interleaved [even channels | odd channels] and padded to 128
-  // floats, + an all-zero row 427 (absent move slots point at it); W1 in MFMA-fragment order [n-block][k-step][lane]
+  const float *p_w1, *a_w1; // second layers in file layout [out][hidden] (k_embed_lds)
   const float *a_w0d, *a_img; // k_embed_arows: padded W0^T (move rows), and the image of its LDS weights (arows_image)
   const float *p_img;         // k_embed_prows: the image of its LDS weights (prows_image)
   int p_hidden, p_out, a_hidden, a_out;
   int side_dim, emb_dim;
   int activation; // 1 relu, 2 clamp
   // main net (value path), rows padded to multiples of 32 with zeros
-  const float *w0, *b0, *w1, *b1, *w2, *b2, *w3;
-  const float *w0f, *w1f, *w2f; // the same three weight matrices in MFMA-fragment order (frag_order below), for k_mainnet_direct
-  const float *w0g, *w1g, *w2g; // ... and in k_mainnet_wave's order (frag_order_wave): a sub-chunk's fragments contiguous
+  const float *b0, *b1, *b2, *w3;
+  const float *w0g, *w1g, *w2g; // the three weight matrices in k_mainnet_wave's MFMA-fragment order (frag_order_wave)
   float b3;
   int H, VH; // padded dims
   // policy heads (main-net.h:67-107): fc2 [PHp][H] (rows padded to 32), fc3 [315][PHp] (+ biases)
@@ -54,7 +49,6 @@ __device__ __forceinline__ float act_fn(float x, int activation) {
 }
 
 // ---- K2 ---------------------------------------------------------------------------------------
-constexpr int EMB_BLOCK = 256;
 
 __device__ __forceinline__ uint32_t status_index(uint32_t status, uint32_t sleeps) { // battle.h:103-123
   if (!(status & 7)) return (uint32_t)__builtin_ctz(status) - 3;
@@ -149,13 +143,9 @@ __device__ __forceinline__ bool active_feature(uint32_t j, uint32_t a0, uint32_t
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
-// ---- K2, tiled form: 64 same-kind items (party slots or actives) per workgroup pass.
-// Phase 1 (per wave, 16 items): sparse feature list -> gather-add of W0^T rows (8 rows = 16 loads in
-// flight) -> activated hidden row into an LDS tile H[64][hidden].  Phase 2: H . W1^T on fp32 MFMA
-// (W1 staged once per workgroup in its file layout [out][hidden]).  Phase 3: bias + activation + scatter
-// into the battle embedding.  The dense second layer is ~80% of the embedding FLOPs, so it belongs on
-// the matrix pipe; the sparse first layer stays a VALU gather.
-constexpr int ET = 64;          // items per tile
+// ---- K2: the embedding passes.  Items = party slots (10 per leaf) or actives (2 per leaf); the dense second layer is ~80% of
+// the embedding FLOPs and runs on the matrix pipe in every form below.
+constexpr int ET = 64;          // items per tile (k_embed_lds)
 constexpr int EHP = 129;        // padded LDS row (odd stride: conflict-free column reads)
 struct EmbedTileArgs {
   NetDev net;
@@ -169,153 +159,6 @@ struct EmbedTileArgs {
   const uint32_t *work_count;
 };
 struct PartyWork { uint32_t item, pk[6], sleep; }; // item = leaf * 10 + q; the slot's stored Pokemon; its public sleep turns
-
-__global__ __launch_bounds__(EMB_BLOCK) void k_embed_tile(EmbedTileArgs a) {
-  extern __shared__ __align__(16) float lds_f[];
-  const NetDev &N = a.net;
-  const bool act_kind = a.kind == 1;
-  const int hidden = act_kind ? N.a_hidden : N.p_hidden;
-  const int out_dim = act_kind ? N.a_out : N.p_out;
-  const int out_pad = (out_dim + 31) & ~31;
-  const int NBo = out_pad / 32;
-  float *Hs = lds_f;                       // ET x EHP
-  float *Ws = Hs + ET * EHP;               // out_pad x EHP
-  float *scratch = Ws + out_pad * EHP;     // per wave 128 floats: idx list, val list
-  uint32_t *dst_off = (uint32_t *)(scratch + 4 * 128); // ET
-  float *hp_ratio = (float *)(dst_off + ET);           // ET
-  uint32_t *Bs = (uint32_t *)(hp_ratio + ET);          // staged battles of the tile's leaves: 98 dwords each
-  const float *W1 = act_kind ? N.a_w1 : N.p_w1;
-  for (int i = threadIdx.x; i < out_pad * 128; i += EMB_BLOCK) {
-    const int o = i >> 7, c = i & 127;
-    Ws[o * EHP + c] = (o < out_dim && c < hidden) ? W1[o * hidden + c] : 0.0f;
-  }
-  const uint32_t lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
-  uint32_t *list_idx = (uint32_t *)(scratch + wib * 128);
-  float *list_val = scratch + wib * 128 + 64;
-  const uint32_t per_leaf = act_kind ? 2 : 10;
-  const uint32_t items = a.n * per_leaf;
-  const uint32_t ntiles = (items + ET - 1) / ET;
-  const float *w0t = act_kind ? N.a_w0t : N.p_w0t;
-  const float *b0 = act_kind ? N.a_b0 : N.p_b0;
-  const float *b1 = act_kind ? N.a_b1 : N.p_b1;
-  const uint32_t c0 = lane, c1 = lane + 64;
-  const bool on0 = (int)c0 < hidden, on1 = (int)c1 < hidden;
-  const uint32_t cc0 = on0 ? c0 : 0, cc1 = on1 ? c1 : 0;
-  for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    __syncthreads(); // previous tile fully consumed (also orders the one-time Ws staging)
-    // ---- phase 0: stage the battles this tile touches (<= ET_LEAVES leaves) with coalesced loads ----
-    const uint32_t first_leaf = (tile * ET) / per_leaf;
-    uint32_t last_leaf = (tile * ET + ET - 1) / per_leaf;
-    if (last_leaf >= a.n) last_leaf = a.n - 1;
-    const uint32_t nleaves = last_leaf - first_leaf + 1;
-    {
-      const uint32_t *gb = (const uint32_t *)a.battles + (size_t)first_leaf * 96;
-      const uint32_t *gd = (const uint32_t *)a.durations + (size_t)first_leaf * 2;
-      for (uint32_t i = threadIdx.x; i < nleaves * 96; i += EMB_BLOCK) { const uint32_t l = i / 96; Bs[l * 98 + (i - l * 96)] = gb[i]; }
-      for (uint32_t i = threadIdx.x; i < nleaves * 2; i += EMB_BLOCK) Bs[(i >> 1) * 98 + 96 + (i & 1)] = gd[i];
-    }
-    __syncthreads();
-    // ---- phase 1: this wave's 16 items ----
-    for (uint32_t ii = 0; ii < 16; ++ii) {
-      const uint32_t i = wib * 16 + ii;
-      const uint32_t g = tile * ET + i;
-      float *hrow = Hs + i * EHP;
-      if (g >= items) { if (lane == 0) dst_off[i] = 0xFFFFFFFFu; hrow[c0] = 0.0f; hrow[c1] = 0.0f; continue; }
-      const uint32_t leaf = g / per_leaf, q = g - leaf * per_leaf;
-      const uint32_t side = act_kind ? q : q / 5, slot = act_kind ? 0 : 1 + (q - side * 5);
-      const uint32_t *lb = Bs + (leaf - first_leaf) * 98;
-      const uint32_t *sb = lb + side * 46;
-      const uint32_t dur = lb[96 + side];
-      const uint32_t o0 = sb[44], o1 = sb[45];
-      const uint32_t id = slot < 4 ? (o0 >> (8 * slot)) & 0xFF : (o1 >> (8 * (slot - 4))) & 0xFF;
-      const uint32_t doff = leaf * N.emb_dim + side * N.side_dim + (act_kind ? 0 : (1 + N.a_out) + (slot - 1) * (1 + N.p_out));
-      uint32_t pk0 = 0, pk1 = 0, pk2 = 0, pk3 = 0, pk4 = 0, pk5 = 0, hp = 0;
-      if (id != 0) {
-        const uint32_t *pk = sb + 6 * (id - 1);
-        pk0 = pk[0]; pk1 = pk[1]; pk2 = pk[2]; pk3 = pk[3]; pk4 = pk[4]; pk5 = pk[5];
-        hp = pk4 >> 16;
-      }
-      if (hp == 0) { // empty or fainted: zero block now, and keep it out of phase 3
-        float *dst = a.emb + doff;
-        for (uint32_t o = lane; o < (uint32_t)out_dim + 1; o += 64) dst[o] = 0.0f;
-        if (lane == 0) dst_off[i] = 0xFFFFFFFFu;
-        hrow[c0] = 0.0f; hrow[c1] = 0.0f;
-        continue;
-      }
-      uint32_t fidx = 0;
-      float fval = 0.0f;
-      bool valid = false;
-      if (act_kind) {
-        const uint32_t *ac = sb + 36;
-        if (lane < 40) valid = active_feature(lane, ac[0], ac[1], ac[2], ac[3], ac[4], ac[5], ac[6], ac[7], dur, fidx, fval);
-        else if (lane < 52) { valid = pokemon_feature(lane - 40, pk0, pk1, pk2, pk3, pk4, pk5, dur & 7, fidx, fval); fidx += 229; }
-      } else if (lane < 12) {
-        valid = pokemon_feature(lane, pk0, pk1, pk2, pk3, pk4, pk5, (dur >> (3 * slot)) & 7, fidx, fval);
-      }
-      const uint64_t mask = __ballot(valid);
-      const uint32_t count = (uint32_t)__popcll(mask);
-      list_idx[lane] = 0;
-      list_val[lane] = 0.0f;
-      if (valid) {
-        const uint32_t pos = (uint32_t)__popcll(mask & ((1ull << lane) - 1));
-        list_idx[pos] = fidx;
-        list_val[pos] = fval;
-      }
-      float h0 = on0 ? b0[c0] : 0.0f, h1 = on1 ? b0[c1] : 0.0f;
-      for (uint32_t k = 0; k < count; k += 16) { // 16 rows = 32 independent loads in flight
-        uint32_t ix[16];
-        float vx[16], x0[16], x1[16];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const uint4 iv = *(const uint4 *)(list_idx + k + 4 * u);
-          const float4 vv = *(const float4 *)(list_val + k + 4 * u);
-          ix[4 * u] = iv.x; ix[4 * u + 1] = iv.y; ix[4 * u + 2] = iv.z; ix[4 * u + 3] = iv.w;
-          vx[4 * u] = vv.x; vx[4 * u + 1] = vv.y; vx[4 * u + 2] = vv.z; vx[4 * u + 3] = vv.w;
-        }
-#pragma unroll
-        for (int u = 0; u < 16; ++u) { const float *rr = w0t + (size_t)ix[u] * hidden; x0[u] = rr[cc0]; x1[u] = rr[cc1]; }
-#pragma unroll
-        for (int u = 0; u < 16; ++u) { h0 = fmaf(x0[u], vx[u], h0); h1 = fmaf(x1[u], vx[u], h1); }
-      }
-      hrow[c0] = on0 ? act_fn(h0, N.activation) : 0.0f;
-      hrow[c1] = on1 ? act_fn(h1, N.activation) : 0.0f;
-      if (lane == 0) { dst_off[i] = doff; hp_ratio[i] = (float)hp / (float)(pk0 & 0xFFFF); }
-    }
-    __syncthreads();
-    // ---- phase 2: OUT[64][out_pad] = H[64][128] . W1^T on fp32 MFMA ----
-    const int mi = wib & 1, nb0 = wib >> 1, r = lane & 31, hh = lane >> 5;
-    f32x16 acc[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int q = 0; q < 16; ++q) acc[j][q] = 0.0f;
-    const float *arow = Hs + (mi * 32 + r) * EHP + hh;
-    const float *brow = Ws + (nb0 * 32 + r) * EHP + hh;
-#pragma unroll 16
-    for (int s = 0; s < 64; ++s) {
-      const float av = arow[2 * s];
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-        if (nb0 + 2 * j < NBo) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, brow[j * 64 * EHP + 2 * s], acc[j], 0, 0, 0);
-    }
-    // ---- phase 3: bias + activation + scatter ----
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int nb = nb0 + 2 * j;
-      if (nb < NBo) {
-        const int o = nb * 32 + r;
-        const float bias = o < out_dim ? b1[o] : 0.0f;
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-          const int row = (q & 3) + 8 * (q >> 2) + 4 * hh;
-          const uint32_t doff = dst_off[mi * 32 + row];
-          if (o < out_dim && doff != 0xFFFFFFFFu) a.emb[(size_t)doff + 1 + o] = act_fn(acc[j][q] + bias, N.activation);
-        }
-      }
-    }
-    if (threadIdx.x < ET && dst_off[threadIdx.x] != 0xFFFFFFFFu) a.emb[dst_off[threadIdx.x]] = hp_ratio[threadIdx.x];
-  }
-}
 
 // ---- K2, LDS-resident first layer (the default).  k_embed_tile's sparse first layer gathers ~210 weight rows of
 // 512 B per leaf from L2 (7 GB per 65,536-leaf batch) one item after the other, and that gather latency is
@@ -635,172 +478,7 @@ __global__ __launch_bounds__(EL_BLOCK) void k_embed_lds(EmbedTileArgs a) {
   EL_FLUSH();
 }
 
-// ---- K2, third form of the party-slot pass (the default): every wave is its own pipeline, no workgroup barrier per tile.
-// k_embed_lds runs five phases back to back per 64-item tile (feature lists with 8 of 64 lanes busy, first layer, barrier,
-// MFMA on four of its eight waves, scatter) because its first layer leaves each item's hidden row spread over a wave
-// (a lane owns two channels) and the MFMA wants it the other way round (a lane owns a row) -- so the rows go through an LDS
-// tile, and a second tile to overlap the phases does not fit next to 99 KB of weights.  Here a lane owns a ROW from the
-// start: lane (r, hh) of a wave computes, for item r of the wave's 32-item mini-tile, the 64 hidden channels k = 2j + hh --
-// exactly the A operand sequence of v_mfma_f32_32x32x2_f32 -- straight into registers, 16 channels at a time:
-//   first layer : the item's 13 fixed (row, value) pairs {bias, 5 stats, 4 move slots, status, 2 types; absent ones are
-//                 (row 0, value 0)}; per pair 4 ds_read_b128 of the lane's part of the de-interleaved weight row + 16 FMAs;
-//   second layer: 16 k-steps x 2 output blocks of MFMA with W1 in registers, accumulating over the four channel quarters;
-// so the activation tile, its barrier and the idle waves are gone, and the two waves of a SIMD overlap by themselves:
-// one sits in its MFMA block (the wave stalls, the matrix pipe runs) while the other reads LDS and issues FMAs.
-// LDS: 199 weight rows (198 + the bias as a row) x 132 floats, rows de-interleaved [even channels | odd channels] and
-// padded so that lanes on different rows spread over the banks (105 KB), + 5.6 KB per wave (staged battles, pair lists).
-constexpr int ER_BLOCK = 512, ER_WAVES = 8, ER_ITEMS = 32, ER_RS = 132, ER_ROWS = 199, ER_PAIRS = 13;
-constexpr int ER_STAGE = 512;                                  // dwords of staged input per wave (5 leaves x 98, or 32 records x 8)
-constexpr int ER_WAVE_WORDS = ER_STAGE + 2 * ER_ITEMS * ER_PAIRS + 2 * ER_ITEMS; // + pair rows, pair values, dst offsets, hp ratios
-constexpr size_t ER_BYTES = (size_t)(ER_ROWS * ER_RS + ER_WAVES * ER_WAVE_WORDS) * 4;
-template <bool LIST>
-__global__ __launch_bounds__(ER_BLOCK) void k_embed_rows(EmbedTileArgs a) {
-  extern __shared__ __align__(16) float lds_f[];
-  const NetDev &N = a.net;
-  const int hidden = N.p_hidden, out_dim = N.p_out;
-  float *W0s = lds_f;
-  for (int i = threadIdx.x; i < ER_ROWS * 128; i += ER_BLOCK) { // row r, slot hh * 64 + j  <-  channel 2j + hh (row 198 = bias)
-    const int r = i >> 7, sl = i & 127, c = 2 * (sl & 63) + (sl >> 6);
-    W0s[r * ER_RS + sl] = c < hidden ? (r < 198 ? N.p_w0t[(size_t)r * hidden + c] : N.p_b0[c]) : 0.0f;
-  }
-  const uint32_t lane = threadIdx.x & 63, wib = threadIdx.x >> 6, r32 = lane & 31, hh = lane >> 5;
-  uint32_t *wl = (uint32_t *)(W0s + ER_ROWS * ER_RS) + wib * ER_WAVE_WORDS; // this wave's private LDS
-  uint32_t *Bs = wl, *prow = Bs + ER_STAGE, *dst_off = prow + 2 * ER_ITEMS * ER_PAIRS;
-  float *pval = (float *)(prow + ER_ITEMS * ER_PAIRS), *hp_ratio = (float *)(dst_off + ER_ITEMS);
-  // B operands of both 32-wide output blocks stay in registers: lane (r32, hh) holds W1[o = nb * 32 + r32][k = 2s + hh]
-  float bf0[64], bf1[64];
-#pragma unroll
-  for (int s2 = 0; s2 < 64; ++s2) {
-    const int c = 2 * s2 + (int)hh, o0 = (int)r32, o1 = 32 + (int)r32;
-    bf0[s2] = (o0 < out_dim && c < hidden) ? N.p_w1[(size_t)o0 * hidden + c] : 0.0f;
-    bf1[s2] = (o1 < out_dim && c < hidden) ? N.p_w1[(size_t)o1 * hidden + c] : 0.0f;
-  }
-  const float ob0 = (int)r32 < out_dim ? N.p_b1[r32] : 0.0f, ob1 = 32 + (int)r32 < out_dim ? N.p_b1[32 + r32] : 0.0f;
-  const uint32_t items = LIST ? *a.work_count : a.n * 10;
-  const uint32_t nmt = (items + ER_ITEMS - 1) / ER_ITEMS;
-  const uint32_t stride = gridDim.x * ER_WAVES;
-  // staged input of a mini-tile, prefetched one mini-tile ahead in registers (8 dwords per lane)
-  uint32_t pf[ER_STAGE / 64];
-  auto prefetch = [&](uint32_t mt) {
-#pragma unroll
-    for (int u = 0; u < ER_STAGE / 64; ++u) {
-      const uint32_t i = lane + 64 * u;
-      pf[u] = 0;
-      if (mt >= nmt) continue;
-      if (LIST) {
-        const uint32_t g = mt * ER_ITEMS + (i >> 3);
-        if (i < ER_ITEMS * 8 && g < items) pf[u] = ((const uint32_t *)a.work)[(size_t)g * 8 + (i & 7)];
-      } else {
-        const uint32_t first_leaf = (mt * ER_ITEMS) / 10;
-        uint32_t last_leaf = (mt * ER_ITEMS + ER_ITEMS - 1) / 10;
-        if (last_leaf >= a.n) last_leaf = a.n - 1;
-        const uint32_t l = i / 98, d = i - l * 98;
-        if (first_leaf + l <= last_leaf) pf[u] = d < 96 ? ((const uint32_t *)a.battles)[(size_t)(first_leaf + l) * 96 + d]
-                                                        : ((const uint32_t *)a.durations)[(size_t)(first_leaf + l) * 2 + (d - 96)];
-      }
-    }
-  };
-  __syncthreads(); // W0s staged (the only workgroup barrier of the kernel)
-  uint32_t mt = blockIdx.x * ER_WAVES + wib;
-  prefetch(mt);
-  EL_T0();
-  EL_MARK(0); // prologue (up to here, wave 0 of every workgroup)
-  for (; mt < nmt; mt += stride) {
-#pragma unroll
-    for (int u = 0; u < ER_STAGE / 64; ++u) Bs[lane + 64 * u] = pf[u];
-    __builtin_amdgcn_wave_barrier();
-    prefetch(mt + stride);
-    EL_MARK(1);
-    // ---- pair lists: lane r (hh = 0) encodes item r ----
-    if (hh == 0) {
-      const uint32_t g = mt * ER_ITEMS + r32;
-      uint32_t doff = 0xFFFFFFFFu, dead_off = 0xFFFFFFFFu;
-      uint32_t *pr = prow + r32 * ER_PAIRS;
-      float *pv = pval + r32 * ER_PAIRS;
-#pragma unroll
-      for (int e = 0; e < ER_PAIRS; ++e) { pr[e] = 0; pv[e] = 0.0f; }
-      if (g < items) {
-        const uint32_t *rec = Bs + r32 * 8;
-        const uint32_t gi = LIST ? rec[0] : g;
-        const uint32_t leaf = gi / 10, q = gi - leaf * 10, side = q / 5, slot = 1 + (q - side * 5);
-        const uint32_t first_leaf = (mt * ER_ITEMS) / 10;
-        const uint32_t *sb = Bs + (LIST ? 0 : (leaf - first_leaf) * 98) + side * 46;
-        const uint32_t sleep = LIST ? rec[7] : (Bs[(leaf - first_leaf) * 98 + 96 + side] >> (3 * slot)) & 7;
-        const uint32_t o0 = LIST ? 0 : sb[44], o1 = LIST ? 0 : sb[45];
-        const uint32_t id = LIST ? 1 : slot < 4 ? (o0 >> (8 * slot)) & 0xFF : (o1 >> (8 * (slot - 4))) & 0xFF;
-        const uint32_t dd = leaf * N.emb_dim + side * N.side_dim + (1 + N.a_out) + (slot - 1) * (1 + N.p_out);
-        uint32_t pk0 = 0, pk1 = 0, pk2 = 0, pk3 = 0, pk4 = 0, pk5 = 0, hp = 0;
-        if (id != 0) {
-          const uint32_t *pk = LIST ? rec + 1 : sb + 6 * (id - 1);
-          pk0 = pk[0]; pk1 = pk[1]; pk2 = pk[2]; pk3 = pk[3]; pk4 = pk[4]; pk5 = pk[5];
-          hp = pk4 >> 16;
-        }
-        if (hp == 0) dead_off = dd; // empty or fainted: zero block (network.h:153-160), kept out of the scatter
-        else {
-          doff = dd;
-          pr[0] = 198 * ER_RS; pv[0] = 1.0f; // the bias, as a row
-#pragma unroll
-          for (uint32_t j = 0; j < 12; ++j) { // fixed positions; an absent feature stays (row 0, value 0): fma(w, 0, h) = h
-            uint32_t fidx = 0; float fval = 0.0f;
-            const bool v = pokemon_feature(j, pk0, pk1, pk2, pk3, pk4, pk5, sleep, fidx, fval);
-            pr[1 + j] = v ? fidx * ER_RS : 0u;
-            pv[1 + j] = v ? fval : 0.0f;
-          }
-          hp_ratio[r32] = (float)hp / (float)(pk0 & 0xFFFF);
-        }
-      }
-      dst_off[r32] = doff;
-      if (dead_off != 0xFFFFFFFFu) for (int o = 0; o <= out_dim; ++o) a.emb[(size_t)dead_off + o] = 0.0f;
-    }
-    __builtin_amdgcn_wave_barrier();
-    EL_MARK(3);
-    // ---- both layers, 16 hidden channels at a time (a quarter of the lane's 64: keeps the live registers under 256) ----
-    f32x16 acc0, acc1;
-#pragma unroll
-    for (int q = 0; q < 16; ++q) { acc0[q] = 0.0f; acc1[q] = 0.0f; }
-    const uint32_t *pr = prow + r32 * ER_PAIRS;
-    const float *pv = pval + r32 * ER_PAIRS;
-#pragma unroll
-    for (int part = 0; part < 4; ++part) {
-      float h[16];
-#pragma unroll
-      for (int j = 0; j < 16; ++j) h[j] = 0.0f;
-#pragma unroll
-      for (int e = 0; e < ER_PAIRS; ++e) {
-        const float v = pv[e];
-        const float4 *w = (const float4 *)(W0s + pr[e] + hh * 64 + part * 16);
-#pragma unroll
-        for (int j4 = 0; j4 < 4; ++j4) {
-          const float4 x = w[j4];
-          h[4 * j4 + 0] = fmaf(x.x, v, h[4 * j4 + 0]); h[4 * j4 + 1] = fmaf(x.y, v, h[4 * j4 + 1]);
-          h[4 * j4 + 2] = fmaf(x.z, v, h[4 * j4 + 2]); h[4 * j4 + 3] = fmaf(x.w, v, h[4 * j4 + 3]);
-        }
-      }
-      EL_MARK(4);
-#pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        const float av = act_fn(h[j], N.activation);
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bf0[part * 16 + j], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bf1[part * 16 + j], acc1, 0, 0, 0);
-      }
-      EL_MARK(6);
-    }
-    // ---- bias + activation + scatter: acc[q] is row (q & 3) + 8 (q >> 2) + 4 hh of the mini-tile, column nb * 32 + r32 ----
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      const int row = (q & 3) + 8 * (q >> 2) + 4 * (int)hh;
-      const uint32_t doff = dst_off[row];
-      if (doff != 0xFFFFFFFFu) {
-        if ((int)r32 < out_dim) a.emb[(size_t)doff + 1 + r32] = act_fn(acc0[q] + ob0, N.activation);
-        if (32 + (int)r32 < out_dim) a.emb[(size_t)doff + 1 + 32 + r32] = act_fn(acc1[q] + ob1, N.activation);
-      }
-    }
-    if (hh == 0 && dst_off[r32] != 0xFFFFFFFFu) a.emb[dst_off[r32]] = hp_ratio[r32];
-    __builtin_amdgcn_wave_barrier(); // the wave's LDS is rewritten by the next mini-tile
-    EL_MARK(7);
-  }
-  EL_FLUSH();
-}
+constexpr int ER_ITEMS = 32, ER_RS = 132; // items per wave mini-tile; padded LDS weight row (floats) of k_embed_arows / k_embed_prows
 
 // Copy a prebuilt image of the kernel's LDS weights (built once at load time in exactly the LDS layout) with every load of
 // a thread in flight at once.  The obvious `lds[i] = cond ? global[f(i)] : 0` loop compiles to load -> wait -> store per
@@ -1360,8 +1038,7 @@ __global__ __launch_bounds__(256) void k_party_tags(NetDev N, const uint8_t *bat
 // ---- K3: main net on fp32 MFMA ------------------------------------------------------------------
 constexpr int MN_BLOCK = 256; // 4 waves
 constexpr int TM = 64;        // leaves per workgroup tile
-constexpr int KC_MAIN = 64;   // K chunk staged per iteration in k_mainnet (LDS: 16.6 + 66.6 KB staging + 65.8 KB activations)
-constexpr int KC_POLICY = 32; // ... in k_policy (two activation tiles: 8.4 + 33.8 KB staging)
+constexpr int KC_POLICY = 32; // K chunk staged per iteration in k_policy (two activation tiles: 8.4 + 33.8 KB staging)
 constexpr int MAXH = 256;
 // dynamic LDS of k_policy: weight / input staging + a TM-leaf tile of the hidden and the policy-hidden activations
 constexpr int POLICY_LDS_LIMIT = 150 * 1024;
@@ -1375,14 +1052,9 @@ struct MainArgs {
   float *h1_out; // nullable: n x H activated fc1 outputs, input of the policy heads (k_policy)
 };
 
-// One dense layer for a TM x Hout tile: acc = A(TM x K) . W^T.
-// A comes either from global (X, staged per K-chunk into xs) or from the LDS activation tile.
-// Staging is software-pipelined: the NEXT chunk's global loads are issued into registers before the
-// MFMAs of the current chunk, so L2 latency hides behind the matrix pipe (one wave per SIMD here).
-
-// KCT = K-chunk staged per iteration (k_mainnet: 64, half the barriers; k_policy: 32, its two activation tiles leave
-// no room for more).  Measured and rejected: double-buffering the chunks in LDS with KCT = 32 (one barrier per chunk,
-// staging under the previous chunk's MFMAs) -- 547 us against 473 us for single-buffered 64-wide chunks.
+// One dense layer for a TM x Hout tile of k_policy (the four-wave tile form the main net used before k_mainnet_wave):
+// acc = A(TM x K) . W^T, W staged through LDS KCT columns at a time, the NEXT chunk's global loads issued into registers
+// before the MFMAs of the current chunk.  A comes from the LDS activation tile (A_FROM_GLOBAL: staged per chunk into xs).
 template <bool A_FROM_GLOBAL, int KCT>
 __device__ __forceinline__ void dense_layer(const float *a_global, int a_ld, uint32_t row0, uint32_t n_rows, // global A
                                             const float *a_lds, int a_lds_ld,                               // LDS A
@@ -1480,200 +1152,6 @@ __device__ __forceinline__ void store_act(const f32x16 (&acc)[4], const float *b
         hs[(mi * 32 + row) * ld + nn] = act_fn(acc[j][q] + b, activation);
       }
     }
-  }
-}
-
-__global__ __launch_bounds__(MN_BLOCK) void k_mainnet(MainArgs a) {
-  extern __shared__ __align__(16) float lds_f[];
-  const NetDev &N = a.net;
-  const int H = N.H, VH = N.VH;
-  const int hld = (H > VH ? H : VH) + 1;
-  float *xs = lds_f;                          // TM x (KC_MAIN + 1)
-  float *ws = xs + TM * (KC_MAIN + 1);        // MAXH x (KC_MAIN + 1)
-  float *hs = ws + MAXH * (KC_MAIN + 1);      // TM x hld
-  const uint32_t row0 = blockIdx.x * TM;
-  const uint32_t n_rows = min((uint32_t)TM, a.n - row0);
-  f32x16 acc[4];
-  dense_layer<true, KC_MAIN>(a.emb, N.emb_dim, row0, n_rows, nullptr, 0, N.w0, N.emb_dim, H, xs, ws, acc);
-  __syncthreads();
-  store_act(acc, N.b0, H, N.activation, hs, hld);
-  __syncthreads();
-  dense_layer<false, KC_MAIN>(nullptr, 0, 0, 0, hs, hld, N.w1, H, H, xs, ws, acc);
-  __syncthreads(); // every wave done reading hs
-  store_act(acc, N.b1, H, N.activation, hs, hld);
-  __syncthreads();
-  if (a.h1_out) { // keep fc1's activations for the policy heads
-    for (uint32_t i = threadIdx.x; i < n_rows * (uint32_t)H; i += MN_BLOCK) {
-      const uint32_t row = i / (uint32_t)H, c = i - row * (uint32_t)H;
-      a.h1_out[(size_t)(row0 + row) * H + c] = hs[row * hld + c];
-    }
-  }
-  dense_layer<false, KC_MAIN>(nullptr, 0, 0, 0, hs, hld, N.w2, H, VH, xs, ws, acc);
-  __syncthreads();
-  store_act(acc, N.b2, VH, N.activation, hs, hld);
-  __syncthreads();
-  if (threadIdx.x < n_rows) { // value_fc3 + sigmoid (network.h:14,75)
-    const float *hrow = hs + threadIdx.x * hld;
-    float y = N.b3;
-    for (int j = 0; j < VH; ++j) y = fmaf(hrow[j], N.w3[j], y);
-    a.values[row0 + threadIdx.x] = 1.0f / (1.0f + expf(-y));
-  }
-}
-
-// ---- K3, direct-to-register weights (the default).  k_mainnet stages every 64-wide chunk of W through LDS (64 KB of
-// LDS writes, two barriers and a 4x re-read per chunk).  Here W is stored in MFMA-FRAGMENT ORDER on the device
-// (frag_order, done once at load time): for chunk c, n-block nb and float4 index q, lane (r, h) finds
-// W[nb*32 + r][c*64 + h*32 + 4q .. 4q+3] at float4 ((c*NB + nb)*8 + q)*64 + lane -- so a wave's operand load is one
-// fully coalesced 1 KB read straight into the registers the MFMAs consume, double-buffered one chunk ahead.  Within a
-// chunk the MFMA's two k-lanes take columns [0,32) and [32,64) instead of interleaved pairs (A and B agree, so the
-// products are the same).  A comes from LDS: the activation tile for fc1 / value_fc2, and for fc0 the embedding rows,
-// staged 256 columns at a time into the (still unused) activation tile.  Barriers per 64-leaf tile: ~12 instead of ~45.
-constexpr int XP = 256; // embedding columns staged per piece (= MAXH, the activation tile's width)
-
-template <int JNc, bool A_PIECE>
-__device__ __forceinline__ void direct_layer(const float4 *Wf, int K, int NB, const float *a_tile, int a_ld, int nb0, int mi, int r, int h,
-                                             const float *a_global, int a_gld, uint32_t row0, uint32_t n_rows, f32x16 (&acc)[4]) {
-  MN_T0();
-  // B operands of one chunk: JNc n-blocks x 8 float4 per lane
-  float4 b0[JNc][8], b1[JNc][8];
-  const int lane = r + 32 * h, tid = threadIdx.x;
-  const int nch = (K + 63) / 64;
-#pragma unroll
-  for (int j = 0; j < 4; ++j)
-#pragma unroll
-    for (int q = 0; q < 16; ++q) acc[j][q] = 0.0f;
-  auto load = [&](float4 (&b)[JNc][8], int c) {
-#pragma unroll
-    for (int j = 0; j < JNc; ++j)
-#pragma unroll
-      for (int q = 0; q < 8; ++q) b[j][q] = Wf[((size_t)(c * NB + nb0 + 2 * j) * 8 + q) * 64 + lane];
-  };
-  // the MFMAs of chunk c, with the loads of chunk c + 1 (into the other register set) spread between them one per
-  // k-step: an MFMA occupies the matrix pipe for 64 cycles but the wave for ~8, so everything else the wave has to
-  // issue belongs in those gaps, not in a clump between two MFMA streams during which the pipe runs dry
-  auto compute = [&](const float4 (&b)[JNc][8], float4 (&bn)[JNc][8], auto has_next_tag, int c, int piece_base) {
-    constexpr bool has_next = decltype(has_next_tag)::value;
-    const bool half_ok = c * 64 + h * 32 < K; // K is a multiple of 32: the upper half of the last chunk may not exist
-    const float *arow = a_tile + (mi * 32 + r) * a_ld + (c * 64 - piece_base) + h * 32;
-    // all 32 A values of the chunk are read up front, UNCONDITIONALLY (the tile row is always addressable; a lane whose
-    // half of the chunk does not exist discards them below): a predicated LDS read is an exec-masked instruction the
-    // compiler can neither hoist nor batch, and every k-step then waits a full LDS round trip in front of its MFMAs
-    float av[32];
-#pragma unroll
-    for (int s = 0; s < 32; ++s) av[s] = arow[s];
-    const float4 *wn = Wf + ((size_t)((c + 1) * NB + nb0) * 8) * 64 + lane;
-#pragma unroll
-    for (int s = 0; s < 32; ++s) {
-      if (has_next && s < 8 * JNc) bn[s >> 3][s & 7] = wn[(size_t)((s >> 3) * 2 * 8 + (s & 7)) * 64];
-      const float a_s = half_ok ? av[s] : 0.0f;
-#pragma unroll
-      for (int j = 0; j < JNc; ++j) {
-        const float4 bq = b[j][s >> 2];
-        const float bv = (s & 3) == 0 ? bq.x : (s & 3) == 1 ? bq.y : (s & 3) == 2 ? bq.z : bq.w;
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_s, bv, acc[j], 0, 0, 0);
-      }
-      __builtin_amdgcn_sched_barrier(0); // keep this step's load next to this step's MFMAs
-    }
-  };
-  // fc0: the embedding rows go through the activation tile 256 columns at a time (prefetched one piece ahead)
-  constexpr int XR = TM * (XP / 4) / MN_BLOCK; // float4 per thread per piece (16)
-  float4 xr[A_PIECE ? XR : 1];
-  auto fetch_piece = [&](int base) {
-    if (A_PIECE) {
-#pragma unroll
-      for (int u = 0; u < XR; ++u) {
-        const int i = tid + u * MN_BLOCK, row = i / (XP / 4), q = i - row * (XP / 4);
-        xr[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if ((uint32_t)row < n_rows && base + 4 * q < K) xr[u] = *(const float4 *)(a_global + (size_t)(row0 + row) * a_gld + base + 4 * q);
-      }
-    }
-  };
-  auto store_piece = [&]() {
-    if (A_PIECE) {
-      float *xt = const_cast<float *>(a_tile);
-#pragma unroll
-      for (int u = 0; u < XR; ++u) {
-        const int i = tid + u * MN_BLOCK, row = i / (XP / 4), q = i - row * (XP / 4);
-        float *d = xt + row * a_ld + 4 * q; d[0] = xr[u].x; d[1] = xr[u].y; d[2] = xr[u].z; d[3] = xr[u].w;
-      }
-    }
-  };
-  if (A_PIECE) fetch_piece(0);
-  load(b0, 0);
-  int piece_base = 0;
-  auto new_piece = [&](int c) { // fc0 only: chunk c (a multiple of 4) opens the next 256 input columns
-    if (A_PIECE && (c * 64) % XP == 0) {
-      piece_base = c * 64;
-      __syncthreads(); // everyone is done with the previous piece
-      store_piece();
-      __syncthreads();
-      if (piece_base + XP < K) fetch_piece(piece_base + XP); // lands during this piece's MFMAs
-    }
-  };
-  using Yes = std::integral_constant<bool, true>;
-  using No = std::integral_constant<bool, false>;
-  int c = 0;
-  for (; c + 2 < nch; c += 2) { // both chunks of the pair have a successor to prefetch
-    new_piece(c);
-    compute(b0, b1, Yes{}, c, piece_base);
-    compute(b1, b0, Yes{}, c + 1, piece_base);
-  }
-  new_piece(c);
-  if (nch - c == 2) {
-    compute(b0, b1, Yes{}, c, piece_base);
-    compute(b1, b0, No{}, c + 1, piece_base);
-  } else {
-    compute(b0, b1, No{}, c, piece_base);
-  }
-  MN_MARK(8);
-}
-
-template <bool A_PIECE>
-__device__ __forceinline__ void direct_layer_jn(const float4 *Wf, int K, int Hout, const float *a_tile, int a_ld, const float *a_global, int a_gld,
-                                                uint32_t row0, uint32_t n_rows, f32x16 (&acc)[4]) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int mi = wave & 1, nb0 = wave >> 1, NB = Hout / 32, r = lane & 31, h = lane >> 5;
-  const int JN = NB - nb0 <= 0 ? 0 : (NB - nb0 + 1) / 2 > 4 ? 4 : (NB - nb0 + 1) / 2; // this wave's n-blocks: nb0, nb0 + 2, ...
-  // every wave takes part in the piece barriers, also one without an n-block of its own (JN = 0 -> runs the JNc = 1
-  // code on n-block nb0 clamped to an existing one and discards the result)
-  if (JN == 4) direct_layer<4, A_PIECE>(Wf, K, NB, a_tile, a_ld, nb0, mi, r, h, a_global, a_gld, row0, n_rows, acc);
-  else if (JN == 3) direct_layer<3, A_PIECE>(Wf, K, NB, a_tile, a_ld, nb0, mi, r, h, a_global, a_gld, row0, n_rows, acc);
-  else if (JN == 2) direct_layer<2, A_PIECE>(Wf, K, NB, a_tile, a_ld, nb0, mi, r, h, a_global, a_gld, row0, n_rows, acc);
-  else direct_layer<1, A_PIECE>(Wf, K, NB, a_tile, a_ld, JN == 1 ? nb0 : 0, mi, r, h, a_global, a_gld, row0, n_rows, acc);
-}
-
-__global__ __launch_bounds__(MN_BLOCK) void k_mainnet_direct(MainArgs a) {
-  extern __shared__ __align__(16) float lds_f[];
-  const NetDev &N = a.net;
-  const int H = N.H, VH = N.VH;
-  const int hld = MAXH + 1;      // the tile doubles as the 256-column staging area of fc0's input
-  float *hs = lds_f;             // TM x hld
-  const uint32_t row0 = blockIdx.x * TM;
-  const uint32_t n_rows = min((uint32_t)TM, a.n - row0);
-  f32x16 acc[4];
-  direct_layer_jn<true>((const float4 *)N.w0f, N.emb_dim, H, hs, hld, a.emb, N.emb_dim, row0, n_rows, acc);
-  __syncthreads(); // every wave done reading the last input piece
-  store_act(acc, N.b0, H, N.activation, hs, hld);
-  __syncthreads();
-  direct_layer_jn<false>((const float4 *)N.w1f, H, H, hs, hld, nullptr, 0, 0, 0, acc);
-  __syncthreads(); // every wave done reading hs
-  store_act(acc, N.b1, H, N.activation, hs, hld);
-  __syncthreads();
-  if (a.h1_out) { // keep fc1's activations for the policy heads
-    for (uint32_t i = threadIdx.x; i < n_rows * (uint32_t)H; i += MN_BLOCK) {
-      const uint32_t row = i / (uint32_t)H, c = i - row * (uint32_t)H;
-      a.h1_out[(size_t)(row0 + row) * H + c] = hs[row * hld + c];
-    }
-  }
-  direct_layer_jn<false>((const float4 *)N.w2f, H, VH, hs, hld, nullptr, 0, 0, 0, acc);
-  __syncthreads();
-  store_act(acc, N.b2, VH, N.activation, hs, hld);
-  __syncthreads();
-  if (threadIdx.x < n_rows) { // value_fc3 + sigmoid (network.h:14,75)
-    const float *hrow = hs + threadIdx.x * hld;
-    float y = N.b3;
-    for (int j = 0; j < VH; ++j) y = fmaf(hrow[j], N.w3[j], y);
-    a.values[row0 + threadIdx.x] = 1.0f / (1.0f + expf(-y));
   }
 }
 
@@ -1987,23 +1465,7 @@ std::vector<float> pad_rows(const HostAffine &a, uint32_t out_pad, uint32_t in_p
     for (uint32_t i = 0; i < a.in; ++i) t[(size_t)o * in_pad + i] = a.w[(size_t)o * a.in + i];
   return t;
 }
-// MFMA-fragment order of a weight matrix for k_mainnet_direct: chunk c (64 columns), n-block nb (32 rows), float4 q,
-// lane (r, h) -> W[nb*32 + r][c*64 + h*32 + 4q .. 4q+3]; rows / columns beyond the matrix are zero.
-std::vector<float> frag_order(const HostAffine &a, uint32_t out_pad) {
-  const uint32_t nch = (a.in + 63) / 64, NB = out_pad / 32;
-  std::vector<float> f((size_t)nch * NB * 8 * 64 * 4, 0.0f);
-  for (uint32_t c = 0; c < nch; ++c)
-    for (uint32_t nb = 0; nb < NB; ++nb)
-      for (uint32_t q = 0; q < 8; ++q)
-        for (uint32_t lane = 0; lane < 64; ++lane)
-          for (uint32_t e = 0; e < 4; ++e) {
-            const uint32_t row = nb * 32 + (lane & 31), col = c * 64 + (lane >> 5) * 32 + 4 * q + e;
-            if (row < a.out && col < a.in) f[((((size_t)c * NB + nb) * 8 + q) * 64 + lane) * 4 + e] = a.w[(size_t)row * a.in + col];
-          }
-  return f;
-}
-
-// k_mainnet_wave's order: the same fragments, but the 2 float4 x NB n-blocks of one SUB-chunk (8 k-steps) are contiguous:
+// k_mainnet_wave's MFMA-fragment order of a weight matrix: the 2 float4 x NB n-blocks of one SUB-chunk (8 k-steps) are contiguous:
 // float4 (((c*4 + u)*NB + nb)*2 + qq)*64 + lane -> W[nb*32 + r][c*64 + h*32 + 8u + 4qq .. +3], so the 16 loads of a sub-chunk
 // are one scalar base + the lane's offset + small constants (no per-block vector address arithmetic).  NB is rounded up to
 // the kernel's template width (1, 2, 4, 8) with all-zero blocks, so that every block index is a compile-time constant.
@@ -2152,16 +1614,10 @@ int oakgpu_net_load_memory(oakgpu_ctx *ctx, const void *bytes, size_t size, oakg
   rc = rc ? rc : upload(net, arows_rows(a0), &D.a_w0d);
   rc = rc ? rc : upload(net, arows_image(a0, a1), &D.a_img);
   rc = rc ? rc : upload(net, prows_image(p0, p1), &D.p_img);
-  rc = rc ? rc : upload(net, pad_rows(fc0, H, fc0.in), &D.w0);
   rc = rc ? rc : upload(net, pad_vec(fc0.b, H), &D.b0);
-  rc = rc ? rc : upload(net, pad_rows(fc1, H, H), &D.w1);
   rc = rc ? rc : upload(net, pad_vec(fc1.b, H), &D.b1);
-  rc = rc ? rc : upload(net, pad_rows(v2, VH, H), &D.w2);
   rc = rc ? rc : upload(net, pad_vec(v2.b, VH), &D.b2);
   rc = rc ? rc : upload(net, pad_vec(v3.w, VH), &D.w3);
-  rc = rc ? rc : upload(net, frag_order(fc0, H), &D.w0f);
-  rc = rc ? rc : upload(net, frag_order(fc1, H), &D.w1f);
-  rc = rc ? rc : upload(net, frag_order(v2, VH), &D.w2f);
   rc = rc ? rc : upload(net, frag_order_wave(fc0, H), &D.w0g);
   rc = rc ? rc : upload(net, frag_order_wave(fc1, H), &D.w1g);
   rc = rc ? rc : upload(net, frag_order_wave(v2, VH), &D.w2g);
@@ -2213,16 +1669,11 @@ int oakgpu_net_shape(const oakgpu_net *net, int *in_dim, int *hidden, int *value
 }
 
 int oakgpu_leaf_set_lds_limits(void) { // per DEVICE (hipFuncSetAttribute applies to the current device): called by oakgpu_create
-  hipError_t e = hipFuncSetAttribute((const void *)oak::k_embed_tile, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-  if (e != hipSuccess) return oakgpu_fail_hip((int)e, "hipFuncSetAttribute(k_embed_tile)");
+  hipError_t e = hipSuccess;
   e = hipFuncSetAttribute((const void *)oak::k_embed_lds<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)oak::ELayout<false>::BYTES);
   if (e != hipSuccess) return oakgpu_fail_hip((int)e, "hipFuncSetAttribute(k_embed_lds<party>)");
   e = hipFuncSetAttribute((const void *)oak::k_embed_lds<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)oak::ELayout<false>::BYTES);
   if (e != hipSuccess) return oakgpu_fail_hip((int)e, "hipFuncSetAttribute(k_embed_lds<party, list>)");
-  e = hipFuncSetAttribute((const void *)oak::k_embed_rows<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)oak::ER_BYTES);
-  if (e != hipSuccess) return oakgpu_fail_hip((int)e, "hipFuncSetAttribute(k_embed_rows)");
-  e = hipFuncSetAttribute((const void *)oak::k_embed_rows<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)oak::ER_BYTES);
-  if (e != hipSuccess) return oakgpu_fail_hip((int)e, "hipFuncSetAttribute(k_embed_rows<list>)");
   e = hipFuncSetAttribute((const void *)oak::k_embed_arows, hipFuncAttributeMaxDynamicSharedMemorySize, (int)oak::ar_bytes(4));
   if (e != hipSuccess) return oakgpu_fail_hip((int)e, "hipFuncSetAttribute(k_embed_arows)");
   e = hipFuncSetAttribute((const void *)oak::k_embed_prows<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)oak::PR_BYTES);
@@ -2242,10 +1693,6 @@ int oakgpu_leaf_set_lds_limits(void) { // per DEVICE (hipFuncSetAttribute applie
   if (e != hipSuccess) return oakgpu_fail_hip((int)e, "hipFuncSetAttribute(k_policy)");
   e = hipFuncSetAttribute((const void *)oak::k_mainnet_wave, hipFuncAttributeMaxDynamicSharedMemorySize, (int)oak::MW_BYTES);
   if (e != hipSuccess) return oakgpu_fail_hip((int)e, "hipFuncSetAttribute(k_mainnet_wave)");
-  e = hipFuncSetAttribute((const void *)oak::k_mainnet_direct, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-  if (e != hipSuccess) return oakgpu_fail_hip((int)e, "hipFuncSetAttribute(k_mainnet_direct)");
-  e = hipFuncSetAttribute((const void *)oak::k_mainnet, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-  if (e != hipSuccess) return oakgpu_fail_hip((int)e, "hipFuncSetAttribute(k_mainnet)");
   return 0;
 }
 
@@ -2263,81 +1710,51 @@ static int leaf_eval_impl(oakgpu_ctx *ctx, oakgpu_net *net, const uint8_t *battl
     if (!emb) return -1;
   }
   const oak::NetDev &D = net->dev;
-  static const int embed_impl = getenv("OAKGPU_EMBED_IMPL") ? atoi(getenv("OAKGPU_EMBED_IMPL")) : 4;
-  const bool rows_ok = D.p_hidden <= 128 && D.p_out <= 64; // k_embed_rows: two 32-wide output blocks
+  // The row kernels (k_embed_prows / k_embed_arows) take embedding nets up to 128 hidden channels, party outputs up to 64
+  // and active outputs up to 128; anything wider goes to k_embed_lds (the 64-item tile form).  OAKGPU_EMBED_TILE=1 forces
+  // the tile form (A/B and a second implementation for the tests).
+  static const bool force_tile = getenv("OAKGPU_EMBED_TILE") != nullptr;
+  const bool prow_ok = !force_tile && D.p_hidden <= 128 && D.p_out <= 64, arow_ok = !force_tile && D.a_hidden <= 128 && D.a_out <= 128;
   hipEvent_t *tev = (hipEvent_t *)oakgpu_ctx_timing_events(ctx); // diagnostic only (oakgpu_set_kernel_timing)
-  {
-    static const int kinds = getenv("OAKGPU_EMBED_KINDS") ? atoi(getenv("OAKGPU_EMBED_KINDS")) : 3; // diagnostics: 1 party, 2 actives
-    static const bool split = getenv("OAKGPU_EMBED_SPLIT") != nullptr; // A/B: the two passes as two launches
-    // default: both embedding passes in one launch (k_embed_both).  Not while the per-kernel timing diagnostic is on (it
-    // wants an event between the passes), nor for layer widths the row kernels do not take.
-    const bool both = embed_impl >= 4 && embed_impl != 6 && rows_ok && D.a_hidden <= 128 && D.a_out <= 128 && kinds == 3 && !split && !tev &&
-                      !getenv("OAKGPU_ACTIVE_TILE");
-    if (both) {
-      oak::EmbedTileArgs tp{D, battles, durations, n, emb, 0, nullptr, nullptr}, tact{D, battles, durations, n, emb, 1, nullptr, nullptr};
-      const uint32_t nmt_a = (n * 2 + oak::ER_ITEMS - 1) / oak::ER_ITEMS, wg_a0 = (nmt_a + oak::AR_WAVES - 1) / oak::AR_WAVES, wg_a = wg_a0 < 256 ? wg_a0 : 256;
-      const size_t lds = oak::PR_BYTES > oak::ar_bytes((D.a_out + 31) / 32) ? oak::PR_BYTES : oak::ar_bytes((D.a_out + 31) / 32);
-      if (slot_tags) { // cached party-slot pass: tag comparison, then only the changed slots (work list)
-        uint8_t *ws = (uint8_t *)oakgpu_ctx_workspace(ctx, 2, (size_t)n * 10 * sizeof(oak::PartyWork) + 16);
-        if (!ws) return -1;
-        uint32_t *count = (uint32_t *)ws;
-        oak::PartyWork *work = (oak::PartyWork *)(ws + 16);
-        hipError_t me = hipMemsetAsync(count, 0, 4, stream);
-        if (me != hipSuccess) return oakgpu_fail_hip((int)me, "hipMemsetAsync(work count)");
-        hipLaunchKernelGGL(oak::k_party_tags, dim3((n * 10 + 256 * oak::TAG_R - 1) / (256 * oak::TAG_R)), dim3(256), 0, stream, D, battles, durations, n, emb, slot_tags, work, count);
-        tp.work = work;
-        tp.work_count = count;
-        hipLaunchKernelGGL(oak::k_embed_both<true>, dim3(256 + wg_a), dim3(oak::PR_BLOCK), lds, stream, tp, tact, 256u);
-      } else {
-        const uint32_t nmt_p = (n * 10 + oak::ER_ITEMS - 1) / oak::ER_ITEMS, wg_p0 = (nmt_p + oak::PR_WAVES - 1) / oak::PR_WAVES, wg_p = wg_p0 < 256 ? wg_p0 : 256;
-        hipLaunchKernelGGL(oak::k_embed_both<false>, dim3(wg_p + wg_a), dim3(oak::PR_BLOCK), lds, stream, tp, tact, wg_p);
-      }
+  static const int kinds = getenv("OAKGPU_EMBED_KINDS") ? atoi(getenv("OAKGPU_EMBED_KINDS")) : 3; // diagnostics: 1 party, 2 actives
+  static const bool split = getenv("OAKGPU_EMBED_SPLIT") != nullptr; // A/B: the two passes as two launches
+  oak::EmbedTileArgs tp{D, battles, durations, n, emb, 0, nullptr, nullptr}, tact{D, battles, durations, n, emb, 1, nullptr, nullptr};
+  if (slot_tags && (kinds & 1)) { // cached party-slot pass: tag comparison first, then only the changed slots (work list)
+    uint8_t *ws = (uint8_t *)oakgpu_ctx_workspace(ctx, 2, (size_t)n * 10 * sizeof(oak::PartyWork) + 16);
+    if (!ws) return -1;
+    uint32_t *count = (uint32_t *)ws;
+    oak::PartyWork *work = (oak::PartyWork *)(ws + 16);
+    hipError_t me = hipMemsetAsync(count, 0, 4, stream);
+    if (me != hipSuccess) return oakgpu_fail_hip((int)me, "hipMemsetAsync(work count)");
+    if (tev) (void)hipEventRecord(tev[0], stream);
+    hipLaunchKernelGGL(oak::k_party_tags, dim3((n * 10 + 256 * oak::TAG_R - 1) / (256 * oak::TAG_R)), dim3(256), 0, stream, D, battles, durations, n, emb, slot_tags, work, count);
+    tp.work = work;
+    tp.work_count = count;
+  } else if (tev) (void)hipEventRecord(tev[0], stream);
+  const uint32_t nmt_p = (n * 10 + oak::ER_ITEMS - 1) / oak::ER_ITEMS, wg_p0 = (nmt_p + oak::PR_WAVES - 1) / oak::PR_WAVES;
+  const uint32_t wg_p = slot_tags ? 256u : (wg_p0 < 256 ? wg_p0 : 256); // (a work list's length is only known on the device)
+  const uint32_t nmt_a = (n * 2 + oak::ER_ITEMS - 1) / oak::ER_ITEMS, wg_a0 = (nmt_a + oak::AR_WAVES - 1) / oak::AR_WAVES, wg_a = wg_a0 < 256 ? wg_a0 : 256;
+  const size_t ar_lds = oak::ar_bytes((D.a_out + 31) / 32);
+  // default: both embedding passes in one launch (k_embed_both).  Not while the per-kernel timing diagnostic is on (it
+  // wants an event between the passes).
+  if (prow_ok && arow_ok && kinds == 3 && !split && !tev) {
+    const size_t lds = oak::PR_BYTES > ar_lds ? oak::PR_BYTES : ar_lds;
+    if (slot_tags) hipLaunchKernelGGL(oak::k_embed_both<true>, dim3(wg_p + wg_a), dim3(oak::PR_BLOCK), lds, stream, tp, tact, wg_p);
+    else hipLaunchKernelGGL(oak::k_embed_both<false>, dim3(wg_p + wg_a), dim3(oak::PR_BLOCK), lds, stream, tp, tact, wg_p);
+  } else {
+    if (kinds & 1) {
+      const uint32_t ntiles = (n * 10u + oak::ET - 1) / oak::ET, grid = ntiles < 256 ? ntiles : 256;
+      // (the work list goes through the same kernel as the plain pass, so that cached and plain embeddings are bit-identical)
+      if (prow_ok && slot_tags) hipLaunchKernelGGL(oak::k_embed_prows<true>, dim3(wg_p), dim3(oak::PR_BLOCK), oak::PR_BYTES, stream, tp);
+      else if (prow_ok) hipLaunchKernelGGL(oak::k_embed_prows<false>, dim3(wg_p), dim3(oak::PR_BLOCK), oak::PR_BYTES, stream, tp);
+      else if (slot_tags) hipLaunchKernelGGL((oak::k_embed_lds<false, true>), dim3(grid), dim3(oak::EL_BLOCK), oak::ELayout<false>::BYTES, stream, tp);
+      else hipLaunchKernelGGL(oak::k_embed_lds<false>, dim3(grid), dim3(oak::EL_BLOCK), oak::ELayout<false>::BYTES, stream, tp);
     }
-    for (int kind = 0; kind < 2 && !both; ++kind) {
-      if (tev) (void)hipEventRecord(tev[kind], stream);
-      if (!((kinds >> kind) & 1)) continue;
-      oak::EmbedTileArgs ta{D, battles, durations, n, emb, kind, nullptr, nullptr};
-      const uint32_t ntiles = (n * (kind ? 2u : 10u) + oak::ET - 1) / oak::ET;
-      if (kind == 0 && slot_tags) { // cached party-slot pass: tag comparison, then only the changed slots (work list)
-        uint8_t *ws = (uint8_t *)oakgpu_ctx_workspace(ctx, 2, (size_t)n * 10 * sizeof(oak::PartyWork) + 16);
-        if (!ws) return -1;
-        uint32_t *count = (uint32_t *)ws;
-        oak::PartyWork *work = (oak::PartyWork *)(ws + 16);
-        hipError_t me = hipMemsetAsync(count, 0, 4, stream);
-        if (me != hipSuccess) return oakgpu_fail_hip((int)me, "hipMemsetAsync(work count)");
-        hipLaunchKernelGGL(oak::k_party_tags, dim3((n * 10 + 256 * oak::TAG_R - 1) / (256 * oak::TAG_R)), dim3(256), 0, stream, D, battles, durations, n, emb, slot_tags, work, count);
-        ta.work = work;
-        ta.work_count = count;
-        // the same kernel as the plain pass (so that cached and plain embeddings are bit-identical); workgroups beyond the
-        // list's length leave before staging any weights
-        if (embed_impl >= 4 && rows_ok) hipLaunchKernelGGL(oak::k_embed_prows<true>, dim3(256), dim3(oak::PR_BLOCK), oak::PR_BYTES, stream, ta);
-        else hipLaunchKernelGGL((oak::k_embed_lds<false, true>), dim3(ntiles < 256 ? ntiles : 256), dim3(oak::EL_BLOCK), oak::ELayout<false>::BYTES, stream, ta);
-        continue;
-      }
-      if (kind == 1 && embed_impl >= 4 && D.a_hidden <= 128 && D.a_out <= 128 && !getenv("OAKGPU_ACTIVE_TILE")) { // default actives' pass
-        const uint32_t nmt = (n * 2 + oak::ER_ITEMS - 1) / oak::ER_ITEMS, wg = (nmt + oak::AR_WAVES - 1) / oak::AR_WAVES;
-        hipLaunchKernelGGL(oak::k_embed_arows, dim3(wg < 256 ? wg : 256), dim3(oak::AR_BLOCK), oak::ar_bytes((D.a_out + 31) / 32), stream, ta);
-        continue;
-      }
-      if (kind == 0 && embed_impl >= 4 && rows_ok) { // default party-slot pass: every wave its own pipeline
-        if (embed_impl == 6) { // the previous form: every lane its own weight rows (A/B)
-          const uint32_t nmt = (n * 10 + oak::ER_ITEMS - 1) / oak::ER_ITEMS, wg = (nmt + oak::ER_WAVES - 1) / oak::ER_WAVES;
-          hipLaunchKernelGGL(oak::k_embed_rows<false>, dim3(wg < 256 ? wg : 256), dim3(oak::ER_BLOCK), oak::ER_BYTES, stream, ta);
-        } else {
-          const uint32_t nmt = (n * 10 + oak::ER_ITEMS - 1) / oak::ER_ITEMS, wg = (nmt + oak::PR_WAVES - 1) / oak::PR_WAVES;
-          hipLaunchKernelGGL(oak::k_embed_prows<false>, dim3(wg < 256 ? wg : 256), dim3(oak::PR_BLOCK), oak::PR_BYTES, stream, ta);
-        }
-        continue;
-      }
-      if (embed_impl == 2) { // second implementation: first-layer rows gathered from L2 (A/B)
-        const int out_pad = ((kind ? D.a_out : D.p_out) + 31) & ~31;
-        const size_t lds = (size_t)(oak::ET * oak::EHP + out_pad * oak::EHP + 4 * 128 + 2 * oak::ET + (kind ? 34 : 9) * 98) * 4;
-        hipLaunchKernelGGL(oak::k_embed_tile, dim3(ntiles < 1024 ? ntiles : 1024), dim3(oak::EMB_BLOCK), lds, stream, ta);
-      } else {               // default: first-layer weights resident in LDS, one workgroup per CU
-        const uint32_t grid = ntiles < 256 ? ntiles : 256;
-        if (kind) hipLaunchKernelGGL(oak::k_embed_lds<true>, dim3(grid), dim3(oak::EL_BLOCK), oak::ELayout<true>::BYTES, stream, ta);
-        else hipLaunchKernelGGL(oak::k_embed_lds<false>, dim3(grid), dim3(oak::EL_BLOCK), oak::ELayout<false>::BYTES, stream, ta);
-      }
+    if (tev) (void)hipEventRecord(tev[1], stream);
+    if (kinds & 2) {
+      const uint32_t ntiles = (n * 2u + oak::ET - 1) / oak::ET, grid = ntiles < 256 ? ntiles : 256;
+      if (arow_ok) hipLaunchKernelGGL(oak::k_embed_arows, dim3(wg_a), dim3(oak::AR_BLOCK), ar_lds, stream, tact);
+      else hipLaunchKernelGGL(oak::k_embed_lds<true>, dim3(grid), dim3(oak::EL_BLOCK), oak::ELayout<true>::BYTES, stream, tact);
     }
   }
   float *h1 = nullptr;
@@ -2347,14 +1764,7 @@ static int leaf_eval_impl(oakgpu_ctx *ctx, oakgpu_net *net, const uint8_t *battl
   }
   if (tev) (void)hipEventRecord(tev[2], stream);
   oak::MainArgs ma{D, emb, n, values, h1};
-  const int hld = (D.H > D.VH ? D.H : D.VH) + 1;
-  const size_t mn_lds = (size_t)((oak::TM + oak::MAXH) * (oak::KC_MAIN + 1) + oak::TM * hld) * 4;
-  static const int main_impl = getenv("OAKGPU_MAINNET_IMPL") ? atoi(getenv("OAKGPU_MAINNET_IMPL")) : 3;
-  if (main_impl == 1) // LDS-staged weights (A/B)
-    hipLaunchKernelGGL(oak::k_mainnet, dim3((n + oak::TM - 1) / oak::TM), dim3(oak::MN_BLOCK), mn_lds, stream, ma);
-  else if (main_impl == 2) // four-wave tiles with workgroup barriers (A/B)
-    hipLaunchKernelGGL(oak::k_mainnet_direct, dim3((n + oak::TM - 1) / oak::TM), dim3(oak::MN_BLOCK), (size_t)oak::TM * (oak::MAXH + 1) * 4, stream, ma);
-  else {
+  {
     const uint32_t wgs = ((n + 31) / 32 + 3) / 4;
     hipLaunchKernelGGL(oak::k_mainnet_wave, dim3(wgs < 256 ? wgs : 256), dim3(oak::MN_BLOCK), oak::MW_BYTES, stream, ma);
   }
