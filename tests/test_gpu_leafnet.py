@@ -95,6 +95,28 @@ def test_ragged_batch_sizes(gpu_ctx, tmp_path, n):
     net.close()
 
 
+def test_tile_form_of_the_embedding_passes_agrees(gpu_ctx, tmp_path):
+    """OAKGPU_EMBED_TILE=1 sends both embedding passes through k_embed_lds (the 64-item tile form, otherwise only taken by
+    embedding nets wider than the row kernels allow): a second implementation of the same function, run in a child process."""
+    import subprocess
+    import sys
+    from oak_amd.engine import Network
+    path = str(tmp_path / "c3.battle.net")
+    NN.write_random_net(path, hidden=256, value_hidden=256, seed=21)
+    b, d = _midgame_states(257, 35, 31337)
+    np.save(str(tmp_path / "b.npy"), b)
+    np.save(str(tmp_path / "d.npy"), d)
+    net = Network(gpu_ctx, path=path)
+    vals = net.value_inference(b, d)
+    net.close()
+    code = ("import sys, numpy as np; sys.path.insert(0, %r); from oak_amd.engine import Context, Network; c = Context(0); "
+            "n = Network(c, path=%r); np.save(%r, n.value_inference(np.load(%r), np.load(%r)))"
+            % (ROOT, path, str(tmp_path / "v.npy"), str(tmp_path / "b.npy"), str(tmp_path / "d.npy")))
+    subprocess.run([sys.executable, "-c", code], check=True, env=dict(os.environ, OAKGPU_EMBED_TILE="1"), timeout=600)
+    tile = np.load(str(tmp_path / "v.npy"))
+    assert np.abs(tile - vals).max() <= TOL
+
+
 def test_bad_network_files_raise(gpu_ctx, tmp_path):
     from oak_amd.engine import Network
     from oak_amd._lib import OakGpuError
