@@ -117,6 +117,31 @@ def test_tile_form_of_the_embedding_passes_agrees(gpu_ctx, tmp_path):
     assert np.abs(tile - vals).max() <= TOL
 
 
+def test_full_size_batch_properties(gpu_ctx, tmp_path):
+    """BASELINE's full size (65,536 leaves, 768-256-256-256-1): properties that need no oracle pass over the whole batch --
+    the evaluation is a pure function of the leaf (a permuted batch gives the permuted values, bit for bit, so no result
+    depends on which lane / wave / tile a leaf lands in), repeatable, every value a probability -- and a 2,048-leaf sample
+    (every 32nd leaf) against the C oracle."""
+    from oak_amd.engine import Network
+    n = 65536
+    path = str(tmp_path / "c3.battle.net")
+    NN.write_random_net(path, hidden=256, value_hidden=256, seed=13)
+    net = Network(gpu_ctx, path=path)
+    b, d, p, r = O.make_random_ou_batch(n, seed0=0xF0115123)
+    O.rollout_batch(b, d, r, p, max_steps=25, threads=8)
+    v0 = net.value_inference(b, d)
+    assert v0.shape == (n,) and np.isfinite(v0).all() and (v0 > 0).all() and (v0 < 1).all()
+    assert (net.value_inference(b, d) == v0).all()
+    perm = np.random.default_rng(5).permutation(n)
+    assert (net.value_inference(b[perm], d[perm]) == v0[perm]).all()
+    cnet = O.CNet(path)
+    idx = np.arange(0, n, 32)
+    exp = cnet.value_inference_batch(np.ascontiguousarray(b[idx]), np.ascontiguousarray(d[idx]), threads=8)
+    assert np.abs(v0[idx] - exp).max() <= TOL
+    cnet.close()
+    net.close()
+
+
 def test_bad_network_files_raise(gpu_ctx, tmp_path):
     from oak_amd.engine import Network
     from oak_amd._lib import OakGpuError
