@@ -645,6 +645,7 @@ __device__ __forceinline__ void embed_arows_body(const EmbedTileArgs &a, float *
   while (mt < nmt) {
     __builtin_amdgcn_wave_barrier();
     EL_MARK(3);
+    __builtin_amdgcn_s_setprio(2); // a wave in its MFMA phases goes before waves that encode or scatter (see the second layer)
     // ---- first layer, dense part on the matrix pipe: hb[blk] = this lane's 16 channels of block blk of item r32 ----
     f32x16 hb[4];
 #pragma unroll
@@ -696,6 +697,9 @@ __device__ __forceinline__ void embed_arows_body(const EmbedTileArgs &a, float *
     __builtin_amdgcn_sched_barrier(0);
     EL_MARK(4);
     // ---- second layer: one 32-wide output block after the other, W1 fragments from LDS (256 B per k-step, conflict-free) ----
+    // wave priority: second layer 3 > first layer 2 > encode / scatter 0 -- the matrix pipe is the kernel's bound, so whoever
+    // can feed it issues first (party pass 200 -> 187 us; the arbitration otherwise favours the oldest wave whatever it does)
+    __builtin_amdgcn_s_setprio(3);
 #pragma unroll 1
     for (int nb = 0; nb < NBo; ++nb) {
       f32x16 acc;
@@ -715,6 +719,7 @@ __device__ __forceinline__ void embed_arows_body(const EmbedTileArgs &a, float *
         if (o < out_dim && doff != 0xFFFFFFFFu) a.emb[(size_t)doff + 1 + o] = act_fn(acc[q] + ob, N.activation);
       }
     }
+    __builtin_amdgcn_s_setprio(0);
     if (hh == 0 && dst_off[r32] != 0xFFFFFFFFu) a.emb[dst_off[r32]] = hp_ratio[r32];
     __builtin_amdgcn_wave_barrier(); // the wave's LDS is rewritten by the next mini-tile
     EL_MARK(7);
@@ -845,6 +850,7 @@ __device__ __forceinline__ void embed_prows_body(const EmbedTileArgs &a, float *
   while (mt < nmt) {
     __builtin_amdgcn_wave_barrier();
     EL_MARK(3);
+    __builtin_amdgcn_s_setprio(2); // a wave in its MFMA phases goes before waves that encode or scatter (see the second layer)
     // ---- first layer: dense part, then the one-hot rows through the identity transposition (see k_embed_arows) ----
     f32x16 hb[4];
 #pragma unroll
@@ -886,6 +892,9 @@ __device__ __forceinline__ void embed_prows_body(const EmbedTileArgs &a, float *
       for (int q = 0; q < 16; ++q) hb[b][q] = act_fn(hb[b][q], N.activation);
     EL_MARK(4);
     // ---- second layer ----
+    // wave priority: second layer 3 > first layer 2 > encode / scatter 0 -- the matrix pipe is the kernel's bound, so whoever
+    // can feed it issues first (party pass 200 -> 187 us; the arbitration otherwise favours the oldest wave whatever it does)
+    __builtin_amdgcn_s_setprio(3);
 #pragma unroll 1
     for (int nb = 0; nb < NBo; ++nb) {
       f32x16 acc;
@@ -905,6 +914,7 @@ __device__ __forceinline__ void embed_prows_body(const EmbedTileArgs &a, float *
         if (o < out_dim && doff != 0xFFFFFFFFu) a.emb[(size_t)doff + 1 + o] = act_fn(acc[q] + ob, N.activation);
       }
     }
+    __builtin_amdgcn_s_setprio(0);
     if (hh == 0 && dst_off[r32] != 0xFFFFFFFFu) a.emb[dst_off[r32]] = hp_ratio[r32];
     __builtin_amdgcn_wave_barrier(); // the wave's LDS is rewritten by the next mini-tile
     EL_MARK(7);
