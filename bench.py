@@ -59,23 +59,32 @@ def main():
                          "whole batch + a leaf eval of every lane, every turn; search = tree search with batched leaves "
                          "(oakgpu_search), iterations/s on one random OU root")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launch / rendezvous / exchange / accounting rehearsal WITHOUT a GPU: gloo backend, CPU tensors, the kernel "
+                         "replaced by a stub that writes a rank-and-batch pattern (no engine, no oracle); the line says dry_run: true "
+                         "and its value measures nothing.  tests/test_bench_launch.py runs `bench.py --gpus 2 --dry-run` here.")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` with no launcher around it: start the N ranks ourselves, BEFORE this process has made
+        # any GPU call (torch is not even imported yet) -- never re-exec a process that touched the GPU
+        raise SystemExit(self_launch(args.gpus))
 
     import numpy as np
     import torch
-    from oak_amd import _lib
-    from oak_amd import dist as oakdist
-    from oak_amd.engine import Context
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`"
-                             % (args.gpus, args.gpus))
+        raise SystemExit("--gpus %d but the launcher started WORLD_SIZE=%d ranks" % (args.gpus, world))
+    if args.dry_run:
+        return dry_run(args, torch, rank, world)
     if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (no CPU fallback exists)")
+        raise SystemExit("bench.py needs a GPU (no CPU fallback exists; --dry-run rehearses the launch and the exchange only)")
+    from oak_amd import _lib
+    from oak_amd import dist as oakdist
+    from oak_amd.engine import Context
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -84,12 +93,18 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm
+        if dist.get_world_size() != world:
+            raise SystemExit("process group has %d ranks, expected %d" % (dist.get_world_size(), world))
 
     if args.workload == "search":
-        return search_workload(args, torch, dev, rank, local_rank, world, dist)
-    if args.workload == "config4":
-        return config4_workload(args, torch, dev, rank, local_rank, world, dist)
-    if args.workload in ("leaf", "config3"):      # one sub-record on its own, same JSON shape as the headline line
+        rec = search_workload(args, torch, dev, rank, local_rank, world, dist)
+        if rank == 0:
+            print(json.dumps(rec), flush=True)
+    elif args.workload == "config4":
+        rec = config4_workload(args, torch, dev, rank, local_rank, world, dist)
+        if rank == 0:
+            print(json.dumps(rec), flush=True)
+    elif args.workload in ("leaf", "config3"):      # one sub-record on its own, same JSON shape as the headline line
         recs = leaf_records(args, torch, dev, rank, local_rank, world, dist, which=(args.workload,))
         if rank == 0:
             rec = recs[args.workload]
@@ -97,19 +112,101 @@ def main():
             print(json.dumps(rec), flush=True)
     else:
         # default ("all"): the headline configs[1] line carries the whole BASELINE metric -- turn-steps/s of batched
-        # playouts plus, as sub-records with their own timed regions, leaf-evals/s and configs[2]
+        # playouts plus, as sub-records with their own timed regions, leaf-evals/s (`leaf`), configs[2] (`config3`),
+        # configs[3] (`config4`: root-parallel MCTS step, STRONG scaling -- so one `--gpus N` command yields both curves)
+        # and configs[4] (`config5`: tree search with network leaves + exact Nash at the root)
         out = rollout_workload(args, torch, dev, rank, local_rank, world, dist, force_dist)
+        subs = {}
         if args.workload == "all":
-            recs = leaf_records(args, torch, dev, rank, local_rank, world, dist)
-            if rank == 0:
-                out.update(recs)
+            subs.update(leaf_records(args, torch, dev, rank, local_rank, world, dist) or {})
+            for name, fn in (("config4", config4_workload), ("config5", search_workload)):
+                try:
+                    rec = fn(args, torch, dev, rank, local_rank, world, dist)
+                except Exception as e:   # a sub-record must never cost the headline line (same code on every rank: they skip together)
+                    rec = {"error": "%s: %s" % (type(e).__name__, e)}
+                    print("bench.py: sub-record %s failed: %s" % (name, rec["error"]), file=sys.stderr, flush=True)
+                if rank == 0:
+                    subs[name] = rec
         if rank == 0 and world == 1 and not args.no_cpu_baseline:   # after every GPU timed region
-            cb = cpu_baseline(args.batch)
-            out = {k: v for k, v in out.items() if k not in ("leaf", "config3")} | {"cpu_baseline": cb} | {k: out[k] for k in ("leaf", "config3") if k in out}
+            out["cpu_baseline"] = cpu_baseline(args.batch)
+            if isinstance(subs.get("config4"), dict) and "error" not in subs["config4"]:
+                subs["config4"]["cpu_baseline"] = cpu_baseline_config4()
         if rank == 0:
+            out.update(subs)
             print(json.dumps(out), flush=True)
     if world > 1 or force_dist:
+        dist.barrier()
         dist.destroy_process_group()
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: N fresh child processes through torch.distributed.run (one rank per
+    GPU, rendezvous on 127.0.0.1), started before this process has imported torch or touched the GPU; rank 0's JSON line
+    goes to the inherited stdout; the exit code is the launcher's (non-zero if any rank failed).  The reference's analogue
+    starts its N workers from one command too (cpp/src/generate.cc:527-536: N std::threads)."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print("bench.py: --gpus %d without WORLD_SIZE: launching %s" % (n, " ".join(cmd)), file=sys.stderr, flush=True)
+    return subprocess.call(cmd, env=env)
+
+
+def dry_run(args, torch, rank, world):
+    """No GPU, no engine, no oracle: what runs is everything AROUND the kernel of the N > 1 headline path -- rendezvous (gloo),
+    the group plan, disjoint lane seeds, ONE all-gather per group through oak_amd.dist.gather_round, the row check of the
+    gather, barrier + max-over-ranks timing, the sum of turn-steps over ranks, rank 0's single JSON line.  The stub
+    'kernel' writes value = rank + batch / 1024 and 100 turn-steps per playout."""
+    import torch.distributed as dist
+    from oak_amd import dist as oakdist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29511")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n = min(args.batch, 4096)
+    G = max(1, min(args.group, 64))
+    timed = [G] * (args.steps // G) + ([args.steps % G] if args.steps % G else [])
+    values = torch.empty((G, n), dtype=torch.float32)
+    gathered = torch.empty((world, G, n), dtype=torch.float32)
+    seeds = [oakdist.lane_seed0(SEED0 + k * n * world, n * world, rank, world) for k in range(G)]
+    my_steps = 0
+    dist.barrier()
+    t0 = time.perf_counter()
+    for gi, count in enumerate(timed):
+        for k in range(count):
+            values[k].fill_(rank + (gi * G + k) / 1024.0)      # the stub
+        my_steps += 100 * n * count
+        oakdist.gather_round(values[:count], gathered[:, :count] if count == G else None)
+    dist.barrier()
+    elapsed = time.perf_counter() - t0
+    probe, _ = oakdist.gather_round(values)
+    for r in range(world):     # rank r's rows of the gather are rank r's values
+        assert torch.equal(probe[r], values - rank + r), "all-gather returned a different row for rank %d" % r
+    t = torch.tensor([elapsed], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    s = torch.tensor([my_steps], dtype=torch.int64)
+    dist.all_reduce(s, op=dist.ReduceOp.SUM)
+    sd = torch.tensor([seeds[0]], dtype=torch.int64)
+    alls = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+    dist.all_gather(alls, sd)
+    if rank == 0:
+        print(json.dumps({
+            "metric": "turn-steps/s (batched playouts)", "value": int(s.item()) / float(t.item()), "unit": "turn-steps/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": float(t.item()) / max(args.steps, 1) * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "u16", "data": "synthetic", "dry_run": True,
+            "ranks_seen": dist.get_world_size(),
+            "config": {"workload": "DRY RUN: stub kernel on CPU tensors over gloo -- rehearses launch, lane sharding, the per-group all-gather "
+                                   "and the accounting of configs[1]; the value measures nothing", "batch_per_gpu": n,
+                       "first_lane_seed_per_rank": [int(x.item()) for x in alls], "groups": len(timed), "group": G},
+        }), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
 
 
 def rollout_workload(args, torch, dev, rank, local_rank, world, dist, force_dist=False):
@@ -240,21 +337,18 @@ def rollout_workload(args, torch, dev, rank, local_rank, world, dist, force_dist
     # executed; duration = HIP events around the launch on its own stream
     launch_s = sum(kern_ms) / 1e3
     achieved = my_steps * ALGO_BYTES_PER_STEP / launch_s / 1e9
-    traffic, valu = None, None
-    tp = os.path.join(ROOT, "profiles", "traffic.json")   # rocprofv3 --pmc results (tools/summarize_profile.py)
-    if os.path.exists(tp):
-        try:
-            tj = json.load(open(tp))
-            per_step = tj.get("k_rollout_hbm_bytes_per_turn_step")
-            traffic = per_step * my_steps / len(timed) if per_step else None
-            valu = tj.get("valu_wave_insts_per_turn_step")
-        except Exception:
-            traffic = None
+    # NOT measured in this run: PMC counters need rocprofv3 around the process.  The committed profile's per-turn-step figures
+    # (profiles/traffic.json, written by tools/summarize_profile_r03.py from the --pmc passes) scaled by THIS run's turn-steps
+    tj = profile_json()
+    per_step = tj.get("k_rollout_hbm_bytes_per_turn_step")
+    traffic = per_step * my_steps / len(timed) if per_step else None
+    valu = tj.get("valu_wave_insts_per_turn_step")
     out = {
         "metric": "turn-steps/s (batched playouts)",
         "value": value,
         "unit": "turn-steps/s",
         "n_gpus": world,
+        "ranks_seen": (dist.get_world_size() if (world > 1 or force_dist) else 1),
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3,
@@ -283,6 +377,8 @@ def rollout_workload(args, torch, dev, rank, local_rank, world, dist, force_dist
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBPS,
             "traffic": traffic,
+            "traffic_source": (PROFILE_SOURCE + ": k_rollout_hbm_bytes_per_turn_step (2 x FETCH_SIZE + WRITE_SIZE of a profiled group launch) x "
+                               "this run's turn-steps per launch; not measured in this run") if traffic else None,
             "avg_launch_ms": launch_s / len(timed) * 1e3,
             "launches": len(timed),
             "algorithmic_bytes_per_turn_step": ALGO_BYTES_PER_STEP,
@@ -295,7 +391,9 @@ def rollout_workload(args, torch, dev, rank, local_rank, world, dist, force_dist
         peak = 1024 * 2.4e9 / 4
         ach = valu * my_steps / elapsed
         out["roofline"]["valu_issue"] = {"wave_insts_per_turn_step": valu, "achieved_ginst_s": ach / 1e9,
-                                         "peak_ginst_s": peak / 1e9, "frac": ach / peak}
+                                         "peak_ginst_s": peak / 1e9, "frac": ach / peak,
+                                         "active_lanes_per_wave_inst": tj.get("valu_active_lanes_per_wave_inst"),
+                                         "source": PROFILE_SOURCE + ": SQ_INSTS_VALU per turn-step of a profiled group launch x this run's turn-steps/s"}
     # (the CPU baseline is timed by the caller AFTER every GPU record: 10-30 s of host work between two GPU timed regions let
     # the device clock down, and the next region then measured the ramp)
     return out
@@ -408,6 +506,7 @@ def leaf_records(args, torch, dev, rank, local_rank, world, dist, which=("leaf",
         return {"k_embed_prows (party slots)": acc[0] / 5 * 1e3, "k_embed_arows (actives)": acc[1] / 5 * 1e3, "k_mainnet_wave": acc[2] / 5 * 1e3}
 
     out = {}
+    tj = profile_json()
     # sub-records: at least 30 untimed calls (~20 ms) before the timed K -- the clocks settle over the first ~15 ms of MFMA
     # work after the integer-VALU rollout phase, and with the driver's --warmup 5 the 14 ms timed region measured that ramp
     K, W = args.steps, max(args.warmup, 30)
@@ -422,7 +521,10 @@ def leaf_records(args, torch, dev, rank, local_rank, world, dist, which=("leaf",
                                    "sigmoid) over 65536 mid-game states per GPU", "batch_per_gpu": n,
                        "parity": "<= 1e-5 vs numpy oracle pinned by the reference torch mirror"},
             "roofline": {"bound": "mfma", "kernel": "oak::k_embed_both (k_embed_prows + k_embed_arows in one launch) + oak::k_mainnet_wave (one value_inference call)",
-                         "achieved": achieved, "peak": 157.3, "unit": "TFLOP/s", "frac": achieved / 157.3, "traffic": None,
+                         "achieved": achieved, "peak": 157.3, "unit": "TFLOP/s", "frac": achieved / 157.3,
+                         "traffic": (tj.get("leaf_hbm_bytes_per_leaf") * n if tj.get("leaf_hbm_bytes_per_leaf") else None),
+                         "traffic_source": (PROFILE_SOURCE + ": leaf_hbm_bytes_per_leaf (2 x FETCH_SIZE + WRITE_SIZE of the call's kernels) x batch; not measured in this run")
+                         if tj.get("leaf_hbm_bytes_per_leaf") else None,
                          "avg_call_ms": avg_s * 1e3, "algorithmic_flop_per_leaf": main_f + emb_f, "mainnet_flop_per_leaf": main_f,
                          "kernel_us": kernel_us()},
         }
@@ -431,6 +533,17 @@ def leaf_records(args, torch, dev, rank, local_rank, world, dist, which=("leaf",
         elapsed, avg_s = timed(config3_step, K, W)
         achieved = (main_f + emb_f) * n / avg_s / 1e12
         steps_done = int(live.sum(dtype=torch.int64).item())
+        # what the cache actually executes: a diagnostic pass (untimed) reads the work list's length after every turn of one episode
+        miss = []
+        turn[0] = 0
+        for _ in range(40):
+            config3_step()
+            cnt = C.c_uint32(0)
+            _lib.check(lib.oakgpu_leaf_cache_last_count(h, C.byref(cnt)))
+            miss.append(cnt.value / (n * 10.0))
+        miss_rate = sum(miss) / len(miss)
+        party_f = 10 * 2 * (12 * 128 + 128 * 59)
+        executed = (main_f + (emb_f - party_f) + party_f * miss_rate) * n / avg_s / 1e12
         if world > 1:
             s_ = torch.tensor([steps_done], dtype=torch.int64, device=dev)
             dist.all_reduce(s_, op=dist.ReduceOp.SUM)
@@ -446,9 +559,14 @@ def leaf_records(args, torch, dev, rank, local_rank, world, dist, which=("leaf",
                        "live_lane_fraction": steps_done / (n * world * K)},
             "roofline": {"bound": "mfma", "kernel": "oak::k_rollout_staged (1 turn-step) + oak::k_party_tags + oak::k_embed_both<list> (changed party slots + "
                                                      "actives) + oak::k_mainnet_wave",
-                         "achieved": achieved, "peak": 157.3, "unit": "TFLOP/s", "frac": achieved / 157.3, "traffic": None,
+                         "achieved": achieved, "peak": 157.3, "unit": "TFLOP/s", "frac": achieved / 157.3,
+                         "frac_executed": executed / 157.3, "achieved_executed": executed, "party_slot_miss_rate": miss_rate,
+                         "traffic": (tj.get("config3_hbm_bytes_per_lane_turn") * n if tj.get("config3_hbm_bytes_per_lane_turn") else None),
+                         "traffic_source": (PROFILE_SOURCE + ": config3_hbm_bytes_per_lane_turn x batch; not measured in this run")
+                         if tj.get("config3_hbm_bytes_per_lane_turn") else None,
                          "avg_step_ms": avg_s * 1e3, "algorithmic_flop_per_leaf": main_f + emb_f,
-                         "note": "algorithmic FLOP count every embedding (SURVEY 8d: recomputed per leaf); the cache skips the unchanged party slots"},
+                         "note": "frac prices the ALGORITHMIC FLOP (SURVEY 8d: every embedding recomputed per leaf); frac_executed prices what ran: the "
+                                 "cache re-embeds party_slot_miss_rate of the party slots (work-list length read back in an untimed 40-turn pass)"},
         }
         out["config3"] = rec
     if rank == 0 and world == 1 and not args.no_cpu_baseline:   # CPU baselines after both GPU timed regions (see main)
@@ -563,32 +681,30 @@ def config4_workload(args, torch, dev, rank, local_rank, world, dist):
     got = np.concatenate([host.numpy()[r * per:r * per + (oakdist.root_shard(n_roots, r, world)[1] - oakdist.root_shard(n_roots, r, world)[0])]
                           for r in range(world)])
     assert got.shape == (n_roots,) and ((got >= 0) & (got <= 1)).all()
+    rec = None
     if rank == 0:
-        print(json.dumps({
+        rec = {
             "metric": "turn-steps/s (root-parallel MCTS step: 256 roots x 4096 playouts)", "value": my_steps / elapsed, "unit": "turn-steps/s",
-            "n_gpus": world, "steps": K, "warmup": args.warmup, "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "strong",
+            "n_gpus": world, "ranks_seen": (dist.get_world_size() if dist is not None else 1),
+            "steps": K, "warmup": args.warmup, "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "u16", "data": "synthetic",
             "config": {"workload": "configs[3]: root-parallel MCTS, 256 roots x 4096 playouts per search step, roots sharded contiguous-by-root, "
                                    "per-root means reduced on the device, ONE all-gather of 256 floats per step, means on the host before the next step",
                        "roots": n_roots, "playouts_per_root": reps, "roots_per_gpu": mine, "playouts_per_s": n_roots * reps * K / elapsed,
                        "exchange": ("oakgpu_all_gather_dev (ncclAllGather)" if comm is not None else "torch.distributed all_gather_into_tensor" if world > 1 else "none (one rank)"),
                        "mean_root_value": float(got.mean())},
-        }), flush=True)
-    dbg = (lambda m: print(m, file=sys.stderr, flush=True)) if os.environ.get("BENCH_DEBUG") else (lambda m: None)
+            "roofline": {"bound": "hbm", "kernel": "oak::k_rollout_queue (one launch = one search step of this rank's roots, root prep included)",
+                         "achieved": my_steps / world * ALGO_BYTES_PER_STEP / elapsed / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": my_steps / world * ALGO_BYTES_PER_STEP / elapsed / 1e9 / HBM_PEAK_GBPS, "traffic": None,
+                         "algorithmic_bytes_per_turn_step": ALGO_BYTES_PER_STEP,
+                         "note": "whole-step clock (launch + segment mean + gather + host copy), per rank; notional like the headline's: the kernel is VALU-issue bound"},
+        }
     torch.cuda.synchronize(dev)
     if comm is not None:
-        lib.oakgpu_comm_destroy(comm)
-        dbg("comm destroyed")
-    del host
-    dbg("host freed")
-    del battles, durations, rin, prng, results, steps_out, values, means, allm, total, rb, rd, rp, rr
-    dbg("tensors freed")
-    del stream
-    dbg("stream wrapper freed")
+        lib.oakgpu_comm_destroy(comm)     # before the stream and buffers it used
+    del host, battles, durations, rin, prng, results, steps_out, values, means, allm, total, rb, rd, rp, rr, stream
     ctx.close()
-    dbg("ctx closed")
-    if world > 1:
-        dist.destroy_process_group()
+    return rec
 
 
 def search_workload(args, torch, dev, rank, local_rank, world, dist):
@@ -657,27 +773,45 @@ def search_workload(args, torch, dev, rank, local_rank, world, dist):
                          "nodes": outs_nn[-1]["nodes"], "mean_depth": outs_nn[-1]["mean_depth"], "nash_value": outs_nn[-1]["nash_value"],
                          "leaf_evals_per_s": iters * K * world / elapsed_nn}}
     net.close()
-    if rank == 0:
-        print(json.dumps({
-            "config5_network_leaves": nn_rec,
-            "metric": "search iterations/s (tree search, batched Monte-Carlo leaves)", "value": iters * K * world / elapsed,
-            "unit": "iterations/s", "n_gpus": world, "steps": K, "warmup": 1, "ms_per_step": elapsed / K * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u16", "data": "synthetic",
-            "config": {"workload": "SURVEY 8(f) rank 1: MCTS::Search::run, Node heap, joint UCB (c = 2), 2^18 iterations per search in "
-                                   "batches of 16384 descents, rollout leaves, roll clamping {3, 1}; one random OU turn-1 root per GPU",
-                       "nodes": outs[-1]["nodes"], "mean_depth": outs[-1]["mean_depth"], "nash_value": outs[-1]["nash_value"]},
-        }), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
+    ctx.close()
+    if rank != 0:
+        return None
+    nn_rec["vs_baseline"] = None
+    nn_rec["search_mc_leaves"] = {
+        "metric": "search iterations/s (tree search, batched Monte-Carlo leaves)", "value": iters * K * world / elapsed,
+        "unit": "iterations/s", "n_gpus": world, "steps": K, "warmup": 1, "ms_per_step": elapsed / K * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u16", "data": "synthetic",
+        "config": {"workload": "SURVEY 8(f) rank 1: MCTS::Search::run, Node heap, joint UCB (c = 2), 2^18 iterations per search in "
+                               "batches of 16384 descents, rollout leaves, roll clamping {3, 1}; one random OU turn-1 root per GPU",
+                   "nodes": outs[-1]["nodes"], "mean_depth": outs[-1]["mean_depth"], "nash_value": outs[-1]["nash_value"]},
+    }
+    return nn_rec
+
+
+PROFILE_SOURCE = "profiles/traffic.json"
+
+
+def profile_json():
+    """Per-unit figures derived from the committed rocprofv3 --pmc passes (tools/summarize_profile_r03.py).  Everything the
+    bench line takes from here is labelled with a *_source field: it is profile-derived, not measured in the run."""
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+    except Exception:
+        return {}
 
 
 def host_threads():
-    """Threads the CPU baselines use: the cores this process may actually use = min(affinity mask, cgroup CPU quota)
-    (a one-GPU job on the GPU box sees every CPU of the host in its mask but is given a 16-CPU share)."""
+    """(threads, source) for the CPU baselines: the cores this process may actually use = min(affinity mask, cgroup CPU quota)
+    (a one-GPU job on the GPU box sees every CPU of the host in its mask but is given a 16-CPU share).  source says where the
+    number came from: "env" (BENCH_CPU_THREADS), "cgroup", "affinity", or "assumed" (no quota visible on a > 64-CPU host: the
+    documented 16-CPU share of a one-GPU job is assumed rather than oversubscribing a shared host)."""
+    if os.environ.get("BENCH_CPU_THREADS"):
+        return int(os.environ["BENCH_CPU_THREADS"]), "env"
     try:
         cores = max(1, len(os.sched_getaffinity(0)))
     except AttributeError:
         cores = os.cpu_count() or 1
+    source = "affinity"
     for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
         try:
             txt = open(path).read().split()
@@ -686,20 +820,22 @@ def host_threads():
             else:
                 quota, period = txt[0], float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
             if quota not in ("max", "-1"):
-                cores = max(1, min(cores, int(round(float(quota) / period))))
+                q = max(1, int(round(float(quota) / period)))
+                if q < cores:
+                    cores, source = q, "cgroup"
             break
         except (OSError, ValueError, IndexError):
             continue
-    if cores > 64 and not os.environ.get("BENCH_CPU_THREADS"):
-        cores = 16   # no quota visible: assume the documented one-GPU share rather than oversubscribing a shared host
-    return int(os.environ.get("BENCH_CPU_THREADS", cores))
+    if cores > 64:
+        cores, source = 16, "assumed"
+    return cores, source
 
 
 def cpu_baseline(n):
     """The CPU oracle (kind "port": this repo's restatement, NOT the Oak binary) on the host cores,
     same lane seeds as the GPU batch, bounded to roughly 10-20 thread-seconds of work."""
     import oracle_lib as O
-    cores = host_threads()
+    cores, tsrc = host_threads()
     sample = min(n, 65536)
     b, d, p, r = O.make_random_ou_batch(sample, SEED0)
     reps, total = 0, 0
@@ -714,6 +850,7 @@ def cpu_baseline(n):
         "value": total / dt,
         "unit": "turn-steps/s",
         "cores": cores,
+        "threads_source": tsrc,
         "kind": "port",
         "sample": "%d passes over %d playouts (same lane seeds as the GPU batch), %d threads, oracle/liboracle.so "
                   "gcc -O3 -march=x86-64-v3" % (reps, sample, cores),
@@ -724,7 +861,7 @@ def cpu_baseline_leaf(net_path, mid, dur_mid):
     """leaf-evals/s of oracle/nn_host.c (plain-C fp32 port of value_inference: sparse first layers, batch-1 GEMVs like
     the reference's Eigen path, no embedding cache -- every battle is evaluated once) on the same mid-game states."""
     import oracle_lib as O
-    cores = host_threads()
+    cores, tsrc = host_threads()
     sample = min(mid.shape[0], 32768)
     b, d = mid[:sample].cpu().numpy(), dur_mid[:sample].cpu().numpy()
     net = O.CNet(net_path)
@@ -735,7 +872,7 @@ def cpu_baseline_leaf(net_path, mid, dur_mid):
         reps += 1
     dt = time.perf_counter() - t0
     net.close()
-    return {"value": sample * reps / dt, "unit": "leaf-evals/s", "cores": cores, "kind": "port",
+    return {"value": sample * reps / dt, "unit": "leaf-evals/s", "cores": cores, "threads_source": tsrc, "kind": "port",
             "sample": "%d passes over %d of the GPU batch's mid-game states, %d threads, oracle/nn_host.c gcc -O3 -march=x86-64-v3"
                       % (reps, sample, cores)}
 
@@ -744,7 +881,7 @@ def cpu_baseline_config3(net_path, n):
     """configs[2] on the host: one random turn-step of every lane (oracle engine) + value_inference of every lane (C port),
     episode of 10 turns from the turn-0 batch."""
     import oracle_lib as O
-    cores = host_threads()
+    cores, tsrc = host_threads()
     sample = min(n, 16384)
     b, d, p, r = O.make_random_ou_batch(sample, SEED0)
     net = O.CNet(net_path)
@@ -758,9 +895,26 @@ def cpu_baseline_config3(net_path, n):
         turns += 1
     dt = time.perf_counter() - t0
     net.close()
-    return {"value": total / dt, "unit": "turn-steps/s", "cores": cores, "kind": "port",
+    return {"value": total / dt, "unit": "turn-steps/s", "cores": cores, "threads_source": tsrc, "kind": "port",
             "sample": "%d turns of %d lanes (turn-step by oracle/liboracle.so + value_inference by oracle/nn_host.c), %d threads"
                       % (turns, sample, cores)}
+
+
+def cpu_baseline_config4():
+    """configs[3] on the host: the oracle's playout loop WITH root prep (battle.rng from the lane's stream +
+    randomize_hidden_variables) over 16 of the 256 roots x 4096 replicas, all host threads."""
+    import numpy as np
+    import oracle_lib as O
+    cores, tsrc = host_threads()
+    roots, reps = 16, 4096
+    b, d, _, r = O.make_random_ou_batch(roots, SEED0)
+    _, _, p, _ = O.make_random_ou_batch(roots * reps, 0xC40000000000)
+    B, D, R = np.repeat(b, reps, axis=0), np.repeat(d, reps, axis=0), np.repeat(r, reps)
+    t0 = time.perf_counter()
+    _, steps = O.rollout_batch(B, D, R, p, max_steps=MAX_STEPS, prep=True, threads=cores)
+    dt = time.perf_counter() - t0
+    return {"value": int(steps.sum()) / dt, "unit": "turn-steps/s", "cores": cores, "threads_source": tsrc, "kind": "port",
+            "sample": "%d of the 256 roots x %d playouts with root prep, %d threads, oracle/liboracle.so" % (roots, reps, cores)}
 
 
 if __name__ == "__main__":

@@ -336,6 +336,9 @@ int oakgpu_leaf_eval(oakgpu_ctx *ctx, oakgpu_net *net, const uint8_t *battles, c
 #define OAKGPU_SLOT_TAG_WORDS 6
 int oakgpu_leaf_eval_cached_dev(oakgpu_ctx *ctx, oakgpu_net *net, const uint8_t *battles, const uint8_t *durations, uint32_t n,
                                 float *values, float *embedding, uint32_t *slot_tags);
+/* Diagnostic (synchronises the context's stream): how many party slots the LAST oakgpu_leaf_eval_cached_dev call of this
+ * context re-embedded (the cache misses of nn/battle/cache.h:81-126), of the n x 10 it looked at. */
+int oakgpu_leaf_cache_last_count(oakgpu_ctx *ctx, uint32_t *slots_recomputed);
 
 /* value_policy_inference (network.h:102-123): value plus, per side, the logits of the <= 9 legal choices
  * (choices n x 9 bytes + counts n bytes per side, as produced by oakgpu_choices*; logits n x 9 floats,

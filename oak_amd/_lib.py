@@ -14,7 +14,7 @@ SYMBOLS = [
     "oakgpu_choices_dev", "oakgpu_choices", "oakgpu_init_battles_dev", "oakgpu_init_battles",
     "oakgpu_set_ou_pools", "oakgpu_random_ou_battles_dev",
     "oakgpu_net_load", "oakgpu_net_load_memory", "oakgpu_net_free", "oakgpu_net_shape",
-    "oakgpu_leaf_eval_dev", "oakgpu_leaf_eval", "oakgpu_leaf_eval_cached_dev", "oakgpu_leaf_eval_policy_dev", "oakgpu_leaf_eval_policy",
+    "oakgpu_leaf_eval_dev", "oakgpu_leaf_eval", "oakgpu_leaf_eval_cached_dev", "oakgpu_leaf_cache_last_count", "oakgpu_leaf_eval_policy_dev", "oakgpu_leaf_eval_policy",
     "oakgpu_tree_step_dev", "oakgpu_search", "oakgpu_search_agent", "oakgpu_agent_networks_clear", "oakgpu_bandit_replay", "oakgpu_solve_matrix",
     "oakgpu_segment_mean_dev", "oakgpu_comm_unique_id", "oakgpu_comm_create", "oakgpu_comm_destroy", "oakgpu_all_gather_dev",
     "oakgpu_frames_size", "oakgpu_frames_write", "oakgpu_frames_read", "oakgpu_selfplay_game", "oakgpu_poke_engine_eval_dev", "oakgpu_poke_engine_eval",
@@ -137,6 +137,7 @@ def load():
     lib.oakgpu_leaf_eval_dev.argtypes = [vp, vp, vp, vp, u32, vp, vp]
     lib.oakgpu_leaf_eval.argtypes = [vp, vp, vp, vp, u32, vp, vp]
     lib.oakgpu_leaf_eval_cached_dev.argtypes = [vp, vp, vp, vp, u32, vp, vp, vp]
+    lib.oakgpu_leaf_cache_last_count.argtypes = [vp, C.POINTER(u32)]
     lib.oakgpu_leaf_eval_policy_dev.argtypes = [vp, vp, vp, vp, u32, vp, vp, vp, vp, vp, vp, vp]
     lib.oakgpu_leaf_eval_policy.argtypes = [vp, vp, vp, vp, u32, vp, vp, vp, vp, vp, vp, vp]
     _lib = lib

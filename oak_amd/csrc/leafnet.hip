@@ -1810,6 +1810,18 @@ int oakgpu_leaf_eval_cached_dev(oakgpu_ctx *ctx, oakgpu_net *net, const uint8_t 
   return leaf_eval_impl(ctx, net, battles, durations, n, values, embedding, nullptr, slot_tags);
 }
 
+int oakgpu_leaf_cache_last_count(oakgpu_ctx *ctx, uint32_t *slots_recomputed) { // diagnostic: synchronises the stream
+  if (!ctx || !slots_recomputed) return oakgpu_fail_msg("oakgpu_leaf_cache_last_count: null pointer");
+  if (int rc = oakgpu_ctx_enter(ctx)) return rc;
+  hipStream_t stream = (hipStream_t)oakgpu_ctx_stream(ctx);
+  const uint32_t *count = (const uint32_t *)oakgpu_ctx_workspace(ctx, 2, 16);
+  if (!count) return -1;
+  hipError_t e = hipMemcpyAsync(slots_recomputed, count, 4, hipMemcpyDeviceToHost, stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(stream);
+  if (e != hipSuccess) return oakgpu_fail_hip((int)e, "oakgpu_leaf_cache_last_count");
+  return 0;
+}
+
 int oakgpu_leaf_eval_policy_dev(oakgpu_ctx *ctx, oakgpu_net *net, const uint8_t *battles, const uint8_t *durations, uint32_t n,
                                 const uint8_t *p1_choices, const uint8_t *p1_counts, const uint8_t *p2_choices,
                                 const uint8_t *p2_counts, float *values, float *p1_logits, float *p2_logits) {
