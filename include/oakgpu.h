@@ -189,7 +189,8 @@ typedef struct {
   uint32_t mucb_delay;
   uint32_t mucb_minimum;
   float mucb_c;
-  float exp3_alpha;      /* Exp3 / PExp3 uniform mixing (search.cc:268-286); 0 = the reference's default 0.05 */
+  float exp3_alpha;      /* Exp3 / PExp3 uniform mixing (search.cc:268-286); negative = the reference's default 0.05 (its value
+                          * when the agent string has no third field); 0 is honoured as 0, as the reference honours it */
   uint64_t duration_us;  /* time budget (search.cc:300-306): when non-zero, `iterations` is ignored and whole batches are
                           * started until this much time has elapsed; output.iterations tells how many ran */
 } oakgpu_search_params;
@@ -206,6 +207,9 @@ typedef struct {
   /* MCTS::Search::process_output (mcts.h:620-659): equilibrium of the empirical root matrix (x 256 as integers, solved
    * exactly, see oakgpu_solve_matrix) */
   double nash_value, p1_nash[9], p2_nash[9];
+  /* Output::Side::logit / prior (mcts.h:70-77): the policy heads' logits of the root's legal choices and their softmax,
+   * filled when a contextual bandit (PUCB / PExp3) initialises a FRESH root (mcts.h:196-209); otherwise as passed in */
+  double p1_logit[9], p2_logit[9], p1_prior[9], p2_prior[9];
 } oakgpu_search_output;
 /* LRSNash::solve_fast as the reference calls it (mcts.h:643-649, pyoak solve_matrix pyoak.cc:394-426): exact Nash
  * equilibrium of the m x n (<= 9 x 9) zero-sum game whose ROW player maximises the integer payoffs[i * n + j]
@@ -238,6 +242,47 @@ int oakgpu_bandit_replay(int kind, float c, float alpha, uint32_t k, const float
 int oakgpu_search(oakgpu_ctx *ctx, oakgpu_net *net /* nullable for eval = 0 */, const uint8_t *battle /* 384 */,
                   const uint8_t *durations /* 8 */, uint8_t result, const oakgpu_search_params *params,
                   oakgpu_search_output *out);
+
+/* ---- RuntimeSearch::Heap (util/search.h:17-32, search.cc:17-58) and the resumable form of Search::run.
+ * A heap keeps the tree of a search -- every node's bandit statistics -- between searches:
+ *   oakgpu_heap_empty   = Heap::empty(): 1 until a search has used the heap (std::monostate);
+ *   oakgpu_heap_update  = Heap::update(i, j, obs) (search.cc:27-52) after the joint action (p1 index i, p2 index j) was PLAYED
+ *                         and produced the 16-byte observation `obs` (pkmn_gen1_battle_options_chance_actions): the child
+ *                         becomes the root with its whole subtree, the rest is dropped; returns 1.  Returns 0 -- and
+ *                         leaves an uninitialised root, like `node = {}` -- when the searches never took that edge, when
+ *                         the root was never initialised, or when the heap is empty;
+ *   a heap holds one bandit type (the first search fixes it, like the variant, search.cc:205-213): searching it with another
+ *   fails with "RuntimeSearch: Bad Heap access. Expecting ...".
+ * oakgpu_search_heap = MCTS::Search::run(device, budget, params, heap, eval, input, output) (mcts.h:153-248):
+ *   heap      nullable: NULL = a fresh tree for this call (oakgpu_search);
+ *   previous  nullable: MCTS::Output is passed BY VALUE and added to -- visit / value matrices, `iterations` and `duration`
+ *             accumulate (:231-247), process_output (:620-659) then runs over the sums; MatrixUCB's delay counts
+ *             the accumulated iterations (:270).  `previous` and `out` may be the same object.
+ *   params->iterations == 0 with duration_us == 0 is legal here: no iteration runs and the output carries the fresh root's
+ *   initial_value / logits / priors (what the reference's cpp_inference reads, pyoak.cc:331-392); the empirical fields are
+ *   then 0 / 0 as in the reference.  A time budget always runs at least one batch (mcts.h:219-226), and its clock -- like
+ *   `duration_us` in the output -- covers the iteration loop only, not the set-up. */
+typedef struct oakgpu_heap oakgpu_heap;
+int oakgpu_heap_create(oakgpu_heap **out);
+void oakgpu_heap_destroy(oakgpu_heap *heap);
+int oakgpu_heap_empty(const oakgpu_heap *heap);
+void oakgpu_heap_clear(oakgpu_heap *heap);                       /* back to std::monostate */
+int oakgpu_heap_kind(const oakgpu_heap *heap);                   /* -1 empty, else oakgpu_search_params.bandit of its nodes */
+uint64_t oakgpu_heap_nodes(const oakgpu_heap *heap);
+int oakgpu_heap_update(oakgpu_heap *heap, uint8_t i, uint8_t j, const uint8_t *obs16);
+/* the root's bandit of one player (0 / 1): scores[9] (Exp3: gains), priors[9], visits[9], k (0 = root not initialised) */
+int oakgpu_heap_root_stats(const oakgpu_heap *heap, int player, float *scores, float *priors, uint32_t *visits, uint8_t *k);
+/* the same view of the child that oakgpu_heap_update(i, j, obs16) would promote; k = 0: no such (initialised) child */
+int oakgpu_heap_child_stats(const oakgpu_heap *heap, uint8_t i, uint8_t j, const uint8_t *obs16, int player, float *scores,
+                            float *priors, uint32_t *visits, uint8_t *k);
+int oakgpu_search_heap(oakgpu_ctx *ctx, oakgpu_net *net, oakgpu_heap *heap, const uint8_t *battle, const uint8_t *durations,
+                       uint8_t result, const oakgpu_search_params *params, const oakgpu_search_output *previous,
+                       oakgpu_search_output *out);
+/* RuntimeSearch::run(device, input, heap, agent, output) (util/search.h:66): oakgpu_search_agent with the heap and the
+ * output to resume. */
+int oakgpu_search_agent_heap(oakgpu_ctx *ctx, oakgpu_heap *heap, const uint8_t *battle, const uint8_t *durations, uint8_t result,
+                             const oakgpu_agent *agent, uint32_t batch, uint64_t seed, const oakgpu_search_output *previous,
+                             oakgpu_search_output *out);
 
 /* ---- the path's one exchange step: per-root pre-reduction on the device + RCCL all-gather over xGMI.
  * Root-parallel MCTS shards its roots contiguously over the GPUs of a node; each rank reduces its playouts' leaf values to

@@ -123,16 +123,36 @@ private:
   oakgpu_net *net_{};
 };
 
-// MCTS::Search::run(device, budget, params, heap, eval, input) (mcts.h:154-155) with an integer budget: the heap is a
-// fresh Node tree per call, `params.bandit` picks UCB::Bandit / PUCB::Bandit, eval = Monte-Carlo (net == nullptr)
-// or the network.  Output carries MCTS::Output's root matrices (mcts.h:68-90).
+// RuntimeSearch::Heap (util/search.h:17-32, search.cc:17-58): the tree of a search kept between searches.
+class Heap {
+public:
+  Heap() { check(oakgpu_heap_create(&h_)); }
+  ~Heap() { oakgpu_heap_destroy(h_); }
+  Heap(const Heap &) = delete;
+  Heap &operator=(const Heap &) = delete;
+  bool empty() const noexcept { return oakgpu_heap_empty(h_) != 0; }
+  // after the joint action (p1 index i, p2 index j) was played and produced `obs` (the 16-byte chance actions): the child
+  // becomes the root (true), or nothing could be kept (false) -- search.cc:27-52
+  bool update(uint8_t i, uint8_t j, const uint8_t *obs16) { return oakgpu_heap_update(h_, i, j, obs16) != 0; }
+  uint64_t nodes() const noexcept { return oakgpu_heap_nodes(h_); }
+  oakgpu_heap *get() const noexcept { return h_; }
+
+private:
+  oakgpu_heap *h_{};
+};
+
+// MCTS::Search::run(device, budget, params, heap, eval, input, output = {}) (mcts.h:154-155): `params.bandit` picks the
+// joint bandit, eval = Monte-Carlo (net == nullptr) or the network; heap == nullptr is a fresh Node tree for this call,
+// `previous` (nullable) is the Output to add to.  The result carries MCTS::Output's root matrices (mcts.h:68-90).
 class TreeSearch {
 public:
   explicit TreeSearch(Context &ctx) : ctx_{ctx} {}
-  oakgpu_search_output run(const Leaf &input, oakgpu_search_params params, Network *net = nullptr) {
+  oakgpu_search_output run(const Leaf &input, oakgpu_search_params params, Network *net = nullptr, Heap *heap = nullptr,
+                           const oakgpu_search_output *previous = nullptr) {
     params.eval = net ? 1 : 0;
     oakgpu_search_output out{};
-    check(oakgpu_search(ctx_.get(), net ? net->get() : nullptr, input.battle, input.durations, input.result, &params, &out));
+    check(oakgpu_search_heap(ctx_.get(), net ? net->get() : nullptr, heap ? heap->get() : nullptr, input.battle, input.durations, input.result,
+                             &params, previous, &out));
     return out;
   }
 
@@ -147,10 +167,11 @@ struct Agent {
   std::string budget{"4096"}, bandit{"ucb-1.0"}, eval{"mc"}, matrix_ucb{};
   bool discrete{false}, table{false};
 };
-inline oakgpu_search_output run(Context &ctx, const Leaf &input, const Agent &agent, uint64_t seed, uint32_t batch = 0) {
+inline oakgpu_search_output run(Context &ctx, const Leaf &input, const Agent &agent, uint64_t seed, uint32_t batch = 0, Heap *heap = nullptr,
+                                const oakgpu_search_output *previous = nullptr) {
   const oakgpu_agent a{agent.budget.c_str(), agent.bandit.c_str(), agent.eval.c_str(), agent.matrix_ucb.c_str(), agent.discrete, agent.table};
   oakgpu_search_output out{};
-  check(oakgpu_search_agent(ctx.get(), input.battle, input.durations, input.result, &a, batch, seed, &out));
+  check(oakgpu_search_agent_heap(ctx.get(), heap ? heap->get() : nullptr, input.battle, input.durations, input.result, &a, batch, seed, previous, &out));
   return out;
 }
 

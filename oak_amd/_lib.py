@@ -15,6 +15,8 @@ SYMBOLS = [
     "oakgpu_set_ou_pools", "oakgpu_random_ou_battles_dev",
     "oakgpu_net_load", "oakgpu_net_load_memory", "oakgpu_net_free", "oakgpu_net_shape",
     "oakgpu_leaf_eval_dev", "oakgpu_leaf_eval", "oakgpu_leaf_eval_cached_dev", "oakgpu_leaf_cache_last_count", "oakgpu_leaf_eval_policy_dev", "oakgpu_leaf_eval_policy",
+    "oakgpu_heap_create", "oakgpu_heap_destroy", "oakgpu_heap_empty", "oakgpu_heap_clear", "oakgpu_heap_kind", "oakgpu_heap_nodes", "oakgpu_heap_update",
+    "oakgpu_heap_root_stats", "oakgpu_heap_child_stats", "oakgpu_search_heap", "oakgpu_search_agent_heap",
     "oakgpu_tree_step_dev", "oakgpu_search", "oakgpu_search_agent", "oakgpu_agent_networks_clear", "oakgpu_bandit_replay", "oakgpu_solve_matrix",
     "oakgpu_segment_mean_dev", "oakgpu_comm_unique_id", "oakgpu_comm_create", "oakgpu_comm_destroy", "oakgpu_all_gather_dev",
     "oakgpu_frames_size", "oakgpu_frames_write", "oakgpu_frames_read", "oakgpu_selfplay_game", "oakgpu_poke_engine_eval_dev", "oakgpu_poke_engine_eval",
@@ -44,7 +46,8 @@ class SearchOutput(C.Structure):      # oakgpu_search_output
                 ("visit_matrix", C.c_uint64 * 81), ("value_matrix", C.c_double * 81), ("iterations", C.c_uint64),
                 ("empirical_value", C.c_double), ("initial_value", C.c_double), ("p1_empirical", C.c_double * 9),
                 ("p2_empirical", C.c_double * 9), ("nodes", C.c_uint64), ("total_depth", C.c_uint64),
-                ("duration_us", C.c_double), ("nash_value", C.c_double), ("p1_nash", C.c_double * 9), ("p2_nash", C.c_double * 9)]
+                ("duration_us", C.c_double), ("nash_value", C.c_double), ("p1_nash", C.c_double * 9), ("p2_nash", C.c_double * 9),
+                ("p1_logit", C.c_double * 9), ("p2_logit", C.c_double * 9), ("p1_prior", C.c_double * 9), ("p2_prior", C.c_double * 9)]
 
 class FrameUpdate(C.Structure):       # oakgpu_frame_update
     _fields_ = [("m", C.c_uint8), ("n", C.c_uint8), ("c1", C.c_uint8), ("c2", C.c_uint8), ("iterations", C.c_uint32),
@@ -104,6 +107,20 @@ def load():
     lib.oakgpu_poke_engine_eval.argtypes = [vp, vp, u32, C.c_float, vp, vp]
     lib.oakgpu_tree_step_dev.argtypes = [vp, vp, vp, vp, vp, vp, u32, u32, vp, vp, vp, vp, vp]
     lib.oakgpu_search.argtypes = [vp, vp, vp, vp, C.c_uint8, C.POINTER(SearchParams), C.POINTER(SearchOutput)]
+    lib.oakgpu_heap_create.argtypes = [C.POINTER(vp)]
+    lib.oakgpu_heap_destroy.argtypes = [vp]
+    lib.oakgpu_heap_destroy.restype = None
+    lib.oakgpu_heap_empty.argtypes = [vp]
+    lib.oakgpu_heap_clear.argtypes = [vp]
+    lib.oakgpu_heap_clear.restype = None
+    lib.oakgpu_heap_kind.argtypes = [vp]
+    lib.oakgpu_heap_nodes.argtypes = [vp]
+    lib.oakgpu_heap_nodes.restype = u64
+    lib.oakgpu_heap_update.argtypes = [vp, C.c_uint8, C.c_uint8, vp]
+    lib.oakgpu_heap_root_stats.argtypes = [vp, i32, vp, vp, vp, vp]
+    lib.oakgpu_heap_child_stats.argtypes = [vp, C.c_uint8, C.c_uint8, vp, i32, vp, vp, vp, vp]
+    lib.oakgpu_search_heap.argtypes = [vp, vp, vp, vp, vp, C.c_uint8, C.POINTER(SearchParams), C.POINTER(SearchOutput), C.POINTER(SearchOutput)]
+    lib.oakgpu_search_agent_heap.argtypes = [vp, vp, vp, vp, C.c_uint8, C.POINTER(Agent), u32, u64, C.POINTER(SearchOutput), C.POINTER(SearchOutput)]
     lib.oakgpu_segment_mean_dev.argtypes = [vp, vp, u32, u32, vp]
     lib.oakgpu_comm_unique_id.argtypes = [vp]
     lib.oakgpu_comm_create.argtypes = [vp, vp, i32, i32, C.POINTER(vp)]

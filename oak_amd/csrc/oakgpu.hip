@@ -15,6 +15,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <random>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -1150,6 +1151,8 @@ struct oakgpu_ctx {
   int timing;               // oakgpu_set_kernel_timing
   hipEvent_t tev[4];
   bool tev_valid;
+  void *attachment = nullptr;              // oakgpu_internal.h: the tree search's cached batch slots
+  void (*attachment_dtor)(void *) = nullptr;
 };
 
 static thread_local std::string g_err;
@@ -1191,6 +1194,12 @@ void *oakgpu_stage_get(oakgpu_ctx *c, size_t bytes) {
   return grow_block(c, c->stage[c->stage_cursor++], bytes ? bytes : 1);
 }
 void *oakgpu_ctx_stream(const oakgpu_ctx *c) { return (void *)c->stream; }
+void *oakgpu_ctx_attachment(const oakgpu_ctx *c) { return c->attachment; }
+void oakgpu_ctx_set_attachment(oakgpu_ctx *c, void *p, void (*dtor)(void *)) {
+  if (c->attachment && c->attachment_dtor) c->attachment_dtor(c->attachment);
+  c->attachment = p;
+  c->attachment_dtor = dtor;
+}
 #define HIPCHK(x) do { hipError_t _e = (x); if (_e != hipSuccess) return fail(_e, #x); } while (0)
 
 // ---- host-buffer conveniences (PCIe-inclusive; never the benchmarked path) ------------------
@@ -1241,12 +1250,27 @@ int oakgpu_create(oakgpu_ctx **out, int device) {
   if (n <= 0) return bad("oakgpu_create: no HIP device (this library has no CPU fallback)");
   if (device < 0 || device >= n) return bad("oakgpu_create: device index out of range");
   HIPCHK(hipSetDevice(device));
-  if (int r = set_lds_limits()) return r;         // kernel attributes are per device: set for every context's device
-  if (int r = oakgpu_leaf_set_lds_limits()) return r;
-  // the engine's table image of this device (idempotent: every context of a device writes the same bytes)
-  hipLaunchKernelGGL(oak::k_build_table_image, dim3(1), dim3(64), oak::TABLE_LDS_PAD, 0);
-  HIPCHK(hipGetLastError());
-  HIPCHK(hipStreamSynchronize(0));
+  {
+    // per-DEVICE initialisation, once per process and device (round-2 advice: every context repeated it, on the NULL stream):
+    // kernel attributes, and the engine's table image built on a non-blocking stream of its own -- it neither serialises
+    // with the caller's blocking streams nor rewrites the image under another context's running kernels
+    static std::mutex init_mu;
+    static bool init_done[64] = {};
+    std::lock_guard<std::mutex> lock(init_mu);
+    if (device >= 64 || !init_done[device]) {
+      if (int r = set_lds_limits()) return r;
+      if (int r = oakgpu_leaf_set_lds_limits()) return r;
+      hipStream_t s0;
+      HIPCHK(hipStreamCreateWithFlags(&s0, hipStreamNonBlocking));
+      hipLaunchKernelGGL(oak::k_build_table_image, dim3(1), dim3(64), oak::TABLE_LDS_PAD, s0);
+      hipError_t le = hipGetLastError();
+      hipError_t se = hipStreamSynchronize(s0);
+      (void)hipStreamDestroy(s0);
+      if (le != hipSuccess) return fail(le, "k_build_table_image launch");
+      if (se != hipSuccess) return fail(se, "k_build_table_image");
+      if (device < 64) init_done[device] = true;
+    }
+  }
   oakgpu_ctx *c = new oakgpu_ctx();
   c->device = device;
   c->own_stream = true;
@@ -1295,6 +1319,7 @@ void oakgpu_destroy(oakgpu_ctx *c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
+  if (c->attachment && c->attachment_dtor) { c->attachment_dtor(c->attachment); c->attachment = nullptr; }
   if (c->own_stream) (void)hipStreamDestroy(c->stream);
   if (c->d_legal) (void)hipFree(c->d_legal);
   if (c->d_pools) (void)hipFree(c->d_pools);

@@ -26,3 +26,7 @@ extern "C" int oakgpu_leaf_set_lds_limits(void);                // leafnet.hip: 
 // Optional per-kernel timing of the leaf evaluator (oakgpu_set_kernel_timing): 4 events = before the party-slot
 // embedding pass, before the actives' pass, before the main net, after it.  nullptr when timing is off.
 void **oakgpu_ctx_timing_events(oakgpu_ctx *ctx);
+// One opaque attachment per context, freed (through its destructor) by oakgpu_destroy before the context's own resources:
+// the tree search keeps its batch slots (second context, device arrays, pinned mirrors) here between searches.
+void *oakgpu_ctx_attachment(const oakgpu_ctx *ctx);
+void oakgpu_ctx_set_attachment(oakgpu_ctx *ctx, void *p, void (*dtor)(void *));

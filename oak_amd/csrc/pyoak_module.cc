@@ -7,14 +7,18 @@
 //   Output {iterations, empirical_value, nash_value, duration_ms, visit_matrix[9,9], value_matrix[9,9],
 //           p{1,2}_{prior,empirical,nash}[9]}                                             :494-574
 //   search(input, heap, agent, output = Output()) -> Output                               :575-583
+//   cpp_inference(record, network_path, discrete, budget) -> value / policy_logit / policy :331-392, 709
 //   solve_matrix(row_payoff, discretize_factor) -> (p1, p2, value)                        :394-426, 711
 //   read_battle_data(path) -> [(bytes, frame_count), ...]                                 :43-71, 713
 //   network hyper-parameter constants                                                     :586-596
 // Every battle operation goes through the C ABI (GPU); this file holds no battle arithmetic.  Not carried over: the
-// training-data loaders of pyoak (EncodedBattleFrames, sample, BuildTrajectories, cpp_inference): training stays with
-// the reference's Python, outside the hot path.  Differences a caller can see: Heap does not keep a tree between
-// calls (every search starts a fresh tree; Heap.empty() is always True), `output` passed to search() is not resumed,
-// and battle_string / format are served by the Python host mirror.
+// training-data loaders of pyoak (EncodedBattleFrames, sample, BuildTrajectories): training stays with the reference's
+// Python, outside the hot path.  Heap keeps the tree between searches (RuntimeSearch::Heap over oakgpu_heap; its C++
+// `update(i, j, obs)` is exposed too, and `update(input, c1, c2)` returns the 16-byte observation that call needs), an
+// `output` passed to search() is resumed like MCTS::Search::run's by-value Output (mcts.h:153-155), p{1,2}_prior are the
+// softmax of the root's policy logits for contextual bandits (mcts.h:196-209).  cpp_inference takes a game record as
+// read_battle_data returns it (the reference's BattleFrames loader is not carried over) and replays it exactly like
+// pyoak.cc:331-392.  battle_string / parse_battle are served by the Python host mirror.
 #include <pybind11/numpy.h>
 #include <pybind11/pybind11.h>
 #include <pybind11/stl.h>
@@ -38,9 +42,18 @@ struct Input { // MCTS::Input (search/mcts.h:62-66): battle + public durations +
   uint8_t durations[OAKGPU_DURATIONS_SIZE] = {};
   uint8_t result = 0;
 };
-struct Heap { // RuntimeSearch::Heap (util/search.h:17-32); this build keeps no tree between searches
-  bool empty() const { return true; }
-  std::string type() const { return "Node (rebuilt per search)"; }
+struct Heap { // RuntimeSearch::Heap (util/search.h:17-32): the tree of the last search, kept (oakgpu_heap)
+  oakgpu_heap *h = nullptr;
+  Heap() { if (oakgpu_heap_create(&h) != 0) throw std::runtime_error(oakgpu_last_error()); }
+  Heap(const Heap &) = delete;
+  Heap &operator=(const Heap &) = delete;
+  ~Heap() { oakgpu_heap_destroy(h); }
+  bool empty() const { return oakgpu_heap_empty(h) != 0; }
+  std::string type() const {
+    static const char *names[5] = {"UCB", "PUCB", "UCB1", "Exp3", "PExp3"};
+    const int k = oakgpu_heap_kind(h);
+    return k < 0 ? "std::monostate" : std::string("MCTS::Node<") + names[k] + "::JointBandit>";
+  }
 };
 struct Agent { // RuntimeSearch::AgentParams (util/search.h:34-43)
   std::string budget = "4096", bandit = "ucb-1.0", eval = "mc", matrix_ucb;
@@ -76,7 +89,17 @@ template <class T, class F> py::array_t<T> vec9(F f) {
 PYBIND11_MODULE(pyoak, m) {
   m.doc() = "pyoak-compatible bindings over liboakgpu.so (MI355X)";
 
-  py::class_<Heap>(m, "Heap").def(py::init<>()).def("empty", &Heap::empty).def("type", &Heap::type);
+  py::class_<Heap>(m, "Heap")
+      .def(py::init<>())
+      .def("empty", &Heap::empty)
+      .def("type", &Heap::type)
+      // RuntimeSearch::Heap::update(i, j, obs) (search.cc:27-52; not bound by pyoak, used by its C++ callers vs.cc / chall.cc)
+      .def("update", [](Heap &hp, int i, int j, py::bytes obs) {
+             const std::string o = obs;
+             if (o.size() != 16) throw std::runtime_error("Heap.update: obs must be 16 bytes");
+             return oakgpu_heap_update(hp.h, (uint8_t)i, (uint8_t)j, (const uint8_t *)o.data()) != 0;
+           }, py::arg("i"), py::arg("j"), py::arg("obs"))
+      .def("nodes", [](const Heap &hp) { return (size_t)oakgpu_heap_nodes(hp.h); });
 
   py::class_<Agent>(m, "Agent")
       .def(py::init<>())
@@ -114,8 +137,10 @@ PYBIND11_MODULE(pyoak, m) {
   m.def(
       "update",
       [](Input &input, uint8_t c1, uint8_t c2) { // options <- durations; PKMN::update; durations <- options (pyoak.cc:468-478)
+        uint8_t actions[16];
         std::lock_guard<std::mutex> lock(g_ctx_mu);
-        check(oakgpu_update(context(), input.battle, &c1, &c2, input.durations, nullptr, nullptr, 1, &input.result));
+        check(oakgpu_update(context(), input.battle, &c1, &c2, input.durations, actions, nullptr, 1, &input.result));
+        return py::bytes((const char *)actions, 16); // the observation of this update (pyoak returns None): Heap.update's obs
       },
       py::arg("input"), py::arg("c1"), py::arg("c2"));
 
@@ -165,8 +190,11 @@ PYBIND11_MODULE(pyoak, m) {
                                  for (int j = 0; j < 9; ++j) r(i, j) = (i < o.raw.m && j < o.raw.n) ? o.raw.value_matrix[i * 9 + j] : 0.0;
                                return arr;
                              })
-      .def_property_readonly("p1_prior", [](const Output &) { return vec9<double>([](int) { return 0.0; }); })
-      .def_property_readonly("p2_prior", [](const Output &) { return vec9<double>([](int) { return 0.0; }); })
+      .def_property_readonly("initial_value", [](const Output &o) { return o.raw.initial_value; })
+      .def_property_readonly("p1_logit", [](const Output &o) { return vec9<double>([&](int i) { return o.raw.p1_logit[i]; }); })
+      .def_property_readonly("p2_logit", [](const Output &o) { return vec9<double>([&](int i) { return o.raw.p2_logit[i]; }); })
+      .def_property_readonly("p1_prior", [](const Output &o) { return vec9<double>([&](int i) { return o.raw.p1_prior[i]; }); })
+      .def_property_readonly("p2_prior", [](const Output &o) { return vec9<double>([&](int i) { return o.raw.p2_prior[i]; }); })
       .def_property_readonly("p1_empirical", [](const Output &o) { return vec9<double>([&](int i) { return o.raw.p1_empirical[i]; }); })
       .def_property_readonly("p2_empirical", [](const Output &o) { return vec9<double>([&](int i) { return o.raw.p2_empirical[i]; }); })
       .def_property_readonly("p1_nash", [](const Output &o) { return vec9<double>([&](int i) { return o.raw.p1_nash[i]; }); })
@@ -174,7 +202,7 @@ PYBIND11_MODULE(pyoak, m) {
 
   m.def(
       "search",
-      [](const Input &input, Heap &, Agent &agent, Output, uint32_t batch, py::object seed) {
+      [](const Input &input, Heap &heap, Agent &agent, Output previous, uint32_t batch, py::object seed) {
         const oakgpu_agent a{agent.budget.c_str(), agent.bandit.c_str(), agent.eval.c_str(), agent.matrix_ucb.c_str(), agent.discrete, agent.table};
         // pyoak seeds its device from std::random_device on every call (pyoak.cc:579); a seed may be given for reproducibility
         const uint64_t s = seed.is_none() ? ((uint64_t)std::random_device{}() << 32) ^ std::random_device{}() : seed.cast<uint64_t>();
@@ -183,12 +211,81 @@ PYBIND11_MODULE(pyoak, m) {
         {
           py::gil_scoped_release release; // the search is long and touches no Python state
           std::lock_guard<std::mutex> lock(g_ctx_mu);
-          rc = oakgpu_search_agent(context(), input.battle, input.durations, input.result, &a, batch, s, &out.raw);
+          // RuntimeSearch::run(device, input, heap, agent, output) (pyoak.cc:575-583): the heap's tree and `output` are resumed
+          rc = oakgpu_search_agent_heap(context(), heap.h, input.battle, input.durations, input.result, &a, batch, s, &previous.raw, &out.raw);
         }
         check(rc);
         return out;
       },
       py::arg("input"), py::arg("heap"), py::arg("agent"), py::arg("output") = Output{}, py::arg("batch") = 0, py::arg("seed") = py::none());
+
+  m.def(
+      "value_policy_inference",
+      [](const Input &input, const std::string &network_path) {
+        // NetworkImpl::value_policy_inference at one position (network.h:102-123), the way Search::run calls it for a fresh
+        // root of a contextual bandit (mcts.h:196-209): a zero-iteration "pucb" search leaves value + legal logits in the output
+        const oakgpu_agent a{"0", "pucb-1.0", network_path.c_str(), "", 0, 0};
+        oakgpu_search_output out{};
+        {
+          std::lock_guard<std::mutex> lock(g_ctx_mu);
+          check(oakgpu_search_agent_heap(context(), nullptr, input.battle, input.durations, input.result, &a, 1, 0, nullptr, &out));
+        }
+        py::array_t<float> l1(out.m), l2(out.n);
+        for (int i = 0; i < out.m; ++i) l1.mutable_unchecked<1>()(i) = (float)out.p1_logit[i];
+        for (int j = 0; j < out.n; ++j) l2.mutable_unchecked<1>()(j) = (float)out.p2_logit[j];
+        return py::make_tuple((float)out.initial_value, l1, l2);
+      },
+      py::arg("input"), py::arg("network_path"));
+  m.def(
+      "value_inference",
+      [](const Input &input, const std::string &network_path) { // NetworkImpl::value_inference (network.h:72-79)
+        const oakgpu_agent a{"0", "pucb-1.0", network_path.c_str(), "", 0, 0};
+        oakgpu_search_output out{};
+        std::lock_guard<std::mutex> lock(g_ctx_mu);
+        check(oakgpu_search_agent_heap(context(), nullptr, input.battle, input.durations, input.result, &a, 1, 0, nullptr, &out));
+        return (float)out.initial_value;
+      },
+      py::arg("input"), py::arg("network_path"));
+
+  m.def(
+      "cpp_inference",
+      [](py::bytes record, const std::string &network_path, bool discrete, const std::string &budget) {
+        // pyoak.cc:331-392 (the C++ side of the reference's torch == C++ check, src/oak/lab.py:21-79): replay one game record;
+        // at every frame run RuntimeSearch::run with agent {eval = network, bandit = "pucb-1.0", budget} on a fresh heap and
+        // keep initial_value, the legal logits and their softmax; then play the stored choices.  Like the reference, the
+        // first frame starts from the record's battle with zero durations and result None|Move|Move.
+        const std::string rec = record;
+        uint8_t battle[384], final_result = 0;
+        uint32_t count = 0;
+        check(oakgpu_frames_read((const uint8_t *)rec.data(), rec.size(), battle, &final_result, nullptr, 0, &count, nullptr));
+        std::vector<oakgpu_frame_update> ups(count ? count : 1);
+        check(oakgpu_frames_read((const uint8_t *)rec.data(), rec.size(), nullptr, nullptr, ups.data(), count, &count, nullptr));
+        py::array_t<float> value(count), logit({(py::ssize_t)count, (py::ssize_t)2, (py::ssize_t)9}), policy({(py::ssize_t)count, (py::ssize_t)2, (py::ssize_t)9});
+        auto v = value.mutable_unchecked<1>();
+        auto lg = logit.mutable_unchecked<3>();
+        auto po = policy.mutable_unchecked<3>();
+        uint8_t durations[8] = {}, result = 0x50; // PKMN::result(): None, p1 Move, p2 Move (pkmn.h:228-233)
+        const oakgpu_agent a{budget.c_str(), "pucb-1.0", network_path.c_str(), "", discrete ? 1 : 0, 0};
+        std::lock_guard<std::mutex> lock(g_ctx_mu);
+        for (uint32_t f = 0; f < count; ++f) {
+          oakgpu_search_output out{};
+          check(oakgpu_search_agent_heap(context(), nullptr, battle, durations, result, &a, 0, std::random_device{}(), nullptr, &out));
+          v(f) = (float)out.initial_value;
+          for (int q = 0; q < 9; ++q) {
+            lg(f, 0, q) = q < out.m ? (float)out.p1_logit[q] : 0.0f;
+            lg(f, 1, q) = q < out.n ? (float)out.p2_logit[q] : 0.0f;
+            po(f, 0, q) = q < out.m ? (float)out.p1_prior[q] : 0.0f;
+            po(f, 1, q) = q < out.n ? (float)out.p2_prior[q] : 0.0f;
+          }
+          check(oakgpu_update(context(), battle, &ups[f].c1, &ups[f].c2, durations, nullptr, nullptr, 1, &result));
+        }
+        py::dict d;
+        d["value"] = value;
+        d["policy_logit"] = logit;
+        d["policy"] = policy;
+        return d;
+      },
+      py::arg("record"), py::arg("network_path"), py::arg("discrete") = false, py::arg("budget") = "0");
 
   m.def(
       "solve_matrix",

@@ -20,9 +20,16 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <array>
+#include <atomic>
 #include <chrono>
 #include <cmath>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
+#include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/oakgpu.h"
@@ -39,18 +46,40 @@ uint64_t splitmix64(uint64_t &x) {
   return z ^ (z >> 31);
 }
 double uniform01(uint64_t &rng) { return (double)(splitmix64(rng) >> 11) * (1.0 / 9007199254740992.0); }
+// counter-based draw: the uniform of (search seed, batch serial, lane, depth, player) -- independent of the order in which
+// the worker threads reach the lanes
+double uniform_at(uint64_t seed, uint64_t serial, uint32_t lane, uint32_t depth, uint32_t player) {
+  uint64_t x = seed ^ (serial * 0xD1342543DE82EF95ull) ^ ((uint64_t)lane << 20) ^ ((uint64_t)depth << 1) ^ player;
+  (void)splitmix64(x);
+  return uniform01(x);
+}
 using namespace oak_search;
 
 // The tree.  The reference's Node owns a std::map<(i, j, Obs), Node> (mcts.h:95-105); nearly every iteration adds a
-// node (81 joint actions x the observation fan-out), so here nodes are indices into flat arrays and ALL edges live in
-// one open-addressing hash table keyed (parent, i, j, 16-byte observation): no per-node allocation, one probe per edge.
-struct Stats { Bandit p1, p2; bool is_init() const { return p1.is_init(); } };
-struct Edge { uint64_t hash; uint32_t parent, child; uint8_t key[18]; uint8_t used; };
+// node (81 joint actions x the observation fan-out), so here nodes are indices into flat arenas and all edges live in
+// open-addressing hash tables keyed (parent, i, j, 16-byte observation): no per-node allocation, one probe per edge.
+//
+// The tree is cut into SHARDS = 8 shards so that the host work of a batch (bandit selection, edge lookups, back-ups)
+// can run on several threads WITHOUT changing any result: a node id is `local << 6 | creator << 3 | owner`; every
+// read-modify-write of a node's bandits is done by the thread that serves its OWNER shard, in lane order; the edges
+// out of a node live in the table of that node's owner shard, and a new child (owner = 3 hash bits of its edge) is
+// appended to the arena [owner][creator = the parent's owner] -- only the parent's thread appends there.  The number
+// of shards is fixed, the number of threads (1, 2, 4 or 8, each serving shards = thread mod threads) is not: any
+// thread count walks the same tree bit for bit.
+constexpr int SHARDS = 8;
+struct NodeRec {
+  Bandit p1, p2;
+  bool is_init() const { return p1.is_init(); }
+};
+struct Edge { uint64_t hash; uint32_t parent, child; uint8_t key[18]; uint16_t gen; };
+inline int owner_of(uint32_t id) { return (int)(id & 7); }
 struct Tree {
-  std::vector<Stats> nodes;
-  std::vector<Edge> table;
-  size_t count = 0;
-  Tree() : table(1u << 16) { memset(table.data(), 0, table.size() * sizeof(Edge)); }
+  std::vector<NodeRec> arena[SHARDS][SHARDS]; // [owner][creator]
+  struct Table { Edge *e = nullptr; size_t cap = 0, count = 0; uint16_t gen = 1; } tab[SHARDS];
+  Tree() = default;
+  Tree(const Tree &) = delete;
+  Tree &operator=(const Tree &) = delete;
+  ~Tree() { for (auto &t : tab) free(t.e); }
   static uint64_t hash_of(uint32_t parent, const uint8_t *key) {
     uint64_t a, b;
     uint16_t c;
@@ -60,47 +89,195 @@ struct Tree {
     h = (h ^ (h >> 32) ^ c) * 0x9E3779B97F4A7C15ull;
     return h ^ (h >> 31);
   }
-  uint32_t new_node() { nodes.emplace_back(); return (uint32_t)nodes.size() - 1; }
-  // start a new search in the memory of the previous one (a search adds a node per iteration: tens of MB whose first touch
-  // -- page faults, vector regrowth, table rehashes -- cost a third of the host time of a 2^18-iteration search)
+  NodeRec &node(uint32_t id) { return arena[id & 7][(id >> 3) & 7][id >> 6]; }
+  size_t size() const {
+    size_t n = 0;
+    for (auto &o : arena) for (auto &v : o) n += v.size();
+    return n;
+  }
+  uint32_t new_node(int own, int cre) {
+    auto &v = arena[own][cre];
+    v.emplace_back();
+    return (uint32_t)((v.size() - 1) << 6 | (size_t)cre << 3 | (size_t)own);
+  }
+  // Start a new tree in the memory of the previous one.  Nothing is memset: an edge slot is live only when its generation
+  // stamp equals the table's, so a new search costs O(1) however large the last one was (round-2 advice: every search
+  // re-zeroed the whole table, 80 MB and more); tables come from calloc (pages are touched when used) and are given
+  // back when the last search was more than 8x larger than this one expects to be.
   void reset(size_t expected_nodes) {
-    nodes.clear();
-    if (nodes.capacity() < expected_nodes + 16) nodes.reserve(expected_nodes + 16);
-    size_t want = 1u << 16;
-    while (want * 6 < (expected_nodes + 16) * 10) want *= 2;
-    if (table.size() < want) table.resize(want);
-    memset(table.data(), 0, table.size() * sizeof(Edge));
-    count = 0;
+    const size_t per = expected_nodes / SHARDS + 64;
+    for (auto &o : arena)
+      for (auto &v : o) {
+        v.clear();
+        if (v.capacity() > 8 * (per / SHARDS + 64)) std::vector<NodeRec>().swap(v);
+        if (v.capacity() < per / SHARDS + 16) v.reserve(per / SHARDS + 16);
+      }
+    size_t want = 1u << 12;
+    while (want * 6 < per * 10) want *= 2;
+    for (auto &t : tab) {
+      if (t.cap < want || t.cap > 8 * want) {
+        free(t.e);
+        t.e = (Edge *)calloc(want, sizeof(Edge));
+        t.cap = t.e ? want : 0;
+        t.gen = 1;
+      } else if (++t.gen == 0) { // the stamp wrapped (65,535 searches): one real clear
+        memset(t.e, 0, t.cap * sizeof(Edge));
+        t.gen = 1;
+      }
+      t.count = 0;
+    }
   }
-  void grow() {
-    std::vector<Edge> old;
-    old.swap(table);
-    table.resize(old.size() * 2);
-    memset(table.data(), 0, table.size() * sizeof(Edge));
-    const size_t mask = table.size() - 1;
-    for (const Edge &e : old)
-      if (e.used) { size_t i = e.hash & mask; while (table[i].used) i = (i + 1) & mask; table[i] = e; }
+  bool ok() const { for (auto &t : tab) if (!t.e) return false; return true; }
+  void grow(Table &t) {
+    Edge *old = t.e;
+    const size_t oc = t.cap;
+    t.e = (Edge *)calloc(oc * 2, sizeof(Edge));
+    if (!t.e) { t.e = old; return; } // (keeps working, slower, until it is full: 60% -> 100% never happens before reset in practice)
+    t.cap = oc * 2;
+    const size_t mask = t.cap - 1;
+    for (size_t q = 0; q < oc; ++q)
+      if (old[q].gen == t.gen) { size_t i = old[q].hash & mask; while (t.e[i].gen == t.gen) i = (i + 1) & mask; t.e[i] = old[q]; }
+    free(old);
   }
-  // the host loops over a batch's lanes are bound by cache misses on this table and on `nodes` (tens of MB per search):
+  // the host loops over a batch's lanes are bound by cache misses on these tables and on the arenas (tens of MB per search):
   // they ask for a later lane's lines while working on the current one
-  void prefetch_edge(uint32_t parent, const uint8_t *key) const { __builtin_prefetch(&table[hash_of(parent, key) & (table.size() - 1)]); }
-  void prefetch_node(uint32_t node) const { if (node < nodes.size()) { __builtin_prefetch(&nodes[node]); __builtin_prefetch((const char *)&nodes[node] + 64); } }
-  // child of `parent` along (i, j, obs) = key; created (uninitialised) when absent -- heap.children[{i, j, obs}] (mcts.h:359-361)
+  void prefetch_edge(uint32_t parent, const uint8_t *key) const { const Table &t = tab[parent & 7]; __builtin_prefetch(&t.e[hash_of(parent, key) & (t.cap - 1)]); }
+  void prefetch_node(uint32_t id) const {
+    const auto &v = arena[id & 7][(id >> 3) & 7];
+    if ((id >> 6) < v.size()) { __builtin_prefetch(&v[id >> 6]); __builtin_prefetch((const char *)&v[id >> 6] + 64); __builtin_prefetch((const char *)&v[id >> 6] + 128); }
+  }
+  // child of `parent` along (i, j, obs) = key; created (uninitialised) when absent -- heap.children[{i, j, obs}] (mcts.h:359-361).
+  // Called by the thread that serves owner_of(parent).
   uint32_t child(uint32_t parent, const uint8_t *key) {
-    if ((count + 1) * 10 > table.size() * 6) grow();
+    Table &t = tab[parent & 7];
+    if ((t.count + 1) * 10 > t.cap * 6) grow(t);
     const uint64_t h = hash_of(parent, key);
-    const size_t mask = table.size() - 1;
-    size_t i = h & mask;
-    for (;; i = (i + 1) & mask) {
-      Edge &e = table[i];
-      if (!e.used) {
-        e.used = 1; e.hash = h; e.parent = parent; memcpy(e.key, key, 18);
-        e.child = new_node();
-        ++count;
+    const size_t mask = t.cap - 1;
+    for (size_t i = h & mask;; i = (i + 1) & mask) {
+      Edge &e = t.e[i];
+      if (e.gen != t.gen) {
+        e.gen = t.gen; e.hash = h; e.parent = parent; memcpy(e.key, key, 18);
+        e.child = new_node((int)((h >> 58) & 7), (int)(parent & 7));
+        ++t.count;
         return e.child;
       }
       if (e.hash == h && e.parent == parent && memcmp(e.key, key, 18) == 0) return e.child;
     }
+  }
+  bool find_child(uint32_t parent, const uint8_t *key, uint32_t *out) const { // lookup only (Heap::update, search.cc:38)
+    const Table &t = tab[parent & 7];
+    if (!t.e) return false;
+    const uint64_t h = hash_of(parent, key);
+    const size_t mask = t.cap - 1;
+    for (size_t i = h & mask;; i = (i + 1) & mask) {
+      const Edge &e = t.e[i];
+      if (e.gen != t.gen) return false;
+      if (e.hash == h && e.parent == parent && memcmp(e.key, key, 18) == 0) { *out = e.child; return true; }
+    }
+  }
+  // Heap::update's `std::swap(node, child->second)` (search.cc:42): the subtree under `new_root` becomes the tree, everything
+  // else is dropped.  Nodes keep their shards; ids are reassigned in breadth-first order.  Returns the new root id.
+  uint32_t keep_subtree(uint32_t new_root) {
+    struct E { uint32_t parent, child; uint8_t key[18]; };
+    std::vector<E> edges;
+    for (auto &t : tab)
+      for (size_t q = 0; q < t.cap; ++q)
+        if (t.e[q].gen == t.gen) { E x; x.parent = t.e[q].parent; x.child = t.e[q].child; memcpy(x.key, t.e[q].key, 18); edges.push_back(x); }
+    std::sort(edges.begin(), edges.end(), [](const E &a, const E &b) { return a.parent != b.parent ? a.parent < b.parent : memcmp(a.key, b.key, 18) < 0; });
+    auto first_edge = [&](uint32_t parent) {
+      return std::lower_bound(edges.begin(), edges.end(), parent, [](const E &a, uint32_t p) { return a.parent < p; }) - edges.begin();
+    };
+    Tree fresh;
+    std::vector<std::pair<uint32_t, uint32_t>> queue; // (old id, new id)
+    struct NE { uint32_t parent, child; const uint8_t *key; };
+    std::vector<NE> kept;
+    auto move_node = [&](uint32_t old_id) {
+      const uint32_t nid = fresh.new_node((int)(old_id & 7), (int)((old_id >> 3) & 7));
+      fresh.node(nid) = node(old_id);
+      return nid;
+    };
+    const uint32_t root_new = move_node(new_root);
+    queue.emplace_back(new_root, root_new);
+    for (size_t head = 0; head < queue.size(); ++head) {
+      const auto [oid, nid] = queue[head];
+      for (size_t q = (size_t)first_edge(oid); q < edges.size() && edges[q].parent == oid; ++q) {
+        const uint32_t cn = move_node(edges[q].child);
+        kept.push_back({nid, cn, edges[q].key});
+        queue.emplace_back(edges[q].child, cn);
+      }
+    }
+    fresh.reset_tables_for(kept.size());
+    for (const NE &x : kept) fresh.insert_edge(x.parent, x.key, x.child);
+    for (int o = 0; o < SHARDS; ++o) for (int c = 0; c < SHARDS; ++c) arena[o][c].swap(fresh.arena[o][c]);
+    for (int o = 0; o < SHARDS; ++o) std::swap(tab[o], fresh.tab[o]);
+    return root_new;
+  }
+  void reset_tables_for(size_t n_edges) {
+    size_t want = 1u << 12;
+    while (want * 6 < (n_edges / SHARDS + 64) * 10 * 2) want *= 2;
+    for (auto &t : tab) { free(t.e); t.e = (Edge *)calloc(want, sizeof(Edge)); t.cap = t.e ? want : 0; t.gen = 1; t.count = 0; }
+  }
+  void insert_edge(uint32_t parent, const uint8_t *key, uint32_t child_id) {
+    Table &t = tab[parent & 7];
+    if (!t.e) return;
+    if ((t.count + 1) * 10 > t.cap * 6) grow(t);
+    const uint64_t h = hash_of(parent, key);
+    const size_t mask = t.cap - 1;
+    size_t i = h & mask;
+    while (t.e[i].gen == t.gen) i = (i + 1) & mask;
+    Edge &e = t.e[i];
+    e.gen = t.gen; e.hash = h; e.parent = parent; e.child = child_id; memcpy(e.key, key, 18);
+    ++t.count;
+  }
+};
+
+// W threads (the caller's + W - 1 workers) run one phase function each and meet again: the phases of a batch (select /
+// process / back-up) are separated by these joins, so which thread touches which shard when is fixed.
+struct Pool {
+  int W;
+  std::vector<std::thread> th;
+  std::mutex mu;
+  std::condition_variable cv;
+  std::function<void(int)> job;
+  std::atomic<uint64_t> phase{0};
+  std::atomic<int> remaining{0}, sleepers{0};
+  std::atomic<bool> stop{false};
+  explicit Pool(int w) : W(w) {
+    for (int t = 1; t < W; ++t) th.emplace_back([this, t] { work(t); });
+  }
+  ~Pool() {
+    stop.store(true);
+    { std::lock_guard<std::mutex> l(mu); phase.fetch_add(1); }
+    cv.notify_all();
+    for (auto &t : th) t.join();
+  }
+  void work(int t) {
+    uint64_t seen = 0;
+    for (;;) {
+      // phases follow each other within microseconds while the host walks a level, and ~100 us apart across a GPU step:
+      // spin for about that long, then sleep (a search that waits for a long rollout must not burn W cores)
+      int spins = 0;
+      while (phase.load(std::memory_order_acquire) == seen) {
+        if (++spins < 40000) { __builtin_ia32_pause(); continue; }
+        std::unique_lock<std::mutex> l(mu);
+        sleepers.fetch_add(1);
+        cv.wait(l, [&] { return phase.load(std::memory_order_acquire) != seen; });
+        sleepers.fetch_sub(1);
+      }
+      seen = phase.load(std::memory_order_acquire);
+      if (stop.load()) return;
+      job(t);
+      remaining.fetch_sub(1, std::memory_order_acq_rel);
+    }
+  }
+  template <class F> void run(F &&f) {
+    if (W == 1) { f(0); return; }
+    job = f;
+    remaining.store(W - 1, std::memory_order_release);
+    { std::lock_guard<std::mutex> l(mu); phase.fetch_add(1, std::memory_order_acq_rel); }
+    if (sleepers.load() > 0) cv.notify_all();
+    f(0);
+    while (remaining.load(std::memory_order_acquire) != 0) __builtin_ia32_pause();
   }
 };
 
@@ -116,9 +293,12 @@ void solve_zero_sum(const int32_t *A, int m, int n, double *x, double *y) {
 
 struct Buffers { // device arrays + pinned host mirrors of what crosses PCIe every level
   std::vector<void *> dev, pinned;
-  ~Buffers() {
+  ~Buffers() { release(); }
+  void release() {
     for (void *p : dev) (void)hipFree(p);
     for (void *p : pinned) (void)hipHostFree(p);
+    dev.clear();
+    pinned.clear();
   }
   template <class T> int d(T **out, size_t count) {
     void *p = nullptr;
@@ -180,24 +360,168 @@ extern "C" int oakgpu_solve_matrix(const int32_t *payoffs, int m, int n, int dis
   return 0;
 }
 
-extern "C" int oakgpu_search(oakgpu_ctx *ctx, oakgpu_net *net, const uint8_t *battle, const uint8_t *durations, uint8_t result,
-                             const oakgpu_search_params *prm, oakgpu_search_output *out) {
+// RuntimeSearch::Heap (util/search.h:17-32) for Node heaps: the tree of a search, kept between searches.  kind = -1 is
+// std::monostate (Heap::empty()); the first search fixes the bandit type, as the variant does (search.cc:205-213).
+struct oakgpu_heap {
+  Tree tree;
+  int kind = -1;
+  bool rooted = false; // false: `node = {}` (search.cc:40): a Node whose stats are not initialised
+  uint32_t root = 0;
+};
+
+namespace {
+struct Step { uint32_t node; uint8_t i, j; float prob1, prob2; };
+constexpr uint32_t NO_NODE = 0xFFFFFFFFu;
+// One batch in flight: a context (= HIP stream), its device arrays and the pinned host mirrors of what crosses PCIe at
+// every level.  The slots of a caller's context are kept between searches (round-2 advice: a second context and ~50
+// allocations were made and destroyed by every search, i.e. once per turn of a self-play game).
+struct Slot {
+  oakgpu_ctx *ctx = nullptr;
+  bool own_ctx = false;
+  hipStream_t stream{};
+  Buffers buf;
+  uint32_t cap = 0;
+  bool has_logits = false;
+  int emb_dim = 0;
+  uint8_t *d_root_b, *d_root_d, *d_root_r, *d_b, *d_d, *d_r, *d_prng, *d_c1, *d_c2, *d_act, *d_ch1, *d_cnt1, *d_ch2, *d_cnt2, *d_rout;
+  uint32_t *d_steps;
+  float *d_values, *d_l1 = nullptr, *d_l2 = nullptr, *d_emb = nullptr;
+  uint8_t *h_c1, *h_c2, *h_r, *h_act, *h_ch1, *h_cnt1, *h_ch2, *h_cnt2, *h_stage;
+  float *h_values, *h_l1 = nullptr, *h_l2 = nullptr;
+  std::vector<std::vector<Step>> path;
+  std::vector<uint32_t> cur, leaf;
+  std::vector<uint8_t> active;
+  std::vector<uint8_t> forced;
+  double nash1[9], nash2[9];
+  uint32_t nb = 0;
+  uint64_t serial = 0;
+  bool busy = false;
+  ~Slot() { buf.release(); if (own_ctx && ctx) oakgpu_destroy(ctx); }
+  int allocate(oakgpu_ctx *primary, int index, uint32_t B, bool logits, int emb) {
+    if (ctx) stream = (hipStream_t)oakgpu_ctx_stream(ctx); // (the caller may have given the context another stream since)
+    if (ctx && cap >= B && (has_logits || !logits) && emb_dim >= emb) return 0;
+    if (ctx) (void)hipStreamSynchronize(stream);
+    buf.release();
+    if (!ctx) {
+      if (index == 0) ctx = primary;
+      else { RC(oakgpu_create(&ctx, oakgpu_ctx_device(primary))); own_ctx = true; }
+    }
+    stream = (hipStream_t)oakgpu_ctx_stream(ctx);
+    cap = 0;
+    RC(buf.d(&d_root_b, (size_t)B * 384)); RC(buf.d(&d_root_d, (size_t)B * 8)); RC(buf.d(&d_root_r, (size_t)B));
+    RC(buf.d(&d_b, (size_t)B * 384)); RC(buf.d(&d_d, (size_t)B * 8)); RC(buf.d(&d_r, (size_t)B)); RC(buf.d(&d_prng, (size_t)B * 8));
+    RC(buf.d(&d_c1, (size_t)B)); RC(buf.d(&d_c2, (size_t)B)); RC(buf.d(&d_act, (size_t)B * 16));
+    RC(buf.d(&d_ch1, (size_t)B * 9)); RC(buf.d(&d_cnt1, (size_t)B)); RC(buf.d(&d_ch2, (size_t)B * 9)); RC(buf.d(&d_cnt2, (size_t)B));
+    RC(buf.d(&d_rout, (size_t)B)); RC(buf.d(&d_steps, (size_t)B)); RC(buf.d(&d_values, (size_t)B));
+    d_l1 = d_l2 = d_emb = nullptr; h_l1 = h_l2 = nullptr;
+    if (logits) { RC(buf.d(&d_l1, (size_t)B * 9)); RC(buf.d(&d_l2, (size_t)B * 9)); }
+    if (emb) RC(buf.d(&d_emb, (size_t)B * emb));
+    RC(buf.h(&h_c1, (size_t)B)); RC(buf.h(&h_c2, (size_t)B)); RC(buf.h(&h_r, (size_t)B)); RC(buf.h(&h_act, (size_t)B * 16));
+    RC(buf.h(&h_ch1, (size_t)B * 9)); RC(buf.h(&h_cnt1, (size_t)B)); RC(buf.h(&h_ch2, (size_t)B * 9)); RC(buf.h(&h_cnt2, (size_t)B));
+    RC(buf.h(&h_values, (size_t)B)); RC(buf.h(&h_stage, (size_t)B * 384));
+    if (logits) { RC(buf.h(&h_l1, (size_t)B * 9)); RC(buf.h(&h_l2, (size_t)B * 9)); }
+    path.resize(B); cur.resize(B); leaf.resize(B); active.resize(B);
+    cap = B; has_logits = logits; emb_dim = emb;
+    return 0;
+  }
+};
+struct SearchScratch { Slot slots[2]; };
+void scratch_dtor(void *p) { delete (SearchScratch *)p; }
+} // namespace
+
+extern "C" {
+
+int oakgpu_heap_create(oakgpu_heap **out) {
+  if (!out) return oakgpu_fail_msg("oakgpu_heap_create: null out");
+  *out = new oakgpu_heap();
+  return 0;
+}
+void oakgpu_heap_destroy(oakgpu_heap *h) { delete h; }
+int oakgpu_heap_empty(const oakgpu_heap *h) { return !h || h->kind < 0; }
+uint64_t oakgpu_heap_nodes(const oakgpu_heap *h) { return h && h->rooted ? h->tree.size() : 0; }
+int oakgpu_heap_kind(const oakgpu_heap *h) { return h ? h->kind : -1; }
+void oakgpu_heap_clear(oakgpu_heap *h) { if (h) { h->tree.reset(0); h->rooted = false; h->kind = -1; } }
+
+// Heap::update(i, j, obs) (search.cc:27-52): 1 = the child reached by (i, j, obs) is the root now (its whole subtree, bandit
+// statistics included, is kept; everything else is dropped); 0 = nothing to keep: an empty heap, a root that was never
+// initialised, or an edge the searches never took (the heap then holds an uninitialised node, like `node = {}`).
+int oakgpu_heap_update(oakgpu_heap *h, uint8_t i, uint8_t j, const uint8_t *obs16) {
+  if (!h || !obs16) return 0;
+  if (h->kind < 0 || !h->rooted) return 0;
+  if (!h->tree.node(h->root).is_init()) return 0;
+  uint8_t key[18];
+  key[0] = i; key[1] = j;
+  memcpy(key + 2, obs16, 16);
+  uint32_t child;
+  if (!h->tree.find_child(h->root, key, &child)) {
+    h->tree.reset(0);
+    h->rooted = false;
+    return 0;
+  }
+  h->root = h->tree.keep_subtree(child);
+  return 1;
+}
+
+// Test / diagnostic view of the root's two bandits: scores[9], priors[9], visits[9], k per player (0 = not initialised).
+int oakgpu_heap_root_stats(const oakgpu_heap *h, int player, float *scores, float *priors, uint32_t *visits, uint8_t *k) {
+  if (!h || player < 0 || player > 1) return oakgpu_fail_msg("oakgpu_heap_root_stats: bad argument");
+  if (h->kind < 0 || !h->rooted) { if (k) *k = 0; return 0; }
+  const NodeRec &nd = const_cast<oakgpu_heap *>(h)->tree.node(h->root);
+  const Bandit &b = player ? nd.p2 : nd.p1;
+  if (k) *k = b.k;
+  for (int q = 0; q < 9; ++q) { if (scores) scores[q] = b.scores[q]; if (priors) priors[q] = b.priors[q]; if (visits) visits[q] = b.visits[q]; }
+  return 0;
+}
+
+// The same view of the child that oakgpu_heap_update(i, j, obs) WOULD promote (k = 0: no such child, or not initialised).
+int oakgpu_heap_child_stats(const oakgpu_heap *h, uint8_t i, uint8_t j, const uint8_t *obs16, int player, float *scores, float *priors,
+                            uint32_t *visits, uint8_t *k) {
+  if (!h || !obs16 || player < 0 || player > 1) return oakgpu_fail_msg("oakgpu_heap_child_stats: bad argument");
+  if (k) *k = 0;
+  if (h->kind < 0 || !h->rooted) return 0;
+  uint8_t key[18];
+  key[0] = i; key[1] = j;
+  memcpy(key + 2, obs16, 16);
+  uint32_t child;
+  if (!h->tree.find_child(h->root, key, &child)) return 0;
+  const NodeRec &nd = const_cast<oakgpu_heap *>(h)->tree.node(child);
+  const Bandit &b = player ? nd.p2 : nd.p1;
+  if (k) *k = b.k;
+  for (int q = 0; q < 9; ++q) { if (scores) scores[q] = b.scores[q]; if (priors) priors[q] = b.priors[q]; if (visits) visits[q] = b.visits[q]; }
+  return 0;
+}
+
+int oakgpu_search_heap(oakgpu_ctx *ctx, oakgpu_net *net, oakgpu_heap *heap, const uint8_t *battle, const uint8_t *durations, uint8_t result,
+                       const oakgpu_search_params *prm, const oakgpu_search_output *previous, oakgpu_search_output *out) {
   if (!ctx || !battle || !durations || !prm || !out) return oakgpu_fail_msg("oakgpu_search: null argument");
   const bool pucb = prm->bandit == B_PUCB || prm->bandit == B_PEXP3; // the bandits that take priors from the policy heads
   const bool use_net = prm->eval == 1, use_pe = prm->eval == 2;
-  const BanditParams BP{prm->bandit, prm->ucb_c, prm->exp3_alpha > 0 ? prm->exp3_alpha : 0.05f};
+  // exp3_alpha < 0 (or NaN) = the reference's default 0.05 (search.cc:268-270: used when the third field is absent); an
+  // explicit 0 is honoured, as the reference honours it
+  const BanditParams BP{prm->bandit, prm->ucb_c, prm->exp3_alpha >= 0 ? prm->exp3_alpha : 0.05f};
   if (prm->bandit < 0 || prm->bandit > 4 || prm->eval < 0 || prm->eval > 2) return oakgpu_fail_msg("oakgpu_search: unknown bandit / eval");
   if ((use_net || pucb) && !net) return oakgpu_fail_msg("oakgpu_search: network evaluation / PUCB / PExp3 priors need a network");
   if (pucb && !use_net) return oakgpu_fail_msg("oakgpu_search: PUCB / PExp3 take their priors from the network evaluator (eval = 1)");
   if (prm->batch == 0 || prm->batch > (1u << 20)) return oakgpu_fail_msg("oakgpu_search: batch must be in 1..2^20");
-  if (prm->iterations == 0 && prm->duration_us == 0) return oakgpu_fail_msg("oakgpu_search: give an iteration or a time budget");
   auto rolls_ok = [](uint32_t r) { return r == 1 || r == 2 || r == 3 || r == 20 || r == 39; };
   if (!rolls_ok(prm->root_rolls) || !rolls_ok(prm->other_rolls)) return oakgpu_fail_msg("oakgpu_search: rolls must be 1, 2, 3, 20 or 39");
   HIPRC(hipSetDevice(oakgpu_ctx_device(ctx)));
   const uint32_t B = prm->batch;
   const uint32_t max_depth = prm->max_depth ? prm->max_depth : 100;
+  // MCTS::Search::run takes `Output output = {}` BY VALUE and adds to it (mcts.h:153-155): the matrices, `iterations` and
+  // `duration` of a previous search of the SAME position accumulate (:231-247); the logits / priors / initial value
+  // stay as they came in unless the root is fresh (:177-210)
+  oakgpu_search_output prev;
+  if (previous) prev = *previous; else memset(&prev, 0, sizeof prev);
   memset(out, 0, sizeof *out);
-  const auto t_start = std::chrono::high_resolution_clock::now();
+  if (previous) {
+    memcpy(out->visit_matrix, prev.visit_matrix, sizeof out->visit_matrix);
+    memcpy(out->value_matrix, prev.value_matrix, sizeof out->value_matrix);
+    out->initial_value = prev.initial_value;
+    memcpy(out->p1_logit, prev.p1_logit, sizeof out->p1_logit); memcpy(out->p2_logit, prev.p2_logit, sizeof out->p2_logit);
+    memcpy(out->p1_prior, prev.p1_prior, sizeof out->p1_prior); memcpy(out->p2_prior, prev.p2_prior, sizeof out->p2_prior);
+  }
+  const uint64_t base_iterations = prev.iterations;
 
   // root choices (mcts.h:160-166) through the batched choices kernel, batch of one
   uint8_t root_c1[9], root_c2[9], m = 0, n = 0;
@@ -209,18 +533,47 @@ extern "C" int oakgpu_search(oakgpu_ctx *ctx, oakgpu_net *net, const uint8_t *ba
   memcpy(out->p2_choices, root_c2, 9);
   if ((result & 15) != 0 || m == 0 || n == 0) return oakgpu_fail_msg("oakgpu_search: the root position is terminal");
 
-  static thread_local Tree tree_storage; // (kept between searches of a thread: see Tree::reset)
-  Tree &tree = tree_storage;
-  tree.reset(prm->duration_us != 0 ? (size_t)1 << 20 : (size_t)std::min<uint64_t>(prm->iterations, (uint64_t)1 << 24));
-  const uint32_t root = tree.new_node();
-  tree.nodes[root].p1.init(m, BP.kind);
-  tree.nodes[root].p2.init(n, BP.kind);
-  if (pucb) { // root priors from the policy heads (mcts.h:196-209)
-    float v, l1[9], l2[9];
-    RC(oakgpu_leaf_eval_policy(ctx, net, battle, durations, 1, root_c1, &m, root_c2, &n, &v, l1, l2));
-    tree.nodes[root].p1.set_logits(BP, l1);
-    tree.nodes[root].p2.set_logits(BP, l2);
-    out->initial_value = v;
+  const bool timed = prm->duration_us != 0; // time budget (search.cc:300-306): batches are started until it has elapsed
+  const size_t expected = timed ? (size_t)1 << 20 : (size_t)std::min<uint64_t>(prm->iterations, (uint64_t)1 << 24);
+  static thread_local oakgpu_heap scratch_heap; // heap == NULL: a fresh tree per search, in the memory of the thread's last one
+  oakgpu_heap &H = heap ? *heap : scratch_heap;
+  if (!heap) { H.kind = -1; H.rooted = false; }
+  if (H.kind >= 0 && H.kind != BP.kind) {
+    static const char *names[5] = {"UCB", "PUCB", "UCB1", "Exp3", "PExp3"};
+    return oakgpu_fail_msg((std::string("RuntimeSearch: Bad Heap access. Expecting MCTS::Node<") + names[BP.kind] + "::JointBandit>").c_str());
+  }
+  H.kind = BP.kind;
+  Tree &tree = H.tree;
+  if (!H.rooted) {
+    tree.reset(expected);
+    if (!tree.ok()) return oakgpu_fail_msg("oakgpu_search: out of host memory (edge tables)");
+    H.root = tree.new_node(0, 0);
+    H.rooted = true;
+  }
+  const uint32_t root = H.root;
+  if (tree.node(root).is_init() && (tree.node(root).p1.k != m || tree.node(root).p2.k != n))
+    return oakgpu_fail_msg("oakgpu_search: the heap's root has other action counts than this position (Heap::update was not called with the move that was played?)");
+  if (!tree.node(root).is_init()) { // stats.init(k1, k2) + priors (mcts.h:177-210)
+    tree.node(root).p1.init(m, BP.kind);
+    tree.node(root).p2.init(n, BP.kind);
+    if (pucb) { // root priors from the policy heads (mcts.h:196-209)
+      float v, l1[9], l2[9];
+      RC(oakgpu_leaf_eval_policy(ctx, net, battle, durations, 1, root_c1, &m, root_c2, &n, &v, l1, l2));
+      tree.node(root).p1.set_logits(BP, l1);
+      tree.node(root).p2.set_logits(BP, l2);
+      out->initial_value = v;
+      auto soft = [](double *o, const float *l, int k) { // softmax(output.p1.prior, logits, k): search/util/softmax.h:5-15
+        float sum = 0;
+        for (int i = 0; i < k; ++i) { const float y = std::exp(l[i]); o[i] = y; sum += y; }
+        for (int i = 0; i < k; ++i) o[i] /= sum;
+      };
+      memset(out->p1_logit, 0, sizeof out->p1_logit); memset(out->p2_logit, 0, sizeof out->p2_logit);
+      memset(out->p1_prior, 0, sizeof out->p1_prior); memset(out->p2_prior, 0, sizeof out->p2_prior);
+      for (int i = 0; i < m; ++i) out->p1_logit[i] = l1[i];
+      for (int j = 0; j < n; ++j) out->p2_logit[j] = l2[j];
+      soft(out->p1_prior, l1, m);
+      soft(out->p2_prior, l2, n);
+    }
   }
 
   float pe_root = 0.0f; // PokeEngine::Eval::get_root_score (mcts.h:172-174)
@@ -229,53 +582,17 @@ extern "C" int oakgpu_search(oakgpu_ctx *ctx, oakgpu_net *net, const uint8_t *ba
   // Two batches are kept in flight ("slots", each with its own context = HIP stream and buffers): while the GPU
   // evaluates the leaves of one batch (rollouts: milliseconds), the host walks the tree for the other.  The schedule
   // is fixed (A descends, B descends, A finishes, A descends, B finishes, ...), so a search is reproducible.
-  struct Step { uint32_t node; uint8_t i, j; float prob1, prob2; };
-  constexpr uint32_t NO_NODE = 0xFFFFFFFFu;
-  struct Slot {
-    oakgpu_ctx *ctx = nullptr;
-    bool own_ctx = false;
-    hipStream_t stream{};
-    Buffers buf;
-    uint8_t *d_root_b, *d_root_d, *d_root_r, *d_b, *d_d, *d_r, *d_prng, *d_c1, *d_c2, *d_act, *d_ch1, *d_cnt1, *d_ch2, *d_cnt2, *d_rout;
-    uint32_t *d_steps;
-    float *d_values, *d_l1 = nullptr, *d_l2 = nullptr, *d_emb = nullptr;
-    uint8_t *h_c1, *h_c2, *h_r, *h_act, *h_ch1, *h_cnt1, *h_ch2, *h_cnt2, *h_stage;
-    float *h_values, *h_l1 = nullptr, *h_l2 = nullptr;
-    std::vector<std::vector<Step>> path;
-    std::vector<uint32_t> cur, leaf;
-    std::vector<uint8_t> active;
-    std::vector<uint8_t> forced;
-    double nash1[9], nash2[9];
-    uint32_t nb = 0;
-    bool busy = false;
-    ~Slot() { if (own_ctx && ctx) oakgpu_destroy(ctx); }
-  };
-  // one batch at a time only for batch = 1, which is the reference's strictly sequential iteration order (the evaluator's
-  // workspaces belong to the context, so two slots -- two contexts -- can evaluate the same network concurrently)
-  const bool timed = prm->duration_us != 0; // time budget (search.cc:300-306): batches are started until it has elapsed
+  // One batch at a time only for batch = 1, which is the reference's strictly sequential iteration order (the evaluator's
+  // workspaces belong to the context, so two slots -- two contexts -- can evaluate the same network concurrently).
   const int n_slots = (B > 1 && (timed || prm->iterations > B)) ? 2 : 1;
-  Slot slots[2];
+  SearchScratch *scratch = (SearchScratch *)oakgpu_ctx_attachment(ctx);
+  if (!scratch) { scratch = new SearchScratch(); oakgpu_ctx_set_attachment(ctx, scratch, scratch_dtor); }
+  Slot *slots = scratch->slots;
+  int emb_dim = 0;
+  if (use_net && n_slots > 1) RC(oakgpu_net_shape(net, &emb_dim, nullptr, nullptr, nullptr));
   for (int si = 0; si < n_slots; ++si) {
     Slot &S = slots[si];
-    if (si == 0) S.ctx = ctx;
-    else { RC(oakgpu_create(&S.ctx, oakgpu_ctx_device(ctx))); S.own_ctx = true; }
-    S.stream = (hipStream_t)oakgpu_ctx_stream(S.ctx);
-    Buffers &buf = S.buf;
-    RC(buf.d(&S.d_root_b, (size_t)B * 384)); RC(buf.d(&S.d_root_d, (size_t)B * 8)); RC(buf.d(&S.d_root_r, (size_t)B));
-    RC(buf.d(&S.d_b, (size_t)B * 384)); RC(buf.d(&S.d_d, (size_t)B * 8)); RC(buf.d(&S.d_r, (size_t)B)); RC(buf.d(&S.d_prng, (size_t)B * 8));
-    RC(buf.d(&S.d_c1, (size_t)B)); RC(buf.d(&S.d_c2, (size_t)B)); RC(buf.d(&S.d_act, (size_t)B * 16));
-    RC(buf.d(&S.d_ch1, (size_t)B * 9)); RC(buf.d(&S.d_cnt1, (size_t)B)); RC(buf.d(&S.d_ch2, (size_t)B * 9)); RC(buf.d(&S.d_cnt2, (size_t)B));
-    RC(buf.d(&S.d_rout, (size_t)B)); RC(buf.d(&S.d_steps, (size_t)B)); RC(buf.d(&S.d_values, (size_t)B));
-    if (pucb) { RC(buf.d(&S.d_l1, (size_t)B * 9)); RC(buf.d(&S.d_l2, (size_t)B * 9)); }
-    if (use_net && n_slots > 1) { // per-slot embedding buffer (kept from round 1; the context's own workspace would do as well)
-      int emb_dim = 0;
-      RC(oakgpu_net_shape(net, &emb_dim, nullptr, nullptr, nullptr));
-      RC(buf.d(&S.d_emb, (size_t)B * emb_dim));
-    }
-    RC(buf.h(&S.h_c1, (size_t)B)); RC(buf.h(&S.h_c2, (size_t)B)); RC(buf.h(&S.h_r, (size_t)B)); RC(buf.h(&S.h_act, (size_t)B * 16));
-    RC(buf.h(&S.h_ch1, (size_t)B * 9)); RC(buf.h(&S.h_cnt1, (size_t)B)); RC(buf.h(&S.h_ch2, (size_t)B * 9)); RC(buf.h(&S.h_cnt2, (size_t)B));
-    RC(buf.h(&S.h_values, (size_t)B)); RC(buf.h(&S.h_stage, (size_t)B * 384));
-    if (pucb) { RC(buf.h(&S.h_l1, (size_t)B * 9)); RC(buf.h(&S.h_l2, (size_t)B * 9)); }
+    RC(S.allocate(ctx, si, B, pucb, emb_dim));
     // root template: B copies of the input; one fast_prng stream per lane (util/random.h:67-133), never all-zero
     for (uint32_t l = 0; l < B; ++l) memcpy(S.h_stage + (size_t)l * 384, battle, 384);
     HIPRC(hipMemcpyAsync(S.d_root_b, S.h_stage, (size_t)B * 384, hipMemcpyHostToDevice, S.stream));
@@ -288,22 +605,39 @@ extern "C" int oakgpu_search(oakgpu_ctx *ctx, oakgpu_net *net, const uint8_t *ba
     HIPRC(hipMemcpyAsync(S.d_prng, S.h_stage, (size_t)B * 8, hipMemcpyHostToDevice, S.stream));
     HIPRC(hipMemsetAsync(S.d_root_r, result, B, S.stream));
     HIPRC(hipStreamSynchronize(S.stream));
-    S.path.resize(B); S.cur.resize(B); S.leaf.resize(B); S.active.resize(B);
+    S.busy = false;
   }
+
+  // host threads of the tree walk: 1, 2, 4 or 8 (OAKGPU_SEARCH_THREADS; default 4, fewer for small batches).  Results do
+  // not depend on the count (see Tree)
+  int W = 4;
+  if (const char *env = getenv("OAKGPU_SEARCH_THREADS")) W = atoi(env);
+  if (B < 1024) W = 1;
+  W = W >= 8 ? 8 : W >= 4 ? 4 : W >= 2 ? 2 : 1;
+  {
+    const unsigned hc = std::thread::hardware_concurrency();
+    while (W > 1 && hc && (unsigned)W > hc) W /= 2;
+  }
+  Pool pool(W);
 
   double total_value = 0;
   const bool timing = getenv("OAKGPU_SEARCH_TIMING") != nullptr;
   double t_sel = 0, t_gpu = 0, t_proc = 0, t_eval = 0, t_back = 0;
   auto now = [] { return std::chrono::high_resolution_clock::now(); };
   auto us = [](auto a, auto b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
-  uint64_t done = 0, started = 0, total_depth = 0;
-  uint64_t mucb_rng = prm->seed ^ 0xA0761D6478BD642Full, bandit_rng = prm->seed ^ 0xE7037ED1A0B428DBull;
+  uint64_t done = 0, started = 0, total_depth = 0, serial = 0;
+  uint64_t mucb_rng = prm->seed ^ 0xA0761D6478BD642Full;
+  const uint64_t bandit_seed = prm->seed ^ 0xE7037ED1A0B428DBull;
+  // the budget's clock starts HERE, after the set-up above (round-2 advice: with t_start in front of ~50 allocations a short
+  // budget on a cold context was spent before the first batch); the reference times only its iteration loop (mcts.h:213-245)
+  const auto t_start = now();
 
   // one batch: root prep, level-synchronous descent (host selection <-> k_tree_step), then the leaf evaluation is
   // LAUNCHED (not awaited)
   auto descend = [&](Slot &S) -> int {
     const uint32_t nb = timed ? B : (uint32_t)std::min<uint64_t>(B, prm->iterations - started);
     S.nb = nb;
+    S.serial = serial++;
     started += nb;
     S.busy = true;
     // root prep on the device (mcts.h:254-259): rollout kernel with max_steps = 0
@@ -312,7 +646,8 @@ extern "C" int oakgpu_search(oakgpu_ctx *ctx, oakgpu_net *net, const uint8_t *ba
     for (uint32_t l = 0; l < nb; ++l) { S.path[l].clear(); S.cur[l] = root; S.leaf[l] = NO_NODE; S.active[l] = 1; }
     uint32_t n_active = nb;
     // MatrixUCB (mcts.h:263-302): the root's joint actions of this batch come from the UCB matrices, not the bandits
-    const bool mucb = prm->matrix_ucb && done >= prm->mucb_delay;
+    const uint64_t so_far = base_iterations + done; // output.iterations at this point (mcts.h:270)
+    const bool mucb = prm->matrix_ucb && so_far >= prm->mucb_delay;
     if (mucb) {
       S.forced.clear();
       uint64_t planned[81];
@@ -322,7 +657,7 @@ extern "C" int oakgpu_search(oakgpu_ctx *ctx, oakgpu_net *net, const uint8_t *ba
           while (planned[i * 9 + j] < prm->mucb_minimum && S.forced.size() < nb) { S.forced.push_back((uint8_t)(i * 9 + j)); ++planned[i * 9 + j]; }
       if (S.forced.size() < nb) {
         int32_t up[81], dn[81];
-        const double log_T = std::log((double)(done ? done : 1)), w = std::log(2.0 * m * n);
+        const double log_T = std::log((double)(so_far ? so_far : 1)), w = std::log(2.0 * m * n);
         for (int i = 0; i < m; ++i)
           for (int j = 0; j < n; ++j) {
             const uint64_t v = out->visit_matrix[i * 9 + j];
@@ -336,13 +671,12 @@ extern "C" int oakgpu_search(oakgpu_ctx *ctx, oakgpu_net *net, const uint8_t *ba
         solve_zero_sum(dn, m, n, dummy, S.nash2);
       }
     }
+    uint32_t shard_done[8];
     for (uint32_t depth = 0; n_active > 0; ++depth) {
       const auto ta = now();
-      for (uint32_t l = 0; l < nb; ++l) { // bandit selection, sequential: each lane sees the virtual losses before it
-        if (l + 12 < nb && S.active[l + 12]) tree.prefetch_node(S.cur[l + 12]);
-        if (!S.active[l]) { S.h_c1[l] = 0xFF; S.h_c2[l] = 0xFF; continue; }
-        uint8_t i, j;
-        if (mucb && depth == 0) { // sampled / forced root action; the root bandits are neither consulted nor updated
+      if (mucb && depth == 0) { // sampled / forced root actions; the root bandits are neither consulted nor updated
+        for (uint32_t l = 0; l < nb; ++l) {
+          uint8_t i, j;
           if (l < S.forced.size()) { i = S.forced[l] / 9; j = S.forced[l] % 9; }
           else {
             auto sample = [&](const double *p, int k) {
@@ -354,18 +688,32 @@ extern "C" int oakgpu_search(oakgpu_ctx *ctx, oakgpu_net *net, const uint8_t *ba
             j = sample(S.nash2, n);
           }
           S.path[l].push_back({NO_NODE, i, j, 1.0f, 1.0f});
-        } else {
-          Stats &nd = tree.nodes[S.cur[l]];
-          float pr1, pr2;
-          auto draw = [&] { return uniform01(bandit_rng); }; // device.uniform() of sample_pdf (util/random.h:40-49)
-          i = nd.p1.select(BP, draw, pr1);
-          j = nd.p2.select(BP, draw, pr2);
-          nd.p1.visit(BP, i);
-          nd.p2.visit(BP, j);
-          S.path[l].push_back({S.cur[l], i, j, pr1, pr2});
+          S.h_c1[l] = root_c1[i];
+          S.h_c2[l] = root_c2[j];
         }
-        S.h_c1[l] = depth == 0 ? root_c1[i] : S.h_ch1[(size_t)l * 9 + i];
-        S.h_c2[l] = depth == 0 ? root_c2[j] : S.h_ch2[(size_t)l * 9 + j];
+      } else {
+        // bandit selection: every thread walks the lanes in order and serves those whose node lives in its shards -- the
+        // lanes of one node are served by one thread, in lane order: each sees the virtual losses of those before it
+        pool.run([&](int w) {
+          uint32_t ahead = 0;
+          for (uint32_t l = 0; l < nb; ++l) {
+            if (!S.active[l]) { if (w == 0) { S.h_c1[l] = 0xFF; S.h_c2[l] = 0xFF; } continue; }
+            const uint32_t id = S.cur[l];
+            if ((owner_of(id) & (W - 1)) != w) continue;
+            if (ahead <= l) ahead = l + 1;
+            for (int pf = 0; ahead < nb && pf < 2; ++ahead) // keep ~12 of this thread's lanes in flight
+              if (S.active[ahead] && (owner_of(S.cur[ahead]) & (W - 1)) == w) { tree.prefetch_node(S.cur[ahead]); ++pf; if (ahead > l + 96) break; }
+            NodeRec &nd = tree.node(id);
+            float pr1, pr2;
+            const uint8_t i = nd.p1.select(BP, [&] { return uniform_at(bandit_seed, S.serial, l, depth, 0); }, pr1); // device.uniform() of sample_pdf (util/random.h:40-49)
+            const uint8_t j = nd.p2.select(BP, [&] { return uniform_at(bandit_seed, S.serial, l, depth, 1); }, pr2);
+            nd.p1.visit(BP, i);
+            nd.p2.visit(BP, j);
+            S.path[l].push_back({id, i, j, pr1, pr2});
+            S.h_c1[l] = depth == 0 ? root_c1[i] : S.h_ch1[(size_t)l * 9 + i];
+            S.h_c2[l] = depth == 0 ? root_c2[j] : S.h_ch2[(size_t)l * 9 + j];
+          }
+        });
       }
       const auto tb = now();
       HIPRC(hipMemcpyAsync(S.d_c1, S.h_c1, nb, hipMemcpyHostToDevice, S.stream));
@@ -380,28 +728,42 @@ extern "C" int oakgpu_search(oakgpu_ctx *ctx, oakgpu_net *net, const uint8_t *ba
       HIPRC(hipMemcpyAsync(S.h_cnt2, S.d_cnt2, nb, hipMemcpyDeviceToHost, S.stream));
       HIPRC(hipStreamSynchronize(S.stream));
       const auto tc = now();
-      for (uint32_t l = 0; l < nb; ++l) {
-        if (l + 16 < nb && S.active[l + 16] && (S.h_r[l + 16] & 15) == 0) {
-          uint8_t pk[18];
-          pk[0] = S.path[l + 16].back().i;
-          pk[1] = S.path[l + 16].back().j;
-          memcpy(pk + 2, S.h_act + (size_t)(l + 16) * 16, 16);
-          tree.prefetch_edge(S.cur[l + 16], pk);
+      // edges: the thread of the parent's shard looks the child up (or creates it) in that shard's table
+      for (int q = 0; q < 8; ++q) shard_done[q] = 0;
+      pool.run([&](int w) {
+        uint32_t fin = 0;
+        uint32_t ahead = 0;
+        auto mine = [&](uint32_t l) { return S.active[l] && (owner_of(S.cur[l]) & (W - 1)) == w; };
+        for (uint32_t l = 0; l < nb; ++l) {
+          if (!mine(l)) continue;
+          if (ahead <= l) ahead = l + 1;
+          for (int pf = 0; ahead < nb && pf < 2; ++ahead)
+            if (mine(ahead) && (S.h_r[ahead] & 15) == 0) {
+              uint8_t pk[18];
+              pk[0] = S.path[ahead].back().i;
+              pk[1] = S.path[ahead].back().j;
+              memcpy(pk + 2, S.h_act + (size_t)ahead * 16, 16);
+              tree.prefetch_edge(S.cur[ahead], pk);
+              ++pf;
+              if (ahead > l + 128) break;
+            }
+          if ((S.h_r[l] & 15) != 0) { // terminal edge: the value comes from the result byte (mcts.h:427-441)
+            S.active[l] = 0; ++fin;
+            continue;
+          }
+          uint8_t key[18];
+          key[0] = S.path[l].back().i;
+          key[1] = S.path[l].back().j;
+          memcpy(key + 2, S.h_act + (size_t)l * 16, 16);
+          const uint32_t child = tree.child(S.cur[l], key);
+          // (a child this thread reads is one it created: arena [owner][creator = this thread's shard])
+          if (tree.node(child).is_init() && depth + 1 < max_depth) { S.cur[l] = child; continue; }
+          S.leaf[l] = child; // first visit (or depth cap): evaluate here (mcts.h:391-426)
+          S.active[l] = 0; ++fin;
         }
-        if (!S.active[l]) continue;
-        if ((S.h_r[l] & 15) != 0) { // terminal edge: the value comes from the result byte (mcts.h:427-441)
-          S.active[l] = 0; --n_active; total_depth += depth + 1;
-          continue;
-        }
-        uint8_t key[18];
-        key[0] = S.path[l].back().i;
-        key[1] = S.path[l].back().j;
-        memcpy(key + 2, S.h_act + (size_t)l * 16, 16);
-        const uint32_t child = tree.child(S.cur[l], key);
-        if (tree.nodes[child].is_init() && depth + 1 < max_depth) { S.cur[l] = child; continue; }
-        S.leaf[l] = child; // first visit (or depth cap): evaluate here (mcts.h:391-426)
-        S.active[l] = 0; --n_active; total_depth += depth + 1;
-      }
+        shard_done[w] = fin;
+      });
+      for (int q = 0; q < W; ++q) { n_active -= shard_done[q]; total_depth += (uint64_t)shard_done[q] * (depth + 1); }
       const auto td = now();
       t_sel += us(ta, tb); t_gpu += us(tb, tc); t_proc += us(tc, td);
     }
@@ -426,24 +788,31 @@ extern "C" int oakgpu_search(oakgpu_ctx *ctx, oakgpu_net *net, const uint8_t *ba
     HIPRC(hipStreamSynchronize(S.stream));
     const auto tf = now();
     const uint32_t nb = S.nb;
-    for (uint32_t l = 0; l < nb; ++l) {
-      if (l + 8 < nb) { for (const Step &st : S.path[l + 8]) if (st.node != NO_NODE) tree.prefetch_node(st.node); if (S.leaf[l + 8] != NO_NODE) tree.prefetch_node(S.leaf[l + 8]); }
-      float v1;
+    auto value_of = [&](uint32_t l) {
       const uint32_t t = S.h_r[l] & 15;
-      if (t != 0) v1 = t == 1 ? 1.0f : t == 2 ? 0.0f : 0.5f;
-      else v1 = S.h_values[l];
-      if (S.leaf[l] != NO_NODE && !tree.nodes[S.leaf[l]].is_init() && S.h_cnt1[l] && S.h_cnt2[l]) { // stats.init(m, n) (+ priors), first evaluation
-        Stats &lf = tree.nodes[S.leaf[l]];
-        lf.p1.init(S.h_cnt1[l], BP.kind);
-        lf.p2.init(S.h_cnt2[l], BP.kind);
-        if (pucb) { lf.p1.set_logits(BP, S.h_l1 + (size_t)l * 9); lf.p2.set_logits(BP, S.h_l2 + (size_t)l * 9); }
+      return t != 0 ? (t == 1 ? 1.0f : t == 2 ? 0.0f : 0.5f) : S.h_values[l];
+    };
+    pool.run([&](int w) { // every node's bandits are written by the thread of its owner shard, in lane order
+      for (uint32_t l = 0; l < nb; ++l) {
+        if (l + 6 < nb) for (const Step &st : S.path[l + 6]) if (st.node != NO_NODE && (owner_of(st.node) & (W - 1)) == w) tree.prefetch_node(st.node);
+        const uint32_t lf_id = S.leaf[l];
+        if (lf_id != NO_NODE && (owner_of(lf_id) & (W - 1)) == w && !tree.node(lf_id).is_init() && S.h_cnt1[l] && S.h_cnt2[l]) { // stats.init(m, n) (+ priors), first evaluation
+          NodeRec &lf = tree.node(lf_id);
+          lf.p1.init(S.h_cnt1[l], BP.kind);
+          lf.p2.init(S.h_cnt2[l], BP.kind);
+          if (pucb) { lf.p1.set_logits(BP, S.h_l1 + (size_t)l * 9); lf.p2.set_logits(BP, S.h_l2 + (size_t)l * 9); }
+        }
+        const float v1 = value_of(l), v2 = 1.0f - v1;
+        for (const Step &st : S.path[l]) { // Bandit::update, the visit was already counted as the virtual loss
+          if (st.node == NO_NODE || (owner_of(st.node) & (W - 1)) != w) continue;  // (MatrixUCB root step: only the root matrices below are updated)
+          NodeRec &nd = tree.node(st.node);
+          nd.p1.update(BP, st.i, v1, st.prob1);
+          nd.p2.update(BP, st.j, v2, st.prob2);
+        }
       }
-      const float v2 = 1.0f - v1;
-      for (const Step &st : S.path[l]) { // Bandit::update, the visit was already counted as the virtual loss
-        if (st.node == NO_NODE) continue;  // MatrixUCB root step: only the root matrices below are updated
-        tree.nodes[st.node].p1.update(BP, st.i, v1, st.prob1);
-        tree.nodes[st.node].p2.update(BP, st.j, v2, st.prob2);
-      }
+    });
+    for (uint32_t l = 0; l < nb; ++l) {
+      const float v1 = value_of(l);
       const Step &s0 = S.path[l].front();
       ++out->visit_matrix[s0.i * 9 + s0.j];
       out->value_matrix[s0.i * 9 + s0.j] += v1;
@@ -456,37 +825,50 @@ extern "C" int oakgpu_search(oakgpu_ctx *ctx, oakgpu_net *net, const uint8_t *ba
   };
   auto more = [&] {
     if (!timed) return started < prm->iterations;
-    return std::chrono::duration<double, std::micro>(std::chrono::high_resolution_clock::now() - t_start).count() < (double)prm->duration_us;
+    // `while (elapsed < duration)` with elapsed = 0 at first (mcts.h:219-226): a time budget always runs at least once
+    return started == 0 || us(t_start, now()) < (double)prm->duration_us;
   };
-  for (int turn = 0; more() || slots[0].busy || slots[1].busy; turn = (turn + 1) % n_slots) {
+  for (int turn = 0; more() || slots[0].busy || (n_slots > 1 && slots[1].busy); turn = (turn + 1) % n_slots) {
     Slot &S = slots[turn];
     if (S.busy) RC(finish(S));
     if (more()) RC(descend(S));
   }
-  if (timing) fprintf(stderr, "oakgpu_search timing (ms): select %.1f  gpu-step %.1f  process %.1f  eval %.1f  backprop %.1f\n", t_sel / 1e3, t_gpu / 1e3, t_proc / 1e3, t_eval / 1e3, t_back / 1e3);
-  out->iterations = done;
-  out->empirical_value = done ? total_value / (double)done : 0.0;
-  for (int i = 0; i < m; ++i)
-    for (int j = 0; j < n; ++j) {
-      out->p1_empirical[i] += (double)out->visit_matrix[i * 9 + j] / (double)done;
-      out->p2_empirical[j] += (double)out->visit_matrix[i * 9 + j] / (double)done;
-    }
-  { // MCTS::Search::process_output (mcts.h:620-659): empirical root matrix x 256 as integers, solved exactly
+  if (timing) fprintf(stderr, "oakgpu_search timing (ms, %d threads): select %.1f  gpu-step %.1f  process %.1f  eval %.1f  backprop %.1f\n", W, t_sel / 1e3, t_gpu / 1e3, t_proc / 1e3, t_eval / 1e3, t_back / 1e3);
+  out->iterations = base_iterations + done;
+  { // MCTS::Search::process_output (mcts.h:620-659) over the ACCUMULATED matrices: empirical_value = sum of the value matrix /
+    // iterations, empirical strategies = row / column visit sums / iterations (0 iterations: 0 / 0, as the reference leaves
+    // it), and the empirical root matrix x 256 as integers, solved exactly
+    double tv = 0;
     int32_t M[81];
     for (int i = 0; i < m; ++i)
       for (int j = 0; j < n; ++j) {
+        tv += out->value_matrix[i * 9 + j];
         uint64_t v = out->visit_matrix[i * 9 + j];
+        out->p1_empirical[i] += (double)v;
+        out->p2_empirical[j] += (double)v;
         v += !v;
         M[i * n + j] = (int32_t)(out->value_matrix[i * 9 + j] / (double)v * 256.0);
       }
+    out->empirical_value = tv / (double)out->iterations;
+    for (int i = 0; i < m; ++i) out->p1_empirical[i] /= (double)(float)out->iterations;
+    for (int j = 0; j < n; ++j) out->p2_empirical[j] /= (double)(float)out->iterations;
     double nv = 0;
     if (oak_nash::solve(M, m, n, out->p1_nash, out->p2_nash, &nv)) out->nash_value = nv / 256.0;
   }
-  out->nodes = tree.nodes.size();
+  (void)total_value;
+  out->nodes = tree.size();
   out->total_depth = total_depth;
-  out->duration_us = std::chrono::duration<double, std::micro>(std::chrono::high_resolution_clock::now() - t_start).count();
+  out->duration_us = prev.duration_us + us(t_start, now()); // output.duration += ... (mcts.h:246-247): the iteration loop only
   return 0;
 }
+
+int oakgpu_search(oakgpu_ctx *ctx, oakgpu_net *net, const uint8_t *battle, const uint8_t *durations, uint8_t result,
+                  const oakgpu_search_params *prm, oakgpu_search_output *out) {
+  if (prm && prm->iterations == 0 && prm->duration_us == 0) return oakgpu_fail_msg("oakgpu_search: give an iteration or a time budget");
+  return oakgpu_search_heap(ctx, net, nullptr, battle, durations, result, prm, nullptr, out);
+}
+
+} // extern "C"
 
 
 // ---- RuntimeSearch::run (cpp/include/util/search.h:17-66, cpp/src/search.cc:150-313): the Agent's strings select budget,
@@ -514,8 +896,9 @@ std::mutex g_net_mu;
 std::map<std::pair<int, std::string>, oakgpu_net *> g_nets; // Agent::network_ptr (search.cc:62-148), shared per (device, path)
 } // namespace
 
-extern "C" int oakgpu_search_agent(oakgpu_ctx *ctx, const uint8_t *battle, const uint8_t *durations, uint8_t result, const oakgpu_agent *agent,
-                                   uint32_t batch, uint64_t seed, oakgpu_search_output *out) {
+extern "C" int oakgpu_search_agent_heap(oakgpu_ctx *ctx, oakgpu_heap *heap, const uint8_t *battle, const uint8_t *durations, uint8_t result,
+                                        const oakgpu_agent *agent, uint32_t batch, uint64_t seed, const oakgpu_search_output *previous,
+                                        oakgpu_search_output *out) {
   if (!ctx || !battle || !durations || !agent || !out) return oakgpu_fail_msg("oakgpu_search_agent: null argument");
   oakgpu_search_params P{};
   P.root_rolls = 3; P.other_rolls = 1; // default_search (mcts.h:131)
@@ -530,7 +913,8 @@ extern "C" int oakgpu_search_agent(oakgpu_ctx *ctx, const uint8_t *battle, const
   else if (unit == "ms" || unit == "millisec" || unit == "milliseconds") P.duration_us = number * 1000;
   else if (unit == "s" || unit == "sec" || unit == "seconds") P.duration_us = number * 1000000;
   else return oakgpu_fail_msg(("Invalid search duration specification: " + budget).c_str());
-  if (P.iterations == 0 && P.duration_us == 0) return oakgpu_fail_msg(("Invalid search duration specification: " + budget).c_str());
+  // ("0" is a legal budget: no iteration runs, the output carries the root's value / logits / priors -- what the
+  // reference's cpp_inference asks for, pyoak.cc:331-392)
   // evaluator: "" / "mc" / "montecarlo" / "monte-carlo" | "fp" | <network path> (util/search.h:56-61)
   const std::string eval = agent->eval ? agent->eval : "";
   const bool mc = eval.empty() || eval == "mc" || eval == "montecarlo" || eval == "monte-carlo", fp = eval == "fp";
@@ -547,7 +931,7 @@ extern "C" int oakgpu_search_agent(oakgpu_ctx *ctx, const uint8_t *battle, const
   else if (name == "pexp3") P.bandit = 4;
   else return oakgpu_fail_msg(("Could not parse bandit string: " + name).c_str());
   if ((P.bandit == 1 || P.bandit == 4) && (mc || fp)) return oakgpu_fail_msg("Contextual bandit specified with eval that does not produce policy priors.");
-  P.exp3_alpha = 0.05f;
+  P.exp3_alpha = -1.0f; // absent third field: the default 0.05 (search.cc:268-270); an explicit value, 0 included, goes through unchanged
   if (P.bandit >= 3 && bs.size() >= 3 && !to_float(bs[2], P.exp3_alpha)) return oakgpu_fail_msg(("Could not parse bandit string: " + bandit).c_str());
   // matrix_ucb: "" | "delay-interval-minimum-c" (search.cc:216-235); the interval is the batch here
   const std::string mu = agent->matrix_ucb ? agent->matrix_ucb : "";
@@ -578,7 +962,12 @@ extern "C" int oakgpu_search_agent(oakgpu_ctx *ctx, const uint8_t *battle, const
     }
     net = it->second;
   }
-  return oakgpu_search(ctx, net, battle, durations, result, &P, out);
+  return oakgpu_search_heap(ctx, net, heap, battle, durations, result, &P, previous, out);
+}
+
+extern "C" int oakgpu_search_agent(oakgpu_ctx *ctx, const uint8_t *battle, const uint8_t *durations, uint8_t result, const oakgpu_agent *agent,
+                                   uint32_t batch, uint64_t seed, oakgpu_search_output *out) {
+  return oakgpu_search_agent_heap(ctx, nullptr, battle, durations, result, agent, batch, seed, nullptr, out);
 }
 
 extern "C" void oakgpu_agent_networks_clear(oakgpu_ctx *ctx) { // drops the networks oakgpu_search_agent loaded on this context's device

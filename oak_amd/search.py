@@ -98,15 +98,85 @@ def process_output(out):
     return out
 
 
+class Heap:
+    """RuntimeSearch::Heap (util/search.h:17-32, search.cc:17-58) over oakgpu_heap: the tree of a search, kept between
+    searches.  empty() is True until a search used it; update(i, j, obs) promotes the child reached by the PLAYED joint
+    action (indices into the root's choice lists) and the 16-byte observation to the root, dropping the rest."""
+
+    def __init__(self):
+        self.lib = _lib.load()
+        h = C.c_void_p()
+        _lib.check(self.lib.oakgpu_heap_create(C.byref(h)))
+        self.handle = h
+
+    def empty(self):
+        return bool(self.lib.oakgpu_heap_empty(self.handle))
+
+    def nodes(self):
+        return int(self.lib.oakgpu_heap_nodes(self.handle))
+
+    def clear(self):
+        self.lib.oakgpu_heap_clear(self.handle)
+
+    def update(self, i, j, obs):
+        o = np.ascontiguousarray(obs, dtype=np.uint8).reshape(16)
+        return bool(self.lib.oakgpu_heap_update(self.handle, int(i), int(j), o.ctypes.data_as(C.c_void_p)))
+
+    def root_stats(self, player):
+        """(scores[k], priors[k], visits[k]) of the root's bandit of `player` (0 / 1); k = 0: the root is not initialised."""
+        sc, pr, vi, k = np.zeros(9, np.float32), np.zeros(9, np.float32), np.zeros(9, np.uint32), C.c_uint8(0)
+        _lib.check(self.lib.oakgpu_heap_root_stats(self.handle, int(player), sc.ctypes.data_as(C.c_void_p), pr.ctypes.data_as(C.c_void_p),
+                                                   vi.ctypes.data_as(C.c_void_p), C.cast(C.byref(k), C.c_void_p)))
+        return sc[:k.value].copy(), pr[:k.value].copy(), vi[:k.value].copy()
+
+    def child_stats(self, i, j, obs, player):
+        """root_stats of the child that update(i, j, obs) would promote (empty arrays: no such initialised child)."""
+        o = np.ascontiguousarray(obs, dtype=np.uint8).reshape(16)
+        sc, pr, vi, k = np.zeros(9, np.float32), np.zeros(9, np.float32), np.zeros(9, np.uint32), C.c_uint8(0)
+        _lib.check(self.lib.oakgpu_heap_child_stats(self.handle, int(i), int(j), o.ctypes.data_as(C.c_void_p), int(player),
+                                                    sc.ctypes.data_as(C.c_void_p), pr.ctypes.data_as(C.c_void_p), vi.ctypes.data_as(C.c_void_p),
+                                                    C.cast(C.byref(k), C.c_void_p)))
+        return sc[:k.value].copy(), pr[:k.value].copy(), vi[:k.value].copy()
+
+    def close(self):
+        if self.handle:
+            self.lib.oakgpu_heap_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _output_dict(res):
+    m, n = int(res.m), int(res.n)
+    return {"m": m, "n": n, "p1_choices": np.array(res.p1_choices[:m], dtype=np.uint8),
+            "p2_choices": np.array(res.p2_choices[:n], dtype=np.uint8),
+            "visit_matrix": np.array(res.visit_matrix, dtype=np.int64).reshape(9, 9)[:m, :n].copy(),
+            "value_matrix": np.array(res.value_matrix, dtype=np.float64).reshape(9, 9)[:m, :n].copy(),
+            "iterations": int(res.iterations), "initial_value": float(res.initial_value), "nodes": int(res.nodes),
+            "mean_depth": res.total_depth / max(int(res.iterations), 1), "duration_ms": res.duration_us / 1e3,
+            # process_output ran in C++ (oakgpu_search_output: exact Nash of the empirical root matrix)
+            "nash_value": float(res.nash_value), "p1_nash": np.array(res.p1_nash[:m]), "p2_nash": np.array(res.p2_nash[:n]),
+            "empirical_value": float(res.empirical_value), "p1_empirical": np.array(res.p1_empirical[:m]),
+            "p2_empirical": np.array(res.p2_empirical[:n]),
+            "p1_logit": np.array(res.p1_logit[:m]), "p2_logit": np.array(res.p2_logit[:n]),
+            "p1_prior": np.array(res.p1_prior[:m]), "p2_prior": np.array(res.p2_prior[:n]),
+            "raw": res}          # the oakgpu_search_output itself: pass the dict back as `previous` to resume (mcts.h:153-155)
+
+
 def tree_search(ctx, battle, durations, result, iterations=1 << 16, batch=4096, c=2.0, bandit="ucb", evaluator="mc",
-                root_rolls=3, other_rolls=1, max_depth=100, seed=0x5EED, matrix_ucb=None, alpha=0.05):
-    """Tree search with batched leaves on the GPU (include/oakgpu.h: oakgpu_search).  bandit: "ucb" | "pucb" | "ucb1" | "exp3" | "pexp3" (c = gamma for the Exp3 family, alpha its uniform mixing);
+                root_rolls=3, other_rolls=1, max_depth=100, seed=0x5EED, matrix_ucb=None, alpha=0.05, heap=None, previous=None,
+                duration_us=0):
+    """Tree search with batched leaves on the GPU (include/oakgpu.h: oakgpu_search_heap).  bandit: "ucb" | "pucb" | "ucb1" | "exp3" | "pexp3" (c = gamma for the Exp3 family, alpha its uniform mixing);
     evaluator: "mc", "poke-engine" (PokeEngine::Eval) or an oak_amd.engine.Network.  Defaults follow the reference's default_search{3, 1} damage-roll
     clamping (mcts.h:131).  matrix_ucb: None or (delay, minimum, c) -- MatrixUCBParams with interval = batch (the
-    reference's "delay-interval-minimum-c" agent string, search.cc:216-231).  Returns a dict shaped like MCTS::Output
-    (mcts.h:68-90)."""
-    import ctypes as C
-    from . import _lib
+    reference's "delay-interval-minimum-c" agent string, search.cc:216-231).  heap: None (fresh tree) or a Heap kept between
+    searches; previous: None or the dict a previous tree_search of the SAME position returned -- matrices, iterations and
+    duration accumulate like MCTS::Search::run's by-value Output (mcts.h:153-155, 231-247).  Returns a dict shaped like
+    MCTS::Output (mcts.h:68-90)."""
     battle = np.ascontiguousarray(battle, dtype=np.uint8).reshape(384)
     durations = np.ascontiguousarray(durations, dtype=np.uint8).reshape(8)
     use_net = not isinstance(evaluator, str)
@@ -114,19 +184,10 @@ def tree_search(ctx, battle, durations, result, iterations=1 << 16, batch=4096, 
                             eval=1 if use_net else {"mc": 0, "poke-engine": 2}[evaluator], max_depth=int(max_depth), root_rolls=int(root_rolls),
                             other_rolls=int(other_rolls), seed=int(seed), matrix_ucb=1 if matrix_ucb else 0,
                             mucb_delay=int(matrix_ucb[0]) if matrix_ucb else 0, mucb_minimum=int(matrix_ucb[1]) if matrix_ucb else 0,
-                            mucb_c=float(matrix_ucb[2]) if matrix_ucb else 0.0, exp3_alpha=float(alpha))
+                            mucb_c=float(matrix_ucb[2]) if matrix_ucb else 0.0, exp3_alpha=float(alpha), duration_us=int(duration_us))
     res = _lib.SearchOutput()
-    _lib.check(ctx.lib.oakgpu_search(ctx.handle, evaluator.handle if use_net else None, battle.ctypes.data_as(C.c_void_p),
-                                     durations.ctypes.data_as(C.c_void_p), int(result), C.byref(prm), C.byref(res)))
-    m, n = int(res.m), int(res.n)
-    out = {"m": m, "n": n, "p1_choices": np.array(res.p1_choices[:m], dtype=np.uint8),
-           "p2_choices": np.array(res.p2_choices[:n], dtype=np.uint8),
-           "visit_matrix": np.array(res.visit_matrix, dtype=np.int64).reshape(9, 9)[:m, :n].copy(),
-           "value_matrix": np.array(res.value_matrix, dtype=np.float64).reshape(9, 9)[:m, :n].copy(),
-           "iterations": int(res.iterations), "initial_value": float(res.initial_value), "nodes": int(res.nodes),
-           "mean_depth": res.total_depth / max(int(res.iterations), 1), "duration_ms": res.duration_us / 1e3,
-           # process_output ran in C++ (oakgpu_search_output: exact Nash of the empirical root matrix)
-           "nash_value": float(res.nash_value), "p1_nash": np.array(res.p1_nash[:m]), "p2_nash": np.array(res.p2_nash[:n]),
-           "empirical_value": float(res.empirical_value), "p1_empirical": np.array(res.p1_empirical[:m]),
-           "p2_empirical": np.array(res.p2_empirical[:n])}
-    return out
+    prev = C.byref(previous["raw"]) if previous is not None else None
+    _lib.check(ctx.lib.oakgpu_search_heap(ctx.handle, evaluator.handle if use_net else None, heap.handle if heap is not None else None,
+                                          battle.ctypes.data_as(C.c_void_p), durations.ctypes.data_as(C.c_void_p), int(result), C.byref(prm),
+                                          prev, C.byref(res)))
+    return _output_dict(res)

@@ -217,3 +217,175 @@ def test_tree_search_output_carries_the_exact_nash_solution(gpu_ctx):
         assert abs(nv - out["nash_value"]) <= 1e-12 and abs(out["p1_nash"].sum() - 1) < 1e-9
         assert (M @ p2).max() <= nv * 256 + 1e-6 and (p1 @ M).min() >= nv * 256 - 1e-6    # equilibrium of the matrix solved
     net.close()
+
+
+# ---- RuntimeSearch::Heap + the resumable Output of Search::run (mcts.h:153-155, 231-247; search.cc:27-52) -------------
+def test_resumed_output_accumulates_like_search_run(gpu_ctx):
+    """Two searches of 2^14 through one Heap with the first Output passed back in: iterations == 2^15, matrices == the sum
+    of what each search contributed, duration adds up -- `Output output = {}` is by value and added to (mcts.h:153-155)."""
+    import oracle_lib as O
+    from oak_amd.search import Heap, tree_search
+    b, d, p, r = O.make_random_ou_batch(1, seed0=424242)
+    res = int(r[0])
+    h1, h2 = Heap(), Heap()
+    assert h1.empty() and h1.nodes() == 0
+    o1 = tree_search(gpu_ctx, b[0], d[0], res, iterations=1 << 14, batch=2048, seed=1, heap=h1)
+    assert not h1.empty() and h1.nodes() == o1["nodes"]
+    o2 = tree_search(gpu_ctx, b[0], d[0], res, iterations=1 << 14, batch=2048, seed=2, heap=h1, previous=o1)
+    # the same two searches through a second heap, the second one NOT resumed: its output is only its own contribution
+    p1 = tree_search(gpu_ctx, b[0], d[0], res, iterations=1 << 14, batch=2048, seed=1, heap=h2)
+    p2 = tree_search(gpu_ctx, b[0], d[0], res, iterations=1 << 14, batch=2048, seed=2, heap=h2)
+    assert (p1["visit_matrix"] == o1["visit_matrix"]).all() and (p1["value_matrix"] == o1["value_matrix"]).all()   # same seed, same tree
+    assert o2["iterations"] == 1 << 15 and p2["iterations"] == 1 << 14
+    assert (o2["visit_matrix"] == o1["visit_matrix"] + p2["visit_matrix"]).all()
+    assert np.allclose(o2["value_matrix"], o1["value_matrix"] + p2["value_matrix"], rtol=0, atol=1e-6)
+    assert int(o2["visit_matrix"].sum()) == 1 << 15
+    assert abs(o2["empirical_value"] - o2["value_matrix"].sum() / (1 << 15)) < 1e-12          # process_output over the sums
+    assert np.allclose(o2["p1_empirical"], o2["visit_matrix"].sum(axis=1) / float(1 << 15))
+    assert o2["duration_ms"] > o1["duration_ms"] > 0                                           # output.duration += ...
+    assert o2["nodes"] > o1["nodes"]                                                           # the tree kept growing
+    # the second search really used the first one's statistics: a fresh-tree search with seed 2 is a different search
+    fresh = tree_search(gpu_ctx, b[0], d[0], res, iterations=1 << 14, batch=2048, seed=2)
+    assert not (fresh["visit_matrix"] == p2["visit_matrix"]).all()
+    h1.close(); h2.close()
+
+
+def test_heap_update_promotes_the_played_child(gpu_ctx):
+    """Heap::update(i, j, obs) (search.cc:27-52): the child's bandit statistics become the root's, bit for bit; the next
+    search continues from them; an edge the search never took leaves an uninitialised root; a heap holds one bandit type."""
+    import oracle_lib as O
+    from oak_amd._lib import OakGpuError
+    from oak_amd.search import Heap, tree_search
+    b, d, p, r = O.make_random_ou_batch(1, seed0=31337)
+    battle, dur, res = b[0].copy(), d[0].copy(), int(r[0])
+    h = Heap()
+    o1 = tree_search(gpu_ctx, battle, dur, res, iterations=1 << 15, batch=2048, seed=5, heap=h)
+    i, j = np.unravel_index(np.argmax(o1["visit_matrix"]), o1["visit_matrix"].shape)
+    # play the most visited joint action for real; several seeds of the battle's own RNG until the observation is one the tree holds
+    for attempt in range(64):
+        nb, nd = battle.copy().reshape(1, 384), dur.copy().reshape(1, 8)
+        nb[0, 376:384] = np.frombuffer(np.uint64(0x9E3779B97F4A7C15 * (attempt + 1) & 0xFFFFFFFFFFFFFFFF).tobytes(), dtype=np.uint8)
+        nres, actions = gpu_ctx.update(nb, np.array([o1["p1_choices"][i]], np.uint8), np.array([o1["p2_choices"][j]], np.uint8), nd)
+        before = [h.child_stats(i, j, actions[0], pl) for pl in (0, 1)]
+        if len(before[0][0]):
+            break
+    assert len(before[0][0]) > 0, "no observation of the most visited joint action is in the tree"
+    nodes_before = h.nodes()
+    assert h.update(i, j, actions[0]) is True
+    after = [h.root_stats(pl) for pl in (0, 1)]
+    for pl in (0, 1):
+        for x, y in zip(before[pl], after[pl]):
+            assert x.tobytes() == y.tobytes()                        # scores, priors, visits: the old child's, exactly
+    assert 0 < h.nodes() < nodes_before                              # the rest of the tree is dropped
+    kept = h.nodes()
+    if (int(nres[0]) & 15) == 0:
+        o2 = tree_search(gpu_ctx, nb[0], nd[0], int(nres[0]), iterations=1 << 13, batch=1024, seed=6, heap=h)
+        assert o2["iterations"] == 1 << 13 and o2["nodes"] > kept
+        visits_root = h.root_stats(0)[2]
+        assert int(visits_root.sum()) == int(after[0][2].sum()) + (1 << 13)     # UCB: every iteration is one more visit at the root
+        # an observation that cannot exist: nothing is kept, the heap holds an uninitialised node (not monostate)
+        assert h.update(0, 0, np.full(16, 0xEE, np.uint8)) is False
+        assert not h.empty() and h.nodes() == 0 and len(h.root_stats(0)[0]) == 0
+        o3 = tree_search(gpu_ctx, nb[0], nd[0], int(nres[0]), iterations=4096, batch=1024, seed=7, heap=h)
+        assert o3["iterations"] == 4096
+        with pytest.raises(OakGpuError, match="Bad Heap access"):
+            tree_search(gpu_ctx, nb[0], nd[0], int(nres[0]), iterations=1024, batch=256, bandit="exp3", c=0.1, heap=h)
+    h.close()
+
+
+def test_time_budget_on_a_cold_context_runs_at_least_one_batch():
+    """Round-2 advice: with the clock started before the set-up a 1 ms budget on a fresh context ran zero batches and
+    returned NaN strategies.  The clock now covers the iteration loop only and a time budget always runs once
+    (`while (elapsed < duration)` starts at elapsed = 0, mcts.h:219-226)."""
+    from oak_amd.engine import Context
+    from oak_amd.search import tree_search
+    import oracle_lib as O
+    b, d, p, r = O.make_random_ou_batch(1, seed0=2024)
+    ctx = Context(0)
+    out = tree_search(ctx, b[0], d[0], int(r[0]), iterations=0, batch=1024, duration_us=1000, seed=1)
+    assert out["iterations"] >= 1024 and out["iterations"] % 1024 == 0
+    assert np.isfinite(out["p1_empirical"]).all() and abs(out["p1_empirical"].sum() - 1) < 1e-6
+    assert np.isfinite(out["empirical_value"]) and 0 < out["duration_ms"] < 2000
+    # a second search on the now warm context: the budget is honoured within a batch or two
+    out2 = tree_search(ctx, b[0], d[0], int(r[0]), iterations=0, batch=1024, duration_us=20000, seed=2)
+    assert 20 <= out2["duration_ms"] < 200 and out2["iterations"] >= 1024
+    ctx.close()
+
+
+def test_contextual_root_priors_and_zero_budget(gpu_ctx):
+    """Output::Side::logit / prior (mcts.h:196-209): the root's legal logits and softmax(logits) for PUCB / PExp3; budget 0
+    runs no iteration and still fills them (what cpp_inference reads, pyoak.cc:331-392)."""
+    import oracle_lib as O
+    from oak_amd.engine import Network
+    from oak_amd.search import tree_search
+    b, d, p, r = O.make_random_ou_batch(1, seed0=777)
+    net = Network(gpu_ctx, path=os.path.join(ROOT, "tests", "golden", "net_default.battle.net"))
+    out = tree_search(gpu_ctx, b[0], d[0], int(r[0]), iterations=0, batch=1, bandit="pucb", evaluator=net, c=1.0)
+    assert out["iterations"] == 0 and int(out["visit_matrix"].sum()) == 0
+    for side in ("p1", "p2"):
+        lg, pr = out[side + "_logit"], out[side + "_prior"]
+        e = np.exp(lg.astype(np.float32))
+        assert np.allclose(pr, e / e.sum(dtype=np.float32), atol=1e-6) and abs(pr.sum() - 1) < 1e-6
+    assert abs(out["initial_value"] - float(net.value_inference(b[:1], d[:1])[0])) <= 1e-6
+    # a non-contextual bandit leaves them at zero, like the reference's value-initialised Output
+    plain = tree_search(gpu_ctx, b[0], d[0], int(r[0]), iterations=1024, batch=256, evaluator=net)
+    assert not plain["p1_prior"].any() and not plain["p1_logit"].any()
+    net.close()
+
+
+def test_host_thread_count_does_not_change_the_search(gpu_ctx):
+    """The tree is cut into 8 shards served by 1, 2, 4 or 8 host threads (search_host.hip): any count walks the same tree."""
+    import oracle_lib as O
+    from oak_amd.search import tree_search
+    b, d, p, r = O.make_random_ou_batch(1, seed0=999)
+    outs = []
+    old = os.environ.get("OAKGPU_SEARCH_THREADS")
+    try:
+        for w in ("1", "2", "4", "8"):
+            os.environ["OAKGPU_SEARCH_THREADS"] = w
+            outs.append(tree_search(gpu_ctx, b[0], d[0], int(r[0]), iterations=1 << 15, batch=4096, seed=13, bandit="exp3", c=0.3))
+            outs.append(tree_search(gpu_ctx, b[0], d[0], int(r[0]), iterations=1 << 15, batch=4096, seed=13))
+    finally:
+        if old is None:
+            os.environ.pop("OAKGPU_SEARCH_THREADS", None)
+        else:
+            os.environ["OAKGPU_SEARCH_THREADS"] = old
+    for k in (2, 4, 6):
+        for base in (0, 1):
+            assert (outs[k + base]["visit_matrix"] == outs[base]["visit_matrix"]).all()
+            assert outs[k + base]["value_matrix"].tobytes() == outs[base]["value_matrix"].tobytes()
+            assert outs[k + base]["nodes"] == outs[base]["nodes"]
+
+
+def test_tutorial_known_answer_snorlax_vs_starmie(gpu_ctx):
+    """The reference's other published known answer (TUTORIAL.md:46-70): `snorlax bodyslam rest | starmie psychic thunderwave
+    recover`, agent ucb-1.0, Monte-Carlo leaves, 8 s (847,615 iterations there) => Value 0.448; the two heavily visited
+    cells BodySlam x ThunderWave 0.443 (813,826 visits) and BodySlam x Psychic 0.602 (23,811).  Exercises paralysis, Rest,
+    Body Slam's secondary, Psychic's special drop, speed order, crits and damage rolls -- far more of the engine than the 13
+    sleep / confusion positions.  Tolerances: 0.03 on the value (the reference's own test tolerance), 0.05 on the cells."""
+    from oak_amd import _lib
+    import ctypes as C
+    b, d = parse_battle("snorlax bodyslam rest | starmie psychic thunderwave recover")
+    res = result_from_state(b)
+    out = _lib.SearchOutput()
+    agent = _lib.Agent(budget=b"1048576", bandit=b"ucb-1.0", eval=b"mc", matrix_ucb=b"", discrete=0, table=0)
+    _lib.check(gpu_ctx.lib.oakgpu_search_agent(gpu_ctx.handle, b.ctypes.data_as(C.c_void_p), d.ctypes.data_as(C.c_void_p), int(res),
+                                               C.byref(agent), 1024, 0x7157, C.byref(out)))
+    from oak_amd.search import _output_dict
+    o = _output_dict(out)
+    assert o["m"] == 2 and o["n"] == 3 and o["iterations"] == 1 << 20
+    names1 = {(1 << 2) | 1: "bodyslam", (2 << 2) | 1: "rest"}
+    names2 = {(1 << 2) | 1: "psychic", (2 << 2) | 1: "thunderwave", (3 << 2) | 1: "recover"}
+    r1 = {names1[int(c)]: k for k, c in enumerate(o["p1_choices"])}
+    r2 = {names2[int(c)]: k for k, c in enumerate(o["p2_choices"])}
+    mean = o["value_matrix"] / np.maximum(o["visit_matrix"], 1)
+    report = {"value": o["empirical_value"], "bs_tw": mean[r1["bodyslam"], r2["thunderwave"]], "bs_psy": mean[r1["bodyslam"], r2["psychic"]],
+              "visits": o["visit_matrix"].tolist(), "p1_emp": o["p1_empirical"].tolist(), "p2_emp": o["p2_empirical"].tolist()}
+    print("TUTORIAL known answer:", report)
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    import json
+    json.dump(report, open(os.path.join(ROOT, "gpurun_out", "tutorial_known_answer.json"), "w"), indent=1)
+    assert abs(o["empirical_value"] - 0.448) <= 0.03, report
+    assert abs(mean[r1["bodyslam"], r2["thunderwave"]] - 0.443) <= 0.05, report
+    assert abs(mean[r1["bodyslam"], r2["psychic"]] - 0.602) <= 0.05, report
+    assert o["p1_empirical"][r1["bodyslam"]] > 0.9 and o["p2_empirical"][r2["thunderwave"]] > 0.8, report

@@ -27,7 +27,8 @@ def _mod():
 
 def test_module_exposes_pyoak_names_and_constants():
     m = _mod()
-    for name in ("Heap", "Agent", "Input", "Output", "parse_battle", "update", "search", "solve_matrix", "read_battle_data"):
+    for name in ("Heap", "Agent", "Input", "Output", "parse_battle", "update", "search", "solve_matrix", "read_battle_data", "cpp_inference",
+                 "value_inference", "value_policy_inference"):
         assert hasattr(m, name), name
     a = m.Agent()
     for field in ("budget", "bandit", "eval", "matrix_ucb", "discrete", "table"):       # pyoak.cc:446-453
@@ -40,7 +41,10 @@ def test_module_exposes_pyoak_names_and_constants():
     assert (m.value_hidden_dim, m.policy_hidden_dim, m.policy_out_dim) == (32, 64, 315)
     o = m.Output()
     assert o.iterations == 0 and o.visit_matrix.shape == (9, 9) and o.p1_nash.shape == (9,)
-    assert m.Heap().empty()
+    h = m.Heap()
+    assert h.empty() and h.type() == "std::monostate" and h.nodes() == 0
+    assert h.update(0, 0, bytes(16)) is False                                           # Heap::update on monostate (search.cc:31-32)
+    assert o.p1_prior.shape == (9,) and not o.p1_prior.any() and o.initial_value == 0.0
 
 
 def test_parse_battle_and_solve_matrix_and_read_battle_data(tmp_path):
@@ -106,3 +110,55 @@ def test_search_and_update_through_the_module():
     bad.budget, bad.bandit, bad.eval = "64", "pucb-1.0", "mc"
     with pytest.raises(RuntimeError, match="Contextual bandit"):                            # search.cc:245-250
         m.search(full, m.Heap(), bad)
+
+
+@pytest.mark.gpu
+def test_heap_resume_priors_and_cpp_inference_through_the_module(tmp_path):
+    """pyoak.search(input, heap, agent, output) resumes both the heap's tree and the output (pyoak.cc:575-583 ->
+    RuntimeSearch::run -> Search::run, mcts.h:153-155); Heap.update promotes the played child (search.cc:27-52); p1/p2_prior
+    are the contextual root priors (mcts.h:196-209); cpp_inference replays a game record like pyoak.cc:331-392."""
+    m = _mod()
+    net_path = os.path.join(ROOT, "tests", "golden", "net_default.battle.net")
+    full = m.parse_battle("starmie surf recover psychic thunderwave | rhydon earthquake rockslide bodyslam substitute")
+    agent = m.Agent()
+    agent.budget, agent.bandit, agent.eval = str(1 << 14), "ucb-1.0", "mc"
+    heap = m.Heap()
+    o1 = m.search(full, heap, agent, batch=1024, seed=1)
+    assert not heap.empty() and "UCB::JointBandit" in heap.type() and heap.nodes() > 16
+    o2 = m.search(full, heap, agent, o1, batch=1024, seed=2)
+    assert o1.iterations == 1 << 14 and o2.iterations == 1 << 15 and o2.visit_matrix.sum() == 1 << 15
+    assert (o2.visit_matrix >= o1.visit_matrix).all() and o2.duration_ms > o1.duration_ms
+    i, j = np.unravel_index(np.argmax(o2.visit_matrix), (9, 9))
+    obs = m.update(full, o2.p1_choices[i], o2.p2_choices[j])                             # plays the action; returns the observation
+    assert isinstance(obs, bytes) and len(obs) == 16
+    kept = heap.update(int(i), int(j), obs)
+    assert kept in (True, False) and (heap.nodes() > 0) == kept
+    if (full.result & 15) == 0:
+        o3 = m.search(full, heap, agent, batch=1024, seed=3)
+        assert o3.iterations == 1 << 14
+    # contextual priors + the per-position inference entry points
+    agent.budget, agent.bandit, agent.eval = "512", "pucb-1.0", net_path
+    pos = m.parse_battle("starmie surf recover psychic thunderwave | rhydon earthquake rockslide bodyslam substitute")
+    o = m.search(pos, m.Heap(), agent, batch=128, seed=4)
+    assert abs(o.p1_prior[:o.m].sum() - 1) < 1e-6 and abs(o.p2_prior[:o.n].sum() - 1) < 1e-6 and not o.p1_prior[o.m:].any()
+    e = np.exp(o.p1_logit[:o.m].astype(np.float32))
+    assert np.allclose(o.p1_prior[:o.m], e / e.sum(dtype=np.float32), atol=1e-6)
+    v, l1, l2 = m.value_policy_inference(pos, net_path)
+    assert abs(v - o.initial_value) <= 1e-6 and np.allclose(l1, o.p1_logit[:o.m], atol=1e-6) and np.allclose(l2, o.p2_logit[:o.n], atol=1e-6)
+    assert abs(m.value_inference(pos, net_path) - v) <= 1e-6
+    # cpp_inference over a self-play record: frame 0 is the record's battle with zero durations (pyoak.cc:349-366)
+    from oak_amd.engine import Context, Network
+    from oak_amd.frames import selfplay_game, read_frames
+    ctx = Context(0)
+    teams = np.array([[[143, 34, 156, 0, 0]] + [[0] * 5] * 5, [[121, 94, 86, 105, 0]] + [[0] * 5] * 5], dtype=np.uint8)   # snorlax | starmie
+    rec, n_frames, result = selfplay_game(ctx, teams, battle_seed=7, iterations=512, batch=128, evaluator="mc", seed=3)
+    out = m.cpp_inference(bytes(rec), net_path)
+    assert out["value"].shape == (n_frames,) and out["policy_logit"].shape == (n_frames, 2, 9) and out["policy"].shape == (n_frames, 2, 9)
+    game = read_frames(rec)[0]
+    battle, ups = game["battle"], game["updates"]
+    net = Network(ctx, path=net_path)
+    assert abs(out["value"][0] - float(net.value_inference(battle.reshape(1, 384), np.zeros((1, 8), np.uint8))[0])) <= 1e-6
+    assert ((out["value"] > 0) & (out["value"] < 1)).all()
+    k1, k2 = ups[0]["m"], ups[0]["n"]
+    assert abs(out["policy"][0, 0, :k1].sum() - 1) < 1e-5 and abs(out["policy"][0, 1, :k2].sum() - 1) < 1e-5 and not out["policy"][0, 0, k1:].any()
+    net.close(); ctx.close()
