@@ -14,6 +14,10 @@
 #include <stdint.h>
 
 #include <cmath>
+#if !defined(__HIP_DEVICE_COMPILE__) && defined(__SSE2__)
+#include <emmintrin.h>
+#define OAK_BANDIT_SSE2 1
+#endif
 
 namespace oak_search {
 
@@ -83,11 +87,29 @@ struct Bandit {
     }
     for (int i = 0; i < k; ++i) N += visits[i];
     const float sqrtN = (float)std::sqrt((double)N);
+#ifdef OAK_BANDIT_SSE2
+    // the same IEEE operations, four arms per instruction (the root of a batched search runs this tens of thousands of
+    // times in a row); lanes past k compute garbage that the argmax below never looks at
+    float a8[8];
+    const __m128 sq = _mm_set1_ps(sqrtN), cc = _mm_set1_ps(P.c), ucb_e = _mm_set1_ps(P.c * sqrtN / k);
+    for (int b = 0; b < 8; b += 4) {
+      const __m128 e = P.kind == B_PUCB ? _mm_mul_ps(_mm_mul_ps(cc, _mm_loadu_ps(priors + b)), sq) : ucb_e;
+      const __m128 v = _mm_cvtepi32_ps(_mm_loadu_si128((const __m128i *)(visits + b)));
+      _mm_storeu_ps(a8 + b, _mm_div_ps(_mm_add_ps(e, _mm_loadu_ps(scores + b)), v));
+    }
+    for (int i = 0; i < k; ++i) {
+      float a;
+      if (i < 8) a = a8[i];
+      else { const float e = P.kind == B_PUCB ? P.c * priors[i] * sqrtN : P.c * sqrtN / k; a = (e + scores[i]) / visits[i]; }
+      if (a > best) { best = a; idx = (uint8_t)i; }
+    }
+#else
     for (int i = 0; i < k; ++i) {
       const float e = P.kind == B_PUCB ? P.c * priors[i] * sqrtN : P.c * sqrtN / k;
       const float a = (e + scores[i]) / visits[i];
       if (a > best) { best = a; idx = (uint8_t)i; }
     }
+#endif
     return idx;
   }
   // the visit of the counting bandits is booked at selection time (virtual loss), their score at back-up time

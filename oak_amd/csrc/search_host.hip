@@ -15,6 +15,7 @@
 //     standard way to keep B simultaneous descents from all choosing the same path.
 // No battle arithmetic happens on the host: every state transition and evaluation above is a kernel launch.
 #include <hip/hip_runtime.h>
+#include <sched.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -61,11 +62,12 @@ using namespace oak_search;
 //
 // The tree is cut into SHARDS = 8 shards so that the host work of a batch (bandit selection, edge lookups, back-ups)
 // can run on several threads WITHOUT changing any result: a node id is `local << 6 | creator << 3 | owner`; every
-// read-modify-write of a node's bandits is done by the thread that serves its OWNER shard, in lane order; the edges
-// out of a node live in the table of that node's owner shard, and a new child (owner = 3 hash bits of its edge) is
-// appended to the arena [owner][creator = the parent's owner] -- only the parent's thread appends there.  The number
-// of shards is fixed, the number of threads (1, 2, 4 or 8, each serving shards = thread mod threads) is not: any
-// thread count walks the same tree bit for bit.
+// read-modify-write of a node's bandits is done by the thread that serves its OWNER shard, in a fixed service order; an
+// edge (parent, i, j, obs) lives in the table picked by 3 bits of ITS hash (so the edges of one hot parent -- the root
+// first of all -- are looked up and created by all threads, not by one), and a new child (owner = 3 other hash bits) is
+// appended to the arena [owner][creator = the edge's table] -- only that table's thread appends there.  The number of
+// shards is fixed, the number of threads (1, 2, 4 or 8, each serving shards = thread mod threads) is not: any thread
+// count walks the same tree bit for bit.
 constexpr int SHARDS = 8;
 struct NodeRec {
   Bandit p1, p2;
@@ -141,23 +143,23 @@ struct Tree {
   }
   // the host loops over a batch's lanes are bound by cache misses on these tables and on the arenas (tens of MB per search):
   // they ask for a later lane's lines while working on the current one
-  void prefetch_edge(uint32_t parent, const uint8_t *key) const { const Table &t = tab[parent & 7]; __builtin_prefetch(&t.e[hash_of(parent, key) & (t.cap - 1)]); }
+  static int edge_shard(uint64_t h) { return (int)(h >> 61); }
+  void prefetch_edge(uint64_t h) const { const Table &t = tab[edge_shard(h)]; __builtin_prefetch(&t.e[h & (t.cap - 1)]); }
   void prefetch_node(uint32_t id) const {
     const auto &v = arena[id & 7][(id >> 3) & 7];
     if ((id >> 6) < v.size()) { __builtin_prefetch(&v[id >> 6]); __builtin_prefetch((const char *)&v[id >> 6] + 64); __builtin_prefetch((const char *)&v[id >> 6] + 128); }
   }
-  // child of `parent` along (i, j, obs) = key; created (uninitialised) when absent -- heap.children[{i, j, obs}] (mcts.h:359-361).
-  // Called by the thread that serves owner_of(parent).
-  uint32_t child(uint32_t parent, const uint8_t *key) {
-    Table &t = tab[parent & 7];
+  // child of `parent` along (i, j, obs) = key, h = hash_of(parent, key); created (uninitialised) when absent --
+  // heap.children[{i, j, obs}] (mcts.h:359-361).  Called by the thread that serves edge_shard(h).
+  uint32_t child(uint32_t parent, const uint8_t *key, uint64_t h) {
+    Table &t = tab[edge_shard(h)];
     if ((t.count + 1) * 10 > t.cap * 6) grow(t);
-    const uint64_t h = hash_of(parent, key);
     const size_t mask = t.cap - 1;
     for (size_t i = h & mask;; i = (i + 1) & mask) {
       Edge &e = t.e[i];
       if (e.gen != t.gen) {
         e.gen = t.gen; e.hash = h; e.parent = parent; memcpy(e.key, key, 18);
-        e.child = new_node((int)((h >> 58) & 7), (int)(parent & 7));
+        e.child = new_node((int)((h >> 58) & 7), edge_shard(h));
         ++t.count;
         return e.child;
       }
@@ -165,9 +167,9 @@ struct Tree {
     }
   }
   bool find_child(uint32_t parent, const uint8_t *key, uint32_t *out) const { // lookup only (Heap::update, search.cc:38)
-    const Table &t = tab[parent & 7];
-    if (!t.e) return false;
     const uint64_t h = hash_of(parent, key);
+    const Table &t = tab[edge_shard(h)];
+    if (!t.e) return false;
     const size_t mask = t.cap - 1;
     for (size_t i = h & mask;; i = (i + 1) & mask) {
       const Edge &e = t.e[i];
@@ -218,10 +220,10 @@ struct Tree {
     for (auto &t : tab) { free(t.e); t.e = (Edge *)calloc(want, sizeof(Edge)); t.cap = t.e ? want : 0; t.gen = 1; t.count = 0; }
   }
   void insert_edge(uint32_t parent, const uint8_t *key, uint32_t child_id) {
-    Table &t = tab[parent & 7];
+    const uint64_t h = hash_of(parent, key);
+    Table &t = tab[edge_shard(h)];
     if (!t.e) return;
     if ((t.count + 1) * 10 > t.cap * 6) grow(t);
-    const uint64_t h = hash_of(parent, key);
     const size_t mask = t.cap - 1;
     size_t i = h & mask;
     while (t.e[i].gen == t.gen) i = (i + 1) & mask;
@@ -370,7 +372,14 @@ struct oakgpu_heap {
 };
 
 namespace {
-struct Step { uint32_t node; uint8_t i, j; float prob1, prob2; };
+// One selection of one lane at one tree level (what Bandit::update needs at back-up time), one lane waiting at a node, one
+// lane's pair of choice bytes for the device.  All per-SHARD lists: a thread only ever appends to the lists of the shards it
+// serves, so no two threads write the same cache line (lane-indexed arrays written by whoever owns the lane's node cost
+// more in line ping-pong than the threads gained).
+struct Sel { uint32_t lane, node; uint8_t i, j; float prob1, prob2; };
+struct LaneNode { uint32_t lane, node; };
+struct OutC { uint32_t lane; uint8_t c1, c2; };
+struct Route { uint64_t hash; uint32_t lane, parent; uint8_t key[18]; }; // a lane's edge on its way to the thread of the edge's table
 constexpr uint32_t NO_NODE = 0xFFFFFFFFu;
 // One batch in flight: a context (= HIP stream), its device arrays and the pinned host mirrors of what crosses PCIe at
 // every level.  The slots of a caller's context are kept between searches (round-2 advice: a second context and ~50
@@ -381,6 +390,7 @@ struct Slot {
   hipStream_t stream{};
   Buffers buf;
   uint32_t cap = 0;
+  static constexpr size_t PACK = 16 + 9 + 9 + 1 + 1 + 1; // actions, both choice lists, result, both counts: bytes per lane per level
   bool has_logits = false;
   int emb_dim = 0;
   uint8_t *d_root_b, *d_root_d, *d_root_r, *d_b, *d_d, *d_r, *d_prng, *d_c1, *d_c2, *d_act, *d_ch1, *d_cnt1, *d_ch2, *d_cnt2, *d_rout;
@@ -388,9 +398,15 @@ struct Slot {
   float *d_values, *d_l1 = nullptr, *d_l2 = nullptr, *d_emb = nullptr;
   uint8_t *h_c1, *h_c2, *h_r, *h_act, *h_ch1, *h_cnt1, *h_ch2, *h_cnt2, *h_stage;
   float *h_values, *h_l1 = nullptr, *h_l2 = nullptr;
-  std::vector<std::vector<Step>> path;
-  std::vector<uint32_t> cur, leaf;
-  std::vector<uint8_t> active;
+  std::vector<std::vector<Sel>> log[SHARDS];     // [shard][depth]: the selections made at nodes of that shard, in service order
+  std::vector<Route> route[SHARDS][SHARDS];      // [shard of the parent][table of the edge]
+  std::vector<Route> work[SHARDS];               // [table of the edge]: its route lists, concatenated
+  std::vector<LaneNode> next[2][SHARDS][SHARDS]; // [parity][table of the edge][shard of the child]: lanes that go one level deeper
+  std::vector<LaneNode> leafs[SHARDS][SHARDS];   // [table of the edge][shard of the leaf]: lanes that stop at a node to evaluate
+  std::vector<OutC> outc[SHARDS][SHARDS];        // [shard][lane block]: choice bytes on their way to the pinned arrays
+  std::vector<uint8_t> root_i, root_j;
+  std::vector<float> root_p1, root_p2;
+  uint32_t levels = 0;
   std::vector<uint8_t> forced;
   double nash1[9], nash2[9];
   uint32_t nb = 0;
@@ -409,18 +425,22 @@ struct Slot {
     stream = (hipStream_t)oakgpu_ctx_stream(ctx);
     cap = 0;
     RC(buf.d(&d_root_b, (size_t)B * 384)); RC(buf.d(&d_root_d, (size_t)B * 8)); RC(buf.d(&d_root_r, (size_t)B));
-    RC(buf.d(&d_b, (size_t)B * 384)); RC(buf.d(&d_d, (size_t)B * 8)); RC(buf.d(&d_r, (size_t)B)); RC(buf.d(&d_prng, (size_t)B * 8));
-    RC(buf.d(&d_c1, (size_t)B)); RC(buf.d(&d_c2, (size_t)B)); RC(buf.d(&d_act, (size_t)B * 16));
-    RC(buf.d(&d_ch1, (size_t)B * 9)); RC(buf.d(&d_cnt1, (size_t)B)); RC(buf.d(&d_ch2, (size_t)B * 9)); RC(buf.d(&d_cnt2, (size_t)B));
+    RC(buf.d(&d_b, (size_t)B * 384)); RC(buf.d(&d_d, (size_t)B * 8)); RC(buf.d(&d_prng, (size_t)B * 8));
+    // what a level sends down (two choice bytes per lane) and what comes back (37 bytes per lane) each travel as ONE copy:
+    // the arrays are carved from one block on either side, in the same order
+    RC(buf.d(&d_c1, (size_t)B * 2)); d_c2 = d_c1 + B;
+    RC(buf.d(&d_act, (size_t)B * PACK));
+    d_ch1 = d_act + (size_t)B * 16; d_ch2 = d_ch1 + (size_t)B * 9; d_r = d_ch2 + (size_t)B * 9; d_cnt1 = d_r + B; d_cnt2 = d_cnt1 + B;
     RC(buf.d(&d_rout, (size_t)B)); RC(buf.d(&d_steps, (size_t)B)); RC(buf.d(&d_values, (size_t)B));
     d_l1 = d_l2 = d_emb = nullptr; h_l1 = h_l2 = nullptr;
     if (logits) { RC(buf.d(&d_l1, (size_t)B * 9)); RC(buf.d(&d_l2, (size_t)B * 9)); }
     if (emb) RC(buf.d(&d_emb, (size_t)B * emb));
-    RC(buf.h(&h_c1, (size_t)B)); RC(buf.h(&h_c2, (size_t)B)); RC(buf.h(&h_r, (size_t)B)); RC(buf.h(&h_act, (size_t)B * 16));
-    RC(buf.h(&h_ch1, (size_t)B * 9)); RC(buf.h(&h_cnt1, (size_t)B)); RC(buf.h(&h_ch2, (size_t)B * 9)); RC(buf.h(&h_cnt2, (size_t)B));
+    RC(buf.h(&h_c1, (size_t)B * 2)); h_c2 = h_c1 + B;
+    RC(buf.h(&h_act, (size_t)B * PACK));
+    h_ch1 = h_act + (size_t)B * 16; h_ch2 = h_ch1 + (size_t)B * 9; h_r = h_ch2 + (size_t)B * 9; h_cnt1 = h_r + B; h_cnt2 = h_cnt1 + B;
     RC(buf.h(&h_values, (size_t)B)); RC(buf.h(&h_stage, (size_t)B * 384));
     if (logits) { RC(buf.h(&h_l1, (size_t)B * 9)); RC(buf.h(&h_l2, (size_t)B * 9)); }
-    path.resize(B); cur.resize(B); leaf.resize(B); active.resize(B);
+    root_i.resize(B); root_j.resize(B); root_p1.resize(B); root_p2.resize(B);
     cap = B; has_logits = logits; emb_dim = emb;
     return 0;
   }
@@ -608,21 +628,25 @@ int oakgpu_search_heap(oakgpu_ctx *ctx, oakgpu_net *net, oakgpu_heap *heap, cons
     S.busy = false;
   }
 
-  // host threads of the tree walk: 1, 2, 4 or 8 (OAKGPU_SEARCH_THREADS; default 4, fewer for small batches).  Results do
-  // not depend on the count (see Tree)
-  int W = 4;
-  if (const char *env = getenv("OAKGPU_SEARCH_THREADS")) W = atoi(env);
+  // host threads of the tree walk: 1, 2, 4 or 8 (OAKGPU_SEARCH_THREADS; default 8 where the process may use >= 16 CPUs, else
+  // half of them; 1 for small batches).  Results do not depend on the count (see Tree)
+  int W = 8;
+  const char *wenv = getenv("OAKGPU_SEARCH_THREADS");
+  if (wenv) W = atoi(wenv);
+  else {
+    unsigned hc = std::thread::hardware_concurrency();
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof set, &set) == 0) hc = (unsigned)CPU_COUNT(&set);
+    while (W > 1 && hc && (unsigned)W * 2 > hc) W /= 2;
+  }
   if (B < 1024) W = 1;
   W = W >= 8 ? 8 : W >= 4 ? 4 : W >= 2 ? 2 : 1;
-  {
-    const unsigned hc = std::thread::hardware_concurrency();
-    while (W > 1 && hc && (unsigned)W > hc) W /= 2;
-  }
   Pool pool(W);
 
   double total_value = 0;
   const bool timing = getenv("OAKGPU_SEARCH_TIMING") != nullptr;
-  double t_sel = 0, t_gpu = 0, t_proc = 0, t_eval = 0, t_back = 0;
+  double t_sel = 0, t_gpu = 0, t_proc = 0, t_eval = 0, t_back = 0, t_sel_d[4] = {}, t_proc_d[4] = {};
+  uint64_t n_d[4] = {};
   auto now = [] { return std::chrono::high_resolution_clock::now(); };
   auto us = [](auto a, auto b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
   uint64_t done = 0, started = 0, total_depth = 0, serial = 0;
@@ -633,7 +657,10 @@ int oakgpu_search_heap(oakgpu_ctx *ctx, oakgpu_net *net, oakgpu_heap *heap, cons
   const auto t_start = now();
 
   // one batch: root prep, level-synchronous descent (host selection <-> k_tree_step), then the leaf evaluation is
-  // LAUNCHED (not awaited)
+  // LAUNCHED (not awaited).  Service order at a node = (shard of the lane's previous node, lane): fixed by the tree, not by
+  // the number of threads.
+  const int rs = owner_of(root);
+  auto shards_of = [&](int w, auto &&fn) { for (int sh = w; sh < SHARDS; sh += W) fn(sh); };
   auto descend = [&](Slot &S) -> int {
     const uint32_t nb = timed ? B : (uint32_t)std::min<uint64_t>(B, prm->iterations - started);
     S.nb = nb;
@@ -643,8 +670,11 @@ int oakgpu_search_heap(oakgpu_ctx *ctx, oakgpu_net *net, oakgpu_heap *heap, cons
     // root prep on the device (mcts.h:254-259): rollout kernel with max_steps = 0
     RC(oakgpu_rollout_dev(S.ctx, S.d_root_b, S.d_root_d, S.d_root_r, S.d_prng, nb, 0, 1, S.d_rout, S.d_steps, S.d_values, S.d_b, S.d_d));
     HIPRC(hipMemcpyAsync(S.d_r, S.d_root_r, nb, hipMemcpyDeviceToDevice, S.stream));
-    for (uint32_t l = 0; l < nb; ++l) { S.path[l].clear(); S.cur[l] = root; S.leaf[l] = NO_NODE; S.active[l] = 1; }
+    for (auto &a : S.leafs) for (auto &v : a) v.clear();
+    for (auto &par : S.next) for (auto &a : par) for (auto &v : a) v.clear();
     uint32_t n_active = nb;
+    const uint32_t block = (nb + SHARDS - 1) / SHARDS; // lane blocks of the scatter phase
+    const uint32_t lane_block = ((block + 63) / 64) * 64;
     // MatrixUCB (mcts.h:263-302): the root's joint actions of this batch come from the UCB matrices, not the bandits
     const uint64_t so_far = base_iterations + done; // output.iterations at this point (mcts.h:270)
     const bool mucb = prm->matrix_ucb && so_far >= prm->mucb_delay;
@@ -671,101 +701,171 @@ int oakgpu_search_heap(oakgpu_ctx *ctx, oakgpu_net *net, oakgpu_heap *heap, cons
         solve_zero_sum(dn, m, n, dummy, S.nash2);
       }
     }
-    uint32_t shard_done[8];
+    uint32_t shard_done[SHARDS];
+    int parity = 0;
     for (uint32_t depth = 0; n_active > 0; ++depth) {
       const auto ta = now();
-      if (mucb && depth == 0) { // sampled / forced root actions; the root bandits are neither consulted nor updated
-        for (uint32_t l = 0; l < nb; ++l) {
-          uint8_t i, j;
-          if (l < S.forced.size()) { i = S.forced[l] / 9; j = S.forced[l] % 9; }
-          else {
-            auto sample = [&](const double *p, int k) {
-              double u = uniform01(mucb_rng);
-              for (int q = 0; q < k; ++q) { u -= p[q]; if (u <= 0) return (uint8_t)q; }
-              return (uint8_t)(k - 1);
-            };
-            i = sample(S.nash1, m);
-            j = sample(S.nash2, n);
+      for (int sh = 0; sh < SHARDS; ++sh) {
+        if (S.log[sh].size() <= depth) S.log[sh].resize(depth + 1);
+      }
+      if (depth == 0) {
+        // Every lane is at the root.  Its two bandits are independent of each other (each sees only its own virtual losses),
+        // so player 1's and player 2's selection sequences run on two threads, on private copies of the bandits.
+        if (mucb) { // sampled / forced root actions; the root bandits are neither consulted nor updated
+          for (uint32_t l = 0; l < nb; ++l) {
+            uint8_t i, j;
+            if (l < S.forced.size()) { i = S.forced[l] / 9; j = S.forced[l] % 9; }
+            else {
+              auto sample = [&](const double *p, int k) {
+                double u = uniform01(mucb_rng);
+                for (int q = 0; q < k; ++q) { u -= p[q]; if (u <= 0) return (uint8_t)q; }
+                return (uint8_t)(k - 1);
+              };
+              i = sample(S.nash1, m);
+              j = sample(S.nash2, n);
+            }
+            S.root_i[l] = i; S.root_j[l] = j; S.root_p1[l] = 1.0f; S.root_p2[l] = 1.0f;
           }
-          S.path[l].push_back({NO_NODE, i, j, 1.0f, 1.0f});
-          S.h_c1[l] = root_c1[i];
-          S.h_c2[l] = root_c2[j];
+        } else {
+          NodeRec &nd = tree.node(root);
+          pool.run([&](int w) {
+            if (w == 0) {
+              Bandit b = nd.p1;
+              for (uint32_t l = 0; l < nb; ++l) {
+                float pr;
+                const uint8_t i = b.select(BP, [&] { return uniform_at(bandit_seed, S.serial, l, 0, 0); }, pr); // device.uniform() of sample_pdf (util/random.h:40-49)
+                b.visit(BP, i);
+                S.root_i[l] = i; S.root_p1[l] = pr;
+              }
+              nd.p1 = b;
+            }
+            if (w == (W > 1 ? 1 : 0)) {
+              Bandit b = nd.p2;
+              for (uint32_t l = 0; l < nb; ++l) {
+                float pr;
+                const uint8_t j = b.select(BP, [&] { return uniform_at(bandit_seed, S.serial, l, 0, 1); }, pr);
+                b.visit(BP, j);
+                S.root_j[l] = j; S.root_p2[l] = pr;
+              }
+              nd.p2 = b;
+            }
+          });
+        }
+        auto &lg = S.log[rs][0];
+        for (int sh = 0; sh < SHARDS; ++sh) S.log[sh][0].clear();
+        lg.resize(nb);
+        for (uint32_t l = 0; l < nb; ++l) {
+          lg[l] = Sel{l, mucb ? NO_NODE : root, S.root_i[l], S.root_j[l], S.root_p1[l], S.root_p2[l]};
+          S.h_c1[l] = root_c1[S.root_i[l]];
+          S.h_c2[l] = root_c2[S.root_j[l]];
         }
       } else {
-        // bandit selection: every thread walks the lanes in order and serves those whose node lives in its shards -- the
-        // lanes of one node are served by one thread, in lane order: each sees the virtual losses of those before it
+        // bandit selection: the thread of a shard serves the lanes waiting at that shard's nodes -- all lanes of one node by
+        // one thread, in service order, each seeing the virtual losses of those before it
         pool.run([&](int w) {
-          uint32_t ahead = 0;
-          for (uint32_t l = 0; l < nb; ++l) {
-            if (!S.active[l]) { if (w == 0) { S.h_c1[l] = 0xFF; S.h_c2[l] = 0xFF; } continue; }
-            const uint32_t id = S.cur[l];
-            if ((owner_of(id) & (W - 1)) != w) continue;
-            if (ahead <= l) ahead = l + 1;
-            for (int pf = 0; ahead < nb && pf < 2; ++ahead) // keep ~12 of this thread's lanes in flight
-              if (S.active[ahead] && (owner_of(S.cur[ahead]) & (W - 1)) == w) { tree.prefetch_node(S.cur[ahead]); ++pf; if (ahead > l + 96) break; }
-            NodeRec &nd = tree.node(id);
-            float pr1, pr2;
-            const uint8_t i = nd.p1.select(BP, [&] { return uniform_at(bandit_seed, S.serial, l, depth, 0); }, pr1); // device.uniform() of sample_pdf (util/random.h:40-49)
-            const uint8_t j = nd.p2.select(BP, [&] { return uniform_at(bandit_seed, S.serial, l, depth, 1); }, pr2);
-            nd.p1.visit(BP, i);
-            nd.p2.visit(BP, j);
-            S.path[l].push_back({id, i, j, pr1, pr2});
-            S.h_c1[l] = depth == 0 ? root_c1[i] : S.h_ch1[(size_t)l * 9 + i];
-            S.h_c2[l] = depth == 0 ? root_c2[j] : S.h_ch2[(size_t)l * 9 + j];
-          }
+          shards_of(w, [&](int sh) {
+            auto &lg = S.log[sh][depth];
+            lg.clear();
+            for (auto &v : S.outc[sh]) v.clear();
+            for (int p = 0; p < SHARDS; ++p) {
+              const auto &todo = S.next[parity][p][sh];
+              const size_t cnt = todo.size();
+              for (size_t q = 0; q < cnt; ++q) {
+                if (q + 10 < cnt) tree.prefetch_node(todo[q + 10].node);
+                const uint32_t l = todo[q].lane, id = todo[q].node;
+                NodeRec &nd = tree.node(id);
+                float pr1, pr2;
+                const uint8_t i = nd.p1.select(BP, [&] { return uniform_at(bandit_seed, S.serial, l, depth, 0); }, pr1);
+                const uint8_t j = nd.p2.select(BP, [&] { return uniform_at(bandit_seed, S.serial, l, depth, 1); }, pr2);
+                nd.p1.visit(BP, i);
+                nd.p2.visit(BP, j);
+                lg.push_back(Sel{l, id, i, j, pr1, pr2});
+                S.outc[sh][l / lane_block].push_back(OutC{l, S.h_ch1[(size_t)l * 9 + i], S.h_ch2[(size_t)l * 9 + j]});
+              }
+            }
+          });
+        });
+        // the choice bytes go to the pinned lane-indexed arrays by lane BLOCK (64-lane aligned): one writer per cache line
+        pool.run([&](int w) {
+          shards_of(w, [&](int blk) {
+            const uint32_t lo = (uint32_t)blk * lane_block, hi = std::min(nb, lo + lane_block);
+            if (lo >= hi) return;
+            memset(S.h_c1 + lo, 0xFF, hi - lo); // 0xFF: the lane is finished, leave it untouched
+            memset(S.h_c2 + lo, 0xFF, hi - lo);
+            for (int sh = 0; sh < SHARDS; ++sh)
+              for (const OutC &o : S.outc[sh][blk]) { S.h_c1[o.lane] = o.c1; S.h_c2[o.lane] = o.c2; }
+          });
         });
       }
       const auto tb = now();
-      HIPRC(hipMemcpyAsync(S.d_c1, S.h_c1, nb, hipMemcpyHostToDevice, S.stream));
-      HIPRC(hipMemcpyAsync(S.d_c2, S.h_c2, nb, hipMemcpyHostToDevice, S.stream));
+      HIPRC(hipMemcpyAsync(S.d_c1, S.h_c1, (size_t)S.cap + nb, hipMemcpyHostToDevice, S.stream)); // c1[0, cap) + c2[0, nb)
       RC(oakgpu_tree_step_dev(S.ctx, S.d_b, S.d_d, S.d_r, S.d_c1, S.d_c2, nb, depth == 0 ? prm->root_rolls : prm->other_rolls, S.d_act,
                               S.d_ch1, S.d_cnt1, S.d_ch2, S.d_cnt2));
-      HIPRC(hipMemcpyAsync(S.h_r, S.d_r, nb, hipMemcpyDeviceToHost, S.stream));
-      HIPRC(hipMemcpyAsync(S.h_act, S.d_act, (size_t)nb * 16, hipMemcpyDeviceToHost, S.stream));
-      HIPRC(hipMemcpyAsync(S.h_ch1, S.d_ch1, (size_t)nb * 9, hipMemcpyDeviceToHost, S.stream));
-      HIPRC(hipMemcpyAsync(S.h_cnt1, S.d_cnt1, nb, hipMemcpyDeviceToHost, S.stream));
-      HIPRC(hipMemcpyAsync(S.h_ch2, S.d_ch2, (size_t)nb * 9, hipMemcpyDeviceToHost, S.stream));
-      HIPRC(hipMemcpyAsync(S.h_cnt2, S.d_cnt2, nb, hipMemcpyDeviceToHost, S.stream));
+      HIPRC(hipMemcpyAsync(S.h_act, S.d_act, (size_t)S.cap * Slot::PACK, hipMemcpyDeviceToHost, S.stream));
       HIPRC(hipStreamSynchronize(S.stream));
       const auto tc = now();
-      // edges: the thread of the parent's shard looks the child up (or creates it) in that shard's table
-      for (int q = 0; q < 8; ++q) shard_done[q] = 0;
+      // edges, in two steps.  Route: the thread of the PARENT's shard hashes its lanes' edges (parent, i, j, observation) and
+      // hands each to the table its hash picks.  Resolve: the thread of that table looks the child up, or creates it, in
+      // the order (parent's shard, service order); the lane goes on to the child's shard or stops there for evaluation.
+      for (int q = 0; q < SHARDS; ++q) shard_done[q] = 0;
       pool.run([&](int w) {
-        uint32_t fin = 0;
-        uint32_t ahead = 0;
-        auto mine = [&](uint32_t l) { return S.active[l] && (owner_of(S.cur[l]) & (W - 1)) == w; };
-        for (uint32_t l = 0; l < nb; ++l) {
-          if (!mine(l)) continue;
-          if (ahead <= l) ahead = l + 1;
-          for (int pf = 0; ahead < nb && pf < 2; ++ahead)
-            if (mine(ahead) && (S.h_r[ahead] & 15) == 0) {
-              uint8_t pk[18];
-              pk[0] = S.path[ahead].back().i;
-              pk[1] = S.path[ahead].back().j;
-              memcpy(pk + 2, S.h_act + (size_t)ahead * 16, 16);
-              tree.prefetch_edge(S.cur[ahead], pk);
-              ++pf;
-              if (ahead > l + 128) break;
-            }
-          if ((S.h_r[l] & 15) != 0) { // terminal edge: the value comes from the result byte (mcts.h:427-441)
-            S.active[l] = 0; ++fin;
-            continue;
+        shards_of(w, [&](int sh) {
+          for (auto &v : S.route[sh]) v.clear();
+          uint32_t fin = 0;
+          const auto &lg = S.log[sh][depth];
+          const size_t cnt = lg.size();
+          for (size_t q = 0; q < cnt; ++q) {
+            if (q + 12 < cnt) { __builtin_prefetch(S.h_act + (size_t)lg[q + 12].lane * 16); __builtin_prefetch(S.h_r + lg[q + 12].lane); } // (fresh from the DMA: in no cache)
+            const Sel &e = lg[q];
+            if ((S.h_r[e.lane] & 15) != 0) { ++fin; continue; } // terminal edge: the value comes from the result byte (mcts.h:427-441)
+            Route r;
+            r.key[0] = e.i; r.key[1] = e.j;
+            memcpy(r.key + 2, S.h_act + (size_t)e.lane * 16, 16);
+            r.lane = e.lane;
+            r.parent = e.node == NO_NODE ? root : e.node;
+            r.hash = Tree::hash_of(r.parent, r.key);
+            S.route[sh][Tree::edge_shard(r.hash)].push_back(r);
           }
-          uint8_t key[18];
-          key[0] = S.path[l].back().i;
-          key[1] = S.path[l].back().j;
-          memcpy(key + 2, S.h_act + (size_t)l * 16, 16);
-          const uint32_t child = tree.child(S.cur[l], key);
-          // (a child this thread reads is one it created: arena [owner][creator = this thread's shard])
-          if (tree.node(child).is_init() && depth + 1 < max_depth) { S.cur[l] = child; continue; }
-          S.leaf[l] = child; // first visit (or depth cap): evaluate here (mcts.h:391-426)
-          S.active[l] = 0; ++fin;
-        }
-        shard_done[w] = fin;
+          shard_done[sh] = fin;
+        });
       });
-      for (int q = 0; q < W; ++q) { n_active -= shard_done[q]; total_depth += (uint64_t)shard_done[q] * (depth + 1); }
+      for (int q = 0; q < SHARDS; ++q) { n_active -= shard_done[q]; total_depth += (uint64_t)shard_done[q] * (depth + 1); shard_done[q] = 0; }
+      pool.run([&](int w) {
+        shards_of(w, [&](int t) {
+          for (auto &v : S.next[parity ^ 1][t]) v.clear();
+          auto &wk = S.work[t];
+          wk.clear();
+          for (int sh = 0; sh < SHARDS; ++sh) wk.insert(wk.end(), S.route[sh][t].begin(), S.route[sh][t].end());
+          const size_t cnt = wk.size();
+          uint32_t fin = 0;
+          constexpr size_t LOOK = 8; // two-stage pipeline: the edge of entry q + LOOK is resolved (child created if new, its node's
+          uint32_t pend[LOOK];       // line requested) while entry q reads whether its child is initialised
+          auto resolve = [&](size_t q) -> uint32_t {
+            const Route &r = wk[q];
+            const uint32_t child = tree.child(r.parent, r.key, r.hash);
+            tree.prefetch_node(child);
+            return child;
+          };
+          for (size_t q = 0; q < std::min(cnt, 2 * LOOK); ++q) tree.prefetch_edge(wk[q].hash);
+          for (size_t q = 0; q < std::min(cnt, LOOK); ++q) pend[q] = resolve(q);
+          for (size_t q = 0; q < cnt; ++q) {
+            const uint32_t child = pend[q % LOOK];
+            if (q + 2 * LOOK < cnt) tree.prefetch_edge(wk[q + 2 * LOOK].hash);
+            if (q + LOOK < cnt) pend[q % LOOK] = resolve(q + LOOK);
+            const uint32_t lane = wk[q].lane;
+            if (tree.node(child).is_init() && depth + 1 < max_depth) { S.next[parity ^ 1][t][owner_of(child)].push_back({lane, child}); continue; }
+            S.leafs[t][owner_of(child)].push_back({lane, child}); // first visit (or depth cap): evaluate here (mcts.h:391-426)
+            ++fin;
+          }
+          shard_done[t] = fin;
+        });
+      });
+      parity ^= 1;
+      for (int q = 0; q < SHARDS; ++q) { n_active -= shard_done[q]; total_depth += (uint64_t)shard_done[q] * (depth + 1); }
+      S.levels = depth + 1;
       const auto td = now();
       t_sel += us(ta, tb); t_gpu += us(tb, tc); t_proc += us(tc, td);
+      if (timing) { const int dd = depth < 3 ? (int)depth : 3; t_sel_d[dd] += us(ta, tb); t_proc_d[dd] += us(tc, td); for (int q = 0; q < SHARDS; ++q) n_d[dd] += S.log[q][depth].size(); }
     }
     // leaf evaluation, in place on the device; results are collected by finish()
     if (use_pe) {
@@ -792,30 +892,36 @@ int oakgpu_search_heap(oakgpu_ctx *ctx, oakgpu_net *net, oakgpu_heap *heap, cons
       const uint32_t t = S.h_r[l] & 15;
       return t != 0 ? (t == 1 ? 1.0f : t == 2 ? 0.0f : 0.5f) : S.h_values[l];
     };
-    pool.run([&](int w) { // every node's bandits are written by the thread of its owner shard, in lane order
-      for (uint32_t l = 0; l < nb; ++l) {
-        if (l + 6 < nb) for (const Step &st : S.path[l + 6]) if (st.node != NO_NODE && (owner_of(st.node) & (W - 1)) == w) tree.prefetch_node(st.node);
-        const uint32_t lf_id = S.leaf[l];
-        if (lf_id != NO_NODE && (owner_of(lf_id) & (W - 1)) == w && !tree.node(lf_id).is_init() && S.h_cnt1[l] && S.h_cnt2[l]) { // stats.init(m, n) (+ priors), first evaluation
-          NodeRec &lf = tree.node(lf_id);
-          lf.p1.init(S.h_cnt1[l], BP.kind);
-          lf.p2.init(S.h_cnt2[l], BP.kind);
-          if (pucb) { lf.p1.set_logits(BP, S.h_l1 + (size_t)l * 9); lf.p2.set_logits(BP, S.h_l2 + (size_t)l * 9); }
+    pool.run([&](int w) { // every node's bandits are written by the thread of its owner shard, in service order
+      shards_of(w, [&](int sh) {
+        for (int p = 0; p < SHARDS; ++p)
+          for (const LaneNode &e : S.leafs[p][sh]) { // stats.init(m, n) (+ priors) at the first evaluation
+            NodeRec &lf = tree.node(e.node);
+            const uint32_t l = e.lane;
+            if (lf.is_init() || !S.h_cnt1[l] || !S.h_cnt2[l]) continue;
+            lf.p1.init(S.h_cnt1[l], BP.kind);
+            lf.p2.init(S.h_cnt2[l], BP.kind);
+            if (pucb) { lf.p1.set_logits(BP, S.h_l1 + (size_t)l * 9); lf.p2.set_logits(BP, S.h_l2 + (size_t)l * 9); }
+          }
+        for (uint32_t d = 0; d < S.levels; ++d) {
+          const auto &lg = S.log[sh][d];
+          const size_t cnt = lg.size();
+          for (size_t q = 0; q < cnt; ++q) { // Bandit::update, the visit was already counted as the virtual loss
+            if (q + 10 < cnt && lg[q + 10].node != NO_NODE) tree.prefetch_node(lg[q + 10].node);
+            const Sel &e = lg[q];
+            if (e.node == NO_NODE) continue; // (MatrixUCB root step: only the root matrices below are updated)
+            const float v1 = value_of(e.lane);
+            NodeRec &nd = tree.node(e.node);
+            nd.p1.update(BP, e.i, v1, e.prob1);
+            nd.p2.update(BP, e.j, 1.0f - v1, e.prob2);
+          }
         }
-        const float v1 = value_of(l), v2 = 1.0f - v1;
-        for (const Step &st : S.path[l]) { // Bandit::update, the visit was already counted as the virtual loss
-          if (st.node == NO_NODE || (owner_of(st.node) & (W - 1)) != w) continue;  // (MatrixUCB root step: only the root matrices below are updated)
-          NodeRec &nd = tree.node(st.node);
-          nd.p1.update(BP, st.i, v1, st.prob1);
-          nd.p2.update(BP, st.j, v2, st.prob2);
-        }
-      }
+      });
     });
-    for (uint32_t l = 0; l < nb; ++l) {
-      const float v1 = value_of(l);
-      const Step &s0 = S.path[l].front();
-      ++out->visit_matrix[s0.i * 9 + s0.j];
-      out->value_matrix[s0.i * 9 + s0.j] += v1;
+    for (const Sel &e : S.log[rs][0]) { // the root matrices, in lane order
+      const float v1 = value_of(e.lane);
+      ++out->visit_matrix[e.i * 9 + e.j];
+      out->value_matrix[e.i * 9 + e.j] += v1;
       total_value += v1;
     }
     t_eval += us(te, tf); t_back += us(tf, now());
@@ -833,7 +939,10 @@ int oakgpu_search_heap(oakgpu_ctx *ctx, oakgpu_net *net, oakgpu_heap *heap, cons
     if (S.busy) RC(finish(S));
     if (more()) RC(descend(S));
   }
-  if (timing) fprintf(stderr, "oakgpu_search timing (ms, %d threads): select %.1f  gpu-step %.1f  process %.1f  eval %.1f  backprop %.1f\n", W, t_sel / 1e3, t_gpu / 1e3, t_proc / 1e3, t_eval / 1e3, t_back / 1e3);
+  if (timing) {
+    fprintf(stderr, "oakgpu_search timing (ms, %d threads): select %.1f  gpu-step %.1f  process %.1f  eval %.1f  backprop %.1f\n", W, t_sel / 1e3, t_gpu / 1e3, t_proc / 1e3, t_eval / 1e3, t_back / 1e3);
+    for (int q = 0; q < 4; ++q) fprintf(stderr, "  depth %d%s: %llu lane-steps, select %.2f ms, process %.2f ms\n", q, q == 3 ? "+" : "", (unsigned long long)n_d[q], t_sel_d[q] / 1e3, t_proc_d[q] / 1e3);
+  }
   out->iterations = base_iterations + done;
   { // MCTS::Search::process_output (mcts.h:620-659) over the ACCUMULATED matrices: empirical_value = sum of the value matrix /
     // iterations, empirical strategies = row / column visit sums / iterations (0 iterations: 0 / 0, as the reference leaves
