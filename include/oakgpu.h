@@ -57,6 +57,17 @@ int oakgpu_set_playouts_per_lane(oakgpu_ctx *ctx, int k);
  * launch large enough to keep every SIMD's wave slots occupied runs as a single dispatch (its tail is bound by the
  * longest playout, not by idle lanes); calling this function applies the given setting to every launch. */
 int oakgpu_set_regroup(oakgpu_ctx *ctx, int rounds, int suspend_below, int shrink);
+/* The tail of a launch that saturates the device (a group of batches): when the playout queue is dry, a wave with fewer
+ * than `below` (1..64; 0 = off) playouts still running parks them, and ONE follow-up dispatch of `waves` waves (0 = one
+ * per compute unit) finishes the parked playouts, `lanes` of them per wave at a time (0 = 64).  The survivors are the rare
+ * playouts that run into the step cap; a wave that holds one of them alone advances it no faster than a wave that holds
+ * a few, and hundreds of such waves slow each other down.  Results never depend on it. */
+int oakgpu_set_tail_pack(oakgpu_ctx *ctx, int below, int waves, int lanes);
+/* Queue order of a launch that saturates the device (default on): playouts with a Ghost-type Pokemon on either team are
+ * handed out first.  They hold practically all of the playouts that run into the step cap (Normal-type Rage / Struggle locks
+ * against a Ghost), and the launch ends with its longest playout: started early, the 1,000-step chains are mostly done when
+ * the queue runs dry.  Pure scheduling: results are indexed by playout and never depend on it. */
+int oakgpu_set_queue_order(oakgpu_ctx *ctx, int on);
 /* Rollout engine (results never depend on it; all three are bit-identical): 2 = register-resident engine, one wave per
  * workgroup, queue refill (default); 1 = LDS-resident engine (first implementation, kept as a second opinion); 3 =
  * register-resident engine in 256-lane workgroups that re-bin their playouts by action class {move, switch / pass,

@@ -446,6 +446,8 @@ struct RoundArgs {
   uint8_t *sres;            // scratch: total results
   uint32_t suspend_below;
   uint32_t *queue;          // this round's queue head
+  uint32_t lanes;           // lanes of a wave that take playouts (0 / 64: all); a tail round runs a few playouts per wave
+  const uint32_t *order;    // round 0, nullable: queue position -> playout (k_queue_order: the likely-long playouts first)
 };
 
 // One launch drains a GROUP of independent batches (oakgpu_rollout_group_dev): the queue hands out GLOBAL playout
@@ -502,6 +504,53 @@ static __device__ unsigned long long g_timeline[5 * 16384];
 #define OAK_TL(slot, v)
 #endif
 
+// Queue order of a group launch: LONGEST-EXPECTED FIRST.  The launch ends with its longest playout, and the longest are the
+// 0.1% that run into the step cap: stalemates -- a Rage-locked or PP-less (Struggle) attacker whose Normal-type hits cannot
+// touch a Ghost, a frozen Ghost nobody can hurt.  Measured on the CPU oracle (3 x 65,536 random OU playouts, 183 capped):
+// 99.5% of the capped playouts have a Ghost-type Pokemon on one of the two teams, against 22% of all playouts; the rest had a
+// Ditto (with Ghosts and Dittos: 183 of 183, 29% of all playouts).  A playout
+// that starts when the queue runs dry still has its 1,000 dependent turn-steps in front of it; one that started in the first
+// fifth of the launch has most of them behind it.  So the playouts with a Ghost on either team go to the front of the queue
+// (order[] filled from the front), the others behind them (filled from the back).  Pure scheduling: results are indexed by
+// playout and never depend on it.
+__global__ __launch_bounds__(256) void k_queue_order(GroupArgs g, uint32_t *order, uint32_t *counters) {
+  __shared__ uint32_t starts[MAX_GROUP + 1];
+  for (uint32_t i = threadIdx.x; i < g.count; i += 256) starts[i] = g.table[i].start;
+  if (threadIdx.x == 0) starts[g.count] = 0xFFFFFFFFu;
+  __syncthreads();
+  const uint32_t idx = blockIdx.x * 256 + threadIdx.x;
+  bool suspect = false;
+  if (idx < g.total) {
+    uint32_t lo = 0, hi = g.count;
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (starts[mid] <= idx) lo = mid; else hi = mid; }
+    const BatchDesc &bd = g.table[lo];
+    const uint8_t *b = bd.battles + (size_t)(idx - bd.start) * 384;
+#pragma unroll
+    for (int side = 0; side < 2; ++side)
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        const uint32_t ty = b[side * SIDE_SZ + k * PK_SZ + P_TYPES];
+        const uint32_t sp = b[side * SIDE_SZ + k * PK_SZ + P_SPECIES];
+        suspect |= sp != 0 && ((ty & 15) == T_Ghost || (ty >> 4) == T_Ghost || sp == 132 /* Ditto: Transform into a stalemate */);
+      }
+  }
+  const uint64_t ms = __ballot(suspect), mo = __ballot(idx < g.total && !suspect);
+  const uint32_t wl = threadIdx.x & 63;
+  uint32_t bs = 0, bo = 0;
+  if (wl == 0) { if (ms) bs = atomicAdd(counters + 0, (uint32_t)__popcll(ms)); if (mo) bo = atomicAdd(counters + 1, (uint32_t)__popcll(mo)); }
+  bs = __shfl(bs, 0, 64);
+  bo = __shfl(bo, 0, 64);
+  if (idx < g.total) {
+    const uint64_t below = (1ull << wl) - 1;
+    if (suspect) order[bs + (uint32_t)__popcll(ms & below)] = idx;
+    else order[g.total - 1 - (bo + (uint32_t)__popcll(mo & below))] = idx;
+  }
+}
+
+#ifndef OAK_LONG_STEPS
+#define OAK_LONG_STEPS 200
+#endif
+constexpr uint32_t LONG_STEPS = OAK_LONG_STEPS;
 template <int BLK, int WPS>
 __global__ __launch_bounds__(BLK, WPS) void k_rollout_queue(GroupArgs g_in, RoundArgs q_in) {
   extern __shared__ __align__(16) uint8_t smem[];
@@ -530,6 +579,7 @@ __global__ __launch_bounds__(BLK, WPS) void k_rollout_queue(GroupArgs g_in, Roun
   FastPrng g;
   g.s0 = g.s1 = 0;
   uint32_t idx = NONE, result = 0, steps = 0;
+  if (q_in.lanes && wl >= q_in.lanes) idx = DONE; // (tail round: this lane stays empty)
   bool dry = false; // wave-uniform: the queue has handed out its last playout
   OAK_PROF_ZERO();
   OAK_TL(0, wall_clock64());
@@ -552,7 +602,8 @@ __global__ __launch_bounds__(BLK, WPS) void k_rollout_queue(GroupArgs g_in, Roun
       if (need) {
         const uint32_t my = base + (uint32_t)__popcll(mask & ((1ull << wl) - 1));
         if (my < total) {
-          idx = resume ? COLD_Q(list_in, const uint32_t *)[my] : my;
+          const uint32_t *order = COLD_Q(order, const uint32_t *);
+          idx = resume ? COLD_Q(list_in, const uint32_t *)[my] : order ? order[my] : my;
           const BatchDesc *bd = find_batch(cold, idx);
           const uint32_t k = idx - bd->start; // playout k of its batch
           const uint32_t *dsrc = resume ? COLD_Q(sd, const uint32_t *) + 2 * (size_t)idx : (const uint32_t *)bd->durations + 2 * (size_t)k;
@@ -581,6 +632,9 @@ __global__ __launch_bounds__(BLK, WPS) void k_rollout_queue(GroupArgs g_in, Roun
       ++steps;
       playing = (result & 15) == 0 && steps < max_steps;
     }
+    // a wave that holds a playout far beyond the usual length (99.5% end before 250 turn-steps) is on the launch's critical
+    // path -- a 1000-step chain: it goes first on its SIMD
+    if (__ballot(playing && steps > LONG_STEPS)) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0);
     // wave-uniform: the queue is dry and too few lanes are still playing -> hand them to the next round
     const uint64_t still = __ballot(playing);
     const bool suspend = dry && still != 0 && (uint32_t)__popcll(still) < suspend_below;
@@ -1139,6 +1193,12 @@ struct oakgpu_ctx {
   uint8_t *d_scratch;     // suspended playout state: n x (384 + 8 + 1) bytes + two n-entry index lists
   size_t scratch_n;
   int rounds_auto;        // a launch that saturates the device runs as one dispatch (no regrouping rounds)
+  int tail_below;         // > 0: a SATURATED launch parks the lanes of dry waves with fewer live lanes than this and ONE follow-up
+  int tail_waves;         //      dispatch of this many waves (0 = one per CU) finishes them, a few to a wave (the tail)
+  int tail_lanes;         //      lanes per wave of that dispatch that take playouts (0 = all 64)
+  int queue_order;        // 1 (default): a saturated launch hands its playouts out likely-longest first (k_queue_order)
+  uint32_t *d_order;      // total entries
+  size_t order_n;
   int n_cu;               // compute units of the device
   static constexpr int TABLE_SLOTS = 8;
   void *h_table, *d_table; // batch tables of the group launches: pinned host ring -> device ring
@@ -1300,6 +1360,16 @@ int oakgpu_create(oakgpu_ctx **out, int device) {
   c->rounds = 4;
   c->suspend_below = 32;
   c->round_shrink = 3;
+  c->tail_below = 0;
+  c->tail_waves = 0;
+  if (const char *env = getenv("OAKGPU_TAIL_BELOW")) c->tail_below = atoi(env) < 0 ? 0 : atoi(env) > 64 ? 64 : atoi(env);
+  if (const char *env = getenv("OAKGPU_TAIL_WAVES")) c->tail_waves = atoi(env) < 0 ? 0 : atoi(env);
+  c->queue_order = 1;
+  if (const char *env = getenv("OAKGPU_QUEUE_ORDER")) c->queue_order = atoi(env) != 0;
+  c->d_order = nullptr;
+  c->order_n = 0;
+  c->tail_lanes = 0;
+  if (const char *env = getenv("OAKGPU_TAIL_LANES")) c->tail_lanes = atoi(env) < 0 ? 0 : atoi(env) > 64 ? 64 : atoi(env);
   if (const char *env = getenv("OAKGPU_ROUNDS")) c->rounds = atoi(env) < 1 ? 1 : atoi(env) > 8 ? 8 : atoi(env);
   if (const char *env = getenv("OAKGPU_SUSPEND_BELOW")) c->suspend_below = atoi(env) < 0 ? 0 : atoi(env) > 64 ? 64 : atoi(env);
   if (const char *env = getenv("OAKGPU_ROUND_SHRINK")) c->round_shrink = atoi(env) < 1 ? 1 : atoi(env);
@@ -1326,6 +1396,7 @@ void oakgpu_destroy(oakgpu_ctx *c) {
   if (c->d_sizes) (void)hipFree(c->d_sizes);
   if (c->d_queue) (void)hipFree(c->d_queue);
   if (c->d_scratch) (void)hipFree(c->d_scratch);
+  if (c->d_order) (void)hipFree(c->d_order);
   for (auto &b : c->stage) if (b.p) (void)hipFree(b.p);
   for (auto &b : c->ws) if (b.p) (void)hipFree(b.p);
   if (c->tev_valid) for (auto &e : c->tev) (void)hipEventDestroy(e);
@@ -1365,6 +1436,20 @@ int oakgpu_set_regroup(oakgpu_ctx *c, int rounds, int suspend_below, int shrink)
   c->suspend_below = suspend_below;
   c->round_shrink = shrink;
   c->rounds_auto = 0; // an explicit setting applies to every launch, saturating or not
+  return 0;
+}
+
+int oakgpu_set_queue_order(oakgpu_ctx *c, int on) {
+  if (!c) return bad("null ctx");
+  c->queue_order = on != 0;
+  return 0;
+}
+
+int oakgpu_set_tail_pack(oakgpu_ctx *c, int below, int waves, int lanes) {
+  if (!c || below < 0 || below > 64 || waves < 0 || lanes < 0 || lanes > 64) return bad("oakgpu_set_tail_pack: bad argument");
+  c->tail_below = below;
+  c->tail_waves = waves;
+  c->tail_lanes = lanes;
   return 0;
 }
 
@@ -1460,7 +1545,8 @@ static int launch_group(oakgpu_ctx *c, const oak::BatchDesc *descs, uint32_t cou
   // regrouping rounds pay off while the launch leaves SIMDs idle in its tail; a launch that saturates the device
   // for most of its life (a group of batches) runs as a single dispatch (measured: DESIGN.md 3)
   // ... and so does a launch capped at a few steps (stepping a resident batch turn by turn): there is no tail to regroup
-  const int rounds = (c->suspend_below > 0 && waves >= 8 && !(c->rounds_auto && (saturated || max_steps <= 64))) ? c->rounds : 1;
+  const bool tail_pack = saturated && c->tail_below > 0 && max_steps > 64;
+  const int rounds = tail_pack ? 2 : (c->suspend_below > 0 && waves >= 8 && !(c->rounds_auto && (saturated || max_steps <= 64))) ? c->rounds : 1;
   if (rounds > 1 && c->scratch_n < total) {
     if (c->d_scratch) { HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipFree(c->d_scratch)); c->d_scratch = nullptr; }
     HIPCHK(hipMalloc((void **)&c->d_scratch, (size_t)total * (384 + 8 + 4 + 4) + (((size_t)total + 15) & ~(size_t)15)));
@@ -1472,19 +1558,31 @@ static int launch_group(oakgpu_ctx *c, const oak::BatchDesc *descs, uint32_t cou
   lists[1] = lists[0] ? lists[0] + c->scratch_n : nullptr;
   uint8_t *sres = lists[1] ? (uint8_t *)(lists[1] + c->scratch_n) : nullptr;
   const oak::GroupArgs g{dt, count, total, max_steps, prep};
+  const uint32_t *order = nullptr;
+  if (c->queue_order && saturated && max_steps > 250) { // (a launch that does not fill the device has no queue to speak of)
+    if (c->order_n < total) {
+      if (c->d_order) { HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipFree(c->d_order)); c->d_order = nullptr; }
+      HIPCHK(hipMalloc((void **)&c->d_order, (size_t)total * 4));
+      c->order_n = total;
+    }
+    hipLaunchKernelGGL(oak::k_queue_order, dim3((total + 255) / 256), dim3(256), 0, c->stream, g, c->d_order, c->d_queue + 32);
+    order = c->d_order;
+  }
   for (int r = 0; r < rounds; ++r) {
     oak::RoundArgs q{};
+    q.order = r == 0 ? order : nullptr;
     q.list_in = r ? lists[(r - 1) & 1] : nullptr;
     q.n_in = r ? c->d_queue + 2 * r - 1 : nullptr; // = count_out of round r - 1
     q.list_out = lists[r & 1];
     q.count_out = c->d_queue + 2 * r + 1;
     q.sb = sb; q.sd = sd; q.sres = sres;
-    q.suspend_below = r + 1 < rounds ? (uint32_t)c->suspend_below : 0u;
+    q.suspend_below = r + 1 < rounds ? (uint32_t)(tail_pack ? c->tail_below : c->suspend_below) : 0u;
     q.queue = c->d_queue + 2 * r;
+    q.lanes = (tail_pack && r > 0) ? (uint32_t)c->tail_lanes : 0u;
 #define OAK_LAUNCH_Q(W) hipLaunchKernelGGL((oak::k_rollout_queue<64, W>), dim3(waves), dim3(64), lq, c->stream, g, q)
     if (c->waves_per_simd >= 4) OAK_LAUNCH_Q(4); else if (c->waves_per_simd == 3) OAK_LAUNCH_Q(3); else OAK_LAUNCH_Q(2);
 #undef OAK_LAUNCH_Q
-    waves = (waves + c->round_shrink - 1) / c->round_shrink;
+    waves = tail_pack ? (uint32_t)(c->tail_waves > 0 ? c->tail_waves : c->n_cu) : (waves + c->round_shrink - 1) / c->round_shrink;
     if (waves < 1) waves = 1;
   }
   HIPCHK(hipGetLastError());

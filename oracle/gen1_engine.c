@@ -17,6 +17,31 @@
  * kernel):  [speed tie] -> [confusion self-hit] -> [full paralysis] -> [thrash/bide
  * duration] -> [metronome] -> accuracy -> critical hit -> damage roll -> [multi-hit /
  * binding count] -> [secondary-effect chance] -> [secondary duration].
+ *
+ * RESTATEMENT CHOICES THAT NOTHING IN THE REFERENCE CAN CONFIRM (libpkmn's source is absent; these follow the
+ * author's reading of the published gen-1 / Pokemon-Showdown mechanics; each lists what the alternative under
+ * pkmn/engine's published `-Dshowdown` code path would be, should a maintainer hold the real library against it):
+ *  1. Multi-hit count (DoubleSlap, PinMissile, ... `EFF_MultiHit`) is rolled AFTER the critical-hit and damage rolls
+ *     (below: `hits = dist[rng_range(b, 0, 8)]` behind randomize_damage).  Alternative: the count rolled right after the
+ *     accuracy check and BEFORE crit / damage -- same number of LCG draws per move, but the three rolls would see each
+ *     other's values: every multi-hit move's (crit, damage, hits) triple would differ although their distributions agree.
+ *  2. Counter deals `last_damage * 2`, gated by the foe's `last_moves[].counterable` byte (set for Normal / Fighting
+ *     moves other than Counter) and a non-zero last_damage.  Alternative (Showdown's gen-1 Counter): gated on the foe's
+ *     last SELECTED move's type and on `last_damage` of either side, with the Desync-Clause failures of the cartridge
+ *     corner cases (Counter after a switch, after a multi-turn move's second turn); the alternative changes WHEN Counter
+ *     fails, never its damage.
+ *  3. Psywave draws `rng_range(1, level * 3 / 2)`: uniform on 1 .. max - 1, never 0, never failing.  Alternative: Showdown
+ *     draws `random(0, max)` and FAILS the move on a 0 (Desync Clause Mod); one draw either way, so the LCG stream stays
+ *     aligned, but 1 in `max` Psywaves (1 / 150 at level 100) would do nothing and the others would be uniform on 1 .. max - 1
+ *     with the draw mapped differently.
+ *  4. Accuracy (`move_hit`) is rolled BEFORE the critical-hit and damage rolls for every damaging move (Showdown order:
+ *     immunity, accuracy, then damage).  Alternative (cartridge order, which pkmn/engine uses without -Dshowdown): crit and
+ *     damage first, accuracy last -- a miss would then have consumed two more draws.
+ * What constrains them today: the 13 known answers of cpp/src/search-test.cc:50-109 (sleep / confusion only) and the
+ * TUTORIAL.md:46-70 search result (Body Slam / Psychic / Thunder Wave / Rest / Recover: paralysis, secondary chances,
+ * crits, damage rolls, speed order; reproduced within tolerance by tests/test_gpu_search.py) -- neither exercises a
+ * multi-hit move, Counter or Psywave, and a 1000-fold-averaged value does not see roll ORDER.  Parity at the libpkmn
+ * boundary stays UNPINNED.
  */
 #include "oracle.h"
 #include "gen1_tables.h"
