@@ -194,6 +194,7 @@ public:
     RolloutResult out{std::vector<float>(n), std::vector<uint32_t>(n), std::vector<uint8_t>(n)};
     if (final_battles) final_battles->assign(size_t{n} * OAKGPU_BATTLE_SIZE, 0);
     for (size_t draws = size_t{n} * 160 + 4096;; draws *= 2) { // grow the generator's output until n playouts fit
+      if (draws > (size_t{1} << 30)) throw std::runtime_error{"oakgpu: the shared generator's stream would exceed 2^30 draws"}; // (before the cast below)
       std::vector<uint64_t> stream(draws);
       check(oakgpu_mt19937_fill(seed, 0, stream.data(), stream.size()));
       uint64_t used = 0;

@@ -55,9 +55,13 @@ Rccl &rccl() {
   static Rccl r;
   static std::once_flag once;
   std::call_once(once, [] {
-    for (const char *name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so.1"}) {
-      r.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+    // the copy the process ALREADY holds first (RTLD_NOLOAD matches by SONAME: torch's bundled RCCL is "librccl.so.1"), so a
+    // torch program never ends up with two RCCL runtimes; only then the search path, versioned name before the dev symlink
+    r.lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL | RTLD_NOLOAD);
+    if (!r.lib) r.lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL | RTLD_NOLOAD);
+    for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
       if (r.lib) break;
+      r.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
     }
     if (!r.lib) { r.why = std::string("RCCL not found: ") + dlerror(); return; }
     r.get_unique_id = (int (*)(rccl_unique_id *))dlsym(r.lib, "ncclGetUniqueId");

@@ -550,7 +550,9 @@ __host__ __device__ constexpr int ar_dense_row(int d) { return d < 6 ? d - 1 : d
 // compact LDS slot of a one-hot row (types 5..19, rows 209..228, rows 398..426) and back
 __device__ __forceinline__ uint32_t ar_sparse_slot(uint32_t row) { return row < 20 ? row - 5 : row < 229 ? row - 209 + 15 : row - 398 + 35; }
 __host__ __device__ constexpr int ar_sparse_row(int slot) { return slot < 15 ? slot + 5 : slot < 35 ? slot - 15 + 209 : slot - 35 + 398; }
+template <int WAVES = AR_WAVES>
 __device__ __forceinline__ void embed_arows_body(const EmbedTileArgs &a, float *lds_f, const uint32_t bid, const uint32_t nblocks) {
+  constexpr int BLOCK = WAVES * 64, MAXR = 8 * AR_WAVES / WAVES;
   EL_T0();
   const NetDev &N = a.net;
   const int hidden = N.a_hidden, out_dim = N.a_out;
@@ -559,15 +561,15 @@ __device__ __forceinline__ void embed_arows_body(const EmbedTileArgs &a, float *
   float *Wd = W0s + (AR_SPARSE + 1) * ER_RS;            // dense fragment: [k-step][channel block][lane]
   float *W1s = Wd + AR_DENSE_WORDS;                     // the second layer's fragments: [block][k-step][lane]
   const int img_words = (AR_SPARSE + 1) * ER_RS + AR_DENSE_WORDS + NBo * 64 * 64;
-  float4 img_t[8];
-  stage_image_load<AR_BLOCK, 8>(img_t, N.a_img, img_words);
+  float4 img_t[MAXR];
+  stage_image_load<BLOCK, MAXR>(img_t, N.a_img, img_words);
   const uint32_t lane = threadIdx.x & 63, wib = threadIdx.x >> 6, r32 = lane & 31, hh = lane >> 5;
   uint32_t *wl = (uint32_t *)(W1s + NBo * 64 * 64) + wib * AR_WAVE_WORDS; // this wave's private LDS
   uint32_t *dst_off = wl + ER_ITEMS * AR_ITEM_WORDS;
   float *hp_ratio = (float *)(dst_off + ER_ITEMS);
   const uint32_t items = a.n * 2;
   const uint32_t nmt = (items + ER_ITEMS - 1) / ER_ITEMS;
-  const uint32_t stride = nblocks * AR_WAVES;
+  const uint32_t stride = nblocks * WAVES;
   EL_MARK(0);
   // ---- encode: BOTH lanes (r, 0) and (r, 1) encode item r straight from global memory (two dependent loads: order ->
   // stored Pokemon) -- the same instructions for the whole wave; each keeps the dense values of its own k-half in
@@ -638,9 +640,9 @@ __device__ __forceinline__ void embed_arows_body(const EmbedTileArgs &a, float *
     }
     zero_blocks(a.emb, hh == 0 ? dead_off : 0xFFFFFFFFu, out_dim + 1);
   };
-  uint32_t mt = bid * AR_WAVES + wib;
+  uint32_t mt = bid * WAVES + wib;
   if (mt < nmt) encode(mt); // needs no weights: the image's round trip runs under it
-  stage_image_store<AR_BLOCK, 8>(lds_f, img_t, img_words);
+  stage_image_store<BLOCK, MAXR>(lds_f, img_t, img_words);
   __syncthreads(); // weights staged (the only workgroup barrier of the kernel)
   while (mt < nmt) {
     __builtin_amdgcn_wave_barrier();
@@ -733,6 +735,8 @@ __global__ __launch_bounds__(AR_BLOCK) void k_embed_arows(EmbedTileArgs a) {
   extern __shared__ __align__(16) float lds_f[];
   embed_arows_body(a, lds_f, blockIdx.x, gridDim.x);
 }
+// (Measured and rejected, round 3: the same body as eight waves of 256 registers -- 237 used, no scratch -- instead of sixteen
+// of 128 with 49 spilled: 86.5 vs 86.4 us.  The spills sit in the encode, which already overlaps other waves' MFMA phases.)
 
 // ---- K2, the party-slot pass in the same form as k_embed_arows (the default).  A bench Pokemon has 6 DENSE features (bias,
 // 5 stats: 3 k-steps x 4 blocks = 12 MFMAs in the "lane = item" orientation) and 7 ONE-HOT rows (4 move slots, status, 2

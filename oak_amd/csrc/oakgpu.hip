@@ -513,37 +513,43 @@ static __device__ unsigned long long g_timeline[5 * 16384];
 // fifth of the launch has most of them behind it.  So the playouts with a Ghost on either team go to the front of the queue
 // (order[] filled from the front), the others behind them (filled from the back).  Pure scheduling: results are indexed by
 // playout and never depend on it.
-__global__ __launch_bounds__(256) void k_queue_order(GroupArgs g, uint32_t *order, uint32_t *counters) {
+__global__ __launch_bounds__(1024) void k_queue_order(GroupArgs g, uint32_t *order, uint32_t *counters) {
   __shared__ uint32_t starts[MAX_GROUP + 1];
-  for (uint32_t i = threadIdx.x; i < g.count; i += 256) starts[i] = g.table[i].start;
+  __shared__ uint32_t wave_s[16], wave_o[16], base_s, base_o;
+  for (uint32_t i = threadIdx.x; i < g.count; i += 1024) starts[i] = g.table[i].start;
   if (threadIdx.x == 0) starts[g.count] = 0xFFFFFFFFu;
   __syncthreads();
-  const uint32_t idx = blockIdx.x * 256 + threadIdx.x;
+  const uint32_t idx = blockIdx.x * 1024 + threadIdx.x, wl = threadIdx.x & 63, wib = threadIdx.x >> 6;
   bool suspect = false;
   if (idx < g.total) {
     uint32_t lo = 0, hi = g.count;
     while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (starts[mid] <= idx) lo = mid; else hi = mid; }
     const BatchDesc &bd = g.table[lo];
-    const uint8_t *b = bd.battles + (size_t)(idx - bd.start) * 384;
+    const uint32_t *b = (const uint32_t *)(bd.battles + (size_t)(idx - bd.start) * 384);
+    uint32_t w[12]; // the dword {status, species, types, level} of each of the 12 Pokemon: all twelve loads in flight together
 #pragma unroll
-    for (int side = 0; side < 2; ++side)
+    for (int k = 0; k < 12; ++k) w[k] = b[((k / 6) * SIDE_SZ + (k % 6) * PK_SZ + P_STATUS) / 4];
 #pragma unroll
-      for (int k = 0; k < 6; ++k) {
-        const uint32_t ty = b[side * SIDE_SZ + k * PK_SZ + P_TYPES];
-        const uint32_t sp = b[side * SIDE_SZ + k * PK_SZ + P_SPECIES];
-        suspect |= sp != 0 && ((ty & 15) == T_Ghost || (ty >> 4) == T_Ghost || sp == 132 /* Ditto: Transform into a stalemate */);
-      }
+    for (int k = 0; k < 12; ++k) {
+      const uint32_t sp = (w[k] >> 8) & 0xFF, ty = (w[k] >> 16) & 0xFF;
+      suspect |= sp != 0 && ((ty & 15) == T_Ghost || (ty >> 4) == T_Ghost || sp == 132 /* Ditto: Transform into a stalemate */);
+    }
   }
+  // one pair of atomics per 1,024 playouts (a pair per wave: 41,000 atomics on two addresses took longer than the loads)
   const uint64_t ms = __ballot(suspect), mo = __ballot(idx < g.total && !suspect);
-  const uint32_t wl = threadIdx.x & 63;
-  uint32_t bs = 0, bo = 0;
-  if (wl == 0) { if (ms) bs = atomicAdd(counters + 0, (uint32_t)__popcll(ms)); if (mo) bo = atomicAdd(counters + 1, (uint32_t)__popcll(mo)); }
-  bs = __shfl(bs, 0, 64);
-  bo = __shfl(bo, 0, 64);
+  if (wl == 0) { wave_s[wib] = (uint32_t)__popcll(ms); wave_o[wib] = (uint32_t)__popcll(mo); }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t ts = 0, to = 0;
+    for (int q = 0; q < 16; ++q) { const uint32_t a = wave_s[q], c = wave_o[q]; wave_s[q] = ts; wave_o[q] = to; ts += a; to += c; }
+    base_s = ts ? atomicAdd(counters + 0, ts) : 0;
+    base_o = to ? atomicAdd(counters + 1, to) : 0;
+  }
+  __syncthreads();
   if (idx < g.total) {
     const uint64_t below = (1ull << wl) - 1;
-    if (suspect) order[bs + (uint32_t)__popcll(ms & below)] = idx;
-    else order[g.total - 1 - (bo + (uint32_t)__popcll(mo & below))] = idx;
+    if (suspect) order[base_s + wave_s[wib] + (uint32_t)__popcll(ms & below)] = idx;
+    else order[g.total - 1 - (base_o + wave_o[wib] + (uint32_t)__popcll(mo & below))] = idx;
   }
 }
 
@@ -1565,7 +1571,7 @@ static int launch_group(oakgpu_ctx *c, const oak::BatchDesc *descs, uint32_t cou
       HIPCHK(hipMalloc((void **)&c->d_order, (size_t)total * 4));
       c->order_n = total;
     }
-    hipLaunchKernelGGL(oak::k_queue_order, dim3((total + 255) / 256), dim3(256), 0, c->stream, g, c->d_order, c->d_queue + 32);
+    hipLaunchKernelGGL(oak::k_queue_order, dim3((total + 1023) / 1024), dim3(1024), 0, c->stream, g, c->d_order, c->d_queue + 32);
     order = c->d_order;
   }
   for (int r = 0; r < rounds; ++r) {
