@@ -339,9 +339,12 @@ typedef struct {
   double policy_temp, policy_min;
   uint32_t max_battle_length;
   uint64_t seed;
+  int32_t keep_node;           /* generate's --keep-node (generate.cc:324-333): one heap for the game, Heap::update with the played
+                                * indices and the observation after every turn (the subtree is searched on); 0 = a fresh heap per turn */
+  uint32_t nodes_kept;         /* out: how many of the game's updates found their child (RuntimeData::update_with_node_counter) */
 } oakgpu_selfplay_params;
 int oakgpu_selfplay_game(oakgpu_ctx *ctx, oakgpu_net *net /* nullable for eval != 1 */, const uint8_t *teams /* 60 */,
-                         uint64_t battle_seed, const oakgpu_selfplay_params *params, uint8_t *buffer, size_t capacity,
+                         uint64_t battle_seed, oakgpu_selfplay_params *params, uint8_t *buffer, size_t capacity,
                          size_t *written, uint32_t *n_frames, uint8_t *result);
 
 /* ---- batched PKMN::battle(p1, p2, seed) (pkmn.h:50-57, init.h:90-154), level 100 sets.

@@ -57,7 +57,7 @@ class FrameUpdate(C.Structure):       # oakgpu_frame_update
 
 class SelfplayParams(C.Structure):    # oakgpu_selfplay_params
     _fields_ = [("search", SearchParams), ("policy_mode", C.c_char * 16), ("policy_temp", C.c_double), ("policy_min", C.c_double),
-                ("max_battle_length", C.c_uint32), ("seed", C.c_uint64)]
+                ("max_battle_length", C.c_uint32), ("seed", C.c_uint64), ("keep_node", C.c_int32), ("nodes_kept", C.c_uint32)]
 
 
 # include/pkmn.h: the libpkmn-named single-battle ABI (batch-of-one wrappers, pkmn_shim.hip)

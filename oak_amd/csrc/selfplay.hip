@@ -160,7 +160,7 @@ int oakgpu_frames_read(const uint8_t *buffer, size_t size, uint8_t *battle, uint
   return 0;
 }
 
-int oakgpu_selfplay_game(oakgpu_ctx *ctx, oakgpu_net *net, const uint8_t *teams, uint64_t battle_seed, const oakgpu_selfplay_params *prm,
+int oakgpu_selfplay_game(oakgpu_ctx *ctx, oakgpu_net *net, const uint8_t *teams, uint64_t battle_seed, oakgpu_selfplay_params *prm,
                          uint8_t *buffer, size_t capacity, size_t *written, uint32_t *n_frames, uint8_t *result_out) {
   if (!ctx || !teams || !prm || !buffer) return oakgpu_fail_msg("oakgpu_selfplay_game: null argument");
   // PKMN::battle(p1, p2, seed) + the opening update(0, 0) (generate.cc:238-240), on the device
@@ -172,11 +172,14 @@ int oakgpu_selfplay_game(oakgpu_ctx *ctx, oakgpu_net *net, const uint8_t *teams,
   uint64_t rng = prm->seed ^ 0x9FB21C651E98DF25ull;
   const uint32_t max_len = prm->max_battle_length ? prm->max_battle_length : 1000;
   oakgpu_search_params sp = prm->search;
+  struct HeapOwner { oakgpu_heap *h = nullptr; ~HeapOwner() { oakgpu_heap_destroy(h); } } heap;
+  if (prm->keep_node && oakgpu_heap_create(&heap.h)) return -1;
+  prm->nodes_kept = 0;
   while ((result & 15) == 0) {
     if (frames.size() >= max_len) return oakgpu_fail_msg("oakgpu_selfplay_game: max battle length exceeded (generate.cc:268-271)");
     oakgpu_search_output out;
     sp.seed = splitmix64(rng);
-    if (int rc = oakgpu_search(ctx, net, battle, durations, result, &sp, &out)) return rc;
+    if (int rc = oakgpu_search_heap(ctx, net, heap.h, battle, durations, result, &sp, nullptr, &out)) return rc;
     double pol1[9], pol2[9];
     if (!get_policy(out.p1_empirical, out.p1_nash, out.m, prm->policy_mode, prm->policy_temp > 0 ? prm->policy_temp : 1.0, prm->policy_min, pol1) ||
         !get_policy(out.p2_empirical, out.p2_nash, out.n, prm->policy_mode, prm->policy_temp > 0 ? prm->policy_temp : 1.0, prm->policy_min, pol2))
@@ -191,7 +194,9 @@ int oakgpu_selfplay_game(oakgpu_ctx *ctx, oakgpu_net *net, const uint8_t *teams,
     for (int k = 0; k < 9; ++k) { u.p1_empirical[k] = out.p1_empirical[k]; u.p1_nash[k] = out.p1_nash[k]; u.p2_empirical[k] = out.p2_empirical[k]; u.p2_nash[k] = out.p2_nash[k]; }
     frames.push_back(u);
     // PKMN::update(battle, c1, c2, options); durations <- options (generate.cc:319-322)
-    if (int rc = oakgpu_update(ctx, battle, &u.c1, &u.c2, durations, nullptr, nullptr, 1, &result)) return rc;
+    uint8_t obs[16];
+    if (int rc = oakgpu_update(ctx, battle, &u.c1, &u.c2, durations, obs, nullptr, 1, &result)) return rc;
+    if (heap.h) prm->nodes_kept += (uint32_t)oakgpu_heap_update(heap.h, (uint8_t)i, (uint8_t)j, obs); // generate.cc:324-329
   }
   if (result_out) *result_out = result;
   if (n_frames) *n_frames = (uint32_t)frames.size();

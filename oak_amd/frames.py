@@ -56,9 +56,11 @@ def write_frames(battle, result, updates):
 
 
 def selfplay_game(ctx, teams, battle_seed, iterations=1 << 12, batch=1024, bandit="ucb", c=2.0, evaluator="mc", policy_mode="e",
-                  policy_temp=1.0, policy_min=0.0, max_battle_length=0, seed=1, alpha=0.05, root_rolls=3, other_rolls=1):
+                  policy_temp=1.0, policy_min=0.0, max_battle_length=0, seed=1, alpha=0.05, root_rolls=3, other_rolls=1, keep_node=False,
+                  stats=None):
     """One self-play game on the GPU path (oakgpu_selfplay_game).  teams: uint8[2, 6, 5] (species + 4 moves per set).
-    Returns (record bytes, number of frames, final result byte)."""
+    keep_node: generate's --keep-node (one heap for the game, Heap::update after every turn); stats: optional dict that
+    receives "nodes_kept".  Returns (record bytes, number of frames, final result byte)."""
     use_net = not isinstance(evaluator, str)
     prm = _lib.SelfplayParams()
     prm.search = _lib.SearchParams(iterations=int(iterations), batch=int(batch), ucb_c=float(c),
@@ -69,10 +71,13 @@ def selfplay_game(ctx, teams, battle_seed, iterations=1 << 12, batch=1024, bandi
     prm.policy_mode = policy_mode.encode()
     prm.policy_temp, prm.policy_min = float(policy_temp), float(policy_min)
     prm.max_battle_length, prm.seed = int(max_battle_length), int(seed)
+    prm.keep_node = 1 if keep_node else 0
     t = np.ascontiguousarray(teams, dtype=np.uint8).reshape(60)
     cap = 4 + 2 + 384 + 1 + 83 * (int(max_battle_length) or 1000)
     out = np.zeros(cap, dtype=np.uint8)
     written, frames, result = C.c_size_t(0), C.c_uint32(0), C.c_uint8(0)
     _lib.check(ctx.lib.oakgpu_selfplay_game(ctx.handle, evaluator.handle if use_net else None, t.ctypes.data_as(C.c_void_p), int(battle_seed),
                                             C.byref(prm), out.ctypes.data_as(C.c_void_p), cap, C.byref(written), C.byref(frames), C.byref(result)))
+    if stats is not None:
+        stats["nodes_kept"] = int(prm.nodes_kept)
     return out[:written.value].tobytes(), int(frames.value), int(result.value)

@@ -61,3 +61,17 @@ def test_selfplay_with_the_network_evaluator_and_length_cap(gpu_ctx):
     with pytest.raises(RuntimeError, match="policy mode"):
         selfplay_game(gpu_ctx, teams, battle_seed=77, iterations=64, batch=64, policy_mode="q", seed=9)
     net.close()
+
+
+def test_selfplay_keep_node_searches_on_in_the_played_subtree(gpu_ctx):
+    """generate's --keep-node (generate.cc:324-333): one heap for the whole game, Heap::update(p1_index, p2_index, obs) after
+    every turn.  The record must replay exactly like any other, most updates find their child (the played action is the
+    most searched one), and the frames still carry `iterations` per turn (each turn's output starts from zero)."""
+    teams = np.array(benchmark_teams(), dtype=np.uint8)
+    stats = {}
+    rec, frames, result = selfplay_game(gpu_ctx, teams, battle_seed=4242, iterations=2048, batch=512, bandit="ucb", c=2.0, evaluator="mc",
+                                        policy_mode="e", seed=5, keep_node=True, stats=stats)
+    (game,) = read_frames(rec)
+    assert len(game["updates"]) == frames and _replay(gpu_ctx, game) == result
+    assert all(u["iterations"] == 2048 for u in game["updates"])
+    assert 0 < stats["nodes_kept"] <= frames and stats["nodes_kept"] >= frames // 4
