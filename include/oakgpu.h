@@ -68,6 +68,16 @@ int oakgpu_set_tail_pack(oakgpu_ctx *ctx, int below, int waves, int lanes);
  * against a Ghost), and the launch ends with its longest playout: started early, the 1,000-step chains are mostly done when
  * the queue runs dry.  Pure scheduling: results are indexed by playout and never depend on it. */
 int oakgpu_set_queue_order(oakgpu_ctx *ctx, int on);
+/* Long-playout migration inside a launch (mode 0 off, 1 = launches that saturate the device (default), 2 = every queue launch:
+ * tests): a wave hands a playout that is still running after `long_steps` turn-steps (default 300; 99.5% end before 250) to
+ * `adopters` dedicated waves (0 = one per two compute units), which from the first donation on hold only such playouts -- a dozen
+ * per wave at the top priority of their SIMD -- so the 1,000-step chains that end a launch advance at a sparse wave's pace
+ * long before the device drains.  State travels as the regrouping rounds' bit-exact image; results never depend on it. */
+int oakgpu_set_migration(oakgpu_ctx *ctx, int mode, int long_steps, int adopters);
+/* Diagnostic (synchronises the stream): the 64 control words of the last queue launch -- [0] playouts handed out, [32] / [33]
+ * the queue order's two counters, [40] donations, [41] adoptions, [42] bulk waves that left, [43] error bits (0 = none:
+ * 1 a ticket never arrived, 2 an adopter gave up waiting). */
+int oakgpu_get_queue_counters(oakgpu_ctx *ctx, uint32_t *out64);
 /* Rollout engine (results never depend on it; all three are bit-identical): 2 = register-resident engine, one wave per
  * workgroup, queue refill (default); 1 = LDS-resident engine (first implementation, kept as a second opinion); 3 =
  * register-resident engine in 256-lane workgroups that re-bin their playouts by action class {move, switch / pass,

@@ -448,6 +448,11 @@ struct RoundArgs {
   uint32_t *queue;          // this round's queue head
   uint32_t lanes;           // lanes of a wave that take playouts (0 / 64: all); a tail round runs a few playouts per wave
   const uint32_t *order;    // round 0, nullable: queue position -> playout (k_queue_order: the likely-long playouts first)
+  // long-playout migration (below): control words {tail, head, bulk waves exited, error}, one list entry per donation
+  uint32_t *adopt_ctl;
+  uint32_t *adopt_list;
+  uint32_t n_adopters;      // 0 = off; waves [0, n_adopters) adopt
+  uint32_t long_steps;      // a bulk wave donates a playout that is still running after this many turn-steps
 };
 
 // One launch drains a GROUP of independent batches (oakgpu_rollout_group_dev): the queue hands out GLOBAL playout
@@ -587,6 +592,23 @@ __global__ __launch_bounds__(BLK, WPS) void k_rollout_queue(GroupArgs g_in, Roun
   uint32_t idx = NONE, result = 0, steps = 0;
   if (q_in.lanes && wl >= q_in.lanes) idx = DONE; // (tail round: this lane stays empty)
   bool dry = false; // wave-uniform: the queue has handed out its last playout
+  // ---- long-playout migration.  The launch ends with its longest playouts -- 1,000-step chains -- and while the device is
+  // full such a playout advances at the pace of a full, divergent wave (31 us per turn-step).  So a BULK wave hands a playout
+  // that is still running after `long_steps` turn-steps (99.5% end before 250) to the ADOPTER waves (the first n_adopters
+  // waves, about one per CU): bit-exact state image to the scratch slot (the regrouping rounds' suspend image), agent-scope
+  // release, a ticket in the adoption list.  An adopter stops taking playouts from the main queue once the first donation
+  // exists, lets its own finish, and from then on holds only long playouts -- a dozen per wave, at the top priority of its
+  // SIMD -- so the chains run at a sparse wave's pace (4-8 us per turn-step) from their 200th step on instead of from the
+  // moment the device drains.  Every wait is bounded (a ticket reserved but not yet written; an adopter with nothing to
+  // adopt while bulk waves still run): on overflow the error word is set and the wave leaves.  Results are indexed by
+  // playout: they do not depend on who finishes a playout.
+  const uint32_t n_adopt = q_in.n_adopters, long_steps = q_in.long_steps;
+  const bool adopter = n_adopt != 0 && blockIdx.x < n_adopt;
+  const uint32_t g_total_guard = g_in.total; // (tickets live in [0, total): one per donation at most)
+  bool adopting = false; // adopter: a donation has been seen, no more playouts from the main queue
+  uint32_t idle_polls = 0, poll_tick = 15;
+  bool any_playing = false;
+  constexpr uint32_t SPIN_CAP = 1u << 22;
   OAK_PROF_ZERO();
   OAK_TL(0, wall_clock64());
 #ifdef OAKGPU_TIMELINE
@@ -594,8 +616,50 @@ __global__ __launch_bounds__(BLK, WPS) void k_rollout_queue(GroupArgs g_in, Roun
   unsigned long long tl_steps = 0;
 #endif
   for (;;) {
-    const bool need = idx == NONE;
-    const uint64_t mask = __ballot(need);
+    bool need = idx == NONE, load = false, from_scratch = resume;
+    uint64_t mask = __ballot(need);
+    // (an adopter looks at the adoption list every 16th turn-step, or at once when it has nothing to play: 256 sparse waves
+    // polling three words on every iteration saturate that L2 line's atomics and slow the whole launch down)
+    if (mask && adopter && ((++poll_tick & 15u) == 0 || !any_playing)) { // wave-uniform: an adopter's free lanes take donated playouts first
+      uint32_t *ctl = COLD_Q(adopt_ctl, uint32_t *);
+      uint32_t h = 0, k = 0, closed = 0;
+      if (wl == 0) {
+        for (int tries = 0; tries < 8; ++tries) {
+          // HEAD first, then TAIL: the tail only grows and the head never passes it, so tail - head cannot underflow (read the
+          // other way round, a head that moved in between claimed tickets beyond the list: a memory fault at full size)
+          const uint32_t hh = __hip_atomic_load(ctl + 1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+          const uint32_t t = __hip_atomic_load(ctl + 0, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+          if (t) closed |= 2; // (bit 1: a donation exists)
+          const uint32_t kk = t > hh ? min(t - hh, (uint32_t)__popcll(mask)) : 0u;
+          if (!kk) {
+            // every bulk wave has left (a wave's last donation is complete before it counts itself out) and nothing is waiting
+            if (__hip_atomic_load(ctl + 2, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - n_adopt &&
+                __hip_atomic_load(ctl + 0, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == hh &&
+                __hip_atomic_load(ctl + 1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == hh) closed |= 1;
+            break;
+          }
+          if (atomicCAS(ctl + 1, hh, hh + kk) == hh) { h = hh; k = kk; break; }
+        }
+      }
+      h = __shfl(h, 0, 64); k = __shfl(k, 0, 64); closed = __shfl(closed, 0, 64);
+      adopting = adopting || (closed & 2) != 0;
+      const uint32_t rank = (uint32_t)__popcll(mask & ((1ull << wl) - 1));
+      const bool take = need && rank < k;
+      uint32_t got = 0;
+      if (take && h + rank < g_total_guard) {
+        const uint32_t *slot = COLD_Q(adopt_list, const uint32_t *) + h + rank;
+        uint32_t spins = 0;
+        while ((got = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0 && ++spins < SPIN_CAP) __builtin_amdgcn_s_sleep(2);
+        if (!got) atomicOr(ctl + 3, 1u); // (a ticket that never arrived: reported, the playout is lost -- the tests would see it)
+      }
+      if (k) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); // the donors' images, step counts and PRNG states
+      if (take && got) { idx = got - 1; load = true; from_scratch = true; }
+      need = idx == NONE;
+      if ((closed & 1) && need) idx = DONE;              // adoption is over
+      mask = (adopting || (closed & 1)) ? 0 : __ballot(need); // once donations exist an adopter takes no more bulk work
+      need = need && mask != 0;
+    }
+    if (adopting) { mask = 0; need = false; } // (an adopter between two looks at the list: no bulk work either)
     if (mask) { // wave-uniform
       OAK_SCOPE(PS_REFILL);
       uint32_t base = 0;
@@ -610,25 +674,31 @@ __global__ __launch_bounds__(BLK, WPS) void k_rollout_queue(GroupArgs g_in, Roun
         if (my < total) {
           const uint32_t *order = COLD_Q(order, const uint32_t *);
           idx = resume ? COLD_Q(list_in, const uint32_t *)[my] : order ? order[my] : my;
-          const BatchDesc *bd = find_batch(cold, idx);
-          const uint32_t k = idx - bd->start; // playout k of its batch
-          const uint32_t *dsrc = resume ? COLD_Q(sd, const uint32_t *) + 2 * (size_t)idx : (const uint32_t *)bd->durations + 2 * (size_t)k;
-          const uint32_t *psrc = (const uint32_t *)bd->prng + 2 * (size_t)k;
-          g.s0 = psrc[0];
-          g.s1 = psrc[1];
-          e.load_battle_global(resume ? COLD_Q(sb, const uint8_t *) + (size_t)idx * 384 : bd->battles + (size_t)k * 384, dsrc[0], dsrc[1]);
-          if (prep) { // mcts.h:254-259
-            const uint32_t hi = g.next32(), lo = g.next32();
-            e.rng = ((uint64_t)hi << 32) | lo;
-            e.randomize_hidden();
-          }
-          result = resume ? COLD_Q(sres, const uint8_t *)[idx] : bd->results_in[k];
-          steps = resume ? bd->steps_out[k] : 0;
-        } else idx = DONE;
+          load = true;
+        } else idx = adopter ? NONE : DONE; // (an adopter's free lanes wait for donations until adoption is over)
+      }
+    }
+    if (__ballot(load)) { // wave-uniform: (re)fill the lanes that got a playout -- from its batch, or from its parked image
+      OAK_SCOPE(PS_REFILL);
+      if (load) {
+        const BatchDesc *bd = find_batch(cold, idx);
+        const uint32_t k = idx - bd->start; // playout k of its batch
+        const uint32_t *dsrc = from_scratch ? COLD_Q(sd, const uint32_t *) + 2 * (size_t)idx : (const uint32_t *)bd->durations + 2 * (size_t)k;
+        const uint32_t *psrc = (const uint32_t *)bd->prng + 2 * (size_t)k;
+        g.s0 = psrc[0];
+        g.s1 = psrc[1];
+        e.load_battle_global(from_scratch ? COLD_Q(sb, const uint8_t *) + (size_t)idx * 384 : bd->battles + (size_t)k * 384, dsrc[0], dsrc[1]);
+        if (prep && !from_scratch) { // mcts.h:254-259
+          const uint32_t hi = g.next32(), lo = g.next32();
+          e.rng = ((uint64_t)hi << 32) | lo;
+          e.randomize_hidden();
+        }
+        result = from_scratch ? COLD_Q(sres, const uint8_t *)[idx] : bd->results_in[k];
+        steps = from_scratch ? bd->steps_out[k] : 0;
       }
     }
     if (__ballot(idx != DONE) == 0) break;
-    bool playing = idx != DONE && (result & 15) == 0 && steps < max_steps;
+    bool playing = idx != DONE && idx != NONE && (result & 15) == 0 && steps < max_steps; // (NONE: an adopter's lane that waits)
 #ifdef OAKGPU_TIMELINE
     tl_steps += (unsigned long long)__popcll(__ballot(playing));
 #endif
@@ -639,12 +709,18 @@ __global__ __launch_bounds__(BLK, WPS) void k_rollout_queue(GroupArgs g_in, Roun
       playing = (result & 15) == 0 && steps < max_steps;
     }
     // a wave that holds a playout far beyond the usual length (99.5% end before 250 turn-steps) is on the launch's critical
-    // path -- a 1000-step chain: it goes first on its SIMD
-    if (__ballot(playing && steps > LONG_STEPS)) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0);
+    // path -- a 1000-step chain: it goes first on its SIMD (an adopter as soon as it adopts)
+    if (adopting || __ballot(playing && steps > LONG_STEPS)) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0);
+    any_playing = __ballot(playing) != 0;
+    if (adopter && !any_playing) { // nothing to play: wait for donations (bounded) without burning issue slots
+      __builtin_amdgcn_s_sleep(100);
+      if (++idle_polls > SPIN_CAP) { if (wl == 0) atomicOr(COLD_Q(adopt_ctl, uint32_t *) + 3, 2u); break; }
+    }
     // wave-uniform: the queue is dry and too few lanes are still playing -> hand them to the next round
     const uint64_t still = __ballot(playing);
     const bool suspend = dry && still != 0 && (uint32_t)__popcll(still) < suspend_below;
-    if (idx != DONE && (!playing || suspend)) { // retire the lane: publish a finished playout / park a suspended one
+    const bool lng = n_adopt != 0 && !adopter && playing && steps >= long_steps; // a bulk wave's long playout: to the adopters
+    if (idx != DONE && idx != NONE && (!playing || suspend || lng)) { // retire the lane: publish a finished playout / park a suspended or donated one
       OAK_SCOPE(PS_PUBLISH);
       const bool fin = !playing;
       e.normalize();
@@ -666,6 +742,19 @@ __global__ __launch_bounds__(BLK, WPS) void k_rollout_queue(GroupArgs g_in, Roun
       if (bdst) e.store_battle_global(bdst);
       idx = fin ? NONE : idx;
     }
+    const uint64_t dm = __ballot(lng);
+    if (dm) { // wave-uniform, rare: release the images, take tickets, write them
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      uint32_t *ctl = COLD_Q(adopt_ctl, uint32_t *);
+      const uint32_t leader = (uint32_t)__ffsll((unsigned long long)dm) - 1;
+      uint32_t base = 0;
+      if (wl == leader) base = atomicAdd(ctl + 0, (uint32_t)__popcll(dm));
+      base = __shfl(base, leader, 64);
+      if (lng) {
+        __hip_atomic_store(COLD_Q(adopt_list, uint32_t *) + base + (uint32_t)__popcll(dm & ((1ull << wl) - 1)), idx + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        idx = NONE; // the lane is free again
+      }
+    }
     if (suspend) {
       const uint32_t leader = (uint32_t)__ffsll((unsigned long long)still) - 1;
       uint32_t base = 0;
@@ -675,6 +764,7 @@ __global__ __launch_bounds__(BLK, WPS) void k_rollout_queue(GroupArgs g_in, Roun
       break;
     }
   }
+  if (n_adopt != 0 && !adopter && wl == 0) atomicAdd(COLD_Q(adopt_ctl, uint32_t *) + 2, 1u); // a bulk wave has left: it donates no more
   OAK_TL(2, wall_clock64());
 #ifdef OAKGPU_TIMELINE
   OAK_TL(4, tl_steps);
@@ -1202,6 +1292,9 @@ struct oakgpu_ctx {
   int tail_below;         // > 0: a SATURATED launch parks the lanes of dry waves with fewer live lanes than this and ONE follow-up
   int tail_waves;         //      dispatch of this many waves (0 = one per CU) finishes them, a few to a wave (the tail)
   int tail_lanes;         //      lanes per wave of that dispatch that take playouts (0 = all 64)
+  int migrate;            // long-playout migration (k_rollout_queue): 0 off, 1 (default) for launches that saturate the device, 2 always
+  int migrate_steps;      //   a bulk wave donates a playout still running after this many turn-steps (default 300)
+  int migrate_adopters;   //   adopter waves (0 = one per two CUs)
   int queue_order;        // 1 (default): a saturated launch hands its playouts out likely-longest first (k_queue_order)
   uint32_t *d_order;      // total entries
   size_t order_n;
@@ -1372,6 +1465,12 @@ int oakgpu_create(oakgpu_ctx **out, int device) {
   if (const char *env = getenv("OAKGPU_TAIL_WAVES")) c->tail_waves = atoi(env) < 0 ? 0 : atoi(env);
   c->queue_order = 1;
   if (const char *env = getenv("OAKGPU_QUEUE_ORDER")) c->queue_order = atoi(env) != 0;
+  c->migrate = 1;
+  c->migrate_steps = 300;
+  c->migrate_adopters = 0;
+  if (const char *env = getenv("OAKGPU_MIGRATE")) c->migrate = atoi(env) < 0 ? 0 : atoi(env) > 2 ? 2 : atoi(env);
+  if (const char *env = getenv("OAKGPU_MIGRATE_STEPS")) c->migrate_steps = atoi(env) < 1 ? 1 : atoi(env);
+  if (const char *env = getenv("OAKGPU_MIGRATE_ADOPTERS")) c->migrate_adopters = atoi(env) < 0 ? 0 : atoi(env);
   c->d_order = nullptr;
   c->order_n = 0;
   c->tail_lanes = 0;
@@ -1442,6 +1541,23 @@ int oakgpu_set_regroup(oakgpu_ctx *c, int rounds, int suspend_below, int shrink)
   c->suspend_below = suspend_below;
   c->round_shrink = shrink;
   c->rounds_auto = 0; // an explicit setting applies to every launch, saturating or not
+  return 0;
+}
+
+int oakgpu_set_migration(oakgpu_ctx *c, int mode, int long_steps, int adopters) {
+  if (!c || mode < 0 || mode > 2 || long_steps < 1 || adopters < 0) return bad("oakgpu_set_migration: bad argument");
+  c->migrate = mode;
+  c->migrate_steps = long_steps;
+  c->migrate_adopters = adopters;
+  return 0;
+}
+
+int oakgpu_get_queue_counters(oakgpu_ctx *c, uint32_t *out64) { // diagnostic: synchronises the stream
+  if (!c || !out64) return bad("oakgpu_get_queue_counters: null argument");
+  if (!c->d_queue) { memset(out64, 0, 256); return 0; }
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(hipMemcpyAsync(out64, c->d_queue, 256, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
   return 0;
 }
 
@@ -1552,8 +1668,12 @@ static int launch_group(oakgpu_ctx *c, const oak::BatchDesc *descs, uint32_t cou
   // for most of its life (a group of batches) runs as a single dispatch (measured: DESIGN.md 3)
   // ... and so does a launch capped at a few steps (stepping a resident batch turn by turn): there is no tail to regroup
   const bool tail_pack = saturated && c->tail_below > 0 && max_steps > 64;
-  const int rounds = tail_pack ? 2 : (c->suspend_below > 0 && waves >= 8 && !(c->rounds_auto && (saturated || max_steps <= 64))) ? c->rounds : 1;
-  if (rounds > 1 && c->scratch_n < total) {
+  const uint32_t adopters = (uint32_t)(c->migrate_adopters > 0 ? c->migrate_adopters : (c->n_cu + 1) / 2); // measured best: one per two CUs
+  // long-playout migration (k_rollout_queue) replaces the regrouping rounds where it applies: a single dispatch
+  const bool migrate = !tail_pack && max_steps > (uint32_t)c->migrate_steps && waves > adopters &&
+                       (c->migrate == 2 || (c->migrate == 1 && saturated && max_steps >= 500));
+  const int rounds = tail_pack ? 2 : migrate ? 1 : (c->suspend_below > 0 && waves >= 8 && !(c->rounds_auto && (saturated || max_steps <= 64))) ? c->rounds : 1;
+  if ((rounds > 1 || migrate) && c->scratch_n < total) {
     if (c->d_scratch) { HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipFree(c->d_scratch)); c->d_scratch = nullptr; }
     HIPCHK(hipMalloc((void **)&c->d_scratch, (size_t)total * (384 + 8 + 4 + 4) + (((size_t)total + 15) & ~(size_t)15)));
     c->scratch_n = total;
@@ -1574,9 +1694,11 @@ static int launch_group(oakgpu_ctx *c, const oak::BatchDesc *descs, uint32_t cou
     hipLaunchKernelGGL(oak::k_queue_order, dim3((total + 1023) / 1024), dim3(1024), 0, c->stream, g, c->d_order, c->d_queue + 32);
     order = c->d_order;
   }
+  if (migrate) HIPCHK(hipMemsetAsync(lists[0], 0, (size_t)total * 4, c->stream)); // the adoption tickets (one per donation at most)
   for (int r = 0; r < rounds; ++r) {
     oak::RoundArgs q{};
     q.order = r == 0 ? order : nullptr;
+    if (migrate) { q.adopt_ctl = c->d_queue + 40; q.adopt_list = lists[0]; q.n_adopters = adopters; q.long_steps = (uint32_t)c->migrate_steps; }
     q.list_in = r ? lists[(r - 1) & 1] : nullptr;
     q.n_in = r ? c->d_queue + 2 * r - 1 : nullptr; // = count_out of round r - 1
     q.list_out = lists[r & 1];

@@ -68,6 +68,16 @@ class Context:
         """Tail regrouping of the queue schedule (include/oakgpu.h: oakgpu_set_regroup); results never change."""
         _lib.check(self.lib.oakgpu_set_regroup(self.handle, int(rounds), int(suspend_below), int(shrink)))
 
+    def set_migration(self, mode=1, long_steps=300, adopters=0):
+        """Long-playout migration of the queue kernel (include/oakgpu.h: oakgpu_set_migration); results never change."""
+        _lib.check(self.lib.oakgpu_set_migration(self.handle, int(mode), int(long_steps), int(adopters)))
+
+    def queue_counters(self):
+        """The 64 control words of the last queue launch (oakgpu_get_queue_counters): [40] donations, [41] adoptions, [43] errors."""
+        out = np.zeros(64, dtype=np.uint32)
+        _lib.check(self.lib.oakgpu_get_queue_counters(self.handle, out.ctypes.data_as(C.c_void_p)))
+        return out
+
     def set_rollout_engine(self, engine=2, workgroups_per_cu=0):
         """2: register engine + queue (default); 1: LDS engine; 3: register engine with per-turn action-class compaction."""
         _lib.check(self.lib.oakgpu_set_rollout_engine(self.handle, int(engine), int(workgroups_per_cu)))

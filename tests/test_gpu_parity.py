@@ -219,6 +219,42 @@ def test_regrouping_rounds_do_not_change_results(gpu_ctx):
         gpu_ctx.set_regroup()
 
 
+def test_long_playout_migration_does_not_change_results(gpu_ctx):
+    """k_rollout_queue's in-launch migration (bulk waves hand playouts that run beyond `long_steps` to adopter waves through
+    the parked state image + an agent-scope release / acquire): forced on for small launches with thresholds that make
+    MANY playouts migrate; every output byte equals the plain launch's and the oracle's, every donation is adopted, no
+    bounded wait ran out."""
+    n = 6000
+    b, d, p, r = O.make_random_ou_batch(n, seed0=0x7E57AB1E)
+    ob, od, op = b.copy(), d.copy(), p.copy()
+    oout, osteps = O.rollout_batch(ob, od, r, op, max_steps=1000, threads=8)
+    gpu_ctx.set_playouts_per_lane(1)
+    gpu_ctx.set_migration(0)
+    plain = gpu_ctx.rollout(b, d, r, p, max_steps=1000, return_state=True)
+    assert (plain["steps"] == osteps).all() and (plain["battles"] == ob).all()
+    try:
+        for ppl, long_steps, adopters in ((2, 20, 2), (2, 60, 1), (3, 5, 4), (2, 150, 8), (4, 1, 3)):
+            gpu_ctx.set_playouts_per_lane(ppl)
+            gpu_ctx.set_migration(2, long_steps, adopters)
+            for prep in (False, True):
+                q = gpu_ctx.rollout(b, d, r, p, max_steps=1000, prep=prep, return_state=True)
+                c = gpu_ctx.queue_counters()
+                assert c[43] == 0, ("bounded wait ran out", ppl, long_steps, adopters, int(c[43]))
+                assert c[40] == c[41] and c[40] > 0, ("donations / adoptions", int(c[40]), int(c[41]))
+                ref = plain
+                if prep:
+                    gpu_ctx.set_playouts_per_lane(1)
+                    gpu_ctx.set_migration(0)
+                    ref = gpu_ctx.rollout(b, d, r, p, max_steps=1000, prep=True, return_state=True)
+                    gpu_ctx.set_playouts_per_lane(ppl)
+                    gpu_ctx.set_migration(2, long_steps, adopters)
+                for key in ("results", "steps", "values", "battles", "durations", "prng"):
+                    assert (q[key] == ref[key]).all(), (ppl, long_steps, adopters, prep, key)
+    finally:
+        gpu_ctx.set_playouts_per_lane(2)
+        gpu_ctx.set_migration(1, 300, 0)
+
+
 def test_rollout_in_place_on_device_buffers(gpu_ctx):
     """oakgpu_rollout_dev with battles_out == battles, durations_out == durations, results_out == results_in
     (how bench.py --workload config3 steps a resident batch one turn at a time): same bytes as out of place.

@@ -49,6 +49,19 @@ def run(below, waves, lanes, reps=3):
     print("below %2d waves %4d lanes %2d : %7.3f ms  %6.2f G turn-steps/s" % (below, waves, lanes, best, tot / best / 1e6), flush=True)
 
 
+if len(sys.argv) > 1 and sys.argv[1] == "migrate":    # long-playout migration A/B (oakgpu_set_migration)
+    import numpy as np
+    def counters():
+        out = np.zeros(64, dtype=np.uint32)
+        _lib.check(lib.oakgpu_get_queue_counters(h, out.ctypes.data_as(C.c_void_p)))
+        return out
+    for mode, ls, ad in ((0, 300, 0), (1, 300, 0), (1, 300, 96), (1, 300, 160), (1, 300, 192), (1, 275, 128), (1, 325, 128), (1, 350, 128), (1, 300, 256), (0, 300, 0), (1, 300, 0)):
+        _lib.check(lib.oakgpu_set_migration(h, mode, ls, ad))
+        print("migrate %d long_steps %3d adopters %3d" % (mode, ls, ad), end="  ")
+        run(0, 0, 0, reps=4)
+        c = counters()
+        print("      donations %d adoptions %d bulk waves left %d errors %d" % (c[40], c[41], c[42], c[43]), flush=True)
+    sys.exit(0)
 if len(sys.argv) > 1 and sys.argv[1] == "order":      # the queue-order A/B only
     for on in (0, 1, 0, 1):
         _lib.check(lib.oakgpu_set_queue_order(h, on))
