@@ -1295,6 +1295,7 @@ struct oakgpu_ctx {
   int migrate;            // long-playout migration (k_rollout_queue): 0 off, 1 (default) for launches that saturate the device, 2 always
   int migrate_steps;      //   a bulk wave donates a playout still running after this many turn-steps (default 300)
   int migrate_adopters;   //   adopter waves (0 = one per two CUs)
+  int migrate_used;       //   the last queue launch ran with migration: oakgpu_synchronize reports its error word
   int queue_order;        // 1 (default): a saturated launch hands its playouts out likely-longest first (k_queue_order)
   uint32_t *d_order;      // total entries
   size_t order_n;
@@ -1468,6 +1469,7 @@ int oakgpu_create(oakgpu_ctx **out, int device) {
   c->migrate = 1;
   c->migrate_steps = 300;
   c->migrate_adopters = 0;
+  c->migrate_used = 0;
   if (const char *env = getenv("OAKGPU_MIGRATE")) c->migrate = atoi(env) < 0 ? 0 : atoi(env) > 2 ? 2 : atoi(env);
   if (const char *env = getenv("OAKGPU_MIGRATE_STEPS")) c->migrate_steps = atoi(env) < 1 ? 1 : atoi(env);
   if (const char *env = getenv("OAKGPU_MIGRATE_ADOPTERS")) c->migrate_adopters = atoi(env) < 0 ? 0 : atoi(env);
@@ -1599,6 +1601,12 @@ int oakgpu_get_leaf_kernel_ms(oakgpu_ctx *c, float ms[3]) {
 int oakgpu_synchronize(oakgpu_ctx *c) {
   if (!c) return bad("null ctx");
   HIPCHK(hipStreamSynchronize(c->stream));
+  if (c->d_queue && c->migrate_used) { // the last queue launch migrated playouts: did one of its bounded waits run out?
+    uint32_t err = 0;
+    HIPCHK(hipMemcpy(&err, c->d_queue + 43, 4, hipMemcpyDeviceToHost));
+    c->migrate_used = 0;
+    if (err) return bad("rollout: a bounded wait of the long-playout migration ran out (playouts were lost) -- oakgpu_set_migration(ctx, 0, ...) turns it off");
+  }
   return 0;
 }
 
@@ -1695,6 +1703,7 @@ static int launch_group(oakgpu_ctx *c, const oak::BatchDesc *descs, uint32_t cou
     order = c->d_order;
   }
   if (migrate) HIPCHK(hipMemsetAsync(lists[0], 0, (size_t)total * 4, c->stream)); // the adoption tickets (one per donation at most)
+  c->migrate_used = migrate ? 1 : 0;
   for (int r = 0; r < rounds; ++r) {
     oak::RoundArgs q{};
     q.order = r == 0 ? order : nullptr;
@@ -2061,7 +2070,7 @@ int oakgpu_rollout_group(oakgpu_ctx *c, const oakgpu_rollout_batch *batches, uin
   if (e != hipSuccess) return fail(e, "oakgpu_rollout_group");
   if (rc) return rc;
   if (se != hipSuccess) return fail(se, "hipStreamSynchronize");
-  return 0;
+  return oakgpu_synchronize(c); // (reports a migration wait that ran out)
 }
 
 int oakgpu_rollout(oakgpu_ctx *c, const uint8_t *battles, const uint8_t *durations, const uint8_t *results_in,

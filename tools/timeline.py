@@ -49,5 +49,9 @@ print("launch %.3f ms, %d waves, total steps %d (kernel counted %d)" % (a.elapse
 print("wave start  us: min %.0f med %.0f max %.0f" % (start.min(), np.median(start), start.max()))
 print("dry seen    us: min %.0f med %.0f max %.0f; live lanes at dry: mean %.1f" % (dry.min(), np.median(dry), dry.max(), tl[:, 3].mean()))
 print("wave exit   us: min %.0f med %.0f p90 %.0f p99 %.0f max %.0f" % (end.min(), np.median(end), np.percentile(end, 90), np.percentile(end, 99), end.max()))
+na = int(os.environ.get("TL_ADOPTERS", "0"))
+if na:   # the first `na` waves are the migration's adopters (oakgpu_set_migration)
+    print("adopters    us: exit min %.0f med %.0f max %.0f; steps per adopter wave: med %.0f max %.0f" % (end[:na].min(), np.median(end[:na]), end[:na].max(), np.median(tl[:na, 4]), tl[:na, 4].max()))
+    print("bulk waves  us: exit med %.0f p99 %.0f max %.0f" % (np.median(end[na:]), np.percentile(end[na:], 99), end[na:].max()))
 for t in range(0, min(int(end.max()) + 1000, 60000), 1000):
     print("  t=%5d us: waves still running %5d" % (t, int((end > t).sum())))
