@@ -85,6 +85,12 @@ def main():
     from oak_amd import _lib
     from oak_amd import dist as oakdist
     from oak_amd.engine import Context
+    # BENCH_REHEARSAL=1: every rank on GPU 0 with the gloo backend (RCCL refuses two ranks on one device) -- the REAL kernels and
+    # the REAL N > 1 code path (lane sharding, per-group gather on its own stream, row check, sub-records with world > 1) on a
+    # one-GPU box; its numbers mean nothing (the ranks share the card, the collective goes through the host)
+    rehearsal = bool(os.environ.get("BENCH_REHEARSAL"))
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -92,7 +98,10 @@ def main():
     if world > 1 or force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm
         if dist.get_world_size() != world:
             raise SystemExit("process group has %d ranks, expected %d" % (dist.get_world_size(), world))
 
@@ -133,6 +142,8 @@ def main():
                 subs["config4"]["cpu_baseline"] = cpu_baseline_config4()
         if rank == 0:
             out.update(subs)
+            if rehearsal:
+                out["rehearsal"] = "BENCH_REHEARSAL: all ranks on GPU 0 over gloo -- a code-path check, not a measurement"
             print(json.dumps(out), flush=True)
     if world > 1 or force_dist:
         dist.barrier()

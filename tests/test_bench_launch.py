@@ -43,3 +43,24 @@ def test_a_failing_rank_fails_the_command():
 def test_world_size_mismatch_is_refused():
     p = _run(["--gpus", "2", "--dry-run"], {"WORLD_SIZE": "3", "RANK": "0", "LOCAL_RANK": "0"})
     assert p.returncode != 0 and "WORLD_SIZE=3" in p.stderr
+
+
+import pytest
+
+
+@pytest.mark.gpu
+def test_gpus_2_rehearsal_on_one_gpu_runs_the_real_exchange_path():
+    """BENCH_REHEARSAL=1: `python bench.py --gpus 2` self-launches two ranks that SHARE GPU 0 over gloo -- the real kernels and
+    the real N > 1 code path of every record (disjoint lane blocks, one gather per group on its own stream, the row check of
+    the gather, sums over ranks, config4's root split with its all-gather of per-root means) on a one-GPU box."""
+    p = _run(["--gpus", "2", "--steps", "8", "--warmup", "2", "--group", "4", "--batch", "16384", "--no-cpu-baseline"], {"BENCH_REHEARSAL": "1"})
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["ranks_seen"] == 2 and "rehearsal" in rec
+    assert 90 < rec["config"]["mean_turn_steps_per_playout"] < 110          # 2 x 8 x 16,384 playouts, all counted
+    for sub in ("leaf", "config3", "config4", "config5"):
+        assert sub in rec and "error" not in rec[sub], (sub, rec.get(sub))
+    assert rec["config4"]["scaling"] == "strong" and rec["config4"]["config"]["roots_per_gpu"] == 128
+    assert rec["config4"]["ranks_seen"] == 2 and 0.3 < rec["config4"]["config"]["mean_root_value"] < 0.7
