@@ -260,6 +260,12 @@ void oakgpu_agent_networks_clear(oakgpu_ctx *ctx);
 int oakgpu_bandit_replay(int kind, float c, float alpha, uint32_t k, const float *logits, uint32_t steps,
                          const double *uniforms, const float *values, uint8_t *index_out, float *prob_out,
                          float *stats_out, uint32_t *visits_out);
+/* Diagnostic (no GPU involved): `count` select + visit rounds of one bandit from the given state (scores[9], priors[9],
+ * visits[9]), once through the register-resident run the batched search uses at the root and once as the plain loop: the two
+ * index sequences (run_out, loop_out: count bytes each) and final visit counts must be identical. */
+int oakgpu_bandit_select_run(int kind, float c, float alpha, uint32_t k, const float *scores, const float *priors,
+                             const uint32_t *visits, uint32_t count, uint8_t *run_out, uint8_t *loop_out, uint32_t *visits_run,
+                             uint32_t *visits_loop);
 int oakgpu_search(oakgpu_ctx *ctx, oakgpu_net *net /* nullable for eval = 0 */, const uint8_t *battle /* 384 */,
                   const uint8_t *durations /* 8 */, uint8_t result, const oakgpu_search_params *params,
                   oakgpu_search_output *out);

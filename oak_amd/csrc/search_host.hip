@@ -351,6 +351,29 @@ extern "C" int oakgpu_bandit_replay(int kind, float c, float alpha, uint32_t k, 
   return 0;
 }
 
+// Diagnostic (no GPU): `count` select + visit rounds of one bandit from a given state, once through Bandit::select_run (the
+// register-resident form the batched search uses at the root) and once as the plain select(); visit() loop it must equal.
+extern "C" int oakgpu_bandit_select_run(int kind, float c, float alpha, uint32_t k, const float *scores, const float *priors,
+                                        const uint32_t *visits, uint32_t count, uint8_t *run_out, uint8_t *loop_out,
+                                        uint32_t *visits_run, uint32_t *visits_loop) {
+  if (kind < 0 || kind > 4 || k < 1 || k > 9 || !scores || !priors || !visits || !run_out || !loop_out) return oakgpu_fail_msg("oakgpu_bandit_select_run: bad argument");
+  const BanditParams P{kind, c, alpha};
+  Bandit a;
+  a.init((uint8_t)k, kind);
+  for (int i = 0; i < 9; ++i) { a.scores[i] = scores[i]; a.priors[i] = priors[i]; a.visits[i] = visits[i]; }
+  Bandit b = a;
+  uint64_t s1 = 0x1234, s2 = 0x1234;
+  a.select_run(P, count, run_out, nullptr, [&](uint32_t) { return uniform01(s1); });
+  for (uint32_t r = 0; r < count; ++r) {
+    float pr;
+    const uint8_t i = b.select(P, [&] { return uniform01(s2); }, pr);
+    b.visit(P, i);
+    loop_out[r] = i;
+  }
+  for (int i = 0; i < 9; ++i) { if (visits_run) visits_run[i] = a.visits[i]; if (visits_loop) visits_loop[i] = b.visits[i]; }
+  return 0;
+}
+
 // pyoak solve_matrix / LRSNash::solve_fast (pyoak.cc:394-426, mcts.h:643-649): exact equilibrium of an integer matrix game
 extern "C" int oakgpu_solve_matrix(const int32_t *payoffs, int m, int n, int discretize_factor, double *p1, double *p2, double *value) {
   if (!payoffs || !p1 || !p2 || !value) return oakgpu_fail_msg("oakgpu_solve_matrix: null argument");
@@ -731,22 +754,12 @@ int oakgpu_search_heap(oakgpu_ctx *ctx, oakgpu_net *net, oakgpu_heap *heap, cons
           pool.run([&](int w) {
             if (w == 0) {
               Bandit b = nd.p1;
-              for (uint32_t l = 0; l < nb; ++l) {
-                float pr;
-                const uint8_t i = b.select(BP, [&] { return uniform_at(bandit_seed, S.serial, l, 0, 0); }, pr); // device.uniform() of sample_pdf (util/random.h:40-49)
-                b.visit(BP, i);
-                S.root_i[l] = i; S.root_p1[l] = pr;
-              }
+              b.select_run(BP, nb, S.root_i.data(), S.root_p1.data(), [&](uint32_t l) { return uniform_at(bandit_seed, S.serial, l, 0, 0); }); // device.uniform() of sample_pdf (util/random.h:40-49)
               nd.p1 = b;
             }
             if (w == (W > 1 ? 1 : 0)) {
               Bandit b = nd.p2;
-              for (uint32_t l = 0; l < nb; ++l) {
-                float pr;
-                const uint8_t j = b.select(BP, [&] { return uniform_at(bandit_seed, S.serial, l, 0, 1); }, pr);
-                b.visit(BP, j);
-                S.root_j[l] = j; S.root_p2[l] = pr;
-              }
+              b.select_run(BP, nb, S.root_j.data(), S.root_p2.data(), [&](uint32_t l) { return uniform_at(bandit_seed, S.serial, l, 0, 1); });
               nd.p2 = b;
             }
           });

@@ -148,3 +148,33 @@ def test_bandit_arithmetic_matches_reference_traces():
     assert seen == {(n, k) for n in kinds for k in (1, 2, 4, 9)}
     # the traces are not degenerate: every 9-armed one visits every arm
     assert all(len(set(t["index"])) == 9 for t in traces if t["k"] == 9)
+
+
+def test_root_select_run_equals_the_plain_select_visit_loop():
+    """Bandit::select_run (csrc/bandit.hpp): the root's batch of consecutive select + visit rounds with the counts kept in SSE
+    registers must be the plain select(); visit() loop, index for index -- UCB and PUCB at every arm count, from random
+    statistics incl. visit counts beyond 2^24 (where a float counter would stop counting), plus the kinds that take the loop."""
+    import ctypes as C
+    from oak_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(11)
+    P = lambda a: a.ctypes.data_as(C.c_void_p)
+    for trial in range(120):
+        kind = [0, 1, 0, 1, 2, 3][trial % 6]
+        k = 1 + trial % 9
+        big = trial % 5 == 0
+        visits = (rng.integers(1, 1 << 26 if big else 4000, 9)).astype(np.uint32)
+        scores = (rng.random(9) * visits * rng.random()).astype(np.float32)
+        pri = rng.random(9).astype(np.float32); pri[:k] /= pri[:k].sum()
+        if kind == 3:
+            scores = (-rng.random(9) * 5).astype(np.float32); scores[np.argmax(scores[:k])] = 0.0; scores[k:] = -np.inf; visits[:] = 0
+        count = 3000
+        run, loop = np.zeros(count, np.uint8), np.zeros(count, np.uint8)
+        vr, vl = np.zeros(9, np.uint32), np.zeros(9, np.uint32)
+        rc = lib.oakgpu_bandit_select_run(kind, C.c_float(0.3 + 2 * rng.random()), C.c_float(0.05), k, P(scores), P(pri), P(visits), count,
+                                          P(run), P(loop), P(vr), P(vl))
+        assert rc == 0
+        assert (run == loop).all(), (trial, kind, k, int(np.argmax(run != loop)))
+        assert (vr == vl).all() and (run < k).all()
+        if kind < 2:
+            assert int(vr.sum()) == int(visits.sum()) + (count if k > 1 else 0) or k == 1
