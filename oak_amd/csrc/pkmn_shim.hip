@@ -1,6 +1,5 @@
 // oak_amd/csrc/pkmn_shim.hip -- the libpkmn-named single-battle C ABI (include/pkmn.h) as batches of one
 // through the HIP kernels behind oakgpu_update / oakgpu_choices.  No CPU implementation.
-#include <mutex>
 #include <stdlib.h>
 #include <string.h>
 
@@ -8,16 +7,24 @@
 #include "../../include/pkmn.h"
 
 namespace {
-oakgpu_ctx *g_ctx = nullptr;
-std::once_flag g_once;
-std::mutex g_mu; // the shared context owns one stream and scratch buffers
+// One context (= one HIP stream + its own staging buffers) PER CALLING THREAD: libpkmn is re-entrant and thread-safe per
+// battle, and the reference runs one game per std::thread (generate.cc:527-536, vs.cc:534-542) -- behind one
+// process-wide context and mutex (rounds 1-2) those threads stepped one battle at a time.  A thread's context lives until the
+// thread ends.
+struct ThreadCtx {
+  oakgpu_ctx *ctx = nullptr;
+  bool tried = false;
+  ~ThreadCtx() { if (ctx) oakgpu_destroy(ctx); }
+};
 oakgpu_ctx *shared_ctx() {
-  std::call_once(g_once, [] {
+  static thread_local ThreadCtx t;
+  if (!t.tried) {
+    t.tried = true;
     int dev = 0;
     if (const char *e = getenv("OAKGPU_DEVICE")) dev = atoi(e);
-    if (oakgpu_create(&g_ctx, dev) != 0) g_ctx = nullptr;
-  });
-  return g_ctx;
+    if (oakgpu_create(&t.ctx, dev) != 0) t.ctx = nullptr;
+  }
+  return t.ctx;
 }
 } // namespace
 
@@ -26,7 +33,6 @@ extern "C" {
 pkmn_result pkmn_gen1_battle_update(pkmn_gen1_battle *battle, pkmn_choice c1, pkmn_choice c2, pkmn_gen1_battle_options *o) {
   oakgpu_ctx *ctx = shared_ctx();
   if (!ctx || !battle || !o) return PKMN_RESULT_ERROR;
-  std::lock_guard<std::mutex> lock(g_mu);
   uint8_t res = PKMN_RESULT_ERROR;
   const int rc = oakgpu_update(ctx, battle->bytes, &c1, &c2, o->durations.bytes, o->actions.bytes,
                                o->has_overrides ? o->overrides.bytes : nullptr, 1, &res);
@@ -37,7 +43,6 @@ uint8_t pkmn_gen1_battle_choices(const pkmn_gen1_battle *battle, pkmn_player pla
                                  size_t len) {
   oakgpu_ctx *ctx = shared_ctx();
   if (!ctx || !battle || !out || len < PKMN_GEN1_MAX_CHOICES) return 0;
-  std::lock_guard<std::mutex> lock(g_mu);
   const uint8_t result = (uint8_t)(player == PKMN_PLAYER_P1 ? (request << 4) : (request << 6));
   uint8_t buf[OAKGPU_MAX_CHOICES], n = 0;
   if (oakgpu_choices(ctx, battle->bytes, &result, (int)player, buf, &n, 1) != 0) return 0;

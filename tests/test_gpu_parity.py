@@ -317,9 +317,10 @@ def test_libpkmn_named_single_battle_abi(gpu_ctx):
     lib.pkmn_gen1_battle_options_set.argtypes = [C.c_void_p] * 4
     lib.pkmn_result_type.restype = C.c_int
     lib.pkmn_result_type.argtypes = [C.c_uint8]
-    b, d, p, r = O.make_random_ou_batch(3, seed0=0xBEEF)
-    rng = np.random.default_rng(1)
-    for i in range(3):
+    b, d, p, r = O.make_random_ou_batch(6, seed0=0xBEEF)
+
+    def play(i, seed):
+        rng = np.random.default_rng(seed)
         gb = b[i].copy()
         opt, oopt = Options(), O.Options()
         res = ores = int(r[i])
@@ -340,6 +341,16 @@ def test_libpkmn_named_single_battle_abi(gpu_ctx):
             ores = O.update(b[i], picks[0], picks[1], oopt)
             assert res == ores and (gb == b[i]).all()
             assert bytes(opt.durations) == oopt.durations.tobytes() and bytes(opt.actions) == oopt.actions.tobytes()
+        return True
+
+    for i in range(3):
+        play(i, 1)
+    # libpkmn is thread-safe per battle and the reference runs one game per thread (generate.cc:527-536): three threads drive
+    # three battles through the libpkmn-named ABI at once -- each on its own per-thread context -- and every step still
+    # agrees with the oracle
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=3) as ex:
+        assert all(f.result() for f in [ex.submit(play, 3 + t, 10 + t) for t in range(3)])
 
 
 def test_full_size_config2_bit_exact(gpu_ctx):
