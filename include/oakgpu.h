@@ -50,12 +50,11 @@ int oakgpu_get_leaf_kernel_ms(oakgpu_ctx *ctx, float ms[3]);
 /* Rollout scheduling (results never depend on it).  k = 1 launches one lane per playout; k > 1 (default 2)
  * launches n/k persistent lanes that refill from an atomic playout queue as playouts finish. */
 int oakgpu_set_playouts_per_lane(oakgpu_ctx *ctx, int k);
-/* Regrouping of the queue schedule's long tail: the rollout runs as `rounds` dispatches (1..8, default 4); in
- * every round but the last a wave whose queue is dry and that has fewer than `suspend_below` (0..64, default 32)
- * playouts still running parks them (bit-exact state image) for the next round, which packs them 64 to a wave
- * again on 1/`shrink` (>= 1, default 3) of the waves.  rounds = 1 or suspend_below = 0 disables it.  By default a
- * launch large enough to keep every SIMD's wave slots occupied runs as a single dispatch (its tail is bound by the
- * longest playout, not by idle lanes); calling this function applies the given setting to every launch. */
+/* Regrouping rounds of the queue schedule (off unless this is called): the rollout runs as `rounds` dispatches (1..8); in
+ * every round but the last a wave whose queue is dry and that has fewer than `suspend_below` (0..64) playouts still running
+ * parks them (bit-exact state image) for the next round, which packs them 64 to a wave again on 1/`shrink` (>= 1) of the
+ * waves.  It paid off while many small launches ran side by side on many streams (round 1); a lone launch is faster as one
+ * dispatch (measured at every size, round 3), which is the default.  rounds = 1 or suspend_below = 0 disables it again. */
 int oakgpu_set_regroup(oakgpu_ctx *ctx, int rounds, int suspend_below, int shrink);
 /* The tail of a launch that saturates the device (a group of batches): when the playout queue is dry, a wave with fewer
  * than `below` (1..64; 0 = off) playouts still running parks them, and ONE follow-up dispatch of `waves` waves (0 = one
@@ -63,7 +62,7 @@ int oakgpu_set_regroup(oakgpu_ctx *ctx, int rounds, int suspend_below, int shrin
  * playouts that run into the step cap; a wave that holds one of them alone advances it no faster than a wave that holds
  * a few, and hundreds of such waves slow each other down.  Results never depend on it. */
 int oakgpu_set_tail_pack(oakgpu_ctx *ctx, int below, int waves, int lanes);
-/* Queue order of a launch that saturates the device (default on): playouts with a Ghost-type Pokemon on either team are
+/* Queue order of a launch of >= 8,192 playouts (default on): playouts with a Ghost-type Pokemon or a Ditto on either team are
  * handed out first.  They hold practically all of the playouts that run into the step cap (Normal-type Rage / Struggle locks
  * against a Ghost), and the launch ends with its longest playout: started early, the 1,000-step chains are mostly done when
  * the queue runs dry.  Pure scheduling: results are indexed by playout and never depend on it. */

@@ -1288,7 +1288,8 @@ struct oakgpu_ctx {
   int round_shrink;       // each round launches 1/round_shrink of the previous round's waves
   uint8_t *d_scratch;     // suspended playout state: n x (384 + 8 + 1) bytes + two n-entry index lists
   size_t scratch_n;
-  int rounds_auto;        // a launch that saturates the device runs as one dispatch (no regrouping rounds)
+  int rounds_auto;        // 1 (default): every launch is one dispatch; 0 after oakgpu_set_regroup: the rounds it asked for
+  int concurrent_hint;    // set by callers that keep several contexts busy at once (the tree search): small launches run in rounds
   int tail_below;         // > 0: a SATURATED launch parks the lanes of dry waves with fewer live lanes than this and ONE follow-up
   int tail_waves;         //      dispatch of this many waves (0 = one per CU) finishes them, a few to a wave (the tail)
   int tail_lanes;         //      lanes per wave of that dispatch that take playouts (0 = all 64)
@@ -1354,6 +1355,7 @@ void *oakgpu_stage_get(oakgpu_ctx *c, size_t bytes) {
   return grow_block(c, c->stage[c->stage_cursor++], bytes ? bytes : 1);
 }
 void *oakgpu_ctx_stream(const oakgpu_ctx *c) { return (void *)c->stream; }
+int oakgpu_ctx_set_concurrent_hint(oakgpu_ctx *c, int on) { const int old = c->concurrent_hint; c->concurrent_hint = on; return old; }
 void *oakgpu_ctx_attachment(const oakgpu_ctx *c) { return c->attachment; }
 void oakgpu_ctx_set_attachment(oakgpu_ctx *c, void *p, void (*dtor)(void *)) {
   if (c->attachment && c->attachment_dtor) c->attachment_dtor(c->attachment);
@@ -1450,6 +1452,7 @@ int oakgpu_create(oakgpu_ctx **out, int device) {
   c->timing = 0;
   c->tev_valid = false;
   c->rounds_auto = 1;
+  c->concurrent_hint = 0;
   if (const char *env = getenv("OAKGPU_ROUNDS_AUTO")) c->rounds_auto = atoi(env) != 0;
   {
     hipDeviceProp_t prop;
@@ -1680,7 +1683,14 @@ static int launch_group(oakgpu_ctx *c, const oak::BatchDesc *descs, uint32_t cou
   // long-playout migration (k_rollout_queue) replaces the regrouping rounds where it applies: a single dispatch
   const bool migrate = !tail_pack && max_steps > (uint32_t)c->migrate_steps && waves > adopters &&
                        (c->migrate == 2 || (c->migrate == 1 && saturated && max_steps >= 500));
-  const int rounds = tail_pack ? 2 : migrate ? 1 : (c->suspend_below > 0 && waves >= 8 && !(c->rounds_auto && (saturated || max_steps <= 64))) ? c->rounds : 1;
+  // Regrouping rounds only on request (oakgpu_set_regroup).  They were the default for launches that do not fill the device while
+  // twenty such launches ran side by side on twenty streams (round 1: a parked wave's slots went to another batch); since group
+  // launches replaced that, a lone launch is measured FASTER as one dispatch at every size (round 3, tools/small_launch_sweep.py:
+  // 16,384 / 65,536 / 131,072 / 262,144 playouts: 10.3 / 11.7 / 11.9 / 12.5 ms with rounds 4 / 32 / 3 against 8.0 / 8.6 / 9.5 / 9.5 ms
+  // as a single dispatch with the queue order below)
+  // (the tree search keeps two batches in flight on two contexts and asks for the rounds -- oakgpu_ctx_set_concurrent_hint --:
+  // behind a single 8 ms dispatch the other context's small per-level kernels queued up: 11 -> 69 ms of waiting per search)
+  const int rounds = tail_pack ? 2 : migrate ? 1 : ((!c->rounds_auto || (c->concurrent_hint && !saturated && max_steps > 64)) && c->suspend_below > 0 && waves >= 8) ? c->rounds : 1;
   if ((rounds > 1 || migrate) && c->scratch_n < total) {
     if (c->d_scratch) { HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipFree(c->d_scratch)); c->d_scratch = nullptr; }
     HIPCHK(hipMalloc((void **)&c->d_scratch, (size_t)total * (384 + 8 + 4 + 4) + (((size_t)total + 15) & ~(size_t)15)));
@@ -1693,7 +1703,7 @@ static int launch_group(oakgpu_ctx *c, const oak::BatchDesc *descs, uint32_t cou
   uint8_t *sres = lists[1] ? (uint8_t *)(lists[1] + c->scratch_n) : nullptr;
   const oak::GroupArgs g{dt, count, total, max_steps, prep};
   const uint32_t *order = nullptr;
-  if (c->queue_order && saturated && max_steps > 250) { // (a launch that does not fill the device has no queue to speak of)
+  if (c->queue_order && max_steps > 250 && total >= 8192) { // (a few thousand playouts have no queue to speak of: they all start at once)
     if (c->order_n < total) {
       if (c->d_order) { HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipFree(c->d_order)); c->d_order = nullptr; }
       HIPCHK(hipMalloc((void **)&c->d_order, (size_t)total * 4));

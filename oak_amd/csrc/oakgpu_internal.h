@@ -30,3 +30,7 @@ void **oakgpu_ctx_timing_events(oakgpu_ctx *ctx);
 // the tree search keeps its batch slots (second context, device arrays, pinned mirrors) here between searches.
 void *oakgpu_ctx_attachment(const oakgpu_ctx *ctx);
 void oakgpu_ctx_set_attachment(oakgpu_ctx *ctx, void *p, void (*dtor)(void *));
+// A caller that keeps several contexts busy at the same time (the tree search: two batches in flight) says so: launches that
+// do not fill the device then run in regrouping rounds, whose dispatch boundaries let the other context's small kernels in.
+// Returns the previous value.
+int oakgpu_ctx_set_concurrent_hint(oakgpu_ctx *ctx, int on);

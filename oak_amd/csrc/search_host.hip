@@ -633,9 +633,15 @@ int oakgpu_search_heap(oakgpu_ctx *ctx, oakgpu_net *net, oakgpu_heap *heap, cons
   Slot *slots = scratch->slots;
   int emb_dim = 0;
   if (use_net && n_slots > 1) RC(oakgpu_net_shape(net, &emb_dim, nullptr, nullptr, nullptr));
+  struct HintGuard { // both slots' contexts run their small launches in rounds while two batches are in flight
+    oakgpu_ctx *c[2] = {nullptr, nullptr};
+    int old[2] = {0, 0};
+    ~HintGuard() { for (int q = 0; q < 2; ++q) if (c[q]) oakgpu_ctx_set_concurrent_hint(c[q], old[q]); }
+  } hint_guard;
   for (int si = 0; si < n_slots; ++si) {
     Slot &S = slots[si];
     RC(S.allocate(ctx, si, B, pucb, emb_dim));
+    if (n_slots > 1) { hint_guard.c[si] = S.ctx; hint_guard.old[si] = oakgpu_ctx_set_concurrent_hint(S.ctx, 1); }
     // root template: B copies of the input; one fast_prng stream per lane (util/random.h:67-133), never all-zero
     for (uint32_t l = 0; l < B; ++l) memcpy(S.h_stage + (size_t)l * 384, battle, 384);
     HIPRC(hipMemcpyAsync(S.d_root_b, S.h_stage, (size_t)B * 384, hipMemcpyHostToDevice, S.stream));

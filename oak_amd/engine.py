@@ -64,8 +64,9 @@ class Context:
         _lib.check(self.lib.oakgpu_poke_engine_eval(self.handle, _p(battles), n, C.c_float(root_score), _p(values), _p(scores)))
         return values, scores
 
-    def set_regroup(self, rounds=4, suspend_below=32, shrink=3):
-        """Tail regrouping of the queue schedule (include/oakgpu.h: oakgpu_set_regroup); results never change."""
+    def set_regroup(self, rounds=1, suspend_below=0, shrink=1):
+        """Regrouping rounds of the queue schedule (include/oakgpu.h: oakgpu_set_regroup; default: off, one dispatch);
+        results never change."""
         _lib.check(self.lib.oakgpu_set_regroup(self.handle, int(rounds), int(suspend_below), int(shrink)))
 
     def set_migration(self, mode=1, long_steps=300, adopters=0):
