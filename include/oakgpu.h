@@ -67,6 +67,10 @@ int oakgpu_set_tail_pack(oakgpu_ctx *ctx, int below, int waves, int lanes);
  * against a Ghost), and the launch ends with its longest playout: started early, the 1,000-step chains are mostly done when
  * the queue runs dry.  Pure scheduling: results are indexed by playout and never depend on it. */
 int oakgpu_set_queue_order(oakgpu_ctx *ctx, int on);
+/* Launches that do not fill the device use its empty wave slots: every wave takes only `lanes` playouts at a time, on as many
+ * more waves as that needs (never more than the device holds).  -1 (default) = automatic: as few lanes per wave as fill the
+ * device, at least 4; 0 or 64 = off.  Results never depend on it. */
+int oakgpu_set_spread(oakgpu_ctx *ctx, int lanes);
 /* Long-playout migration inside a launch (mode 0 off, 1 = launches that saturate the device (default), 2 = every queue launch:
  * tests): a wave hands a playout that is still running after `long_steps` turn-steps (default 300; 99.5% end before 250) to
  * `adopters` dedicated waves (0 = one per two compute units), which from the first donation on hold only such playouts -- a dozen

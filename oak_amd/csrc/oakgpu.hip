@@ -1297,6 +1297,7 @@ struct oakgpu_ctx {
   int migrate_steps;      //   a bulk wave donates a playout still running after this many turn-steps (default 300)
   int migrate_adopters;   //   adopter waves (0 = one per two CUs)
   int migrate_used;       //   the last queue launch ran with migration: oakgpu_synchronize reports its error word
+  int spread_lanes;       // launches that do not fill the device: lanes per wave that take playouts (-1 automatic, 0 / 64 = all)
   int queue_order;        // 1 (default): a saturated launch hands its playouts out likely-longest first (k_queue_order)
   uint32_t *d_order;      // total entries
   size_t order_n;
@@ -1467,6 +1468,8 @@ int oakgpu_create(oakgpu_ctx **out, int device) {
   c->tail_waves = 0;
   if (const char *env = getenv("OAKGPU_TAIL_BELOW")) c->tail_below = atoi(env) < 0 ? 0 : atoi(env) > 64 ? 64 : atoi(env);
   if (const char *env = getenv("OAKGPU_TAIL_WAVES")) c->tail_waves = atoi(env) < 0 ? 0 : atoi(env);
+  c->spread_lanes = -1; // automatic
+  if (const char *env = getenv("OAKGPU_SPREAD_LANES")) c->spread_lanes = atoi(env) < -1 ? -1 : atoi(env) > 64 ? 64 : atoi(env);
   c->queue_order = 1;
   if (const char *env = getenv("OAKGPU_QUEUE_ORDER")) c->queue_order = atoi(env) != 0;
   c->migrate = 1;
@@ -1563,6 +1566,12 @@ int oakgpu_get_queue_counters(oakgpu_ctx *c, uint32_t *out64) { // diagnostic: s
   HIPCHK(hipSetDevice(c->device));
   HIPCHK(hipMemcpyAsync(out64, c->d_queue, 256, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+int oakgpu_set_spread(oakgpu_ctx *c, int lanes) {
+  if (!c || lanes < -1 || lanes > 64) return bad("oakgpu_set_spread: lanes must be -1 (automatic) or 0..64");
+  c->spread_lanes = lanes;
   return 0;
 }
 
@@ -1673,8 +1682,24 @@ static int launch_group(oakgpu_ctx *c, const oak::BatchDesc *descs, uint32_t cou
   uint32_t waves = (n64 + c->playouts_per_lane - 1) / c->playouts_per_lane;
   if (waves < 1) waves = 1;
   const uint32_t resident = (uint32_t)c->n_cu * 4u * (uint32_t)(c->waves_per_simd >= 4 ? 4 : c->waves_per_simd == 3 ? 3 : 2);
-  const bool saturated = waves >= resident;
+  bool saturated = waves >= resident;
   if (saturated) waves = resident;
+  // A launch that leaves wave slots empty uses them: the same playouts in flight on MORE waves, each taking only a few at a
+  // time -- a wave of 8 lanes executes the union of 8 playouts' paths instead of 64's, and the device had the issue slots free
+  // (round 3, tools/small_launch_sweep.py ... spread: 65,536 playouts 8.5 -> 7.7 ms at 8 lanes per wave, 16,384 playouts 7.8 ->
+  // 6.2 ms at 4, a rank's share of configs[3] 9.3 -> 8.3 ms at 16).  Automatic: as few lanes per wave as fill the resident
+  // waves, at least 4.  Not for callers that keep several contexts busy (the other context needs the slots).
+  uint32_t spread = 0;
+  if (!saturated && c->spread_lanes != 0 && !c->concurrent_hint && max_steps > 64) {
+    const uint64_t slots = ((uint64_t)total + c->playouts_per_lane - 1) / c->playouts_per_lane; // lanes in flight
+    uint32_t lanes = c->spread_lanes > 0 ? (uint32_t)c->spread_lanes : (uint32_t)((slots + resident - 1) / resident);
+    if (lanes < 4) lanes = 4;
+    if (lanes < 64) {
+      uint32_t w = (uint32_t)((slots + lanes - 1) / lanes);
+      if (w > resident) w = resident;
+      if (w > waves) { waves = w; spread = lanes; }
+    }
+  }
   // regrouping rounds pay off while the launch leaves SIMDs idle in its tail; a launch that saturates the device
   // for most of its life (a group of batches) runs as a single dispatch (measured: DESIGN.md 3)
   // ... and so does a launch capped at a few steps (stepping a resident batch turn by turn): there is no tail to regroup
@@ -1725,7 +1750,7 @@ static int launch_group(oakgpu_ctx *c, const oak::BatchDesc *descs, uint32_t cou
     q.sb = sb; q.sd = sd; q.sres = sres;
     q.suspend_below = r + 1 < rounds ? (uint32_t)(tail_pack ? c->tail_below : c->suspend_below) : 0u;
     q.queue = c->d_queue + 2 * r;
-    q.lanes = (tail_pack && r > 0) ? (uint32_t)c->tail_lanes : 0u;
+    q.lanes = (tail_pack && r > 0) ? (uint32_t)c->tail_lanes : (r == 0 ? spread : 0u);
 #define OAK_LAUNCH_Q(W) hipLaunchKernelGGL((oak::k_rollout_queue<64, W>), dim3(waves), dim3(64), lq, c->stream, g, q)
     if (c->waves_per_simd >= 4) OAK_LAUNCH_Q(4); else if (c->waves_per_simd == 3) OAK_LAUNCH_Q(3); else OAK_LAUNCH_Q(2);
 #undef OAK_LAUNCH_Q

@@ -54,6 +54,13 @@ def run(label, reps_=4):
 
 run("default")
 run("default")
+if len(sys.argv) > 4 and sys.argv[4] == "spread":
+    for ppl in (2, 1):
+        ctx.set_playouts_per_lane(ppl)
+        for lanes in (0, 48, 32, 24, 16, 12, 8, 4):
+            _lib.check(lib.oakgpu_set_spread(h, lanes))
+            run("playouts per lane %d, spread: %s lanes per wave" % (ppl, lanes or "all 64"))
+    sys.exit(0)
 _lib.check(lib.oakgpu_set_queue_order(h, 0))
 _lib.check(lib.oakgpu_set_regroup(h, 4, 32, 3))
 run("regrouping rounds 4 / 32 / 3, queue order 0")
