@@ -857,11 +857,17 @@ def cpu_baseline(n):
         total += int(steps.sum())
         reps += 1
     dt = time.perf_counter() - t0
+    # one thread, like the reference's `benchmark` binary (benchmark.cc:9-51: one search thread; TUTORIAL.md:18-21 is its number)
+    s1 = min(sample, 4096)
+    t1 = time.perf_counter()
+    _, st1 = O.rollout_batch(b[:s1].copy(), d[:s1].copy(), r[:s1], p[:s1].copy(), max_steps=MAX_STEPS, threads=1)
+    dt1 = time.perf_counter() - t1
     return {
         "value": total / dt,
         "unit": "turn-steps/s",
         "cores": cores,
         "threads_source": tsrc,
+        "single_thread": {"value": int(st1.sum()) / dt1, "unit": "turn-steps/s", "sample": "%d playouts, 1 thread" % s1},
         "kind": "port",
         "sample": "%d passes over %d playouts (same lane seeds as the GPU batch), %d threads, oracle/liboracle.so "
                   "gcc -O3 -march=x86-64-v3" % (reps, sample, cores),
