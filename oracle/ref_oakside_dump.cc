@@ -10,6 +10,9 @@
 //   * MCTS::randomize_hidden_variables                                       (cpp/include/search/durations.h:25-97)
 //   * PokeEngine::evaluate_battle / Eval::evaluate                           (cpp/include/search/poke-engine-evaluate.h:184-204)
 //   * PKMN::battle (Init::init_side / init_pokemon / compute_stat)           (cpp/include/libpkmn/pkmn.h:50-57, init.h:90-154)
+//   * PKMN::result(battle), the request byte recomputed from a state        (cpp/include/libpkmn/pkmn.h:235-272)
+//   * Train::Battle::CompressedFrames::write / Update::write / compress_probs (cpp/include/train/battle/compressed-frame.h:11-25,
+//     48-57,84-118,181-214): the `.battle.data` record of a game, from search outputs handed in as doubles
 //
 // HOW IT IS COMPILED, stated plainly: every header above includes <pkmn.h>, libpkmn's GENERATED C header, which this checkout
 // does not have.  The include path therefore names ../include, i.e. the PRODUCT's own boundary header include/pkmn.h -- the
@@ -18,8 +21,14 @@
 // into these fixtures: they are outputs of the reference's own arithmetic on given bytes.  This is an integration build of the
 // reference's headers against the drop-in header, not a build of libpkmn, and it pins nothing at the libpkmn boundary.
 //
+// NOT covered, because it cannot be: Parse::parse_battle (util/parse.h) includes util/strings.h -> search/mcts.h -> the
+// network headers -> Eigen, which is absent; no stand-in is written for it (oak_amd/parse.py stays pinned only by the positions
+// of search-test.cc / TUTORIAL.md it has to reproduce).
+//
 // usage: ref_oakside_dump states <file>   records of 400 B: battle[384] durations[8] seed_le[8]
 //        ref_oakside_dump teams  <file>   records of 68 B: 2 x 6 x (species, move[4]) then seed_le[8]
+//        ref_oakside_dump frames <file>   games: battle[384] result[1] count_le[2] then count x { m n c1 c2 iterations_le[4]
+//                                         double empirical_value nash_value p1_empirical[9] p1_nash[9] p2_empirical[9] p2_nash[9] }
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
@@ -31,6 +40,7 @@
 #include <libpkmn/pkmn.h>
 #include <search/durations.h>
 #include <search/poke-engine-evaluate.h>
+#include <train/battle/compressed-frame.h>
 
 namespace {
 std::vector<uint8_t> slurp(const char *path) {
@@ -115,6 +125,7 @@ void dump_state(const uint8_t *rec, bool first) {
   {
     PokeEngine::Eval e{};
     e.get_root_score(b);
+    printf(",\"result\":%u", (unsigned)PKMN::result(b));
     printf(",\"pe_score\":%.9g,\"pe_value_at_root\":%.9g", PokeEngine::evaluate_battle(battle), e.evaluate(b));
   }
   printf("}");
@@ -134,11 +145,46 @@ void dump_team(const uint8_t *rec, bool first) {
   const pkmn_gen1_battle b = PKMN::battle(t[0], t[1], seed);
   printf("%s", first ? "" : ",\n"); hex(reinterpret_cast<const uint8_t *>(&b), 384);
 }
+
+// What Update's constructor reads of an MCTS::Output (mcts.h:68-90: k, empirical, nash per side; iterations; the two values).
+struct OutputSide { uint8_t k; std::array<double, 9> empirical; std::array<double, 9> nash; };
+struct OutputLike { size_t iterations; double empirical_value; double nash_value; OutputSide p1; OutputSide p2; };
+
+size_t dump_game(const uint8_t *p, size_t left, bool first) {
+  if (left < 387) { fprintf(stderr, "short game header\n"); exit(2); }
+  pkmn_gen1_battle b; memcpy(&b, p, 384);
+  Train::Battle::CompressedFrames frames{b};
+  frames.result = p[384];
+  uint16_t count; memcpy(&count, p + 385, 2);
+  size_t at = 387;
+  for (unsigned u = 0; u < count; ++u) {
+    if (left < at + 8 + 38 * 8) { fprintf(stderr, "short update\n"); exit(2); }
+    OutputLike o{};
+    o.p1.k = p[at]; o.p2.k = p[at + 1];
+    const pkmn_choice c1 = p[at + 2], c2 = p[at + 3];
+    uint32_t it; memcpy(&it, p + at + 4, 4); o.iterations = it;
+    double v[38]; memcpy(v, p + at + 8, sizeof v);
+    o.empirical_value = v[0]; o.nash_value = v[1];
+    for (int i = 0; i < 9; ++i) { o.p1.empirical[i] = v[2 + i]; o.p1.nash[i] = v[11 + i]; o.p2.empirical[i] = v[20 + i]; o.p2.nash[i] = v[29 + i]; }
+    frames.updates.emplace_back(o, c1, c2);
+    at += 8 + 38 * 8;
+  }
+  std::vector<char> buf(frames.n_bytes());
+  frames.write(buf.data());
+  printf("%s", first ? "" : ",\n"); hex(reinterpret_cast<const uint8_t *>(buf.data()), buf.size());
+  return at;
+}
 } // namespace
 
 int main(int argc, char **argv) {
   if (argc != 3) { fprintf(stderr, "usage: %s states|teams <file>\n", argv[0]); return 2; }
   const auto in = slurp(argv[2]);
+  if (!strcmp(argv[1], "frames")) {
+    printf("[");
+    for (size_t at = 0, i = 0; at < in.size(); ++i) at += dump_game(in.data() + at, in.size() - at, i == 0);
+    printf("]\n");
+    return 0;
+  }
   const bool states = !strcmp(argv[1], "states");
   const size_t rec = states ? 400 : 68;
   if (in.size() % rec) { fprintf(stderr, "input is not a whole number of %zu-byte records\n", rec); return 2; }

@@ -102,6 +102,35 @@ def main():
         teams.append((bytes(t), seed))
         payload += bytes(t) + seed.to_bytes(8, "little")
     init = run_dump("teams", payload)
+
+    # `.battle.data` records: games of 1 / 14 / 40 updates with random search outputs (doubles, exact in JSON), plus the
+    # truncation edges of compress_probs (0, 1, just below k / 65535 steps)
+    import struct
+    frng = np.random.default_rng(77)
+    games, payload = [], b""
+    for gi, count in enumerate((1, 14, 40)):
+        battle = b[keep[gi]].tobytes()
+        result = int(frng.integers(1, 4))
+        ups = []
+        for u in range(count):
+            m, n = int(frng.integers(1, 10)), int(frng.integers(1, 10))
+            dd = lambda k: [float(x) for x in frng.dirichlet(np.ones(k))]
+            up = dict(m=m, n=n, c1=int(frng.integers(0, 28)), c2=int(frng.integers(0, 28)), iterations=int(frng.integers(1, 1 << 31)),
+                      empirical_value=float(frng.random()), nash_value=float(frng.random()),
+                      p1_empirical=dd(m), p1_nash=dd(m), p2_empirical=dd(n), p2_nash=dd(n))
+            if u == 0:
+                up.update(empirical_value=1.0, nash_value=0.0, p1_empirical=[1.0] + [0.0] * (m - 1), p2_nash=[3 / 65535.0 - 1e-12] + dd(n)[1:])
+            ups.append(up)
+        games.append(dict(battle=battle.hex(), result=result, updates=ups))
+        payload += battle + bytes([result]) + struct.pack("<H", count)
+        for up in ups:
+            pad = lambda v: list(v) + [0.0] * (9 - len(v))
+            payload += struct.pack("<BBBBI", up["m"], up["n"], up["c1"], up["c2"], up["iterations"])
+            payload += struct.pack("<38d", up["empirical_value"], up["nash_value"], *pad(up["p1_empirical"]), *pad(up["p1_nash"]),
+                                   *pad(up["p2_empirical"]), *pad(up["p2_nash"]))
+    records = run_dump("frames", payload)
+    for g, r in zip(games, records):
+        g["record"] = r
     out = dict(
         about="reference Oak-side outputs on committed inputs; generated by tests/golden/make_oakside_goldens.py via "
               "oracle/_ref/ref_oakside_dump (reference headers compiled against include/pkmn.h; no pkmn_* function linked)",
@@ -109,7 +138,8 @@ def main():
                       pokemon_keys=len({i for k, i in seen if k == "pk"}), policy_indices=len({i for k, i in seen if k == "pol"}),
                       candidates=len(b)),
         states=states,
-        teams=[dict(teams=t.hex(), seed=s, battle=h) for (t, s), h in zip(teams, init)])
+        teams=[dict(teams=t.hex(), seed=s, battle=h) for (t, s), h in zip(teams, init)],
+        frames=games)
     path = os.path.join(HERE, "oakside_goldens.json")
     with open(path, "w") as f:
         json.dump(out, f, separators=(",", ":"))
