@@ -349,7 +349,8 @@ int oakgpu_frames_read(const uint8_t *buffer, size_t size, uint8_t *battle /* 38
                        oakgpu_frame_update *updates /* nullable */, uint32_t capacity, uint32_t *count, size_t *consumed);
 /* One self-play game, the per-game loop of the reference's data generator (cpp/src/generate.cc:238-322): PKMN::battle(teams,
  * battle_seed) + opening update, then per turn oakgpu_search -> RuntimePolicy::process_and_sample for both sides
- * (util/policy.h:22-106; mode words e / n / x with optional weights, e.g. "e0.9-x0.1") -> frame -> update, until the result
+ * (util/policy.h:22-106; mode words e / n / x / p with optional weights, e.g. "e0.9-x0.1"; p = prior + empirical, the
+ * reference's fall-through, useful with the contextual bandits only) -> frame -> update, until the result
  * is terminal; the finished record is written to `buffer`.  Every battle operation runs on the GPU.  Fails (no record
  * written) when the game exceeds max_battle_length turns (0 = 1000), like the reference (generate.cc:268-271). */
 typedef struct {

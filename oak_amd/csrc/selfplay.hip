@@ -46,9 +46,11 @@ double uniform01(uint64_t &rng) { return (double)(splitmix64(rng) >> 11) * (1.0 
 
 // RuntimePolicy::get_policy (util/policy.h:22-98) for the modes the search output can feed: words of the mode string are
 // 'e' (empirical), 'n' (nash), 'x' (argmax of empirical), each optionally followed by a weight ("e0.9-x0.1"); then
-// temperature, the minimum-probability cut and renormalisation.  'p' (prior) and 'b' (beta) need fields this output
-// does not carry and are refused, like an unknown mode character.
-bool get_policy(const double *empirical, const double *nash, int k, const char *mode, double temp, double minp, double *policy) {
+// temperature, the minimum-probability cut and renormalisation.  'p' (prior, the contextual bandits' softmaxed logits) adds
+// w * prior AND THEN w * empirical: the reference's `case Mode::prior` has no `break` and falls into the empirical case
+// (policy.h:37-46), and a drop-in follows what the code does.  'b' (beta) throws in the reference (policy.h:59-60) and is
+// refused here, like an unknown mode character.
+bool get_policy(const double *prior, const double *empirical, const double *nash, int k, const char *mode, double temp, double minp, double *policy) {
   for (int i = 0; i < 9; ++i) policy[i] = 0;
   const std::string s(mode && *mode ? mode : "e");
   size_t pos = 0;
@@ -59,7 +61,8 @@ bool get_policy(const double *empirical, const double *nash, int k, const char *
     pos = end + 1;
     if (word.empty()) continue;
     const double w = word.size() > 1 ? atof(word.c_str() + 1) : 1.0;
-    if (word[0] == 'e') { for (int i = 0; i < k; ++i) policy[i] += w * empirical[i]; }
+    if (word[0] == 'p') { for (int i = 0; i < k; ++i) policy[i] += w * prior[i] + w * empirical[i]; }
+    else if (word[0] == 'e') { for (int i = 0; i < k; ++i) policy[i] += w * empirical[i]; }
     else if (word[0] == 'n') { for (int i = 0; i < k; ++i) policy[i] += w * nash[i]; }
     else if (word[0] == 'x') { policy[std::max_element(empirical, empirical + k) - empirical] += w; }
     else return false;
@@ -181,8 +184,8 @@ int oakgpu_selfplay_game(oakgpu_ctx *ctx, oakgpu_net *net, const uint8_t *teams,
     sp.seed = splitmix64(rng);
     if (int rc = oakgpu_search_heap(ctx, net, heap.h, battle, durations, result, &sp, nullptr, &out)) return rc;
     double pol1[9], pol2[9];
-    if (!get_policy(out.p1_empirical, out.p1_nash, out.m, prm->policy_mode, prm->policy_temp > 0 ? prm->policy_temp : 1.0, prm->policy_min, pol1) ||
-        !get_policy(out.p2_empirical, out.p2_nash, out.n, prm->policy_mode, prm->policy_temp > 0 ? prm->policy_temp : 1.0, prm->policy_min, pol2))
+    if (!get_policy(out.p1_prior, out.p1_empirical, out.p1_nash, out.m, prm->policy_mode, prm->policy_temp > 0 ? prm->policy_temp : 1.0, prm->policy_min, pol1) ||
+        !get_policy(out.p2_prior, out.p2_empirical, out.p2_nash, out.n, prm->policy_mode, prm->policy_temp > 0 ? prm->policy_temp : 1.0, prm->policy_min, pol2))
       return oakgpu_fail_msg("oakgpu_selfplay_game: policy mode must be built from e / n / x words and leave a non-zero policy (util/policy.h:22-98)");
     const int i = sample_pdf(pol1, out.m, rng), j = sample_pdf(pol2, out.n, rng);
     oakgpu_frame_update u{};

@@ -56,6 +56,13 @@ def test_selfplay_with_the_network_evaluator_and_length_cap(gpu_ctx):
     rec, frames, result = selfplay_game(gpu_ctx, teams, battle_seed=77, iterations=256, batch=256, bandit="pucb", c=1.5, evaluator=net, seed=9)
     (game,) = read_frames(rec)
     assert len(game["updates"]) == frames and _replay(gpu_ctx, game) == result
+    # 'p': the contextual bandit's prior mixed in (policy.h:37-46, the reference's fall-through into 'e')
+    rec, frames, result = selfplay_game(gpu_ctx, teams, battle_seed=78, iterations=256, batch=256, bandit="pucb", c=1.5, evaluator=net,
+                                        policy_mode="p0.5-x0.5", seed=10)
+    (game,) = read_frames(rec)
+    assert len(game["updates"]) == frames and _replay(gpu_ctx, game) == result
+    with pytest.raises(RuntimeError, match="policy mode"):
+        selfplay_game(gpu_ctx, teams, battle_seed=77, iterations=64, batch=64, policy_mode="b", seed=9)
     with pytest.raises(RuntimeError, match="max battle length"):
         selfplay_game(gpu_ctx, teams, battle_seed=77, iterations=64, batch=64, max_battle_length=3, seed=9)
     with pytest.raises(RuntimeError, match="policy mode"):
