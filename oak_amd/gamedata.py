@@ -32,6 +32,33 @@ def species_id(name):
     return _SPECIES_BY_LOWER[name.lower().replace(" ", "").replace("-", "")]
 
 
+def _unique_prefix(names, width, token):
+    """PKMN::unique_index over the fixed-width name arrays (libpkmn/strings.h:53-83; widths data/strings.h:17-19,63-66): a
+    token matches every name it is a case-insensitive PREFIX of; exactly one match -> its index, anything else -> -1.  The
+    reference's "prefer the exact-length match" branch compares with the ARRAY width (13 / 12), which no token that matched
+    can have, so an ambiguous prefix is never rescued by an exact name: "mew" (Mewtwo, Mew) and "thunder" (ThunderShock,
+    Thunderbolt, ThunderWave, Thunder) match nothing.  A drop-in does what the code does."""
+    t = token.lower()
+    if len(t) >= width:
+        return -1
+    hits = [i for i, n in enumerate(names) if n.lower().startswith(t)]
+    return hits[0] if len(hits) == 1 else -1
+
+
+def match_move(token):
+    """PKMN::string_to_move as parse_set uses it (util/parse.h:24-41): move id, or None when the word is not (uniquely) a move."""
+    i = _unique_prefix(MOVE_NAMES, 13, token)
+    return None if i < 0 else i
+
+
+def match_species(token):
+    """PKMN::string_to_species (libpkmn/strings.h:313-321); raises like the reference."""
+    i = _unique_prefix(SPECIES_NAMES, 12, token)
+    if i < 0:
+        raise RuntimeError("Could not match string to Species")
+    return i
+
+
 def ou_pools():
     """(legal_species u8[149], pool_moves u8[152,48], pool_sizes u8[152])."""
     legal = np.array(DATA["ou_legal_species"], dtype=np.uint8)

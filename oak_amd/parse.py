@@ -19,16 +19,13 @@ def _put16(buf, off, v):
 
 def _parse_set(words):
     """parse.h:14-110 -> dict(species, moves[4], pp[4], hp, percent, status, sleeps, level)."""
-    s = dict(species=G.species_id(words[0]), moves=[0, 0, 0, 0], pp=[64, 64, 64, 64], hp=-1,
+    s = dict(species=G.match_species(words[0]), moves=[0, 0, 0, 0], pp=[64, 64, 64, 64], hp=-1,
              percent=100, status=0, sleeps=0, level=100)
     n_moves = 0
     for word in words[1:]:
         if n_moves < 4:
             mp = word.split(":")
-            try:
-                m = G.move_id(mp[0])
-            except KeyError:
-                m = None
+            m = G.match_move(mp[0])
             if m is not None:
                 s["moves"][n_moves] = m
                 s["pp"][n_moves] = min(255, int(mp[1])) if len(mp) > 1 else 0xFF

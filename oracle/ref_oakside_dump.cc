@@ -10,6 +10,8 @@
 //   * MCTS::randomize_hidden_variables                                       (cpp/include/search/durations.h:25-97)
 //   * PokeEngine::evaluate_battle / Eval::evaluate                           (cpp/include/search/poke-engine-evaluate.h:184-204)
 //   * PKMN::battle (Init::init_side / init_pokemon / compute_stat)           (cpp/include/libpkmn/pkmn.h:50-57, init.h:90-154)
+//   * PKMN::string_to_species / string_to_move: the prefix matching parse_battle's words go through (libpkmn/strings.h:53-83,
+//     313-331)
 //   * PKMN::result(battle), the request byte recomputed from a state        (cpp/include/libpkmn/pkmn.h:235-272)
 //   * Train::Battle::CompressedFrames::write / Update::write / compress_probs (cpp/include/train/battle/compressed-frame.h:11-25,
 //     48-57,84-118,181-214): the `.battle.data` record of a game, from search outputs handed in as doubles
@@ -27,6 +29,7 @@
 //
 // usage: ref_oakside_dump states <file>   records of 400 B: battle[384] durations[8] seed_le[8]
 //        ref_oakside_dump teams  <file>   records of 68 B: 2 x 6 x (species, move[4]) then seed_le[8]
+//        ref_oakside_dump names  <file>   one token per line -> [species index or -1, move index or -1]
 //        ref_oakside_dump frames <file>   games: battle[384] result[1] count_le[2] then count x { m n c1 c2 iterations_le[4]
 //                                         double empirical_value nash_value p1_empirical[9] p1_nash[9] p2_empirical[9] p2_nash[9] }
 #include <cstdint>
@@ -182,6 +185,24 @@ int main(int argc, char **argv) {
   if (!strcmp(argv[1], "frames")) {
     printf("[");
     for (size_t at = 0, i = 0; at < in.size(); ++i) at += dump_game(in.data() + at, in.size() - at, i == 0);
+    printf("]\n");
+    return 0;
+  }
+  if (!strcmp(argv[1], "names")) {
+    std::string text(in.begin(), in.end());
+    printf("[");
+    size_t at = 0; bool first = true;
+    while (at < text.size()) {
+      size_t nl = text.find('\n', at);
+      if (nl == std::string::npos) nl = text.size();
+      const std::string tok = text.substr(at, nl - at);
+      at = nl + 1;
+      if (tok.empty()) continue;
+      int sp = -1, mv = -1;
+      try { sp = (int)PKMN::string_to_species(tok); } catch (const std::exception &) {}
+      try { mv = (int)PKMN::string_to_move(tok); } catch (const std::exception &) {}
+      printf("%s[%d,%d]", first ? "" : ",", sp, mv); first = false;
+    }
     printf("]\n");
     return 0;
   }

@@ -131,6 +131,21 @@ def main():
     records = run_dump("frames", payload)
     for g, r in zip(games, records):
         g["record"] = r
+    # name matching of parse_battle's words: every name, every proper prefix, case variants and a few non-names
+    from oak_amd import gamedata as GD
+    toks = set()
+    for nm in GD.SPECIES_NAMES + GD.MOVE_NAMES:
+        for k in range(1, len(nm) + 1):
+            toks.add(nm[:k].lower())
+        toks.add(nm)
+        toks.add(nm.upper())
+        toks.add(nm + "x")
+    toks |= {"par", "psn", "brn", "frz", "slp3", "rst2", "100hp", "50%", "lvl50", "body-slam", "body slam".replace(" ", "_"), "(conf:3)",
+             "atk+2", "spc=300", "thunderwavee", "farfetchd"}
+    toks = sorted(toks)
+    pairs = run_dump("names", ("\n".join(toks) + "\n").encode())
+    assert len(pairs) == len(toks)
+    names = dict(tokens=toks, species=[a for a, _ in pairs], moves=[b_ for _, b_ in pairs])
     out = dict(
         about="reference Oak-side outputs on committed inputs; generated by tests/golden/make_oakside_goldens.py via "
               "oracle/_ref/ref_oakside_dump (reference headers compiled against include/pkmn.h; no pkmn_* function linked)",
@@ -139,7 +154,7 @@ def main():
                       candidates=len(b)),
         states=states,
         teams=[dict(teams=t.hex(), seed=s, battle=h) for (t, s), h in zip(teams, init)],
-        frames=games)
+        frames=games, names=names)
     path = os.path.join(HERE, "oakside_goldens.json")
     with open(path, "w") as f:
         json.dump(out, f, separators=(",", ":"))

@@ -341,11 +341,11 @@ def test_counter_only_answers_normal_and_fighting():
 
 
 def test_mirror_move_and_metronome():
-    b, d = parse_battle("pidgeot mirrormove | starmie surf")
+    b, d = parse_battle("fearow mirrormove | starmie surf")
     h1 = hp(b, 1)
     step(b, d, mv(b, 0, "MirrorMove"), mv(b, 1, "Surf"))           # Starmie is faster: its Surf is mirrored
     assert hp(b, 1) < h1 and int(b[183]) == G.move_id("Surf")       # last_used_move = the copied move
-    b, d = parse_battle("pidgeot mirrormove | snorlax bodyslam")
+    b, d = parse_battle("fearow mirrormove | snorlax bodyslam")
     h1 = hp(b, 1)
     step(b, d, mv(b, 0, "MirrorMove"), mv(b, 1, "BodySlam"))       # Pidgeot is faster: nothing to mirror yet
     assert hp(b, 1) == h1

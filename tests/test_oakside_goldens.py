@@ -130,6 +130,22 @@ def test_result_from_state_matches_the_reference():
     assert len(kinds) >= 3   # plain turns and forced switches on either side at least
 
 
+def test_name_matching_of_battle_strings_matches_the_reference():
+    """PKMN::string_to_species / string_to_move (libpkmn/strings.h:53-83,313-331): unique case-insensitive prefix, and an
+    ambiguous prefix is NOT rescued by an exact name ("mew", "thunder")."""
+    from oak_amd import gamedata as GD
+    N = G["names"]
+    assert len(N["tokens"]) > 2000
+    for tok, sp, mv in zip(N["tokens"], N["species"], N["moves"]):
+        assert GD._unique_prefix(GD.SPECIES_NAMES, 12, tok) == sp, tok
+        assert GD._unique_prefix(GD.MOVE_NAMES, 13, tok) == mv, tok
+    look = dict(zip(N["tokens"], zip(N["species"], N["moves"])))
+    assert look["mew"][0] == -1 and look["thunder"][1] == -1 and look["mewt"][0] == 150 and look["thunderw"][1] == 86
+    with pytest.raises(RuntimeError, match="Could not match string to Species"):
+        from oak_amd.parse import parse_battle
+        parse_battle("mew psychic | snorlax bodyslam")
+
+
 def test_turn0_init_matches_the_reference():
     """PKMN::battle / Init::init_side / init_pokemon / compute_stat (pkmn.h:50-57, init.h:90-154), all 384 bytes."""
     for t in G["teams"]:
