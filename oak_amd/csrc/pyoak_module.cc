@@ -159,7 +159,6 @@ PYBIND11_MODULE(pyoak, m) {
       "battle_string",
       [](const Input &input) {
         py::object mod = py::module_::import("oak_amd.parse");
-        if (!py::hasattr(mod, "battle_string")) throw std::runtime_error("battle_string: not provided by oak_amd.parse");
         return mod.attr("battle_string")(py::bytes((const char *)input.battle, 384), py::bytes((const char *)input.durations, 8)).cast<std::string>();
       },
       py::arg("input"));
@@ -199,6 +198,33 @@ PYBIND11_MODULE(pyoak, m) {
       .def_property_readonly("p2_empirical", [](const Output &o) { return vec9<double>([&](int i) { return o.raw.p2_empirical[i]; }); })
       .def_property_readonly("p1_nash", [](const Output &o) { return vec9<double>([&](int i) { return o.raw.p1_nash[i]; }); })
       .def_property_readonly("p2_nash", [](const Output &o) { return vec9<double>([&](int i) { return o.raw.p2_nash[i]; }); });
+
+  m.def(
+      "format",
+      [](const Input &input, const Output &o) { // MCTS::output_string(output, input), pyoak.cc:487-492
+        py::object mod = py::module_::import("oak_amd.parse");
+        py::dict d;
+        const int mm = o.raw.m, nn = o.raw.n;
+        d["m"] = mm; d["n"] = nn;
+        d["iterations"] = (uint64_t)o.raw.iterations;
+        d["duration_ms"] = o.raw.duration_us / 1e3;
+        d["empirical_value"] = o.raw.empirical_value;
+        d["p1_choices"] = std::vector<int>(o.raw.p1_choices, o.raw.p1_choices + mm);
+        d["p2_choices"] = std::vector<int>(o.raw.p2_choices, o.raw.p2_choices + nn);
+        d["p1_empirical"] = std::vector<double>(o.raw.p1_empirical, o.raw.p1_empirical + 9);
+        d["p2_empirical"] = std::vector<double>(o.raw.p2_empirical, o.raw.p2_empirical + 9);
+        d["p1_nash"] = std::vector<double>(o.raw.p1_nash, o.raw.p1_nash + 9);
+        d["p2_nash"] = std::vector<double>(o.raw.p2_nash, o.raw.p2_nash + 9);
+        d["p1_prior"] = std::vector<double>(o.raw.p1_prior, o.raw.p1_prior + 9);
+        d["p2_prior"] = std::vector<double>(o.raw.p2_prior, o.raw.p2_prior + 9);
+        py::array_t<double> vis({9, 9}), val({9, 9});
+        auto rv = vis.mutable_unchecked<2>(); auto rw = val.mutable_unchecked<2>();
+        for (int i = 0; i < 9; ++i)
+          for (int j = 0; j < 9; ++j) { rv(i, j) = (double)o.raw.visit_matrix[i * 9 + j]; rw(i, j) = o.raw.value_matrix[i * 9 + j]; }
+        d["visit_matrix"] = vis; d["value_matrix"] = val;
+        return mod.attr("format_output")(py::bytes((const char *)input.battle, 384), d).cast<std::string>();
+      },
+      py::arg("input"), py::arg("output"));
 
   m.def(
       "search",

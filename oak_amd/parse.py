@@ -213,3 +213,129 @@ def result_from_state(battle):
     if f2:
         return 2 << 6
     return (1 << 4) | (1 << 6)
+
+
+_VOL_FLAGS = ("bide", "thrashing", "multi-hit", "flinch", "charging", "binding", "invulnerable", "confused", "mist", "focus-energy",
+              "substitute", "recharging", "rage", "leech-seed", "toxic", "light-screen", "reflect", "transform")
+_STATUS_TEXT = {0x08: "PSN", 0x10: "BRN", 0x20: "FRZ", 0x40: "PAR", 0x88: "TOX"}
+
+
+def _status_text(st):
+    """PKMN::status_string (libpkmn/strings.h:85-112)."""
+    if st == 0:
+        return ""
+    if st & 7:
+        return "RST" if st & 0x80 else "SLP"
+    return _STATUS_TEXT.get(st, "")
+
+
+def battle_string(battle, durations):
+    """PKMN::battle_data_to_string (libpkmn/strings.h:187-303), pyoak's `battle_string(input)` (pyoak.cc:480-485): the text
+    dump of both sides -- per side the lead's changed stats, its public durations and volatiles, then one line per party
+    slot in battle order."""
+    b = np.frombuffer(bytes(battle), dtype=np.uint8)
+    d = np.frombuffer(bytes(durations), dtype=np.uint8)
+    u16 = lambda a, o: int(a[o]) | (int(a[o + 1]) << 8)
+    out = []
+    for s in range(2):
+        side = b[184 * s:184 * (s + 1)]
+        dur = int.from_bytes(bytes(d[4 * s:4 * s + 4]), "little")
+        act = side[144:176]
+        vol = int.from_bytes(bytes(act[16:24]), "little")
+        for i in range(6):
+            pid = int(side[176 + i])
+            if pid == 0:
+                continue
+            pk = side[24 * (pid - 1):24 * pid]
+            if i == 0:
+                changed = False
+                for k, name in ((1, "atk"), (2, "def"), (3, "spe"), (4, "spc")):
+                    if u16(act, 2 * k) != u16(pk, 2 * k):
+                        out.append("(%s %d>>%d) " % (name, u16(pk, 2 * k), u16(act, 2 * k)))
+                        changed = True
+                if changed:
+                    out.append("\n")
+                any_dur = False
+                for text, sh, bits in (("conf: ", 18, 3), (" disable: ", 21, 4), (" attacking: ", 25, 3), (" binding: ", 28, 3)):
+                    v = (dur >> sh) & ((1 << bits) - 1)
+                    if v:
+                        out.append("%s%d" % (text, v))
+                        any_dur = True
+                if any_dur:
+                    out.append("\n")
+                vt = "".join("(%s)" % n for k, n in enumerate(_VOL_FLAGS) if (vol >> k) & 1)
+                for name, sh, mask in (("confusion_left", 18, 7), ("attacks", 21, 7), ("state", 24, 0xFFFF), ("sub_hp", 40, 0xFF)):
+                    if (vol >> sh) & mask:
+                        vt += "(%s: %d)" % (name, (vol >> sh) & mask)
+                if (vol >> 48) & 15:
+                    vt += "(transform: %s)" % G.SPECIES_NAMES[(vol >> 48) & 15]
+                for name, sh, mask in (("disable_left", 52, 15), ("disable_move", 56, 7), ("toxic_counter", 59, 31)):
+                    if (vol >> sh) & mask:
+                        vt += "(%s: %d)" % (name, (vol >> sh) & mask)
+                if vt:
+                    out.append(vt + "\n")
+            else:
+                out.append("  ")
+            out.append(G.SPECIES_NAMES[int(pk[21])])
+            if int(pk[23]) != 100:
+                out.append(" L%d" % int(pk[23]))
+            out.append(": ")
+            hp, mx = u16(pk, 18), u16(pk, 0)
+            if hp == 0:
+                out.append("KO \n")
+                continue
+            pct = int(np.ceil(np.float32(np.float32(100) * np.float32(hp)) / np.float32(mx)))     # Pokemon::percent, data.h:49-51
+            out.append("%d%% (%d/%d) " % (pct, hp, mx))
+            st = int(pk[20])
+            if st:
+                out.append(_status_text(st))
+                if st & 7:
+                    out.append(":%d" % ((st & 7) if st & 0x80 else (dur >> (3 * i)) & 7))
+                out.append(" ")
+            for m in range(4):
+                out.append("%s:%d " % (G.MOVE_NAMES[int(pk[10 + 2 * m])], int(pk[11 + 2 * m])))
+            out.append("\n")
+        if s == 0:
+            out.append("--- --- --- %d --- --- ---\n" % u16(b, 368))
+    return "".join(out)
+
+
+def choice_label(side, choice):
+    """PKMN::side_choice_string (libpkmn/strings.h:30-51); side = 184 bytes."""
+    kind, data = int(choice) & 3, int(choice) >> 2
+    slot = lambda k: side[24 * (int(side[176 + k - 1]) - 1):][:24]
+    if kind == 0:
+        return "Pass"
+    if kind == 1:
+        return "None" if data == 0 else G.MOVE_NAMES[int(slot(1)[8 + 2 * data])]
+    return G.SPECIES_NAMES[int(slot(data)[21])]
+
+
+def format_output(battle, output):
+    """MCTS::output_string (util/strings.h:61-152), pyoak's `format(input, output)` (pyoak.cc:487-492).  `output`: the dict
+    oak_amd.search.tree_search returns.  (The reference's function cannot be run here -- util/strings.h reaches Eigen -- so this
+    text layout is a port by reading, unlike battle_string which is checked against the reference's own output.)"""
+    b = np.frombuffer(bytes(battle), dtype=np.uint8)
+    m, n = int(output["m"]), int(output["n"])
+    l1 = [choice_label(b[0:184], c) for c in output["p1_choices"][:m]]
+    l2 = [choice_label(b[184:368], c) for c in output["p2_choices"][:n]]
+    fix = lambda label: "%-8s" % label[:7]
+    row = lambda prefix, cells: prefix + "".join(c + "  " for c in cells) + "\n"
+    num = lambda arr, k: ["%-8.3f" % float(x) for x in arr[:k]]
+    out = ["Iterations: %d, Time: %g ms\n" % (int(output["iterations"]), float(output["duration_ms"])),
+           "Value: %.3f\n\n" % float(output["empirical_value"])]
+    for name, labels, k, side in (("Player 1:", l1, m, "p1"), ("Player 2:", l2, n, "p2")):
+        out.append(name + "\n")
+        out.append(row("   ", ["%-8s" % x for x in labels]))
+        out.append(row("e: ", num(output[side + "_empirical"], k)))
+        out.append(row("n: ", num(output[side + "_nash"], k)))
+        out.append(row("p: ", num(output[side + "_prior"], k)))
+    visits, values = np.asarray(output["visit_matrix"]), np.asarray(output["value_matrix"])
+    header = fix(" " * 8) + " " + "".join(fix(x) + " " for x in l2) + "\n"
+    out.append("\nEV Matrix:\n" + header)
+    for i in range(m):
+        out.append(fix(l1[i]) + " " + "".join(" ----    " if visits[i, j] == 0 else "%-8.3f " % (values[i, j] / visits[i, j]) for j in range(n)) + "\n")
+    out.append("\nVisits:\n" + header)
+    for i in range(m):
+        out.append(fix(l1[i]) + " " + "".join(" ----    " if visits[i, j] == 0 else "%-8d " % int(visits[i, j]) for j in range(n)) + "\n")
+    return "".join(out)

@@ -12,6 +12,7 @@
 //   * PKMN::battle (Init::init_side / init_pokemon / compute_stat)           (cpp/include/libpkmn/pkmn.h:50-57, init.h:90-154)
 //   * PKMN::string_to_species / string_to_move: the prefix matching parse_battle's words go through (libpkmn/strings.h:53-83,
 //     313-331)
+//   * PKMN::battle_data_to_string, pyoak's battle_string                    (libpkmn/strings.h:187-303)
 //   * PKMN::result(battle), the request byte recomputed from a state        (cpp/include/libpkmn/pkmn.h:235-272)
 //   * Train::Battle::CompressedFrames::write / Update::write / compress_probs (cpp/include/train/battle/compressed-frame.h:11-25,
 //     48-57,84-118,181-214): the `.battle.data` record of a game, from search outputs handed in as doubles
@@ -129,6 +130,11 @@ void dump_state(const uint8_t *rec, bool first) {
     PokeEngine::Eval e{};
     e.get_root_score(b);
     printf(",\"result\":%u", (unsigned)PKMN::result(b));
+    printf(",\"text\":\"");
+    for (const char c : PKMN::battle_data_to_string(b, d)) {
+      if (c == '\n') printf("\\n"); else if (c == '"' || c == '\\') printf("\\%c", c); else putchar(c);
+    }
+    printf("\"");
     printf(",\"pe_score\":%.9g,\"pe_value_at_root\":%.9g", PokeEngine::evaluate_battle(battle), e.evaluate(b));
   }
   printf("}");

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Generate tests/golden/oakside_goldens.json: outputs of the reference's own header-only Oak-side code (feature encoders,
+"""Generate tests/golden/oakside_goldens.json.gz: outputs of the reference's own header-only Oak-side code (feature encoders,
 cache key, policy index, hidden-variable resampling, PokeEngine score, turn-0 init) on committed input bytes.
 
 Runs ONLY in the authoring container: it executes oracle/_ref/ref_oakside_dump, a binary compiled (oracle/Makefile, target
@@ -155,9 +155,10 @@ def main():
         states=states,
         teams=[dict(teams=t.hex(), seed=s, battle=h) for (t, s), h in zip(teams, init)],
         frames=games, names=names)
-    path = os.path.join(HERE, "oakside_goldens.json")
-    with open(path, "w") as f:
-        json.dump(out, f, separators=(",", ":"))
+    import gzip
+    path = os.path.join(HERE, "oakside_goldens.json.gz")
+    with open(path, "wb") as raw, gzip.GzipFile(fileobj=raw, mode="wb", mtime=0) as f:
+        f.write(json.dumps(out, separators=(",", ":")).encode())
     print(path, os.path.getsize(path), "bytes;", len(states), "states;", out["coverage"])
 
 

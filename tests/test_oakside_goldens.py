@@ -1,5 +1,5 @@
 """The oracle's Oak-side pieces (feature encoders, policy index, hidden-variable resampling, PokeEngine score, turn-0 init)
-against outputs of the REFERENCE's own header-only code on the same bytes (tests/golden/oakside_goldens.json, made by
+against outputs of the REFERENCE's own header-only code on the same bytes (tests/golden/oakside_goldens.json.gz, made by
 tests/golden/make_oakside_goldens.py through oracle/_ref/ref_oakside_dump -- see that source's header for how it is built).
 
 These pin SURVEY 8 rows a7 / a8 / a11 / a13 / a14 (encoders) / f3 (policy index) / f4 (PokeEngine) mechanically; they say
@@ -18,7 +18,9 @@ sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import nn_oracle as NN  # noqa: E402
 import oracle_lib as O  # noqa: E402
 
-with open(os.path.join(HERE, "golden", "oakside_goldens.json")) as f:
+import gzip  # noqa: E402
+
+with gzip.open(os.path.join(HERE, "golden", "oakside_goldens.json.gz"), "rt") as f:
     G = json.load(f)
 STATES = G["states"]
 
@@ -144,6 +146,17 @@ def test_name_matching_of_battle_strings_matches_the_reference():
     with pytest.raises(RuntimeError, match="Could not match string to Species"):
         from oak_amd.parse import parse_battle
         parse_battle("mew psychic | snorlax bodyslam")
+
+
+def test_battle_string_matches_the_reference():
+    """PKMN::battle_data_to_string (libpkmn/strings.h:187-303) = pyoak.battle_string, character for character."""
+    from oak_amd.parse import battle_string
+    kinds = 0
+    for st in STATES:
+        got = battle_string(_bytes(st["battle"]), _bytes(st["durations"]))
+        assert got == st["text"]
+        kinds += ">>" in got
+    assert kinds > 20
 
 
 def test_turn0_init_matches_the_reference():

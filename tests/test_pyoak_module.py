@@ -27,7 +27,7 @@ def _mod():
 
 def test_module_exposes_pyoak_names_and_constants():
     m = _mod()
-    for name in ("Heap", "Agent", "Input", "Output", "parse_battle", "update", "search", "solve_matrix", "read_battle_data", "cpp_inference",
+    for name in ("Heap", "Agent", "Input", "Output", "parse_battle", "battle_string", "format", "update", "search", "solve_matrix", "read_battle_data", "cpp_inference",
                  "value_inference", "value_policy_inference"):
         assert hasattr(m, name), name
     a = m.Agent()
@@ -53,6 +53,10 @@ def test_parse_battle_and_solve_matrix_and_read_battle_data(tmp_path):
     inp = m.parse_battle(s)                                                             # seed default 0x123456
     b, d = parse_battle(s)
     assert inp.battle == b.tobytes() and inp.durations == d.tobytes() and inp.result == result_from_state(b)
+    text = m.battle_string(inp)                                                         # pyoak.cc:480-485
+    assert text == ("Starmie: 32% (101/323) SLP:4 SeismicToss:32 None:0 None:0 None:0 \n--- --- --- 1 --- --- ---\n"
+                    "Snorlax: 1% (1/523) SeismicToss:32 None:0 None:0 None:0 \n")
+    assert "Iterations: 0" in m.format(inp, m.Output())
     p1, p2, v = m.solve_matrix(np.array([[0.5, 0.0, 1.0], [1.0, 0.5, 0.0], [0.0, 1.0, 0.5]], dtype=np.float32), 256)
     assert p1.dtype == np.float32 and np.allclose(p1, 1 / 3, atol=1e-6) and np.allclose(p2, 1 / 3, atol=1e-6) and abs(v - 0.5) < 1e-6
     with pytest.raises(RuntimeError, match="Expecting 2d array"):                        # pyoak.cc:396-398
@@ -98,6 +102,10 @@ def test_search_and_update_through_the_module():
         agent.budget, agent.eval, agent.bandit = "2048", ev, bandit
         out = m.search(full, m.Heap(), agent, batch=256, seed=1)
         assert out.iterations == 2048 and out.m == 4 and out.n == 4 and abs(out.p1_nash.sum() - 1) < 1e-9
+        text = m.format(full, out).split("\n")                                          # MCTS::output_string, util/strings.h:61-152
+        assert text[0].startswith("Iterations: 2048, Time: ") and text[3] == "Player 1:" and text[4].split() == ["Surf", "Recover", "Psychic", "ThunderWave"]
+        assert text[9].split() == ["Earthquake", "RockSlide", "BodySlam", "Substitute"] and text[14] == "EV Matrix:" and text[15].split() == ["Earthqu", "RockSli", "BodySla", "Substit"]
+        assert sum(int(x) for ln in text[23:27] for x in ln.split()[1:] if x != "----") == 2048
     for field, value, text in (("budget", "12parsecs", "Invalid search duration specification"), ("bandit", "thompson-1", "Could not parse bandit string"),
                                ("bandit", "ucb", "Could not parse bandit string"), ("matrix_ucb", "1-2-3", "Could not parse MatrixUCB name"),
                                ("eval", "/nonexistent/x.battle.net", "Cannot open network file")):
