@@ -400,6 +400,14 @@ int oakgpu_net_load_memory(oakgpu_ctx *ctx, const void *bytes, size_t size, oakg
 void oakgpu_net_free(oakgpu_ctx *ctx, oakgpu_net *net);
 /* MainNet::shape() (main-net.h:32-34): fc0.in, fc0.out, value_fc2.out, p1_policy_fc2.out */
 int oakgpu_net_shape(const oakgpu_net *net, int *in_dim, int *hidden, int *value_hidden, int *policy_hidden);
+/* How the main net's three dense layers are multiplied (results are fp32 either way, held to the same 1e-5 against the
+ * oracle): OAKGPU_MAIN_SPLIT (default) = every fp32 value as an exact sum of three bf16 parts, six bf16 MFMAs per fp32
+ * multiply-add block, fp32 accumulation (k_mainnet_split: 187 us per 65,536 leaves); OAKGPU_MAIN_FP32 = fp32 MFMA
+ * (k_mainnet_wave: 336 us).  The environment variable OAKGPU_MAIN_NET=fp32 makes the latter the default of networks loaded
+ * after it is set.  Returns the previous mode, -1 on a bad argument. */
+#define OAKGPU_MAIN_FP32 0
+#define OAKGPU_MAIN_SPLIT 1
+int oakgpu_net_set_main_precision(oakgpu_net *net, int mode);
 int oakgpu_leaf_eval_dev(oakgpu_ctx *ctx, oakgpu_net *net, const uint8_t *battles, const uint8_t *durations,
                          uint32_t n, float *values, float *embedding_out);
 int oakgpu_leaf_eval(oakgpu_ctx *ctx, oakgpu_net *net, const uint8_t *battles, const uint8_t *durations, uint32_t n,

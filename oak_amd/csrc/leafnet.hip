@@ -38,6 +38,10 @@ struct NetDev {
   const float *w0g, *w1g, *w2g; // the three weight matrices in k_mainnet_wave's MFMA-fragment order (frag_order_wave)
   float b3;
   int H, VH; // padded dims
+  // k_mainnet_split: the three matrices as ONE stream of bf16 triples in its MFMA-fragment order (split_stream), the k-steps
+  // of fc0 (ws_T0, a multiple of 4), the block count both widths are padded to (ws_NB: 1, 2, 4, 8)
+  const uint16_t *ws;
+  int ws_T0, ws_NB;
   // policy heads (main-net.h:67-107): fc2 [PHp][H] (rows padded to 32), fc3 [315][PHp] (+ biases)
   const float *q1a, *q1a_b, *q1b, *q1b_b, *q2a, *q2a_b, *q2b, *q2b_b;
   int PH; // padded policy hidden width
@@ -178,9 +182,16 @@ static __device__ unsigned long long g_leaf_prof[16];
 #define EL_FLUSH() do { if (threadIdx.x == 0) for (int _i = 0; _i < 8; ++_i) atomicAdd(&g_leaf_prof[_i], el_acc[_i]); } while (0)
 #define MN_T0() long long mn_t = clock64()
 #define MN_MARK(id) do { const long long _t = clock64(); if (threadIdx.x == 0) atomicAdd(&g_leaf_prof[id], (unsigned long long)(_t - mn_t)); mn_t = _t; } while (0)
+// k_mainnet_split counts its vector-memory operations by hand: its marks are kept in registers and added once per tile
+#define MS_T0() long long ms_t = clock64(); long long ms_d[6] = {0, 0, 0, 0, 0, 0}
+#define MS_MARK(i) do { const long long _t = clock64(); ms_d[i] = _t - ms_t; ms_t = _t; } while (0)
+#define MS_FLUSH() do { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); if (threadIdx.x == 0) for (int i_ = 0; i_ < 6; ++i_) atomicAdd(&g_leaf_prof[10 + i_], (unsigned long long)ms_d[i_]); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); } while (0)
 #else
 #define MN_T0()
 #define MN_MARK(id)
+#define MS_T0()
+#define MS_MARK(i)
+#define MS_FLUSH()
 #define EL_MARK(id)
 #define EL_T0()
 #define EL_FLUSH()
@@ -1357,6 +1368,299 @@ __global__ __launch_bounds__(MN_BLOCK) void k_mainnet_wave(MainArgs a) {
   }
 }
 
+// ---- K3': the main net on the bf16 matrix pipe, fp32 values carried as bf16 TRIPLES --------------------------------------
+// An fp32 value x is x = h + m + l exactly, with h = bf16(x), m = bf16(x - h), l = bf16(x - h - m) (each remainder is exact in
+// fp32 and the last one fits bf16's 8 significant bits).  A product x * w is then the sum of nine bf16 x bf16 products, each of
+// which is EXACT in the matrix pipe's fp32 accumulator; the kernel issues the six largest (hh, hm, mh, mm, hl, lh) and drops
+// ml + lm + ll <= 3 * 2^-25 |x w| -- less than the rounding error of the one fp32 multiply it replaces.  Sums accumulate in
+// fp32 exactly as before.  Why: v_mfma_f32_32x32x16_bf16 retires 32 x 32 x 16 multiply-adds in 32 cycles, the fp32 form
+// (32x32x2) needs 8 x 64 cycles for the same block -- six bf16 MFMAs are 192 cycles against 512 (MI355X_MICROARCH.md, cycle
+// constants).  The result is an fp32 result: tests/test_gpu_leafnet.py holds it to the same 1e-5 against the fp32 oracle and
+// measures its error against a float64 evaluation next to k_mainnet_wave's.
+//
+// Orientation: Out^T = W . In^T, i.e. the WEIGHTS are the A operand (rows = output features) and the batch rows sit on the
+// MFMA's columns = lanes.  A layer's result then has its features in the 16 accumulator registers and the batch row on the
+// lane -- which is exactly the B-operand layout of the next layer summing over those features (cdna_hip_programming.md, "an
+// accumulator tile as the next MFMA's operand"): activations never leave the registers, there is no LDS tile and no
+// transposition.  The k-order this implies (k-step t of fc1 / value_fc2 = registers 8 (t & 1) .. + 7 of block t >> 1 =
+// features 32 (t >> 1) + (reg & 3) + 8 (reg >> 2) + 4 h) is baked into the weight stream on the host (split_stream).
+//
+// One workgroup = 4 waves = 4 x 32 batch rows sharing ONE pass over the weight stream through a two-buffer LDS ring (a phase
+// = MS_G k-steps = NB x 6 KB): while the phase-p MFMAs run, phase p + 1 arrives in the other buffer by LDS-DMA (every wave
+// issues its 1-KB pieces at the start of phase p), and the waves meet at one barrier per phase.  L2 -> CU weight traffic is
+// 1 / 4 of k_mainnet_wave's per row although the triples are 1.5 x the bytes.
+//
+// Where it stands (profiles/r03_mainnet_split.json): 187 us per 65,536 leaves against k_mainnet_wave's 336; the six-fold MFMA
+// count keeps the matrix pipe 60-62 % busy, the level the best bf16 GEMMs reach on this chip under its power limit.  Deeper
+// rings, hand-counted vmcnt waits, interleaved accumulation chains, one LDS read per MFMA pair and a level-wise split all
+// measured 186-189 us; only removing work moved it (no split: 132 us, no LDS reads: 169 us) -- so the simplest form is kept.
+constexpr int MS_G = 2;
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+template <int NB> struct MSplit {
+  static constexpr int PHASE_BYTES = MS_G * NB * 3072;            // [k-step][block][h m l][lane] x 16 B
+  static constexpr int PT = (PHASE_BYTES + 4095) / 4096;          // 1-KB DMA pieces per wave per phase, at most
+  static constexpr size_t LDS = 2 * (size_t)PHASE_BYTES + 4 * MAXH * 4;
+};
+
+typedef __attribute__((address_space(3))) void ms_lds_void;
+typedef __attribute__((address_space(1))) const void ms_glb_void;
+// One phase of the stream into one ring buffer by LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write): a wave
+// instruction lands 64 x 16 B = 1 KB at a wave-uniform LDS base, lane-linear -- the stream IS the LDS image.
+template <int NB>
+__device__ __forceinline__ void ms_dma_phase(const uint8_t *src, uint8_t *dst, int tid) {
+  using M = MSplit<NB>;
+  const int wave = tid >> 6;
+#pragma unroll
+  for (int i = 0; i < M::PT; ++i) {
+    const int piece = (i * MN_BLOCK + wave * 64) * 16; // wave-uniform; PHASE_BYTES is a multiple of 1 KB
+    if (M::PHASE_BYTES % 4096 == 0 || piece < M::PHASE_BYTES)
+      __builtin_amdgcn_global_load_lds((ms_glb_void *)(src + (i * MN_BLOCK + tid) * 16), (ms_lds_void *)(dst + piece), 16, 0, 0);
+  }
+}
+// The ring of one workgroup: `cur` = the buffer the phase being computed is read from, `phase` = its position in the stream
+struct MSRing { int cur, phase, n_phases; const uint8_t *stream; uint8_t *lds; };
+// End of a phase.  The next phase's bytes were put in flight when THIS phase started (into the other buffer, which every wave
+// had finished reading at the barrier before that); the barrier's own vmcnt(0) retires this wave's pieces, the barrier the
+// others'.  Then the phase after next goes in flight into the buffer just finished with.  (The wave's own LDS reads, which the
+// compiler does not see, are retired by ms_wait_a<0> in front of every call.)
+template <int NB>
+__device__ __forceinline__ void ms_next_phase(MSRing &R, int tid) {
+  using M = MSplit<NB>;
+  __syncthreads();
+  const int done = R.cur;
+  R.cur ^= 1;
+  R.phase = R.phase + 1 == R.n_phases ? 0 : R.phase + 1;
+  const int nx = R.phase + 1 == R.n_phases ? 0 : R.phase + 1;
+  ms_dma_phase<NB>(R.stream + (size_t)nx * M::PHASE_BYTES, R.lds + done * M::PHASE_BYTES, tid);
+}
+// The weight triple (h, m, l) of the block at LDS byte address `addr` + OFF (this lane's 16 bytes of each 1-KB piece).  Written
+// as the instructions themselves because the waits are: hipcc's own lgkmcnt for these reads came out as lgkmcnt(0) in every other
+// block -- right behind the NEXT block's reads, i.e. a full LDS round trip exposed per block on a SIMD with one wave (226 us
+// against 189).  The compiler does not know these are in flight; ms_wait_a is the wait, and it names the registers so that no
+// MFMA moves above it.
+template <int OFF>
+__device__ __forceinline__ void ms_load_a(bf16x8 (&A)[3], uint32_t addr) {
+  static_assert(OFF >= 0 && OFF + 2048 < 65536, "ds_read offset field");
+  asm volatile("ds_read_b128 %0, %3 offset:%4\n\tds_read_b128 %1, %3 offset:%5\n\tds_read_b128 %2, %3 offset:%6"
+               : "=&v"(A[0]), "=&v"(A[1]), "=&v"(A[2])
+               : "v"(addr), "n"(OFF), "n"(OFF + 1024), "n"(OFF + 2048));
+}
+template <int YOUNGER> // wait for a triple with YOUNGER LDS reads (0 or 3) issued behind it
+__device__ __forceinline__ void ms_wait_a(bf16x8 (&A)[3]) {
+  if (YOUNGER == 3) asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(A[0]), "+v"(A[1]), "+v"(A[2]));
+  else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(A[0]), "+v"(A[1]), "+v"(A[2]));
+}
+__device__ __forceinline__ uint32_t ms_lds_addr(const uint8_t *p) { return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const uint8_t *)p; }
+// elements [e0, e1) of a k-step's 8 activation values as their triples
+__device__ __forceinline__ void ms_split_part(const float (&v)[8], bf16x8 (&B)[3], int e0, int e1) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+    if (i >= e0 && i < e1) {
+      const __bf16 hh = (__bf16)v[i];
+      const float r1 = v[i] - (float)hh;
+      const __bf16 mm = (__bf16)r1;
+      B[0][i] = hh; B[1][i] = mm; B[2][i] = (__bf16)(r1 - (float)mm);
+    }
+}
+// One k-step: the activation triple B against the NB weight blocks at LDS address `base`.  Software pipeline, one wave per
+// SIMD: block nb + 1's weight triple is read from LDS in front of block nb's six MFMAs (192 cycles cover the read), the NEXT
+// k-step's activation values are split into their triple one share per block in the MFMAs' shadow, and the next k-step's
+// first weight triple is read in front of the last block when that k-step lies in the same phase (SAME_PHASE: it starts
+// NB x 3 KB further on; otherwise the caller reads it behind the phase barrier).  A0 in: block 0's weights, reads in flight;
+// out: the next k-step's when SAME_PHASE.
+template <int NB, bool SAME_PHASE>
+__device__ __forceinline__ void ms_kstep(f32x16 (&acc)[NB], const bf16x8 (&B)[3], const float (&vn)[8], bf16x8 (&Bn)[3], bf16x8 (&A0)[3],
+                                         uint32_t base) {
+  bf16x8 A[2][3];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+    bf16x8 (&W)[3] = nb == 0 ? A0 : A[nb & 1];
+    // (constant offsets: the template argument must be a constant expression, hence the chain)
+#define MS_LOAD_NEXT(NBV)                                                                   \
+  if (nb == NBV) {                                                                          \
+    if (NBV + 1 < NB) ms_load_a<(NBV + 1) * 3072>(A[(NBV + 1) & 1], base);                   \
+    else if (SAME_PHASE) ms_load_a<NB * 3072>(A[(NBV + 1) & 1], base);                       \
+  }
+    MS_LOAD_NEXT(0) MS_LOAD_NEXT(1) MS_LOAD_NEXT(2) MS_LOAD_NEXT(3) MS_LOAD_NEXT(4) MS_LOAD_NEXT(5) MS_LOAD_NEXT(6) MS_LOAD_NEXT(7)
+#undef MS_LOAD_NEXT
+    if (nb + 1 < NB || SAME_PHASE) ms_wait_a<3>(W); else ms_wait_a<0>(W);
+    ms_split_part(vn, Bn, nb * 8 / NB, (nb + 1) * 8 / NB);
+    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W[2], B[0], acc[nb], 0, 0, 0); // l . h   (small terms first)
+    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W[0], B[2], acc[nb], 0, 0, 0); // h . l
+    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W[1], B[1], acc[nb], 0, 0, 0); // m . m
+    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W[1], B[0], acc[nb], 0, 0, 0); // m . h
+    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W[0], B[1], acc[nb], 0, 0, 0); // h . m
+    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W[0], B[0], acc[nb], 0, 0, 0); // h . h
+    // inside the block: the MFMAs with the split's vector instructions in their shadows (an MFMA holds the vector issue for
+    // 8 of its 32 cycles)
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if (SAME_PHASE) { A0[0] = A[NB & 1][0]; A0[1] = A[NB & 1][1]; A0[2] = A[NB & 1][2]; }
+}
+// bias + activation in place: register q of block nb = feature 32 nb + (q & 3) + 8 (q >> 2) + 4 h
+template <int NB>
+__device__ __forceinline__ void ms_bias_act(f32x16 (&acc)[NB], const float *bias, int h, int activation) {
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const float4 b = *(const float4 *)(bias + 32 * nb + 8 * g + 4 * h);
+      acc[nb][4 * g + 0] = act_fn(acc[nb][4 * g + 0] + b.x, activation);
+      acc[nb][4 * g + 1] = act_fn(acc[nb][4 * g + 1] + b.y, activation);
+      acc[nb][4 * g + 2] = act_fn(acc[nb][4 * g + 2] + b.z, activation);
+      acc[nb][4 * g + 3] = act_fn(acc[nb][4 * g + 3] + b.w, activation);
+    }
+}
+// a layer whose input is the previous layer's accumulators (k-step t = registers 8 (t & 1) .. + 7 of block t >> 1)
+template <int NB>
+__device__ __forceinline__ void ms_reg_layer(f32x16 (&acc)[NB], const f32x16 (&in)[NB], MSRing &R, int tid) {
+  using M = MSplit<NB>;
+  const int lane16 = (tid & 63) * 16;
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[nb][q] = 0.0f;
+  bf16x8 B[3], Bn[3], A0[3];
+  {
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = in[0][j];
+    ms_split_part(v, B, 0, 8);
+  }
+  ms_load_a<0>(A0, ms_lds_addr(R.lds + R.cur * M::PHASE_BYTES + lane16));
+  static_assert(MS_G == 2, "k-steps alternate: first of a phase, last of a phase");
+#pragma unroll
+  for (int t = 0; t < 2 * NB; ++t) {
+    float vn[8];
+    const int tn = t + 1 < 2 * NB ? t + 1 : t;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) vn[j] = in[tn >> 1][8 * (tn & 1) + j];
+    const uint32_t base = ms_lds_addr(R.lds + R.cur * M::PHASE_BYTES + (t % MS_G) * NB * 3072 + lane16);
+    if (t % MS_G == 0) ms_kstep<NB, true>(acc, B, vn, Bn, A0, base);
+    else ms_kstep<NB, false>(acc, B, vn, Bn, A0, base);
+    B[0] = Bn[0]; B[1] = Bn[1]; B[2] = Bn[2];
+    if (t % MS_G == MS_G - 1) {
+      ms_next_phase<NB>(R, tid);
+      ms_load_a<0>(A0, ms_lds_addr(R.lds + R.cur * M::PHASE_BYTES + lane16)); // (behind the last k-step: the next layer's first weights)
+    }
+  }
+  ms_wait_a<0>(A0); // nothing of this layer's reads stays in flight past it (the next layer reads A0 again)
+}
+
+template <int NB>
+__global__ __launch_bounds__(MN_BLOCK) void k_mainnet_split(MainArgs a) {
+  extern __shared__ __align__(16) uint8_t lds_b[];
+  using M = MSplit<NB>;
+  const NetDev &N = a.net;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+  float *vec = (float *)(lds_b + 2 * M::PHASE_BYTES); // [b0 | b1 | b2 | w3], MAXH each
+  for (int i = tid; i < MAXH; i += MN_BLOCK) {
+    vec[i] = i < N.H ? N.b0[i] : 0.0f; vec[MAXH + i] = i < N.H ? N.b1[i] : 0.0f;
+    vec[2 * MAXH + i] = i < N.VH ? N.b2[i] : 0.0f; vec[3 * MAXH + i] = i < N.VH ? N.w3[i] : 0.0f;
+  }
+  const int T0 = N.ws_T0, K = N.emb_dim;
+  MSRing R{0, 0, (T0 + 4 * NB) / MS_G, (const uint8_t *)N.ws, lds_b}; // fc0: T0 k-steps, fc1 and value_fc2: 2 NB each
+  ms_dma_phase<NB>(R.stream, lds_b, tid);
+  __syncthreads(); // (also publishes vec)
+  ms_dma_phase<NB>(R.stream + (size_t)M::PHASE_BYTES, lds_b + M::PHASE_BYTES, tid); // (a stream has at least 4 phases)
+
+  f32x16 X[NB], Y[NB];
+  const uint32_t ngroups = (a.n + 127) / 128;
+  for (uint32_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+    const uint32_t row0 = grp * 128 + wave * 32;
+    const uint32_t n_rows = row0 < a.n ? min(32u, a.n - row0) : 0u;
+    const uint32_t grow = n_rows ? row0 + ((uint32_t)r < n_rows ? (uint32_t)r : n_rows - 1) : a.n - 1; // rows past the batch repeat a real one
+    const float *arow = a.emb + (size_t)grow * K;
+    // ---- fc0: the lane's row of the embedding, 64 columns (4 k-steps) at a time, one chunk ahead ----
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) X[nb][q] = 0.0f;
+    float4 aC[8], aN[8];
+    // k-step u of chunk c: columns 64 c + 16 u + 8 h .. + 7; past K: a clamped address (its weights are zero)
+#define MS_LOAD_A(av, c)                                                                                         \
+  _Pragma("unroll") for (int u_ = 0; u_ < 4; ++u_) _Pragma("unroll") for (int qq_ = 0; qq_ < 2; ++qq_) {          \
+    const int col_ = 64 * (c) + 16 * u_ + 8 * h + 4 * qq_;                                                       \
+    av[2 * u_ + qq_] = *(const float4 *)(arow + (col_ < K ? col_ : 0));                                          \
+  }
+    const int nch = T0 / 4;
+    MS_T0();
+    MS_LOAD_A(aC, 0);
+    bf16x8 B[3], Bn[3], A0[3];
+    {
+      const float v[8] = {aC[0].x, aC[0].y, aC[0].z, aC[0].w, aC[1].x, aC[1].y, aC[1].z, aC[1].w};
+      ms_split_part(v, B, 0, 8);
+    }
+    ms_load_a<0>(A0, ms_lds_addr(R.lds + R.cur * M::PHASE_BYTES + lane * 16));
+#pragma unroll 1
+    for (int c = 0; c < nch; ++c) {
+      const int cn = c + 1 < nch ? c + 1 : c;
+      MS_LOAD_A(aN, cn);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        // the NEXT k-step's values: k-step u + 1 of this chunk, or k-step 0 of the next chunk (the last chunk: itself, unused)
+        const float4 n0 = u < 3 ? aC[2 * (u < 3 ? u + 1 : 0)] : aN[0], n1 = u < 3 ? aC[2 * (u < 3 ? u + 1 : 0) + 1] : aN[1];
+        const float vn[8] = {n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, n1.z, n1.w};
+        const uint32_t base = ms_lds_addr(R.lds + R.cur * M::PHASE_BYTES + (u % MS_G) * NB * 3072 + lane * 16);
+        if (u % MS_G == 0) ms_kstep<NB, true>(X, B, vn, Bn, A0, base);
+        else ms_kstep<NB, false>(X, B, vn, Bn, A0, base);
+        B[0] = Bn[0]; B[1] = Bn[1]; B[2] = Bn[2];
+        if (u % MS_G == MS_G - 1) {
+          ms_next_phase<NB>(R, tid);
+          ms_load_a<0>(A0, ms_lds_addr(R.lds + R.cur * M::PHASE_BYTES + lane * 16));
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 8; ++q) aC[q] = aN[q];
+    }
+#undef MS_LOAD_A
+    ms_wait_a<0>(A0);
+    MS_MARK(0);
+    ms_bias_act<NB>(X, vec, h, N.activation);
+    MS_MARK(1);
+    // ---- fc1 ----
+    ms_reg_layer<NB>(Y, X, R, tid);
+    MS_MARK(2);
+    ms_bias_act<NB>(Y, vec + MAXH, h, N.activation);
+    if (a.h1_out && n_rows && (uint32_t)r < n_rows) { // keep fc1's activations for the policy heads (row-major n x H)
+      float *dst = a.h1_out + (size_t)(row0 + r) * N.H;
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          if (32 * nb + 8 * g + 4 * h < N.H) *(float4 *)(dst + 32 * nb + 8 * g + 4 * h) = make_float4(Y[nb][4 * g], Y[nb][4 * g + 1], Y[nb][4 * g + 2], Y[nb][4 * g + 3]);
+    }
+    // ---- value_fc2, then value_fc3 + sigmoid straight from the accumulators (network.h:14,75) ----
+    MS_MARK(3);
+    ms_reg_layer<NB>(X, Y, R, tid);
+    MS_MARK(4);
+    float part = 0.0f;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float4 b = *(const float4 *)(vec + 2 * MAXH + 32 * nb + 8 * g + 4 * h);
+        const float4 w = *(const float4 *)(vec + 3 * MAXH + 32 * nb + 8 * g + 4 * h);
+        part = fmaf(act_fn(X[nb][4 * g + 0] + b.x, N.activation), w.x, part);
+        part = fmaf(act_fn(X[nb][4 * g + 1] + b.y, N.activation), w.y, part);
+        part = fmaf(act_fn(X[nb][4 * g + 2] + b.z, N.activation), w.z, part);
+        part = fmaf(act_fn(X[nb][4 * g + 3] + b.w, N.activation), w.w, part);
+      }
+    part += __shfl_xor(part, 32, 64);
+    if (h == 0 && (uint32_t)r < n_rows) a.values[row0 + r] = 1.0f / (1.0f + expf(-(part + N.b3)));
+    MS_MARK(5);
+    MS_FLUSH();
+  }
+  // The ring always has one phase in flight.  It must have landed before the wave ends: LDS-DMA still outstanding at
+  // s_endpgm would be written into LDS that by then belongs to another workgroup (seen as 1e-5 noise in the next launch).
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 // ---- policy heads: value_policy_inference's logits (network.h:102-123, main-net.h:67-107) ----------
 // Encode::Battle::Policy::get_index (encode/battle/policy.h:29-58) on the raw battle bytes
 __device__ __forceinline__ uint32_t policy_index(const uint8_t *side, uint32_t choice) {
@@ -1433,6 +1737,7 @@ struct oakgpu_net {
   std::vector<void *> allocs;
   int in_dim, hidden, value_hidden, policy_hidden; // unpadded, as in the file
   int device;        // the device the weights live on
+  int main_mode;     // which kernel runs the main net: 0 = k_mainnet_wave (fp32 MFMA), 1 = k_mainnet_split (bf16 triples)
 };
 
 namespace {
@@ -1497,6 +1802,47 @@ std::vector<float> frag_order_wave(const HostAffine &a, uint32_t out_pad) {
               if (row < a.out && col < a.in) f[(((((size_t)c * 4 + u) * NB + nb) * 2 + qq) * 64 + lane) * 4 + e] = a.w[(size_t)row * a.in + col];
             }
   return f;
+}
+
+// k_mainnet_split's weight stream: fc0, fc1, value_fc2 back to back, every weight as the bf16 triple (h, m, l), in the order
+// the kernel's LDS ring is read: byte (((t * NB + nb) * 3 + part) * 64 + lane) * 16 + 2 j = part of W[32 nb + (lane & 31)][k],
+// k = 16 t + 8 h + j for fc0 (h = lane >> 5) and 32 (t >> 1) + (reg & 3) + 8 (reg >> 2) + 4 h, reg = 8 (t & 1) + j, for the two
+// layers whose input is the previous layer's accumulators.  Absent rows / columns are zeros.
+uint16_t f32_to_bf16(float f) { // round to nearest even (weights are finite; a NaN stays a NaN)
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  if ((u & 0x7FFFFFFFu) > 0x7F800000u) return (uint16_t)((u >> 16) | 0x40);
+  return (uint16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+}
+float bf16_to_f32(uint16_t b) { const uint32_t u = (uint32_t)b << 16; float f; memcpy(&f, &u, 4); return f; }
+std::vector<uint16_t> split_stream(const HostAffine &fc0, const HostAffine &fc1, const HostAffine &v2, uint32_t NB, uint32_t T0) {
+  const uint32_t steps = T0 + 4 * NB;
+  std::vector<uint16_t> w((size_t)steps * NB * 3 * 64 * 8, 0);
+  auto put = [&](uint32_t t_flat, const HostAffine &a, uint32_t nb, uint32_t lane, uint32_t j, uint32_t k) {
+    const uint32_t n = 32 * nb + (lane & 31);
+    if (n >= a.out || k >= a.in) return;
+    const float x = a.w[(size_t)n * a.in + k];
+    const uint16_t hh = f32_to_bf16(x);
+    const float r1 = x - bf16_to_f32(hh);
+    const uint16_t mm = f32_to_bf16(r1);
+    const uint16_t ll = f32_to_bf16(r1 - bf16_to_f32(mm));
+    const size_t base = ((size_t)t_flat * NB + nb) * 3;
+    w[((base + 0) * 64 + lane) * 8 + j] = hh;
+    w[((base + 1) * 64 + lane) * 8 + j] = mm;
+    w[((base + 2) * 64 + lane) * 8 + j] = ll;
+  };
+  for (uint32_t nb = 0; nb < NB; ++nb)
+    for (uint32_t lane = 0; lane < 64; ++lane)
+      for (uint32_t j = 0; j < 8; ++j) {
+        const uint32_t hb = lane >> 5;
+        for (uint32_t t = 0; t < T0; ++t) put(t, fc0, nb, lane, j, 16 * t + 8 * hb + j);
+        for (uint32_t t = 0; t < 2 * NB; ++t) {
+          const uint32_t reg = 8 * (t & 1) + j, k = 32 * (t >> 1) + (reg & 3) + 8 * (reg >> 2) + 4 * hb;
+          put(T0 + t, fc1, nb, lane, j, k);
+          put(T0 + 2 * NB + t, v2, nb, lane, j, k);
+        }
+      }
+  return w;
 }
 
 // k_embed_arows: W0^T padded to 128 floats per row, + an all-zero last row (the move rows are read from this copy)
@@ -1636,6 +1982,23 @@ int oakgpu_net_load_memory(oakgpu_ctx *ctx, const void *bytes, size_t size, oakg
   rc = rc ? rc : upload(net, frag_order_wave(fc1, H), &D.w1g);
   rc = rc ? rc : upload(net, frag_order_wave(v2, VH), &D.w2g);
   {
+    const uint32_t nbr = (H > VH ? H : VH) / 32, NB = nbr > 4 ? 8 : nbr > 2 ? 4 : nbr, T0 = 4 * ((fc0.in + 63) / 64);
+    const std::vector<uint16_t> ws = split_stream(fc0, fc1, v2, NB, T0);
+    void *dptr = nullptr;
+    if (!rc) {
+      he = hipMalloc(&dptr, ws.size() * 2);
+      if (he != hipSuccess) rc = oakgpu_fail_hip((int)he, "hipMalloc(weight stream)");
+      else {
+        net->allocs.push_back(dptr);
+        he = hipMemcpy(dptr, ws.data(), ws.size() * 2, hipMemcpyHostToDevice);
+        if (he != hipSuccess) rc = oakgpu_fail_hip((int)he, "hipMemcpy(weight stream)");
+      }
+    }
+    D.ws = (const uint16_t *)dptr; D.ws_T0 = (int)T0; D.ws_NB = (int)NB;
+    const char *env = getenv("OAKGPU_MAIN_NET");
+    net->main_mode = env ? (strcmp(env, "fp32") == 0 ? 0 : 1) : 1;
+  }
+  {
     const HostAffine &q1a = L[8], &q1b = L[9], &q2a = L[10], &q2b = L[11];
     if (q1a.in != fc1.out || q2a.in != fc1.out || q1b.in != q1a.out || q2b.in != q2a.out || q1a.out != q2a.out ||
         q1b.out != 315 || q2b.out != 315) { oakgpu_net_free(ctx, net); return oakgpu_fail_msg("network file: inconsistent policy-head dims"); }
@@ -1673,6 +2036,13 @@ int oakgpu_net_load(oakgpu_ctx *ctx, const char *path, oakgpu_net **out) {
   return oakgpu_net_load_memory(ctx, buf.data(), buf.size(), out);
 }
 
+int oakgpu_net_set_main_precision(oakgpu_net *net, int mode) {
+  if (!net || (mode != OAKGPU_MAIN_FP32 && mode != OAKGPU_MAIN_SPLIT)) { oakgpu_fail_msg("oakgpu_net_set_main_precision: bad argument"); return -1; }
+  const int prev = net->main_mode;
+  net->main_mode = mode;
+  return prev;
+}
+
 int oakgpu_net_shape(const oakgpu_net *net, int *in_dim, int *hidden, int *value_hidden, int *policy_hidden) {
   if (!net) return oakgpu_fail_msg("null net");
   if (in_dim) *in_dim = net->in_dim;
@@ -1707,6 +2077,11 @@ int oakgpu_leaf_set_lds_limits(void) { // per DEVICE (hipFuncSetAttribute applie
   if (e != hipSuccess) return oakgpu_fail_hip((int)e, "hipFuncSetAttribute(k_policy)");
   e = hipFuncSetAttribute((const void *)oak::k_mainnet_wave, hipFuncAttributeMaxDynamicSharedMemorySize, (int)oak::MW_BYTES);
   if (e != hipSuccess) return oakgpu_fail_hip((int)e, "hipFuncSetAttribute(k_mainnet_wave)");
+  e = hipFuncSetAttribute((const void *)oak::k_mainnet_split<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)oak::MSplit<8>::LDS);
+  if (e == hipSuccess) e = hipFuncSetAttribute((const void *)oak::k_mainnet_split<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)oak::MSplit<4>::LDS);
+  if (e == hipSuccess) e = hipFuncSetAttribute((const void *)oak::k_mainnet_split<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)oak::MSplit<2>::LDS);
+  if (e == hipSuccess) e = hipFuncSetAttribute((const void *)oak::k_mainnet_split<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)oak::MSplit<1>::LDS);
+  if (e != hipSuccess) return oakgpu_fail_hip((int)e, "hipFuncSetAttribute(k_mainnet_split)");
   return 0;
 }
 
@@ -1779,8 +2154,12 @@ static int leaf_eval_impl(oakgpu_ctx *ctx, oakgpu_net *net, const uint8_t *battl
   if (tev) (void)hipEventRecord(tev[2], stream);
   oak::MainArgs ma{D, emb, n, values, h1};
   {
-    const uint32_t wgs = ((n + 31) / 32 + 3) / 4;
-    hipLaunchKernelGGL(oak::k_mainnet_wave, dim3(wgs < 256 ? wgs : 256), dim3(oak::MN_BLOCK), oak::MW_BYTES, stream, ma);
+    const uint32_t wgs = ((n + 31) / 32 + 3) / 4, grid = wgs < 256 ? wgs : 256;
+    if (net->main_mode == 0) hipLaunchKernelGGL(oak::k_mainnet_wave, dim3(grid), dim3(oak::MN_BLOCK), oak::MW_BYTES, stream, ma);
+    else if (D.ws_NB == 8) hipLaunchKernelGGL(oak::k_mainnet_split<8>, dim3(grid), dim3(oak::MN_BLOCK), oak::MSplit<8>::LDS, stream, ma);
+    else if (D.ws_NB == 4) hipLaunchKernelGGL(oak::k_mainnet_split<4>, dim3(grid), dim3(oak::MN_BLOCK), oak::MSplit<4>::LDS, stream, ma);
+    else if (D.ws_NB == 2) hipLaunchKernelGGL(oak::k_mainnet_split<2>, dim3(grid), dim3(oak::MN_BLOCK), oak::MSplit<2>::LDS, stream, ma);
+    else hipLaunchKernelGGL(oak::k_mainnet_split<1>, dim3(grid), dim3(oak::MN_BLOCK), oak::MSplit<1>::LDS, stream, ma);
   }
   if (tev) (void)hipEventRecord(tev[3], stream);
   if (pol) {

@@ -218,6 +218,14 @@ class Network:
         _lib.check(self.ctx.lib.oakgpu_net_shape(self.handle, *[C.byref(x) for x in v]))
         return tuple(x.value for x in v)
 
+    def set_main_precision(self, mode):
+        """"split" (default: fp32 values as bf16 triples on the bf16 matrix pipe, fp32 accumulation) or "fp32" (fp32 MFMA);
+        include/oakgpu.h: oakgpu_net_set_main_precision.  Returns the previous mode."""
+        prev = self.ctx.lib.oakgpu_net_set_main_precision(self.handle, {"fp32": 0, "split": 1}[mode])
+        if prev < 0:
+            raise _lib.OakGpuError("oakgpu_net_set_main_precision failed")
+        return ("fp32", "split")[prev]
+
     def value_inference(self, battles, durations, return_embedding=False):
         battles = _u8(battles)
         n = battles.shape[0]

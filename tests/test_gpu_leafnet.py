@@ -57,6 +57,46 @@ def test_config3_net_256(gpu_ctx, tmp_path):
     net.close()
 
 
+def _main_value_f64(onet, emb):
+    """The main net's value path in float64 from a given embedding (fp32 weights as stored): the yardstick both main-net
+    kernels are measured against."""
+    h = emb.astype(np.float64)
+    for layer in (onet.fc0, onet.fc1, onet.v2):
+        h = layer.W.astype(np.float64) @ h + layer.b.astype(np.float64)
+        h = np.maximum(h, 0.0) if onet.activation == 1 else np.clip(h, 0.0, 1.0)
+    y = float(onet.v3.W.astype(np.float64)[0] @ h + np.float64(onet.v3.b[0]))
+    return 1.0 / (1.0 + np.exp(-y))
+
+
+@pytest.mark.parametrize("kind", ["config3", "default", "tiny"])
+def test_bf16_triple_main_net_is_an_fp32_result(gpu_ctx, tmp_path, kind):
+    """k_mainnet_split multiplies fp32 values as exact sums of three bf16 parts (six bf16 MFMAs per block, fp32 accumulation)
+    and drops only terms below 2^-24 of a product.  Held here to what that claims: against a FLOAT64 evaluation of the same
+    embedding its error is of the size of k_mainnet_wave's (fp32 MFMA) and far inside the 1e-5 bar; the two kernels agree to
+    1e-6; and the mode switch really switches (the two results are not bit-identical everywhere)."""
+    from oak_amd.engine import Network
+    if kind == "config3":
+        path = str(tmp_path / "c3.battle.net")
+        NN.write_random_net(path, hidden=256, value_hidden=256, seed=7)
+    else:
+        path = os.path.join(ROOT, "tests", "golden", "net_%s.battle.net" % kind)
+    net = Network(gpu_ctx, path=path)
+    onet = NN.Net(path)
+    b, d = _midgame_states(700, 30, 4242)          # 5 full 128-row groups + a ragged one
+    assert net.set_main_precision("split") == "split"   # the default
+    v_split, emb = net.value_inference(b, d, return_embedding=True)
+    assert net.set_main_precision("fp32") == "split"
+    v_fp32 = net.value_inference(b, d)
+    net.set_main_precision("split")
+    ref = np.array([_main_value_f64(onet, emb[i]) for i in range(b.shape[0])])
+    e_split, e_fp32 = np.abs(v_split - ref).max(), np.abs(v_fp32 - ref).max()
+    assert e_split <= 1e-6 and e_fp32 <= 1e-6, (e_split, e_fp32)
+    assert e_split <= 4 * e_fp32 + 2e-7, (e_split, e_fp32)
+    assert np.abs(v_split - v_fp32).max() <= 1e-6
+    assert (v_split != v_fp32).any() or kind != "config3"
+    net.close()
+
+
 @pytest.mark.parametrize("dims", [
     dict(hidden=96, value_hidden=160),                                        # 3 and 5 output blocks: padded to the 4- and 8-wide kernels
     dict(hidden=32, value_hidden=32, pokemon_out=27, active_out=19),          # one block everywhere, embedding dim 312

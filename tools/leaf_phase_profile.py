@@ -37,11 +37,11 @@ for kind, env in ((os.environ.get("OAKGPU_EMBED_KINDS", "both kinds"), None),):
     lib.oakgpu_leaf_profile(buf, 0)
     print("== kinds", kind)
     names = ["prologue (weights -> LDS)", "stage Bs + barrier", "issue prefetch", "1a feature lists", "1c first layer", "barrier", "2 mfma", "3 scatter"]
-    print("k_mainnet_direct wave 0: outside compute %d cycles, inside compute (MFMA streams) %d cycles" % (buf[8], buf[9]))
-    wn = ["fc0 (196,608 MFMA cycles per tile)", "store 0", "fc1 (65,536)", "store 1 (+ h1)", "value_fc2 (65,536)", "store 2 + value_fc3"]
+    print("k_mainnet_split thread 0: %d cycles inside %d phase barriers (%.0f per barrier)" % (buf[8], buf[9], buf[8] / max(buf[9], 1)))
+    wn = ["fc0 (split: 73,728 MFMA cycles per tile)", "bias + act 0", "fc1 (24,576)", "bias + act 1 (+ h1)", "value_fc2 (24,576)", "value_fc3 + sigmoid"]
     wt = sum(buf[10 + i] for i in range(6))
     for i, nm in enumerate(wn):
-        print("k_mainnet_wave wave 0: %-36s %12d cycles  %5.1f%%  (%.0f per tile)" % (nm, buf[10 + i], 100.0 * buf[10 + i] / max(wt, 1), buf[10 + i] / 512.0))
+        print("main net wave 0: %-36s %12d cycles  %5.1f%%  (%.0f per tile)" % (nm, buf[10 + i], 100.0 * buf[10 + i] / max(wt, 1), buf[10 + i] / 512.0))
     tot = sum(buf[i] for i in range(8))
     for i, nm in enumerate(names):
         print("%-22s %12d cycles  %5.1f%%" % (nm, buf[i], 100.0 * buf[i] / tot))
