@@ -514,7 +514,23 @@ def leaf_records(args, torch, dev, rank, local_rank, world, dist, which=("leaf",
             _lib.check(lib.oakgpu_get_leaf_kernel_ms(h, ms))
             acc = [x + y for x, y in zip(acc, ms)]
         _lib.check(lib.oakgpu_set_kernel_timing(h, 0))
-        return {"k_embed_prows (party slots)": acc[0] / 5 * 1e3, "k_embed_arows (actives)": acc[1] / 5 * 1e3, "k_mainnet_wave": acc[2] / 5 * 1e3}
+        return {"k_embed_prows (party slots)": acc[0] / 5 * 1e3, "k_embed_arows (actives)": acc[1] / 5 * 1e3, MAIN_KERNEL: acc[2] / 5 * 1e3}
+
+    # the main net's kernel: fp32 values as exact bf16 triples on the bf16 matrix pipe unless OAKGPU_MAIN_NET=fp32 (include/oakgpu.h)
+    split = os.environ.get("OAKGPU_MAIN_NET", "") != "fp32"
+    MAIN_KERNEL = "k_mainnet_split<8>" if split else "k_mainnet_wave"
+    ARITH = ("fp32 results throughout.  Embedding nets: fp32 MFMA.  Main net: every fp32 value is the exact sum of three bf16 parts and every "
+             "product runs as its six largest bf16 x bf16 partial products (exact in the fp32 accumulator; dropped: < 2^-24 of the product) "
+             "on v_mfma_f32_32x32x16_bf16, fp32 accumulation; error vs float64 at the fp32-MFMA kernel's level "
+             "(tests/test_gpu_leafnet.py::test_bf16_triple_main_net_is_an_fp32_result)") if split else "fp32 MFMA throughout"
+
+    def main_net_note(kus):
+        if not split or not kus.get(MAIN_KERNEL):
+            return None
+        ex = 6 * main_f * n / (kus[MAIN_KERNEL] * 1e-6) / 1e12
+        return {"kernel": "oak::" + MAIN_KERNEL, "executed_bf16_tflops": ex, "bf16_dense_peak_tflops": 2500.0, "frac_of_bf16_peak": ex / 2500.0,
+                "note": "6 bf16 MFMA FLOP per algorithmic fp32 FLOP; `peak` of this record stays the fp32 matrix peak (157.3), the dtype "
+                        "the path computes in -- `frac` is algorithmic fp32 FLOP/s over that and is NOT bounded by 1 any more"}
 
     out = {}
     tj = profile_json()
@@ -531,7 +547,8 @@ def leaf_records(args, torch, dev, rank, local_rank, world, dist, which=("leaf",
             "config": {"workload": "leaf part of configs[2]: value_inference (encode + embeddings + 768-256-256-256-1 MainNet + "
                                    "sigmoid) over 65536 mid-game states per GPU", "batch_per_gpu": n,
                        "parity": "<= 1e-5 vs numpy oracle pinned by the reference torch mirror"},
-            "roofline": {"bound": "mfma", "kernel": "oak::k_embed_both (k_embed_prows + k_embed_arows in one launch) + oak::k_mainnet_wave (one value_inference call)",
+            "arithmetic": ARITH,
+            "roofline": {"bound": "mfma", "kernel": "oak::k_embed_both (k_embed_prows + k_embed_arows in one launch) + oak::%s (one value_inference call)" % MAIN_KERNEL,
                          "achieved": achieved, "peak": 157.3, "unit": "TFLOP/s", "frac": achieved / 157.3,
                          "traffic": (tj.get("leaf_hbm_bytes_per_leaf") * n if tj.get("leaf_hbm_bytes_per_leaf") else None),
                          "traffic_source": (PROFILE_SOURCE + ": leaf_hbm_bytes_per_leaf (2 x FETCH_SIZE + WRITE_SIZE of the call's kernels) x batch; not measured in this run")
@@ -539,6 +556,7 @@ def leaf_records(args, torch, dev, rank, local_rank, world, dist, which=("leaf",
                          "avg_call_ms": avg_s * 1e3, "algorithmic_flop_per_leaf": main_f + emb_f, "mainnet_flop_per_leaf": main_f,
                          "kernel_us": kernel_us()},
         }
+        rec["roofline"]["main_net"] = main_net_note(rec["roofline"]["kernel_us"])
         out["leaf"] = rec
     if "config3" in which:
         elapsed, avg_s = timed(config3_step, K, W)
@@ -562,14 +580,14 @@ def leaf_records(args, torch, dev, rank, local_rank, world, dist, which=("leaf",
         rec = {
             "metric": "turn-steps/s (rollout + leaf eval every turn)", "value": steps_done / elapsed, "unit": "turn-steps/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": elapsed / K * 1e3, "higher_is_better": True,
-            "scaling": "weak", "dtype": "f32", "data": "synthetic",
+            "scaling": "weak", "dtype": "f32", "data": "synthetic", "arithmetic": ARITH,
             "config": {"workload": "configs[2]: batch=65536 random OU team pairs per GPU; every step = one random turn-step of the "
                                    "whole batch (in place) + value_inference (768-256-256-256-1) of every lane, party-slot embeddings cached by identity "
                                    "tags (PokemonCache analogue); 40-turn episodes",
                        "batch_per_gpu": n, "leaf_evals_per_s": n * world * K / elapsed,
                        "live_lane_fraction": steps_done / (n * world * K)},
             "roofline": {"bound": "mfma", "kernel": "oak::k_rollout_staged (1 turn-step) + oak::k_party_tags + oak::k_embed_both<list> (changed party slots + "
-                                                     "actives) + oak::k_mainnet_wave",
+                                                     "actives) + oak::" + MAIN_KERNEL,
                          "achieved": achieved, "peak": 157.3, "unit": "TFLOP/s", "frac": achieved / 157.3,
                          "frac_executed": executed / 157.3, "achieved_executed": executed, "party_slot_miss_rate": miss_rate,
                          "traffic": (tj.get("config3_hbm_bytes_per_lane_turn") * n if tj.get("config3_hbm_bytes_per_lane_turn") else None),
