@@ -95,6 +95,8 @@ public:
     check(oakgpu_net_shape(net_, &a, &b, &c, &d));
     return {a, b, c, d};
   }
+  // how the main net's dense layers are multiplied: OAKGPU_MAIN_SPLIT (default, bf16 triples, fp32 results) or OAKGPU_MAIN_FP32
+  int set_main_precision(int mode) { return oakgpu_net_set_main_precision(net_, mode); }
   // value_inference(battle, durations) for every leaf (network.h:72-79)
   std::vector<float> value_inference(const std::vector<Leaf> &leaves) {
     const uint32_t n = static_cast<uint32_t>(leaves.size());
