@@ -91,11 +91,11 @@ def hbm_bytes(v):   # guide: FETCH_SIZE (KB) reports half of the bytes of wide c
 
 
 leaf_tr = {}
-lk = {k: v for k, v in leaf.items() if ("k_embed_both<false>" in k or "k_mainnet_wave" in k) and "FETCH_SIZE" in v and "WRITE_SIZE" in v}
+lk = {k: v for k, v in leaf.items() if ("k_embed_both<false>" in k or "k_mainnet" in k) and "FETCH_SIZE" in v and "WRITE_SIZE" in v}
 if len(lk) >= 2:
     tot = sum(hbm_bytes(v) for v in lk.values())
     leaf_tr = {"leaf_hbm_bytes_per_call_65536": tot, "leaf_hbm_bytes_per_leaf": tot / 65536,
-               "leaf_source": "profiles/r03_leaf_pmc.json: k_embed_both<false> + k_mainnet_wave, 2 x FETCH_SIZE + WRITE_SIZE (KB), one 65536-leaf value_inference call"}
+               "leaf_source": "profiles/r03_leaf_pmc.json: k_embed_both<false> + the main-net kernel, 2 x FETCH_SIZE + WRITE_SIZE (KB), one 65536-leaf value_inference call"}
 c3 = {}
 for sub in ("pmc_c3_fetch", "pmc_c3_write"):
     p = pmc(sub, "oak::k_")
@@ -105,11 +105,11 @@ for sub in ("pmc_c3_fetch", "pmc_c3_write"):
                 continue
             c3.setdefault(k, {}).update(v)
 c3_tr = {}
-c3k = {k: v for k, v in c3.items() if "FETCH_SIZE" in v and "WRITE_SIZE" in v and any(t in k for t in ("k_rollout_staged", "k_party_tags", "k_embed_both<true>", "k_mainnet_wave"))}
+c3k = {k: v for k, v in c3.items() if "FETCH_SIZE" in v and "WRITE_SIZE" in v and any(t in k for t in ("k_rollout_staged", "k_party_tags", "k_embed_both<true>", "k_mainnet"))}
 if c3k:
     tot = sum(hbm_bytes(v) for v in c3k.values())
     c3_tr = {"config3_hbm_bytes_per_step_65536": tot, "config3_hbm_bytes_per_lane_turn": tot / 65536,
-             "config3_source": "gpurun_out/r03 pmc_c3_* passes: mean per launch of k_rollout_staged + k_party_tags + k_embed_both<true> + k_mainnet_wave, 2 x FETCH_SIZE + WRITE_SIZE",
+             "config3_source": "gpurun_out/r03 pmc_c3_* passes: mean per launch of k_rollout_staged + k_party_tags + k_embed_both<true> + the main-net kernel, 2 x FETCH_SIZE + WRITE_SIZE",
              "config3_kernels": {k: hbm_bytes(v) for k, v in c3k.items()}}
 out["config3_pmc"] = c3
 
