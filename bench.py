@@ -524,6 +524,29 @@ def leaf_records(args, torch, dev, rank, local_rank, world, dist, which=("leaf",
              "on v_mfma_f32_32x32x16_bf16, fp32 accumulation; error vs float64 at the fp32-MFMA kernel's level "
              "(tests/test_gpu_leafnet.py::test_bf16_triple_main_net_is_an_fp32_result)") if split else "fp32 MFMA throughout"
 
+    def policy_note(value_call_s):   # SURVEY 8 row f3, untimed diagnostic pass: value_policy_inference (network.h:102-123) over the same states
+        c1, c2 = (torch.empty((n, 9), dtype=u8, device=dev) for _ in range(2))
+        n1, n2 = (torch.empty((n,), dtype=u8, device=dev) for _ in range(2))
+        l1, l2 = (torch.empty((n, 9), dtype=torch.float32, device=dev) for _ in range(2))
+        _lib.check(lib.oakgpu_choices_dev(h, P(mid), P(rout), 0, P(c1), P(n1), n))
+        _lib.check(lib.oakgpu_choices_dev(h, P(mid), P(rout), 1, P(c2), P(n2), n))
+
+        def call():
+            _lib.check(lib.oakgpu_leaf_eval_policy_dev(h, net.handle, P(mid), P(dur_mid), n, P(c1), P(n1), P(c2), P(n2), P(values), P(l1), P(l2)))
+        for _ in range(5):
+            call()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ctx.synchronize()
+        a.record(stream)
+        for _ in range(10):
+            call()
+        b.record(stream)
+        ctx.synchronize()
+        t = a.elapsed_time(b) / 10 / 1e3
+        return {"what": "value_policy_inference: the value + the logits of every legal choice of both sides (<= 9 each), 64-wide policy heads",
+                "leaf_evals_per_s": n / t, "ms_per_call": t * 1e3, "policy_heads_ms": (t - value_call_s) * 1e3,
+                "kernel": "the leaf call's kernels + oak::k_policy_rows<2>", "parity": "<= 2e-5 per logit vs the numpy oracle (tests/test_gpu_leafnet.py)"}
+
     def main_net_note(kus):
         if not split or not kus.get(MAIN_KERNEL):
             return None
@@ -557,6 +580,7 @@ def leaf_records(args, torch, dev, rank, local_rank, world, dist, which=("leaf",
                          "kernel_us": kernel_us()},
         }
         rec["roofline"]["main_net"] = main_net_note(rec["roofline"]["kernel_us"])
+        rec["policy"] = policy_note(avg_s)
         out["leaf"] = rec
     if "config3" in which:
         elapsed, avg_s = timed(config3_step, K, W)

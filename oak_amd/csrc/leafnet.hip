@@ -44,6 +44,7 @@ struct NetDev {
   int ws_T0, ws_NB;
   // policy heads (main-net.h:67-107): fc2 [PHp][H] (rows padded to 32), fc3 [315][PHp] (+ biases)
   const float *q1a, *q1a_b, *q1b, *q1b_b, *q2a, *q2a_b, *q2b, *q2b_b;
+  const float *q1a_f, *q2a_f; // fc2 of the two heads as k_policy_rows' A operand (policy_frag_order)
   int PH; // padded policy hidden width
 };
 
@@ -1062,12 +1063,7 @@ __global__ __launch_bounds__(256) void k_party_tags(NetDev N, const uint8_t *bat
 
 // ---- K3: main net on fp32 MFMA ------------------------------------------------------------------
 constexpr int MN_BLOCK = 256; // 4 waves
-constexpr int TM = 64;        // leaves per workgroup tile
-constexpr int KC_POLICY = 32; // K chunk staged per iteration in k_policy (two activation tiles: 8.4 + 33.8 KB staging)
 constexpr int MAXH = 256;
-// dynamic LDS of k_policy: weight / input staging + a TM-leaf tile of the hidden and the policy-hidden activations
-constexpr int POLICY_LDS_LIMIT = 150 * 1024;
-constexpr int policy_lds_bytes(int H, int PH) { return ((TM + MAXH) * (KC_POLICY + 1) + TM * (H + 1) + TM * (PH + 1)) * 4; }
 
 struct MainArgs {
   NetDev net;
@@ -1076,109 +1072,6 @@ struct MainArgs {
   float *values;
   float *h1_out; // nullable: n x H activated fc1 outputs, input of the policy heads (k_policy)
 };
-
-// One dense layer for a TM x Hout tile of k_policy (the four-wave tile form the main net used before k_mainnet_wave):
-// acc = A(TM x K) . W^T, W staged through LDS KCT columns at a time, the NEXT chunk's global loads issued into registers
-// before the MFMAs of the current chunk.  A comes from the LDS activation tile (A_FROM_GLOBAL: staged per chunk into xs).
-template <bool A_FROM_GLOBAL, int KCT>
-__device__ __forceinline__ void dense_layer(const float *a_global, int a_ld, uint32_t row0, uint32_t n_rows, // global A
-                                            const float *a_lds, int a_lds_ld,                               // LDS A
-                                            const float *W, int K, int Hout, float *xs, float *ws, f32x16 (&acc)[4]) {
-  constexpr int KCPT = KCT + 1;                          // padded LDS row stride (odd => conflict-free column reads)
-  constexpr int WREGT = MAXH * (KCT / 4) / MN_BLOCK;     // float4 per thread per W chunk
-  constexpr int XREGT = TM * (KCT / 4) / MN_BLOCK;       // float4 per thread per X chunk
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int mi = wave & 1, nb0 = wave >> 1, NB = Hout / 32;
-  const int r = lane & 31, h = lane >> 5;
-#pragma unroll
-  for (int j = 0; j < 4; ++j)
-#pragma unroll
-    for (int q = 0; q < 16; ++q) acc[j][q] = 0.0f;
-  float4 wreg[WREGT], xreg[XREGT];
-  auto prefetch = [&](int k0) {
-    const bool full = Hout == MAXH && k0 + KCT <= K; // the usual case: no per-load bounds branches
-#pragma unroll
-    for (int u = 0; u < WREGT; ++u) {
-      const int i = tid + u * MN_BLOCK, row = i / (KCT / 4), q = i - row * (KCT / 4);
-      if (full) wreg[u] = *(const float4 *)(W + (size_t)row * K + k0 + 4 * q);
-      else {
-        wreg[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (row < Hout && k0 + 4 * q < K) wreg[u] = *(const float4 *)(W + (size_t)row * K + k0 + 4 * q);
-      }
-    }
-    if (A_FROM_GLOBAL) {
-#pragma unroll
-      for (int u = 0; u < XREGT; ++u) {
-        const int i = tid + u * MN_BLOCK, row = i / (KCT / 4), q = i - row * (KCT / 4);
-        xreg[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if ((uint32_t)row < n_rows && k0 + 4 * q < K) xreg[u] = *(const float4 *)(a_global + (size_t)(row0 + row) * a_ld + k0 + 4 * q);
-      }
-    }
-  };
-  // JN = how many of this wave's four n-blocks exist (wave-uniform).  The count is resolved ONCE, so that the k-steps
-  // below are straight-line code: with a per-MFMA `if (block exists)` every MFMA sits in its own basic block and the
-  // next step's LDS reads cannot be scheduled under the current step's MFMAs.
-  const int JN = NB - nb0 <= 0 ? 0 : (NB - nb0 + 1) / 2 > 4 ? 4 : (NB - nb0 + 1) / 2;
-  prefetch(0);
-  for (int k0 = 0; k0 < K; k0 += KCT) {
-    __syncthreads(); // previous chunk fully consumed
-#pragma unroll
-    for (int u = 0; u < WREGT; ++u) {
-      const int i = tid + u * MN_BLOCK, row = i / (KCT / 4), q = i - row * (KCT / 4);
-      if (row < Hout) { float *d = ws + row * KCPT + 4 * q; d[0] = wreg[u].x; d[1] = wreg[u].y; d[2] = wreg[u].z; d[3] = wreg[u].w; }
-    }
-    if (A_FROM_GLOBAL) {
-#pragma unroll
-      for (int u = 0; u < XREGT; ++u) {
-        const int i = tid + u * MN_BLOCK, row = i / (KCT / 4), q = i - row * (KCT / 4);
-        float *d = xs + row * KCPT + 4 * q; d[0] = xreg[u].x; d[1] = xreg[u].y; d[2] = xreg[u].z; d[3] = xreg[u].w;
-      }
-    }
-    __syncthreads();
-    if (k0 + KCT < K) prefetch(k0 + KCT); // in flight during the MFMAs below
-    const int kmax = (K - k0) < KCT ? (K - k0) : KCT;
-    const float *arow = A_FROM_GLOBAL ? xs + (mi * 32 + r) * KCPT + h : a_lds + (mi * 32 + r) * a_lds_ld + k0 + h;
-    const float *brow = ws + (nb0 * 32 + r) * KCPT + h; // n-block j of this wave sits 64 rows further per j
-    auto run = [&](auto jn_tag) {
-      constexpr int JNc = decltype(jn_tag)::value;
-      auto step = [&](int s) {
-        const float av = arow[2 * s];
-#pragma unroll
-        for (int j = 0; j < JNc; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, brow[j * 64 * KCPT + 2 * s], acc[j], 0, 0, 0);
-      };
-      if (kmax == KCT) {
-#pragma unroll
-        for (int s = 0; s < KCT / 2; ++s) step(s); // fully unrolled: next step's ds_reads issue under this step's MFMAs
-      } else {
-        for (int s = 0; s < kmax / 2; ++s) step(s);
-      }
-    };
-    if (JN == 4) run(std::integral_constant<int, 4>{});
-    else if (JN == 3) run(std::integral_constant<int, 3>{});
-    else if (JN == 2) run(std::integral_constant<int, 2>{});
-    else if (JN == 1) run(std::integral_constant<int, 1>{});
-  }
-}
-
-// bias + activation, accumulators -> LDS activation tile [TM][ld]
-__device__ __forceinline__ void store_act(const f32x16 (&acc)[4], const float *bias, int Hout, int activation, float *hs, int ld) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int mi = wave & 1, nb0 = wave >> 1, NB = Hout / 32;
-  const int col = lane & 31, hh = lane >> 5;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int ni = nb0 + 2 * j;
-    if (ni < NB) {
-      const int nn = ni * 32 + col;
-      const float b = bias[nn];
-#pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        const int row = (q & 3) + 8 * (q >> 2) + 4 * hh;
-        hs[(mi * 32 + row) * ld + nn] = act_fn(acc[j][q] + b, activation);
-      }
-    }
-  }
-}
 
 // ---- K3, wave-independent form (the default).  k_mainnet_direct runs one wave per SIMD (its double-buffered weight
 // fragments take the whole register file), so nothing overlaps with anything: every workgroup barrier (fc0's three
@@ -1688,44 +1581,105 @@ struct PolicyArgs {
   uint32_t n;
 };
 
-__global__ __launch_bounds__(MN_BLOCK) void k_policy(PolicyArgs a) {
+// ---- policy heads, row form (round 3).  Rounds 1-2's k_policy staged a 64-leaf tile and both weight matrices through LDS
+// behind workgroup barriers and finished with one THREAD per (leaf, choice) walking a 256-byte weight row of its own through
+// L1 (64 lanes = 64 cache lines per load): 300-450 us per 65,536 leaves for 10 % of the main net's arithmetic.  Here a wave
+// owns 32 leaves, like the main net's kernels:
+//   fc2 (H -> PH): P^T = Wa . H1^T on fp32 MFMA with the WEIGHTS as the A operand (fragments in policy_frag_order, four
+//   k-steps per float4, straight from L2) and the leaf's fc1 row as the B operand (lane (b, hh) reads 16 bytes of its row per
+//   four k-steps) -- the result has the policy-hidden features in the accumulator registers and the leaf on the lane;
+//   fc3 (PH -> 315, <= 9 legal rows per side, policy.h:29-58): lane (b, hh) holds half of leaf b's features in registers and
+//   dots them with the weight row of each legal choice -- rows in LDS (315 x (PH + 4) floats, staged once per head and
+//   workgroup; the pad spreads the row starts over the banks) when they fit, else from global memory -- then adds its
+//   partner's half (one cross-lane add).
+template <int PB> struct PolicyRows {
+  static constexpr int ROWS = 315;
+  static constexpr int STRIDE = PB * 32 + 4;                       // floats per fc3 row in LDS
+  static constexpr bool WB_LDS = (size_t)ROWS * STRIDE * 4 <= 128 * 1024;
+  static constexpr size_t LDS = WB_LDS ? (size_t)ROWS * STRIDE * 4 : 16;
+};
+template <int PB>
+__global__ __launch_bounds__(MN_BLOCK) void k_policy_rows(PolicyArgs a) {
   extern __shared__ __align__(16) float lds_f[];
+  using PR = PolicyRows<PB>;
   const NetDev &N = a.net;
   const int H = N.H, PH = N.PH;
-  const int hld = H + 1, old = PH + 1;
-  float *xs = lds_f;              // unused staging slot of dense_layer<false> (kept for its signature)
-  float *ws = xs + TM * (KC_POLICY + 1);      // MAXH x (KC_POLICY + 1)
-  float *hs = ws + MAXH * (KC_POLICY + 1);    // TM x hld : fc1 activations
-  float *os = hs + TM * hld;      // TM x old : policy fc2 activations
-  const uint32_t row0 = blockIdx.x * TM;
-  const uint32_t n_rows = min((uint32_t)TM, a.n - row0);
-  for (uint32_t i = threadIdx.x; i < TM * (uint32_t)H; i += MN_BLOCK) {
-    const uint32_t row = i / (uint32_t)H, c = i - row * (uint32_t)H;
-    hs[row * hld + c] = row < n_rows ? a.h1[(size_t)(row0 + row) * H + c] : 0.0f;
-  }
-  __syncthreads();
-  f32x16 acc[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, hh = lane >> 5;
+  const uint32_t ntiles = (a.n + 31) / 32;
+  const int nu = H / 8; // float4 groups of four k-steps: k = 8 u + 4 hh + e
   for (int head = 0; head < 2; ++head) {
-    const float *Wa = head ? N.q2a : N.q1a, *ba = head ? N.q2a_b : N.q1a_b;
+    const float4 *Wf = (const float4 *)(head ? N.q2a_f : N.q1a_f);
+    const float *ba = head ? N.q2a_b : N.q1a_b;
     const float *Wb = head ? N.q2b : N.q1b, *bb = head ? N.q2b_b : N.q1b_b;
-    dense_layer<false, KC_POLICY>(nullptr, 0, 0, 0, hs, hld, Wa, H, PH, xs, ws, acc);
-    __syncthreads();
-    store_act(acc, ba, PH, N.activation, os, old);
-    __syncthreads();
-    for (uint32_t e = threadIdx.x; e < TM * OAKGPU_MAX_CHOICES; e += MN_BLOCK) {
-      const uint32_t row = e / OAKGPU_MAX_CHOICES, j = e - row * OAKGPU_MAX_CHOICES;
-      if (row >= n_rows) continue;
-      const size_t leaf = row0 + row;
-      float logit = 0.0f;
-      if (j < a.counts[head][leaf]) {
-        const uint32_t idx = policy_index(a.battles + leaf * 384 + head * 184, a.choices[head][leaf * OAKGPU_MAX_CHOICES + j]);
-        const float *w = Wb + (size_t)idx * PH, *o = os + row * old;
-        logit = bb[idx];
-        for (int c = 0; c < PH; ++c) logit = fmaf(w[c], o[c], logit);
+    if (PR::WB_LDS) {
+      __syncthreads(); // (the previous head's rows are no longer read)
+      for (int i = threadIdx.x; i < PR::ROWS * PB * 8; i += MN_BLOCK) { // float4 pieces of the (padded-to-PH) rows
+        const int row = i / (PB * 8), c4 = i - row * (PB * 8);
+        *(float4 *)(lds_f + row * PR::STRIDE + 4 * c4) = *(const float4 *)(Wb + (size_t)row * PH + 4 * c4);
       }
-      a.logits[head][leaf * OAKGPU_MAX_CHOICES + j] = logit;
+      __syncthreads();
     }
-    __syncthreads(); // os / ws reused by the second head
+    for (uint32_t wt = blockIdx.x * 4 + wave; wt < ntiles; wt += gridDim.x * 4) {
+      const uint32_t row0 = wt * 32, n_rows = min(32u, a.n - row0);
+      const uint32_t leaf = row0 + ((uint32_t)r < n_rows ? (uint32_t)r : n_rows - 1); // rows past the batch repeat the last one, dropped below
+      const float *hrow = a.h1 + (size_t)leaf * H + 4 * hh;
+      f32x16 acc[PB];
+#pragma unroll
+      for (int b = 0; b < PB; ++b)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[b][q] = 0.0f;
+      float4 xc = *(const float4 *)hrow, xn;
+      float4 wc[PB], wn[PB];
+#pragma unroll
+      for (int b = 0; b < PB; ++b) wc[b] = Wf[(size_t)b * 64 + lane];
+#pragma unroll 2
+      for (int u = 0; u < nu; ++u) {
+        const int un = u + 1 < nu ? u + 1 : u;
+        xn = *(const float4 *)(hrow + 8 * un);
+#pragma unroll
+        for (int b = 0; b < PB; ++b) wn[b] = Wf[((size_t)un * PB + b) * 64 + lane];
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int b = 0; b < PB; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(f4_pick(wc[b], e), f4_pick(xc, e), acc[b], 0, 0, 0);
+        xc = xn;
+#pragma unroll
+        for (int b = 0; b < PB; ++b) wc[b] = wn[b];
+      }
+      // bias + activation: register q of block b = feature 32 b + (q & 3) + 8 (q >> 2) + 4 hh of leaf r
+#pragma unroll
+      for (int b = 0; b < PB; ++b)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const float4 bv = *(const float4 *)(ba + 32 * b + 8 * g + 4 * hh);
+          acc[b][4 * g + 0] = act_fn(acc[b][4 * g + 0] + bv.x, N.activation);
+          acc[b][4 * g + 1] = act_fn(acc[b][4 * g + 1] + bv.y, N.activation);
+          acc[b][4 * g + 2] = act_fn(acc[b][4 * g + 2] + bv.z, N.activation);
+          acc[b][4 * g + 3] = act_fn(acc[b][4 * g + 3] + bv.w, N.activation);
+        }
+      // the legal rows of fc3
+      const uint32_t cnt = a.counts[head][leaf];
+      const uint8_t *side = a.battles + (size_t)leaf * 384 + head * 184;
+#pragma unroll 1
+      for (uint32_t j = 0; j < OAKGPU_MAX_CHOICES; ++j) {
+        const bool live = j < cnt;
+        const uint32_t idx = live ? policy_index(side, a.choices[head][(size_t)leaf * OAKGPU_MAX_CHOICES + j]) : 0u;
+        const float *w = (PR::WB_LDS ? lds_f + idx * PR::STRIDE : Wb + (size_t)idx * PH) + 4 * hh;
+        float part = 0.0f;
+#pragma unroll
+        for (int b = 0; b < PB; ++b)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const float4 wv = *(const float4 *)(w + 32 * b + 8 * g);
+            part = fmaf(wv.x, acc[b][4 * g + 0], part);
+            part = fmaf(wv.y, acc[b][4 * g + 1], part);
+            part = fmaf(wv.z, acc[b][4 * g + 2], part);
+            part = fmaf(wv.w, acc[b][4 * g + 3], part);
+          }
+        part += __shfl_xor(part, 32, 64);
+        if (hh == 0 && (uint32_t)r < n_rows) a.logits[head][(size_t)leaf * OAKGPU_MAX_CHOICES + j] = live ? part + bb[idx] : 0.0f;
+      }
+    }
   }
 }
 
@@ -1843,6 +1797,21 @@ std::vector<uint16_t> split_stream(const HostAffine &fc0, const HostAffine &fc1,
         }
       }
   return w;
+}
+
+// k_policy_rows' A operand of a policy head's fc2 (H -> PH): float4 ((u * PB + b) * 64 + lane) = W[32 b + (lane & 31)][8 u + 4 (lane >> 5) .. + 3]
+// (four k-steps per load; the leaf's fc1 row supplies the same columns as the B operand).  Absent rows / columns are zeros.
+std::vector<float> policy_frag_order(const HostAffine &a, uint32_t H, uint32_t PB) {
+  const uint32_t nu = H / 8;
+  std::vector<float> f((size_t)nu * PB * 64 * 4, 0.0f);
+  for (uint32_t u = 0; u < nu; ++u)
+    for (uint32_t b = 0; b < PB; ++b)
+      for (uint32_t lane = 0; lane < 64; ++lane)
+        for (uint32_t e = 0; e < 4; ++e) {
+          const uint32_t row = 32 * b + (lane & 31), col = 8 * u + 4 * (lane >> 5) + e;
+          if (row < a.out && col < a.in) f[(((size_t)u * PB + b) * 64 + lane) * 4 + e] = a.w[(size_t)row * a.in + col];
+        }
+  return f;
 }
 
 // k_embed_arows: W0^T padded to 128 floats per row, + an all-zero last row (the move rows are read from this copy)
@@ -2002,13 +1971,9 @@ int oakgpu_net_load_memory(oakgpu_ctx *ctx, const void *bytes, size_t size, oakg
     const HostAffine &q1a = L[8], &q1b = L[9], &q2a = L[10], &q2b = L[11];
     if (q1a.in != fc1.out || q2a.in != fc1.out || q1b.in != q1a.out || q2b.in != q2a.out || q1a.out != q2a.out ||
         q1b.out != 315 || q2b.out != 315) { oakgpu_net_free(ctx, net); return oakgpu_fail_msg("network file: inconsistent policy-head dims"); }
-    const uint32_t PH = up32(q1a.out);
-    if (PH > (uint32_t)oak::MAXH) { oakgpu_net_free(ctx, net); return oakgpu_fail_msg("policy hidden width above 256 unsupported"); }
-    // k_policy keeps a 64-leaf tile of the hidden and policy-hidden activations in LDS next to its weight chunk
-    if (oak::policy_lds_bytes((int)H, (int)PH) > oak::POLICY_LDS_LIMIT) {
-      oakgpu_net_free(ctx, net);
-      return oakgpu_fail_msg("policy heads too wide for this hidden width (k_policy's LDS tile): at hidden 256 policy_hidden may be at most 160");
-    }
+    const uint32_t ph32 = up32(q1a.out);
+    if (ph32 > (uint32_t)oak::MAXH) { oakgpu_net_free(ctx, net); return oakgpu_fail_msg("policy hidden width above 256 unsupported"); }
+    const uint32_t PB = ph32 > 128 ? 8 : ph32 > 64 ? 4 : ph32 > 32 ? 2 : 1, PH = 32 * PB; // k_policy_rows' block count: absent features are zeros
     D.PH = (int)PH;
     rc = rc ? rc : upload(net, pad_rows(q1a, PH, H), &D.q1a);
     rc = rc ? rc : upload(net, pad_vec(q1a.b, PH), &D.q1a_b);
@@ -2018,6 +1983,8 @@ int oakgpu_net_load_memory(oakgpu_ctx *ctx, const void *bytes, size_t size, oakg
     rc = rc ? rc : upload(net, pad_vec(q2a.b, PH), &D.q2a_b);
     rc = rc ? rc : upload(net, pad_rows(q2b, 315, PH), &D.q2b);
     rc = rc ? rc : upload(net, q2b.b, &D.q2b_b);
+    rc = rc ? rc : upload(net, policy_frag_order(q1a, H, PB), &D.q1a_f);
+    rc = rc ? rc : upload(net, policy_frag_order(q2a, H, PB), &D.q2a_f);
   }
   if (rc) { oakgpu_net_free(ctx, net); return rc; }
   *out = net;
@@ -2073,8 +2040,11 @@ int oakgpu_leaf_set_lds_limits(void) { // per DEVICE (hipFuncSetAttribute applie
   if (e != hipSuccess) return oakgpu_fail_hip((int)e, "hipFuncSetAttribute(k_embed_prows<list>)");
   e = hipFuncSetAttribute((const void *)oak::k_embed_lds<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)oak::ELayout<true>::BYTES);
   if (e != hipSuccess) return oakgpu_fail_hip((int)e, "hipFuncSetAttribute(k_embed_lds<active>)");
-  e = hipFuncSetAttribute((const void *)oak::k_policy, hipFuncAttributeMaxDynamicSharedMemorySize, oak::POLICY_LDS_LIMIT);
-  if (e != hipSuccess) return oakgpu_fail_hip((int)e, "hipFuncSetAttribute(k_policy)");
+  e = hipFuncSetAttribute((const void *)oak::k_policy_rows<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)oak::PolicyRows<1>::LDS);
+  if (e == hipSuccess) e = hipFuncSetAttribute((const void *)oak::k_policy_rows<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)oak::PolicyRows<2>::LDS);
+  if (e == hipSuccess) e = hipFuncSetAttribute((const void *)oak::k_policy_rows<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)oak::PolicyRows<4>::LDS);
+  if (e == hipSuccess) e = hipFuncSetAttribute((const void *)oak::k_policy_rows<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)oak::PolicyRows<8>::LDS);
+  if (e != hipSuccess) return oakgpu_fail_hip((int)e, "hipFuncSetAttribute(k_policy_rows)");
   e = hipFuncSetAttribute((const void *)oak::k_mainnet_wave, hipFuncAttributeMaxDynamicSharedMemorySize, (int)oak::MW_BYTES);
   if (e != hipSuccess) return oakgpu_fail_hip((int)e, "hipFuncSetAttribute(k_mainnet_wave)");
   e = hipFuncSetAttribute((const void *)oak::k_mainnet_split<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)oak::MSplit<8>::LDS);
@@ -2166,8 +2136,11 @@ static int leaf_eval_impl(oakgpu_ctx *ctx, oakgpu_net *net, const uint8_t *battl
     oak::PolicyArgs pa = *pol;
     pa.net = D;
     pa.h1 = h1;
-    const size_t pl_lds = (size_t)oak::policy_lds_bytes(D.H, D.PH);
-    hipLaunchKernelGGL(oak::k_policy, dim3((n + oak::TM - 1) / oak::TM), dim3(oak::MN_BLOCK), pl_lds, stream, pa);
+    const uint32_t wgs = ((n + 31) / 32 + 3) / 4, pgrid = wgs < 256 ? wgs : 256;
+    if (D.PH == 256) hipLaunchKernelGGL(oak::k_policy_rows<8>, dim3(pgrid), dim3(oak::MN_BLOCK), oak::PolicyRows<8>::LDS, stream, pa);
+    else if (D.PH == 128) hipLaunchKernelGGL(oak::k_policy_rows<4>, dim3(pgrid), dim3(oak::MN_BLOCK), oak::PolicyRows<4>::LDS, stream, pa);
+    else if (D.PH == 64) hipLaunchKernelGGL(oak::k_policy_rows<2>, dim3(pgrid), dim3(oak::MN_BLOCK), oak::PolicyRows<2>::LDS, stream, pa);
+    else hipLaunchKernelGGL(oak::k_policy_rows<1>, dim3(pgrid), dim3(oak::MN_BLOCK), oak::PolicyRows<1>::LDS, stream, pa);
   }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return oakgpu_fail_hip((int)e, "leaf_eval launch");

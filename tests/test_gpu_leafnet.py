@@ -282,15 +282,15 @@ def test_value_policy_inference_config3_net(gpu_ctx, tmp_path):
     net.close()
 
 
-def test_policy_width_limits_are_enforced_at_load(gpu_ctx, tmp_path):
-    """k_policy keeps the hidden and policy-hidden activations of a 64-leaf tile in LDS: at hidden = 256 the widest policy
-    head that fits is 160.  160 must load and agree with the oracle; 192 must be refused by the loader (not fail at the
-    first value_policy_inference launch)."""
+@pytest.mark.parametrize("ph", [24, 96, 160, 192])
+def test_policy_head_widths(gpu_ctx, tmp_path, ph):
+    """k_policy_rows pads the policy-hidden width to 32 / 64 / 128 / 256 and keeps fc3's rows in LDS up to 64-wide heads (from
+    global memory beyond): every width class against the oracle.  (Rounds 1-2's kernel refused heads above 160 at hidden 256.)"""
     import oracle_lib as O
     from oak_amd.engine import Network
-    ok = str(tmp_path / "p160.battle.net")
-    NN.write_random_net(ok, hidden=256, value_hidden=64, policy_hidden=160, seed=11)
-    net, onet = Network(gpu_ctx, path=ok), NN.Net(ok)
+    path = str(tmp_path / ("p%d.battle.net" % ph))
+    NN.write_random_net(path, hidden=256, value_hidden=64, policy_hidden=ph, seed=11)
+    net, onet = Network(gpu_ctx, path=path), NN.Net(path)
     b, d = _midgame_states(70, 12, 4242)
     r = np.array([O.LIB.oracle_result_from_state(O.ptr(b[i])) for i in range(b.shape[0])], dtype=np.uint8)
     keep = (r & 15) == 0
@@ -298,13 +298,18 @@ def test_policy_width_limits_are_enforced_at_load(gpu_ctx, tmp_path):
     c1, n1 = gpu_ctx.choices(b, r, 0)
     c2, n2 = gpu_ctx.choices(b, r, 1)
     vals, l1, l2 = net.value_policy_inference(b, d, c1, n1, c2, n2)
-    for i in range(0, b.shape[0], 5):
+    for i in range(0, b.shape[0], 3):
         ev, e1, e2 = NN.value_policy_inference(onet, b[i], d[i], c1[i, :n1[i]], c2[i, :n2[i]])
         assert abs(float(vals[i]) - float(ev)) <= TOL
         assert np.abs(l1[i, :n1[i]] - e1).max() <= 2e-5 and np.abs(l2[i, :n2[i]] - e2).max() <= 2e-5
+        assert (l1[i, n1[i]:] == 0).all() and (l2[i, n2[i]:] == 0).all()
     net.close()
-    bad = str(tmp_path / "p192.battle.net")
-    NN.write_random_net(bad, hidden=256, value_hidden=64, policy_hidden=192, seed=11)
+
+
+def test_policy_heads_wider_than_256_are_refused_at_load(gpu_ctx, tmp_path):
+    from oak_amd.engine import Network
+    bad = str(tmp_path / "p288.battle.net")
+    NN.write_random_net(bad, hidden=256, value_hidden=64, policy_hidden=288, seed=11)
     with pytest.raises(RuntimeError, match="policy"):
         Network(gpu_ctx, path=bad)
 
