@@ -1359,20 +1359,21 @@ __device__ __forceinline__ void ms_split_part(const float (&v)[8], bf16x8 (&B)[3
 // SIMD: block nb + 1's weight triple is read from LDS in front of block nb's six MFMAs (192 cycles cover the read), the NEXT
 // k-step's activation values are split into their triple one share per block in the MFMAs' shadow, and the next k-step's
 // first weight triple is read in front of the last block when that k-step lies in the same phase (SAME_PHASE: it starts
-// NB x 3 KB further on; otherwise the caller reads it behind the phase barrier).  A0 in: block 0's weights, reads in flight;
-// out: the next k-step's when SAME_PHASE.
+// NB x 3 KB further on; otherwise the caller reads it behind the phase barrier).  Afirst: block 0's weights, reads in flight;
+// Anext: where the next k-step's block 0 goes when SAME_PHASE.  These are two buffers the callers alternate, never copied:
+// a register copy of a triple whose LDS reads are still in flight would read stale registers (the compiler does not know).
 template <int NB, bool SAME_PHASE>
-__device__ __forceinline__ void ms_kstep(f32x16 (&acc)[NB], const bf16x8 (&B)[3], const float (&vn)[8], bf16x8 (&Bn)[3], bf16x8 (&A0)[3],
-                                         uint32_t base) {
+__device__ __forceinline__ void ms_kstep(f32x16 (&acc)[NB], const bf16x8 (&B)[3], const float (&vn)[8], bf16x8 (&Bn)[3], bf16x8 (&Afirst)[3],
+                                         bf16x8 (&Anext)[3], uint32_t base) {
   bf16x8 A[2][3];
 #pragma unroll
   for (int nb = 0; nb < NB; ++nb) {
-    bf16x8 (&W)[3] = nb == 0 ? A0 : A[nb & 1];
+    bf16x8 (&W)[3] = nb == 0 ? Afirst : A[nb & 1];
     // (constant offsets: the template argument must be a constant expression, hence the chain)
 #define MS_LOAD_NEXT(NBV)                                                                   \
   if (nb == NBV) {                                                                          \
     if (NBV + 1 < NB) ms_load_a<(NBV + 1) * 3072>(A[(NBV + 1) & 1], base);                   \
-    else if (SAME_PHASE) ms_load_a<NB * 3072>(A[(NBV + 1) & 1], base);                       \
+    else if (SAME_PHASE) ms_load_a<NB * 3072>(Anext, base);                                  \
   }
     MS_LOAD_NEXT(0) MS_LOAD_NEXT(1) MS_LOAD_NEXT(2) MS_LOAD_NEXT(3) MS_LOAD_NEXT(4) MS_LOAD_NEXT(5) MS_LOAD_NEXT(6) MS_LOAD_NEXT(7)
 #undef MS_LOAD_NEXT
@@ -1393,7 +1394,6 @@ __device__ __forceinline__ void ms_kstep(f32x16 (&acc)[NB], const bf16x8 (&B)[3]
     }
     __builtin_amdgcn_sched_barrier(0);
   }
-  if (SAME_PHASE) { A0[0] = A[NB & 1][0]; A0[1] = A[NB & 1][1]; A0[2] = A[NB & 1][2]; }
 }
 // bias + activation in place: register q of block nb = feature 32 nb + (q & 3) + 8 (q >> 2) + 4 h
 template <int NB>
@@ -1418,7 +1418,7 @@ __device__ __forceinline__ void ms_reg_layer(f32x16 (&acc)[NB], const f32x16 (&i
   for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
     for (int q = 0; q < 16; ++q) acc[nb][q] = 0.0f;
-  bf16x8 B[3], Bn[3], A0[3];
+  bf16x8 B[3], Bn[3], A0[3], A1[3]; // A0 / A1: block 0's weights of the first / second k-step of a phase
   {
     float v[8];
 #pragma unroll
@@ -1434,8 +1434,8 @@ __device__ __forceinline__ void ms_reg_layer(f32x16 (&acc)[NB], const f32x16 (&i
 #pragma unroll
     for (int j = 0; j < 8; ++j) vn[j] = in[tn >> 1][8 * (tn & 1) + j];
     const uint32_t base = ms_lds_addr(R.lds + R.cur * M::PHASE_BYTES + (t % MS_G) * NB * 3072 + lane16);
-    if (t % MS_G == 0) ms_kstep<NB, true>(acc, B, vn, Bn, A0, base);
-    else ms_kstep<NB, false>(acc, B, vn, Bn, A0, base);
+    if (t % MS_G == 0) ms_kstep<NB, true>(acc, B, vn, Bn, A0, A1, base);
+    else ms_kstep<NB, false>(acc, B, vn, Bn, A1, A0, base);
     B[0] = Bn[0]; B[1] = Bn[1]; B[2] = Bn[2];
     if (t % MS_G == MS_G - 1) {
       ms_next_phase<NB>(R, tid);
@@ -1484,7 +1484,7 @@ __global__ __launch_bounds__(MN_BLOCK) void k_mainnet_split(MainArgs a) {
     const int nch = T0 / 4;
     MS_T0();
     MS_LOAD_A(aC, 0);
-    bf16x8 B[3], Bn[3], A0[3];
+    bf16x8 B[3], Bn[3], A0[3], A1[3];
     {
       const float v[8] = {aC[0].x, aC[0].y, aC[0].z, aC[0].w, aC[1].x, aC[1].y, aC[1].z, aC[1].w};
       ms_split_part(v, B, 0, 8);
@@ -1500,8 +1500,8 @@ __global__ __launch_bounds__(MN_BLOCK) void k_mainnet_split(MainArgs a) {
         const float4 n0 = u < 3 ? aC[2 * (u < 3 ? u + 1 : 0)] : aN[0], n1 = u < 3 ? aC[2 * (u < 3 ? u + 1 : 0) + 1] : aN[1];
         const float vn[8] = {n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, n1.z, n1.w};
         const uint32_t base = ms_lds_addr(R.lds + R.cur * M::PHASE_BYTES + (u % MS_G) * NB * 3072 + lane * 16);
-        if (u % MS_G == 0) ms_kstep<NB, true>(X, B, vn, Bn, A0, base);
-        else ms_kstep<NB, false>(X, B, vn, Bn, A0, base);
+        if (u % MS_G == 0) ms_kstep<NB, true>(X, B, vn, Bn, A0, A1, base);
+        else ms_kstep<NB, false>(X, B, vn, Bn, A1, A0, base);
         B[0] = Bn[0]; B[1] = Bn[1]; B[2] = Bn[2];
         if (u % MS_G == MS_G - 1) {
           ms_next_phase<NB>(R, tid);
