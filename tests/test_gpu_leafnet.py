@@ -120,7 +120,7 @@ def test_layer_widths(gpu_ctx, tmp_path, dims):
     net.close()
 
 
-@pytest.mark.parametrize("n", [1, 31, 32, 33, 65])
+@pytest.mark.parametrize("n", [1, 31, 32, 33, 65, 127, 128, 129, 257])   # wave tiles of 32, workgroup groups of 128
 def test_ragged_batch_sizes(gpu_ctx, tmp_path, n):
     """Batches around the kernels' 32-item mini-tiles (1 leaf = 10 party items + 2 actives; 33 leaves = a second main-net tile of one row)."""
     from oak_amd.engine import Network
@@ -132,6 +132,16 @@ def test_ragged_batch_sizes(gpu_ctx, tmp_path, n):
     vals = net.value_inference(b, d)
     exp = np.array([float(NN.value_inference(onet, b[i], d[i])) for i in range(n)])
     assert vals.shape == (n,) and np.abs(vals - exp).max() <= TOL
+    net.close()
+
+
+def test_empty_leaf_batch(gpu_ctx):
+    from oak_amd.engine import Network
+    net = Network(gpu_ctx, path=os.path.join(ROOT, "tests", "golden", "net_default.battle.net"))
+    z = lambda *s: np.zeros(s, dtype=np.uint8)
+    assert net.value_inference(z(0, 384), z(0, 8)).shape == (0,)
+    v, l1, l2 = net.value_policy_inference(z(0, 384), z(0, 8), z(0, 9), z(0), z(0, 9), z(0))
+    assert v.shape == (0,) and l1.shape == (0, 9) and l2.shape == (0, 9)
     net.close()
 
 
