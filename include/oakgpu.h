@@ -393,8 +393,9 @@ int oakgpu_random_ou_battles_dev(oakgpu_ctx *ctx, uint64_t seed0, uint32_t n, ui
  * bytes, unsupported widths) return non-zero with a message, where the reference throws
  * std::runtime_error (search.cc:81,92,103,138,146).
  * oakgpu_leaf_eval* = value_inference(battle, durations) for n leaves (network.h:72-79):
- * encode + both embedding nets + MainNet value path + sigmoid, fp32 throughout (dense layers on
- * fp32 MFMA).  embedding_out (nullable): the n x in_dim battle embeddings (network.h:131-175). */
+ * encode + both embedding nets + MainNet value path + sigmoid, fp32 results throughout (the embedding nets' dense layers on
+ * fp32 MFMA, the main net's as exact bf16 triples on the bf16 matrix pipe unless oakgpu_net_set_main_precision says
+ * otherwise).  embedding_out (nullable): the n x in_dim battle embeddings (network.h:131-175). */
 int oakgpu_net_load(oakgpu_ctx *ctx, const char *path, oakgpu_net **out);
 int oakgpu_net_load_memory(oakgpu_ctx *ctx, const void *bytes, size_t size, oakgpu_net **out);
 void oakgpu_net_free(oakgpu_ctx *ctx, oakgpu_net *net);
