@@ -1596,7 +1596,7 @@ template <int PB> struct PolicyRows {
   static constexpr int ROWS = 315;
   static constexpr int STRIDE = PB * 32 + 4;                       // floats per fc3 row in LDS
   static constexpr bool WB_LDS = (size_t)ROWS * STRIDE * 4 <= 128 * 1024;
-  static constexpr size_t LDS = WB_LDS ? (size_t)ROWS * STRIDE * 4 : 16;
+  static constexpr size_t LDS = WB_LDS ? ((size_t)ROWS * STRIDE + 320) * 4 : 16; // the rows + fc3's biases
 };
 template <int PB>
 __global__ __launch_bounds__(MN_BLOCK) void k_policy_rows(PolicyArgs a) {
@@ -1617,6 +1617,7 @@ __global__ __launch_bounds__(MN_BLOCK) void k_policy_rows(PolicyArgs a) {
         const int row = i / (PB * 8), c4 = i - row * (PB * 8);
         *(float4 *)(lds_f + row * PR::STRIDE + 4 * c4) = *(const float4 *)(Wb + (size_t)row * PH + 4 * c4);
       }
+      for (int i = threadIdx.x; i < PR::ROWS; i += MN_BLOCK) lds_f[PR::ROWS * PR::STRIDE + i] = bb[i];
       __syncthreads();
     }
     for (uint32_t wt = blockIdx.x * 4 + wave; wt < ntiles; wt += gridDim.x * 4) {
@@ -1657,13 +1658,54 @@ __global__ __launch_bounds__(MN_BLOCK) void k_policy_rows(PolicyArgs a) {
           acc[b][4 * g + 2] = act_fn(acc[b][4 * g + 2] + bv.z, N.activation);
           acc[b][4 * g + 3] = act_fn(acc[b][4 * g + 3] + bv.w, N.activation);
         }
-      // the legal rows of fc3
+      // the legal rows of fc3.  Policy::get_index (policy.h:29-58) of all nine choice slots from ONE round trip: the side's six
+      // stored Pokemon (their move ids and species), its order bytes and the nine choice bytes are asked for together and the
+      // right fields selected in registers -- per choice it is three DEPENDENT byte loads (choice -> order -> species / move),
+      // 27 global-memory latencies in a row per tile and head with one wave per SIMD to hide them (144 us of the call).
       const uint32_t cnt = a.counts[head][leaf];
-      const uint8_t *side = a.battles + (size_t)leaf * 384 + head * 184;
+      const uint32_t *sb = (const uint32_t *)(a.battles + (size_t)leaf * 384 + head * 184);
+      uint2 pw2[18];
+#pragma unroll
+      for (int u = 0; u < 18; ++u) pw2[u] = ((const uint2 *)sb)[u]; // 6 x 24 B of stored Pokemon (8-byte aligned: 384 and 184 are)
+      const uint2 ow = *(const uint2 *)(sb + 44);                   // order[6] at bytes 176..181
+      uint32_t cb[OAKGPU_MAX_CHOICES];
+#pragma unroll
+      for (int j = 0; j < OAKGPU_MAX_CHOICES; ++j) cb[j] = a.choices[head][(size_t)leaf * OAKGPU_MAX_CHOICES + j];
+      const uint32_t pwd[36] = {pw2[0].x, pw2[0].y, pw2[1].x, pw2[1].y, pw2[2].x, pw2[2].y, pw2[3].x, pw2[3].y, pw2[4].x, pw2[4].y, pw2[5].x, pw2[5].y,
+                                pw2[6].x, pw2[6].y, pw2[7].x, pw2[7].y, pw2[8].x, pw2[8].y, pw2[9].x, pw2[9].y, pw2[10].x, pw2[10].y, pw2[11].x, pw2[11].y,
+                                pw2[12].x, pw2[12].y, pw2[13].x, pw2[13].y, pw2[14].x, pw2[14].y, pw2[15].x, pw2[15].y, pw2[16].x, pw2[16].y, pw2[17].x, pw2[17].y};
+      // per stored Pokemon k: its four move ids (bytes 10, 12, 14, 16) packed in one word, and its species (byte 21)
+      uint32_t mv4[6], spc[6];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        const uint32_t d2 = pwd[6 * k + 2], d3 = pwd[6 * k + 3], d4 = pwd[6 * k + 4], d5 = pwd[6 * k + 5];
+        mv4[k] = ((d2 >> 16) & 0xFF) | ((d3 & 0xFF) << 8) | (((d3 >> 16) & 0xFF) << 16) | ((d4 & 0xFF) << 24);
+        spc[k] = (d5 >> 8) & 0xFF;
+      }
+      const uint32_t ord[6] = {ow.x & 0xFF, (ow.x >> 8) & 0xFF, (ow.x >> 16) & 0xFF, ow.x >> 24, ow.y & 0xFF, (ow.y >> 8) & 0xFF};
+      auto by_id = [&](const uint32_t (&v)[6], uint32_t id) { // v[id - 1], id in 1..6 (0 for anything else)
+        uint32_t x = 0;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) x = id == (uint32_t)(k + 1) ? v[k] : x;
+        return x;
+      };
+      const uint32_t stored_moves = by_id(mv4, ord[0]);
 #pragma unroll 1
       for (uint32_t j = 0; j < OAKGPU_MAX_CHOICES; ++j) {
         const bool live = j < cnt;
-        const uint32_t idx = live ? policy_index(side, a.choices[head][(size_t)leaf * OAKGPU_MAX_CHOICES + j]) : 0u;
+        uint32_t c = cb[0];
+#pragma unroll
+        for (int q = 1; q < OAKGPU_MAX_CHOICES; ++q) c = j == (uint32_t)q ? cb[q] : c;
+        const uint32_t kind = c & 3, data = c >> 2;
+        uint32_t idx = 0;
+        if (kind == 1 && data >= 1 && data <= 4) { const uint32_t mid = (stored_moves >> (8 * (data - 1))) & 0xFF; idx = mid == 0 ? 0 : mid - 1; }
+        if (kind == 2 && data >= 1 && data <= 6) {
+          uint32_t pid = ord[0];
+#pragma unroll
+          for (int q = 1; q < 6; ++q) pid = data == (uint32_t)(q + 1) ? ord[q] : pid;
+          idx = 164 + by_id(spc, pid) - 1u;
+        }
+        idx = live && idx < (uint32_t)PR::ROWS ? idx : 0u;
         const float *w = (PR::WB_LDS ? lds_f + idx * PR::STRIDE : Wb + (size_t)idx * PH) + 4 * hh;
         float part = 0.0f;
 #pragma unroll
@@ -1677,7 +1719,8 @@ __global__ __launch_bounds__(MN_BLOCK) void k_policy_rows(PolicyArgs a) {
             part = fmaf(wv.w, acc[b][4 * g + 3], part);
           }
         part += __shfl_xor(part, 32, 64);
-        if (hh == 0 && (uint32_t)r < n_rows) a.logits[head][(size_t)leaf * OAKGPU_MAX_CHOICES + j] = live ? part + bb[idx] : 0.0f;
+        const float bias = PR::WB_LDS ? lds_f[PR::ROWS * PR::STRIDE + idx] : bb[idx];
+        if (hh == 0 && (uint32_t)r < n_rows) a.logits[head][(size_t)leaf * OAKGPU_MAX_CHOICES + j] = live ? part + bias : 0.0f;
       }
     }
   }
