@@ -398,11 +398,13 @@ def rollout_workload(args, torch, dev, rank, local_rank, world, dist, force_dist
     }
     if valu:
         # the kernel is integer-VALU bound, not HBM bound: wave-instructions issued per turn-step (PMC
-        # SQ_INSTS_VALU, committed in profiles/) against 1024 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction
-        peak = 1024 * 2.4e9 / 4
+        # SQ_INSTS_VALU, committed in profiles/) against the MEASURED issue peak of a mixed integer instruction stream
+        # (profiles/r04_valu_issue.json, tools/experiments/valu_issue_bench.hip: 4 cycles per wave64 instruction per SIMD;
+        # the 2 cycles of the microarchitecture guide hold for homogeneous v_add / v_and / v_mov streams only)
+        peak, peak_src = valu_issue_peak()
         ach = valu * my_steps / elapsed
         out["roofline"]["valu_issue"] = {"wave_insts_per_turn_step": valu, "achieved_ginst_s": ach / 1e9,
-                                         "peak_ginst_s": peak / 1e9, "frac": ach / peak,
+                                         "peak_ginst_s": peak / 1e9, "peak_source": peak_src, "frac": ach / peak,
                                          "active_lanes_per_wave_inst": tj.get("valu_active_lanes_per_wave_inst"),
                                          "source": PROFILE_SOURCE + ": SQ_INSTS_VALU per turn-step of a profiled group launch x this run's turn-steps/s"}
     # (the CPU baseline is timed by the caller AFTER every GPU record: 10-30 s of host work between two GPU timed regions let
@@ -851,6 +853,29 @@ def profile_json():
         return json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
     except Exception:
         return {}
+
+
+def valu_issue_peak():
+    """(wave-instructions/s, where it comes from): the best MIXED integer instruction stream of the issue microbenchmark."""
+    try:
+        pk = json.load(open(os.path.join(ROOT, "profiles", "r04_valu_issue.json")))["peak"]
+        return pk[pk["used_by_bench"]] * 1e9, ("profiles/r04_valu_issue.json: peak.%s (best mixed v_add / v_bfe / v_cndmask / v_cmp ... stream, every CU, "
+                                               "4-8 waves per SIMD; homogeneous v_add streams reach %.0f G/s, no mixture does)"
+                                               % (pk["used_by_bench"], pk["homogeneous_fast_stream_g_per_s"]))
+    except Exception:
+        return 1024 * 2.4e9 / 4, "nominal: 1,024 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction (profiles/r04_valu_issue.json not found)"
+
+
+def priced(kernels):
+    """One roofline fraction for a step made of several kernels on DIFFERENT pipes: each kernel's executed work priced against
+    the peak of the pipe it runs on.  kernels = [{name, pipe, work, peak, unit, us}] (work per step in the unit's numerator).
+    frac = (sum of work / peak) / (sum of measured time): the time the step would take with every kernel at its pipe's peak
+    over the time it took -- bounded by 1 as long as `work` is what really executes."""
+    t_min = sum(k["work"] / k["peak"] for k in kernels)
+    t = sum(k["us"] for k in kernels) * 1e-6
+    rows = [{"kernel": k["name"], "pipe": k["pipe"], "us": k["us"], "achieved": k["work"] / (k["us"] * 1e-6) / k["scale"],
+             "peak": k["peak"] / k["scale"], "unit": k["unit"], "frac": k["work"] / k["peak"] / (k["us"] * 1e-6)} for k in kernels]
+    return t_min / t, rows
 
 
 def host_threads():

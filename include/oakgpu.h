@@ -78,8 +78,10 @@ int oakgpu_set_spread(oakgpu_ctx *ctx, int lanes);
  * long before the device drains.  State travels as the regrouping rounds' bit-exact image; results never depend on it. */
 int oakgpu_set_migration(oakgpu_ctx *ctx, int mode, int long_steps, int adopters);
 /* Diagnostic (synchronises the stream): the 64 control words of the last queue launch -- [0] playouts handed out, [32] / [33]
- * the queue order's two counters, [40] donations, [41] adoptions, [42] bulk waves that left, [43] error bits (0 = none:
- * 1 a ticket never arrived, 2 an adopter gave up waiting). */
+ * the queue order's two counters, [40] donations, [41] adoptions, [42] bulk waves that left, [63] error bits (0 = none:
+ * 1 a ticket never arrived, 2 an adopter gave up waiting) -- STICKY: no launch clears them; oakgpu_synchronize reports a
+ * non-zero word as a failed call and clears it, so the error of any launch since the last synchronize is seen, not only the
+ * last launch's. */
 int oakgpu_get_queue_counters(oakgpu_ctx *ctx, uint32_t *out64);
 /* Rollout engine (results never depend on it; all three are bit-identical): 2 = register-resident engine, one wave per
  * workgroup, queue refill (default); 1 = LDS-resident engine (first implementation, kept as a second opinion); 3 =
@@ -213,11 +215,19 @@ typedef struct {
   uint32_t mucb_delay;
   uint32_t mucb_minimum;
   float mucb_c;
-  float exp3_alpha;      /* Exp3 / PExp3 uniform mixing (search.cc:268-286); negative = the reference's default 0.05 (its value
-                          * when the agent string has no third field); 0 is honoured as 0, as the reference honours it */
+  float exp3_alpha;      /* Exp3 / PExp3 uniform mixing (search.cc:268-286); negative (OAKGPU_EXP3_ALPHA_DEFAULT) = the reference's
+                          * default 0.05 (its value when the agent string has no third field); 0 is honoured as 0, as the
+                          * reference honours it -- so a ZERO-INITIALISED struct asks for no mixing at all: start from
+                          * OAKGPU_SEARCH_PARAMS_INIT (or set this field) when Exp3 / PExp3 is used.  With alpha = 0 an arm's
+                          * probability can underflow to 0; the importance-weighted update then divides by the smallest
+                          * normal float instead (the reference would divide by zero) */
   uint64_t duration_us;  /* time budget (search.cc:300-306): when non-zero, `iterations` is ignored and whole batches are
                           * started until this much time has elapsed; output.iterations tells how many ran */
 } oakgpu_search_params;
+#define OAKGPU_EXP3_ALPHA_DEFAULT (-1.0f)
+/* the reference's defaults where a zero is not one: UCB c = 2 is the caller's business (agent strings carry it), root / other
+ * rolls = default_search {3, 1} (mcts.h:131), Exp3 mixing = the default of an absent field */
+#define OAKGPU_SEARCH_PARAMS_INIT {0, 0, 0.0f, 0, 0, 0, 3, 1, 0, 0, 0, 0, 0.0f, OAKGPU_EXP3_ALPHA_DEFAULT, 0}
 typedef struct {
   uint8_t m, n;                 /* legal choices per side at the root */
   uint8_t p1_choices[9], p2_choices[9];
@@ -300,6 +310,11 @@ void oakgpu_heap_clear(oakgpu_heap *heap);                       /* back to std:
 int oakgpu_heap_kind(const oakgpu_heap *heap);                   /* -1 empty, else oakgpu_search_params.bandit of its nodes */
 uint64_t oakgpu_heap_nodes(const oakgpu_heap *heap);
 int oakgpu_heap_update(oakgpu_heap *heap, uint8_t i, uint8_t j, const uint8_t *obs16);
+/* diagnostics of the host tree's sharding (tests): edges whose child sits in another table's arena (0 in a consistent tree);
+ * a host-only self-test (no GPU) that grows a random tree with the search's own threaded resolve phase, promotes a child,
+ * checks the shards and grows on: 0 = every check held; out = {nodes before, nodes kept, nodes at the end, shard violations} */
+uint64_t oakgpu_heap_check_shards(const oakgpu_heap *heap);
+int oakgpu_heap_selftest(uint32_t rounds, uint32_t lanes, uint64_t seed, int threads, uint64_t out[4]);
 /* the root's bandit of one player (0 / 1): scores[9] (Exp3: gains), priors[9], visits[9], k (0 = root not initialised) */
 int oakgpu_heap_root_stats(const oakgpu_heap *heap, int player, float *scores, float *priors, uint32_t *visits, uint8_t *k);
 /* the same view of the child that oakgpu_heap_update(i, j, obs16) would promote; k = 0: no such (initialised) child */

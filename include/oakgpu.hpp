@@ -2,7 +2,9 @@
 // reference's search-node surface so Oak's tree code can use it as an `eval` (cpp/include/search/mcts.h:25-57).
 //
 //   OakGPU::Context            <- per-thread owner of device state (reference: per-thread Agent/Heap, util/search.h:17-64)
-//   OakGPU::Network            <- NN::Battle::Network (nn/battle/network.h:22-176): shape(), value_inference(batch)
+//   OakGPU::Network            <- NN::Battle::Network (nn/battle/network.h:22-176): shape(), value_inference(batch), and the
+//                                 reference's own per-leaf eval signatures value_inference(battle, durations) /
+//                                 value_policy_inference(b, d, m, n, c1, c2, p1, p2) that MCTS::Search::run calls (mcts.h:196-209,401-422)
 //   OakGPU::BatchedMonteCarlo  <- MCTS::MonteCarlo (mcts.h:21-23) + init_stats_and_rollout (mcts.h:448-496), batched
 //   OakGPU::TreeSearch         <- MCTS::Search::run (mcts.h:154-247): Node heap + the five joint bandits, leaves batched on the GPU
 //   OakGPU::run                <- RuntimeSearch::run (util/search.h:66, search.cc:150-313): the Agent's strings pick everything
@@ -20,6 +22,7 @@
 #include <vector>
 
 #include "oakgpu.h"
+#include "pkmn.h"
 
 namespace OakGPU {
 
@@ -110,6 +113,53 @@ public:
     return values;
   }
 
+  // ---- the reference's per-leaf `eval` signatures (nn/battle/network.h:72-79, 102-123), what an UNCHANGED MCTS::Search::run
+  // calls at every new leaf (mcts.h:401-422) and at a fresh contextual root (mcts.h:196-209).  Each is a batch of ONE through the
+  // same kernels as the batched forms (like include/pkmn.h's update / choices): correct and within the same 1e-5 / 2e-5 of
+  // the oracle, but it costs three kernel launches and four small PCIe copies per leaf (~60-100 us against 15 ns per leaf in
+  // a 65,536-leaf batch).  It exists so that the network drops into the reference's sequential search unchanged; throughput
+  // comes from the batched forms above and from OakGPU::TreeSearch.
+  float value_inference(const pkmn_gen1_battle &b, const pkmn_gen1_chance_durations &d) {
+    float value = 0.0f;
+    check(oakgpu_leaf_eval(ctx_.get(), net_, b.bytes, d.bytes, 1, &value, nullptr));
+    return value;
+  }
+  // m / n legal choices of the two sides (as pkmn_gen1_battle_choices returned them); p1 / p2 receive their m / n logits
+  template <class Count, class Choice>
+  float value_policy_inference(const pkmn_gen1_battle &b, const pkmn_gen1_chance_durations &d, const Count m, const Count n,
+                               const Choice *p1_choice, const Choice *p2_choice, float *p1, float *p2) {
+    if (m > 9 || n > 9) throw std::runtime_error{"oakgpu: more than PKMN_GEN1_MAX_CHOICES choices"};
+    uint8_t c1[9] = {}, c2[9] = {};
+    const uint8_t k1 = static_cast<uint8_t>(m), k2 = static_cast<uint8_t>(n);
+    for (uint8_t i = 0; i < k1; ++i) c1[i] = static_cast<uint8_t>(p1_choice[i]);
+    for (uint8_t i = 0; i < k2; ++i) c2[i] = static_cast<uint8_t>(p2_choice[i]);
+    float value = 0.0f, l1[9], l2[9];
+    check(oakgpu_leaf_eval_policy(ctx_.get(), net_, b.bytes, d.bytes, 1, c1, &k1, c2, &k2, &value, l1, l2));
+    for (uint8_t i = 0; i < k1; ++i) p1[i] = l1[i];
+    for (uint8_t i = 0; i < k2; ++i) p2[i] = l2[i];
+    return value;
+  }
+  // value_policy_inference for every leaf (network.h:102-123): choices / counts as pkmn_gen1_battle_choices fills them (n x 9
+  // bytes, n bytes per side); returns the values, fills the n x 9 logit arrays (entries past a count are 0)
+  std::vector<float> value_policy_inference(const std::vector<Leaf> &leaves, const std::vector<uint8_t> &p1_choices,
+                                            const std::vector<uint8_t> &p1_counts, const std::vector<uint8_t> &p2_choices,
+                                            const std::vector<uint8_t> &p2_counts, std::vector<float> &p1_logits, std::vector<float> &p2_logits) {
+    const uint32_t n = static_cast<uint32_t>(leaves.size());
+    if (p1_choices.size() != size_t{n} * 9 || p2_choices.size() != size_t{n} * 9 || p1_counts.size() != n || p2_counts.size() != n)
+      throw std::runtime_error{"oakgpu: choices must be n x 9 bytes and counts n bytes per side"};
+    std::vector<uint8_t> battles(size_t{n} * OAKGPU_BATTLE_SIZE), durations(size_t{n} * OAKGPU_DURATIONS_SIZE);
+    for (uint32_t i = 0; i < n; ++i) {
+      std::memcpy(&battles[size_t{i} * OAKGPU_BATTLE_SIZE], leaves[i].battle, OAKGPU_BATTLE_SIZE);
+      std::memcpy(&durations[size_t{i} * OAKGPU_DURATIONS_SIZE], leaves[i].durations, OAKGPU_DURATIONS_SIZE);
+    }
+    std::vector<float> values(n);
+    p1_logits.assign(size_t{n} * 9, 0.0f);
+    p2_logits.assign(size_t{n} * 9, 0.0f);
+    check(oakgpu_leaf_eval_policy(ctx_.get(), net_, battles.data(), durations.data(), n, p1_choices.data(), p1_counts.data(), p2_choices.data(),
+                                  p2_counts.data(), values.data(), p1_logits.data(), p2_logits.data()));
+    return values;
+  }
+
   // A RESIDENT batch evaluated every turn (device pointers): party-slot embeddings cached by exact identity tags, the GPU
   // form of NN::Battle::PokemonCache (nn/battle/cache.h:18-131).  `embedding` (n x in_dim floats) and `slot_tags`
   // (n x 10 x OAKGPU_SLOT_TAG_WORDS u32, initialised to 0xFF bytes) are the caller's, kept between calls.
@@ -149,6 +199,9 @@ private:
 class TreeSearch {
 public:
   explicit TreeSearch(Context &ctx) : ctx_{ctx} {}
+  // Start from these, not from `oakgpu_search_params{}`: roll clamping {3, 1} (mcts.h:131) and the DEFAULT Exp3 mixing of an
+  // absent agent-string field -- a zeroed struct asks for alpha = 0 (no uniform mixing), which the reference only does on request.
+  static oakgpu_search_params default_params() { return oakgpu_search_params OAKGPU_SEARCH_PARAMS_INIT; }
   oakgpu_search_output run(const Leaf &input, oakgpu_search_params params, Network *net = nullptr, Heap *heap = nullptr,
                            const oakgpu_search_output *previous = nullptr) {
     params.eval = net ? 1 : 0;

@@ -184,7 +184,8 @@ struct Bandit {
   void visit(const BanditParams &P, uint8_t i) { if (P.kind < B_EXP3) ++visits[i]; }
   void update(const BanditParams &P, uint8_t i, float value, float prob) {
     if (P.kind < B_EXP3) { scores[i] += value; return; }
-    if ((scores[i] += (value - 0.5) / prob) > 0) { // Exp3::update (the reference's 0.5 is a double literal): keep the largest gain at 0
+    // (prob == 0: only with alpha = 0 and an underflowed softmax, where the reference divides by zero -- the smallest normal float instead)
+    if ((scores[i] += (value - 0.5) / (prob > 0 ? prob : 1.17549435e-38f)) > 0) { // Exp3::update (the reference's 0.5 is a double literal): keep the largest gain at 0
       const float mx = scores[i];
       for (int q = 0; q < 9; ++q) scores[q] -= mx;
     }

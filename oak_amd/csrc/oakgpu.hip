@@ -579,19 +579,30 @@ __global__ __launch_bounds__(BLK, WPS) void k_rollout_queue(GroupArgs g_in, Roun
   __syncthreads();
   const uint32_t tid = threadIdx.x, wl = tid & 63;
   constexpr uint32_t NONE = 0xFFFFFFFFu, DONE = 0xFFFFFFFEu;
-  // the few scalars the turn loop itself needs stay in SGPRs
-  const bool resume = q_in.list_in != nullptr; // a later round: playouts come from the previous round's suspended list
-  const uint32_t total = resume ? *q_in.n_in : g_in.total;
-  const uint32_t max_steps = g_in.max_steps, suspend_below = q_in.suspend_below;
-  const bool prep = !resume && g_in.prep;
+  // the few scalars the turn loop itself needs stay in SGPRs -- each read back from the LDS copy as a 32-bit value of its own:
+  // taken straight from the kernel arguments they stay sub-registers of the 16-dword argument load, and the register
+  // allocator then spills and restores that WHOLE tuple around the turn loop (round 3: 39 SGPR spills, 16 v_readlane per
+  // wave iteration, after the migration arguments joined RoundArgs)
+#define COLD_U32(off) ((uint32_t)__builtin_amdgcn_readfirstlane((int)cold[(off) / 4]))
+#define COLD_QU(field) COLD_U32(offsetof(ColdArgs, q) + offsetof(RoundArgs, field))
+#define COLD_GU(field) COLD_U32(offsetof(ColdArgs, g) + offsetof(GroupArgs, field))
+  // (wave-uniform booleans live as BITS of one scalar word: as `bool`s each is a 64-bit lane mask, two SGPRs, and the turn loop
+  // has none to spare)
+  constexpr uint32_t U_RESUME = 1, U_PREP = 2, U_ADOPTER = 4, U_DRY = 8, U_ADOPTING = 16, U_ANY_PLAYING = 32;
+  uint32_t ust = (COLD_QU(list_in) | COLD_U32(offsetof(ColdArgs, q) + offsetof(RoundArgs, list_in) + 4)) != 0 ? U_RESUME : 0u; // a later round: playouts come from the previous round's suspended list
+#define IS_RESUME ((ust & U_RESUME) != 0)
+#define IS_PREP ((ust & U_PREP) != 0)
+  const uint32_t total = IS_RESUME ? (uint32_t)__builtin_amdgcn_readfirstlane((int)*COLD_Q(n_in, const uint32_t *)) : COLD_GU(total);
+  const uint32_t max_steps = COLD_GU(max_steps), suspend_below = COLD_QU(suspend_below);
+  if (!IS_RESUME && COLD_GU(prep) != 0) ust |= U_PREP;
   ER e;
   e.m = party + tid;
   e.T = T;
   FastPrng g;
   g.s0 = g.s1 = 0;
   uint32_t idx = NONE, result = 0, steps = 0;
-  if (q_in.lanes && wl >= q_in.lanes) idx = DONE; // (tail round: this lane stays empty)
-  bool dry = false; // wave-uniform: the queue has handed out its last playout
+  { const uint32_t lanes = COLD_QU(lanes); if (lanes && wl >= lanes) idx = DONE; } // (tail round: this lane stays empty)
+#define IS_DRY ((ust & U_DRY) != 0) // wave-uniform: the queue has handed out its last playout
   // ---- long-playout migration.  The launch ends with its longest playouts -- 1,000-step chains -- and while the device is
   // full such a playout advances at the pace of a full, divergent wave (31 us per turn-step).  So a BULK wave hands a playout
   // that is still running after `long_steps` turn-steps (99.5% end before 250) to the ADOPTER waves (the first n_adopters
@@ -602,13 +613,14 @@ __global__ __launch_bounds__(BLK, WPS) void k_rollout_queue(GroupArgs g_in, Roun
   // moment the device drains.  Every wait is bounded (a ticket reserved but not yet written; an adopter with nothing to
   // adopt while bulk waves still run): on overflow the error word is set and the wave leaves.  Results are indexed by
   // playout: they do not depend on who finishes a playout.
-  const uint32_t n_adopt = q_in.n_adopters, long_steps = q_in.long_steps;
-  const bool adopter = n_adopt != 0 && blockIdx.x < n_adopt;
-  const uint32_t g_total_guard = g_in.total; // (tickets live in [0, total): one per donation at most)
-  bool adopting = false; // adopter: a donation has been seen, no more playouts from the main queue
+  const uint32_t n_adopt = COLD_QU(n_adopters), long_steps = COLD_QU(long_steps);
+  if (n_adopt != 0 && blockIdx.x < n_adopt) ust |= U_ADOPTER;
+#define IS_ADOPTER ((ust & U_ADOPTER) != 0)
+#define IS_ADOPTING ((ust & U_ADOPTING) != 0) // adopter: a donation has been seen, no more playouts from the main queue
+#define ANY_PLAYING ((ust & U_ANY_PLAYING) != 0)
   uint32_t idle_polls = 0, poll_tick = 15;
-  bool any_playing = false;
   constexpr uint32_t SPIN_CAP = 1u << 22;
+  constexpr int ERR_WORD = 23; // adopt_ctl + 23 = word 63 of the context's control block: STICKY (no launch clears it; oakgpu_synchronize reads and clears)
   OAK_PROF_ZERO();
   OAK_TL(0, wall_clock64());
 #ifdef OAKGPU_TIMELINE
@@ -616,11 +628,11 @@ __global__ __launch_bounds__(BLK, WPS) void k_rollout_queue(GroupArgs g_in, Roun
   unsigned long long tl_steps = 0;
 #endif
   for (;;) {
-    bool need = idx == NONE, load = false, from_scratch = resume;
+    bool need = idx == NONE, load = false, from_scratch = IS_RESUME;
     uint64_t mask = __ballot(need);
     // (an adopter looks at the adoption list every 16th turn-step, or at once when it has nothing to play: 256 sparse waves
     // polling three words on every iteration saturate that L2 line's atomics and slow the whole launch down)
-    if (mask && adopter && ((++poll_tick & 15u) == 0 || !any_playing)) { // wave-uniform: an adopter's free lanes take donated playouts first
+    if (mask && IS_ADOPTER && ((++poll_tick & 15u) == 0 || !ANY_PLAYING)) { // wave-uniform: an adopter's free lanes take donated playouts first
       uint32_t *ctl = COLD_Q(adopt_ctl, uint32_t *);
       uint32_t h = 0, k = 0, closed = 0;
       if (wl == 0) {
@@ -641,41 +653,44 @@ __global__ __launch_bounds__(BLK, WPS) void k_rollout_queue(GroupArgs g_in, Roun
           if (atomicCAS(ctl + 1, hh, hh + kk) == hh) { h = hh; k = kk; break; }
         }
       }
-      h = __shfl(h, 0, 64); k = __shfl(k, 0, 64); closed = __shfl(closed, 0, 64);
-      adopting = adopting || (closed & 2) != 0;
+      h = (uint32_t)__builtin_amdgcn_readfirstlane((int)h); k = (uint32_t)__builtin_amdgcn_readfirstlane((int)k); closed = (uint32_t)__builtin_amdgcn_readfirstlane((int)closed);
+      if (closed & 2) ust |= U_ADOPTING;
       const uint32_t rank = (uint32_t)__popcll(mask & ((1ull << wl) - 1));
       const bool take = need && rank < k;
       uint32_t got = 0;
-      if (take && h + rank < g_total_guard) {
+      if (take && h + rank < COLD_GU(total)) { // (tickets live in [0, total): one per donation at most)
         const uint32_t *slot = COLD_Q(adopt_list, const uint32_t *) + h + rank;
         uint32_t spins = 0;
         while ((got = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0 && ++spins < SPIN_CAP) __builtin_amdgcn_s_sleep(2);
-        if (!got) atomicOr(ctl + 3, 1u); // (a ticket that never arrived: reported, the playout is lost -- the tests would see it)
+        if (!got) atomicOr(ctl + ERR_WORD, 1u); // (a ticket that never arrived: reported, the playout is lost -- the tests would see it)
       }
       if (k) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); // the donors' images, step counts and PRNG states
       if (take && got) { idx = got - 1; load = true; from_scratch = true; }
       need = idx == NONE;
       if ((closed & 1) && need) idx = DONE;              // adoption is over
-      mask = (adopting || (closed & 1)) ? 0 : __ballot(need); // once donations exist an adopter takes no more bulk work
+      mask = (IS_ADOPTING || (closed & 1)) ? 0 : __ballot(need); // once donations exist an adopter takes no more bulk work
       need = need && mask != 0;
     }
-    if (adopting) { mask = 0; need = false; } // (an adopter between two looks at the list: no bulk work either)
-    if (mask) { // wave-uniform
+    if (IS_ADOPTING) { mask = 0; need = false; } // (an adopter between two looks at the list: no bulk work either)
+    // (an adopter's free lanes stay NONE after the queue has run dry -- they wait for donations -- and must not keep asking the
+    // dry queue: ~150 waves adding to one L2 word on every iteration, and in a long launch the 32-bit head could wrap and hand
+    // playouts out twice; round-3 advice)
+    if (mask && !(IS_DRY && IS_ADOPTER)) { // wave-uniform
       OAK_SCOPE(PS_REFILL);
       uint32_t base = 0;
       if (wl == 0) base = atomicAdd(COLD_Q(queue, uint32_t *), (uint32_t)__popcll(mask));
-      base = __shfl(base, 0, 64);
-      dry = base + (uint32_t)__popcll(mask) >= total;
+      base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base); // (lane 0 is active: whole waves run this loop)
+      if (base + (uint32_t)__popcll(mask) >= total) ust |= U_DRY; else ust &= ~U_DRY;
 #ifdef OAKGPU_TIMELINE
-      if (dry && !tl_dry) { tl_dry = true; OAK_TL(1, wall_clock64()); }
+      if (IS_DRY && !tl_dry) { tl_dry = true; OAK_TL(1, wall_clock64()); }
 #endif
       if (need) {
         const uint32_t my = base + (uint32_t)__popcll(mask & ((1ull << wl) - 1));
         if (my < total) {
           const uint32_t *order = COLD_Q(order, const uint32_t *);
-          idx = resume ? COLD_Q(list_in, const uint32_t *)[my] : order ? order[my] : my;
+          idx = IS_RESUME ? COLD_Q(list_in, const uint32_t *)[my] : order ? order[my] : my;
           load = true;
-        } else idx = adopter ? NONE : DONE; // (an adopter's free lanes wait for donations until adoption is over)
+        } else idx = IS_ADOPTER ? NONE : DONE; // (an adopter's free lanes wait for donations until adoption is over)
       }
     }
     if (__ballot(load)) { // wave-uniform: (re)fill the lanes that got a playout -- from its batch, or from its parked image
@@ -688,7 +703,7 @@ __global__ __launch_bounds__(BLK, WPS) void k_rollout_queue(GroupArgs g_in, Roun
         g.s0 = psrc[0];
         g.s1 = psrc[1];
         e.load_battle_global(from_scratch ? COLD_Q(sb, const uint8_t *) + (size_t)idx * 384 : bd->battles + (size_t)k * 384, dsrc[0], dsrc[1]);
-        if (prep && !from_scratch) { // mcts.h:254-259
+        if (IS_PREP && !from_scratch) { // mcts.h:254-259
           const uint32_t hi = g.next32(), lo = g.next32();
           e.rng = ((uint64_t)hi << 32) | lo;
           e.randomize_hidden();
@@ -710,16 +725,16 @@ __global__ __launch_bounds__(BLK, WPS) void k_rollout_queue(GroupArgs g_in, Roun
     }
     // a wave that holds a playout far beyond the usual length (99.5% end before 250 turn-steps) is on the launch's critical
     // path -- a 1000-step chain: it goes first on its SIMD (an adopter as soon as it adopts)
-    if (adopting || __ballot(playing && steps > LONG_STEPS)) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0);
-    any_playing = __ballot(playing) != 0;
-    if (adopter && !any_playing) { // nothing to play: wait for donations (bounded) without burning issue slots
+    if (IS_ADOPTING || __ballot(playing && steps > LONG_STEPS)) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0);
+    if (__ballot(playing) != 0) ust |= U_ANY_PLAYING; else ust &= ~U_ANY_PLAYING;
+    if (IS_ADOPTER && !ANY_PLAYING) { // nothing to play: wait for donations (bounded) without burning issue slots
       __builtin_amdgcn_s_sleep(100);
-      if (++idle_polls > SPIN_CAP) { if (wl == 0) atomicOr(COLD_Q(adopt_ctl, uint32_t *) + 3, 2u); break; }
+      if (++idle_polls > SPIN_CAP) { if (wl == 0) atomicOr(COLD_Q(adopt_ctl, uint32_t *) + ERR_WORD, 2u); break; }
     }
     // wave-uniform: the queue is dry and too few lanes are still playing -> hand them to the next round
     const uint64_t still = __ballot(playing);
-    const bool suspend = dry && still != 0 && (uint32_t)__popcll(still) < suspend_below;
-    const bool lng = n_adopt != 0 && !adopter && playing && steps >= long_steps; // a bulk wave's long playout: to the adopters
+    const bool suspend = IS_DRY && still != 0 && (uint32_t)__popcll(still) < suspend_below;
+    const bool lng = n_adopt != 0 && !IS_ADOPTER && playing && steps >= long_steps; // a bulk wave's long playout: to the adopters
     if (idx != DONE && idx != NONE && (!playing || suspend || lng)) { // retire the lane: publish a finished playout / park a suspended or donated one
       OAK_SCOPE(PS_PUBLISH);
       const bool fin = !playing;
@@ -749,7 +764,7 @@ __global__ __launch_bounds__(BLK, WPS) void k_rollout_queue(GroupArgs g_in, Roun
       const uint32_t leader = (uint32_t)__ffsll((unsigned long long)dm) - 1;
       uint32_t base = 0;
       if (wl == leader) base = atomicAdd(ctl + 0, (uint32_t)__popcll(dm));
-      base = __shfl(base, leader, 64);
+      base = (uint32_t)__builtin_amdgcn_readlane((int)base, (int)leader);
       if (lng) {
         __hip_atomic_store(COLD_Q(adopt_list, uint32_t *) + base + (uint32_t)__popcll(dm & ((1ull << wl) - 1)), idx + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         idx = NONE; // the lane is free again
@@ -759,12 +774,12 @@ __global__ __launch_bounds__(BLK, WPS) void k_rollout_queue(GroupArgs g_in, Roun
       const uint32_t leader = (uint32_t)__ffsll((unsigned long long)still) - 1;
       uint32_t base = 0;
       if (wl == leader) base = atomicAdd(COLD_Q(count_out, uint32_t *), (uint32_t)__popcll(still));
-      base = __shfl(base, leader, 64);
+      base = (uint32_t)__builtin_amdgcn_readlane((int)base, (int)leader);
       if (playing) COLD_Q(list_out, uint32_t *)[base + (uint32_t)__popcll(still & ((1ull << wl) - 1))] = idx;
       break;
     }
   }
-  if (n_adopt != 0 && !adopter && wl == 0) atomicAdd(COLD_Q(adopt_ctl, uint32_t *) + 2, 1u); // a bulk wave has left: it donates no more
+  if (n_adopt != 0 && !IS_ADOPTER && wl == 0) atomicAdd(COLD_Q(adopt_ctl, uint32_t *) + 2, 1u); // a bulk wave has left: it donates no more
   OAK_TL(2, wall_clock64());
 #ifdef OAKGPU_TIMELINE
   OAK_TL(4, tl_steps);
@@ -772,6 +787,15 @@ __global__ __launch_bounds__(BLK, WPS) void k_rollout_queue(GroupArgs g_in, Roun
   OAK_PROF_FLUSH();
 }
 #undef COLD_Q
+#undef COLD_U32
+#undef COLD_QU
+#undef COLD_GU
+#undef IS_RESUME
+#undef IS_PREP
+#undef IS_DRY
+#undef IS_ADOPTER
+#undef IS_ADOPTING
+#undef ANY_PLAYING
 
 // ---- K1 with per-turn ACTION-CLASS COMPACTION across the waves of a workgroup (north_star: "wavefront ballot / prefix-sum
 // for per-turn branch compaction").  In k_rollout_queue every wave runs the move pipeline and the switch code twice per
@@ -1613,10 +1637,11 @@ int oakgpu_get_leaf_kernel_ms(oakgpu_ctx *c, float ms[3]) {
 int oakgpu_synchronize(oakgpu_ctx *c) {
   if (!c) return bad("null ctx");
   HIPCHK(hipStreamSynchronize(c->stream));
-  if (c->d_queue && c->migrate_used) { // the last queue launch migrated playouts: did one of its bounded waits run out?
+  if (c->d_queue && c->migrate_used) { // a queue launch since the last check migrated playouts: did a bounded wait run out?
     uint32_t err = 0;
-    HIPCHK(hipMemcpy(&err, c->d_queue + 43, 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(&err, c->d_queue + 63, 4, hipMemcpyDeviceToHost));
     c->migrate_used = 0;
+    if (err) HIPCHK(hipMemset(c->d_queue + 63, 0, 4));
     if (err) return bad("rollout: a bounded wait of the long-playout migration ran out (playouts were lost) -- oakgpu_set_migration(ctx, 0, ...) turns it off");
   }
   return 0;
@@ -1647,7 +1672,7 @@ static inline uint32_t grid_for(uint32_t n) { return (n + oak::BLOCK - 1) / oak:
 // stream; a slot is reused only after the event behind its previous copy has completed).
 static int launch_group(oakgpu_ctx *c, const oak::BatchDesc *descs, uint32_t count, uint32_t total, uint32_t max_steps, int prep) {
   HIPCHK(hipSetDevice(c->device));
-  if (!c->d_queue) HIPCHK(hipMalloc((void **)&c->d_queue, 256));
+  if (!c->d_queue) { HIPCHK(hipMalloc((void **)&c->d_queue, 256)); HIPCHK(hipMemset(c->d_queue, 0, 256)); }
   if (!c->h_table) {
     HIPCHK(hipHostMalloc((void **)&c->h_table, sizeof(oak::BatchDesc) * oak::MAX_GROUP * oakgpu_ctx::TABLE_SLOTS, hipHostMallocDefault));
     HIPCHK(hipMalloc((void **)&c->d_table, sizeof(oak::BatchDesc) * oak::MAX_GROUP * oakgpu_ctx::TABLE_SLOTS));
@@ -1659,7 +1684,7 @@ static int launch_group(oakgpu_ctx *c, const oak::BatchDesc *descs, uint32_t cou
   memcpy(ht, descs, sizeof(oak::BatchDesc) * count);
   HIPCHK(hipMemcpyAsync(dt, ht, sizeof(oak::BatchDesc) * count, hipMemcpyHostToDevice, c->stream));
   HIPCHK(hipEventRecord(c->table_ev[slot], c->stream));
-  HIPCHK(hipMemsetAsync(c->d_queue, 0, 256, c->stream));
+  HIPCHK(hipMemsetAsync(c->d_queue, 0, 252, c->stream)); // (word 63 is the sticky migration error word: never cleared here)
   if (c->rollout_engine == 3 && max_steps < (1u << 24)) { // per-turn action-class compaction (k_rollout_bins): 256-lane workgroups
     const int wps = c->bins_wps;
     uint32_t blocks = ((total + oak::BINS_BLK - 1) / oak::BINS_BLK + c->playouts_per_lane - 1) / c->playouts_per_lane;
@@ -1738,7 +1763,7 @@ static int launch_group(oakgpu_ctx *c, const oak::BatchDesc *descs, uint32_t cou
     order = c->d_order;
   }
   if (migrate) HIPCHK(hipMemsetAsync(lists[0], 0, (size_t)total * 4, c->stream)); // the adoption tickets (one per donation at most)
-  c->migrate_used = migrate ? 1 : 0;
+  if (migrate) c->migrate_used = 1; // (sticky, like the device word: back-to-back launches keep an earlier launch's error)
   for (int r = 0; r < rounds; ++r) {
     oak::RoundArgs q{};
     q.order = r == 0 ? order : nullptr;

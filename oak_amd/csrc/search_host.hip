@@ -178,7 +178,11 @@ struct Tree {
     }
   }
   // Heap::update's `std::swap(node, child->second)` (search.cc:42): the subtree under `new_root` becomes the tree, everything
-  // else is dropped.  Nodes keep their shards; ids are reassigned in breadth-first order.  Returns the new root id.
+  // else is dropped.  Ids are reassigned in breadth-first order.  A kept node keeps its OWNER shard, but its CREATOR becomes the
+  // table its incoming edge re-hashes to under the new parent id: the resolve phase relies on "arena[owner][t] is touched only
+  // by the thread of table t" (a lookup through table t reads node(child) while table t's thread may append to -- and so
+  // reallocate -- exactly the arenas [*][t]); with the old creator kept, thread t would read an arena that another thread is
+  // appending to (round-3 advice).  Returns the new root id.
   uint32_t keep_subtree(uint32_t new_root) {
     struct E { uint32_t parent, child; uint8_t key[18]; };
     std::vector<E> edges;
@@ -193,17 +197,17 @@ struct Tree {
     std::vector<std::pair<uint32_t, uint32_t>> queue; // (old id, new id)
     struct NE { uint32_t parent, child; const uint8_t *key; };
     std::vector<NE> kept;
-    auto move_node = [&](uint32_t old_id) {
-      const uint32_t nid = fresh.new_node((int)(old_id & 7), (int)((old_id >> 3) & 7));
+    auto move_node = [&](uint32_t old_id, int creator) {
+      const uint32_t nid = fresh.new_node((int)(old_id & 7), creator);
       fresh.node(nid) = node(old_id);
       return nid;
     };
-    const uint32_t root_new = move_node(new_root);
+    const uint32_t root_new = move_node(new_root, (int)((new_root >> 3) & 7)); // (no incoming edge: never reached through a table)
     queue.emplace_back(new_root, root_new);
     for (size_t head = 0; head < queue.size(); ++head) {
       const auto [oid, nid] = queue[head];
       for (size_t q = (size_t)first_edge(oid); q < edges.size() && edges[q].parent == oid; ++q) {
-        const uint32_t cn = move_node(edges[q].child);
+        const uint32_t cn = move_node(edges[q].child, edge_shard(hash_of(nid, edges[q].key)));
         kept.push_back({nid, cn, edges[q].key});
         queue.emplace_back(edges[q].child, cn);
       }
@@ -436,9 +440,23 @@ struct Slot {
   uint64_t serial = 0;
   bool busy = false;
   ~Slot() { buf.release(); if (own_ctx && ctx) oakgpu_destroy(ctx); }
+  uint32_t lay = 0; // the batch size the packed arrays are carved for (<= cap): what a level copies is sized by THIS, not by cap
+  // the packed per-level arrays, carved from their blocks for a batch of B lanes (same order on either side)
+  void carve(uint32_t B) {
+    d_c2 = d_c1 + B;
+    d_ch1 = d_act + (size_t)B * 16; d_ch2 = d_ch1 + (size_t)B * 9; d_r = d_ch2 + (size_t)B * 9; d_cnt1 = d_r + B; d_cnt2 = d_cnt1 + B;
+    h_c2 = h_c1 + B;
+    h_ch1 = h_act + (size_t)B * 16; h_ch2 = h_ch1 + (size_t)B * 9; h_r = h_ch2 + (size_t)B * 9; h_cnt1 = h_r + B; h_cnt2 = h_cnt1 + B;
+    lay = B;
+  }
   int allocate(oakgpu_ctx *primary, int index, uint32_t B, bool logits, int emb) {
     if (ctx) stream = (hipStream_t)oakgpu_ctx_stream(ctx); // (the caller may have given the context another stream since)
-    if (ctx && cap >= B && (has_logits || !logits) && emb_dim >= emb) return 0;
+    // kept between searches, re-carved for this search's batch; given back when the last search was more than 8x larger (round-3
+    // advice: after one 2^20-lane search every later 1,024-lane search moved 37 MB per tree level)
+    if (ctx && cap >= B && cap <= 8 * (size_t)B + 4096 && (has_logits || !logits) && emb_dim >= emb) {
+      if (lay != B) { (void)hipStreamSynchronize(stream); carve(B); }
+      return 0;
+    }
     if (ctx) (void)hipStreamSynchronize(stream);
     buf.release();
     if (!ctx) {
@@ -451,16 +469,15 @@ struct Slot {
     RC(buf.d(&d_b, (size_t)B * 384)); RC(buf.d(&d_d, (size_t)B * 8)); RC(buf.d(&d_prng, (size_t)B * 8));
     // what a level sends down (two choice bytes per lane) and what comes back (37 bytes per lane) each travel as ONE copy:
     // the arrays are carved from one block on either side, in the same order
-    RC(buf.d(&d_c1, (size_t)B * 2)); d_c2 = d_c1 + B;
+    RC(buf.d(&d_c1, (size_t)B * 2));
     RC(buf.d(&d_act, (size_t)B * PACK));
-    d_ch1 = d_act + (size_t)B * 16; d_ch2 = d_ch1 + (size_t)B * 9; d_r = d_ch2 + (size_t)B * 9; d_cnt1 = d_r + B; d_cnt2 = d_cnt1 + B;
     RC(buf.d(&d_rout, (size_t)B)); RC(buf.d(&d_steps, (size_t)B)); RC(buf.d(&d_values, (size_t)B));
     d_l1 = d_l2 = d_emb = nullptr; h_l1 = h_l2 = nullptr;
     if (logits) { RC(buf.d(&d_l1, (size_t)B * 9)); RC(buf.d(&d_l2, (size_t)B * 9)); }
     if (emb) RC(buf.d(&d_emb, (size_t)B * emb));
-    RC(buf.h(&h_c1, (size_t)B * 2)); h_c2 = h_c1 + B;
+    RC(buf.h(&h_c1, (size_t)B * 2));
     RC(buf.h(&h_act, (size_t)B * PACK));
-    h_ch1 = h_act + (size_t)B * 16; h_ch2 = h_ch1 + (size_t)B * 9; h_r = h_ch2 + (size_t)B * 9; h_cnt1 = h_r + B; h_cnt2 = h_cnt1 + B;
+    carve(B);
     RC(buf.h(&h_values, (size_t)B)); RC(buf.h(&h_stage, (size_t)B * 384));
     if (logits) { RC(buf.h(&h_l1, (size_t)B * 9)); RC(buf.h(&h_l2, (size_t)B * 9)); }
     root_i.resize(B); root_j.resize(B); root_p1.resize(B); root_p2.resize(B);
@@ -503,6 +520,105 @@ int oakgpu_heap_update(oakgpu_heap *h, uint8_t i, uint8_t j, const uint8_t *obs1
   }
   h->root = h->tree.keep_subtree(child);
   return 1;
+}
+
+// Diagnostic: live edges whose child does NOT sit in an arena created by the edge's own table.  0 in a consistent tree; the
+// resolve phase's threading relies on it (Tree::keep_subtree re-establishes it after a promotion).
+uint64_t oakgpu_heap_check_shards(const oakgpu_heap *h) {
+  if (!h) return 0;
+  uint64_t bad = 0;
+  for (int t = 0; t < SHARDS; ++t) {
+    const Tree::Table &tb = h->tree.tab[t];
+    for (size_t q = 0; q < tb.cap; ++q)
+      if (tb.e[q].gen == tb.gen) {
+        const Edge &e = tb.e[q];
+        bad += (int)((e.child >> 3) & 7) != t || Tree::edge_shard(e.hash) != t || Tree::hash_of(e.parent, e.key) != e.hash;
+      }
+  }
+  return bad;
+}
+
+// Host-only self-test of the sharded tree (no GPU): grows a random tree with the search's own resolve phase -- edges routed to
+// the table their hash picks, `threads` threads each serving tables t = thread mod threads, every thread creating children
+// and reading whether the child it found is initialised -- promotes a random child of the root (Heap::update), checks the
+// shard invariant, and grows the promoted tree again with the same threads.  Returns 0 when every check holds, else a code;
+// out[0] = nodes before the promotion, out[1] = nodes kept, out[2] = nodes at the end, out[3] = shard violations seen.
+int oakgpu_heap_selftest(uint32_t rounds, uint32_t lanes, uint64_t seed, int threads, uint64_t out[4]) {
+  if (threads != 1 && threads != 2 && threads != 4 && threads != 8) return oakgpu_fail_msg("oakgpu_heap_selftest: threads must be 1, 2, 4 or 8");
+  oakgpu_heap H;
+  Tree &tree = H.tree;
+  tree.reset((size_t)rounds * lanes);
+  if (!tree.ok()) return oakgpu_fail_msg("oakgpu_heap_selftest: out of memory");
+  H.kind = 0; H.rooted = true;
+  H.root = tree.new_node(0, 0);
+  tree.node(H.root).p1.init(3, 0); tree.node(H.root).p2.init(3, 0);
+  Pool pool(threads);
+  uint64_t rng = seed * 0x9E3779B97F4A7C15ull + 1;
+  auto next = [&] { rng ^= rng << 13; rng ^= rng >> 7; rng ^= rng << 17; return rng; };
+  std::vector<uint32_t> nodes{H.root};
+  std::vector<Route> route[SHARDS];
+  std::vector<uint32_t> made[SHARDS];
+  auto grow_rounds = [&](uint32_t n) {
+    for (uint32_t r = 0; r < n; ++r) {
+      for (auto &v : route) v.clear();
+      for (uint32_t l = 0; l < lanes; ++l) { // a lane walks from a known initialised node along a random edge
+        Route x{};
+        x.lane = l;
+        x.parent = nodes[next() % nodes.size()];
+        x.key[0] = (uint8_t)(next() % 3); x.key[1] = (uint8_t)(next() % 3); x.key[2] = (uint8_t)(next() % 4);
+        x.hash = Tree::hash_of(x.parent, x.key);
+        route[Tree::edge_shard(x.hash)].push_back(x);
+      }
+      pool.run([&](int w) {
+        for (int t = w; t < SHARDS; t += threads) {
+          made[t].clear();
+          for (const Route &x : route[t]) {
+            const uint32_t c = tree.child(x.parent, x.key, x.hash);
+            if (!tree.node(c).is_init()) made[t].push_back(c); // (the read the promotion used to race with)
+          }
+        }
+      });
+      pool.run([&](int w) { // initialise the new leaves: by the thread of the node's OWNER shard, as finish() does
+        for (int own = w; own < SHARDS; own += threads)
+          for (int t = 0; t < SHARDS; ++t)
+            for (uint32_t c : made[t])
+              if (owner_of(c) == own && !tree.node(c).is_init()) { tree.node(c).p1.init(3, 0); tree.node(c).p2.init(3, 0); }
+      });
+      for (int t = 0; t < SHARDS; ++t) for (uint32_t c : made[t]) nodes.push_back(c);
+      std::sort(nodes.begin(), nodes.end());
+      nodes.erase(std::unique(nodes.begin(), nodes.end()), nodes.end());
+    }
+  };
+  grow_rounds(rounds);
+  uint64_t bad = oakgpu_heap_check_shards(&H);
+  out[0] = tree.size();
+  if (out[0] != nodes.size()) return 2;
+  // promote the root's most travelled kind of child: any existing edge of the root
+  uint32_t child = 0;
+  bool found = false;
+  for (int a = 0; a < 3 && !found; ++a) for (int b = 0; b < 3 && !found; ++b) for (int c = 0; c < 4 && !found; ++c) {
+    uint8_t key[18] = {(uint8_t)a, (uint8_t)b, (uint8_t)c};
+    found = tree.find_child(H.root, key, &child);
+  }
+  if (!found) return 3;
+  H.root = tree.keep_subtree(child);
+  out[1] = tree.size();
+  bad += oakgpu_heap_check_shards(&H);
+  // every kept node is reachable from the new root through the re-hashed tables, initialised, and counted once
+  nodes.assign(1, H.root);
+  for (size_t head = 0; head < nodes.size(); ++head)
+    for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) for (int c = 0; c < 4; ++c) {
+      uint8_t key[18] = {(uint8_t)a, (uint8_t)b, (uint8_t)c};
+      uint32_t ch;
+      if (tree.find_child(nodes[head], key, &ch)) { if (!tree.node(ch).is_init()) return 4; nodes.push_back(ch); }
+    }
+  if (nodes.size() != out[1]) return 5;
+  grow_rounds(rounds);
+  out[2] = tree.size();
+  bad += oakgpu_heap_check_shards(&H);
+  out[3] = bad;
+  if (out[2] != nodes.size()) return 6;
+  return bad ? 7 : 0;
 }
 
 // Test / diagnostic view of the root's two bandits: scores[9], priors[9], visits[9], k per player (0 = not initialised).
@@ -817,10 +933,10 @@ int oakgpu_search_heap(oakgpu_ctx *ctx, oakgpu_net *net, oakgpu_heap *heap, cons
         });
       }
       const auto tb = now();
-      HIPRC(hipMemcpyAsync(S.d_c1, S.h_c1, (size_t)S.cap + nb, hipMemcpyHostToDevice, S.stream)); // c1[0, cap) + c2[0, nb)
+      HIPRC(hipMemcpyAsync(S.d_c1, S.h_c1, (size_t)S.lay + nb, hipMemcpyHostToDevice, S.stream)); // c1[0, lay) + c2[0, nb)
       RC(oakgpu_tree_step_dev(S.ctx, S.d_b, S.d_d, S.d_r, S.d_c1, S.d_c2, nb, depth == 0 ? prm->root_rolls : prm->other_rolls, S.d_act,
                               S.d_ch1, S.d_cnt1, S.d_ch2, S.d_cnt2));
-      HIPRC(hipMemcpyAsync(S.h_act, S.d_act, (size_t)S.cap * Slot::PACK, hipMemcpyDeviceToHost, S.stream));
+      HIPRC(hipMemcpyAsync(S.h_act, S.d_act, (size_t)S.lay * Slot::PACK, hipMemcpyDeviceToHost, S.stream));
       HIPRC(hipStreamSynchronize(S.stream));
       const auto tc = now();
       // edges, in two steps.  Route: the thread of the PARENT's shard hashes its lanes' edges (parent, i, j, observation) and

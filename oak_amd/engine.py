@@ -74,7 +74,7 @@ class Context:
         _lib.check(self.lib.oakgpu_set_migration(self.handle, int(mode), int(long_steps), int(adopters)))
 
     def queue_counters(self):
-        """The 64 control words of the last queue launch (oakgpu_get_queue_counters): [40] donations, [41] adoptions, [43] errors."""
+        """The 64 control words of the last queue launch (oakgpu_get_queue_counters): [40] donations, [41] adoptions, [63] sticky error bits."""
         out = np.zeros(64, dtype=np.uint32)
         _lib.check(self.lib.oakgpu_get_queue_counters(self.handle, out.ctypes.data_as(C.c_void_p)))
         return out

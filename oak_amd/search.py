@@ -118,6 +118,10 @@ class Heap:
     def clear(self):
         self.lib.oakgpu_heap_clear(self.handle)
 
+    def shard_violations(self):
+        """Edges whose child sits in another table's arena (oakgpu_heap_check_shards): 0 in a consistent tree."""
+        return int(self.lib.oakgpu_heap_check_shards(self.handle))
+
     def update(self, i, j, obs):
         o = np.ascontiguousarray(obs, dtype=np.uint8).reshape(16)
         return bool(self.lib.oakgpu_heap_update(self.handle, int(i), int(j), o.ctypes.data_as(C.c_void_p)))

@@ -4,6 +4,8 @@ import ctypes as C
 import os
 import re
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -56,8 +58,26 @@ def test_cpp_host_layer_compiles_and_links(tmp_path):
     subprocess.check_call(["g++", "-std=c++17", "-Wall", "-I", os.path.join(ROOT, "include"),
                            os.path.join(ROOT, "tests", "cpp_host_smoke.cc"), "-L", os.path.join(ROOT, "oak_amd"), "-loakgpu",
                            "-Wl,-rpath," + os.path.join(ROOT, "oak_amd"), "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
-    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    env = dict(os.environ, OAKGPU_SMOKE_NET=os.path.join(ROOT, "tests", "golden", "net_default.battle.net"))
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120, env=env)
     assert out.returncode == 0, out.stdout + out.stderr
+
+
+@pytest.mark.gpu
+def test_cpp_host_layer_runs_on_the_gpu_and_per_leaf_eval_equals_batched(tmp_path):
+    """The GPU half of tests/cpp_host_smoke.cc: a rollout through OakGPU::BatchedMonteCarlo, the refusals of TreeSearch / run,
+    and the reference's per-leaf eval signatures -- OakGPU::Network::value_inference(battle, durations) and
+    value_policy_inference(b, d, m, n, c1, c2, p1, p2) (nn/battle/network.h:72-79,102-123, as mcts.h:196-209,401-422 calls them)
+    -- against the batched calls on the same leaves: identical values and logits."""
+    import subprocess
+    exe = str(tmp_path / "cpp_host_smoke")
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp_host_smoke.cc"), "-L", os.path.join(ROOT, "oak_amd"), "-loakgpu",
+                           "-Wl,-rpath," + os.path.join(ROOT, "oak_amd"), "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
+    env = dict(os.environ, OAKGPU_SMOKE_NET=os.path.join(ROOT, "tests", "golden", "net_default.battle.net"))
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "per-leaf eval == batched eval" in out.stdout and out.stdout.strip().endswith("ok"), out.stdout
 
 
 def test_host_mt19937_fill_matches_reference_known_answers():

@@ -239,7 +239,7 @@ def test_long_playout_migration_does_not_change_results(gpu_ctx):
             for prep in (False, True):
                 q = gpu_ctx.rollout(b, d, r, p, max_steps=1000, prep=prep, return_state=True)
                 c = gpu_ctx.queue_counters()
-                assert c[43] == 0, ("bounded wait ran out", ppl, long_steps, adopters, int(c[43]))
+                assert c[63] == 0, ("bounded wait ran out", ppl, long_steps, adopters, int(c[63]))
                 assert c[40] == c[41] and c[40] > 0, ("donations / adoptions", int(c[40]), int(c[41]))
                 ref = plain
                 if prep:

@@ -277,10 +277,11 @@ def test_heap_update_promotes_the_played_child(gpu_ctx):
         for x, y in zip(before[pl], after[pl]):
             assert x.tobytes() == y.tobytes()                        # scores, priors, visits: the old child's, exactly
     assert 0 < h.nodes() < nodes_before                              # the rest of the tree is dropped
+    assert h.shard_violations() == 0                                 # every kept edge's child was re-homed to the edge's new table
     kept = h.nodes()
     if (int(nres[0]) & 15) == 0:
         o2 = tree_search(gpu_ctx, nb[0], nd[0], int(nres[0]), iterations=1 << 13, batch=1024, seed=6, heap=h)
-        assert o2["iterations"] == 1 << 13 and o2["nodes"] > kept
+        assert o2["iterations"] == 1 << 13 and o2["nodes"] > kept and h.shard_violations() == 0
         visits_root = h.root_stats(0)[2]
         assert int(visits_root.sum()) == int(after[0][2].sum()) + (1 << 13)     # UCB: every iteration is one more visit at the root
         # an observation that cannot exist: nothing is kept, the heap holds an uninitialised node (not monostate)

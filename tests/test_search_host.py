@@ -178,3 +178,23 @@ def test_root_select_run_equals_the_plain_select_visit_loop():
         assert (vr == vl).all() and (run < k).all()
         if kind < 2:
             assert int(vr.sum()) == int(visits.sum()) + (count if k > 1 else 0) or k == 1
+
+
+@pytest.mark.parametrize("threads", [1, 4, 8])
+def test_promoted_heap_keeps_the_shard_invariant_of_the_threaded_walk(threads):
+    """Round-3 advice (data race after Heap::update): Tree::keep_subtree kept a node's OLD creator shard while its edge
+    re-hashed into another table, so the thread of that table read arena[owner][creator'] while thread creator' could append
+    to (and reallocate) it.  Host-only self-test of the sharded tree: grow with the search's own threaded resolve phase,
+    promote a child of the root, check that every edge's child sits in an arena of the edge's table, grow again with the
+    same threads.  The tree's size does not depend on the number of threads."""
+    import ctypes as C
+    from oak_amd import _lib
+    lib = _lib.load()
+    out = (C.c_uint64 * 4)()
+    rc = lib.oakgpu_heap_selftest(24, 2048, 7, threads, C.byref(out))
+    assert rc == 0, (rc, list(out))
+    before, kept, after, bad = list(out)
+    assert bad == 0 and 0 < kept < before and after > kept
+    ref = (C.c_uint64 * 4)()
+    assert lib.oakgpu_heap_selftest(24, 2048, 7, 1, C.byref(ref)) == 0
+    assert list(ref) == list(out)

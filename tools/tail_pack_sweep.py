@@ -60,7 +60,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "migrate":    # long-playout migration A
         print("migrate %d long_steps %3d adopters %3d" % (mode, ls, ad), end="  ")
         run(0, 0, 0, reps=4)
         c = counters()
-        print("      donations %d adoptions %d bulk waves left %d errors %d" % (c[40], c[41], c[42], c[43]), flush=True)
+        print("      donations %d adoptions %d bulk waves left %d errors %d" % (c[40], c[41], c[42], c[63]), flush=True)
     sys.exit(0)
 if len(sys.argv) > 1 and sys.argv[1] == "order":      # the queue-order A/B only
     for on in (0, 1, 0, 1):
