@@ -424,6 +424,14 @@ int oakgpu_net_shape(const oakgpu_net *net, int *in_dim, int *hidden, int *value
 #define OAKGPU_MAIN_FP32 0
 #define OAKGPU_MAIN_SPLIT 1
 int oakgpu_net_set_main_precision(oakgpu_net *net, int mode);
+/* Edges of the bf16-triple form.  (1) A parameter file with a NaN / inf anywhere is REFUSED by oakgpu_net_load* ("non-finite
+ * parameter ... in <layer>"); the reference loads it and propagates NaN (nn/affine.h:72-85 is a plain fp32 W x + b).  (2) A
+ * triple carries a value to fp32 accuracy only while its low parts are normal bf16 numbers (|x| >= ~2^-102); what a flushed
+ * part loses is at most 2^-126 per factor, harmless unless later layers multiply it back up.  So a network with a main-net
+ * weight (fc0 / fc1 / value_fc2) above 2^20 in magnitude runs its main net on fp32 MFMA, and a request for OAKGPU_MAIN_SPLIT
+ * is not honoured for it (tests/test_gpu_leafnet.py: layers scaled by 2^-100 / 2^-120 / 2^+100, alone and compensated).  Returns the mode in effect (-1: null net); *split_allowed (nullable) = 0 for such
+ * a network. */
+int oakgpu_net_main_precision(const oakgpu_net *net, int *split_allowed);
 int oakgpu_leaf_eval_dev(oakgpu_ctx *ctx, oakgpu_net *net, const uint8_t *battles, const uint8_t *durations,
                          uint32_t n, float *values, float *embedding_out);
 int oakgpu_leaf_eval(oakgpu_ctx *ctx, oakgpu_net *net, const uint8_t *battles, const uint8_t *durations, uint32_t n,

@@ -13,7 +13,7 @@ SYMBOLS = [
     "oakgpu_mt19937_fill", "oakgpu_rollout_draws_dev", "oakgpu_rollout_shared_device", "oakgpu_update_dev", "oakgpu_update",
     "oakgpu_choices_dev", "oakgpu_choices", "oakgpu_init_battles_dev", "oakgpu_init_battles",
     "oakgpu_set_ou_pools", "oakgpu_random_ou_battles_dev",
-    "oakgpu_net_load", "oakgpu_net_load_memory", "oakgpu_net_free", "oakgpu_net_shape", "oakgpu_net_set_main_precision",
+    "oakgpu_net_load", "oakgpu_net_load_memory", "oakgpu_net_free", "oakgpu_net_shape", "oakgpu_net_set_main_precision", "oakgpu_net_main_precision",
     "oakgpu_leaf_eval_dev", "oakgpu_leaf_eval", "oakgpu_leaf_eval_cached_dev", "oakgpu_leaf_cache_last_count", "oakgpu_leaf_eval_policy_dev", "oakgpu_leaf_eval_policy",
     "oakgpu_heap_create", "oakgpu_heap_destroy", "oakgpu_heap_empty", "oakgpu_heap_clear", "oakgpu_heap_kind", "oakgpu_heap_nodes", "oakgpu_heap_update",
     "oakgpu_heap_root_stats", "oakgpu_heap_child_stats", "oakgpu_search_heap", "oakgpu_search_agent_heap", "oakgpu_heap_check_shards", "oakgpu_heap_selftest",
@@ -161,6 +161,7 @@ def load():
     lib.oakgpu_net_free.restype = None
     lib.oakgpu_net_shape.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
     lib.oakgpu_net_set_main_precision.argtypes = [vp, C.c_int]
+    lib.oakgpu_net_main_precision.argtypes = [vp, C.POINTER(C.c_int)]
     lib.oakgpu_leaf_eval_dev.argtypes = [vp, vp, vp, vp, u32, vp, vp]
     lib.oakgpu_leaf_eval.argtypes = [vp, vp, vp, vp, u32, vp, vp]
     lib.oakgpu_leaf_eval_cached_dev.argtypes = [vp, vp, vp, vp, u32, vp, vp, vp]

@@ -14,6 +14,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <cmath>
 #include <string>
 #include <type_traits>
 #include <vector>
@@ -1735,6 +1736,7 @@ struct oakgpu_net {
   int in_dim, hidden, value_hidden, policy_hidden; // unpadded, as in the file
   int device;        // the device the weights live on
   int main_mode;     // which kernel runs the main net: 0 = k_mainnet_wave (fp32 MFMA), 1 = k_mainnet_split (bf16 triples)
+  bool split_safe;   // no main-net weight above 2^20 in magnitude: what a flushed low bf16 part loses cannot be amplified back (else fp32 MFMA only)
 };
 
 namespace {
@@ -1949,6 +1951,19 @@ int oakgpu_net_load_memory(oakgpu_ctx *ctx, const void *bytes, size_t size, oakg
   for (int i = 0; i < 12; ++i)
     if (!read_affine(p, end, L[i])) return oakgpu_fail_msg("network file: truncated or malformed layer");
   if (p != end) return oakgpu_fail_msg("network file: trailing bytes (network.h:60-63)");
+  // Non-finite parameters are refused.  The reference would load them and propagate NaN / inf through every inference (its
+  // value_inference asserts !isnan in debug builds, network.h:77); a file with such a parameter is a failed training run, and
+  // here an infinite weight would also split into (inf, NaN, NaN) on the bf16 pipe -- a different wrong answer than fp32's.
+  {
+    static const char *names[12] = {"pokemon_net.fc0", "pokemon_net.fc1", "active_net.fc0", "active_net.fc1", "main_net.fc0", "main_net.fc1", "main_net.value_fc2",
+                                    "main_net.value_fc3", "main_net.p1_policy_fc2", "main_net.p1_policy_fc3", "main_net.p2_policy_fc2", "main_net.p2_policy_fc3"};
+    for (int i = 0; i < 12; ++i) {
+      bool finite = true;
+      for (float v : L[i].b) finite = finite && std::isfinite(v);
+      for (float v : L[i].w) finite = finite && std::isfinite(v);
+      if (!finite) return oakgpu_fail_msg((std::string("network file: non-finite parameter (NaN / inf) in ") + names[i]).c_str());
+    }
+  }
   const HostAffine &p0 = L[0], &p1 = L[1], &a0 = L[2], &a1 = L[3], &fc0 = L[4], &fc1 = L[5], &v2 = L[6], &v3 = L[7];
   if (p0.in != 198 || a0.in != 427) return oakgpu_fail_msg("network file: embedding input dims must be 198 / 427");
   if (p1.in != p0.out || a1.in != a0.out || fc1.in != fc0.out || v2.in != fc1.out || v3.in != v2.out || v3.out != 1)
@@ -2007,8 +2022,18 @@ int oakgpu_net_load_memory(oakgpu_ctx *ctx, const void *bytes, size_t size, oakg
       }
     }
     D.ws = (const uint16_t *)dptr; D.ws_T0 = (int)T0; D.ws_NB = (int)NB;
+    // The bf16 triple (h, m, l) of a value x is exact to 2^-24 |x| only while its low parts are normal bf16 numbers (|x| >= ~2^-102);
+    // below that a part that flushes loses at most 2^-126 per factor -- an ABSOLUTE error of at most 2^-126 |other factor| per
+    // product.  That is harmless unless later layers amplify it: a layer scaled by 2^-120 feeding one scaled by 2^+120 computes an
+    // O(1) value in fp32, and there the lost parts would come back multiplied by 2^120.  So the triple form is used only while
+    // no main-net weight exceeds 2^20 in magnitude (two layers of 256 such weights amplify by < 2^56: 2^-126 x 768 x 2^56 is
+    // nothing); a network with a larger weight runs its main net on fp32 MFMA, whose products need no such care.
+    bool safe = true;
+    for (const HostAffine *a : {&fc0, &fc1, &v2})
+      for (float v : a->w) safe = safe && std::fabs(v) <= 0x1p20f;
+    net->split_safe = safe;
     const char *env = getenv("OAKGPU_MAIN_NET");
-    net->main_mode = env ? (strcmp(env, "fp32") == 0 ? 0 : 1) : 1;
+    net->main_mode = !safe ? 0 : env ? (strcmp(env, "fp32") == 0 ? 0 : 1) : 1;
   }
   {
     const HostAffine &q1a = L[8], &q1b = L[9], &q2a = L[10], &q2b = L[11];
@@ -2049,8 +2074,16 @@ int oakgpu_net_load(oakgpu_ctx *ctx, const char *path, oakgpu_net **out) {
 int oakgpu_net_set_main_precision(oakgpu_net *net, int mode) {
   if (!net || (mode != OAKGPU_MAIN_FP32 && mode != OAKGPU_MAIN_SPLIT)) { oakgpu_fail_msg("oakgpu_net_set_main_precision: bad argument"); return -1; }
   const int prev = net->main_mode;
-  net->main_mode = mode;
+  // (a network with a main-net weight above 2^20 in magnitude stays on fp32 MFMA: the request for bf16 triples is not honoured --
+  // the returned previous mode and oakgpu_net_main_precision say what runs)
+  net->main_mode = (mode == OAKGPU_MAIN_SPLIT && !net->split_safe) ? OAKGPU_MAIN_FP32 : mode;
   return prev;
+}
+
+int oakgpu_net_main_precision(const oakgpu_net *net, int *split_allowed) {
+  if (!net) { oakgpu_fail_msg("oakgpu_net_main_precision: null net"); return -1; }
+  if (split_allowed) *split_allowed = net->split_safe ? 1 : 0;
+  return net->main_mode;
 }
 
 int oakgpu_net_shape(const oakgpu_net *net, int *in_dim, int *hidden, int *value_hidden, int *policy_hidden) {

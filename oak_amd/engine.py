@@ -218,6 +218,14 @@ class Network:
         _lib.check(self.ctx.lib.oakgpu_net_shape(self.handle, *[C.byref(x) for x in v]))
         return tuple(x.value for x in v)
 
+    def main_precision(self):
+        """(mode in effect: "fp32" | "split", whether the bf16-triple form is allowed for this network): oakgpu_net_main_precision."""
+        allowed = C.c_int(0)
+        mode = self.ctx.lib.oakgpu_net_main_precision(self.handle, C.byref(allowed))
+        if mode < 0:
+            raise _lib.OakGpuError("oakgpu_net_main_precision failed")
+        return ("fp32", "split")[mode], bool(allowed.value)
+
     def set_main_precision(self, mode):
         """"split" (default: fp32 values as bf16 triples on the bf16 matrix pipe, fp32 accumulation) or "fp32" (fp32 MFMA);
         include/oakgpu.h: oakgpu_net_set_main_precision.  Returns the previous mode."""

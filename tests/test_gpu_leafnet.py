@@ -97,6 +97,96 @@ def test_bf16_triple_main_net_is_an_fp32_result(gpu_ctx, tmp_path, kind):
     net.close()
 
 
+def _rewrite_net(src, dst, edit):
+    """Copy a .battle.net file with edit(layer index, bias, W) -> (bias, W) applied to each of its 12 Affine blocks
+    (order: pokemon_net 0-1, active_net 2-3, fc0 4, fc1 5, value_fc2 6, value_fc3 7, policy heads 8-11)."""
+    import struct
+    raw = open(src, "rb").read()
+    out, off = [raw[:8]], 8
+    for i in range(12):
+        n_in, n_out = struct.unpack_from("<II", raw, off)
+        off += 8
+        b = np.frombuffer(raw, "<f4", n_out, off).copy()
+        off += 4 * n_out
+        W = np.frombuffer(raw, "<f4", n_out * n_in, off).copy().reshape(n_out, n_in)
+        off += 4 * n_out * n_in
+        b, W = edit(i, b, W)
+        out += [struct.pack("<II", n_in, n_out), b.astype("<f4").tobytes(), W.astype("<f4").tobytes()]
+    assert off == len(raw)
+    open(dst, "wb").write(b"".join(out))
+
+
+@pytest.mark.parametrize("case", ["down20_up20", "down100_up100", "down120_up120", "down100", "down120", "up100", "tiny_weights"])
+def test_bf16_triple_main_net_at_the_edges_of_the_exponent_range(gpu_ctx, tmp_path, case):
+    """where the low parts of a bf16 triple flush.  Layers of the 256-wide ReLU net are rescaled by powers of two
+    (exact in fp32; ReLU commutes with a positive scale, so a layer scaled down and the next scaled up computes the SAME
+    function) and the value is held to a float64 evaluation of the rescaled net from the kernel's own embedding:
+      * compensated pairs fc0 x 2^-s, fc1 x 2^+s: s = 20 stays on the bf16 pipe (no weight above 2^20); s = 100 and 120 have
+        weights far above 2^20 -- the loader runs such a net on fp32 MFMA, says so, and does not honour a request for the split;
+      * one layer scaled down alone (2^-100, 2^-120: every low part flushes, the hidden activations are ~1e-30) stays on the
+        bf16 pipe: what is lost is absolute and nothing multiplies it back up;
+      * fc0 x 2^+100 alone: fp32 MFMA, values saturate exactly like the float64 evaluation;
+      * a net whose fc1 holds weights down to 1e-38 (normal and subnormal fp32) next to ordinary ones: bf16 pipe."""
+    from oak_amd.engine import Network
+    src = str(tmp_path / "c3.battle.net")
+    NN.write_random_net(src, hidden=256, value_hidden=256, seed=11)
+    dst = str(tmp_path / "edge.battle.net")
+    dn = {"down20_up20": -20, "down100_up100": -100, "down120_up120": -120, "down100": -100, "down120": -120, "up100": 100}.get(case, 0)
+    up = -dn if "_up" in case else 0
+
+    def edit(i, b, W):
+        if i == 4 and dn:
+            return b * np.float32(2.0 ** dn), W * np.float32(2.0 ** dn)
+        if i == 5 and up:
+            return b, W * np.float32(2.0 ** up)
+        if i == 5 and case == "tiny_weights":
+            W = W.copy()
+            W[::3, ::5] *= np.float32(1e-30)     # ~1e-32: normal fp32, every bf16 part below m flushes
+            W[1::7, 2::11] = np.float32(1e-40)   # subnormal fp32
+        return b, W
+    _rewrite_net(src, dst, edit)
+    net = Network(gpu_ctx, path=dst)
+    onet = NN.Net(dst)
+    expect_split = case in ("down20_up20", "down100", "down120", "tiny_weights")
+    assert net.main_precision() == (("split", True) if expect_split else ("fp32", False))
+    net.set_main_precision("split")                       # not honoured where the loader refused it
+    assert net.main_precision()[0] == ("split" if expect_split else "fp32")
+    b, d = _midgame_states(300, 30, 555)
+    v, emb = net.value_inference(b, d, return_embedding=True)
+    with np.errstate(over="ignore"):
+        ref = np.array([_main_value_f64(onet, emb[i]) for i in range(b.shape[0])])
+    assert np.isfinite(v).all() and np.abs(v - ref).max() <= 1e-6, (case, np.abs(v - ref).max())
+    if expect_split:                                       # and the fp32-MFMA kernel agrees with it
+        net.set_main_precision("fp32")
+        assert np.abs(net.value_inference(b, d) - v).max() <= 1e-6
+    if "_up" in case:                                      # the same function as the unscaled net
+        plain = Network(gpu_ctx, path=src)
+        assert np.abs(plain.value_inference(b, d) - v).max() <= 2e-6
+        plain.close()
+    net.close()
+
+
+def test_non_finite_parameters_are_refused_by_the_loader(gpu_ctx, tmp_path):
+    """oakgpu_net_load refuses a parameter file that holds a NaN or an infinity, naming the layer (the reference would load
+    it and propagate NaN through every inference; on the bf16 pipe an infinite weight would split into inf + NaN)."""
+    from oak_amd._lib import OakGpuError
+    from oak_amd.engine import Network
+    src = os.path.join(ROOT, "tests", "golden", "net_default.battle.net")
+    for layer, name, bad in ((5, "main_net.fc1", np.inf), (0, "pokemon_net.fc0", np.nan), (7, "main_net.value_fc3", -np.inf), (11, "main_net.p2_policy_fc3", np.nan)):
+        dst = str(tmp_path / ("bad%d.battle.net" % layer))
+
+        def edit(i, b, W, layer=layer, bad=bad):
+            if i == layer:
+                if layer == 7:
+                    b = b.copy(); b[0] = bad
+                else:
+                    W = W.copy(); W[W.shape[0] // 2, W.shape[1] // 3] = bad
+            return b, W
+        _rewrite_net(src, dst, edit)
+        with pytest.raises(OakGpuError, match="non-finite parameter.*" + name.replace(".", r"\.")):
+            Network(gpu_ctx, path=dst)
+
+
 @pytest.mark.parametrize("dims", [
     dict(hidden=96, value_hidden=160),                                        # 3 and 5 output blocks: padded to the 4- and 8-wide kernels
     dict(hidden=32, value_hidden=32, pokemon_out=27, active_out=19),          # one block everywhere, embedding dim 312
