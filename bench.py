@@ -53,6 +53,8 @@ def main():
     ap.add_argument("--exchange", choices=["torch", "rccl"], default="torch",
                     help="config4: the all-gather of the per-root means through torch.distributed (RCCL underneath) or through "
                          "the library's own ncclAllGather call site (oakgpu_all_gather_dev)")
+    ap.add_argument("--root-groups", type=int, default=4,
+                    help="config4: independent groups a rank cuts its roots into (oak_amd.dist.RootGroups); 1 = one launch per step")
     ap.add_argument("--workload", choices=["all", "rollout", "leaf", "config3", "config4", "search"], default="all",
                     help="all (default) = the configs[1] headline line + `leaf` and `config3` sub-records; rollout = configs[1] "
                          "only; leaf = leaf-evals/s of the 768-256-256-256-1 net; config3 = configs[2]: one turn-step of the "
@@ -636,21 +638,22 @@ def leaf_records(args, torch, dev, rank, local_rank, world, dist, which=("leaf",
 
 def config4_workload(args, torch, dev, rank, local_rank, world, dist):
     """BASELINE configs[3]: root-parallel MCTS, 256 roots x 4096 playouts per search step, STRONG scaling: the roots are
-    sharded contiguous-by-root over the ranks (oak_amd.dist.root_shard), every rank rolls out its roots' playouts with root
-    prep (battle.rng from the lane's stream + randomize_hidden_variables, mcts.h:250-263), reduces them to one mean per root
-    on the device (oakgpu_segment_mean_dev) and ONE all-gather of those means (256 floats in total) gives every rank every
-    root's value.  A search step ends when the means are on the HOST (the tree update that consumes them is sequential), so
-    steps do not overlap: each pays its own tail."""
+    sharded contiguous-by-root over the ranks (oak_amd.dist.root_shard); every rank cuts ITS roots into independent GROUPS
+    (oak_amd.dist.RootGroups, `--root-groups`): a group's step = root prep (battle.rng from the lane's stream +
+    randomize_hidden_variables, mcts.h:250-263) + the playouts of its roots -> one mean per root on the device
+    (oakgpu_segment_mean_dev) -> ONE all-gather of the group's means -> means on the HOST.  The roots are independent trees
+    (the reference's workers never wait for each other, generate.cc:527-536), so a group's next step starts as soon as ITS
+    means have arrived, whatever the other groups are doing: one group's bulk fills the SIMDs another group's tail -- its
+    1,000-step playouts -- leaves idle.  Every root performs exactly K steps; per-root results do not depend on the grouping
+    (tests/test_gpu_parity.py::test_root_groups_pipeline_gives_the_unpipelined_per_root_results).
+    At N = 1 the record also carries `rank_share`: the SAME pipelined code over 32 roots (one rank's share at 8 GPUs), and the
+    8-GPU speed-up that projects -- a one-GPU measurement of a rank's work, NOT a hardware scaling curve."""
     import numpy as np
     from oak_amd import _lib
     from oak_amd import dist as oakdist
     from oak_amd.engine import Context
     n_roots, reps = 256, 4096
-    lo, hi = oakdist.root_shard(n_roots, rank, world)
-    mine = hi - lo
-    n = mine * reps
     ctx = Context(local_rank)
-    stream = torch.cuda.ExternalStream(ctx.stream_ptr(), device=dev)
     ctx.ensure_ou_pools()
     lib, h = ctx.lib, ctx.handle
     u8 = torch.uint8
@@ -661,25 +664,7 @@ def config4_workload(args, torch, dev, rank, local_rank, world, dist):
     rb, rd, rp, rr = (torch.empty(s_, dtype=u8, device=dev) for s_ in ((n_roots, 384), (n_roots, 8), (n_roots, 8), (n_roots,)))
     _lib.check(lib.oakgpu_random_ou_battles_dev(h, C.c_uint64(SEED0), n_roots, P(rb), P(rd), P(rp), P(rr)))
     ctx.synchronize()
-    battles = rb[lo:hi].repeat_interleave(reps, 0).contiguous()
-    durations = rd[lo:hi].repeat_interleave(reps, 0).contiguous()
-    rin = rr[lo:hi].repeat_interleave(reps, 0).contiguous()
-    # one fast_prng stream per replica, seeded by its GLOBAL lane index (results do not depend on the number of ranks)
-    prng = torch.empty((n, 8), dtype=u8, device=dev)
-    with torch.no_grad():
-        tb, tdur, tr = torch.empty((n, 384), dtype=u8, device=dev), torch.empty((n, 8), dtype=u8, device=dev), torch.empty((n,), dtype=u8, device=dev)
-        _lib.check(lib.oakgpu_random_ou_battles_dev(h, C.c_uint64(0xC40000000000 + lo * reps), n, P(tb), P(tdur), P(prng), P(tr)))
-        ctx.synchronize()
-        del tb, tdur, tr
-    results = torch.empty((n,), dtype=u8, device=dev)
-    steps_out = torch.zeros((n,), dtype=torch.int32, device=dev)
-    values = torch.empty((n,), dtype=torch.float32, device=dev)
-    per = -(-n_roots // world)                                     # padded shard size (ragged splits)
-    means = torch.zeros((per,), dtype=torch.float32, device=dev)
-    allm = torch.empty((world * per,), dtype=torch.float32, device=dev)
-    host = torch.empty((world * per,), dtype=torch.float32).pin_memory()
-    total = torch.zeros((), dtype=torch.int64, device=dev)
-    comm = None
+    comm = [None]
     if args.exchange == "rccl":      # the library's own ncclAllGather call site; the id travels through torch.distributed
         idt = torch.zeros(128, dtype=u8)
         if rank == 0:
@@ -691,73 +676,128 @@ def config4_workload(args, torch, dev, rank, local_rank, world, dist):
             dist.broadcast(idt, 0)
             idt = idt.cpu()
         idb = (C.c_uint8 * 128)(*idt.tolist())
-        comm = C.c_void_p()
-        _lib.check(lib.oakgpu_comm_create(h, idb, rank, world, C.byref(comm)))
+        comm[0] = C.c_void_p()
+        _lib.check(lib.oakgpu_comm_create(h, idb, rank, world, C.byref(comm[0])))
 
-    def step():
-        _lib.check(lib.oakgpu_rollout_dev(h, P(battles), P(durations), P(rin), P(prng), n, MAX_STEPS, 1, P(results), P(steps_out),
-                                          P(values), None, None))
-        _lib.check(lib.oakgpu_segment_mean_dev(h, P(values), mine, reps, P(means)))
-        with torch.cuda.stream(stream):
-            total.add_(steps_out.sum(dtype=torch.int64))
-            if comm is not None:
-                _lib.check(lib.oakgpu_all_gather_dev(h, comm, P(means), P(allm), per))
-            elif world > 1:
-                dist.all_gather_into_tensor(allm, means)
+    rccl = args.exchange == "rccl"    # the library's communicator lives on `ctx`'s stream: ONE group, on that context
+
+    def make_context():
+        if rccl:
+            return ctx
+        c = Context(local_rank)
+        c.ensure_ou_pools()
+        # several launches share the device: one lane per playout and no spreading over idle wave slots (measured,
+        # profiles/r04_config4_pipeline.json: 256 roots in 4 groups 12.5 ms per step against 14.2 ms as one queue launch)
+        c.set_playouts_per_lane(1)
+        _lib.check(c.lib.oakgpu_set_spread(c.handle, 0))
+        return c
+
+    def run(lo, hi, groups, K, W, w, r, exchange_on):
+        """K timed steps of roots [lo, hi) in `groups` groups as rank r of w; returns (seconds, my turn-steps, groups used, last means)."""
+        mine = hi - lo
+        n = mine * reps
+        battles = rb[lo:hi].repeat_interleave(reps, 0).contiguous()
+        durations = rd[lo:hi].repeat_interleave(reps, 0).contiguous()
+        rin = rr[lo:hi].repeat_interleave(reps, 0).contiguous()
+        # one fast_prng stream per replica, seeded by its GLOBAL lane index (results do not depend on the number of ranks or groups)
+        prng = torch.empty((n, 8), dtype=u8, device=dev)
+        tb, tdur, tr = torch.empty((n, 384), dtype=u8, device=dev), torch.empty((n, 8), dtype=u8, device=dev), torch.empty((n,), dtype=u8, device=dev)
+        _lib.check(lib.oakgpu_random_ou_battles_dev(h, C.c_uint64(0xC40000000000 + lo * reps), n, P(tb), P(tdur), P(prng), P(tr)))
+        ctx.synchronize()
+        del tb, tdur, tr
+        G = max(1, min(groups, (n_roots // w) if exchange_on else mine))
+        per = oakdist.group_padding(n_roots, w, G) if exchange_on else None
+
+        def exchange(means, out):     # on the group's stream
+            if rccl:
+                _lib.check(lib.oakgpu_all_gather_dev(h, comm[0], P(means), P(out), per))
             else:
-                allm.copy_(means)
-            host.copy_(allm, non_blocking=True)
-        ctx.synchronize()                                           # the host now holds all 256 means: the step is over
+                dist.all_gather_into_tensor(out, means)
+        ex = exchange if (exchange_on and (w > 1 or rccl)) else None
+        rg = oakdist.RootGroups(make_context, dev, battles, durations, rin, prng, mine, reps, G, world=(w if exchange_on else 1), exchange=ex, per=per,
+                                owns_contexts=not rccl)
+        ordered = exchange_on and w > 1
+        rg.run(max(W, 1), ordered=ordered)
+        rg.total.zero_()
+        torch.cuda.synchronize(dev)
+        if exchange_on and w > 1:
+            dist.barrier()
+        t0 = time.perf_counter()
+        rg.run(K, ordered=ordered, keep=True)
+        torch.cuda.synchronize(dev)
+        if exchange_on and w > 1:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        my_steps = int(rg.total.sum().item())
+        blocks = [g_["history"][-1] for g_ in rg.groups]
+        rg.close()
+        del battles, durations, rin, prng
+        return dt, my_steps, G, blocks
 
-    for _ in range(max(args.warmup, 1)):
-        step()
-    with torch.cuda.stream(stream):
-        total.zero_()
-    ctx.synchronize()
+    if rccl:
+        args.root_groups = 1
+    lo, hi = oakdist.root_shard(n_roots, rank, world)
     K = args.steps
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    for _ in range(K):
-        step()
-    torch.cuda.synchronize(dev)
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    my_steps = int(total.item())
+    elapsed, my_steps, G, blocks = run(lo, hi, args.root_groups, K, args.warmup, world, rank, True)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
         s_ = torch.tensor([my_steps], dtype=torch.int64, device=dev)
         dist.all_reduce(s_, op=dist.ReduceOp.SUM)
-        my_steps = int(s_.item())
-    got = np.concatenate([host.numpy()[r * per:r * per + (oakdist.root_shard(n_roots, r, world)[1] - oakdist.root_shard(n_roots, r, world)[0])]
-                          for r in range(world)])
-    assert got.shape == (n_roots,) and ((got >= 0) & (got <= 1)).all()
+        all_steps = int(s_.item())
+    else:
+        all_steps = my_steps
+    got = oakdist.assemble_group_means(n_roots, world, G, blocks)
+    assert got.shape == (n_roots,) and ((got >= 0) & (got <= 1)).all(), "the gathered per-root means are not the 256 roots' means"
     rec = None
     if rank == 0:
+        tj = profile_json()
+        per_step = tj.get("config4_hbm_bytes_per_turn_step")
         rec = {
-            "metric": "turn-steps/s (root-parallel MCTS step: 256 roots x 4096 playouts)", "value": my_steps / elapsed, "unit": "turn-steps/s",
+            "metric": "turn-steps/s (root-parallel MCTS step: 256 roots x 4096 playouts)", "value": all_steps / elapsed, "unit": "turn-steps/s",
             "n_gpus": world, "ranks_seen": (dist.get_world_size() if dist is not None else 1),
             "steps": K, "warmup": args.warmup, "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "u16", "data": "synthetic",
-            "config": {"workload": "configs[3]: root-parallel MCTS, 256 roots x 4096 playouts per search step, roots sharded contiguous-by-root, "
-                                   "per-root means reduced on the device, ONE all-gather of 256 floats per step, means on the host before the next step",
-                       "roots": n_roots, "playouts_per_root": reps, "roots_per_gpu": mine, "playouts_per_s": n_roots * reps * K / elapsed,
-                       "exchange": ("oakgpu_all_gather_dev (ncclAllGather)" if comm is not None else "torch.distributed all_gather_into_tensor" if world > 1 else "none (one rank)"),
+            "config": {"workload": "configs[3]: root-parallel MCTS, 256 roots x 4096 playouts per search step and root, roots sharded contiguous-by-root over "
+                                   "the ranks and cut into independent groups per rank (no barrier across roots: a group's next step starts when ITS "
+                                   "means are on the host); per-root means reduced on the device, ONE all-gather per group and step; every root performs "
+                                   "exactly `steps` steps", "roots": n_roots, "playouts_per_root": reps, "roots_per_gpu": hi - lo, "root_groups_per_gpu": G,
+                       "playouts_per_s": n_roots * reps * K / elapsed,
+                       "exchange": ("oakgpu_all_gather_dev (ncclAllGather)" if comm[0] is not None else "torch.distributed all_gather_into_tensor, one per group and step"
+                                    if world > 1 else "none (one rank)"),
                        "mean_root_value": float(got.mean())},
-            "roofline": {"bound": "hbm", "kernel": "oak::k_rollout_queue (one launch = one search step of this rank's roots, root prep included)",
-                         "achieved": my_steps / world * ALGO_BYTES_PER_STEP / elapsed / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": my_steps / world * ALGO_BYTES_PER_STEP / elapsed / 1e9 / HBM_PEAK_GBPS, "traffic": None,
+            "roofline": {"bound": "hbm", "kernel": "oak::k_rollout_regs (one launch = one search step of one group's roots, root prep included)" if G > 1 else
+                                                   "oak::k_rollout_queue (one launch = one search step of this rank's roots, root prep included)",
+                         "achieved": my_steps * ALGO_BYTES_PER_STEP / elapsed / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": my_steps * ALGO_BYTES_PER_STEP / elapsed / 1e9 / HBM_PEAK_GBPS,
+                         "traffic": (per_step * my_steps / K if per_step else None),
+                         "traffic_source": (PROFILE_SOURCE + ": config4_hbm_bytes_per_turn_step (2 x FETCH_SIZE + WRITE_SIZE of a profiled step) x this run's "
+                                            "turn-steps per step; not measured in this run") if per_step else None,
                          "algorithmic_bytes_per_turn_step": ALGO_BYTES_PER_STEP,
-                         "note": "whole-step clock (launch + segment mean + gather + host copy), per rank; notional like the headline's: the kernel is VALU-issue bound"},
+                         "note": "whole-job clock over all groups (launches + segment means + gathers + host copies), per rank; notional like the headline's: "
+                                 "the kernels are VALU-issue bound"},
+        }
+    if world == 1 and not rccl and not os.environ.get("BENCH_NO_RANK_SHARE"):
+        # one rank's share at 8 GPUs (32 roots x 4096), same pipelined code, on this one GPU: what bounds the strong-scaling curve
+        share = n_roots // 8
+        e8, s8, g8, _ = run(0, share, min(args.root_groups, 2), K, max(args.warmup, 2), 1, 0, False)
+        rec["rank_share"] = {
+            "what": "ONE rank's share of configs[3] at 8 GPUs (%d roots x %d playouts per step) through the same grouped code on this one GPU" % (share, reps),
+            "rank_share_ms": e8 / K * 1e3, "root_groups": g8, "turn_steps_per_s": s8 / e8,
+            "frac_of_full_job_rate": (s8 / e8) / (all_steps / elapsed),
+            "projected_8gpu_speedup": (elapsed / K) / (e8 / K),
+            "note": "projection from a one-GPU measurement, NOT a hardware curve: 8 ranks each take rank_share_ms per step (the all-gather of 256 floats "
+                    "is microseconds), so 8 GPUs would run the job full-job-ms / rank_share_ms times faster than one.  The share does not fill a GPU: "
+                    "its step cannot end before its longest playout, and 98% of the roots' 4096-playout batches hold a playout that runs to the "
+                    "1,000-step cap -- 1,000 DEPENDENT turn-steps at a lone lane's ~6.5 us each (DESIGN 6).  More roots per GPU, not more GPUs per "
+                    "root, is what fills a node (profiles/r04_config4_pipeline.json: turn-steps/s by roots in flight).",
         }
     torch.cuda.synchronize(dev)
-    if comm is not None:
-        lib.oakgpu_comm_destroy(comm)     # before the stream and buffers it used
-    del host, battles, durations, rin, prng, results, steps_out, values, means, allm, total, rb, rd, rp, rr, stream
+    if comm[0] is not None:
+        lib.oakgpu_comm_destroy(comm[0])     # before the stream and buffers it used (DESIGN 6)
+    del rb, rd, rp, rr
+    torch.cuda.empty_cache()
     ctx.close()
     return rec
 

@@ -76,3 +76,145 @@ def gather_root_means(local_means, n_roots):
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return local_means
     return gather_values(local_means, n_roots)
+
+
+def group_padding(n_roots, world, groups):
+    """Floats per rank in one group's all-gather: the largest group of the rank with the most roots."""
+    most = -(-n_roots // world)
+    return -(-most // max(1, min(groups, most)))
+
+
+def assemble_group_means(n_roots, world, groups, blocks):
+    """blocks[g] = one gathered block [world * per] of group g (RootGroups history entry) -> the n_roots means in global root
+    order: rank r's roots are root_shard(n_roots, r, world), its group g the g-th contiguous part of them."""
+    import numpy as np
+    out = np.full(n_roots, np.nan, dtype=np.float32)
+    per = len(blocks[0]) // world
+    for r in range(world):
+        lo, hi = root_shard(n_roots, r, world)
+        G = max(1, min(groups, hi - lo)) if hi > lo else 1
+        for g in range(G):
+            a, b = shard_range(hi - lo, g, G)
+            out[lo + a:lo + b] = blocks[g][r * per:r * per + (b - a)]
+    return out
+
+
+class RootGroups:
+    """BASELINE configs[3] without a barrier across roots.  The roots of root-parallel MCTS are independent trees (the
+    reference's workers never wait for each other, cpp/src/generate.cc:527-536): nothing requires every root to finish search
+    step k before any root starts step k + 1.  This rank's roots are cut into `groups` contiguous GROUPS, each with its own
+    context (HIP stream); a group's step = root prep + playouts of its roots (mcts.h:250-263, 448-496) -> one mean per root on
+    the device -> the group's exchange (one all-gather of its means) -> means on the host -> event; the group's NEXT step is
+    launched as soon as that event has completed, whatever the other groups are doing, so one group's bulk fills the SIMDs that
+    another group's tail (its longest playouts) leaves idle.  Per-root results do not depend on the grouping: a playout's
+    streams are its own (seeded by global lane index) and a root's mean is reduced in a fixed order.
+
+    battles / durations / results_in / prng: device tensors over ALL this rank's lanes (roots x reps, root-major); a group
+    works on its contiguous slice in place (prng advances from step to step).  exchange(means, out) -- nullable -- gathers a
+    group's padded means [per] into out [world * per] on the current stream; ordered=True launches in a fixed (step, group)
+    order so that every rank issues its collectives in the same order (required whenever exchange is a collective)."""
+
+    def __init__(self, make_context, device, battles, durations, results_in, prng, roots, reps, groups, world=1, exchange=None,
+                 max_steps=1000, per=None, owns_contexts=True):
+        import ctypes as C
+        self.C, self.torch, self.dev = C, torch, device
+        self.reps, self.world, self.exchange, self.max_steps, self.owns = reps, world, exchange, max_steps, owns_contexts
+        G = max(1, min(int(groups), roots)) if roots else 1
+        self.bounds = [shard_range(roots, g, G) for g in range(G)]
+        # padded group size: the same on every rank when the exchange is a collective (group_padding), else this rank's largest group
+        self.per = int(per) if per else max((hi - lo for lo, hi in self.bounds), default=0)
+        n = roots * reps
+        self.results = torch.empty((n,), dtype=torch.uint8, device=device)
+        self.steps_out = torch.zeros((n,), dtype=torch.int32, device=device)
+        self.values = torch.empty((n,), dtype=torch.float32, device=device)
+        self.total = torch.zeros((G,), dtype=torch.int64, device=device)
+        self.groups = []
+        for g, (lo, hi) in enumerate(self.bounds):
+            ctx = make_context()
+            st = torch.cuda.ExternalStream(ctx.stream_ptr(), device=device)
+            a, b = lo * reps, hi * reps
+            self.groups.append(dict(
+                ctx=ctx, stream=st, lo=lo, hi=hi, n=b - a, battles=battles[a:b], durations=durations[a:b], rin=results_in[a:b],
+                prng=prng[a:b], results=self.results[a:b], steps=self.steps_out[a:b], values=self.values[a:b],
+                means=torch.zeros((max(self.per, 1),), dtype=torch.float32, device=device),
+                allm=torch.empty((world * max(self.per, 1),), dtype=torch.float32, device=device),
+                host=torch.empty((world * max(self.per, 1),), dtype=torch.float32).pin_memory(),
+                event=torch.cuda.Event(), done=0, inflight=False, history=[]))
+
+    def _p(self, t):
+        return self.C.c_void_p(t.data_ptr())
+
+    def launch(self, g):
+        from . import _lib
+        G, P = self.groups[g], self._p
+        lib, h = G["ctx"].lib, G["ctx"].handle
+        if G["n"]:
+            _lib.check(lib.oakgpu_rollout_dev(h, P(G["battles"]), P(G["durations"]), P(G["rin"]), P(G["prng"]), G["n"], self.max_steps, 1,
+                                              P(G["results"]), P(G["steps"]), P(G["values"]), None, None))
+            _lib.check(lib.oakgpu_segment_mean_dev(h, P(G["values"]), G["hi"] - G["lo"], self.reps, P(G["means"])))
+        with self.torch.cuda.stream(G["stream"]):
+            if G["n"]:
+                self.total[g] += G["steps"].sum(dtype=self.torch.int64)
+            if self.exchange is not None:
+                self.exchange(G["means"], G["allm"])
+            else:
+                G["allm"].copy_(G["means"])
+            G["host"].copy_(G["allm"], non_blocking=True)
+            G["event"].record(G["stream"])
+        G["inflight"] = True
+
+    def _finish(self, g, keep):
+        G = self.groups[g]
+        G["event"].synchronize()                       # the host now holds this group's means of every rank: its step is over
+        if keep:
+            G["history"].append(G["host"].numpy().copy())
+        G["done"] += 1
+        G["inflight"] = False
+
+    def run(self, steps, ordered=False, keep=False):
+        """Every group performs `steps` search steps.  ordered: fixed (step, group) launch order (collectives match across
+        ranks); else work-conserving: whichever group's means have arrived is relaunched first."""
+        for G in self.groups:
+            G["done"], G["inflight"], G["history"] = 0, False, []
+        if ordered:
+            for k in range(steps):
+                for g in range(len(self.groups)):
+                    if self.groups[g]["inflight"]:
+                        self._finish(g, keep)
+                    self.launch(g)
+            for g in range(len(self.groups)):
+                if self.groups[g]["inflight"]:
+                    self._finish(g, keep)
+            return
+        launched = [0] * len(self.groups)
+        for g in range(len(self.groups)):
+            if steps > 0:
+                self.launch(g)
+                launched[g] = 1
+        while any(G["inflight"] for G in self.groups):
+            progressed = False
+            for g, G in enumerate(self.groups):
+                if G["inflight"] and G["event"].query():
+                    self._finish(g, keep)
+                    if launched[g] < steps:
+                        self.launch(g)
+                        launched[g] += 1
+                    progressed = True
+            if not progressed:          # nothing ready: block on the group that was launched first among those in flight
+                g = min((g for g, G in enumerate(self.groups) if G["inflight"]), key=lambda q: self.groups[q]["done"])
+                self._finish(g, keep)
+                if launched[g] < steps:
+                    self.launch(g)
+                    launched[g] += 1
+
+    def close(self):
+        # the groups' streams belong to their contexts: torch must hold nothing that refers to them when they are destroyed (its
+        # caching allocator keeps blocks freed on a stream tied to that stream)
+        self.torch.cuda.synchronize(self.dev)
+        ctxs = [G["ctx"] for G in self.groups]
+        self.groups = []
+        self.results = self.steps_out = self.values = self.total = None
+        self.torch.cuda.empty_cache()
+        if self.owns:
+            for c in ctxs:
+                c.close()

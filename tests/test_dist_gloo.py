@@ -164,3 +164,50 @@ def test_config4_root_sharding_and_mean_gather():
         p.join(timeout=180)
         assert p.exitcode == 0
     assert got.shape == (n_roots,) and (got == _config4_means(n_roots, reps, 0, n_roots)).all()
+
+
+def _config4_groups_worker(rank, world, port, n_roots, reps, groups, q):
+    """configs[3] as independent root GROUPS (oak_amd.dist.RootGroups' exchange): every rank cuts its roots into `groups`
+    contiguous groups; a group's step ends with ONE all-gather of its means, padded to group_padding() floats per rank; the
+    collectives are issued in a fixed (step, group) order on every rank."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oak_amd import dist as D
+    lo, hi = D.root_shard(n_roots, rank, world)
+    per = D.group_padding(n_roots, world, groups)
+    means = _config4_means(n_roots, reps, lo, hi)
+    G = max(1, min(groups, hi - lo))
+    blocks = []
+    for g in range(groups):                      # (every rank issues `groups` collectives, also one whose group g is empty here)
+        a, b = D.shard_range(hi - lo, g, G) if g < G else (0, 0)
+        padded = torch.zeros(per, dtype=torch.float32)
+        padded[:b - a] = torch.from_numpy(means[a:b])
+        out = torch.empty(world * per, dtype=torch.float32)
+        dist.all_gather_into_tensor(out, padded)
+        blocks.append(out.numpy().copy())
+    if rank == 0:
+        q.put(D.assemble_group_means(n_roots, world, groups, blocks))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_config4_root_groups_exchange_reassembles_the_global_root_order():
+    """The grouped form of configs[3]: 13 roots ragged over 2 ranks (7 + 6), 3 groups per rank (3 + 2 + 2 and
+    2 + 2 + 2 roots), one padded all-gather per group: the assembled means equal the single-process means in global root order."""
+    n_roots, reps, world, groups = 13, 6, 2, 3
+    from oak_amd import dist as D
+    assert D.group_padding(n_roots, world, groups) == 3 and D.group_padding(256, 8, 4) == 8 and D.group_padding(256, 1, 4) == 64
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_config4_groups_worker, args=(r, world, port, n_roots, reps, groups, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=180)
+    for p in procs:
+        p.join(timeout=180)
+        assert p.exitcode == 0
+    assert got.shape == (n_roots,) and (got == _config4_means(n_roots, reps, 0, n_roots)).all()

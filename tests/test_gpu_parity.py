@@ -603,3 +603,17 @@ def test_group_launch_limits(gpu_ctx):
     descs[0] = _lib.RolloutBatch(None, None, None, None, 5, None, None, None, None, None)
     assert gpu_ctx.lib.oakgpu_rollout_group_dev(gpu_ctx.handle, descs, 1, 10, 0) != 0
     assert b"null required pointer" in gpu_ctx.lib.oakgpu_last_error()
+
+
+def test_root_groups_pipeline_gives_the_unpipelined_per_root_results():
+    """configs[3] as independent root groups (oak_amd.dist.RootGroups): 12 roots x 256 playouts with root prep,
+    two search steps, cut into 1 / 3 / 5 (ragged) groups on their own contexts, launched in fixed order and work-conserving:
+    every playout's result, step count and choice-RNG state after both steps, and every root's mean of either step, equal the
+    oracle's (= the unpipelined step's) -- scheduling never shows in the results.  Runs tests/root_groups_check.py in a child
+    process: RootGroups keeps its buffers in torch tensors, and torch must initialise the GPU before the library does."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tests", "root_groups_check.py")], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "root groups ok" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
