@@ -49,6 +49,23 @@ struct NetDev {
   int PH; // padded policy hidden width
 };
 
+// bias + activation of 16 accumulator registers (or activation alone), the activation chosen by a wave-uniform branch: computed per
+// value as `activation == 1 ? relu : clamp` it costs max + min + select for each of them
+typedef __attribute__((ext_vector_type(16))) float act_f32x16;
+template <int NB_>
+__device__ __forceinline__ void act_blocks(act_f32x16 (&v)[NB_], int activation) {
+  if (activation == 1) {
+#pragma unroll
+    for (int b = 0; b < NB_; ++b)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) v[b][q] = fmaxf(v[b][q], 0.0f);
+  } else {
+#pragma unroll
+    for (int b = 0; b < NB_; ++b)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) v[b][q] = fminf(fmaxf(v[b][q], 0.0f), 1.0f);
+  }
+}
 __device__ __forceinline__ float act_fn(float x, int activation) {
   x = fmaxf(x, 0.0f);
   return activation == 2 ? fminf(x, 1.0f) : x;
@@ -491,7 +508,118 @@ __global__ __launch_bounds__(EL_BLOCK) void k_embed_lds(EmbedTileArgs a) {
   EL_FLUSH();
 }
 
-constexpr int ER_ITEMS = 32, ER_RS = 132; // items per wave mini-tile; padded LDS weight row (floats) of k_embed_arows / k_embed_prows
+constexpr int ER_ITEMS = 32, ER_RS = 128; // items per wave mini-tile; LDS weight row (floats) of k_embed_arows / k_embed_prows (a half-wave
+                                          // reads a whole row per instruction: contiguous, conflict-free at any stride -- no padding)
+
+// ---- the embedding nets' SECOND layers on the bf16 matrix pipe (round 4) ----
+// Rounds 2-3 ran them on v_mfma_f32_32x32x2_f32: 128 (party) / 192 (actives) MFMAs of 64 cycles per 32-item mini-tile, 8.2 k of a
+// party mini-tile's 13.1 k matrix-pipe cycles.  The bf16 pipe is 16x faster per FLOP, and an fp32 value is the exact sum of three
+// bf16 parts (h, m, l), so, as in k_mainnet_split:
+//   second layer : the 128 hidden activations of an item as triples against W1's triples (LDS, prebuilt), the six largest partial
+//                  products per 32x32x16 block, fp32 accumulation: 8 k-steps x 6 x NBo MFMAs of 32 cycles (party 96: 3.1 k cycles
+//                  against 8.2 k) -- fp32 results (dropped terms < 2^-24 of a product);
+//   transposition: ALSO tried on the bf16 pipe (the one-hot selector is exact in bf16: three MFMAs move the (h, m, l) parts of four
+//                  k-steps' row sums into the item lanes at once, 48 MFMAs of 32 cycles instead of 64 of 64) and dropped: with the
+//                  second layer off the fp32 pipe the kernels are bound by the instructions a wave issues, and splitting the row
+//                  sums costs ~1,000 more of them per mini-tile (first layer 12.2 k cycles per mini-tile against 9.8 k).
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+constexpr int E2_BLOCK_BYTES = 8 * 3 * 1024; // W1's triples of one 32-wide output block: [k-step T][h m l][lane] x 16 B
+// v[0..7] as their bf16 triples, by TRUNCATION: h = the top 16 bits of x (its 8 leading significant bits), m = the top 16 bits of
+// x - h (the next 8), l = x - h - m (the last 8: it has no more, so its low 16 bits are zero) -- x = h + m + l EXACTLY, every
+// subtraction exact, four vector instructions per value (and, sub, and, sub) and one v_perm per pair and part to pack; the
+// round-to-nearest split of k_mainnet_split costs 7.5 (these kernels are bound by the instructions a wave issues).
+__device__ __forceinline__ void e_split(const float (&v)[8], bf16x8 (&P)[3]) {
+  uint32_t hb[8], mb[8], lb[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    hb[i] = __float_as_uint(v[i]) & 0xFFFF0000u;
+    const float r1 = v[i] - __uint_as_float(hb[i]);
+    mb[i] = __float_as_uint(r1) & 0xFFFF0000u;
+    lb[i] = __float_as_uint(r1 - __uint_as_float(mb[i]));
+  }
+  typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+  u32x4 ph, pm, pl;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { // element 2i in the low half, 2i + 1 in the high half: bytes {a.2, a.3, b.2, b.3}
+    ph[i] = __builtin_amdgcn_perm(hb[2 * i + 1], hb[2 * i], 0x07060302u);
+    pm[i] = __builtin_amdgcn_perm(mb[2 * i + 1], mb[2 * i], 0x07060302u);
+    pl[i] = __builtin_amdgcn_perm(lb[2 * i + 1], lb[2 * i], 0x07060302u);
+  }
+  P[0] = __builtin_bit_cast(bf16x8, ph); P[1] = __builtin_bit_cast(bf16x8, pm); P[2] = __builtin_bit_cast(bf16x8, pl);
+}
+// Second layer: hb = the item's 128 activated hidden channels (lane (item r, hh): register s of block b = channel ar_channel),
+// w1t = this lane's 16 bytes of W1's triple image in LDS.  Orientation Out^T = W1 . H^T: the weights are the A operand (lane
+// (o, h) element j = W1[32 nb + o][ar_channel(8 T + j, h)], prebuilt on the host: embed_triple_order), the activations the B
+// operand (lane (item r, h) element j = that channel = its own registers 8 T .. 8 T + 7) -- so acc[nb] holds, on lane (item r,
+// h), the item's outputs 32 nb + 8 (q >> 2) + 4 h + (q & 3): every lane scatters ITS OWN item, four consecutive outputs per
+// 16-byte store (embed_scatter), with the destination offset in a register.  (Rounds 2-3 had the outputs on the lanes and the
+// items in the registers: 16 four-byte stores per block, each behind an LDS read of the item's offset, a branch and -- stores
+// count in vmcnt -- the completion of the store before it: 11.8 k of a party mini-tile's 35 k cycles.)
+template <int NBMAX>
+__device__ __forceinline__ void embed_layer2(const f32x16 (&hb)[4], const uint8_t *w1t, int NBo, f32x16 (&acc)[NBMAX]) {
+#pragma unroll
+  for (int nb = 0; nb < NBMAX; ++nb)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[nb][q] = 0.0f;
+#pragma unroll
+  for (int T = 0; T < 8; ++T) {
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = hb[T >> 1][8 * (T & 1) + j];
+    bf16x8 A[3];
+    e_split(v, A);
+#pragma unroll
+    for (int nb = 0; nb < NBMAX; ++nb)
+      if (nb < NBo) { // wave-uniform
+        const uint8_t *p = w1t + nb * E2_BLOCK_BYTES + T * 3072;
+        const bf16x8 W0 = *(const bf16x8 *)p, W1 = *(const bf16x8 *)(p + 1024), W2 = *(const bf16x8 *)(p + 2048);
+        acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W0, A[2], acc[nb], 0, 0, 0); // l . h   (small terms first)
+        acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W2, A[0], acc[nb], 0, 0, 0); // h . l
+        acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W1, A[1], acc[nb], 0, 0, 0); // m . m
+        acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W0, A[1], acc[nb], 0, 0, 0); // m . h
+        acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W1, A[0], acc[nb], 0, 0, 0); // h . m
+        acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W0, A[0], acc[nb], 0, 0, 0); // h . h
+      }
+  }
+}
+// The item's outputs to its block of the battle embedding: bias + activation, four consecutive outputs per store (the block
+// starts one float behind a 16-byte boundary -- the hp ratio comes first -- so the stores are 4-byte aligned dwordx4's), all
+// stores of a lane back to back.  doff = the item's block (0xFFFFFFFF: no live item on this lane); bias padded to 32 NBo floats.
+struct __attribute__((packed, aligned(4))) f4u { float x, y, z, w; };
+template <int NBMAX>
+__device__ __forceinline__ void embed_scatter(float *emb, uint32_t doff, float hpr, uint32_t hh, const f32x16 (&acc)[NBMAX], int NBo, int out_dim,
+                                              const float *bias, int activation) {
+  float4 b[NBMAX][4];
+#pragma unroll
+  for (int nb = 0; nb < NBMAX; ++nb)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) b[nb][g] = nb < NBo ? *(const float4 *)(bias + 32 * nb + 8 * g + 4 * hh) : make_float4(0.f, 0.f, 0.f, 0.f);
+  f32x16 o[NBMAX];
+#pragma unroll
+  for (int nb = 0; nb < NBMAX; ++nb)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      o[nb][4 * g + 0] = acc[nb][4 * g + 0] + b[nb][g].x; o[nb][4 * g + 1] = acc[nb][4 * g + 1] + b[nb][g].y;
+      o[nb][4 * g + 2] = acc[nb][4 * g + 2] + b[nb][g].z; o[nb][4 * g + 3] = acc[nb][4 * g + 3] + b[nb][g].w;
+    }
+  act_blocks<NBMAX>(o, activation);
+  if (doff != 0xFFFFFFFFu) {
+    float *dst = emb + (size_t)doff + 1;
+#pragma unroll
+    for (int nb = 0; nb < NBMAX; ++nb)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int o0 = 32 * nb + 8 * g + 4 * (int)hh;
+        if (nb < NBo && o0 < out_dim) {
+          f4u v;
+          v.x = o[nb][4 * g + 0]; v.y = o[nb][4 * g + 1]; v.z = o[nb][4 * g + 2]; v.w = o[nb][4 * g + 3];
+          if (o0 + 3 < out_dim) *(f4u *)(dst + o0) = v;
+          else { dst[o0] = v.x; if (o0 + 1 < out_dim) dst[o0 + 1] = v.y; if (o0 + 2 < out_dim) dst[o0 + 2] = v.z; }
+        }
+      }
+    if (hh == 0) emb[doff] = hpr;
+  }
+}
 
 // Copy a prebuilt image of the kernel's LDS weights (built once at load time in exactly the LDS layout) with every load of
 // a thread in flight at once.  The obvious `lds[i] = cond ? global[f(i)] : 0` loop compiles to load -> wait -> store per
@@ -550,11 +678,17 @@ __device__ __forceinline__ void zero_blocks(float *emb, uint32_t dead_off, int l
 // per wave (row indices) = <= 141 KB, staged from one prebuilt image (stage_image_load / _store).
 constexpr int AR_SPARSE = 64, AR_ZERO = 64;   // LDS-resident one-hot rows (ar_sparse_slot) + a zero row
 constexpr int AR_FIXED = 36, AR_HOT = 9, AR_MOVES = 8, AR_KSTEPS = AR_FIXED / 2;
-constexpr int AR_ITEM_WORDS = 5 + 4;            // 9 u16 LDS offsets (5 words), 8 u16 global rows (4 words)
-constexpr int AR_WAVE_WORDS = ER_ITEMS * AR_ITEM_WORDS + 2 * ER_ITEMS;
-constexpr int AR_BLOCK = 1024, AR_WAVES = 16; // 16 waves = 4 per SIMD at <= 128 registers: the phases of different waves overlap
+constexpr int AR_ITEM_WORDS = 20;               // ready to use: 9 LDS byte offsets of the item's one-hot rows, 8 byte offsets of its move rows in L2 (+ 3 pad)
+constexpr int AR_WAVE_WORDS = ER_ITEMS * AR_ITEM_WORDS;
+#ifndef OAK_EMBED_WAVES
+#define OAK_EMBED_WAVES 8
+#endif
+// 8 waves of <= 256 registers (2 per SIMD): no scratch.  Measured, round 4, with the second layer on the bf16 pipe: 16 waves of
+// 128 registers spill 150-400 of them (party pass 633 us), 12 of 168 spill 60-130 (246 us), 8 of 256 none (140 us).
+constexpr int AR_WAVES = OAK_EMBED_WAVES, AR_BLOCK = 64 * AR_WAVES;
 constexpr int AR_DENSE_WORDS = AR_KSTEPS * 4 * 64; // the dense weight fragment: [k-step][channel block][lane]
-constexpr size_t ar_bytes(int nbo) { return (size_t)((AR_SPARSE + 1) * ER_RS + AR_DENSE_WORDS + nbo * 64 * 64 + AR_WAVES * AR_WAVE_WORDS) * 4; }
+constexpr int AR_MAX_NBO = 3; // W1 as bf16 triples: 24 KB per 32-wide output block; four blocks (outputs above 96) do not fit beside the rest
+constexpr size_t ar_bytes(int nbo) { return (size_t)((AR_SPARSE + 1) * ER_RS + AR_DENSE_WORDS + AR_WAVES * AR_WAVE_WORDS + 32 * nbo) * 4 + (size_t)nbo * E2_BLOCK_BYTES; }
 // channel held by register s (0..63) of a lane in half hh: the C layout of four 32x32 MFMA blocks, block b's row i being
 // channel 4 i + b (so that a lane's float4 of a weight row feeds the four blocks)
 __host__ __device__ constexpr int ar_channel(int s, int hh) { return 4 * ((s & 3) + 8 * ((s & 15) >> 2) + 4 * hh) + (s >> 4); }
@@ -563,33 +697,62 @@ __host__ __device__ constexpr int ar_dense_row(int d) { return d < 6 ? d - 1 : d
 // compact LDS slot of a one-hot row (types 5..19, rows 209..228, rows 398..426) and back
 __device__ __forceinline__ uint32_t ar_sparse_slot(uint32_t row) { return row < 20 ? row - 5 : row < 229 ? row - 209 + 15 : row - 398 + 35; }
 __host__ __device__ constexpr int ar_sparse_row(int slot) { return slot < 15 ? slot + 5 : slot < 35 ? slot - 15 + 209 : slot - 35 + 398; }
-template <int WAVES = AR_WAVES>
+// bias (padded to 32 NBo floats) behind W1's triples in both images: embed_scatter reads it from LDS
+constexpr int ar_img_words(int nbo) { return (AR_SPARSE + 1) * ER_RS + AR_DENSE_WORDS + nbo * (E2_BLOCK_BYTES / 4) + 32 * nbo; }
+template <int WAVES, int NBO>
 __device__ __forceinline__ void embed_arows_body(const EmbedTileArgs &a, float *lds_f, const uint32_t bid, const uint32_t nblocks) {
-  constexpr int BLOCK = WAVES * 64, MAXR = 8 * AR_WAVES / WAVES;
+  constexpr int BLOCK = WAVES * 64, MAXR = (ar_img_words(NBO) / 4 + BLOCK - 1) / BLOCK;
   EL_T0();
   const NetDev &N = a.net;
-  const int hidden = N.a_hidden, out_dim = N.a_out;
-  const int NBo = (out_dim + 31) >> 5;
+  const int out_dim = N.a_out;
   float *W0s = lds_f;                                   // sparse rows, channels in natural order, + a zero row
   float *Wd = W0s + (AR_SPARSE + 1) * ER_RS;            // dense fragment: [k-step][channel block][lane]
-  float *W1s = Wd + AR_DENSE_WORDS;                     // the second layer's fragments: [block][k-step][lane]
-  const int img_words = (AR_SPARSE + 1) * ER_RS + AR_DENSE_WORDS + NBo * 64 * 64;
+  const uint8_t *W1t = (const uint8_t *)(Wd + AR_DENSE_WORDS); // the second layer's bf16 triples: [block][k-step][h m l][lane] x 16 B
+  const float *b1s = (const float *)(W1t + NBO * E2_BLOCK_BYTES);
+  constexpr int img_words = ar_img_words(NBO);
   float4 img_t[MAXR];
   stage_image_load<BLOCK, MAXR>(img_t, N.a_img, img_words);
   const uint32_t lane = threadIdx.x & 63, wib = threadIdx.x >> 6, r32 = lane & 31, hh = lane >> 5;
-  uint32_t *wl = (uint32_t *)(W1s + NBo * 64 * 64) + wib * AR_WAVE_WORDS; // this wave's private LDS
-  uint32_t *dst_off = wl + ER_ITEMS * AR_ITEM_WORDS;
-  float *hp_ratio = (float *)(dst_off + ER_ITEMS);
+  uint32_t *wl = (uint32_t *)(lds_f + img_words) + wib * AR_WAVE_WORDS; // this wave's private LDS (the items' row indices)
   const uint32_t items = a.n * 2;
   const uint32_t nmt = (items + ER_ITEMS - 1) / ER_ITEMS;
   const uint32_t stride = nblocks * WAVES;
   EL_MARK(0);
-  // ---- encode: BOTH lanes (r, 0) and (r, 1) encode item r straight from global memory (two dependent loads: order ->
-  // stored Pokemon) -- the same instructions for the whole wave; each keeps the dense values of its own k-half in
-  // registers (x[t] = value 2t + hh, the B operand below) and lane (r, 0) writes the row indices to the wave's LDS.  The
-  // wave's first encode runs BEFORE the weights are written to LDS (it needs none): the image's round trip hides under it ----
+  // ---- encode, in three parts.  LOAD 1 (at the top of the previous mini-tile's body): both lanes (r, 0) and (r, 1) ask for item
+  // r's active block, the slot of its stored Pokemon and the durations word; LOAD 2 (behind that body's first layer, when LOAD
+  // 1 has long arrived): the stored Pokemon; nothing waits for either.  COMPUTE (behind its second layer): the same
+  // instructions for the whole wave; each lane keeps the dense values of its own k-half in registers (x[t] = value 2t + hh,
+  // the B operand below) and lane (r, 0) writes the row indices to the wave's LDS.  The wave's first encode runs BEFORE the
+  // weights are written to LDS (it needs none): the image's round trip hides under it ----
   float x[AR_KSTEPS];
-  auto encode = [&](uint32_t mt)
+  uint32_t my_doff = 0xFFFFFFFFu; // this lane's item: its block of the embedding (both lanes (r, 0), (r, 1) hold item r's) and hp ratio
+  float my_hpr = 0.0f;
+  uint4 in_av0 = make_uint4(0, 0, 0, 0), in_av1 = in_av0;
+  uint32_t in_id = 0, in_dur = 0, in_pk[6] = {0, 0, 0, 0, 0, 0};
+  auto encode_load1 = [&](uint32_t mt)
+  {
+    const uint32_t g = mt * ER_ITEMS + r32;
+    if (g < items) {
+      const uint32_t leaf = g >> 1, side = g & 1;
+      const uint32_t *sb = (const uint32_t *)a.battles + (size_t)leaf * 96 + side * 46;
+      in_av0 = *(const uint4 *)(sb + 36); in_av1 = *(const uint4 *)(sb + 40);
+      in_id = sb[44] & 0xFF;
+      in_dur = ((const uint32_t *)a.durations)[(size_t)leaf * 2 + side];
+    }
+  };
+  auto encode_load2 = [&](uint32_t mt)
+  {
+    const uint32_t g = mt * ER_ITEMS + r32;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) in_pk[k] = 0;
+    if (g < items && in_id != 0) {
+      const uint32_t leaf = g >> 1, side = g & 1;
+      const uint32_t *pk = (const uint32_t *)a.battles + (size_t)leaf * 96 + side * 46 + 6 * (in_id - 1);
+      const uint2 p01 = *(const uint2 *)pk, p23 = *(const uint2 *)(pk + 2), p45 = *(const uint2 *)(pk + 4);
+      in_pk[0] = p01.x; in_pk[1] = p01.y; in_pk[2] = p23.x; in_pk[3] = p23.y; in_pk[4] = p45.x; in_pk[5] = p45.y;
+    }
+  };
+  auto encode_compute = [&](uint32_t mt)
   {
     const uint32_t g = mt * ER_ITEMS + r32;
     float fv[AR_FIXED];
@@ -604,17 +767,11 @@ __device__ __forceinline__ void embed_arows_body(const EmbedTileArgs &a, float *
     for (int k = 0; k < AR_MOVES; ++k) mv[k] = 427;
     if (g < items) {
       const uint32_t leaf = g >> 1, side = g & 1;
-      const uint32_t *sb = (const uint32_t *)a.battles + (size_t)leaf * 96 + side * 46;
-      const uint32_t dur = ((const uint32_t *)a.durations)[(size_t)leaf * 2 + side];
-      const uint4 av0 = *(const uint4 *)(sb + 36), av1 = *(const uint4 *)(sb + 40);
-      const uint32_t id = sb[44] & 0xFF;
+      const uint4 av0 = in_av0, av1 = in_av1;
+      const uint32_t dur = in_dur, id = in_id;
       const uint32_t dd = leaf * N.emb_dim + side * N.side_dim;
-      uint32_t pk0 = 0, pk1 = 0, pk2 = 0, pk3 = 0, pk4 = 0, pk5 = 0, hp = 0;
-      if (id != 0) {
-        const uint32_t *pk = sb + 6 * (id - 1);
-        pk0 = pk[0]; pk1 = pk[1]; pk2 = pk[2]; pk3 = pk[3]; pk4 = pk[4]; pk5 = pk[5];
-        hp = pk4 >> 16;
-      }
+      const uint32_t pk0 = in_pk[0], pk1 = in_pk[1], pk2 = in_pk[2], pk3 = in_pk[3], pk4 = in_pk[4], pk5 = in_pk[5];
+      const uint32_t hp = id != 0 ? pk4 >> 16 : 0u;
       if (hp == 0) dead_off = dd; // no active / fainted active: zero block (network.h:142-143)
       else {
         doff = dd;
@@ -644,23 +801,28 @@ __device__ __forceinline__ void embed_arows_body(const EmbedTileArgs &a, float *
     }
 #pragma unroll
     for (int t = 0; t < AR_KSTEPS; ++t) x[t] = hh ? fv[2 * t + 1] : fv[2 * t];
-    if (hh == 0) {
+    if (hh == 0) { // (byte offsets: the readers add their own 16 bytes of the row and nothing else)
       uint32_t *it = wl + r32 * AR_ITEM_WORDS;
-      it[0] = hot[0] | hot[1] << 16; it[1] = hot[2] | hot[3] << 16; it[2] = hot[4] | hot[5] << 16; it[3] = hot[6] | hot[7] << 16; it[4] = hot[8];
-      it[5] = mv[0] | mv[1] << 16; it[6] = mv[2] | mv[3] << 16; it[7] = mv[4] | mv[5] << 16; it[8] = mv[6] | mv[7] << 16;
-      dst_off[r32] = doff;
-      hp_ratio[r32] = hpr;
+      *(uint4 *)it = make_uint4(hot[0] * 16, hot[1] * 16, hot[2] * 16, hot[3] * 16);
+      *(uint4 *)(it + 4) = make_uint4(hot[4] * 16, hot[5] * 16, hot[6] * 16, hot[7] * 16);
+      *(uint4 *)(it + 8) = make_uint4(hot[8] * 16, mv[0] * 512, mv[1] * 512, mv[2] * 512);
+      *(uint4 *)(it + 12) = make_uint4(mv[3] * 512, mv[4] * 512, mv[5] * 512, mv[6] * 512);
+      it[16] = mv[7] * 512;
     }
+    my_doff = doff;
+    my_hpr = hpr;
     zero_blocks(a.emb, hh == 0 ? dead_off : 0xFFFFFFFFu, out_dim + 1);
   };
   uint32_t mt = bid * WAVES + wib;
-  if (mt < nmt) encode(mt); // needs no weights: the image's round trip runs under it
+  if (mt < nmt) { encode_load1(mt); encode_load2(mt); encode_compute(mt); } // needs no weights: the image's round trip runs under it
   stage_image_store<BLOCK, MAXR>(lds_f, img_t, img_words);
   __syncthreads(); // weights staged (the only workgroup barrier of the kernel)
   while (mt < nmt) {
     __builtin_amdgcn_wave_barrier();
     EL_MARK(3);
     __builtin_amdgcn_s_setprio(2); // a wave in its MFMA phases goes before waves that encode or scatter (see the second layer)
+    const uint32_t next = mt + stride;
+    if (next < nmt) encode_load1(next);
     // ---- first layer, dense part on the matrix pipe: hb[blk] = this lane's 16 channels of block blk of item r32 ----
     f32x16 hb[4];
 #pragma unroll
@@ -675,145 +837,153 @@ __device__ __forceinline__ void embed_arows_body(const EmbedTileArgs &a, float *
     // ---- the one-hot and move rows.  Read "lane = item" they cost a 16-byte piece of 64 different cache lines per load
     // instruction (8,192 line requests per mini-tile: the L1 was the bottleneck of the whole kernel).  So they are read
     // "lane = channels": in k-step t the half-wave hh sums the 17 rows of item 2t + hh, lane (i, hh) taking channels
-    // 4i .. 4i+3 (one float4: a half-wave reads a whole 512-byte row per instruction), and an MFMA against the identity
-    // (B[k][j] = [k == j]) transposes-and-accumulates the sums into the "lane = item" registers: D[channel][item j] +=
-    // sum[item k][channel] [k == j] -- exact in fp32, 64 more MFMAs per mini-tile.
+    // 4i .. 4i+3 (one float4: a half-wave reads a whole 512-byte row per instruction), and MFMAs against a one-hot selector
+    // (B[k][j] = [item of k == j]) transpose-and-accumulate the sums into the "lane = item" registers: D[channel][item j] +=
+    // sum[item k][channel] [item k == j] -- exact in fp32, 64 more MFMAs per mini-tile.
+    const uint8_t *w0lane = (const uint8_t *)W0s + 16 * r32, *mvlane = (const uint8_t *)N.a_w0d + 16 * r32;
 #pragma unroll 2
     for (int t = 0; t < 16; ++t) {
       const uint32_t *ip = wl + (2 * t + hh) * AR_ITEM_WORDS;
-      uint32_t iw[9];
-#pragma unroll
-      for (int k = 0; k < 9; ++k) iw[k] = ip[k];
+      const uint4 i0 = *(const uint4 *)ip, i1 = *(const uint4 *)(ip + 4), i2 = *(const uint4 *)(ip + 8), i3 = *(const uint4 *)(ip + 12);
+      const uint32_t i4 = ip[16];
+      const uint32_t ho[AR_HOT] = {i0.x, i0.y, i0.z, i0.w, i1.x, i1.y, i1.z, i1.w, i2.x}, mo[AR_MOVES] = {i2.y, i2.z, i2.w, i3.x, i3.y, i3.z, i3.w, i4};
       float4 g[AR_MOVES];
 #pragma unroll
-      for (int k = 0; k < AR_MOVES; ++k) {
-        const uint32_t row = (iw[5 + (k >> 1)] >> (16 * (k & 1))) & 0xFFFF;
-        g[k] = *(const float4 *)(N.a_w0d + (size_t)row * 128 + 4 * r32); // rows in L2
-      }
+      for (int k = 0; k < AR_MOVES; ++k) g[k] = *(const float4 *)(mvlane + mo[k]); // rows in L2
       float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
       for (int k = 0; k < AR_HOT; ++k) {
-        const uint32_t off = (iw[k >> 1] >> (16 * (k & 1))) & 0xFFFF;
-        const float4 x = *(const float4 *)(W0s + off * 4 + 4 * r32);
-        sum.x += x.x; sum.y += x.y; sum.z += x.z; sum.w += x.w;
+        const float4 xr = *(const float4 *)(w0lane + ho[k]);
+        sum.x += xr.x; sum.y += xr.y; sum.z += xr.z; sum.w += xr.w;
       }
 #pragma unroll
       for (int k = 0; k < AR_MOVES; ++k) { sum.x += g[k].x; sum.y += g[k].y; sum.z += g[k].z; sum.w += g[k].w; }
-      const float ident = (uint32_t)(2 * t) + hh == r32 ? 1.0f : 0.0f;
+      const float ident = (uint32_t)(2 * t) + hh == r32 ? 1.0f : 0.0f; // (the transposition stays on the fp32 pipe: see k_embed_prows)
       hb[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(sum.x, ident, hb[0], 0, 0, 0);
       hb[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(sum.y, ident, hb[1], 0, 0, 0);
       hb[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(sum.z, ident, hb[2], 0, 0, 0);
       hb[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(sum.w, ident, hb[3], 0, 0, 0);
     }
-#pragma unroll
-    for (int b = 0; b < 4; ++b)
-#pragma unroll
-      for (int q = 0; q < 16; ++q) hb[b][q] = act_fn(hb[b][q], N.activation);
+    act_blocks<4>(hb, N.activation);
     __builtin_amdgcn_sched_barrier(0);
     EL_MARK(4);
-    // ---- second layer: one 32-wide output block after the other, W1 fragments from LDS (256 B per k-step, conflict-free) ----
-    // wave priority: second layer 3 > first layer 2 > encode / scatter 0 -- the matrix pipe is the kernel's bound, so whoever
-    // can feed it issues first (party pass 200 -> 187 us; the arbitration otherwise favours the oldest wave whatever it does)
+    if (next < nmt) encode_load2(next); // (the slot byte of LOAD 1 arrived during the first layer)
+    // ---- second layer on the bf16 pipe (embed_layer2): W1's triples from LDS ----
+    // wave priority: second layer 3 > first layer 2 > encode / scatter 0 -- whoever can feed the matrix pipe issues first
     __builtin_amdgcn_s_setprio(3);
-#pragma unroll 1
-    for (int nb = 0; nb < NBo; ++nb) {
-      f32x16 acc;
-#pragma unroll
-      for (int q = 0; q < 16; ++q) acc[q] = 0.0f;
-      const float *wc = W1s + nb * 64 * 64 + lane;
-#pragma unroll
-      for (int b = 0; b < 4; ++b)
-#pragma unroll
-        for (int s2 = 0; s2 < 16; ++s2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(hb[b][s2], wc[(b * 16 + s2) * 64], acc, 0, 0, 0);
-      const int o = nb * 32 + (int)r32;
-      const float ob = o < out_dim ? N.a_b1[o] : 0.0f;
-#pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        const int row = (q & 3) + 8 * (q >> 2) + 4 * (int)hh;
-        const uint32_t doff = dst_off[row];
-        if (o < out_dim && doff != 0xFFFFFFFFu) a.emb[(size_t)doff + 1 + o] = act_fn(acc[q] + ob, N.activation);
-      }
-    }
+    f32x16 acc[NBO];
+    embed_layer2<NBO>(hb, W1t + lane * 16, NBO, acc);
+    EL_MARK(6);
     __builtin_amdgcn_s_setprio(0);
-    if (hh == 0 && dst_off[r32] != 0xFFFFFFFFu) a.emb[dst_off[r32]] = hp_ratio[r32];
-    __builtin_amdgcn_wave_barrier(); // the wave's LDS is rewritten by the next mini-tile
+    const uint32_t cur_doff = my_doff;
+    const float cur_hpr = my_hpr;
+    __builtin_amdgcn_wave_barrier(); // the wave's row indices are rewritten by the next mini-tile's encode
+    // the next encode BEFORE this mini-tile's stores: its loads are then the oldest vector-memory operations in flight and the
+    // wait for them does not wait for the stores (vmcnt retires in order)
+    if (next < nmt) encode_compute(next);
     EL_MARK(7);
-    mt += stride;
-    if (mt < nmt) encode(mt);
+    embed_scatter<NBO>(a.emb, cur_doff, cur_hpr, hh, acc, NBO, out_dim, b1s, N.activation);
+    EL_MARK(5);
+    mt = next;
   }
   EL_FLUSH();
 }
 
+template <int WAVES = AR_WAVES>
+__device__ __forceinline__ void embed_arows_dispatch(const EmbedTileArgs &a, float *lds_f, const uint32_t bid, const uint32_t nblocks) {
+  const int NBo = (a.net.a_out + 31) >> 5; // wave-uniform
+  if (NBo == 1) embed_arows_body<WAVES, 1>(a, lds_f, bid, nblocks);
+  else if (NBo == 2) embed_arows_body<WAVES, 2>(a, lds_f, bid, nblocks);
+  else embed_arows_body<WAVES, 3>(a, lds_f, bid, nblocks);
+}
+
 __global__ __launch_bounds__(AR_BLOCK) void k_embed_arows(EmbedTileArgs a) {
   extern __shared__ __align__(16) float lds_f[];
-  embed_arows_body(a, lds_f, blockIdx.x, gridDim.x);
+  embed_arows_dispatch(a, lds_f, blockIdx.x, gridDim.x);
 }
-// (Measured and rejected, round 3: the same body as eight waves of 256 registers -- 237 used, no scratch -- instead of sixteen
-// of 128 with 49 spilled: 86.5 vs 86.4 us.  The spills sit in the encode, which already overlaps other waves' MFMA phases.)
+// (Round 3 measured the fp32-MFMA form of this body as eight waves of 256 registers against sixteen of 128 with 49 spilled: 86.5
+// vs 86.4 us.  Since round 4 -- second layer and transposition on the bf16 pipe, the next input prefetched across the second
+// layer -- the kernels run as eight waves: the sixteen-wave form spills 150-400 registers.)
 
 // ---- K2, the party-slot pass in the same form as k_embed_arows (the default).  A bench Pokemon has 6 DENSE features (bias,
 // 5 stats: 3 k-steps x 4 blocks = 12 MFMAs in the "lane = item" orientation) and 7 ONE-HOT rows (4 move slots, status, 2
 // types; 193 possible rows, all LDS-resident in natural channel order): in k-step t the half-wave hh sums the 7 rows of
 // item 2t + hh, a whole 512-byte row per ds_read_b128 and so free of the bank conflicts of k_embed_rows (every lane another
-// row at the same column), and an identity MFMA transposes the sums into the item lanes.  Second layer (<= 2 output
-// blocks) with W1 fragments from LDS.  The input is read straight from global memory (the encode of a Pokemon is 12
-// features; no staging).  LDS: 194 x 528 B rows + 3 KB dense fragment + 32 KB W1 fragments + 768 B per wave = 147 KB.
+// row at the same column), and selector MFMAs transpose the sums into the item lanes.  Second layer (<= 2 output
+// blocks) with W1's bf16 triples from LDS.  The input is read straight from global memory (the encode of a Pokemon is 12
+// features; no staging).  LDS: 194 x 512 B rows + 3 KB dense fragment + 48 KB W1 triples + bias + 512 B per wave.
 constexpr int PR_SPARSE = 193, PR_ZERO = 193, PR_KSTEPS = 3, PR_HOT = 7;
-constexpr int PR_ITEM_WORDS = 4;                 // 7 u16 LDS offsets
-constexpr int PR_WAVE_WORDS = ER_ITEMS * PR_ITEM_WORDS + 2 * ER_ITEMS;
-constexpr int PR_BLOCK = 1024, PR_WAVES = 16;
+constexpr int PR_ITEM_WORDS = 8;                 // 7 LDS byte offsets of the item's one-hot rows, ready to use (+ 1 pad: two 16-byte reads)
+constexpr int PR_WAVE_WORDS = ER_ITEMS * PR_ITEM_WORDS;
+constexpr int PR_WAVES = OAK_EMBED_WAVES, PR_BLOCK = 64 * PR_WAVES;
 constexpr int PR_DENSE_WORDS = PR_KSTEPS * 4 * 64;
-constexpr size_t PR_BYTES = (size_t)((PR_SPARSE + 1) * ER_RS + PR_DENSE_WORDS + 2 * 64 * 64 + PR_WAVES * PR_WAVE_WORDS) * 4;
-template <bool LIST>
+constexpr int PR_MAX_NBO = 2;
+constexpr int pr_img_words(int nbo) { return (PR_SPARSE + 1) * ER_RS + PR_DENSE_WORDS + nbo * (E2_BLOCK_BYTES / 4) + 32 * nbo; }
+constexpr size_t PR_BYTES = (size_t)(pr_img_words(PR_MAX_NBO) + PR_WAVES * PR_WAVE_WORDS) * 4;
+static_assert(PR_BYTES <= 160 * 1024, "the party pass's LDS image fits one CU");
+template <bool LIST, int NBO>
 __device__ __forceinline__ void embed_prows_body(const EmbedTileArgs &a, float *lds_f, const uint32_t bid, const uint32_t nblocks) {
   EL_T0();
   const NetDev &N = a.net;
-  const int hidden = N.p_hidden, out_dim = N.p_out;
-  const int NBo = (out_dim + 31) >> 5;
+  const int out_dim = N.p_out;
   const uint32_t items = LIST ? *a.work_count : a.n * 10;
   const uint32_t nmt = (items + ER_ITEMS - 1) / ER_ITEMS;
   if (bid >= nmt) return; // (a very short work list: no weights staged for nothing)
   float *W0s = lds_f;                                   // rows 5..197 of W0^T, channels in natural order, + a zero row
   float *Wd = W0s + (PR_SPARSE + 1) * ER_RS;            // dense fragment
-  float *W1s = Wd + PR_DENSE_WORDS;                     // second layer's fragments: [block][k-step][lane]
-  const int img_words = (PR_SPARSE + 1) * ER_RS + PR_DENSE_WORDS + NBo * 64 * 64;
-  float4 img_t[9];
-  stage_image_load<PR_BLOCK, 9>(img_t, N.p_img, img_words);
+  const uint8_t *W1t = (const uint8_t *)(Wd + PR_DENSE_WORDS); // second layer's bf16 triples: [block][k-step][h m l][lane] x 16 B
+  const float *b1s = (const float *)(W1t + NBO * E2_BLOCK_BYTES);
+  constexpr int img_words = pr_img_words(NBO);
+  constexpr int MAXR = (img_words / 4 + PR_BLOCK - 1) / PR_BLOCK;
+  float4 img_t[MAXR];
+  stage_image_load<PR_BLOCK, MAXR>(img_t, N.p_img, img_words);
   const uint32_t lane = threadIdx.x & 63, wib = threadIdx.x >> 6, r32 = lane & 31, hh = lane >> 5;
-  uint32_t *wl = (uint32_t *)(W1s + 2 * 64 * 64) + wib * PR_WAVE_WORDS; // this wave's private LDS
-  uint32_t *dst_off = wl + ER_ITEMS * PR_ITEM_WORDS;
-  float *hp_ratio = (float *)(dst_off + ER_ITEMS);
+  uint32_t *wl = (uint32_t *)(lds_f + img_words) + wib * PR_WAVE_WORDS; // this wave's private LDS (the items' row indices)
   const uint32_t stride = nblocks * PR_WAVES;
   EL_MARK(0);
-  // ---- encode: both lanes (r, 0) and (r, 1) encode item r; each keeps the dense values of its own k-half.  The loop below
-  // is rotated: a mini-tile's encode runs at the END of the previous one's body (the first one before the weights are
-  // written to LDS -- it needs none, so the image's round trip and the workgroup barrier hide under it). ----
+  // ---- encode, in two halves (see k_embed_arows): LOAD asks for the item's raw input -- the side's whole party (36 dwords)
+  // together with its order bytes, the right Pokemon selected afterwards: ONE round trip to memory instead of two dependent
+  // ones (the five lanes of a side read the same lines); a work-list record in LIST mode -- and COMPUTE, a whole second layer
+  // later, turns it into dense values (registers) and row indices (the wave's LDS).  Both lanes (r, 0) and (r, 1) encode item r.
   float x[PR_KSTEPS];
-  auto encode = [&](uint32_t mt)
+  uint32_t my_doff = 0xFFFFFFFFu; // this lane's item: its block of the embedding (both lanes (r, 0), (r, 1) hold item r's) and hp ratio
+  float my_hpr = 0.0f;
+  uint4 in_pw[LIST ? 2 : 9];
+  uint2 in_ow = make_uint2(0, 0);
+  uint32_t in_dur = 0;
+  auto encode_load = [&](uint32_t mt)
+  {
+    const uint32_t g = mt * ER_ITEMS + r32;
+    if (g < items) {
+      if (LIST) {
+        const uint32_t *rec = (const uint32_t *)a.work + (size_t)g * 8;
+        in_pw[0] = *(const uint4 *)rec; in_pw[1] = *(const uint4 *)(rec + 4);
+      } else {
+        const uint32_t leaf = g / 10, q = g - leaf * 10, side = q / 5;
+        const uint32_t *sb = (const uint32_t *)a.battles + (size_t)leaf * 96 + side * 46;
+#pragma unroll
+        for (int u = 0; u < (LIST ? 2 : 9); ++u) in_pw[u] = ((const uint4 *)sb)[u];
+        in_ow = *(const uint2 *)(sb + 44);
+        in_dur = ((const uint32_t *)a.durations)[(size_t)leaf * 2 + side];
+      }
+    }
+  };
+  auto encode_compute = [&](uint32_t mt)
   {
     const uint32_t g = mt * ER_ITEMS + r32;
     uint32_t gi = g, pk0 = 0, pk1 = 0, pk2 = 0, pk3 = 0, pk4 = 0, pk5 = 0, sleep = 0;
     if (g < items) {
-      if (LIST) {
-        const uint32_t *rec = (const uint32_t *)a.work + (size_t)g * 8;
-        const uint4 r0 = *(const uint4 *)rec, r1 = *(const uint4 *)(rec + 4);
+      if constexpr (LIST) {
+        const uint4 r0 = in_pw[0], r1 = in_pw[1];
         gi = r0.x; pk0 = r0.y; pk1 = r0.z; pk2 = r0.w; pk3 = r1.x; pk4 = r1.y; pk5 = r1.z; sleep = r1.w;
       } else {
         const uint32_t leaf = g / 10, q = g - leaf * 10, side = q / 5, slot = 1 + (q - side * 5);
-        // the side's whole party (36 dwords) is asked for together with its order bytes and the right Pokemon selected
-        // afterwards: ONE round trip to memory instead of two dependent ones (the five lanes of a side read the same lines)
-        const uint32_t *sb = (const uint32_t *)a.battles + (size_t)leaf * 96 + side * 46;
-        uint4 pw[9];
-#pragma unroll
-        for (int u = 0; u < 9; ++u) pw[u] = ((const uint4 *)sb)[u];
-        const uint2 ow = *(const uint2 *)(sb + 44);
-        const uint32_t o0 = ow.x, o1 = ow.y;
-        const uint32_t dur = ((const uint32_t *)a.durations)[(size_t)leaf * 2 + side];
+        const uint32_t o0 = in_ow.x, o1 = in_ow.y;
         const uint32_t id = slot < 4 ? (o0 >> (8 * slot)) & 0xFF : (o1 >> (8 * (slot - 4))) & 0xFF;
-        sleep = (dur >> (3 * slot)) & 7;
-        const uint32_t w[36] = {pw[0].x, pw[0].y, pw[0].z, pw[0].w, pw[1].x, pw[1].y, pw[1].z, pw[1].w, pw[2].x, pw[2].y, pw[2].z, pw[2].w,
-                                pw[3].x, pw[3].y, pw[3].z, pw[3].w, pw[4].x, pw[4].y, pw[4].z, pw[4].w, pw[5].x, pw[5].y, pw[5].z, pw[5].w,
-                                pw[6].x, pw[6].y, pw[6].z, pw[6].w, pw[7].x, pw[7].y, pw[7].z, pw[7].w, pw[8].x, pw[8].y, pw[8].z, pw[8].w};
+        sleep = (in_dur >> (3 * slot)) & 7;
+        const uint32_t w[36] = {in_pw[0].x, in_pw[0].y, in_pw[0].z, in_pw[0].w, in_pw[1].x, in_pw[1].y, in_pw[1].z, in_pw[1].w, in_pw[2].x, in_pw[2].y, in_pw[2].z, in_pw[2].w,
+                                in_pw[3].x, in_pw[3].y, in_pw[3].z, in_pw[3].w, in_pw[4].x, in_pw[4].y, in_pw[4].z, in_pw[4].w, in_pw[5].x, in_pw[5].y, in_pw[5].z, in_pw[5].w,
+                                in_pw[6].x, in_pw[6].y, in_pw[6].z, in_pw[6].w, in_pw[7].x, in_pw[7].y, in_pw[7].z, in_pw[7].w, in_pw[8].x, in_pw[8].y, in_pw[8].z, in_pw[8].w};
 #pragma unroll
         for (uint32_t k = 0; k < 6; ++k) {
           const bool m = id == k + 1;
@@ -829,7 +999,7 @@ __device__ __forceinline__ void embed_prows_body(const EmbedTileArgs &a, float *
 #pragma unroll
     for (int f = 0; f < 6; ++f) fv[f] = 0.0f;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) hot[k] = PR_ZERO * ER_RS / 4;
+    for (int k = 0; k < 8; ++k) hot[k] = PR_ZERO * ER_RS / 4; // (row offsets in 16-byte units)
     if (g < items) {
       const uint32_t leaf = gi / 10, q = gi - leaf * 10, side = q / 5, slot = 1 + (q - side * 5);
       const uint32_t hp = pk4 >> 16;
@@ -850,25 +1020,25 @@ __device__ __forceinline__ void embed_prows_body(const EmbedTileArgs &a, float *
     }
 #pragma unroll
     for (int t = 0; t < PR_KSTEPS; ++t) x[t] = hh ? fv[2 * t + 1] : fv[2 * t];
-    if (hh == 0) {
+    if (hh == 0) { // (byte offsets from W0s: the readers add their own 16 bytes of the row and nothing else)
       uint32_t *it = wl + r32 * PR_ITEM_WORDS;
-      it[0] = hot[0] | hot[1] << 16; it[1] = hot[2] | hot[3] << 16; it[2] = hot[4] | hot[5] << 16; it[3] = hot[6];
-      dst_off[r32] = doff;
-      hp_ratio[r32] = hpr;
+      *(uint4 *)it = make_uint4(hot[0] * 16, hot[1] * 16, hot[2] * 16, hot[3] * 16);
+      *(uint4 *)(it + 4) = make_uint4(hot[4] * 16, hot[5] * 16, hot[6] * 16, 0);
     }
+    my_doff = doff;
+    my_hpr = hpr;
     zero_blocks(a.emb, hh == 0 ? dead_off : 0xFFFFFFFFu, out_dim + 1);
   };
-  // mini-tiles go round-robin over the WORKGROUPS first, so that a short work list still spreads over every CU (two waves per
-  // SIMD finish a mini-tile much sooner than four)
+  // mini-tiles go round-robin over the WORKGROUPS first, so that a short work list still spreads over every CU
   uint32_t mt = wib * nblocks + bid;
-  if (mt < nmt) encode(mt); // needs no weights: the image's round trip runs under it
-  stage_image_store<PR_BLOCK, 9>(lds_f, img_t, img_words);
+  if (mt < nmt) { encode_load(mt); encode_compute(mt); } // needs no weights: the image's round trip runs under it
+  stage_image_store<PR_BLOCK, MAXR>(lds_f, img_t, img_words);
   __syncthreads(); // weights staged (the only workgroup barrier of the kernel)
   while (mt < nmt) {
     __builtin_amdgcn_wave_barrier();
     EL_MARK(3);
     __builtin_amdgcn_s_setprio(2); // a wave in its MFMA phases goes before waves that encode or scatter (see the second layer)
-    // ---- first layer: dense part, then the one-hot rows through the identity transposition (see k_embed_arows) ----
+    // ---- first layer: dense part, then the one-hot rows through the selector transposition (see k_embed_arows) ----
     f32x16 hb[4];
 #pragma unroll
     for (int b = 0; b < 4; ++b)
@@ -878,73 +1048,76 @@ __device__ __forceinline__ void embed_prows_body(const EmbedTileArgs &a, float *
     for (int t = 0; t < PR_KSTEPS; ++t)
 #pragma unroll
       for (int b = 0; b < 4; ++b) hb[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(Wd[(t * 4 + b) * 64 + lane], x[t], hb[b], 0, 0, 0);
-    // (not unrolled, all seven row reads of a k-step issued before the first add: unrolled, the register allocator -- 128
-    // registers, 64 of them accumulators -- gave every read the same four registers and a full LDS round trip each)
-    uint4 iw = *(const uint4 *)(wl + hh * PR_ITEM_WORDS);
-#pragma unroll 1
-    for (int t = 0; t < 16; ++t) {
-      const uint32_t w[4] = {iw.x, iw.y, iw.z, iw.w};
-      float4 r[PR_HOT];
+    // The transposition stays on the fp32 pipe (64 identity MFMAs of 64 cycles per mini-tile): on the bf16 pipe it needs the
+    // row sums split into bf16 triples first -- 48 MFMAs of 32 cycles but ~1,000 more vector instructions per mini-tile, and with
+    // the second layer on the bf16 pipe these kernels are bound by the instructions a wave issues, not by the matrix pipe
+    // (measured, round 4: first layer 12.2 k cycles per mini-tile that way against 9.8 k this way).
+    // Software pipeline over the 16 k-steps, fully unrolled: an MFMA holds the wave's in-order issue until the matrix pipe takes it
+    // (64 cycles each on the fp32 pipe), so k-step t + 1's row reads are issued IN FRONT of k-step t's four MFMAs and their LDS
+    // round trip runs under them; the row indices are read two k-steps ahead.
+    const uint8_t *w0lane = (const uint8_t *)W0s + 16 * r32;
+    auto rows_of = [&](const uint4 &ia, const uint4 &ib, float4 (&r)[PR_HOT]) {
+      r[0] = *(const float4 *)(w0lane + ia.x); r[1] = *(const float4 *)(w0lane + ia.y); r[2] = *(const float4 *)(w0lane + ia.z);
+      r[3] = *(const float4 *)(w0lane + ia.w); r[4] = *(const float4 *)(w0lane + ib.x); r[5] = *(const float4 *)(w0lane + ib.y);
+      r[6] = *(const float4 *)(w0lane + ib.z);
+    };
+    {
+      uint4 ian = *(const uint4 *)(wl + (2 * 1 + hh) * PR_ITEM_WORDS), ibn = *(const uint4 *)(wl + (2 * 1 + hh) * PR_ITEM_WORDS + 4);
+      float4 rc[PR_HOT], rn[PR_HOT];
+      rows_of(*(const uint4 *)(wl + hh * PR_ITEM_WORDS), *(const uint4 *)(wl + hh * PR_ITEM_WORDS + 4), rc);
 #pragma unroll
-      for (int k = 0; k < PR_HOT; ++k) {
-        const uint32_t off = (w[k >> 1] >> (16 * (k & 1))) & 0xFFFF;
-        r[k] = *(const float4 *)(W0s + off * 4 + 4 * r32);
+      for (int t = 0; t < 16; ++t) {
+        if (t + 1 < 16) rows_of(ian, ibn, rn);
+        if (t + 2 < 16) { ian = *(const uint4 *)(wl + (2 * (t + 2) + hh) * PR_ITEM_WORDS); ibn = *(const uint4 *)(wl + (2 * (t + 2) + hh) * PR_ITEM_WORDS + 4); }
+        float4 sum;
+        sum.x = ((rc[0].x + rc[1].x) + (rc[2].x + rc[3].x)) + ((rc[4].x + rc[5].x) + rc[6].x);
+        sum.y = ((rc[0].y + rc[1].y) + (rc[2].y + rc[3].y)) + ((rc[4].y + rc[5].y) + rc[6].y);
+        sum.z = ((rc[0].z + rc[1].z) + (rc[2].z + rc[3].z)) + ((rc[4].z + rc[5].z) + rc[6].z);
+        sum.w = ((rc[0].w + rc[1].w) + (rc[2].w + rc[3].w)) + ((rc[4].w + rc[5].w) + rc[6].w);
+        const float ident = (uint32_t)(2 * t) + hh == r32 ? 1.0f : 0.0f;
+        hb[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(sum.x, ident, hb[0], 0, 0, 0);
+        hb[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(sum.y, ident, hb[1], 0, 0, 0);
+        hb[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(sum.z, ident, hb[2], 0, 0, 0);
+        hb[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(sum.w, ident, hb[3], 0, 0, 0);
+#pragma unroll
+        for (int k = 0; k < PR_HOT; ++k) rc[k] = rn[k];
       }
-      iw = *(const uint4 *)(wl + (2 * (t < 15 ? t + 1 : t) + hh) * PR_ITEM_WORDS); // the next k-step's row indices
-      __builtin_amdgcn_sched_barrier(0);
-      float4 sum;
-      sum.x = ((r[0].x + r[1].x) + (r[2].x + r[3].x)) + ((r[4].x + r[5].x) + r[6].x);
-      sum.y = ((r[0].y + r[1].y) + (r[2].y + r[3].y)) + ((r[4].y + r[5].y) + r[6].y);
-      sum.z = ((r[0].z + r[1].z) + (r[2].z + r[3].z)) + ((r[4].z + r[5].z) + r[6].z);
-      sum.w = ((r[0].w + r[1].w) + (r[2].w + r[3].w)) + ((r[4].w + r[5].w) + r[6].w);
-      const float ident = (uint32_t)(2 * t) + hh == r32 ? 1.0f : 0.0f;
-      hb[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(sum.x, ident, hb[0], 0, 0, 0);
-      hb[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(sum.y, ident, hb[1], 0, 0, 0);
-      hb[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(sum.z, ident, hb[2], 0, 0, 0);
-      hb[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(sum.w, ident, hb[3], 0, 0, 0);
     }
-#pragma unroll
-    for (int b = 0; b < 4; ++b)
-#pragma unroll
-      for (int q = 0; q < 16; ++q) hb[b][q] = act_fn(hb[b][q], N.activation);
+    act_blocks<4>(hb, N.activation);
     EL_MARK(4);
-    // ---- second layer ----
-    // wave priority: second layer 3 > first layer 2 > encode / scatter 0 -- the matrix pipe is the kernel's bound, so whoever
-    // can feed it issues first (party pass 200 -> 187 us; the arbitration otherwise favours the oldest wave whatever it does)
+    const uint32_t next = mt + stride;
+    if (next < nmt) encode_load(next); // the next mini-tile's raw input: asked for now, looked at after the second layer
+    // ---- second layer on the bf16 pipe (embed_layer2) ----
+    // wave priority: second layer 3 > first layer 2 > encode / scatter 0 -- whoever can feed the matrix pipe issues first
     __builtin_amdgcn_s_setprio(3);
-#pragma unroll 1
-    for (int nb = 0; nb < NBo; ++nb) {
-      f32x16 acc;
-#pragma unroll
-      for (int q = 0; q < 16; ++q) acc[q] = 0.0f;
-      const float *wc = W1s + nb * 64 * 64 + lane;
-#pragma unroll
-      for (int b = 0; b < 4; ++b)
-#pragma unroll
-        for (int s2 = 0; s2 < 16; ++s2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(hb[b][s2], wc[(b * 16 + s2) * 64], acc, 0, 0, 0);
-      const int o = nb * 32 + (int)r32;
-      const float ob = o < out_dim ? N.p_b1[o] : 0.0f;
-#pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        const int row = (q & 3) + 8 * (q >> 2) + 4 * (int)hh;
-        const uint32_t doff = dst_off[row];
-        if (o < out_dim && doff != 0xFFFFFFFFu) a.emb[(size_t)doff + 1 + o] = act_fn(acc[q] + ob, N.activation);
-      }
-    }
+    f32x16 acc[NBO];
+    embed_layer2<NBO>(hb, W1t + lane * 16, NBO, acc);
+    EL_MARK(6);
     __builtin_amdgcn_s_setprio(0);
-    if (hh == 0 && dst_off[r32] != 0xFFFFFFFFu) a.emb[dst_off[r32]] = hp_ratio[r32];
-    __builtin_amdgcn_wave_barrier(); // the wave's LDS is rewritten by the next mini-tile
+    const uint32_t cur_doff = my_doff;
+    const float cur_hpr = my_hpr;
+    __builtin_amdgcn_wave_barrier(); // the wave's row indices are rewritten by the next mini-tile's encode
+    // the next encode BEFORE this mini-tile's stores: its loads are then the oldest vector-memory operations in flight and the
+    // wait for them does not wait for the stores (vmcnt retires in order)
+    if (next < nmt) encode_compute(next);
     EL_MARK(7);
-    mt += stride;
-    if (mt < nmt) encode(mt);
+    embed_scatter<NBO>(a.emb, cur_doff, cur_hpr, hh, acc, NBO, out_dim, b1s, N.activation);
+    EL_MARK(5);
+    mt = next;
   }
   EL_FLUSH();
 }
 
 template <bool LIST>
+__device__ __forceinline__ void embed_prows_dispatch(const EmbedTileArgs &a, float *lds_f, const uint32_t bid, const uint32_t nblocks) {
+  if (a.net.p_out <= 32) embed_prows_body<LIST, 1>(a, lds_f, bid, nblocks); // wave-uniform
+  else embed_prows_body<LIST, 2>(a, lds_f, bid, nblocks);
+}
+
+template <bool LIST>
 __global__ __launch_bounds__(PR_BLOCK) void k_embed_prows(EmbedTileArgs a) {
   extern __shared__ __align__(16) float lds_f[];
-  embed_prows_body<LIST>(a, lds_f, blockIdx.x, gridDim.x);
+  embed_prows_dispatch<LIST>(a, lds_f, blockIdx.x, gridDim.x);
 }
 
 // Both embedding passes in ONE launch (the default): workgroups [0, np) run the party-slot pass, the rest the actives'
@@ -955,8 +1128,8 @@ static_assert(PR_BLOCK == AR_BLOCK, "the merged launch uses one workgroup size")
 template <bool LIST>
 __global__ __launch_bounds__(PR_BLOCK) void k_embed_both(EmbedTileArgs party, EmbedTileArgs actives, uint32_t np) {
   extern __shared__ __align__(16) float lds_f[];
-  if (blockIdx.x < np) embed_prows_body<LIST>(party, lds_f, blockIdx.x, np);
-  else embed_arows_body(actives, lds_f, blockIdx.x - np, gridDim.x - np);
+  if (blockIdx.x < np) embed_prows_dispatch<LIST>(party, lds_f, blockIdx.x, np);
+  else embed_arows_dispatch(actives, lds_f, blockIdx.x - np, gridDim.x - np);
 }
 
 // ---- party-slot embedding cache (the GPU form of NN::Battle::PokemonCache, cpp/include/nn/battle/cache.h:18-131) ------------
@@ -1289,7 +1462,6 @@ __global__ __launch_bounds__(MN_BLOCK) void k_mainnet_wave(MainArgs a) {
 // rings, hand-counted vmcnt waits, interleaved accumulation chains, one LDS read per MFMA pair and a level-wise split all
 // measured 186-189 us; only removing work moved it (no split: 132 us, no LDS reads: 169 us) -- so the simplest form is kept.
 constexpr int MS_G = 2;
-using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 template <int NB> struct MSplit {
   static constexpr int PHASE_BYTES = MS_G * NB * 3072;            // [k-step][block][h m l][lane] x 16 B
   static constexpr int PT = (PHASE_BYTES + 4095) / 4096;          // 1-KB DMA pieces per wave per phase, at most
@@ -1320,6 +1492,13 @@ struct MSRing { int cur, phase, n_phases; const uint8_t *stream; uint8_t *lds; }
 template <int NB>
 __device__ __forceinline__ void ms_next_phase(MSRing &R, int tid) {
   using M = MSplit<NB>;
+  // The wait is written out: __syncthreads() does NOT reliably wait for LDS-DMA in flight.  hipcc (ROCm 7.2) emitted
+  // `s_waitcnt vmcnt(0)` in front of every second barrier of the k-loops only (k_mainnet_split<2>: three of six barriers were
+  // a bare `s_waitcnt lgkmcnt(0); s_barrier`), so a phase could start on a buffer whose bytes were still on their way.  With
+  // 8 blocks a phase is 192 MFMAs long and the DMA always won; with 1-2 blocks (64-wide nets) it is 24-48 MFMAs and about one
+  // run of the leaf tests in twelve read stale weights (round 4: values off by 1e-7 .. 1e-2 in a few rows, never reproducible
+  // in isolation).  This wave's pieces are retired here, the other waves' by the barrier.
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   const int done = R.cur;
   R.cur ^= 1;
@@ -1460,6 +1639,7 @@ __global__ __launch_bounds__(MN_BLOCK) void k_mainnet_split(MainArgs a) {
   const int T0 = N.ws_T0, K = N.emb_dim;
   MSRing R{0, 0, (T0 + 4 * NB) / MS_G, (const uint8_t *)N.ws, lds_b}; // fc0: T0 k-steps, fc1 and value_fc2: 2 NB each
   ms_dma_phase<NB>(R.stream, lds_b, tid);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // (written out: see ms_next_phase)
   __syncthreads(); // (also publishes vec)
   ms_dma_phase<NB>(R.stream + (size_t)M::PHASE_BYTES, lds_b + M::PHASE_BYTES, tid); // (a stream has at least 4 phases)
 
@@ -1902,32 +2082,60 @@ std::vector<float> embed_frag_order(const HostAffine &a) {
   return f;
 }
 
-// the images of the two kernels' LDS weights: [one-hot rows (stride ER_RS) + a zero row | dense fragment | W1 fragments]
-std::vector<float> arows_image(const HostAffine &a0, const HostAffine &a1) {
-  std::vector<float> img((size_t)(oak::AR_SPARSE + 1) * oak::ER_RS, 0.0f);
-  for (int sl = 0; sl < oak::AR_SPARSE; ++sl)
-    for (uint32_t c = 0; c < a0.out && c < 128; ++c) img[(size_t)sl * oak::ER_RS + c] = a0.w[(size_t)c * a0.in + (uint32_t)oak::ar_sparse_row(sl)];
-  const std::vector<float> d = arows_dense_frag(a0), f = embed_frag_order(a1);
-  img.insert(img.end(), d.begin(), d.end());
-  img.insert(img.end(), f.begin(), f.end());
-  return img;
-}
-std::vector<float> prows_image(const HostAffine &p0, const HostAffine &p1) {
-  std::vector<float> img((size_t)(oak::PR_SPARSE + 1) * oak::ER_RS, 0.0f);
-  for (int sl = 0; sl < oak::PR_SPARSE; ++sl)
-    for (uint32_t c = 0; c < p0.out && c < 128; ++c) img[(size_t)sl * oak::ER_RS + c] = p0.w[(size_t)c * p0.in + (uint32_t)(sl + 5)];
-  const std::vector<float> d = prows_dense_frag(p0), f = embed_frag_order(p1);
-  img.insert(img.end(), d.begin(), d.end());
-  img.insert(img.end(), f.begin(), f.end());
-  return img;
-}
-
 std::vector<float> pad_vec(const std::vector<float> &v, uint32_t n) {
   std::vector<float> t(n, 0.0f);
   for (size_t i = 0; i < v.size(); ++i) t[i] = v[i];
   return t;
 }
 uint32_t up32(uint32_t x) { return (x + 31) & ~31u; }
+
+// W1 of an embedding net as bf16 triples in embed_layer2's order: 16-bit word ((((nb * 8 + T) * 3 + part) * 64 + lane) * 8 + j) = part of
+// W1[32 nb + (lane & 31)][ar_channel(8 T + j, lane >> 5)]; absent rows / channels are zeros.  Returned as floats (the LDS image's unit).
+std::vector<float> embed_triple_order(const HostAffine &a, uint32_t NB) {
+  std::vector<uint16_t> w((size_t)NB * 8 * 3 * 64 * 8, 0);
+  for (uint32_t nb = 0; nb < NB; ++nb)
+    for (uint32_t T = 0; T < 8; ++T)
+      for (uint32_t lane = 0; lane < 64; ++lane)
+        for (uint32_t j = 0; j < 8; ++j) {
+          const uint32_t o = nb * 32 + (lane & 31), c = (uint32_t)oak::ar_channel((int)(8 * T + j), (int)(lane >> 5));
+          if (o >= a.out || c >= a.in) continue;
+          const float x = a.w[(size_t)o * a.in + c];
+          const uint16_t hh = f32_to_bf16(x);
+          const float r1 = x - bf16_to_f32(hh);
+          const uint16_t mm = f32_to_bf16(r1);
+          const uint16_t ll = f32_to_bf16(r1 - bf16_to_f32(mm));
+          const size_t base = ((size_t)nb * 8 + T) * 3;
+          w[((base + 0) * 64 + lane) * 8 + j] = hh;
+          w[((base + 1) * 64 + lane) * 8 + j] = mm;
+          w[((base + 2) * 64 + lane) * 8 + j] = ll;
+        }
+  std::vector<float> f(w.size() / 2);
+  memcpy(f.data(), w.data(), w.size() * 2);
+  return f;
+}
+
+// the images of the two kernels' LDS weights: [one-hot rows (stride ER_RS) + a zero row | dense fragment | W1's bf16 triples]
+std::vector<float> arows_image(const HostAffine &a0, const HostAffine &a1) {
+  std::vector<float> img((size_t)(oak::AR_SPARSE + 1) * oak::ER_RS, 0.0f);
+  for (int sl = 0; sl < oak::AR_SPARSE; ++sl)
+    for (uint32_t c = 0; c < a0.out && c < 128; ++c) img[(size_t)sl * oak::ER_RS + c] = a0.w[(size_t)c * a0.in + (uint32_t)oak::ar_sparse_row(sl)];
+  const std::vector<float> d = arows_dense_frag(a0), f = embed_triple_order(a1, (a1.out + 31) / 32), bp = pad_vec(a1.b, up32(a1.out));
+  img.insert(img.end(), d.begin(), d.end());
+  img.insert(img.end(), f.begin(), f.end());
+  img.insert(img.end(), bp.begin(), bp.end());
+  return img;
+}
+std::vector<float> prows_image(const HostAffine &p0, const HostAffine &p1) {
+  std::vector<float> img((size_t)(oak::PR_SPARSE + 1) * oak::ER_RS, 0.0f);
+  for (int sl = 0; sl < oak::PR_SPARSE; ++sl)
+    for (uint32_t c = 0; c < p0.out && c < 128; ++c) img[(size_t)sl * oak::ER_RS + c] = p0.w[(size_t)c * p0.in + (uint32_t)(sl + 5)];
+  const std::vector<float> d = prows_dense_frag(p0), f = embed_triple_order(p1, (p1.out + 31) / 32), bp = pad_vec(p1.b, up32(p1.out));
+  img.insert(img.end(), d.begin(), d.end());
+  img.insert(img.end(), f.begin(), f.end());
+  img.insert(img.end(), bp.begin(), bp.end());
+  return img;
+}
+
 } // namespace
 
 extern "C" {
@@ -1994,10 +2202,10 @@ int oakgpu_net_load_memory(oakgpu_ctx *ctx, const void *bytes, size_t size, oakg
   rc = rc ? rc : upload(net, p0.b, &D.p_b0);
   rc = rc ? rc : upload(net, p1.w, &D.p_w1);
   rc = rc ? rc : upload(net, a1.w, &D.a_w1);
-  rc = rc ? rc : upload(net, p1.b, &D.p_b1);
+  rc = rc ? rc : upload(net, pad_vec(p1.b, up32(p1.out)), &D.p_b1); // (padded: embed_scatter reads whole float4 groups)
   rc = rc ? rc : upload(net, transpose(a0), &D.a_w0t);
   rc = rc ? rc : upload(net, a0.b, &D.a_b0);
-  rc = rc ? rc : upload(net, a1.b, &D.a_b1);
+  rc = rc ? rc : upload(net, pad_vec(a1.b, up32(a1.out)), &D.a_b1);
   rc = rc ? rc : upload(net, arows_rows(a0), &D.a_w0d);
   rc = rc ? rc : upload(net, arows_image(a0, a1), &D.a_img);
   rc = rc ? rc : upload(net, prows_image(p0, p1), &D.p_img);
@@ -2101,12 +2309,12 @@ int oakgpu_leaf_set_lds_limits(void) { // per DEVICE (hipFuncSetAttribute applie
   if (e != hipSuccess) return oakgpu_fail_hip((int)e, "hipFuncSetAttribute(k_embed_lds<party>)");
   e = hipFuncSetAttribute((const void *)oak::k_embed_lds<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)oak::ELayout<false>::BYTES);
   if (e != hipSuccess) return oakgpu_fail_hip((int)e, "hipFuncSetAttribute(k_embed_lds<party, list>)");
-  e = hipFuncSetAttribute((const void *)oak::k_embed_arows, hipFuncAttributeMaxDynamicSharedMemorySize, (int)oak::ar_bytes(4));
+  e = hipFuncSetAttribute((const void *)oak::k_embed_arows, hipFuncAttributeMaxDynamicSharedMemorySize, (int)oak::ar_bytes(oak::AR_MAX_NBO));
   if (e != hipSuccess) return oakgpu_fail_hip((int)e, "hipFuncSetAttribute(k_embed_arows)");
   e = hipFuncSetAttribute((const void *)oak::k_embed_prows<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)oak::PR_BYTES);
   if (e != hipSuccess) return oakgpu_fail_hip((int)e, "hipFuncSetAttribute(k_embed_prows)");
   {
-    const int both_bytes = (int)(oak::PR_BYTES > oak::ar_bytes(4) ? oak::PR_BYTES : oak::ar_bytes(4));
+    const int both_bytes = (int)(oak::PR_BYTES > oak::ar_bytes(oak::AR_MAX_NBO) ? oak::PR_BYTES : oak::ar_bytes(oak::AR_MAX_NBO));
     e = hipFuncSetAttribute((const void *)oak::k_embed_both<false>, hipFuncAttributeMaxDynamicSharedMemorySize, both_bytes);
     if (e != hipSuccess) return oakgpu_fail_hip((int)e, "hipFuncSetAttribute(k_embed_both)");
     e = hipFuncSetAttribute((const void *)oak::k_embed_both<true>, hipFuncAttributeMaxDynamicSharedMemorySize, both_bytes);
@@ -2149,7 +2357,7 @@ static int leaf_eval_impl(oakgpu_ctx *ctx, oakgpu_net *net, const uint8_t *battl
   // and active outputs up to 128; anything wider goes to k_embed_lds (the 64-item tile form).  OAKGPU_EMBED_TILE=1 forces
   // the tile form (A/B and a second implementation for the tests).
   static const bool force_tile = getenv("OAKGPU_EMBED_TILE") != nullptr;
-  const bool prow_ok = !force_tile && D.p_hidden <= 128 && D.p_out <= 64, arow_ok = !force_tile && D.a_hidden <= 128 && D.a_out <= 128;
+  const bool prow_ok = !force_tile && D.p_hidden <= 128 && D.p_out <= 64, arow_ok = !force_tile && D.a_hidden <= 128 && D.a_out <= 32 * oak::AR_MAX_NBO;
   hipEvent_t *tev = (hipEvent_t *)oakgpu_ctx_timing_events(ctx); // diagnostic only (oakgpu_set_kernel_timing)
   static const int kinds = getenv("OAKGPU_EMBED_KINDS") ? atoi(getenv("OAKGPU_EMBED_KINDS")) : 3; // diagnostics: 1 party, 2 actives
   static const bool split = getenv("OAKGPU_EMBED_SPLIT") != nullptr; // A/B: the two passes as two launches

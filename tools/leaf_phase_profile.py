@@ -36,7 +36,7 @@ for kind, env in ((os.environ.get("OAKGPU_EMBED_KINDS", "both kinds"), None),):
     torch.cuda.synchronize()
     lib.oakgpu_leaf_profile(buf, 0)
     print("== kinds", kind)
-    names = ["prologue (weights -> LDS)", "stage Bs + barrier", "issue prefetch", "1a feature lists", "1c first layer", "barrier", "2 mfma", "3 scatter"]
+    names = ["prologue (image loads issued)", "-", "-", "loop top (first pass: first encode + image store + barrier)", "first layer (dense MFMA, row sums, transposition, activation)", "scatter", "next input's loads issued + second layer (split + MFMA)", "next encode (compute)"]
     wn = ["fc0 (split: 73,728 MFMA cycles per tile)", "bias + act 0", "fc1 (24,576)", "bias + act 1 (+ h1)", "value_fc2 (24,576)", "value_fc3 + sigmoid"]
     wt = sum(buf[10 + i] for i in range(6))
     for i, nm in enumerate(wn):

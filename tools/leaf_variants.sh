@@ -1,9 +1,16 @@
 #!/bin/bash
-# Manual GPU tool: main-net kernel time of experiment builds (prof_build/liboakgpu_<name>.so; results are NOT checked).
+# Manual GPU tool: leaf kernel times of experiment builds (prof_build/liboakgpu_<name>.so), each first held to the leaf tests.
+# usage: tools/leaf_variants.sh <name> ...      (TESTS=0 skips the tests)
 cd "$GRAFT_REPO_ROOT"
+mkdir -p gpurun_out/r04
 cp oak_amd/liboakgpu.so /tmp/liboakgpu_saved.so
 for v in "$@"; do
   cp prof_build/liboakgpu_$v.so oak_amd/liboakgpu.so
-  timeout -k 10 120 python3 bench.py --workload leaf --no-cpu-baseline 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$v', d['roofline']['kernel_us'])"
+  if [ "${TESTS:-1}" != "0" ]; then
+    timeout -k 10 400 python3 -m pytest tests/test_gpu_leafnet.py -m gpu -x -q > gpurun_out/r04/leaf_variant_$v.log 2>&1; echo "$v tests: $(tail -1 gpurun_out/r04/leaf_variant_$v.log)"
+  fi
+  for rep in 1 2; do
+    timeout -k 10 120 python3 bench.py --workload leaf --steps 20 --warmup 10 --no-cpu-baseline 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$v', '%.1f M leaf-evals/s' % (d['value']/1e6), {k: round(x, 1) for k, x in d['roofline']['kernel_us'].items()})"
+  done
 done
 cp /tmp/liboakgpu_saved.so oak_amd/liboakgpu.so
