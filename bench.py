@@ -420,7 +420,9 @@ def leaf_records(args, torch, dev, rank, local_rank, world, dist, which=("leaf",
               turn-steps on the device) with the config-3 network (768 -> 256 -> 256 -> 256 -> 1, seeded synthetic weights).
     config3 : one step = one random turn-step of the resident 65,536-lane batch, in place, + value_inference of every
               lane (BASELINE configs[2]: "MLP leaf eval every turn"); 40-turn episodes.
-    Roofline: fp32 MFMA (157.3 TFLOP/s dense), algorithmic FLOP per leaf from SURVEY 8(d) (oak_amd.netfile.flops_per_leaf)."""
+    Roofline: every layer priced against the dense peak of the matrix pipe it runs on (fp32 MFMA 157.3 TFLOP/s; bf16 MFMA 2,500
+    TFLOP/s for the layers computed as bf16 triples, six partial products per multiply-add), one time-weighted fraction per record
+    (`priced`); algorithmic FLOP per leaf from SURVEY 8(d) (oak_amd.netfile.flops_per_leaf)."""
     import tempfile
     from oak_amd import _lib, netfile
     from oak_amd import dist as oakdist
@@ -523,10 +525,11 @@ def leaf_records(args, torch, dev, rank, local_rank, world, dist, which=("leaf",
     # the main net's kernel: fp32 values as exact bf16 triples on the bf16 matrix pipe unless OAKGPU_MAIN_NET=fp32 (include/oakgpu.h)
     split = os.environ.get("OAKGPU_MAIN_NET", "") != "fp32"
     MAIN_KERNEL = "k_mainnet_split<8>" if split else "k_mainnet_wave"
-    ARITH = ("fp32 results throughout.  Embedding nets: fp32 MFMA.  Main net: every fp32 value is the exact sum of three bf16 parts and every "
-             "product runs as its six largest bf16 x bf16 partial products (exact in the fp32 accumulator; dropped: < 2^-24 of the product) "
-             "on v_mfma_f32_32x32x16_bf16, fp32 accumulation; error vs float64 at the fp32-MFMA kernel's level "
-             "(tests/test_gpu_leafnet.py::test_bf16_triple_main_net_is_an_fp32_result)") if split else "fp32 MFMA throughout"
+    ARITH = ("fp32 results throughout.  Embedding nets: first layers on fp32 MFMA, second layers as exact bf16 triples on the bf16 pipe.  Main net: every "
+             "fp32 value is the exact sum of three bf16 parts and every product runs as its six largest bf16 x bf16 partial products (exact in the "
+             "fp32 accumulator; dropped: < 2^-24 of the product) on v_mfma_f32_32x32x16_bf16, fp32 accumulation; error vs float64 at the fp32-MFMA "
+             "kernel's level (tests/test_gpu_leafnet.py::test_bf16_triple_main_net_is_an_fp32_result)") if split else \
+            "embedding nets: first layers fp32 MFMA, second layers bf16 triples; main net fp32 MFMA"
 
     def policy_note(value_call_s):   # SURVEY 8 row f3, untimed diagnostic pass: value_policy_inference (network.h:102-123) over the same states
         c1, c2 = (torch.empty((n, 9), dtype=u8, device=dev) for _ in range(2))
@@ -551,13 +554,24 @@ def leaf_records(args, torch, dev, rank, local_rank, world, dist, which=("leaf",
                 "leaf_evals_per_s": n / t, "ms_per_call": t * 1e3, "policy_heads_ms": (t - value_call_s) * 1e3,
                 "kernel": "the leaf call's kernels + oak::k_policy_rows<2>", "parity": "<= 2e-5 per logit vs the numpy oracle (tests/test_gpu_leafnet.py)"}
 
-    def main_net_note(kus):
-        if not split or not kus.get(MAIN_KERNEL):
-            return None
-        ex = 6 * main_f * n / (kus[MAIN_KERNEL] * 1e-6) / 1e12
-        return {"kernel": "oak::" + MAIN_KERNEL, "executed_bf16_tflops": ex, "bf16_dense_peak_tflops": 2500.0, "frac_of_bf16_peak": ex / 2500.0,
-                "note": "6 bf16 MFMA FLOP per algorithmic fp32 FLOP; `peak` of this record stays the fp32 matrix peak (157.3), the dtype "
-                        "the path computes in -- `frac` is algorithmic fp32 FLOP/s over that and is NOT bounded by 1 any more"}
+    def leaf_kernels(kus, party_fraction=1.0):
+        """The call's kernels priced per pipe (SURVEY 8d's per-leaf FLOP split by layer): first layers of the embedding nets on the
+        fp32 matrix pipe (one-hot / dense rows: nnz x 128 multiply-adds per item), their second layers and the main net's three
+        dense layers as bf16 triples on the bf16 pipe (6 partial products per multiply-add), the 256 -> 1 head on the vector pipe
+        (not priced: 512 FLOP per leaf).  party_fraction: the share of the party slots actually re-embedded (configs[2]'s cache)."""
+        p1, p2 = 10 * 2 * 12 * 128 * party_fraction, 10 * 2 * 128 * 59 * party_fraction
+        a1, a2 = 2 * 2 * 45 * 128, 2 * 2 * 128 * 83
+        mainf = main_f - 2 * 256
+        F, B = FP32_MATRIX_TFLOPS * 1e12, BF16_MATRIX_TFLOPS * 1e12
+        ks = [{"name": "oak::k_embed_prows (party slots; half of oak::k_embed_both)", "us": kus["k_embed_prows (party slots)"],
+               "parts": [("first layer (6 dense + 7 one-hot rows per item)", "fp32 MFMA", p1 * n, F), ("second layer 128 -> 59 as bf16 triples", "bf16 MFMA x 6", 6 * p2 * n, B)]},
+              {"name": "oak::k_embed_arows (actives; the other half)", "us": kus["k_embed_arows (actives)"],
+               "parts": [("first layer (36 dense + 17 one-hot / move rows per item)", "fp32 MFMA", a1 * n, F), ("second layer 128 -> 83 as bf16 triples", "bf16 MFMA x 6", 6 * a2 * n, B)]}]
+        if split:
+            ks.append({"name": "oak::" + MAIN_KERNEL, "us": kus[MAIN_KERNEL], "parts": [("768 -> 256 -> 256 -> 256 as bf16 triples", "bf16 MFMA x 6", 6 * mainf * n, B)]})
+        else:
+            ks.append({"name": "oak::" + MAIN_KERNEL, "us": kus[MAIN_KERNEL], "parts": [("768 -> 256 -> 256 -> 256", "fp32 MFMA", mainf * n, F)]})
+        return ks
 
     out = {}
     tj = profile_json()
@@ -566,24 +580,34 @@ def leaf_records(args, torch, dev, rank, local_rank, world, dist, which=("leaf",
     K, W = args.steps, max(args.warmup, 30)
     if "leaf" in which:
         elapsed, avg_s = timed(leaf_step, K, W)
+        kus = kernel_us()
+        frac, rows, tmin, tsum = priced(leaf_kernels(kus))
         achieved = (main_f + emb_f) * n / avg_s / 1e12
         rec = {
             "metric": "leaf-evals/s", "value": n * world * K / elapsed, "unit": "leaf-evals/s", "n_gpus": world, "steps": K,
             "warmup": W, "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak", "dtype": "f32",
             "data": "synthetic",
+            "note": "warmup: at least 30 untimed calls in front of the timed ones whatever --warmup says -- the clocks settle over the first ~15 ms of matrix "
+                    "work after the integer rollout phase, and with the driver's --warmup 5 the timed region measured that ramp",
             "config": {"workload": "leaf part of configs[2]: value_inference (encode + embeddings + 768-256-256-256-1 MainNet + "
                                    "sigmoid) over 65536 mid-game states per GPU", "batch_per_gpu": n,
                        "parity": "<= 1e-5 vs numpy oracle pinned by the reference torch mirror"},
             "arithmetic": ARITH,
+            # `achieved` / `peak` / `frac`: ALGORITHMIC fp32 FLOP per second of the whole call, and what that rate would be with every
+            # layer at the peak of the pipe it runs on (time-weighted over the call's kernels) -- frac = achieved / peak <= 1
             "roofline": {"bound": "mfma", "kernel": "oak::k_embed_both (k_embed_prows + k_embed_arows in one launch) + oak::%s (one value_inference call)" % MAIN_KERNEL,
-                         "achieved": achieved, "peak": 157.3, "unit": "TFLOP/s", "frac": achieved / 157.3,
+                         "achieved": achieved, "peak": achieved / (tmin / avg_s), "unit": "TFLOP/s", "frac": tmin / avg_s,
+                         "frac_note": "sum over the call's layers of (algorithmic work on its pipe / that pipe's dense peak: fp32 MFMA 157.3 TFLOP/s, bf16 MFMA "
+                                      "2,500 TFLOP/s with 6 partial products per multiply-add) / the call's measured time; `kernels` has it per kernel "
+                                      "(durations from HIP events around each launch, a diagnostic pass outside the timed region: "
+                                      "time-weighted %.3f over those)" % frac,
+                         "kernels": rows,
                          "traffic": (tj.get("leaf_hbm_bytes_per_leaf") * n if tj.get("leaf_hbm_bytes_per_leaf") else None),
                          "traffic_source": (PROFILE_SOURCE + ": leaf_hbm_bytes_per_leaf (2 x FETCH_SIZE + WRITE_SIZE of the call's kernels) x batch; not measured in this run")
                          if tj.get("leaf_hbm_bytes_per_leaf") else None,
                          "avg_call_ms": avg_s * 1e3, "algorithmic_flop_per_leaf": main_f + emb_f, "mainnet_flop_per_leaf": main_f,
-                         "kernel_us": kernel_us()},
+                         "kernel_us": kus},
         }
-        rec["roofline"]["main_net"] = main_net_note(rec["roofline"]["kernel_us"])
         rec["policy"] = policy_note(avg_s)
         out["leaf"] = rec
     if "config3" in which:
@@ -601,6 +625,12 @@ def leaf_records(args, torch, dev, rank, local_rank, world, dist, which=("leaf",
         miss_rate = sum(miss) / len(miss)
         party_f = 10 * 2 * (12 * 128 + 128 * 59)
         executed = (main_f + (emb_f - party_f) + party_f * miss_rate) * n / avg_s / 1e12
+        # the step priced per pipe: the turn-step and the tag comparison against the HBM roof with their algorithmic bytes (802 B per
+        # turn-step, 480 B of tags per leaf), the leaf kernels as in `leaf` with the party pass scaled to the slots the cache re-embeds
+        lk = leaf_kernels(out["leaf"]["roofline"]["kernel_us"] if "leaf" in out else kernel_us(), miss_rate)
+        tmin_leaf = sum(w / pk for k_ in lk for _, _, w, pk in k_["parts"])
+        tmin_hbm = (ALGO_BYTES_PER_STEP + 480) * n / (HBM_PEAK_GBPS * 1e9)
+        frac3 = (tmin_leaf + tmin_hbm) / avg_s
         if world > 1:
             s_ = torch.tensor([steps_done], dtype=torch.int64, device=dev)
             dist.all_reduce(s_, op=dist.ReduceOp.SUM)
@@ -609,6 +639,7 @@ def leaf_records(args, torch, dev, rank, local_rank, world, dist, which=("leaf",
             "metric": "turn-steps/s (rollout + leaf eval every turn)", "value": steps_done / elapsed, "unit": "turn-steps/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": elapsed / K * 1e3, "higher_is_better": True,
             "scaling": "weak", "dtype": "f32", "data": "synthetic", "arithmetic": ARITH,
+            "note": "warmup: at least 30 untimed steps (see `leaf`)",
             "config": {"workload": "configs[2]: batch=65536 random OU team pairs per GPU; every step = one random turn-step of the "
                                    "whole batch (in place) + value_inference (768-256-256-256-1) of every lane, party-slot embeddings cached by identity "
                                    "tags (PokemonCache analogue); 40-turn episodes",
@@ -616,14 +647,16 @@ def leaf_records(args, torch, dev, rank, local_rank, world, dist, which=("leaf",
                        "live_lane_fraction": steps_done / (n * world * K)},
             "roofline": {"bound": "mfma", "kernel": "oak::k_rollout_staged (1 turn-step) + oak::k_party_tags + oak::k_embed_both<list> (changed party slots + "
                                                      "actives) + oak::" + MAIN_KERNEL,
-                         "achieved": achieved, "peak": 157.3, "unit": "TFLOP/s", "frac": achieved / 157.3,
-                         "frac_executed": executed / 157.3, "achieved_executed": executed, "party_slot_miss_rate": miss_rate,
+                         "achieved": executed, "peak": executed / frac3, "unit": "TFLOP/s", "frac": frac3,
+                         "frac_note": "EXECUTED work per pipe over the step's measured time: the matrix layers as in `leaf` (the party pass scaled by "
+                                      "party_slot_miss_rate: the cache re-embeds only the changed slots), the turn-step and the tag pass as 802 + 480 "
+                                      "algorithmic bytes per lane against the 8 TB/s HBM roof; `achieved` = executed fp32-equivalent TFLOP/s",
+                         "algorithmic_tflops_if_every_embedding_were_recomputed": achieved, "party_slot_miss_rate": miss_rate,
+                         "us_at_peak": {"matrix_layers": tmin_leaf * 1e6, "turn_step_and_tags_hbm": tmin_hbm * 1e6},
                          "traffic": (tj.get("config3_hbm_bytes_per_lane_turn") * n if tj.get("config3_hbm_bytes_per_lane_turn") else None),
                          "traffic_source": (PROFILE_SOURCE + ": config3_hbm_bytes_per_lane_turn x batch; not measured in this run")
                          if tj.get("config3_hbm_bytes_per_lane_turn") else None,
-                         "avg_step_ms": avg_s * 1e3, "algorithmic_flop_per_leaf": main_f + emb_f,
-                         "note": "frac prices the ALGORITHMIC FLOP (SURVEY 8d: every embedding recomputed per leaf); frac_executed prices what ran: the "
-                                 "cache re-embeds party_slot_miss_rate of the party slots (work-list length read back in an untimed 40-turn pass)"},
+                         "avg_step_ms": avg_s * 1e3, "algorithmic_flop_per_leaf": main_f + emb_f},
         }
         out["config3"] = rec
     if rank == 0 and world == 1 and not args.no_cpu_baseline:   # CPU baselines after both GPU timed regions (see main)
@@ -906,16 +939,26 @@ def valu_issue_peak():
         return 1024 * 2.4e9 / 4, "nominal: 1,024 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction (profiles/r04_valu_issue.json not found)"
 
 
+FP32_MATRIX_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+BF16_MATRIX_TFLOPS = 2500.0     # v_mfma_f32_32x32x16_bf16, dense
+
+
 def priced(kernels):
-    """One roofline fraction for a step made of several kernels on DIFFERENT pipes: each kernel's executed work priced against
-    the peak of the pipe it runs on.  kernels = [{name, pipe, work, peak, unit, us}] (work per step in the unit's numerator).
-    frac = (sum of work / peak) / (sum of measured time): the time the step would take with every kernel at its pipe's peak
-    over the time it took -- bounded by 1 as long as `work` is what really executes."""
-    t_min = sum(k["work"] / k["peak"] for k in kernels)
-    t = sum(k["us"] for k in kernels) * 1e-6
-    rows = [{"kernel": k["name"], "pipe": k["pipe"], "us": k["us"], "achieved": k["work"] / (k["us"] * 1e-6) / k["scale"],
-             "peak": k["peak"] / k["scale"], "unit": k["unit"], "frac": k["work"] / k["peak"] / (k["us"] * 1e-6)} for k in kernels]
-    return t_min / t, rows
+    """One roofline fraction for a step made of several kernels whose layers run on DIFFERENT pipes.  kernels = [{name, us,
+    parts: [(what, pipe, work, peak)]}] with work and peak in the same unit per second (FLOP, FLOP/s -- or bytes, bytes/s).
+    A kernel's t_min = sum over its parts of work / peak (the time it would take with every part at the peak of the pipe it
+    runs on); frac = t_min / measured time, per kernel and -- time-weighted -- for the step: sum of t_min / sum of time.  Work
+    is ALGORITHMIC (an fp32 layer computed as bf16 triples counts its six bf16 partial products: that is the algorithm on
+    that pipe), never more than what executes, so no fraction can exceed 1."""
+    rows, tmin_all, t_all = [], 0.0, 0.0
+    for k in kernels:
+        t = k["us"] * 1e-6
+        tmin = sum(w / pk for _, _, w, pk in k["parts"])
+        rows.append({"kernel": k["name"], "us": k["us"], "frac": tmin / t,
+                     "parts": [{"what": what, "pipe": pipe, "work": w, "peak_per_s": pk, "us_at_peak": w / pk * 1e6} for what, pipe, w, pk in k["parts"]]})
+        tmin_all += tmin
+        t_all += t
+    return tmin_all / t_all, rows, tmin_all, t_all
 
 
 def host_threads():

@@ -1529,10 +1529,14 @@ __device__ __forceinline__ void ms_split_part(const float (&v)[8], bf16x8 (&B)[3
 #pragma unroll
   for (int i = 0; i < 8; ++i)
     if (i >= e0 && i < e1) {
-      const __bf16 hh = (__bf16)v[i];
-      const float r1 = v[i] - (float)hh;
-      const __bf16 mm = (__bf16)r1;
-      B[0][i] = hh; B[1][i] = mm; B[2][i] = (__bf16)(r1 - (float)mm);
+      // by truncation (round 4; see e_split): x = h + m + l EXACTLY, and two vector instructions fewer per value than rounding
+      const uint32_t hb = __float_as_uint(v[i]) & 0xFFFF0000u;
+      const float r1 = v[i] - __uint_as_float(hb);
+      const uint32_t mb = __float_as_uint(r1) & 0xFFFF0000u;
+      const uint32_t lb = __float_as_uint(r1 - __uint_as_float(mb));
+      B[0][i] = __builtin_bit_cast(__bf16, (uint16_t)(hb >> 16));
+      B[1][i] = __builtin_bit_cast(__bf16, (uint16_t)(mb >> 16));
+      B[2][i] = __builtin_bit_cast(__bf16, (uint16_t)(lb >> 16));
     }
 }
 // One k-step: the activation triple B against the NB weight blocks at LDS address `base`.  Software pipeline, one wave per
