@@ -892,14 +892,50 @@ def search_workload(args, torch, dev, rank, local_rank, world, dist):
         t = torch.tensor([elapsed_nn], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed_nn = float(t.item())
+    single_rate = iters * K * world / elapsed_nn
+    # ... and R roots per GPU at once (oakgpu_search_many): one tree per root -- the positions of R self-play games -- each on its own
+    # context and its share of the host cores; a single tree leaves the card mostly idle (its walk is host work).  Every search is
+    # the search it would be alone (tests/test_gpu_search.py::test_concurrent_searches_equal_the_searches_run_alone).
+    from oak_amd.search import tree_search_many
+    R = int(os.environ.get("BENCH_SEARCH_ROOTS", "8"))
+    cores, _src = host_threads()
+    os.environ["OAKGPU_SEARCH_CORES"] = str(cores)           # (the job's CPU share, not the host's affinity mask)
+    rtb, rtd, rtp, rtr = (torch.empty(s_, dtype=torch.uint8, device=dev) for s_ in ((R, 384), (R, 8), (R, 8), (R,)))
+    _lib.check(ctx.lib.oakgpu_random_ou_battles_dev(ctx.handle, C.c_uint64(oakdist.lane_seed0(SEED0 + 4096, R * world, rank, world)), R, P(rtb), P(rtd), P(rtp), P(rtr)))
+    torch.cuda.synchronize(dev)
+    rb_, rd_, rr_ = rtb.cpu().numpy(), rtd.cpu().numpy(), rtr.cpu().numpy()
+    many_ctx = [Context(local_rank) for _ in range(R)]
+    tree_search_many(many_ctx, rb_, rd_, rr_, list(range(R)), iterations=2 * batch, batch=batch, evaluator=net)      # warm-up
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for k in range(K):
+        outs_many = tree_search_many(many_ctx, rb_, rd_, rr_, [100 * k + i for i in range(R)], iterations=iters, batch=batch, evaluator=net)
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    elapsed_many = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed_many], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed_many = float(t.item())
+    for c_ in many_ctx:
+        c_.close()
+    many_rate = iters * K * R * world / elapsed_many
     nn_rec = {"metric": "search iterations/s (tree search, batched network leaf evaluations, exact Nash at the root)",
-              "value": iters * K * world / elapsed_nn, "unit": "iterations/s", "n_gpus": world, "steps": K, "warmup": 1,
-              "ms_per_step": elapsed_nn / K * 1e3, "higher_is_better": True, "scaling": "weak", "dtype": "f32", "data": "synthetic",
+              "value": many_rate, "unit": "iterations/s", "n_gpus": world, "steps": K, "warmup": 1,
+              "ms_per_step": elapsed_many / K * 1e3, "higher_is_better": True, "scaling": "weak", "dtype": "f32", "data": "synthetic",
               "config": {"workload": "configs[4]: MCTS::Search::run with NN::Battle::Network leaves (768-256-256-256-1, seeded synthetic "
                                      "weights), joint UCB (c = 2), 2^18 iterations per search in batches of 16384 descents, exact Nash "
-                                     "of the root's empirical matrix on the host; one random OU turn-1 root per GPU",
-                         "nodes": outs_nn[-1]["nodes"], "mean_depth": outs_nn[-1]["mean_depth"], "nash_value": outs_nn[-1]["nash_value"],
-                         "leaf_evals_per_s": iters * K * world / elapsed_nn}}
+                                     "of the root's empirical matrix on the host; %d random OU turn-1 roots per GPU searched AT ONCE "
+                                     "(oakgpu_search_many: one tree, one context, %d host threads per root); one step = one search of every root" % (R, max(1, cores // R)),
+                         "roots_per_gpu": R, "host_cores": cores,
+                         "nodes": outs_many[-1]["nodes"], "mean_depth": outs_many[-1]["mean_depth"], "nash_value": outs_many[-1]["nash_value"],
+                         "leaf_evals_per_s": many_rate},
+              "one_root_at_a_time": {"value": single_rate, "unit": "iterations/s", "ms_per_search": elapsed_nn / K * 1e3,
+                                     "nodes": outs_nn[-1]["nodes"], "mean_depth": outs_nn[-1]["mean_depth"], "nash_value": outs_nn[-1]["nash_value"],
+                                     "note": "the same search, one root per GPU on all host threads (rounds 2-3's figure)"}}
     net.close()
     ctx.close()
     if rank != 0:

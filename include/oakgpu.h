@@ -325,6 +325,15 @@ int oakgpu_search_heap(oakgpu_ctx *ctx, oakgpu_net *net, oakgpu_heap *heap, cons
                        oakgpu_search_output *out);
 /* RuntimeSearch::run(device, input, heap, agent, output) (util/search.h:66): oakgpu_search_agent with the heap and the
  * output to resume. */
+/* n independent searches at once on ONE GPU: one tree per root (the positions of n self-play games; the reference runs them as N worker
+ * threads that never wait for each other, generate.cc:527-536), search i on ctxs[i] -- every search needs a context of its own (its
+ * stream and batch slots) and, when heaps != NULL, a heap of its own -- with battles n x 384, durations n x 8, results n, params n
+ * entries (seeds!), outs n entries.  Each search is exactly oakgpu_search_heap(ctxs[i], net, heaps[i], ..., NULL, &outs[i]): same output,
+ * same heap, whatever runs beside it.  threads_per_search: host threads of each tree walk (1, 2, 4, 8); 0 = the usable cores shared
+ * evenly (OAKGPU_SEARCH_CORES overrides the affinity mask's count, e.g. under a cgroup quota). */
+int oakgpu_search_many(oakgpu_ctx *const *ctxs, oakgpu_net *net, oakgpu_heap *const *heaps, const uint8_t *battles, const uint8_t *durations,
+                       const uint8_t *results, const oakgpu_search_params *params, uint32_t n, int threads_per_search,
+                       oakgpu_search_output *outs);
 int oakgpu_search_agent_heap(oakgpu_ctx *ctx, oakgpu_heap *heap, const uint8_t *battle, const uint8_t *durations, uint8_t result,
                              const oakgpu_agent *agent, uint32_t batch, uint64_t seed, const oakgpu_search_output *previous,
                              oakgpu_search_output *out);

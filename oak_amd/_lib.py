@@ -17,7 +17,7 @@ SYMBOLS = [
     "oakgpu_leaf_eval_dev", "oakgpu_leaf_eval", "oakgpu_leaf_eval_cached_dev", "oakgpu_leaf_cache_last_count", "oakgpu_leaf_eval_policy_dev", "oakgpu_leaf_eval_policy",
     "oakgpu_heap_create", "oakgpu_heap_destroy", "oakgpu_heap_empty", "oakgpu_heap_clear", "oakgpu_heap_kind", "oakgpu_heap_nodes", "oakgpu_heap_update",
     "oakgpu_heap_root_stats", "oakgpu_heap_child_stats", "oakgpu_search_heap", "oakgpu_search_agent_heap", "oakgpu_heap_check_shards", "oakgpu_heap_selftest",
-    "oakgpu_tree_step_dev", "oakgpu_search", "oakgpu_search_agent", "oakgpu_agent_networks_clear", "oakgpu_bandit_replay", "oakgpu_bandit_select_run", "oakgpu_solve_matrix",
+    "oakgpu_tree_step_dev", "oakgpu_search", "oakgpu_search_many", "oakgpu_search_agent", "oakgpu_agent_networks_clear", "oakgpu_bandit_replay", "oakgpu_bandit_select_run", "oakgpu_solve_matrix",
     "oakgpu_segment_mean_dev", "oakgpu_comm_unique_id", "oakgpu_comm_create", "oakgpu_comm_destroy", "oakgpu_all_gather_dev",
     "oakgpu_frames_size", "oakgpu_frames_write", "oakgpu_frames_read", "oakgpu_selfplay_game", "oakgpu_poke_engine_eval_dev", "oakgpu_poke_engine_eval",
 ]
@@ -128,6 +128,7 @@ def load():
     lib.oakgpu_heap_selftest.argtypes = [u32, u32, u64, i32, C.POINTER(u64 * 4)]
     lib.oakgpu_heap_child_stats.argtypes = [vp, C.c_uint8, C.c_uint8, vp, i32, vp, vp, vp, vp]
     lib.oakgpu_search_heap.argtypes = [vp, vp, vp, vp, vp, C.c_uint8, C.POINTER(SearchParams), C.POINTER(SearchOutput), C.POINTER(SearchOutput)]
+    lib.oakgpu_search_many.argtypes = [C.POINTER(vp), vp, C.POINTER(vp), vp, vp, vp, C.POINTER(SearchParams), u32, i32, C.POINTER(SearchOutput)]
     lib.oakgpu_search_agent_heap.argtypes = [vp, vp, vp, vp, C.c_uint8, C.POINTER(Agent), u32, u64, C.POINTER(SearchOutput), C.POINTER(SearchOutput)]
     lib.oakgpu_segment_mean_dev.argtypes = [vp, vp, u32, u32, vp]
     lib.oakgpu_comm_unique_id.argtypes = [vp]

@@ -1641,7 +1641,7 @@ int oakgpu_synchronize(oakgpu_ctx *c) {
     uint32_t err = 0;
     HIPCHK(hipMemcpy(&err, c->d_queue + 63, 4, hipMemcpyDeviceToHost));
     c->migrate_used = 0;
-    if (err) HIPCHK(hipMemset(c->d_queue + 63, 0, 4));
+    if (err) { HIPCHK(hipMemsetAsync(c->d_queue + 63, 0, 4, c->stream)); HIPCHK(hipStreamSynchronize(c->stream)); }
     if (err) return bad("rollout: a bounded wait of the long-playout migration ran out (playouts were lost) -- oakgpu_set_migration(ctx, 0, ...) turns it off");
   }
   return 0;
@@ -1672,7 +1672,9 @@ static inline uint32_t grid_for(uint32_t n) { return (n + oak::BLOCK - 1) / oak:
 // stream; a slot is reused only after the event behind its previous copy has completed).
 static int launch_group(oakgpu_ctx *c, const oak::BatchDesc *descs, uint32_t count, uint32_t total, uint32_t max_steps, int prep) {
   HIPCHK(hipSetDevice(c->device));
-  if (!c->d_queue) { HIPCHK(hipMalloc((void **)&c->d_queue, 256)); HIPCHK(hipMemset(c->d_queue, 0, 256)); }
+  // (the first clearing covers the sticky word too, ON THE CONTEXT'S STREAM: a hipMemset on the NULL stream is not ordered with a
+  // non-blocking stream and could land in the middle of the first launch -- queue heads zeroed under a running kernel)
+  if (!c->d_queue) { HIPCHK(hipMalloc((void **)&c->d_queue, 256)); HIPCHK(hipMemsetAsync(c->d_queue, 0, 256, c->stream)); }
   if (!c->h_table) {
     HIPCHK(hipHostMalloc((void **)&c->h_table, sizeof(oak::BatchDesc) * oak::MAX_GROUP * oakgpu_ctx::TABLE_SLOTS, hipHostMallocDefault));
     HIPCHK(hipMalloc((void **)&c->d_table, sizeof(oak::BatchDesc) * oak::MAX_GROUP * oakgpu_ctx::TABLE_SLOTS));

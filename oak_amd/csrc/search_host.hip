@@ -486,6 +486,7 @@ struct Slot {
   }
 };
 struct SearchScratch { Slot slots[2]; };
+thread_local int tl_search_threads = 0; // > 0: host threads of the searches started by THIS thread (set by oakgpu_search_many's workers)
 void scratch_dtor(void *p) { delete (SearchScratch *)p; }
 } // namespace
 
@@ -777,7 +778,8 @@ int oakgpu_search_heap(oakgpu_ctx *ctx, oakgpu_net *net, oakgpu_heap *heap, cons
   // half of them; 1 for small batches).  Results do not depend on the count (see Tree)
   int W = 8;
   const char *wenv = getenv("OAKGPU_SEARCH_THREADS");
-  if (wenv) W = atoi(wenv);
+  if (tl_search_threads > 0) W = tl_search_threads; // (oakgpu_search_many: the cores are shared by the concurrent searches)
+  else if (wenv) W = atoi(wenv);
   else {
     unsigned hc = std::thread::hardware_concurrency();
     cpu_set_t set;
@@ -1139,6 +1141,51 @@ bool to_u64(const std::string &s, uint64_t &v) { char *e = nullptr; v = strtoull
 std::mutex g_net_mu;
 std::map<std::pair<int, std::string>, oakgpu_net *> g_nets; // Agent::network_ptr (search.cc:62-148), shared per (device, path)
 } // namespace
+
+// Several independent searches at once: one tree per root (the positions of n self-play games, the roots of a root-parallel search),
+// each on ITS OWN context (stream, batch slots) and its own host threads, all on one GPU.  A single search leaves the card mostly
+// idle -- per 2^18 iterations ~25 ms of host tree walk against ~6 ms of GPU work -- and eight host threads do not speed one tree
+// up eightfold; n trees walked by n x (cores / n) threads keep both sides busy.  Every search is exactly the search
+// oakgpu_search_heap would run with the same arguments (the tree walk does not depend on the thread count): same outputs, same
+// heaps.  The reference's analogue is its worker pool -- N threads, one search each, never waiting for each other
+// (cpp/src/generate.cc:527-536).  threads_per_search: 0 = the usable cores shared evenly (1, 2, 4 or 8 each).
+extern "C" int oakgpu_search_many(oakgpu_ctx *const *ctxs, oakgpu_net *net, oakgpu_heap *const *heaps, const uint8_t *battles, const uint8_t *durations,
+                                  const uint8_t *results, const oakgpu_search_params *params, uint32_t n, int threads_per_search,
+                                  oakgpu_search_output *outs) {
+  if (n == 0) return 0;
+  if (!ctxs || !battles || !durations || !results || !params || !outs) return oakgpu_fail_msg("oakgpu_search_many: null argument");
+  for (uint32_t i = 0; i < n; ++i) {
+    if (!ctxs[i]) return oakgpu_fail_msg("oakgpu_search_many: null context");
+    for (uint32_t k = 0; k < i; ++k)
+      if (ctxs[k] == ctxs[i] || (heaps && heaps[i] && heaps[k] == heaps[i])) return oakgpu_fail_msg("oakgpu_search_many: every search needs a context (and heap) of its own");
+  }
+  int W = threads_per_search;
+  if (W <= 0) {
+    unsigned hc = std::thread::hardware_concurrency();
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof set, &set) == 0) hc = (unsigned)CPU_COUNT(&set);
+    if (const char *e = getenv("OAKGPU_SEARCH_CORES")) hc = (unsigned)atoi(e); // (a cgroup quota below the affinity mask is not visible here)
+    W = (int)(hc / n);
+  }
+  W = W >= 8 ? 8 : W >= 4 ? 4 : W >= 2 ? 2 : 1;
+  std::vector<int> rc(n, 0);
+  std::vector<std::string> err(n);
+  std::vector<std::thread> th;
+  th.reserve(n);
+  static const bool serial = getenv("OAKGPU_SEARCH_MANY_SERIAL") != nullptr; // (diagnostic: the same threads, one after the other)
+  for (uint32_t i = 0; i < n; ++i) {
+    if (serial && !th.empty()) th.back().join();
+    th.emplace_back([&, i] {
+      tl_search_threads = W;
+      rc[i] = oakgpu_search_heap(ctxs[i], net, heaps ? heaps[i] : nullptr, battles + (size_t)i * 384, durations + (size_t)i * 8, results[i], params + i, nullptr, outs + i);
+      if (rc[i]) err[i] = oakgpu_last_error(); // (the error text is per thread: carry it to the caller's)
+    });
+  }
+  for (auto &t : th) if (t.joinable()) t.join();
+  for (uint32_t i = 0; i < n; ++i)
+    if (rc[i]) return oakgpu_fail_msg(("oakgpu_search_many: search " + std::to_string(i) + ": " + err[i]).c_str());
+  return 0;
+}
 
 extern "C" int oakgpu_search_agent_heap(oakgpu_ctx *ctx, oakgpu_heap *heap, const uint8_t *battle, const uint8_t *durations, uint8_t result,
                                         const oakgpu_agent *agent, uint32_t batch, uint64_t seed, const oakgpu_search_output *previous,

@@ -171,6 +171,35 @@ def _output_dict(res):
             "raw": res}          # the oakgpu_search_output itself: pass the dict back as `previous` to resume (mcts.h:153-155)
 
 
+def tree_search_many(ctxs, battles, durations, results, seeds, iterations=1 << 16, batch=4096, c=2.0, bandit="ucb", evaluator="mc",
+                     root_rolls=3, other_rolls=1, max_depth=100, alpha=0.05, heaps=None, threads_per_search=0):
+    """n independent tree searches at once on one GPU (include/oakgpu.h: oakgpu_search_many): search i runs on ctxs[i] (a Context of its
+    own each) from battles[i] with seeds[i]; heaps: None or one Heap per search.  Returns the list of output dicts -- each identical to
+    tree_search(ctxs[i], battles[i], ..., seed=seeds[i]) run alone."""
+    n = len(ctxs)
+    battles = np.ascontiguousarray(battles, dtype=np.uint8).reshape(n, 384)
+    durations = np.ascontiguousarray(durations, dtype=np.uint8).reshape(n, 8)
+    results = np.ascontiguousarray(results, dtype=np.uint8).reshape(n)
+    use_net = not isinstance(evaluator, str)
+    prms = (_lib.SearchParams * n)()
+    for i in range(n):
+        prms[i] = _lib.SearchParams(iterations=int(iterations), batch=int(batch), ucb_c=float(c), bandit={"ucb": 0, "pucb": 1, "ucb1": 2, "exp3": 3, "pexp3": 4}[bandit],
+                                    eval=1 if use_net else {"mc": 0, "poke-engine": 2}[evaluator], max_depth=int(max_depth), root_rolls=int(root_rolls),
+                                    other_rolls=int(other_rolls), seed=int(seeds[i]), matrix_ucb=0, mucb_delay=0, mucb_minimum=0, mucb_c=0.0,
+                                    exp3_alpha=float(alpha), duration_us=0)
+    outs = (_lib.SearchOutput * n)()
+    cp = (C.c_void_p * n)(*[c_.handle for c_ in ctxs])
+    hp = (C.c_void_p * n)(*[h.handle for h in heaps]) if heaps is not None else None
+    _lib.check(ctxs[0].lib.oakgpu_search_many(cp, evaluator.handle if use_net else None, hp, battles.ctypes.data_as(C.c_void_p),
+                                              durations.ctypes.data_as(C.c_void_p), results.ctypes.data_as(C.c_void_p), prms, n, int(threads_per_search), outs))
+    res = []
+    for i in range(n):   # (_output_dict keeps a reference to its raw struct: give each its own copy)
+        o = _lib.SearchOutput()
+        C.memmove(C.byref(o), C.byref(outs[i]), C.sizeof(_lib.SearchOutput))
+        res.append(_output_dict(o))
+    return res
+
+
 def tree_search(ctx, battle, durations, result, iterations=1 << 16, batch=4096, c=2.0, bandit="ucb", evaluator="mc",
                 root_rolls=3, other_rolls=1, max_depth=100, seed=0x5EED, matrix_ucb=None, alpha=0.05, heap=None, previous=None,
                 duration_us=0):

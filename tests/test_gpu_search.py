@@ -390,3 +390,38 @@ def test_tutorial_known_answer_snorlax_vs_starmie(gpu_ctx):
     assert abs(mean[r1["bodyslam"], r2["thunderwave"]] - 0.443) <= 0.05, report
     assert abs(mean[r1["bodyslam"], r2["psychic"]] - 0.602) <= 0.05, report
     assert o["p1_empirical"][r1["bodyslam"]] > 0.9 and o["p2_empirical"][r2["thunderwave"]] > 0.8, report
+
+
+def test_concurrent_searches_equal_the_searches_run_alone(gpu_ctx):
+    """oakgpu_search_many (several roots per GPU at once): six independent searches on six contexts, their tree walks
+    on two host threads each, Monte-Carlo leaves and -- a second round -- network leaves with PUCB priors: every output (visit and
+    value matrices, node counts, Nash value) equals the same search run alone on the primary context, and so do the heaps' roots."""
+    import oracle_lib as O
+    from oak_amd.engine import Context, Network
+    from oak_amd.search import Heap, tree_search, tree_search_many
+    n = 6
+    b, d, p, r = O.make_random_ou_batch(n, seed0=0x51DE5)
+    ctxs = [Context(0) for _ in range(n)]
+    net = Network(gpu_ctx, path=os.path.join(ROOT, "tests", "golden", "net_default.battle.net"))
+    try:
+        for kw in (dict(evaluator="mc", bandit="ucb", c=2.0), dict(evaluator=net, bandit="pucb", c=1.0)):
+            seeds = [1000 + 17 * i for i in range(n)]
+            heaps = [Heap() for _ in range(n)]
+            many = tree_search_many(ctxs, b, d, r, seeds, iterations=1 << 13, batch=1024, heaps=heaps, threads_per_search=2, **kw)
+            for i in range(n):
+                h = Heap()
+                alone = tree_search(gpu_ctx, b[i], d[i], int(r[i]), iterations=1 << 13, batch=1024, seed=seeds[i], heap=h, **kw)
+                for key in ("visit_matrix", "value_matrix"):
+                    assert (many[i][key] == alone[key]).all(), (i, key)
+                assert many[i]["nodes"] == alone["nodes"] and many[i]["iterations"] == alone["iterations"] == 1 << 13
+                assert many[i]["nash_value"] == alone["nash_value"] and many[i]["mean_depth"] == alone["mean_depth"]
+                for pl in (0, 1):
+                    for x, y in zip(heaps[i].root_stats(pl), h.root_stats(pl)):
+                        assert x.tobytes() == y.tobytes()
+                h.close()
+            for h in heaps:
+                h.close()
+    finally:
+        net.close()
+        for c in ctxs:
+            c.close()
