@@ -391,6 +391,14 @@ int oakgpu_selfplay_game(oakgpu_ctx *ctx, oakgpu_net *net /* nullable for eval !
                          uint64_t battle_seed, oakgpu_selfplay_params *params, uint8_t *buffer, size_t capacity,
                          size_t *written, uint32_t *n_frames, uint8_t *result);
 
+/* n self-play games at once on one GPU (the generator's N worker threads, generate.cc:527-536): game g on ctxs[g] -- a context of its own
+ * each -- with teams + 60 g, battle_seeds[g], params[g]; its record goes to buffers + g * capacity_each, written[g] / n_frames[g] /
+ * results[g] as oakgpu_selfplay_game returns them.  Every game is byte for byte the game it would be alone.  threads_per_game: host
+ * threads of each game's tree walks (1, 2, 4, 8); 0 = the usable cores shared evenly. */
+int oakgpu_selfplay_games(oakgpu_ctx *const *ctxs, oakgpu_net *net, const uint8_t *teams, const uint64_t *battle_seeds, oakgpu_selfplay_params *params,
+                          uint32_t n, int threads_per_game, uint8_t *buffers, size_t capacity_each, size_t *written, uint32_t *n_frames,
+                          uint8_t *results);
+
 /* ---- batched PKMN::battle(p1, p2, seed) (pkmn.h:50-57, init.h:90-154), level 100 sets.
  * teams: n x 60 bytes; seeds: n x u64; with first_update != 0 also performs the opening
  * update(battle, 0, 0) (benchmark.cc:29) and writes its result byte. */

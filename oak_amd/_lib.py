@@ -19,7 +19,7 @@ SYMBOLS = [
     "oakgpu_heap_root_stats", "oakgpu_heap_child_stats", "oakgpu_search_heap", "oakgpu_search_agent_heap", "oakgpu_heap_check_shards", "oakgpu_heap_selftest",
     "oakgpu_tree_step_dev", "oakgpu_search", "oakgpu_search_many", "oakgpu_search_agent", "oakgpu_agent_networks_clear", "oakgpu_bandit_replay", "oakgpu_bandit_select_run", "oakgpu_solve_matrix",
     "oakgpu_segment_mean_dev", "oakgpu_comm_unique_id", "oakgpu_comm_create", "oakgpu_comm_destroy", "oakgpu_all_gather_dev",
-    "oakgpu_frames_size", "oakgpu_frames_write", "oakgpu_frames_read", "oakgpu_selfplay_game", "oakgpu_poke_engine_eval_dev", "oakgpu_poke_engine_eval",
+    "oakgpu_frames_size", "oakgpu_frames_write", "oakgpu_frames_read", "oakgpu_selfplay_game", "oakgpu_selfplay_games", "oakgpu_poke_engine_eval_dev", "oakgpu_poke_engine_eval",
 ]
 
 
@@ -142,6 +142,8 @@ def load():
     lib.oakgpu_frames_read.argtypes = [vp, C.c_size_t, vp, C.POINTER(C.c_uint8), C.POINTER(FrameUpdate), u32, C.POINTER(u32), C.POINTER(C.c_size_t)]
     lib.oakgpu_selfplay_game.argtypes = [vp, vp, vp, u64, C.POINTER(SelfplayParams), vp, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(u32),
                                          C.POINTER(C.c_uint8)]
+    lib.oakgpu_selfplay_games.argtypes = [C.POINTER(vp), vp, vp, C.POINTER(u64), C.POINTER(SelfplayParams), u32, i32, vp, C.c_size_t, C.POINTER(C.c_size_t),
+                                          C.POINTER(u32), C.POINTER(C.c_uint8)]
     lib.oakgpu_search_agent.argtypes = [vp, vp, vp, C.c_uint8, C.POINTER(Agent), u32, u64, C.POINTER(SearchOutput)]
     lib.oakgpu_agent_networks_clear.argtypes = [vp]
     lib.oakgpu_agent_networks_clear.restype = None

@@ -34,3 +34,6 @@ void oakgpu_ctx_set_attachment(oakgpu_ctx *ctx, void *p, void (*dtor)(void *));
 // do not fill the device then run in regrouping rounds, whose dispatch boundaries let the other context's small kernels in.
 // Returns the previous value.
 int oakgpu_ctx_set_concurrent_hint(oakgpu_ctx *ctx, int on);
+// Host threads of the tree walks started by the CALLING thread (0 = the default rule): callers that run several searches side
+// by side -- oakgpu_search_many, oakgpu_selfplay_games -- give each its share of the cores.
+void oakgpu_set_thread_search_threads(int threads);

@@ -1142,6 +1142,8 @@ std::mutex g_net_mu;
 std::map<std::pair<int, std::string>, oakgpu_net *> g_nets; // Agent::network_ptr (search.cc:62-148), shared per (device, path)
 } // namespace
 
+void oakgpu_set_thread_search_threads(int threads) { tl_search_threads = threads > 0 ? threads : 0; }
+
 // Several independent searches at once: one tree per root (the positions of n self-play games, the roots of a root-parallel search),
 // each on ITS OWN context (stream, batch slots) and its own host threads, all on one GPU.  A single search leaves the card mostly
 // idle -- per 2^18 iterations ~25 ms of host tree walk against ~6 ms of GPU work -- and eight host threads do not speed one tree

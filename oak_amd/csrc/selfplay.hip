@@ -20,6 +20,7 @@
 #include <algorithm>
 #include <cmath>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/oakgpu.h"
@@ -182,7 +183,16 @@ int oakgpu_selfplay_game(oakgpu_ctx *ctx, oakgpu_net *net, const uint8_t *teams,
     if (frames.size() >= max_len) return oakgpu_fail_msg("oakgpu_selfplay_game: max battle length exceeded (generate.cc:268-271)");
     oakgpu_search_output out;
     sp.seed = splitmix64(rng);
-    if (int rc = oakgpu_search_heap(ctx, net, heap.h, battle, durations, result, &sp, nullptr, &out)) return rc;
+    int src = oakgpu_search_heap(ctx, net, heap.h, battle, durations, result, &sp, nullptr, &out);
+    if (src && heap.h && strstr(oakgpu_last_error(), "other action counts")) {
+      // --keep-node: the kept child was expanded by a playout whose RESAMPLED hidden variables (mcts.h:254-259) gave it other
+      // legal choices than the position the game really reached (a thrash / bide counter that ran out in one and not in the
+      // other).  Its statistics are about another decision: start this position's tree afresh, like an update that found no child.
+      oakgpu_heap_clear(heap.h);
+      if (prm->nodes_kept) --prm->nodes_kept;
+      src = oakgpu_search_heap(ctx, net, heap.h, battle, durations, result, &sp, nullptr, &out);
+    }
+    if (src) return src;
     double pol1[9], pol2[9];
     if (!get_policy(out.p1_prior, out.p1_empirical, out.p1_nash, out.m, prm->policy_mode, prm->policy_temp > 0 ? prm->policy_temp : 1.0, prm->policy_min, pol1) ||
         !get_policy(out.p2_prior, out.p2_empirical, out.p2_nash, out.n, prm->policy_mode, prm->policy_temp > 0 ? prm->policy_temp : 1.0, prm->policy_min, pol2))
@@ -204,6 +214,45 @@ int oakgpu_selfplay_game(oakgpu_ctx *ctx, oakgpu_net *net, const uint8_t *teams,
   if (result_out) *result_out = result;
   if (n_frames) *n_frames = (uint32_t)frames.size();
   return oakgpu_frames_write(first, result, frames.data(), (uint32_t)frames.size(), buffer, capacity, written);
+}
+
+// n self-play games at once on one GPU -- the generator's worker pool (generate.cc:527-536: N threads, one game each, never waiting
+// for each other): game g runs oakgpu_selfplay_game on ctxs[g] (a context of its own each) with teams[g], battle_seeds[g], params[g],
+// its record into buffers + g * capacity_each.  One game at a time leaves the card idle for most of every search (the tree walk is host
+// work); n games keep n trees in flight.  Every game is the game it would be alone.  threads_per_game: host threads of each game's tree
+// walks (1, 2, 4, 8); 0 = the usable cores shared evenly (OAKGPU_SEARCH_CORES overrides the affinity mask's count).
+int oakgpu_selfplay_games(oakgpu_ctx *const *ctxs, oakgpu_net *net, const uint8_t *teams, const uint64_t *battle_seeds, oakgpu_selfplay_params *params,
+                          uint32_t n, int threads_per_game, uint8_t *buffers, size_t capacity_each, size_t *written, uint32_t *n_frames, uint8_t *results) {
+  if (n == 0) return 0;
+  if (!ctxs || !teams || !battle_seeds || !params || !buffers || !written) return oakgpu_fail_msg("oakgpu_selfplay_games: null argument");
+  for (uint32_t g = 0; g < n; ++g) {
+    if (!ctxs[g]) return oakgpu_fail_msg("oakgpu_selfplay_games: null context");
+    for (uint32_t k = 0; k < g; ++k) if (ctxs[k] == ctxs[g]) return oakgpu_fail_msg("oakgpu_selfplay_games: every game needs a context of its own");
+  }
+  int W = threads_per_game;
+  if (W <= 0) {
+    unsigned hc = std::thread::hardware_concurrency();
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof set, &set) == 0) hc = (unsigned)CPU_COUNT(&set);
+    if (const char *e = getenv("OAKGPU_SEARCH_CORES")) hc = (unsigned)atoi(e);
+    W = (int)(hc / n);
+  }
+  W = W >= 8 ? 8 : W >= 4 ? 4 : W >= 2 ? 2 : 1;
+  std::vector<int> rc(n, 0);
+  std::vector<std::string> err(n);
+  std::vector<std::thread> th;
+  th.reserve(n);
+  for (uint32_t g = 0; g < n; ++g)
+    th.emplace_back([&, g] {
+      oakgpu_set_thread_search_threads(W);
+      rc[g] = oakgpu_selfplay_game(ctxs[g], net, teams + (size_t)g * 60, battle_seeds[g], params + g, buffers + (size_t)g * capacity_each, capacity_each,
+                                   written + g, n_frames ? n_frames + g : nullptr, results ? results + g : nullptr);
+      if (rc[g]) err[g] = oakgpu_last_error();
+    });
+  for (auto &t : th) t.join();
+  for (uint32_t g = 0; g < n; ++g)
+    if (rc[g]) return oakgpu_fail_msg(("oakgpu_selfplay_games: game " + std::to_string(g) + ": " + err[g]).c_str());
+  return 0;
 }
 
 } // extern "C"

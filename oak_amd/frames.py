@@ -81,3 +81,33 @@ def selfplay_game(ctx, teams, battle_seed, iterations=1 << 12, batch=1024, bandi
     if stats is not None:
         stats["nodes_kept"] = int(prm.nodes_kept)
     return out[:written.value].tobytes(), int(frames.value), int(result.value)
+
+
+def selfplay_games(ctxs, teams, battle_seeds, seeds, iterations=1 << 12, batch=1024, bandit="ucb", c=2.0, evaluator="mc", policy_mode="e",
+                   policy_temp=1.0, policy_min=0.0, max_battle_length=0, alpha=0.05, root_rolls=3, other_rolls=1, keep_node=False,
+                   threads_per_game=0):
+    """n self-play games at once on one GPU (oakgpu_selfplay_games): game g on ctxs[g] with teams[g] (uint8[n, 2, 6, 5]), battle_seeds[g]
+    and policy seed seeds[g].  Returns a list of (record bytes, number of frames, final result byte) -- each what selfplay_game(ctxs[g],
+    teams[g], battle_seeds[g], seed=seeds[g], ...) returns alone."""
+    n = len(ctxs)
+    use_net = not isinstance(evaluator, str)
+    prms = (_lib.SelfplayParams * n)()
+    for g in range(n):
+        prms[g].search = _lib.SearchParams(iterations=int(iterations), batch=int(batch), ucb_c=float(c),
+                                           bandit={"ucb": 0, "pucb": 1, "ucb1": 2, "exp3": 3, "pexp3": 4}[bandit],
+                                           eval=1 if use_net else {"mc": 0, "poke-engine": 2}[evaluator], max_depth=0, root_rolls=int(root_rolls),
+                                           other_rolls=int(other_rolls), seed=0, matrix_ucb=0, mucb_delay=0, mucb_minimum=0, mucb_c=0.0,
+                                           exp3_alpha=float(alpha))
+        prms[g].policy_mode = policy_mode.encode()
+        prms[g].policy_temp, prms[g].policy_min = float(policy_temp), float(policy_min)
+        prms[g].max_battle_length, prms[g].seed = int(max_battle_length), int(seeds[g])
+        prms[g].keep_node = 1 if keep_node else 0
+    t = np.ascontiguousarray(teams, dtype=np.uint8).reshape(n, 60)
+    bs = (C.c_uint64 * n)(*[int(x) for x in battle_seeds])
+    cap = 4 + 2 + 384 + 1 + 83 * (int(max_battle_length) or 1000)
+    out = np.zeros((n, cap), dtype=np.uint8)
+    written, frames, result = (C.c_size_t * n)(), (C.c_uint32 * n)(), (C.c_uint8 * n)()
+    cp = (C.c_void_p * n)(*[c_.handle for c_ in ctxs])
+    _lib.check(ctxs[0].lib.oakgpu_selfplay_games(cp, evaluator.handle if use_net else None, t.ctypes.data_as(C.c_void_p), bs, prms, n, int(threads_per_game),
+                                                 out.ctypes.data_as(C.c_void_p), cap, written, frames, result))
+    return [(out[g, :written[g]].tobytes(), int(frames[g]), int(result[g])) for g in range(n)]

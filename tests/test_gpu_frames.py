@@ -82,3 +82,26 @@ def test_selfplay_keep_node_searches_on_in_the_played_subtree(gpu_ctx):
     assert len(game["updates"]) == frames and _replay(gpu_ctx, game) == result
     assert all(u["iterations"] == 2048 for u in game["updates"])
     assert 0 < stats["nodes_kept"] <= frames and stats["nodes_kept"] >= frames // 4
+
+
+def test_concurrent_selfplay_games_are_the_games_played_alone(gpu_ctx):
+    """oakgpu_selfplay_games (the generator's worker pool on one GPU, generate.cc:527-536): four games at once on four contexts, two
+    host threads per game's tree walks, with and without --keep-node -- every record is byte for byte the record of the same game
+    played alone, and replays to its stored result."""
+    from oak_amd.engine import Context
+    from oak_amd.frames import selfplay_games
+    teams = np.array(benchmark_teams(), dtype=np.uint8)
+    n = 4
+    ctxs = [Context(0) for _ in range(n)]
+    try:
+        for keep in (False, True):
+            kw = dict(iterations=512, batch=256, bandit="ucb", c=2.0, evaluator="mc", policy_mode="e", keep_node=keep)
+            many = selfplay_games(ctxs, np.stack([teams] * n), [2000 + g for g in range(n)], [g + 1 for g in range(n)], threads_per_game=2, **kw)
+            for g in range(n):
+                alone = selfplay_game(gpu_ctx, teams, battle_seed=2000 + g, seed=g + 1, **kw)
+                assert many[g] == alone, (keep, g, many[g][1:], alone[1:])
+            game = read_frames(many[0][0])[0]
+            assert _replay(gpu_ctx, game) == game["result"] == many[0][2]
+    finally:
+        for c in ctxs:
+            c.close()
