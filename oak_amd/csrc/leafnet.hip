@@ -518,10 +518,10 @@ constexpr int ER_ITEMS = 32, ER_RS = 128; // items per wave mini-tile; LDS weigh
 //   second layer : the 128 hidden activations of an item as triples against W1's triples (LDS, prebuilt), the six largest partial
 //                  products per 32x32x16 block, fp32 accumulation: 8 k-steps x 6 x NBo MFMAs of 32 cycles (party 96: 3.1 k cycles
 //                  against 8.2 k) -- fp32 results (dropped terms < 2^-24 of a product);
-//   transposition: ALSO tried on the bf16 pipe (the one-hot selector is exact in bf16: three MFMAs move the (h, m, l) parts of four
-//                  k-steps' row sums into the item lanes at once, 48 MFMAs of 32 cycles instead of 64 of 64) and dropped: with the
-//                  second layer off the fp32 pipe the kernels are bound by the instructions a wave issues, and splitting the row
-//                  sums costs ~1,000 more of them per mini-tile (first layer 12.2 k cycles per mini-tile against 9.8 k).
+//   transposition: on the bf16 pipe too (SelTranspose below: the one-hot selector is exact in bf16; twelve MFMAs move the (h, m, l)
+//                  parts of four k-steps' row sums into the item lanes).  A first attempt with the round-to-nearest split cost
+//                  ~1,000 more vector instructions per mini-tile and lost; with the truncation split it is 352, and the fp32
+//                  MFMAs it replaces turned out to hold the vector issue for their whole 64 cycles.
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 constexpr int E2_BLOCK_BYTES = 8 * 3 * 1024; // W1's triples of one 32-wide output block: [k-step T][h m l][lane] x 16 B
 // v[0..7] as their bf16 triples, by TRUNCATION: h = the top 16 bits of x (its 8 leading significant bits), m = the top 16 bits of
@@ -546,6 +546,108 @@ __device__ __forceinline__ void e_split(const float (&v)[8], bf16x8 (&P)[3]) {
     pl[i] = __builtin_amdgcn_perm(lb[2 * i + 1], lb[2 * i], 0x07060302u);
   }
   P[0] = __builtin_bit_cast(bf16x8, ph); P[1] = __builtin_bit_cast(bf16x8, pm); P[2] = __builtin_bit_cast(bf16x8, pl);
+}
+// First layer, the selector transposition on the bf16 pipe.  In k-step t the half-wave hh holds the row sums of item 2 t + hh,
+// lane (i, hh) the channels 4 i .. 4 i + 3 (`sum`); the second layer wants "lane = item".  D[channel i][item n] += sum over k of
+// A[i][k] S[k][n] with a one-hot selector S[k][n] = [item of k == n] does it, and S is exact in bf16 -- but the sums are fp32, so
+// they go through as their (h, m, l) triples (truncation split, e_split): 16 + 6 vector instructions per k-step and 12
+// v_mfma_f32_32x32x8_bf16 per FOUR k-steps (element j of lane (i, kh) = k-step 4 G + j, item 2 (4 G + j) + kh), against four
+// v_mfma_f32_32x32x2_f32 per k-step.  The fp32 MFMA is the expensive one: tools/experiments/mfma_overlap_bench.hip shows that a
+// 32x32x2 fp32 MFMA holds the SIMD's vector issue for ALL of its 64 cycles (time = pipe + issue: it runs on the vector ALUs),
+// while the bf16 ones overlap with vector work (hold: 8 cycles).  Each (channel, item) receives exactly one non-zero term per
+// part, l then m then h, so the result is the fp32 sum to within two roundings of the accumulator.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+struct SelTranspose {
+  uint32_t pe[4][3];    // the even k-step's parts, waiting for the odd one
+  uint32_t pa[4][3][2]; // four k-steps packed: [component][part][pair]
+  __device__ __forceinline__ void step(const int t, const float4 &sum, f32x16 (&hb)[4], const uint32_t r32, const uint32_t hh) {
+    const float v[4] = {sum.x, sum.y, sum.z, sum.w};
+    uint32_t p[4][3];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      p[c][0] = __float_as_uint(v[c]) & 0xFFFF0000u;
+      const float r1 = v[c] - __uint_as_float(p[c][0]);
+      p[c][1] = __float_as_uint(r1) & 0xFFFF0000u;
+      p[c][2] = __float_as_uint(r1 - __uint_as_float(p[c][1]));
+    }
+    if ((t & 1) == 0) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) pe[c][q] = p[c][q];
+      return;
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int q = 0; q < 3; ++q) pa[c][q][(t >> 1) & 1] = __builtin_amdgcn_perm(p[c][q], pe[c][q], 0x07060302u); // even step low half, odd step high half
+    if ((t & 3) != 3) return;
+    // the selector of this group of four k-steps: element j of lane (n, kh) is 1.0 iff n == 2 (4 G + j) + kh
+    const int e = (int)r32 - (int)hh - 8 * (t >> 2);
+    typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+    u32x2 sel;
+    sel[0] = e == 0 ? 0x3F80u : e == 2 ? 0x3F800000u : 0u;
+    sel[1] = e == 4 ? 0x3F80u : e == 6 ? 0x3F800000u : 0u;
+    const s16x4 S = __builtin_bit_cast(s16x4, sel);
+#pragma unroll
+    for (int q = 2; q >= 0; --q) // l, m, h: small parts first
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        u32x2 a;
+        a[0] = pa[c][q][0]; a[1] = pa[c][q][1];
+        hb[c] = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(__builtin_bit_cast(s16x4, a), S, hb[c], 0, 0, 0);
+      }
+  }
+};
+// First layer, the DENSE features (bias, stats, boosts, volatiles: the weight row is the same for every item, only the value
+// differs) on the bf16 pipe as well: H^T = W0d^T . X^T with both sides as triples, v_mfma_f32_32x32x8_bf16, KT k-steps of eight
+// features.  Lane (item r, kh) holds the values of features 8 T + 4 kh + j (xv[T][j]) -> their triples xp; the weights'
+// triples are prebuilt in LDS, 8 bytes per lane: [T][channel block][h m l][lane], lane (i, kh) element j = W0[channel 4 i + blk]
+// [row of feature 8 T + 4 kh + j] (feature 0 = the bias).  Six products per block and k-step as in embed_layer2.  On the fp32 pipe
+// (v_mfma_f32_32x32x2_f32, 64 cycles each, vector issue held throughout) the actives' 36 features cost 4.6 k cycles per mini-tile.
+template <int KT>
+__device__ __forceinline__ void dense_split(const float (&xv)[KT][4], uint32_t (&xp)[KT][3][2]) {
+#pragma unroll
+  for (int T = 0; T < KT; ++T) {
+    uint32_t p[4][3];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      p[j][0] = __float_as_uint(xv[T][j]) & 0xFFFF0000u;
+      const float r1 = xv[T][j] - __uint_as_float(p[j][0]);
+      p[j][1] = __float_as_uint(r1) & 0xFFFF0000u;
+      p[j][2] = __float_as_uint(r1 - __uint_as_float(p[j][1]));
+    }
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      xp[T][q][0] = __builtin_amdgcn_perm(p[1][q], p[0][q], 0x07060302u);
+      xp[T][q][1] = __builtin_amdgcn_perm(p[3][q], p[2][q], 0x07060302u);
+    }
+  }
+}
+template <int KT>
+__device__ __forceinline__ void dense_layer_bf16(const uint8_t *wd_lane, const uint32_t (&xp)[KT][3][2], f32x16 (&hb)[4]) {
+  typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+#pragma unroll
+  for (int T = 0; T < KT; ++T) {
+    s16x4 X[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      u32x2 v;
+      v[0] = xp[T][q][0]; v[1] = xp[T][q][1];
+      X[q] = __builtin_bit_cast(s16x4, v);
+    }
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const uint8_t *p = wd_lane + (T * 4 + b) * 3 * 512;
+      const s16x4 W0 = *(const s16x4 *)p, W1 = *(const s16x4 *)(p + 512), W2 = *(const s16x4 *)(p + 1024);
+      hb[b] = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(W0, X[2], hb[b], 0, 0, 0); // h . l  (small terms first)
+      hb[b] = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(W2, X[0], hb[b], 0, 0, 0); // l . h
+      hb[b] = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(W1, X[1], hb[b], 0, 0, 0); // m . m
+      hb[b] = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(W0, X[1], hb[b], 0, 0, 0); // h . m
+      hb[b] = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(W1, X[0], hb[b], 0, 0, 0); // m . h
+      hb[b] = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(W0, X[0], hb[b], 0, 0, 0); // h . h
+    }
+  }
 }
 // Second layer: hb = the item's 128 activated hidden channels (lane (item r, hh): register s of block b = channel ar_channel),
 // w1t = this lane's 16 bytes of W1's triple image in LDS.  Orientation Out^T = W1 . H^T: the weights are the A operand (lane
@@ -677,7 +779,7 @@ __device__ __forceinline__ void zero_blocks(float *emb, uint32_t dead_off, int l
 // ONE 16-wave workgroup (4 waves per SIMD).  LDS: 65 x 528 B rows + 18 KB dense fragment + <= 64 KB W1 fragments + 1.4 KB
 // per wave (row indices) = <= 141 KB, staged from one prebuilt image (stage_image_load / _store).
 constexpr int AR_SPARSE = 64, AR_ZERO = 64;   // LDS-resident one-hot rows (ar_sparse_slot) + a zero row
-constexpr int AR_FIXED = 36, AR_HOT = 9, AR_MOVES = 8, AR_KSTEPS = AR_FIXED / 2;
+constexpr int AR_FIXED = 36, AR_HOT = 9, AR_MOVES = 8, AR_KT = (AR_FIXED + 7) / 8; // (dense features in k-steps of eight)
 constexpr int AR_ITEM_WORDS = 20;               // ready to use: 9 LDS byte offsets of the item's one-hot rows, 8 byte offsets of its move rows in L2 (+ 3 pad)
 constexpr int AR_WAVE_WORDS = ER_ITEMS * AR_ITEM_WORDS;
 #ifndef OAK_EMBED_WAVES
@@ -686,7 +788,8 @@ constexpr int AR_WAVE_WORDS = ER_ITEMS * AR_ITEM_WORDS;
 // 8 waves of <= 256 registers (2 per SIMD): no scratch.  Measured, round 4, with the second layer on the bf16 pipe: 16 waves of
 // 128 registers spill 150-400 of them (party pass 633 us), 12 of 168 spill 60-130 (246 us), 8 of 256 none (140 us).
 constexpr int AR_WAVES = OAK_EMBED_WAVES, AR_BLOCK = 64 * AR_WAVES;
-constexpr int AR_DENSE_WORDS = AR_KSTEPS * 4 * 64; // the dense weight fragment: [k-step][channel block][lane]
+constexpr int AR_DENSE_WORDS = AR_KT * 4 * 3 * 64 * 2; // the dense weights' triples: [k-step][channel block][h m l][lane] x 8 B (dense_layer_bf16)
+constexpr int AR_COMBINED = 428; // first precombined (active + stored) move row of a_w0d: behind W0^T's 427 rows and the zero row
 constexpr int AR_MAX_NBO = 3; // W1 as bf16 triples: 24 KB per 32-wide output block; four blocks (outputs above 96) do not fit beside the rest
 constexpr size_t ar_bytes(int nbo) { return (size_t)((AR_SPARSE + 1) * ER_RS + AR_DENSE_WORDS + AR_WAVES * AR_WAVE_WORDS + 32 * nbo) * 4 + (size_t)nbo * E2_BLOCK_BYTES; }
 // channel held by register s (0..63) of a lane in half hh: the C layout of four 32x32 MFMA blocks, block b's row i being
@@ -718,13 +821,13 @@ __device__ __forceinline__ void embed_arows_body(const EmbedTileArgs &a, float *
   const uint32_t nmt = (items + ER_ITEMS - 1) / ER_ITEMS;
   const uint32_t stride = nblocks * WAVES;
   EL_MARK(0);
-  // ---- encode, in three parts.  LOAD 1 (at the top of the previous mini-tile's body): both lanes (r, 0) and (r, 1) ask for item
-  // r's active block, the slot of its stored Pokemon and the durations word; LOAD 2 (behind that body's first layer, when LOAD
-  // 1 has long arrived): the stored Pokemon; nothing waits for either.  COMPUTE (behind its second layer): the same
+  // ---- encode, in three parts.  LOAD 1 (at the top of the previous mini-tile's body): both lanes (r, 0) and (r, 1) ask for the
+  // slot of item r's stored Pokemon and the durations word; LOAD 2 (behind that body's first layer, when LOAD 1 has long
+  // arrived): the active block and the stored Pokemon; nothing waits for either.  COMPUTE (behind its second layer): the same
   // instructions for the whole wave; each lane keeps the dense values of its own k-half in registers (x[t] = value 2t + hh,
   // the B operand below) and lane (r, 0) writes the row indices to the wave's LDS.  The wave's first encode runs BEFORE the
   // weights are written to LDS (it needs none): the image's round trip hides under it ----
-  float x[AR_KSTEPS];
+  uint32_t xp[AR_KT][3][2]; // the dense values of this lane's k-half as bf16 triples (dense_split)
   uint32_t my_doff = 0xFFFFFFFFu; // this lane's item: its block of the embedding (both lanes (r, 0), (r, 1) hold item r's) and hp ratio
   float my_hpr = 0.0f;
   uint4 in_av0 = make_uint4(0, 0, 0, 0), in_av1 = in_av0;
@@ -735,7 +838,6 @@ __device__ __forceinline__ void embed_arows_body(const EmbedTileArgs &a, float *
     if (g < items) {
       const uint32_t leaf = g >> 1, side = g & 1;
       const uint32_t *sb = (const uint32_t *)a.battles + (size_t)leaf * 96 + side * 46;
-      in_av0 = *(const uint4 *)(sb + 36); in_av1 = *(const uint4 *)(sb + 40);
       in_id = sb[44] & 0xFF;
       in_dur = ((const uint32_t *)a.durations)[(size_t)leaf * 2 + side];
     }
@@ -745,6 +847,10 @@ __device__ __forceinline__ void embed_arows_body(const EmbedTileArgs &a, float *
     const uint32_t g = mt * ER_ITEMS + r32;
 #pragma unroll
     for (int k = 0; k < 6; ++k) in_pk[k] = 0;
+    if (g < items) { // (the active block with LOAD 2: eight registers less across the first layer, which has none to spare)
+      const uint32_t *sb = (const uint32_t *)a.battles + (size_t)(g >> 1) * 96 + (g & 1) * 46;
+      in_av0 = *(const uint4 *)(sb + 36); in_av1 = *(const uint4 *)(sb + 40);
+    }
     if (g < items && in_id != 0) {
       const uint32_t leaf = g >> 1, side = g & 1;
       const uint32_t *pk = (const uint32_t *)a.battles + (size_t)leaf * 96 + side * 46 + 6 * (in_id - 1);
@@ -799,15 +905,33 @@ __device__ __forceinline__ void embed_arows_body(const EmbedTileArgs &a, float *
         hpr = (float)hp / (float)(pk0 & 0xFFFF);
       }
     }
+    float xv[AR_KT][4];
+    // Slot k's active move row (45 + id - 1) and stored move row (229 + 5 + id - 1) are the same move unless Transform / Mimic
+    // replaced the active one: the pair is then ONE load of the precombined row AR_COMBINED + id - 1 (arows_rows: the sum of the
+    // two) and the stored half of the pair becomes the zero row; `extra` says whether any stored half is left
+    uint32_t extra = 0;
 #pragma unroll
-    for (int t = 0; t < AR_KSTEPS; ++t) x[t] = hh ? fv[2 * t + 1] : fv[2 * t];
+    for (int k = 0; k < 4; ++k) {
+      const bool same = mv[k] != 427u && mv[4 + k] == mv[k] + 189u;
+      mv[k] = same ? mv[k] - 45u + AR_COMBINED : mv[k];
+      mv[4 + k] = same ? 427u : mv[4 + k];
+      extra |= mv[4 + k] != 427u ? 1u : 0u;
+    }
+#pragma unroll
+    for (int T = 0; T < AR_KT; ++T)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int d0 = 8 * T + j, d1 = d0 + 4;
+        xv[T][j] = hh ? (d1 < AR_FIXED ? fv[d1 < AR_FIXED ? d1 : 0] : 0.0f) : (d0 < AR_FIXED ? fv[d0 < AR_FIXED ? d0 : 0] : 0.0f);
+      }
+    dense_split<AR_KT>(xv, xp);
     if (hh == 0) { // (byte offsets: the readers add their own 16 bytes of the row and nothing else)
       uint32_t *it = wl + r32 * AR_ITEM_WORDS;
       *(uint4 *)it = make_uint4(hot[0] * 16, hot[1] * 16, hot[2] * 16, hot[3] * 16);
       *(uint4 *)(it + 4) = make_uint4(hot[4] * 16, hot[5] * 16, hot[6] * 16, hot[7] * 16);
       *(uint4 *)(it + 8) = make_uint4(hot[8] * 16, mv[0] * 512, mv[1] * 512, mv[2] * 512);
       *(uint4 *)(it + 12) = make_uint4(mv[3] * 512, mv[4] * 512, mv[5] * 512, mv[6] * 512);
-      it[16] = mv[7] * 512;
+      *(uint2 *)(it + 16) = make_uint2(mv[7] * 512, extra);
     }
     my_doff = doff;
     my_hpr = hpr;
@@ -823,33 +947,40 @@ __device__ __forceinline__ void embed_arows_body(const EmbedTileArgs &a, float *
     __builtin_amdgcn_s_setprio(2); // a wave in its MFMA phases goes before waves that encode or scatter (see the second layer)
     const uint32_t next = mt + stride;
     if (next < nmt) encode_load1(next);
+    const uint8_t *w0lane = (const uint8_t *)W0s + 16 * r32, *mvlane = (const uint8_t *)N.a_w0d + 16 * r32;
     // ---- first layer, dense part on the matrix pipe: hb[blk] = this lane's 16 channels of block blk of item r32 ----
     f32x16 hb[4];
 #pragma unroll
     for (int b = 0; b < 4; ++b)
 #pragma unroll
       for (int q = 0; q < 16; ++q) hb[b][q] = 0.0f;
-#pragma unroll
-    for (int t = 0; t < AR_KSTEPS; ++t) {
-#pragma unroll
-      for (int b = 0; b < 4; ++b) hb[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(Wd[(t * 4 + b) * 64 + lane], x[t], hb[b], 0, 0, 0);
-    }
+    dense_layer_bf16<AR_KT>((const uint8_t *)Wd + lane * 8, xp, hb);
     // ---- the one-hot and move rows.  Read "lane = item" they cost a 16-byte piece of 64 different cache lines per load
     // instruction (8,192 line requests per mini-tile: the L1 was the bottleneck of the whole kernel).  So they are read
-    // "lane = channels": in k-step t the half-wave hh sums the 17 rows of item 2t + hh, lane (i, hh) taking channels
-    // 4i .. 4i+3 (one float4: a half-wave reads a whole 512-byte row per instruction), and MFMAs against a one-hot selector
-    // (B[k][j] = [item of k == j]) transpose-and-accumulate the sums into the "lane = item" registers: D[channel][item j] +=
-    // sum[item k][channel] [item k == j] -- exact in fp32, 64 more MFMAs per mini-tile.
-    const uint8_t *w0lane = (const uint8_t *)W0s + 16 * r32, *mvlane = (const uint8_t *)N.a_w0d + 16 * r32;
-#pragma unroll 2
+    // "lane = channels": in k-step t the half-wave hh sums the rows of item 2t + hh, lane (i, hh) taking channels
+    // 4i .. 4i+3 (one float4: a half-wave reads a whole 512-byte row per instruction), and SelTranspose moves the sums into
+    // the "lane = item" registers.
+    // The move rows come from L2: four loads per k-step (the slots' COMBINED rows, see encode_compute) and four more only if
+    // one of the step's two items has a slot whose active and stored move differ (Transform, Mimic).  Their round trip is not
+    // what the step waits for: with register rings that keep one or two later k-steps' loads in flight the pass took 72 / 99 us
+    // against 67.5 (round 4) -- what costs is the REQUESTS: with every row an L1 hit the pass took 56 us.
+    SelTranspose tr;
+#pragma unroll
     for (int t = 0; t < 16; ++t) {
       const uint32_t *ip = wl + (2 * t + hh) * AR_ITEM_WORDS;
-      const uint4 i0 = *(const uint4 *)ip, i1 = *(const uint4 *)(ip + 4), i2 = *(const uint4 *)(ip + 8), i3 = *(const uint4 *)(ip + 12);
-      const uint32_t i4 = ip[16];
-      const uint32_t ho[AR_HOT] = {i0.x, i0.y, i0.z, i0.w, i1.x, i1.y, i1.z, i1.w, i2.x}, mo[AR_MOVES] = {i2.y, i2.z, i2.w, i3.x, i3.y, i3.z, i3.w, i4};
+      const uint4 i2 = *(const uint4 *)(ip + 8), i3 = *(const uint4 *)(ip + 12);
+      const uint2 i4 = *(const uint2 *)(ip + 16);
+      const uint32_t mo[AR_MOVES] = {i2.y, i2.z, i2.w, i3.x, i3.y, i3.z, i3.w, i4.x};
       float4 g[AR_MOVES];
 #pragma unroll
-      for (int k = 0; k < AR_MOVES; ++k) g[k] = *(const float4 *)(mvlane + mo[k]); // rows in L2
+      for (int k = 0; k < 4; ++k) g[k] = *(const float4 *)(mvlane + mo[k]); // rows in L2
+      const bool extra = __builtin_amdgcn_ballot_w64(i4.y != 0) != 0; // wave-uniform
+      if (extra) {
+#pragma unroll
+        for (int k = 4; k < AR_MOVES; ++k) g[k] = *(const float4 *)(mvlane + mo[k]);
+      }
+      const uint4 i0 = *(const uint4 *)ip, i1 = *(const uint4 *)(ip + 4);
+      const uint32_t ho[AR_HOT] = {i0.x, i0.y, i0.z, i0.w, i1.x, i1.y, i1.z, i1.w, i2.x};
       float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
       for (int k = 0; k < AR_HOT; ++k) {
@@ -857,12 +988,14 @@ __device__ __forceinline__ void embed_arows_body(const EmbedTileArgs &a, float *
         sum.x += xr.x; sum.y += xr.y; sum.z += xr.z; sum.w += xr.w;
       }
 #pragma unroll
-      for (int k = 0; k < AR_MOVES; ++k) { sum.x += g[k].x; sum.y += g[k].y; sum.z += g[k].z; sum.w += g[k].w; }
-      const float ident = (uint32_t)(2 * t) + hh == r32 ? 1.0f : 0.0f; // (the transposition stays on the fp32 pipe: see k_embed_prows)
-      hb[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(sum.x, ident, hb[0], 0, 0, 0);
-      hb[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(sum.y, ident, hb[1], 0, 0, 0);
-      hb[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(sum.z, ident, hb[2], 0, 0, 0);
-      hb[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(sum.w, ident, hb[3], 0, 0, 0);
+      for (int k = 0; k < 4; ++k) { sum.x += g[k].x; sum.y += g[k].y; sum.z += g[k].z; sum.w += g[k].w; }
+      if (extra) {
+#pragma unroll
+        for (int k = 4; k < AR_MOVES; ++k) { sum.x += g[k].x; sum.y += g[k].y; sum.z += g[k].z; sum.w += g[k].w; }
+      }
+      uint32_t r32o = r32;
+      asm volatile("" : "+v"(r32o)); // (opaque: unrolled, the selectors would otherwise be hoisted out of the mini-tile loop into registers)
+      tr.step(t, sum, hb, r32o, hh);
     }
     act_blocks<4>(hb, N.activation);
     __builtin_amdgcn_sched_barrier(0);
@@ -912,11 +1045,11 @@ __global__ __launch_bounds__(AR_BLOCK) void k_embed_arows(EmbedTileArgs a) {
 // row at the same column), and selector MFMAs transpose the sums into the item lanes.  Second layer (<= 2 output
 // blocks) with W1's bf16 triples from LDS.  The input is read straight from global memory (the encode of a Pokemon is 12
 // features; no staging).  LDS: 194 x 512 B rows + 3 KB dense fragment + 48 KB W1 triples + bias + 512 B per wave.
-constexpr int PR_SPARSE = 193, PR_ZERO = 193, PR_KSTEPS = 3, PR_HOT = 7;
+constexpr int PR_SPARSE = 193, PR_ZERO = 193, PR_KT = 1, PR_HOT = 7; // (6 dense features: one k-step of eight)
 constexpr int PR_ITEM_WORDS = 8;                 // 7 LDS byte offsets of the item's one-hot rows, ready to use (+ 1 pad: two 16-byte reads)
 constexpr int PR_WAVE_WORDS = ER_ITEMS * PR_ITEM_WORDS;
 constexpr int PR_WAVES = OAK_EMBED_WAVES, PR_BLOCK = 64 * PR_WAVES;
-constexpr int PR_DENSE_WORDS = PR_KSTEPS * 4 * 64;
+constexpr int PR_DENSE_WORDS = PR_KT * 4 * 3 * 64 * 2;
 constexpr int PR_MAX_NBO = 2;
 constexpr int pr_img_words(int nbo) { return (PR_SPARSE + 1) * ER_RS + PR_DENSE_WORDS + nbo * (E2_BLOCK_BYTES / 4) + 32 * nbo; }
 constexpr size_t PR_BYTES = (size_t)(pr_img_words(PR_MAX_NBO) + PR_WAVES * PR_WAVE_WORDS) * 4;
@@ -945,7 +1078,7 @@ __device__ __forceinline__ void embed_prows_body(const EmbedTileArgs &a, float *
   // together with its order bytes, the right Pokemon selected afterwards: ONE round trip to memory instead of two dependent
   // ones (the five lanes of a side read the same lines); a work-list record in LIST mode -- and COMPUTE, a whole second layer
   // later, turns it into dense values (registers) and row indices (the wave's LDS).  Both lanes (r, 0) and (r, 1) encode item r.
-  float x[PR_KSTEPS];
+  uint32_t xp[PR_KT][3][2]; // the dense values of this lane's k-half as bf16 triples (dense_split)
   uint32_t my_doff = 0xFFFFFFFFu; // this lane's item: its block of the embedding (both lanes (r, 0), (r, 1) hold item r's) and hp ratio
   float my_hpr = 0.0f;
   uint4 in_pw[LIST ? 2 : 9];
@@ -1018,8 +1151,9 @@ __device__ __forceinline__ void embed_prows_body(const EmbedTileArgs &a, float *
         hpr = (float)hp / (float)(pk0 & 0xFFFF);
       }
     }
-#pragma unroll
-    for (int t = 0; t < PR_KSTEPS; ++t) x[t] = hh ? fv[2 * t + 1] : fv[2 * t];
+    float xv[PR_KT][4];
+    xv[0][0] = hh ? fv[4] : fv[0]; xv[0][1] = hh ? fv[5] : fv[1]; xv[0][2] = hh ? 0.0f : fv[2]; xv[0][3] = hh ? 0.0f : fv[3];
+    dense_split<PR_KT>(xv, xp);
     if (hh == 0) { // (byte offsets from W0s: the readers add their own 16 bytes of the row and nothing else)
       uint32_t *it = wl + r32 * PR_ITEM_WORDS;
       *(uint4 *)it = make_uint4(hot[0] * 16, hot[1] * 16, hot[2] * 16, hot[3] * 16);
@@ -1044,14 +1178,9 @@ __device__ __forceinline__ void embed_prows_body(const EmbedTileArgs &a, float *
     for (int b = 0; b < 4; ++b)
 #pragma unroll
       for (int q = 0; q < 16; ++q) hb[b][q] = 0.0f;
-#pragma unroll
-    for (int t = 0; t < PR_KSTEPS; ++t)
-#pragma unroll
-      for (int b = 0; b < 4; ++b) hb[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(Wd[(t * 4 + b) * 64 + lane], x[t], hb[b], 0, 0, 0);
-    // The transposition stays on the fp32 pipe (64 identity MFMAs of 64 cycles per mini-tile): on the bf16 pipe it needs the
-    // row sums split into bf16 triples first -- 48 MFMAs of 32 cycles but ~1,000 more vector instructions per mini-tile, and with
-    // the second layer on the bf16 pipe these kernels are bound by the instructions a wave issues, not by the matrix pipe
-    // (measured, round 4: first layer 12.2 k cycles per mini-tile that way against 9.8 k this way).
+    dense_layer_bf16<PR_KT>((const uint8_t *)Wd + lane * 8, xp, hb);
+    // The transposition runs on the bf16 pipe (SelTranspose): the 64 identity MFMAs of the fp32 form held the SIMD's vector issue
+    // for 64 cycles each.
     // Software pipeline over the 16 k-steps, fully unrolled: an MFMA holds the wave's in-order issue until the matrix pipe takes it
     // (64 cycles each on the fp32 pipe), so k-step t + 1's row reads are issued IN FRONT of k-step t's four MFMAs and their LDS
     // round trip runs under them; the row indices are read two k-steps ahead.
@@ -1064,6 +1193,7 @@ __device__ __forceinline__ void embed_prows_body(const EmbedTileArgs &a, float *
     {
       uint4 ian = *(const uint4 *)(wl + (2 * 1 + hh) * PR_ITEM_WORDS), ibn = *(const uint4 *)(wl + (2 * 1 + hh) * PR_ITEM_WORDS + 4);
       float4 rc[PR_HOT], rn[PR_HOT];
+      SelTranspose tr;
       rows_of(*(const uint4 *)(wl + hh * PR_ITEM_WORDS), *(const uint4 *)(wl + hh * PR_ITEM_WORDS + 4), rc);
 #pragma unroll
       for (int t = 0; t < 16; ++t) {
@@ -1074,11 +1204,15 @@ __device__ __forceinline__ void embed_prows_body(const EmbedTileArgs &a, float *
         sum.y = ((rc[0].y + rc[1].y) + (rc[2].y + rc[3].y)) + ((rc[4].y + rc[5].y) + rc[6].y);
         sum.z = ((rc[0].z + rc[1].z) + (rc[2].z + rc[3].z)) + ((rc[4].z + rc[5].z) + rc[6].z);
         sum.w = ((rc[0].w + rc[1].w) + (rc[2].w + rc[3].w)) + ((rc[4].w + rc[5].w) + rc[6].w);
+#ifdef OAK_EMBED_FP32_TRANSPOSE
         const float ident = (uint32_t)(2 * t) + hh == r32 ? 1.0f : 0.0f;
         hb[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(sum.x, ident, hb[0], 0, 0, 0);
         hb[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(sum.y, ident, hb[1], 0, 0, 0);
         hb[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(sum.z, ident, hb[2], 0, 0, 0);
         hb[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(sum.w, ident, hb[3], 0, 0, 0);
+#else
+        tr.step(t, sum, hb, r32, hh);
+#endif
 #pragma unroll
         for (int k = 0; k < PR_HOT; ++k) rc[k] = rn[k];
       }
@@ -2044,34 +2178,47 @@ std::vector<float> policy_frag_order(const HostAffine &a, uint32_t H, uint32_t P
 }
 
 // k_embed_arows: W0^T padded to 128 floats per row, + an all-zero last row (the move rows are read from this copy)
+// + rows AR_COMBINED + i (i = move id - 1, 0..164): the active move row 45 + i PLUS the stored Pokemon's move row 229 + 5 + i --
+// the two halves of a move slot hold the same move unless Transform / Mimic replaced the active one, so the pass loads one row
 std::vector<float> arows_rows(const HostAffine &a) { // a.w is [out = hidden][in]; row r of W0^T = column r of W
-  std::vector<float> d((size_t)(a.in + 1) * 128, 0.0f);
+  std::vector<float> d((size_t)(oak::AR_COMBINED + 165) * 128, 0.0f);
   for (uint32_t r = 0; r < a.in; ++r)
     for (uint32_t c = 0; c < a.out && c < 128; ++c) d[(size_t)r * 128 + c] = a.w[(size_t)c * a.in + r];
+  for (uint32_t i = 0; i < 165; ++i)
+    for (uint32_t c = 0; c < 128; ++c) d[(size_t)(oak::AR_COMBINED + i) * 128 + c] = d[(size_t)(45 + i) * 128 + c] + d[(size_t)(229 + 5 + i) * 128 + c];
   return d;
 }
-// ... the dense part of W0 as the A operand of H^T = W0d^T . X^T: [k-step t][channel block][lane (i, hh)] =
-// W0[channel 4 i + blk][row of dense feature d = 2t + hh]  (d = 0: the bias)
-std::vector<float> arows_dense_frag(const HostAffine &a) {
-  std::vector<float> f((size_t)oak::AR_DENSE_WORDS, 0.0f);
-  for (uint32_t t = 0; t < (uint32_t)oak::AR_KSTEPS; ++t)
+// ... the dense part of W0 as bf16 triples, the A operand of dense_layer_bf16: 16-bit word ((((T * 4 + blk) * 3 + part) * 64 + lane) * 4 + j)
+// = part of W0[channel 4 (lane & 31) + blk][row of dense feature d = 8 T + 4 (lane >> 5) + j]  (d = 0: the bias; d >= F: zero)
+template <class RowOf>
+std::vector<float> dense_triple_frag(const HostAffine &a, uint32_t KT, uint32_t F, RowOf row_of) {
+  std::vector<uint16_t> w((size_t)KT * 4 * 3 * 64 * 4, 0);
+  for (uint32_t T = 0; T < KT; ++T)
     for (uint32_t blk = 0; blk < 4; ++blk)
-      for (uint32_t lane = 0; lane < 64; ++lane) {
-        const uint32_t d = 2 * t + (lane >> 5), c = 4 * (lane & 31) + blk;
-        if (c < a.out) f[((size_t)t * 4 + blk) * 64 + lane] = d == 0 ? a.b[c] : a.w[(size_t)c * a.in + (uint32_t)oak::ar_dense_row((int)d)];
-      }
+      for (uint32_t lane = 0; lane < 64; ++lane)
+        for (uint32_t j = 0; j < 4; ++j) {
+          const uint32_t d = 8 * T + 4 * (lane >> 5) + j, c = 4 * (lane & 31) + blk;
+          if (d >= F || c >= a.out) continue;
+          const float x = d == 0 ? a.b[c] : a.w[(size_t)c * a.in + row_of(d)];
+          const uint16_t hh = f32_to_bf16(x);
+          const float r1 = x - bf16_to_f32(hh);
+          const uint16_t mm = f32_to_bf16(r1);
+          const uint16_t ll = f32_to_bf16(r1 - bf16_to_f32(mm));
+          const size_t base = ((size_t)T * 4 + blk) * 3;
+          w[((base + 0) * 64 + lane) * 4 + j] = hh;
+          w[((base + 1) * 64 + lane) * 4 + j] = mm;
+          w[((base + 2) * 64 + lane) * 4 + j] = ll;
+        }
+  std::vector<float> f(w.size() / 2);
+  memcpy(f.data(), w.data(), w.size() * 2);
   return f;
+}
+std::vector<float> arows_dense_frag(const HostAffine &a) {
+  return dense_triple_frag(a, (uint32_t)oak::AR_KT, (uint32_t)oak::AR_FIXED, [](uint32_t d) { return (uint32_t)oak::ar_dense_row((int)d); });
 }
 // the same for k_embed_prows: dense feature d = 0 is the bias, d = 1..5 are W0^T rows 0..4 (the stats)
 std::vector<float> prows_dense_frag(const HostAffine &a) {
-  std::vector<float> f((size_t)oak::PR_DENSE_WORDS, 0.0f);
-  for (uint32_t t = 0; t < (uint32_t)oak::PR_KSTEPS; ++t)
-    for (uint32_t blk = 0; blk < 4; ++blk)
-      for (uint32_t lane = 0; lane < 64; ++lane) {
-        const uint32_t d = 2 * t + (lane >> 5), c = 4 * (lane & 31) + blk;
-        if (c < a.out) f[((size_t)t * 4 + blk) * 64 + lane] = d == 0 ? a.b[c] : a.w[(size_t)c * a.in + (d - 1)];
-      }
-  return f;
+  return dense_triple_frag(a, (uint32_t)oak::PR_KT, 6u, [](uint32_t d) { return d - 1; });
 }
 // ... and W1 [out][hidden] in MFMA-fragment order: [n-block][k-step s][lane (r32, hh)] = W1[nb * 32 + r32][ar_channel(s, hh)]
 std::vector<float> embed_frag_order(const HostAffine &a) {

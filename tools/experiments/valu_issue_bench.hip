@@ -22,7 +22,7 @@
 enum Op { OP_AND, OP_SHL, OP_BFE, OP_CNDMASK, OP_ADD, OP_MUL_LO, OP_LANE, OP_ADD3, OP_CMP, OP_SALU, OP_MIX, OP_VS,
           // encoding study (which instructions issue in 2 cycles, which in 4)
           OP_ADD_E64, OP_AND_LIT, OP_XOR, OP_MOV, OP_SHL_V, OP_LSHR, OP_CND_E32, OP_CMP_E32, OP_SUB, OP_MIN, OP_MAD24, OP_LSHL_OR, OP_AND_OR,
-          OP_MUL24, OP_ADD_BFE, OP_ADD_SHL, OP_ADDC, OP_FFSS, OP_F4S4, OP_F6S2, OP_F7S1, OP_CND_VCC64, OP_CMP_CND32, OP_CMP_CND64, OP_COUNT };
+          OP_MUL24, OP_ADD_BFE, OP_ADD_SHL, OP_ADDC, OP_FFSS, OP_F4S4, OP_F6S2, OP_F7S1, OP_CND_VCC64, OP_CMP_CND32, OP_CMP_CND64, OP_PK_ADD, OP_ADD_F32, OP_PK_ADD_MIX, OP_COUNT };
 static const char *op_name[OP_COUNT] = {"v_and_b32", "v_lshlrev_b32", "v_bfe_u32", "v_cndmask_b32", "v_add_u32", "v_mul_lo_u32",
                                         "v_readlane+v_writelane", "v_add3_u32", "v_cmp_lt_u32", "s_add_u32",
                                         "engine mix (and/shl/bfe/cndmask/add/cmp/and/add3)", "v_add_u32+s_add_u32 alternating",
@@ -31,7 +31,8 @@ static const char *op_name[OP_COUNT] = {"v_and_b32", "v_lshlrev_b32", "v_bfe_u32
                                         "v_lshl_or_b32", "v_and_or_b32", "v_mul_u32_u24", "v_add_u32 / v_bfe_u32 alternating",
                                         "v_add_u32 / v_lshlrev_b32 alternating", "v_addc_co_u32 (vcc in/out)",
                                         "pattern add add bfe bfe", "pattern 4 x add, 4 x bfe", "pattern 6 x add, 2 x bfe", "pattern 7 x add, 1 x bfe",
-                                        "v_cndmask_b32_e64 (vcc as the mask)", "v_cmp_lt_u32_e32 vcc + v_cndmask_b32_e32 vcc pairs", "v_cmp_lt_u32_e64 s[] + v_cndmask_b32_e64 s[] pairs"};
+                                        "v_cndmask_b32_e64 (vcc as the mask)", "v_cmp_lt_u32_e32 vcc + v_cndmask_b32_e32 vcc pairs", "v_cmp_lt_u32_e64 s[] + v_cndmask_b32_e64 s[] pairs",
+                                        "v_pk_add_f32 (two floats per lane)", "v_add_f32", "v_pk_add_f32 / v_bfe_u32 alternating"};
 
 // One asm statement holds the whole 256-instruction body (`.rept 32` over 8 instructions): hipcc pads every boundary between
 // two dependent asm statements with s_nop (it cannot see inside them), which would put a nop behind every instruction of a
@@ -65,6 +66,7 @@ static const char *op_name[OP_COUNT] = {"v_and_b32", "v_lshlrev_b32", "v_bfe_u32
 #define I_ADDC(X) "v_addc_co_u32 " X ", vcc, %10, " X ", vcc\n"
 #define I_CNDV64(X) "v_cndmask_b32_e64 " X ", " X ", %10, vcc\n"
 #define I_CNDS64(X) "v_cndmask_b32_e64 " X ", " X ", %10, %9\n"
+#define I_ADDF(X) "v_add_f32 " X ", %10, " X "\n"
 #define IND8(I) I("%0") I("%1") I("%2") I("%3") I("%4") I("%5") I("%6") I("%7")
 #define DEP8(I) I("%0") I("%0") I("%0") I("%0") I("%0") I("%0") I("%0") I("%0")
 #define MIX8(A, B, C, D, E, F, G, H) I_AND(A) I_SHL(B) I_BFE(C) I_CND(D) I_ADD(E) I_CMP(F) I_AND(G) I_ADD3(H)
@@ -106,6 +108,21 @@ __device__ __forceinline__ void issue_all(uint32_t (&r)[8], uint32_t &sreg, uint
   else if constexpr (OP == OP_CND_VCC64) { asm volatile("s_mov_b64 vcc, %0" :: "s"(m) : "vcc"); BODY(IND8(I_CNDV64)); }
   else if constexpr (OP == OP_CMP_CND32) BODY(I_CMP32("%0") I_CND32("%1") I_CMP32("%2") I_CND32("%3") I_CMP32("%4") I_CND32("%5") I_CMP32("%6") I_CND32("%7"));
   else if constexpr (OP == OP_CMP_CND64) BODY(I_CMP("%0") I_CNDS64("%1") I_CMP("%2") I_CNDS64("%3") I_CMP("%4") I_CNDS64("%5") I_CMP("%6") I_CNDS64("%7"));
+  else if constexpr (OP == OP_ADD_F32) BODY(IND8(I_ADDF));
+  else if constexpr (OP == OP_PK_ADD || OP == OP_PK_ADD_MIX) {
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    f2 p0 = {__uint_as_float(r[0]), __uint_as_float(r[1])}, p1 = {__uint_as_float(r[2]), __uint_as_float(r[3])}, p2 = {__uint_as_float(r[4]), __uint_as_float(r[5])},
+       p3 = {__uint_as_float(r[6]), __uint_as_float(r[7])}, cc = {1.0f, 2.0f};
+    if constexpr (OP == OP_PK_ADD)
+      asm volatile(".rept 32\nv_pk_add_f32 %0, %0, %4\nv_pk_add_f32 %1, %1, %4\nv_pk_add_f32 %2, %2, %4\nv_pk_add_f32 %3, %3, %4\n"
+                   "v_pk_add_f32 %0, %0, %4\nv_pk_add_f32 %1, %1, %4\nv_pk_add_f32 %2, %2, %4\nv_pk_add_f32 %3, %3, %4\n.endr\n"
+                   : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3) : "v"(cc));
+    else
+      asm volatile(".rept 32\nv_pk_add_f32 %0, %0, %4\nv_bfe_u32 %5, %5, 1, 31\nv_pk_add_f32 %1, %1, %4\nv_bfe_u32 %5, %5, 1, 31\n"
+                   "v_pk_add_f32 %2, %2, %4\nv_bfe_u32 %5, %5, 1, 31\nv_pk_add_f32 %3, %3, %4\nv_bfe_u32 %5, %5, 1, 31\n.endr\n"
+                   : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3) : "v"(cc), "v"(c));
+    r[0] = __float_as_uint(p0.x + p1.x + p2.x + p3.x); r[1] = __float_as_uint(p0.y + p1.y + p2.y + p3.y);
+  }
   else if constexpr (OP == OP_FFSS) BODY(I_ADD("%0") I_ADD("%1") I_BFE("%2") I_BFE("%3") I_ADD("%4") I_ADD("%5") I_BFE("%6") I_BFE("%7"));
   else if constexpr (OP == OP_F4S4) BODY(I_ADD("%0") I_ADD("%1") I_ADD("%2") I_ADD("%3") I_BFE("%4") I_BFE("%5") I_BFE("%6") I_BFE("%7"));
   else if constexpr (OP == OP_F6S2) BODY(I_ADD("%0") I_ADD("%1") I_ADD("%2") I_ADD("%3") I_ADD("%4") I_ADD("%5") I_BFE("%6") I_BFE("%7"));
@@ -254,7 +271,7 @@ int main(int argc, char **argv) {
   // encoding study, 4 and 8 waves per SIMD
 #define STUDY(OPX) rows.push_back(run<OPX, false, 4, 64>(iters)); rows.push_back(run<OPX, false, 8, 64>(iters));
   STUDY(OP_ADD_E64) STUDY(OP_AND_LIT) STUDY(OP_XOR) STUDY(OP_MOV) STUDY(OP_SHL_V) STUDY(OP_LSHR) STUDY(OP_CND_E32) STUDY(OP_CMP_E32) STUDY(OP_SUB)
-  STUDY(OP_MIN) STUDY(OP_MAD24) STUDY(OP_LSHL_OR) STUDY(OP_AND_OR) STUDY(OP_MUL24) STUDY(OP_ADD_BFE) STUDY(OP_ADD_SHL) STUDY(OP_ADDC) STUDY(OP_CND_VCC64) STUDY(OP_CMP_CND32) STUDY(OP_CMP_CND64) STUDY(OP_FFSS) STUDY(OP_F4S4) STUDY(OP_F6S2) STUDY(OP_F7S1)
+  STUDY(OP_MIN) STUDY(OP_MAD24) STUDY(OP_LSHL_OR) STUDY(OP_AND_OR) STUDY(OP_MUL24) STUDY(OP_ADD_BFE) STUDY(OP_ADD_SHL) STUDY(OP_ADDC) STUDY(OP_PK_ADD) STUDY(OP_ADD_F32) STUDY(OP_PK_ADD_MIX) STUDY(OP_CND_VCC64) STUDY(OP_CMP_CND32) STUDY(OP_CMP_CND64) STUDY(OP_FFSS) STUDY(OP_F4S4) STUDY(OP_F6S2) STUDY(OP_F7S1)
   // partial EXEC: does a wave with its upper half (or three quarters) masked off issue faster?
   sweep_w<OP_ADD, false, 32>(rows, iters);
   sweep_w<OP_ADD, false, 16>(rows, iters);
