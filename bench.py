@@ -525,7 +525,8 @@ def leaf_records(args, torch, dev, rank, local_rank, world, dist, which=("leaf",
     # the main net's kernel: fp32 values as exact bf16 triples on the bf16 matrix pipe unless OAKGPU_MAIN_NET=fp32 (include/oakgpu.h)
     split = os.environ.get("OAKGPU_MAIN_NET", "") != "fp32"
     MAIN_KERNEL = "k_mainnet_split<8>" if split else "k_mainnet_wave"
-    ARITH = ("fp32 results throughout.  Embedding nets: first layers on fp32 MFMA, second layers as exact bf16 triples on the bf16 pipe.  Main net: every "
+    ARITH = ("fp32 results throughout.  Embedding nets: one-hot rows summed in fp32 on the vector ALUs; dense features, the move of the sums into the item "
+             "lanes and the second layers as exact bf16 triples on the bf16 pipe.  Main net: every "
              "fp32 value is the exact sum of three bf16 parts and every product runs as its six largest bf16 x bf16 partial products (exact in the "
              "fp32 accumulator; dropped: < 2^-24 of the product) on v_mfma_f32_32x32x16_bf16, fp32 accumulation; error vs float64 at the fp32-MFMA "
              "kernel's level (tests/test_gpu_leafnet.py::test_bf16_triple_main_net_is_an_fp32_result)") if split else \
@@ -555,8 +556,10 @@ def leaf_records(args, torch, dev, rank, local_rank, world, dist, which=("leaf",
                 "kernel": "the leaf call's kernels + oak::k_policy_rows<2>", "parity": "<= 2e-5 per logit vs the numpy oracle (tests/test_gpu_leafnet.py)"}
 
     def leaf_kernels(kus, party_fraction=1.0):
-        """The call's kernels priced per pipe (SURVEY 8d's per-leaf FLOP split by layer): first layers of the embedding nets on the
-        fp32 matrix pipe (one-hot / dense rows: nnz x 128 multiply-adds per item), their second layers and the main net's three
+        """The call's kernels priced per pipe (SURVEY 8d's per-leaf FLOP split by layer): first layers of the embedding nets against
+        the fp32 peak (one-hot / dense rows: nnz x 128 multiply-adds per item; since round 4 the row sums run on the vector ALUs,
+        whose fp32 peak equals the fp32 matrix pipe's 157.3 TFLOP/s -- the fp32 MFMAs they replaced ran on those ALUs anyway:
+        tools/experiments/mfma_overlap_bench.hip), their second layers and the main net's three
         dense layers as bf16 triples on the bf16 pipe (6 partial products per multiply-add), the 256 -> 1 head on the vector pipe
         (not priced: 512 FLOP per leaf).  party_fraction: the share of the party slots actually re-embedded (configs[2]'s cache)."""
         p1, p2 = 10 * 2 * 12 * 128 * party_fraction, 10 * 2 * 128 * 59 * party_fraction
@@ -564,9 +567,9 @@ def leaf_records(args, torch, dev, rank, local_rank, world, dist, which=("leaf",
         mainf = main_f - 2 * 256
         F, B = FP32_MATRIX_TFLOPS * 1e12, BF16_MATRIX_TFLOPS * 1e12
         ks = [{"name": "oak::k_embed_prows (party slots; half of oak::k_embed_both)", "us": kus["k_embed_prows (party slots)"],
-               "parts": [("first layer (6 dense + 7 one-hot rows per item)", "fp32 MFMA", p1 * n, F), ("second layer 128 -> 59 as bf16 triples", "bf16 MFMA x 6", 6 * p2 * n, B)]},
+               "parts": [("first layer (6 dense + 7 one-hot rows per item)", "fp32 vector ALUs (157.3 TFLOP/s, = the fp32 MFMA peak)", p1 * n, F), ("second layer 128 -> 59 as bf16 triples", "bf16 MFMA x 6", 6 * p2 * n, B)]},
               {"name": "oak::k_embed_arows (actives; the other half)", "us": kus["k_embed_arows (actives)"],
-               "parts": [("first layer (36 dense + 17 one-hot / move rows per item)", "fp32 MFMA", a1 * n, F), ("second layer 128 -> 83 as bf16 triples", "bf16 MFMA x 6", 6 * a2 * n, B)]}]
+               "parts": [("first layer (36 dense + 17 one-hot / move rows per item)", "fp32 vector ALUs (157.3 TFLOP/s, = the fp32 MFMA peak)", a1 * n, F), ("second layer 128 -> 83 as bf16 triples", "bf16 MFMA x 6", 6 * a2 * n, B)]}]
         if split:
             ks.append({"name": "oak::" + MAIN_KERNEL, "us": kus[MAIN_KERNEL], "parts": [("768 -> 256 -> 256 -> 256 as bf16 triples", "bf16 MFMA x 6", 6 * mainf * n, B)]})
         else:
@@ -597,7 +600,7 @@ def leaf_records(args, torch, dev, rank, local_rank, world, dist, which=("leaf",
             # layer at the peak of the pipe it runs on (time-weighted over the call's kernels) -- frac = achieved / peak <= 1
             "roofline": {"bound": "mfma", "kernel": "oak::k_embed_both (k_embed_prows + k_embed_arows in one launch) + oak::%s (one value_inference call)" % MAIN_KERNEL,
                          "achieved": achieved, "peak": achieved / (tmin / avg_s), "unit": "TFLOP/s", "frac": tmin / avg_s,
-                         "frac_note": "sum over the call's layers of (algorithmic work on its pipe / that pipe's dense peak: fp32 MFMA 157.3 TFLOP/s, bf16 MFMA "
+                         "frac_note": "sum over the call's layers of (algorithmic work on its pipe / that pipe's dense peak: fp32 (vector ALUs = fp32 MFMA) 157.3 TFLOP/s, bf16 MFMA "
                                       "2,500 TFLOP/s with 6 partial products per multiply-add) / the call's measured time; `kernels` has it per kernel "
                                       "(durations from HIP events around each launch, a diagnostic pass outside the timed region: "
                                       "time-weighted %.3f over those)" % frac,

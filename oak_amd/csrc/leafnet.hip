@@ -723,29 +723,28 @@ __device__ __forceinline__ void embed_scatter(float *emb, uint32_t doff, float h
   }
 }
 
-// Copy a prebuilt image of the kernel's LDS weights (built once at load time in exactly the LDS layout) with every load of
-// a thread in flight at once.  The obvious `lds[i] = cond ? global[f(i)] : 0` loop compiles to load -> wait -> store per
-// iteration: ~30 serialized L2 round trips per workgroup, 20-50 us in front of every embedding kernel.
-// The copy is split in two: the loads are issued at the top of the kernel, the LDS writes (and the workgroup barrier behind
-// them) come after the wave's FIRST encode, which needs no weights -- the image's round trip runs under it.
-template <int BLOCK, int MAXR>
-__device__ __forceinline__ void stage_image_load(float4 (&t)[MAXR], const float *img, int words) {
-  const int n4 = words >> 2; // (images are padded to a multiple of 4 floats)
-#pragma unroll
-  for (int u = 0; u < MAXR; ++u) {
-    const int i = (int)threadIdx.x + u * BLOCK;
-    t[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (i < n4) t[u] = ((const float4 *)img)[i];
+// Copy a prebuilt image of the kernel's LDS weights (built once at load time in exactly the LDS layout) by LDS-DMA
+// (global_load_lds_dwordx4: a wave instruction lands 64 x 16 B at a wave-uniform LDS base, lane-linear; no staging registers).
+// The pieces are issued at the top of the kernel; the wait (stage_image_wait: vmcnt(0) written out -- a bare __syncthreads() is
+// not a wait for LDS-DMA -- and the workgroup barrier) comes after the wave's FIRST encode, which needs no weights.
+// History: the obvious `lds[i] = cond ? global[f(i)] : 0` loop compiled to load -> wait -> store per iteration (~30 serialized L2
+// round trips per workgroup, 20-50 us in front of every embedding kernel); rounds 2-4 staged through registers, every load of a
+// thread in flight at once -- 76-80 registers across the first encode, which is where the kernels' last 40 spilled registers were.
+typedef __attribute__((address_space(3))) void img_lds_void;
+typedef __attribute__((address_space(1))) const void img_glb_void;
+template <int BLOCK>
+__device__ __forceinline__ void stage_image_dma(float *lds, const float *img, int words) {
+  const int n16 = words >> 2; // 16-byte pieces (images are padded to a multiple of 4 floats)
+  const int tid = (int)threadIdx.x, wave = tid >> 6;
+  for (int base = 0; base < n16; base += BLOCK) { // wave-uniform trip count
+    const int first = base + wave * 64;            // this wave's 1-KB piece
+    if (first + (tid & 63) < n16)
+      __builtin_amdgcn_global_load_lds((img_glb_void *)((const float4 *)img + first + (tid & 63)), (img_lds_void *)((float4 *)lds + first), 16, 0, 0);
   }
 }
-template <int BLOCK, int MAXR>
-__device__ __forceinline__ void stage_image_store(float *lds, const float4 (&t)[MAXR], int words) {
-  const int n4 = words >> 2;
-#pragma unroll
-  for (int u = 0; u < MAXR; ++u) {
-    const int i = (int)threadIdx.x + u * BLOCK;
-    if (i < n4) ((float4 *)lds)[i] = t[u];
-  }
+__device__ __forceinline__ void stage_image_wait() {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
 }
 
 // The embedding blocks of empty / fainted slots are all-zero (network.h:142-143,153-160).  The lanes that found one hand it to
@@ -777,7 +776,7 @@ __device__ __forceinline__ void zero_blocks(float *emb, uint32_t dead_off, int l
 // Then the <= 4 output blocks one after the other with W1's fragments from LDS (256 B per k-step, conflict-free).  No
 // activation tile, no workgroup barrier per tile, every wave on the MFMA; the kernel fits 128 registers so that a CU holds
 // ONE 16-wave workgroup (4 waves per SIMD).  LDS: 65 x 528 B rows + 18 KB dense fragment + <= 64 KB W1 fragments + 1.4 KB
-// per wave (row indices) = <= 141 KB, staged from one prebuilt image (stage_image_load / _store).
+// per wave (row indices) = <= 141 KB, staged from one prebuilt image (stage_image_dma).
 constexpr int AR_SPARSE = 64, AR_ZERO = 64;   // LDS-resident one-hot rows (ar_sparse_slot) + a zero row
 constexpr int AR_FIXED = 36, AR_HOT = 9, AR_MOVES = 8, AR_KT = (AR_FIXED + 7) / 8; // (dense features in k-steps of eight)
 constexpr int AR_ITEM_WORDS = 20;               // ready to use: 9 LDS byte offsets of the item's one-hot rows, 8 byte offsets of its move rows in L2 (+ 3 pad)
@@ -804,7 +803,7 @@ __host__ __device__ constexpr int ar_sparse_row(int slot) { return slot < 15 ? s
 constexpr int ar_img_words(int nbo) { return (AR_SPARSE + 1) * ER_RS + AR_DENSE_WORDS + nbo * (E2_BLOCK_BYTES / 4) + 32 * nbo; }
 template <int WAVES, int NBO>
 __device__ __forceinline__ void embed_arows_body(const EmbedTileArgs &a, float *lds_f, const uint32_t bid, const uint32_t nblocks) {
-  constexpr int BLOCK = WAVES * 64, MAXR = (ar_img_words(NBO) / 4 + BLOCK - 1) / BLOCK;
+  constexpr int BLOCK = WAVES * 64;
   EL_T0();
   const NetDev &N = a.net;
   const int out_dim = N.a_out;
@@ -813,8 +812,7 @@ __device__ __forceinline__ void embed_arows_body(const EmbedTileArgs &a, float *
   const uint8_t *W1t = (const uint8_t *)(Wd + AR_DENSE_WORDS); // the second layer's bf16 triples: [block][k-step][h m l][lane] x 16 B
   const float *b1s = (const float *)(W1t + NBO * E2_BLOCK_BYTES);
   constexpr int img_words = ar_img_words(NBO);
-  float4 img_t[MAXR];
-  stage_image_load<BLOCK, MAXR>(img_t, N.a_img, img_words);
+  stage_image_dma<BLOCK>(lds_f, N.a_img, img_words);
   const uint32_t lane = threadIdx.x & 63, wib = threadIdx.x >> 6, r32 = lane & 31, hh = lane >> 5;
   uint32_t *wl = (uint32_t *)(lds_f + img_words) + wib * AR_WAVE_WORDS; // this wave's private LDS (the items' row indices)
   const uint32_t items = a.n * 2;
@@ -939,8 +937,7 @@ __device__ __forceinline__ void embed_arows_body(const EmbedTileArgs &a, float *
   };
   uint32_t mt = bid * WAVES + wib;
   if (mt < nmt) { encode_load1(mt); encode_load2(mt); encode_compute(mt); } // needs no weights: the image's round trip runs under it
-  stage_image_store<BLOCK, MAXR>(lds_f, img_t, img_words);
-  __syncthreads(); // weights staged (the only workgroup barrier of the kernel)
+  stage_image_wait(); // weights staged (the only workgroup barrier of the kernel)
   while (mt < nmt) {
     __builtin_amdgcn_wave_barrier();
     EL_MARK(3);
@@ -1067,9 +1064,7 @@ __device__ __forceinline__ void embed_prows_body(const EmbedTileArgs &a, float *
   const uint8_t *W1t = (const uint8_t *)(Wd + PR_DENSE_WORDS); // second layer's bf16 triples: [block][k-step][h m l][lane] x 16 B
   const float *b1s = (const float *)(W1t + NBO * E2_BLOCK_BYTES);
   constexpr int img_words = pr_img_words(NBO);
-  constexpr int MAXR = (img_words / 4 + PR_BLOCK - 1) / PR_BLOCK;
-  float4 img_t[MAXR];
-  stage_image_load<PR_BLOCK, MAXR>(img_t, N.p_img, img_words);
+  stage_image_dma<PR_BLOCK>(lds_f, N.p_img, img_words);
   const uint32_t lane = threadIdx.x & 63, wib = threadIdx.x >> 6, r32 = lane & 31, hh = lane >> 5;
   uint32_t *wl = (uint32_t *)(lds_f + img_words) + wib * PR_WAVE_WORDS; // this wave's private LDS (the items' row indices)
   const uint32_t stride = nblocks * PR_WAVES;
@@ -1166,8 +1161,7 @@ __device__ __forceinline__ void embed_prows_body(const EmbedTileArgs &a, float *
   // mini-tiles go round-robin over the WORKGROUPS first, so that a short work list still spreads over every CU
   uint32_t mt = wib * nblocks + bid;
   if (mt < nmt) { encode_load(mt); encode_compute(mt); } // needs no weights: the image's round trip runs under it
-  stage_image_store<PR_BLOCK, MAXR>(lds_f, img_t, img_words);
-  __syncthreads(); // weights staged (the only workgroup barrier of the kernel)
+  stage_image_wait(); // weights staged (the only workgroup barrier of the kernel)
   while (mt < nmt) {
     __builtin_amdgcn_wave_barrier();
     EL_MARK(3);
