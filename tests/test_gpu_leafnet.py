@@ -478,3 +478,58 @@ def test_cached_leaf_eval_equals_plain_eval_over_a_resident_batch(gpu_ctx, tmp_p
     for x in (gb, gd, gp, gr, steps, vals, v_plain, v_cached, e_plain, e_cached, tags):
         x.free()
     net.close()
+
+
+def test_active_move_slots_that_differ_from_the_stored_ones(gpu_ctx):
+    """The actives pass loads ONE precombined row per move slot when the active and the stored Pokemon hold the same move there
+    (leafnet.hip AR_COMBINED) and falls back to two rows otherwise -- Transform / Mimic in play, or here: patched bytes.  Every
+    combination per slot: same move, different move, active PP 0, stored PP 0, empty active slot, Struggle's id (never a
+    feature), both sides, mixed with untouched leaves inside the same 32-item mini-tiles (the fallback is a per-k-step,
+    wave-uniform branch).  Embedding and value against the oracle."""
+    from oak_amd.engine import Network
+    path = os.path.join(ROOT, "tests", "golden", "net_default.battle.net")
+    net = Network(gpu_ctx, path=path)
+    onet = NN.Net(path)
+    b, d = _midgame_states(320, 12, 8100)
+    b = b.copy()
+    rng = np.random.default_rng(99)
+    patched = 0
+    for i in range(b.shape[0]):
+        if i % 3 == 2:
+            continue  # untouched neighbours
+        for side in range(2):
+            base = 184 * side
+            slot = int(b[i, base + 176])          # order[0]: the active's party slot (1-based), 0 = none
+            if slot == 0 or (i + side) % 4 == 3:
+                continue
+            act = base + 144 + 24                  # active.moves[4] {id, pp}
+            sto = base + 24 * (slot - 1) + 10      # stored.moves[4]
+            for k in range(4):
+                mode = int(rng.integers(0, 7))
+                if mode == 0:
+                    continue                                                    # as played
+                if mode == 1:
+                    b[i, act + 2 * k] = rng.integers(1, 165)                    # a different move in the active slot
+                    b[i, act + 2 * k + 1] = max(int(b[i, act + 2 * k + 1]), 1)
+                elif mode == 2:
+                    b[i, act + 2 * k + 1] = 0                                   # active PP 0, stored PP kept
+                elif mode == 3:
+                    b[i, sto + 2 * k + 1] = 0                                   # stored PP 0, active PP kept
+                elif mode == 4:
+                    b[i, act + 2 * k] = 0                                       # empty active slot
+                elif mode == 5:
+                    b[i, act + 2 * k] = 165                                     # Struggle: no feature (battle.h move slots)
+                    b[i, act + 2 * k + 1] = 5
+                else:
+                    b[i, sto + 2 * k] = rng.integers(1, 165)                    # a different move in the stored slot
+                    b[i, sto + 2 * k + 1] = max(int(b[i, sto + 2 * k + 1]), 1)
+                patched += 1
+    assert patched > 300
+    vals, emb = net.value_inference(b, d, return_embedding=True)
+    worst = 0.0
+    for i in range(b.shape[0]):
+        oe = NN.battle_embedding(onet, b[i], d[i])
+        assert np.abs(emb[i] - oe).max() <= 2e-5, (i, int(np.abs(emb[i] - oe).argmax()))
+        worst = max(worst, abs(float(vals[i]) - float(onet.main_value(oe))))
+    assert worst <= TOL, worst
+    net.close()
