@@ -46,6 +46,7 @@ struct NetDev {
   // policy heads (main-net.h:67-107): fc2 [PHp][H] (rows padded to 32), fc3 [315][PHp] (+ biases)
   const float *q1a, *q1a_b, *q1b, *q1b_b, *q2a, *q2a_b, *q2b, *q2b_b;
   const float *q1a_f, *q2a_f; // fc2 of the two heads as k_policy_rows' A operand (policy_frag_order)
+  const float *q1a_t, *q2a_t; // ... and as bf16 triples (policy_triple_order), or null: a weight above 2^20 (see split_safe)
   int PH; // padded policy hidden width
 };
 
@@ -1898,7 +1899,8 @@ struct PolicyArgs {
 // behind workgroup barriers and finished with one THREAD per (leaf, choice) walking a 256-byte weight row of its own through
 // L1 (64 lanes = 64 cache lines per load): 300-450 us per 65,536 leaves for 10 % of the main net's arithmetic.  Here a wave
 // owns 32 leaves, like the main net's kernels:
-//   fc2 (H -> PH): P^T = Wa . H1^T on fp32 MFMA with the WEIGHTS as the A operand (fragments in policy_frag_order, four
+//   fc2 (H -> PH): P^T = Wa . H1^T with the WEIGHTS as the A operand -- as bf16 triples on the bf16 pipe since round 4 (TRIPLE:
+//   the branch at the top of the tile loop), or on fp32 MFMA when the net runs in fp32 mode (fragments in policy_frag_order, four
 //   k-steps per float4, straight from L2) and the leaf's fc1 row as the B operand (lane (b, hh) reads 16 bytes of its row per
 //   four k-steps) -- the result has the policy-hidden features in the accumulator registers and the leaf on the lane;
 //   fc3 (PH -> 315, <= 9 legal rows per side, policy.h:29-58): lane (b, hh) holds half of leaf b's features in registers and
@@ -1910,9 +1912,13 @@ template <int PB> struct PolicyRows {
   static constexpr int STRIDE = PB * 32 + 4;                       // floats per fc3 row in LDS
   static constexpr bool WB_LDS = (size_t)ROWS * STRIDE * 4 <= 128 * 1024;
   static constexpr size_t LDS = WB_LDS ? ((size_t)ROWS * STRIDE + 320) * 4 : 16; // the rows + fc3's biases
+  // One workgroup per CU (the rows fill its LDS).  With <= 64 policy-hidden features the kernel needs < 256 registers, so the
+  // workgroup has EIGHT waves (two per SIMD) instead of four: the kernel waits -- for the weight fragments from L2, the leaf's
+  // fc1 row, the 27-field gather behind the choices -- more than it computes (round 3: SQ_WAIT_ANY 63 % of its wave cycles).
+  static constexpr int WAVES = PB <= 2 ? 8 : 4, BLOCK = 64 * WAVES;
 };
-template <int PB>
-__global__ __launch_bounds__(MN_BLOCK) void k_policy_rows(PolicyArgs a) {
+template <int PB, bool TRIPLE>
+__global__ __launch_bounds__(PolicyRows<PB>::BLOCK) void k_policy_rows(PolicyArgs a) {
   extern __shared__ __align__(16) float lds_f[];
   using PR = PolicyRows<PB>;
   const NetDev &N = a.net;
@@ -1926,14 +1932,14 @@ __global__ __launch_bounds__(MN_BLOCK) void k_policy_rows(PolicyArgs a) {
     const float *Wb = head ? N.q2b : N.q1b, *bb = head ? N.q2b_b : N.q1b_b;
     if (PR::WB_LDS) {
       __syncthreads(); // (the previous head's rows are no longer read)
-      for (int i = threadIdx.x; i < PR::ROWS * PB * 8; i += MN_BLOCK) { // float4 pieces of the (padded-to-PH) rows
+      for (int i = threadIdx.x; i < PR::ROWS * PB * 8; i += PR::BLOCK) { // float4 pieces of the (padded-to-PH) rows
         const int row = i / (PB * 8), c4 = i - row * (PB * 8);
         *(float4 *)(lds_f + row * PR::STRIDE + 4 * c4) = *(const float4 *)(Wb + (size_t)row * PH + 4 * c4);
       }
-      for (int i = threadIdx.x; i < PR::ROWS; i += MN_BLOCK) lds_f[PR::ROWS * PR::STRIDE + i] = bb[i];
+      for (int i = threadIdx.x; i < PR::ROWS; i += PR::BLOCK) lds_f[PR::ROWS * PR::STRIDE + i] = bb[i];
       __syncthreads();
     }
-    for (uint32_t wt = blockIdx.x * 4 + wave; wt < ntiles; wt += gridDim.x * 4) {
+    for (uint32_t wt = blockIdx.x * PR::WAVES + wave; wt < ntiles; wt += gridDim.x * PR::WAVES) {
       const uint32_t row0 = wt * 32, n_rows = min(32u, a.n - row0);
       const uint32_t leaf = row0 + ((uint32_t)r < n_rows ? (uint32_t)r : n_rows - 1); // rows past the batch repeat the last one, dropped below
       const float *hrow = a.h1 + (size_t)leaf * H + 4 * hh;
@@ -1942,6 +1948,48 @@ __global__ __launch_bounds__(MN_BLOCK) void k_policy_rows(PolicyArgs a) {
       for (int b = 0; b < PB; ++b)
 #pragma unroll
         for (int q = 0; q < 16; ++q) acc[b][q] = 0.0f;
+      if constexpr (TRIPLE) {
+        // fc2 as bf16 triples (round 4): the fp32 MFMAs of the other branch hold the SIMD's vector issue for 64 cycles each
+        // (profiles/r04_mfma_overlap.json) -- 256 of them per head and tile.  Here: k-step T = columns 16 T + 8 hh .. + 7 of the
+        // leaf's fc1 row, split by truncation (e_split), against the weights' prebuilt triples (policy_triple_order, from L2),
+        // the six largest partial products per block as in the main net; the next k-step's row piece and weights are asked for
+        // in front of this one's MFMAs.
+        const uint8_t *Wt = (const uint8_t *)(head ? N.q2a_t : N.q1a_t) + lane * 16;
+        const float *hr = a.h1 + (size_t)leaf * H + 8 * hh;
+        const int nT = H / 16;
+        float4 x0 = *(const float4 *)hr, x1 = *(const float4 *)(hr + 4);
+        bf16x8 Wc[PB][3], Wn[PB][3];
+#pragma unroll
+        for (int b = 0; b < PB; ++b)
+#pragma unroll
+          for (int q = 0; q < 3; ++q) Wc[b][q] = *(const bf16x8 *)(Wt + ((size_t)b * 3 + q) * 1024);
+#pragma unroll 2
+        for (int T = 0; T < nT; ++T) {
+          const int Tn = T + 1 < nT ? T + 1 : T;
+          const float4 n0 = *(const float4 *)(hr + 16 * Tn), n1 = *(const float4 *)(hr + 16 * Tn + 4);
+#pragma unroll
+          for (int b = 0; b < PB; ++b)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) Wn[b][q] = *(const bf16x8 *)(Wt + (((size_t)Tn * PB + b) * 3 + q) * 1024);
+          const float v[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+          bf16x8 X[3];
+          e_split(v, X);
+#pragma unroll
+          for (int b = 0; b < PB; ++b) {
+            acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Wc[b][2], X[0], acc[b], 0, 0, 0); // l . h   (small terms first)
+            acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Wc[b][0], X[2], acc[b], 0, 0, 0); // h . l
+            acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Wc[b][1], X[1], acc[b], 0, 0, 0); // m . m
+            acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Wc[b][1], X[0], acc[b], 0, 0, 0); // m . h
+            acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Wc[b][0], X[1], acc[b], 0, 0, 0); // h . m
+            acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Wc[b][0], X[0], acc[b], 0, 0, 0); // h . h
+          }
+          x0 = n0; x1 = n1;
+#pragma unroll
+          for (int b = 0; b < PB; ++b)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) Wc[b][q] = Wn[b][q];
+        }
+      } else {
       float4 xc = *(const float4 *)hrow, xn;
       float4 wc[PB], wn[PB];
 #pragma unroll
@@ -1959,6 +2007,7 @@ __global__ __launch_bounds__(MN_BLOCK) void k_policy_rows(PolicyArgs a) {
         xc = xn;
 #pragma unroll
         for (int b = 0; b < PB; ++b) wc[b] = wn[b];
+      }
       }
       // bias + activation: register q of block b = feature 32 b + (q & 3) + 8 (q >> 2) + 4 hh of leaf r
 #pragma unroll
@@ -2158,6 +2207,9 @@ std::vector<uint16_t> split_stream(const HostAffine &fc0, const HostAffine &fc1,
 
 // k_policy_rows' A operand of a policy head's fc2 (H -> PH): float4 ((u * PB + b) * 64 + lane) = W[32 b + (lane & 31)][8 u + 4 (lane >> 5) .. + 3]
 // (four k-steps per load; the leaf's fc1 row supplies the same columns as the B operand).  Absent rows / columns are zeros.
+// ... and as bf16 triples, k_policy_rows<PB, true>'s A operand: 16-bit word ((((T * PB + b) * 3 + part) * 64 + lane) * 8 + j) = part of
+// W[32 b + (lane & 31)][16 T + 8 (lane >> 5) + j]; absent rows / columns are zeros.  Returned as floats (the upload's unit).
+std::vector<float> policy_triple_order(const HostAffine &a, uint32_t H, uint32_t PB);
 std::vector<float> policy_frag_order(const HostAffine &a, uint32_t H, uint32_t PB) {
   const uint32_t nu = H / 8;
   std::vector<float> f((size_t)nu * PB * 64 * 4, 0.0f);
@@ -2224,6 +2276,30 @@ std::vector<float> embed_frag_order(const HostAffine &a) {
         const uint32_t o = nb * 32 + (lane & 31), c = (uint32_t)oak::ar_channel((int)s2, (int)(lane >> 5));
         if (o < a.out && c < a.in) f[((size_t)nb * 64 + s2) * 64 + lane] = a.w[(size_t)o * a.in + c];
       }
+  return f;
+}
+
+std::vector<float> policy_triple_order(const HostAffine &a, uint32_t H, uint32_t PB) {
+  const uint32_t nT = H / 16;
+  std::vector<uint16_t> w((size_t)nT * PB * 3 * 64 * 8, 0);
+  for (uint32_t T = 0; T < nT; ++T)
+    for (uint32_t b = 0; b < PB; ++b)
+      for (uint32_t lane = 0; lane < 64; ++lane)
+        for (uint32_t j = 0; j < 8; ++j) {
+          const uint32_t row = 32 * b + (lane & 31), col = 16 * T + 8 * (lane >> 5) + j;
+          if (row >= a.out || col >= a.in) continue;
+          const float x = a.w[(size_t)row * a.in + col];
+          const uint16_t hh = f32_to_bf16(x);
+          const float r1 = x - bf16_to_f32(hh);
+          const uint16_t mm = f32_to_bf16(r1);
+          const uint16_t ll = f32_to_bf16(r1 - bf16_to_f32(mm));
+          const size_t base = ((size_t)T * PB + b) * 3;
+          w[((base + 0) * 64 + lane) * 8 + j] = hh;
+          w[((base + 1) * 64 + lane) * 8 + j] = mm;
+          w[((base + 2) * 64 + lane) * 8 + j] = ll;
+        }
+  std::vector<float> f(w.size() / 2);
+  memcpy(f.data(), w.data(), w.size() * 2);
   return f;
 }
 
@@ -2406,6 +2482,14 @@ int oakgpu_net_load_memory(oakgpu_ctx *ctx, const void *bytes, size_t size, oakg
     rc = rc ? rc : upload(net, q2b.b, &D.q2b_b);
     rc = rc ? rc : upload(net, policy_frag_order(q1a, H, PB), &D.q1a_f);
     rc = rc ? rc : upload(net, policy_frag_order(q2a, H, PB), &D.q2a_f);
+    // the triples only while no fc2 weight is above 2^20 in magnitude (as for the main net: split_safe)
+    bool psafe = true;
+    for (float v : q1a.w) psafe = psafe && std::fabs(v) <= 1048576.0f;
+    for (float v : q2a.w) psafe = psafe && std::fabs(v) <= 1048576.0f;
+    if (psafe) {
+      rc = rc ? rc : upload(net, policy_triple_order(q1a, H, PB), &D.q1a_t);
+      rc = rc ? rc : upload(net, policy_triple_order(q2a, H, PB), &D.q2a_t);
+    }
   }
   if (rc) { oakgpu_net_free(ctx, net); return rc; }
   *out = net;
@@ -2469,10 +2553,12 @@ int oakgpu_leaf_set_lds_limits(void) { // per DEVICE (hipFuncSetAttribute applie
   if (e != hipSuccess) return oakgpu_fail_hip((int)e, "hipFuncSetAttribute(k_embed_prows<list>)");
   e = hipFuncSetAttribute((const void *)oak::k_embed_lds<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)oak::ELayout<true>::BYTES);
   if (e != hipSuccess) return oakgpu_fail_hip((int)e, "hipFuncSetAttribute(k_embed_lds<active>)");
-  e = hipFuncSetAttribute((const void *)oak::k_policy_rows<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)oak::PolicyRows<1>::LDS);
-  if (e == hipSuccess) e = hipFuncSetAttribute((const void *)oak::k_policy_rows<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)oak::PolicyRows<2>::LDS);
-  if (e == hipSuccess) e = hipFuncSetAttribute((const void *)oak::k_policy_rows<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)oak::PolicyRows<4>::LDS);
-  if (e == hipSuccess) e = hipFuncSetAttribute((const void *)oak::k_policy_rows<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)oak::PolicyRows<8>::LDS);
+#define OAK_POLICY_ATTR(PBV)                                                                                                                              \
+  if (e == hipSuccess) e = hipFuncSetAttribute((const void *)oak::k_policy_rows<PBV, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)oak::PolicyRows<PBV>::LDS); \
+  if (e == hipSuccess) e = hipFuncSetAttribute((const void *)oak::k_policy_rows<PBV, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)oak::PolicyRows<PBV>::LDS);
+  e = hipSuccess;
+  OAK_POLICY_ATTR(1) OAK_POLICY_ATTR(2) OAK_POLICY_ATTR(4) OAK_POLICY_ATTR(8)
+#undef OAK_POLICY_ATTR
   if (e != hipSuccess) return oakgpu_fail_hip((int)e, "hipFuncSetAttribute(k_policy_rows)");
   e = hipFuncSetAttribute((const void *)oak::k_mainnet_wave, hipFuncAttributeMaxDynamicSharedMemorySize, (int)oak::MW_BYTES);
   if (e != hipSuccess) return oakgpu_fail_hip((int)e, "hipFuncSetAttribute(k_mainnet_wave)");
@@ -2565,11 +2651,20 @@ static int leaf_eval_impl(oakgpu_ctx *ctx, oakgpu_net *net, const uint8_t *battl
     oak::PolicyArgs pa = *pol;
     pa.net = D;
     pa.h1 = h1;
-    const uint32_t wgs = ((n + 31) / 32 + 3) / 4, pgrid = wgs < 256 ? wgs : 256;
-    if (D.PH == 256) hipLaunchKernelGGL(oak::k_policy_rows<8>, dim3(pgrid), dim3(oak::MN_BLOCK), oak::PolicyRows<8>::LDS, stream, pa);
-    else if (D.PH == 128) hipLaunchKernelGGL(oak::k_policy_rows<4>, dim3(pgrid), dim3(oak::MN_BLOCK), oak::PolicyRows<4>::LDS, stream, pa);
-    else if (D.PH == 64) hipLaunchKernelGGL(oak::k_policy_rows<2>, dim3(pgrid), dim3(oak::MN_BLOCK), oak::PolicyRows<2>::LDS, stream, pa);
-    else hipLaunchKernelGGL(oak::k_policy_rows<1>, dim3(pgrid), dim3(oak::MN_BLOCK), oak::PolicyRows<1>::LDS, stream, pa);
+    const uint32_t ptiles = (n + 31) / 32;
+    auto pgrid = [&](uint32_t waves) { const uint32_t wgs = (ptiles + waves - 1) / waves; return dim3(wgs < 256 ? wgs : 256); };
+    // fc2 as bf16 triples when the main net runs that way and no fc2 weight forbids it (q1a_t), else on fp32 MFMA
+    const bool triple = net->main_mode == OAKGPU_MAIN_SPLIT && D.q1a_t != nullptr && D.q2a_t != nullptr;
+#define OAK_POLICY_LAUNCH(PBV)                                                                                                                            \
+  do {                                                                                                                                                    \
+    if (triple) hipLaunchKernelGGL((oak::k_policy_rows<PBV, true>), pgrid(oak::PolicyRows<PBV>::WAVES), dim3(oak::PolicyRows<PBV>::BLOCK), oak::PolicyRows<PBV>::LDS, stream, pa);  \
+    else hipLaunchKernelGGL((oak::k_policy_rows<PBV, false>), pgrid(oak::PolicyRows<PBV>::WAVES), dim3(oak::PolicyRows<PBV>::BLOCK), oak::PolicyRows<PBV>::LDS, stream, pa);       \
+  } while (0)
+    if (D.PH == 256) OAK_POLICY_LAUNCH(8);
+    else if (D.PH == 128) OAK_POLICY_LAUNCH(4);
+    else if (D.PH == 64) OAK_POLICY_LAUNCH(2);
+    else OAK_POLICY_LAUNCH(1);
+#undef OAK_POLICY_LAUNCH
   }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return oakgpu_fail_hip((int)e, "leaf_eval launch");

@@ -397,12 +397,16 @@ def test_policy_head_widths(gpu_ctx, tmp_path, ph):
     b, d, r = b[keep], d[keep], r[keep]
     c1, n1 = gpu_ctx.choices(b, r, 0)
     c2, n2 = gpu_ctx.choices(b, r, 1)
-    vals, l1, l2 = net.value_policy_inference(b, d, c1, n1, c2, n2)
-    for i in range(0, b.shape[0], 3):
-        ev, e1, e2 = NN.value_policy_inference(onet, b[i], d[i], c1[i, :n1[i]], c2[i, :n2[i]])
-        assert abs(float(vals[i]) - float(ev)) <= TOL
-        assert np.abs(l1[i, :n1[i]] - e1).max() <= 2e-5 and np.abs(l2[i, :n2[i]] - e2).max() <= 2e-5
-        assert (l1[i, n1[i]:] == 0).all() and (l2[i, n2[i]:] == 0).all()
+    # both forms of fc2: bf16 triples (the default, with the main net) and fp32 MFMA (what "fp32" selects for the whole net)
+    for mode in ("split", "fp32"):
+        net.set_main_precision(mode)
+        assert net.main_precision()[0] == mode
+        vals, l1, l2 = net.value_policy_inference(b, d, c1, n1, c2, n2)
+        for i in range(0, b.shape[0], 3):
+            ev, e1, e2 = NN.value_policy_inference(onet, b[i], d[i], c1[i, :n1[i]], c2[i, :n2[i]])
+            assert abs(float(vals[i]) - float(ev)) <= TOL
+            assert np.abs(l1[i, :n1[i]] - e1).max() <= 2e-5 and np.abs(l2[i, :n2[i]] - e2).max() <= 2e-5, mode
+            assert (l1[i, n1[i]:] == 0).all() and (l2[i, n2[i]:] == 0).all()
     net.close()
 
 
