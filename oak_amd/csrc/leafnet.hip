@@ -47,6 +47,7 @@ struct NetDev {
   const float *q1a, *q1a_b, *q1b, *q1b_b, *q2a, *q2a_b, *q2b, *q2b_b;
   const float *q1a_f, *q2a_f; // fc2 of the two heads as k_policy_rows' A operand (policy_frag_order)
   const float *q1a_t, *q2a_t; // ... and as bf16 triples (policy_triple_order), or null: a weight above 2^20 (see split_safe)
+  const float *q1b_img, *q2b_img; // fc3's rows + biases exactly as k_policy_rows lays them out in LDS (policy_rows_image), or null: PH > 64
   int PH; // padded policy hidden width
 };
 
@@ -1911,7 +1912,8 @@ template <int PB> struct PolicyRows {
   static constexpr int ROWS = 315;
   static constexpr int STRIDE = PB * 32 + 4;                       // floats per fc3 row in LDS
   static constexpr bool WB_LDS = (size_t)ROWS * STRIDE * 4 <= 128 * 1024;
-  static constexpr size_t LDS = WB_LDS ? ((size_t)ROWS * STRIDE + 320) * 4 : 16; // the rows + fc3's biases
+  static constexpr int IMG_WORDS = ROWS * STRIDE + 320;             // the rows + fc3's biases (315, padded)
+  static constexpr size_t LDS = WB_LDS ? (size_t)IMG_WORDS * 4 : 16;
   // One workgroup per CU (the rows fill its LDS).  With <= 64 policy-hidden features the kernel needs < 256 registers, so the
   // workgroup has EIGHT waves (two per SIMD) instead of four: the kernel waits -- for the weight fragments from L2, the leaf's
   // fc1 row, the 27-field gather behind the choices -- more than it computes (round 3: SQ_WAIT_ANY 63 % of its wave cycles).
@@ -1931,13 +1933,11 @@ __global__ __launch_bounds__(PolicyRows<PB>::BLOCK) void k_policy_rows(PolicyArg
     const float *ba = head ? N.q2a_b : N.q1a_b;
     const float *Wb = head ? N.q2b : N.q1b, *bb = head ? N.q2b_b : N.q1b_b;
     if (PR::WB_LDS) {
+      // the head's rows + biases: one prebuilt image, by LDS-DMA (round 4; as a `lds[..] = global[..]` loop it was ten dependent L2
+      // round trips per head in front of every tile)
       __syncthreads(); // (the previous head's rows are no longer read)
-      for (int i = threadIdx.x; i < PR::ROWS * PB * 8; i += PR::BLOCK) { // float4 pieces of the (padded-to-PH) rows
-        const int row = i / (PB * 8), c4 = i - row * (PB * 8);
-        *(float4 *)(lds_f + row * PR::STRIDE + 4 * c4) = *(const float4 *)(Wb + (size_t)row * PH + 4 * c4);
-      }
-      for (int i = threadIdx.x; i < PR::ROWS; i += PR::BLOCK) lds_f[PR::ROWS * PR::STRIDE + i] = bb[i];
-      __syncthreads();
+      stage_image_dma<PR::BLOCK>(lds_f, head ? N.q2b_img : N.q1b_img, PR::IMG_WORDS);
+      stage_image_wait();
     }
     for (uint32_t wt = blockIdx.x * PR::WAVES + wave; wt < ntiles; wt += gridDim.x * PR::WAVES) {
       const uint32_t row0 = wt * 32, n_rows = min(32u, a.n - row0);
@@ -2279,6 +2279,16 @@ std::vector<float> embed_frag_order(const HostAffine &a) {
   return f;
 }
 
+// fc3 of a policy head as k_policy_rows keeps it in LDS: 315 rows of PH floats at a stride of PH + 4, then the 315 biases (padded to 320)
+std::vector<float> policy_rows_image(const HostAffine &b, uint32_t PH) {
+  const uint32_t stride = PH + 4;
+  std::vector<float> img((size_t)315 * stride + 320, 0.0f);
+  for (uint32_t r = 0; r < 315 && r < b.out; ++r) {
+    for (uint32_t c = 0; c < b.in && c < PH; ++c) img[(size_t)r * stride + c] = b.w[(size_t)r * b.in + c];
+    img[(size_t)315 * stride + r] = b.b[r];
+  }
+  return img;
+}
 std::vector<float> policy_triple_order(const HostAffine &a, uint32_t H, uint32_t PB) {
   const uint32_t nT = H / 16;
   std::vector<uint16_t> w((size_t)nT * PB * 3 * 64 * 8, 0);
@@ -2482,6 +2492,10 @@ int oakgpu_net_load_memory(oakgpu_ctx *ctx, const void *bytes, size_t size, oakg
     rc = rc ? rc : upload(net, q2b.b, &D.q2b_b);
     rc = rc ? rc : upload(net, policy_frag_order(q1a, H, PB), &D.q1a_f);
     rc = rc ? rc : upload(net, policy_frag_order(q2a, H, PB), &D.q2a_f);
+    if (PH <= 64) { // (PolicyRows<PB>::WB_LDS: the rows fit the CU's LDS)
+      rc = rc ? rc : upload(net, policy_rows_image(q1b, PH), &D.q1b_img);
+      rc = rc ? rc : upload(net, policy_rows_image(q2b, PH), &D.q2b_img);
+    }
     // the triples only while no fc2 weight is above 2^20 in magnitude (as for the main net: split_safe)
     bool psafe = true;
     for (float v : q1a.w) psafe = psafe && std::fabs(v) <= 1048576.0f;
