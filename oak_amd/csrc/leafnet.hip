@@ -964,11 +964,20 @@ __device__ __forceinline__ void embed_arows_body(const EmbedTileArgs &a, float *
     // what the step waits for: with register rings that keep one or two later k-steps' loads in flight the pass took 72 / 99 us
     // against 67.5 (round 4) -- what costs is the REQUESTS: with every row an L1 hit the pass took 56 us.
     SelTranspose tr;
+    // the row offsets of k-step t + 1 are read while step t's rows are summed (a step's thirteen row reads wait for them)
+    struct StepIdx { uint4 i0, i1, i2, i3; uint2 i4; };
+    auto idx_of = [&](int t, StepIdx &I) {
+      const uint32_t *ip = wl + (2 * t + hh) * AR_ITEM_WORDS;
+      I.i0 = *(const uint4 *)ip; I.i1 = *(const uint4 *)(ip + 4); I.i2 = *(const uint4 *)(ip + 8); I.i3 = *(const uint4 *)(ip + 12);
+      I.i4 = *(const uint2 *)(ip + 16);
+    };
+    StepIdx Ic, In;
+    idx_of(0, Ic);
 #pragma unroll
     for (int t = 0; t < 16; ++t) {
-      const uint32_t *ip = wl + (2 * t + hh) * AR_ITEM_WORDS;
-      const uint4 i2 = *(const uint4 *)(ip + 8), i3 = *(const uint4 *)(ip + 12);
-      const uint2 i4 = *(const uint2 *)(ip + 16);
+      if (t + 1 < 16) idx_of(t + 1, In);
+      const uint4 i0 = Ic.i0, i1 = Ic.i1, i2 = Ic.i2, i3 = Ic.i3;
+      const uint2 i4 = Ic.i4;
       const uint32_t mo[AR_MOVES] = {i2.y, i2.z, i2.w, i3.x, i3.y, i3.z, i3.w, i4.x};
       float4 g[AR_MOVES];
 #pragma unroll
@@ -978,7 +987,6 @@ __device__ __forceinline__ void embed_arows_body(const EmbedTileArgs &a, float *
 #pragma unroll
         for (int k = 4; k < AR_MOVES; ++k) g[k] = *(const float4 *)(mvlane + mo[k]);
       }
-      const uint4 i0 = *(const uint4 *)ip, i1 = *(const uint4 *)(ip + 4);
       const uint32_t ho[AR_HOT] = {i0.x, i0.y, i0.z, i0.w, i1.x, i1.y, i1.z, i1.w, i2.x};
       float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
@@ -995,6 +1003,7 @@ __device__ __forceinline__ void embed_arows_body(const EmbedTileArgs &a, float *
       uint32_t r32o = r32;
       asm volatile("" : "+v"(r32o)); // (opaque: unrolled, the selectors would otherwise be hoisted out of the mini-tile loop into registers)
       tr.step(t, sum, hb, r32o, hh);
+      Ic = In;
     }
     act_blocks<4>(hb, N.activation);
     __builtin_amdgcn_sched_barrier(0);
