@@ -452,7 +452,8 @@ struct RoundArgs {
   uint32_t *adopt_ctl;
   uint32_t *adopt_list;
   uint32_t n_adopters;      // 0 = off; waves [0, n_adopters) adopt
-  uint32_t long_steps;      // a bulk wave donates a playout that is still running after this many turn-steps
+  uint32_t long_steps;      // bits 0-15: a bulk wave donates a playout that is still running after this many turn-steps;
+                            // bits 16-24: ... or whose actives' {slot, hp} have not changed for this many turn-steps (256: never)
 };
 
 // One launch drains a GROUP of independent batches (oakgpu_rollout_group_dev): the queue hands out GLOBAL playout
@@ -562,6 +563,10 @@ __global__ __launch_bounds__(1024) void k_queue_order(GroupArgs g, uint32_t *ord
 #define OAK_LONG_STEPS 200
 #endif
 constexpr uint32_t LONG_STEPS = OAK_LONG_STEPS;
+#ifndef OAK_PRIO_STILL
+#define OAK_PRIO_STILL 24
+#endif
+constexpr uint32_t PRIO_STILL = OAK_PRIO_STILL;
 template <int BLK, int WPS>
 __global__ __launch_bounds__(BLK, WPS) void k_rollout_queue(GroupArgs g_in, RoundArgs q_in) {
   extern __shared__ __align__(16) uint8_t smem[];
@@ -613,7 +618,12 @@ __global__ __launch_bounds__(BLK, WPS) void k_rollout_queue(GroupArgs g_in, Roun
   // moment the device drains.  Every wait is bounded (a ticket reserved but not yet written; an adopter with nothing to
   // adopt while bulk waves still run): on overflow the error word is set and the wave leaves.  Results are indexed by
   // playout: they do not depend on who finishes a playout.
+  // Round 4: a STANDSTILL counter donates earlier.  Measured on the oracle (2 x 65,536 playouts): the playouts that run into the cap
+  // stop changing any hp at a median of turn-step 85 (p90 160) -- from then on they are the stalemates of k_queue_order's comment --
+  // while an ordinary playout almost never goes 40 turn-steps without its actives' {slot, hp} changing.  `stale` = a 24-bit
+  // signature of both actives (hp xor, slot sum: symmetric, the frame may be swapped) | the turn-steps it has stood still << 24.
   const uint32_t n_adopt = COLD_QU(n_adopters), long_steps = COLD_QU(long_steps);
+  uint32_t stale = 0;
   if (n_adopt != 0 && blockIdx.x < n_adopt) ust |= U_ADOPTER;
 #define IS_ADOPTER ((ust & U_ADOPTER) != 0)
 #define IS_ADOPTING ((ust & U_ADOPTING) != 0) // adopter: a donation has been seen, no more playouts from the main queue
@@ -710,6 +720,7 @@ __global__ __launch_bounds__(BLK, WPS) void k_rollout_queue(GroupArgs g_in, Roun
         }
         result = from_scratch ? COLD_Q(sres, const uint8_t *)[idx] : bd->results_in[k];
         steps = from_scratch ? bd->steps_out[k] : 0;
+        stale = 0;
       }
     }
     if (__ballot(idx != DONE) == 0) break;
@@ -722,10 +733,14 @@ __global__ __launch_bounds__(BLK, WPS) void k_rollout_queue(GroupArgs g_in, Roun
       result = e.random_step(result, hi, lo);
       ++steps;
       playing = (result & 15) == 0 && steps < max_steps;
+      const uint32_t sg = ((e.S.p4 ^ e.F.p4) >> 16) | (((e.S.o0 + e.F.o0) & 0xFFu) << 16);
+      stale = sg != (stale & 0xFFFFFFu) ? sg : stale + (stale < 0xFF000000u ? 0x01000000u : 0u);
     }
     // a wave that holds a playout far beyond the usual length (99.5% end before 250 turn-steps) is on the launch's critical
     // path -- a 1000-step chain: it goes first on its SIMD (an adopter as soon as it adopts)
-    if (IS_ADOPTING || __ballot(playing && steps > LONG_STEPS)) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0);
+    // (round 4: ... or one whose actives have stood still for PRIO_STILL turn-steps -- the stalemates that run into the cap stop changing
+    // at a median of turn-step 85, so their wave goes first ~90 turn-steps earlier; a false alarm costs nothing but a while of priority)
+    if (IS_ADOPTING || __ballot(playing && (steps > LONG_STEPS || stale >= (PRIO_STILL << 24)))) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0);
     if (__ballot(playing) != 0) ust |= U_ANY_PLAYING; else ust &= ~U_ANY_PLAYING;
     if (IS_ADOPTER && !ANY_PLAYING) { // nothing to play: wait for donations (bounded) without burning issue slots
       __builtin_amdgcn_s_sleep(100);
@@ -734,7 +749,7 @@ __global__ __launch_bounds__(BLK, WPS) void k_rollout_queue(GroupArgs g_in, Roun
     // wave-uniform: the queue is dry and too few lanes are still playing -> hand them to the next round
     const uint64_t still = __ballot(playing);
     const bool suspend = IS_DRY && still != 0 && (uint32_t)__popcll(still) < suspend_below;
-    const bool lng = n_adopt != 0 && !IS_ADOPTER && playing && steps >= long_steps; // a bulk wave's long playout: to the adopters
+    const bool lng = n_adopt != 0 && !IS_ADOPTER && playing && (steps >= (long_steps & 0xFFFFu) || (stale >> 24) >= (long_steps >> 16)); // a bulk wave's long (or standing-still) playout: to the adopters
     if (idx != DONE && idx != NONE && (!playing || suspend || lng)) { // retire the lane: publish a finished playout / park a suspended or donated one
       OAK_SCOPE(PS_PUBLISH);
       const bool fin = !playing;
@@ -1320,6 +1335,7 @@ struct oakgpu_ctx {
   int migrate;            // long-playout migration (k_rollout_queue): 0 off, 1 (default) for launches that saturate the device, 2 always
   int migrate_steps;      //   a bulk wave donates a playout still running after this many turn-steps (default 300)
   int migrate_adopters;   //   adopter waves (0 = one per two CUs)
+  int migrate_window;     //   ... or whose actives' {slot, hp} stood still for this many turn-steps (0 = off, at most 255)
   int migrate_used;       //   the last queue launch ran with migration: oakgpu_synchronize reports its error word
   int spread_lanes;       // launches that do not fill the device: lanes per wave that take playouts (-1 automatic, 0 / 64 = all)
   int queue_order;        // 1 (default): a saturated launch hands its playouts out likely-longest first (k_queue_order)
@@ -1499,10 +1515,12 @@ int oakgpu_create(oakgpu_ctx **out, int device) {
   c->migrate = 1;
   c->migrate_steps = 300;
   c->migrate_adopters = 0;
+  c->migrate_window = 48;
   c->migrate_used = 0;
   if (const char *env = getenv("OAKGPU_MIGRATE")) c->migrate = atoi(env) < 0 ? 0 : atoi(env) > 2 ? 2 : atoi(env);
   if (const char *env = getenv("OAKGPU_MIGRATE_STEPS")) c->migrate_steps = atoi(env) < 1 ? 1 : atoi(env);
   if (const char *env = getenv("OAKGPU_MIGRATE_ADOPTERS")) c->migrate_adopters = atoi(env) < 0 ? 0 : atoi(env);
+  if (const char *env = getenv("OAKGPU_MIGRATE_WINDOW")) c->migrate_window = atoi(env) < 0 ? 0 : atoi(env) > 255 ? 255 : atoi(env);
   c->d_order = nullptr;
   c->order_n = 0;
   c->tail_lanes = 0;
@@ -1581,6 +1599,12 @@ int oakgpu_set_migration(oakgpu_ctx *c, int mode, int long_steps, int adopters) 
   c->migrate = mode;
   c->migrate_steps = long_steps;
   c->migrate_adopters = adopters;
+  return 0;
+}
+
+int oakgpu_set_migration_window(oakgpu_ctx *c, int window) {
+  if (!c || window < 0 || window > 255) return bad("oakgpu_set_migration_window: window must be 0 (off) .. 255 turn-steps");
+  c->migrate_window = window;
   return 0;
 }
 
@@ -1769,7 +1793,8 @@ static int launch_group(oakgpu_ctx *c, const oak::BatchDesc *descs, uint32_t cou
   for (int r = 0; r < rounds; ++r) {
     oak::RoundArgs q{};
     q.order = r == 0 ? order : nullptr;
-    if (migrate) { q.adopt_ctl = c->d_queue + 40; q.adopt_list = lists[0]; q.n_adopters = adopters; q.long_steps = (uint32_t)c->migrate_steps; }
+    q.long_steps = (uint32_t)(c->migrate_steps > 0xFFFF ? 0xFFFF : c->migrate_steps) | (uint32_t)(c->migrate_window > 0 ? c->migrate_window : 256) << 16;
+    if (migrate) { q.adopt_ctl = c->d_queue + 40; q.adopt_list = lists[0]; q.n_adopters = adopters; }
     q.list_in = r ? lists[(r - 1) & 1] : nullptr;
     q.n_in = r ? c->d_queue + 2 * r - 1 : nullptr; // = count_out of round r - 1
     q.list_out = lists[r & 1];

@@ -73,6 +73,10 @@ class Context:
         """Long-playout migration of the queue kernel (include/oakgpu.h: oakgpu_set_migration); results never change."""
         _lib.check(self.lib.oakgpu_set_migration(self.handle, int(mode), int(long_steps), int(adopters)))
 
+    def set_migration_window(self, window=48):
+        """Donate a playout whose actives stood still for `window` turn-steps (oakgpu_set_migration_window; 0 = off)."""
+        _lib.check(self.lib.oakgpu_set_migration_window(self.handle, int(window)))
+
     def queue_counters(self):
         """The 64 control words of the last queue launch (oakgpu_get_queue_counters): [40] donations, [41] adoptions, [63] sticky error bits."""
         out = np.zeros(64, dtype=np.uint32)

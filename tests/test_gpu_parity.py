@@ -233,9 +233,13 @@ def test_long_playout_migration_does_not_change_results(gpu_ctx):
     plain = gpu_ctx.rollout(b, d, r, p, max_steps=1000, return_state=True)
     assert (plain["steps"] == osteps).all() and (plain["battles"] == ob).all()
     try:
-        for ppl, long_steps, adopters in ((2, 20, 2), (2, 60, 1), (3, 5, 4), (2, 150, 8), (4, 1, 3)):
+        # (window: the standstill counter of round 4 -- a playout whose actives kept their slots and hp for that many turn-steps is
+        # donated too; 0 = off.  Windows of 1-3 turn-steps donate nearly every playout several times over.)
+        for ppl, long_steps, adopters, window in ((2, 20, 2, 0), (2, 60, 1, 0), (3, 5, 4, 0), (2, 150, 8, 0), (4, 1, 3, 0),
+                                                  (2, 999, 4, 2), (2, 300, 8, 8), (3, 999, 2, 1), (2, 999, 16, 40)):
             gpu_ctx.set_playouts_per_lane(ppl)
             gpu_ctx.set_migration(2, long_steps, adopters)
+            gpu_ctx.set_migration_window(window)
             for prep in (False, True):
                 q = gpu_ctx.rollout(b, d, r, p, max_steps=1000, prep=prep, return_state=True)
                 c = gpu_ctx.queue_counters()
@@ -253,6 +257,7 @@ def test_long_playout_migration_does_not_change_results(gpu_ctx):
     finally:
         gpu_ctx.set_playouts_per_lane(2)
         gpu_ctx.set_migration(1, 300, 0)
+        gpu_ctx.set_migration_window(48)
 
 
 def test_rollout_in_place_on_device_buffers(gpu_ctx):

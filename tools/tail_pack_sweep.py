@@ -62,6 +62,21 @@ if len(sys.argv) > 1 and sys.argv[1] == "migrate":    # long-playout migration A
         c = counters()
         print("      donations %d adoptions %d bulk waves left %d errors %d" % (c[40], c[41], c[42], c[63]), flush=True)
     sys.exit(0)
+if len(sys.argv) > 1 and sys.argv[1] == "window":     # standstill-window donation A/B (oakgpu_set_migration_window)
+    import numpy as np
+    def counters():
+        out = np.zeros(64, dtype=np.uint32)
+        _lib.check(lib.oakgpu_get_queue_counters(h, out.ctypes.data_as(C.c_void_p)))
+        return out
+    for win, ls, ad in ((0, 300, 0), (64, 300, 0), (48, 300, 0), (40, 300, 0), (32, 300, 0), (24, 300, 0), (16, 300, 0), (40, 300, 192), (32, 300, 256), (24, 300, 256),
+                        (32, 250, 0), (40, 1000, 0), (0, 300, 0), (40, 300, 0)):
+        _lib.check(lib.oakgpu_set_migration(h, 1, ls, ad))
+        _lib.check(lib.oakgpu_set_migration_window(h, win))
+        print("window %3d long_steps %4d adopters %3d" % (win, ls, ad), end="  ")
+        run(0, 0, 0, reps=4)
+        c = counters()
+        print("      donations %d adoptions %d bulk waves left %d errors %d" % (c[40], c[41], c[42], c[63]), flush=True)
+    sys.exit(0)
 if len(sys.argv) > 1 and sys.argv[1] == "order":      # the queue-order A/B only
     for on in (0, 1, 0, 1):
         _lib.check(lib.oakgpu_set_queue_order(h, on))
