@@ -381,7 +381,8 @@ int oakgpu_frames_read(const uint8_t *buffer, size_t size, uint8_t *battle /* 38
  * (util/policy.h:22-106; mode words e / n / x / p with optional weights, e.g. "e0.9-x0.1"; p = prior + empirical, the
  * reference's fall-through, useful with the contextual bandits only) -> frame -> update, until the result
  * is terminal; the finished record is written to `buffer`.  Every battle operation runs on the GPU.  Fails (no record
- * written) when the game exceeds max_battle_length turns (0 = 1000), like the reference (generate.cc:268-271). */
+ * written) when the game exceeds max_battle_length updates, like the reference (generate.cc:268-271); 0 = no limit, the reference's
+ * default: the engine ends a game at turn 1,000 by itself (records of up to ~1,010 frames). */
 typedef struct {
   oakgpu_search_params search; /* seed is replaced per turn from `seed` below */
   char policy_mode[16];

@@ -174,7 +174,9 @@ int oakgpu_selfplay_game(oakgpu_ctx *ctx, oakgpu_net *net, const uint8_t *teams,
   memcpy(first, battle, 384); // CompressedFrames{battle_data.battle} (generate.cc:244)
   std::vector<oakgpu_frame_update> frames;
   uint64_t rng = prm->seed ^ 0x9FB21C651E98DF25ull;
-  const uint32_t max_len = prm->max_battle_length ? prm->max_battle_length : 1000;
+  // 0 = no limit, the reference's default (--max-battle-length -1, generate.cc:49-52): the engine itself ends a game at turn 1,000,
+  // and only the handful of forced-switch updates come on top of that (2,048 is a backstop against a bug, never a rule of the game)
+  const uint32_t max_len = prm->max_battle_length ? prm->max_battle_length : 2048;
   oakgpu_search_params sp = prm->search;
   struct HeapOwner { oakgpu_heap *h = nullptr; ~HeapOwner() { oakgpu_heap_destroy(h); } } heap;
   if (prm->keep_node && oakgpu_heap_create(&heap.h)) return -1;

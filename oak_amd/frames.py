@@ -73,7 +73,7 @@ def selfplay_game(ctx, teams, battle_seed, iterations=1 << 12, batch=1024, bandi
     prm.max_battle_length, prm.seed = int(max_battle_length), int(seed)
     prm.keep_node = 1 if keep_node else 0
     t = np.ascontiguousarray(teams, dtype=np.uint8).reshape(60)
-    cap = 4 + 2 + 384 + 1 + 83 * (int(max_battle_length) or 1000)
+    cap = 4 + 2 + 384 + 1 + 83 * (int(max_battle_length) or 2048)
     out = np.zeros(cap, dtype=np.uint8)
     written, frames, result = C.c_size_t(0), C.c_uint32(0), C.c_uint8(0)
     _lib.check(ctx.lib.oakgpu_selfplay_game(ctx.handle, evaluator.handle if use_net else None, t.ctypes.data_as(C.c_void_p), int(battle_seed),
@@ -104,7 +104,7 @@ def selfplay_games(ctxs, teams, battle_seeds, seeds, iterations=1 << 12, batch=1
         prms[g].keep_node = 1 if keep_node else 0
     t = np.ascontiguousarray(teams, dtype=np.uint8).reshape(n, 60)
     bs = (C.c_uint64 * n)(*[int(x) for x in battle_seeds])
-    cap = 4 + 2 + 384 + 1 + 83 * (int(max_battle_length) or 1000)
+    cap = 4 + 2 + 384 + 1 + 83 * (int(max_battle_length) or 2048)
     out = np.zeros((n, cap), dtype=np.uint8)
     written, frames, result = (C.c_size_t * n)(), (C.c_uint32 * n)(), (C.c_uint8 * n)()
     cp = (C.c_void_p * n)(*[c_.handle for c_ in ctxs])
