@@ -4,7 +4,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liboakgpu.so")
+LIB_PATH = os.environ.get("OAKGPU_LIB") or os.path.join(_HERE, "liboakgpu.so")   # (OAKGPU_LIB: an alternative build of the SAME library, e.g. tools/engine_variants.sh)
 
 # every symbol include/oakgpu.h declares (checked by tests/test_abi.py)
 SYMBOLS = [

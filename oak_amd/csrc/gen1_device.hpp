@@ -22,6 +22,17 @@ namespace oak {
 
 #include "gen1_tables.inc"
 
+// Roll-order choices that pkmn/engine's -Dshowdown path settles by following Pokemon Showdown's own code (the reference builds
+// libpkmn with -Dshowdown: /root/reference/dev/libpkmn:9).  Same names and defaults in the CPU checker's restatement of the engine (the tests hold the three to each other); 0 = rounds 1-3:
+//   OAK_MULTIHIT_ROLL_FIRST  multi-hit count rolled behind the accuracy check, before crit / damage (gen-1 tryMoveHit)
+//   OAK_PSYWAVE_SHOWDOWN     Psywave = random(0, level * 3 / 2), a 0 fails (Desync Clause Mod); the action holds the roll + 1
+#ifndef OAK_MULTIHIT_ROLL_FIRST
+#define OAK_MULTIHIT_ROLL_FIRST 1
+#endif
+#ifndef OAK_PSYWAVE_SHOWDOWN
+#define OAK_PSYWAVE_SHOWDOWN 1
+#endif
+
 // ---- result / choice encodings (cpp/include/libpkmn/pkmn.h:108-133,214-233) ------------
 enum : uint32_t { R_NONE = 0, R_WIN = 1, R_LOSE = 2, R_TIE = 3, R_ERROR = 4 };
 enum : uint32_t { C_PASS = 0, C_MOVE = 1, C_SWITCH = 2 };
@@ -890,6 +901,7 @@ struct Engine {
       return;
     }
 
+    uint32_t hits = 1;
     if (fixed) {
       uint32_t d;
       if (move_id == M_Counter) { d = r16(B_LAST_DAMAGE) * 2; if (d > 65535) d = 65535; }
@@ -898,13 +910,25 @@ struct Engine {
       else if (move_id == M_DragonRage) d = 40;
       else if (move_id == M_Psywave) {
         uint32_t max = r8(sp + P_LEVEL) * 3 / 2;
+#if OAK_PSYWAVE_SHOWDOWN
+        d = rng_range(0, max ? max : 1); // Showdown: random(0, max), a 0 fails the move; the action holds the roll + 1
+        act_set(p, AC_PSYWAVE, 8, d + 1);
+        if (d == 0) { w16(B_LAST_DAMAGE, 0); clear_binding(p); return; }
+#else
         d = max <= 1 ? 1 : rng_range(1, max);
         act_set(p, AC_PSYWAVE, 8, d);
+#endif
       } else d = r8(sp + P_LEVEL); // SeismicToss, NightShade
       w16(B_LAST_DAMAGE, d);
     } else if (ohko) {
       w16(B_LAST_DAMAGE, 65535);
     } else {
+#if OAK_MULTIHIT_ROLL_FIRST
+      if (eff == E_MultiHit) { // Showdown order: the count behind the accuracy check, before crit / damage
+        hits = (0x54333222u >> (4 * rng_range(0, 8))) & 15; // {2,2,2,3,3,3,4,5}
+        act_set(p, AC_MULTIHIT, 4, hits);
+      }
+#endif
       bool crit = check_crit(p, mv);
       if (!calc_damage(p, p ^ 1, mv.bp(), mv.type(), eff == E_Explode, crit)) return;
       adjust_damage(p, mv);
@@ -912,12 +936,13 @@ struct Engine {
       if (r16(B_LAST_DAMAGE) == 0) { clear_binding(p); return; }
     }
 
-    uint32_t hits = 1;
     if (eff == E_DoubleHit || eff == E_Twineedle) hits = 2;
+#if !OAK_MULTIHIT_ROLL_FIRST
     else if (eff == E_MultiHit) {
       hits = (0x54333222u >> (4 * rng_range(0, 8))) & 15; // {2,2,2,3,3,3,4,5}
       act_set(p, AC_MULTIHIT, 4, hits);
     }
+#endif
 
     bool broke = false, hit_sub = false;
     uint32_t dealt = 0;

@@ -896,6 +896,7 @@ struct EngineR {
       // -- stage 4: damage ---------------------------------------------------------------------------
       OAK_SCOPE(PS_DAMAGE);
       OAK_T0(t_cd);
+      uint32_t hits = 1;
       if (fixed) {
         uint32_t dd;
         if (move_id == M_Counter) { dd = last_damage * 2; if (dd > 65535) dd = 65535; }
@@ -904,25 +905,38 @@ struct EngineR {
         else if (move_id == M_DragonRage) dd = 40;
         else if (move_id == M_Psywave) {
           const uint32_t max = level(S) * 3 / 2;
+#if OAK_PSYWAVE_SHOWDOWN
+          dd = rng_range(0, max ? max : 1); // Showdown: random(0, max), a 0 fails the move; the action holds the roll + 1
+          act_set(true, AC_PSYWAVE, 8, dd + 1);
+          if (dd == 0) { last_damage = 0; clear_binding(S); return; }
+#else
           dd = max <= 1 ? 1 : rng_range(1, max);
           act_set(true, AC_PSYWAVE, 8, dd);
+#endif
         } else dd = level(S); // SeismicToss, NightShade
         last_damage = dd;
       } else if (ohko) {
         last_damage = 65535;
       } else {
+#if OAK_MULTIHIT_ROLL_FIRST
+        if (eff == E_MultiHit) { // Showdown order: the count behind the accuracy check, before crit / damage
+          hits = (0x54333222u >> (4 * rng_range(0, 8))) & 15; // {2,2,2,3,3,3,4,5}
+          act_set(true, AC_MULTIHIT, 4, hits);
+        }
+#endif
         const bool crit = check_crit(mv);
         if (!calc_damage(F, mv.bp(), mtype, eff == E_Explode, crit)) return;
         adjust_damage(mv);
         randomize_damage();
         if (last_damage == 0) { clear_binding(S); return; } // rounded down to nothing
       }
-      uint32_t hits = 1;
       if (eff == E_DoubleHit || eff == E_Twineedle) hits = 2;
+#if !OAK_MULTIHIT_ROLL_FIRST
       else if (eff == E_MultiHit) {
         hits = (0x54333222u >> (4 * rng_range(0, 8))) & 15; // {2,2,2,3,3,3,4,5}
         act_set(true, AC_MULTIHIT, 4, hits);
       }
+#endif
       OAK_T1(PS_CALC_DAMAGE, t_cd);
       OAK_T0(t_ah);
       bool broke = false, hit_sub = false;

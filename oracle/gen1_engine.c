@@ -15,25 +15,27 @@
  *
  * RNG call order per executed damaging move (documented contract, mirrored by the HIP
  * kernel):  [speed tie] -> [confusion self-hit] -> [full paralysis] -> [thrash/bide
- * duration] -> [metronome] -> accuracy -> critical hit -> damage roll -> [multi-hit /
- * binding count] -> [secondary-effect chance] -> [secondary duration].
+ * duration] -> [metronome] -> accuracy -> [multi-hit count] -> critical hit -> damage roll ->
+ * [binding count] -> [secondary-effect chance] -> [secondary duration].  (Rounds 1-3 rolled the
+ * multi-hit count behind the damage roll: OAK_MULTIHIT_ROLL_FIRST=0.)
  *
  * RESTATEMENT CHOICES THAT NOTHING IN THE REFERENCE CAN CONFIRM (libpkmn's source is absent; these follow the
  * author's reading of the published gen-1 / Pokemon-Showdown mechanics; each lists what the alternative under
  * pkmn/engine's published `-Dshowdown` code path would be, should a maintainer hold the real library against it):
- *  1. Multi-hit count (DoubleSlap, PinMissile, ... `EFF_MultiHit`) is rolled AFTER the critical-hit and damage rolls
- *     (below: `hits = dist[rng_range(b, 0, 8)]` behind randomize_damage).  Alternative: the count rolled right after the
- *     accuracy check and BEFORE crit / damage -- same number of LCG draws per move, but the three rolls would see each
- *     other's values: every multi-hit move's (crit, damage, hits) triple would differ although their distributions agree.
+ *  1. Multi-hit count (DoubleSlap, PinMissile, ... `EFF_MultiHit`).  SINCE ROUND 4 rolled right after the accuracy check and
+ *     BEFORE crit / damage -- Pokemon Showdown's gen-1 tryMoveHit samples `hits` and only then calls moveHit, which rolls crit
+ *     and the damage factor, and pkmn/engine's -Dshowdown path exists to reproduce Showdown's RNG stream.  Rounds 1-3 rolled
+ *     it AFTER the damage roll (OAK_MULTIHIT_ROLL_FIRST=0): same number of LCG draws per move and the same distributions, but
+ *     every multi-hit move's (hits, crit, damage) triple differs between the two orders.
  *  2. Counter deals `last_damage * 2`, gated by the foe's `last_moves[].counterable` byte (set for Normal / Fighting
  *     moves other than Counter) and a non-zero last_damage.  Alternative (Showdown's gen-1 Counter): gated on the foe's
  *     last SELECTED move's type and on `last_damage` of either side, with the Desync-Clause failures of the cartridge
  *     corner cases (Counter after a switch, after a multi-turn move's second turn); the alternative changes WHEN Counter
  *     fails, never its damage.
- *  3. Psywave draws `rng_range(1, level * 3 / 2)`: uniform on 1 .. max - 1, never 0, never failing.  Alternative: Showdown
- *     draws `random(0, max)` and FAILS the move on a 0 (Desync Clause Mod); one draw either way, so the LCG stream stays
- *     aligned, but 1 in `max` Psywaves (1 / 150 at level 100) would do nothing and the others would be uniform on 1 .. max - 1
- *     with the draw mapped differently.
+ *  3. Psywave.  SINCE ROUND 4 Showdown's rule: `random(0, level * 3 / 2)`, and a 0 FAILS the move (gen-1 moves.ts psywave:
+ *     "Desync Clause Mod activated!"); the chance action holds the roll + 1 (0 = no Psywave this turn).  Rounds 1-3 drew
+ *     `rng_range(1, max)` -- uniform on 1 .. max - 1, never failing (OAK_PSYWAVE_SHOWDOWN=0).  One draw either way, so the LCG
+ *     stream stays aligned; 1 in `max` Psywaves (1 / 150 at level 100) now does nothing and the others map the draw differently.
  *  4. Accuracy (`move_hit`) is rolled BEFORE the critical-hit and damage rolls for every damaging move (Showdown order:
  *     immunity, accuracy, then damage).  Alternative (cartridge order, which pkmn/engine uses without -Dshowdown): crit and
  *     damage first, accuracy last -- a miss would then have consumed two more draws.
@@ -46,6 +48,20 @@
 #include "oracle.h"
 #include "gen1_tables.h"
 #include <string.h>
+
+/* The two roll-order choices above that pkmn/engine's -Dshowdown path settles by following Pokemon Showdown's own code (the
+ * build of /root/reference/dev/libpkmn:9 IS -Dshowdown), as compile-time switches shared -- by name and default -- with the two
+ * HIP engines (oak_amd/csrc/gen1_device.hpp); 0 restores rounds 1-3's behaviour in all three:
+ *   OAK_MULTIHIT_ROLL_FIRST  the multi-hit count is rolled behind the accuracy check, BEFORE crit / damage (Showdown
+ *                            data/mods/gen1/scripts.ts tryMoveHit: `hits = this.battle.sample([2,2,2,3,3,3,4,5])`, then moveHit);
+ *   OAK_PSYWAVE_SHOWDOWN     Psywave draws random(0, level * 3 / 2) and FAILS on 0 (data/mods/gen1/moves.ts psywave: "Desync
+ *                            Clause Mod activated!"); the chance action holds the roll + 1. */
+#ifndef OAK_MULTIHIT_ROLL_FIRST
+#define OAK_MULTIHIT_ROLL_FIRST 1
+#endif
+#ifndef OAK_PSYWAVE_SHOWDOWN
+#define OAK_PSYWAVE_SHOWDOWN 1
+#endif
 
 #pragma pack(push, 1)
 typedef struct { uint16_t hp, atk, def, spe, spc; } Stats;
@@ -800,7 +816,7 @@ static void do_move(Ctx *c, int player, uint8_t mslot) {
     return;
   }
 
-  int crit = 0;
+  int crit = 0, hits = 1;
   if (fixed) {
     uint32_t d;
     if (move_id == MV_Counter) { d = (uint32_t)b->last_damage * 2; if (d > 65535) d = 65535; }
@@ -809,13 +825,27 @@ static void do_move(Ctx *c, int player, uint8_t mslot) {
     else if (move_id == MV_DragonRage) d = 40;
     else if (move_id == MV_Psywave) {
       uint32_t max = (uint32_t)sp->level * 3 / 2;
+#if OAK_PSYWAVE_SHOWDOWN
+      /* Showdown: random(0, max); a 0 fails the move (Desync Clause Mod).  The action holds the roll + 1 (0 = no Psywave). */
+      d = rng_range(b, 0, max ? max : 1);
+      act_set(c, player, A_PSYWAVE, 8, d + 1);
+      if (d == 0) { b->last_damage = 0; clear_binding(c, player); return; }
+#else
       d = max <= 1 ? 1 : rng_range(b, 1, max);
       act_set(c, player, A_PSYWAVE, 8, d);
+#endif
     } else d = sp->level; /* SeismicToss, NightShade */
     b->last_damage = (uint16_t)d;
   } else if (ohko) {
     b->last_damage = 65535;
   } else {
+#if OAK_MULTIHIT_ROLL_FIRST
+    if (mv->effect == EFF_MultiHit) { /* Showdown's gen-1 tryMoveHit samples the count right behind the accuracy check, before moveHit rolls crit / damage */
+      static const uint8_t dist0[8] = {2, 2, 2, 3, 3, 3, 4, 5};
+      hits = dist0[rng_range(b, 0, 8)];
+      act_set(c, player, A_MULTIHIT, 4, (uint32_t)hits);
+    }
+#endif
     crit = check_crit(c, player, mv);
     if (!calc_damage(c, player, player ^ 1, mv, crit)) return;
     (void)adjust_damage(b, player, mv);
@@ -823,13 +853,14 @@ static void do_move(Ctx *c, int player, uint8_t mslot) {
     if (b->last_damage == 0) { clear_binding(c, player); return; } /* rounded down to nothing */
   }
 
-  int hits = 1;
   if (mv->effect == EFF_DoubleHit || mv->effect == EFF_Twineedle) hits = 2;
+#if !OAK_MULTIHIT_ROLL_FIRST
   else if (mv->effect == EFF_MultiHit) {
     static const uint8_t dist[8] = {2, 2, 2, 3, 3, 3, 4, 5};
     hits = dist[rng_range(b, 0, 8)];
     act_set(c, player, A_MULTIHIT, 4, (uint32_t)hits);
   }
+#endif
 
   int broke = 0, hit_sub = 0;
   uint32_t dealt = 0;

@@ -5,7 +5,7 @@ import subprocess
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-_SO = os.path.join(ROOT, "oracle", "liboracle.so")
+_SO = os.environ.get("ORACLE_SO") or os.path.join(ROOT, "oracle", "liboracle.so")   # (ORACLE_SO: a variant build, tools/engine_variants.sh)
 
 
 def build():

@@ -425,3 +425,21 @@ def test_concurrent_searches_equal_the_searches_run_alone(gpu_ctx):
         net.close()
         for c in ctxs:
             c.close()
+
+
+@pytest.mark.gpu
+def test_tutorial_vs_known_answer_small_sample():
+    """TUTORIAL.md:99-104: `vs --budget=4096 --bandit=ucb-1.0 --policy-mode=x --p1-eval=fp --p2-eval=mc` scores 186-1-31 for the PokeEngine
+    agent over the 16 sample teams.  tools/tutorial_stats.py rebuilds vs.cc's loop on the GPU path (218 games: 179-0-39 at 64 descents per
+    batch, profiles/r04_tutorial_stats.json); here a fixed-seed sample of 16 games through the same loop: the agent with the static
+    evaluation must still win clearly (the run is deterministic for a given build; 10 of 16 is 1.5 sigma under the 218-game rate)."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, SEED="20261004", CONC="16")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "tutorial_stats.py"), "vs", "8", "256"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    rec = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert rec["games"] == 16 and rec["W"] + rec["D"] + rec["L"] == 16
+    assert rec["W"] + 0.5 * rec["D"] >= 10, rec
+    assert 30 <= rec["mean_updates"] <= 200, rec
