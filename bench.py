@@ -36,7 +36,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 ALGO_BYTES_PER_STEP = 802          # 384 battle + 8 durations + 8 rng + 1 result, read + written
 HBM_PEAK_GBPS = 8000.0             # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
-SEED0 = 0x0A4B00000000             # SURVEY 8(d) config-2 lane seed base
+SEED0 = 0x0A4B00000000 + int(os.environ.get("BENCH_SEED_OFFSET", "0"))   # SURVEY 8(d) config-2 lane seed base (the offset: other samples of the same generator, for A/B runs)
 MAX_STEPS = 1000
 
 

@@ -760,6 +760,13 @@ struct EngineR {
     // -- stage 2: THE accuracy check ------------------------------------------------------------------
     bool hit = true;
     if (go && need_hit) hit = move_hit(mv);
+#if OAK_MULTIHIT_ROLL_FIRST
+    if (eff == E_MultiHit && go && hit) { // Showdown order: the count right behind the accuracy check, before crit / damage
+      const uint32_t h = (0x54333222u >> (4 * rng_range(0, 8))) & 15; // {2,2,2,3,3,3,4,5}
+      act_set(true, AC_MULTIHIT, 4, h);
+      S.misc = (S.misc & 0x00FFFFFFu) | (h << 24); // parked in the spare top byte of the mover's side word until the hit loop
+    }
+#endif
     OAK_T1(PS_GATES_HIT, t_g);
     if (!(go && hit)) {
       if (damaging) {
@@ -896,7 +903,6 @@ struct EngineR {
       // -- stage 4: damage ---------------------------------------------------------------------------
       OAK_SCOPE(PS_DAMAGE);
       OAK_T0(t_cd);
-      uint32_t hits = 1;
       if (fixed) {
         uint32_t dd;
         if (move_id == M_Counter) { dd = last_damage * 2; if (dd > 65535) dd = 65535; }
@@ -918,20 +924,17 @@ struct EngineR {
       } else if (ohko) {
         last_damage = 65535;
       } else {
-#if OAK_MULTIHIT_ROLL_FIRST
-        if (eff == E_MultiHit) { // Showdown order: the count behind the accuracy check, before crit / damage
-          hits = (0x54333222u >> (4 * rng_range(0, 8))) & 15; // {2,2,2,3,3,3,4,5}
-          act_set(true, AC_MULTIHIT, 4, hits);
-        }
-#endif
         const bool crit = check_crit(mv);
         if (!calc_damage(F, mv.bp(), mtype, eff == E_Explode, crit)) return;
         adjust_damage(mv);
         randomize_damage();
         if (last_damage == 0) { clear_binding(S); return; } // rounded down to nothing
       }
+      uint32_t hits = 1;
       if (eff == E_DoubleHit || eff == E_Twineedle) hits = 2;
-#if !OAK_MULTIHIT_ROLL_FIRST
+#if OAK_MULTIHIT_ROLL_FIRST
+      else if (eff == E_MultiHit) hits = S.misc >> 24;
+#else
       else if (eff == E_MultiHit) {
         hits = (0x54333222u >> (4 * rng_range(0, 8))) & 15; // {2,2,2,3,3,3,4,5}
         act_set(true, AC_MULTIHIT, 4, hits);
@@ -1316,6 +1319,20 @@ struct EngineR {
       a = fast_mod(a * two32 + fast_mod(lo, n), n);
     }
     return a;
+  }
+  // Is this position a frozen-versus-frozen standstill whose every further turn-step is the same turn-step?  (k_rollout_queue
+  // skips all but the last of them.)  Both sides: request Move, exactly the active alive, status exactly FRZ, none of the
+  // volatiles that act without a move or change what select_move / before_move do in front of the freeze check (recharging,
+  // Rage, thrashing, charging, Bide, binding, Leech Seed), and speeds that differ (no tie draw).  Then update_frame does:
+  // select_move x 2 (clears the flinch bit, writes last selected move and last move index from the choice), an order decision
+  // that draws nothing, before_move x 2 -> `status & FRZ`: last used move = 0, done; no residual damage (FRZ excludes PSN / BRN,
+  // no Leech Seed), nobody faints; turn + 1, tie at 1,000.  Everything it writes is either the same every time or overwritten
+  // by the next turn-step before it is read.
+  __device__ __forceinline__ bool frozen_standstill(uint32_t result) const {
+    constexpr uint32_t busy = V_RECHARGING | V_RAGE | V_THRASHING | V_CHARGING | V_BIDE | V_BINDING | V_LEECHSEED | V_MULTIHIT;
+    return result == mk_result(0, C_MOVE, C_MOVE) && turn >= 1 && turn < 1000 &&
+           status(S) == ST_FRZ && status(F) == ST_FRZ && (S.misc & 63) == 1 && (F.misc & 63) == 1 &&
+           ((S.vlo | F.vlo) & busy) == 0 && spe(S) != spe(F) && hp(S) > 0 && hp(F) > 0;
   }
   // one random-policy turn-step of the rollout (choices x2 + update), frame-agnostic
   __device__ __forceinline__ uint32_t random_step(uint32_t result, uint32_t hi, uint32_t lo) {

@@ -728,6 +728,23 @@ __global__ __launch_bounds__(BLK, WPS) void k_rollout_queue(GroupArgs g_in, Roun
 #ifdef OAKGPU_TIMELINE
     tl_steps += (unsigned long long)__popcll(__ballot(playing));
 #endif
+    // A standstill that can be PROVEN: both sides down to one Pokemon, both FROZEN (gen 1 never thaws by itself), nothing that acts
+    // on a Pokemon that cannot move (Leech Seed, a binding or multi-turn volatile) and different speeds.  Such a turn-step draws
+    // nothing from battle.rng (no speed tie), executes no move (before_move returns at the freeze check) and leaves every byte as
+    // it was except the turn counter and the fields the NEXT turn-step overwrites unconditionally -- last selected move, last
+    // move index, last used move = 0, the flinch bit -- see EngineR::frozen_standstill.  So all but the last of the remaining
+    // turn-steps are taken at once: turn and step count advance, the choice stream advances by its two draws per turn-step, and
+    // the last turn-step runs for real (it writes those fields and, at turn 1,000, the tie).  These are the stalemates the queue
+    // order cannot see in the teams (round 4: 1-5 per 1.31 M playouts, started anywhere in the queue, each ~950 dependent
+    // turn-steps at a lone lane's 4.7 us: the launches they ended took 16.4-16.6 ms instead of 14.7-14.9).  Exact, not a
+    // heuristic: tests/test_gpu_parity.py holds it to the oracle, which plays every turn.
+    if (playing && stale >= (8u << 24) && e.frozen_standstill(result)) {
+      const uint32_t by_steps = max_steps - steps, by_turn = 1000u - e.turn;
+      const uint32_t skip = (by_steps < by_turn ? by_steps : by_turn) - 1u; // (both >= 1 while playing)
+      for (uint32_t k = 0; k < skip; ++k) { (void)g.next32(); (void)g.next32(); }
+      e.turn += skip;
+      steps += skip;
+    }
     if (playing) {
       const uint32_t hi = g.next32(), lo = g.next32(); // uniform_64 = hi << 32 | lo
       result = e.random_step(result, hi, lo);

@@ -622,3 +622,53 @@ def test_root_groups_pipeline_gives_the_unpipelined_per_root_results():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, os.path.join(root, "tests", "root_groups_check.py")], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "root groups ok" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
+
+
+def _frozen_standstills(n, seed0, clear_volatiles_every=2, turn=None):
+    """Mid-game random OU battles patched into last-Pokemon-against-last-Pokemon positions with BOTH actives frozen -- the stalemate
+    k_rollout_queue takes in one go (EngineR::frozen_standstill).  Every `clear_volatiles_every`-th lane has its actives' volatiles
+    cleared (the proven case); the others keep whatever the game left there (Leech Seed, confusion, substitutes ...: mostly NOT
+    the proven case, same answer required)."""
+    b, d, p, r = O.make_random_ou_batch(n, seed0=seed0)
+    res, _ = O.rollout_batch(b, d, r, p, max_steps=24, threads=8)
+    keep = np.where(res == 0x50)[0]          # still running, both sides asked for a move
+    b, d, p, res = b[keep].copy(), d[keep].copy(), p[keep].copy(), res[keep].copy()
+    for k in range(len(keep)):
+        for s in range(2):
+            so = s * 184
+            act = int(b[k, so + 176]) - 1      # order[0]: the active's party slot
+            for q in range(6):
+                o = so + q * 24
+                if q != act:
+                    b[k, o + 18] = b[k, o + 19] = 0     # hp 0: fainted
+                    b[k, o + 20] = 0
+                else:
+                    b[k, o + 20] = 0x20                 # FRZ
+                    if b[k, o + 18] == 0 and b[k, o + 19] == 0:
+                        b[k, o + 18] = 1
+            if k % clear_volatiles_every == 0:
+                b[k, so + 144 + 16:so + 144 + 24] = 0   # the active's volatiles
+        if turn is not None:
+            b[k, 368], b[k, 369] = turn & 0xFF, turn >> 8
+    d[:] = 0
+    return b, d, p, res
+
+
+@pytest.mark.gpu
+def test_frozen_standstill_skip_is_exact(gpu_ctx):
+    """k_rollout_queue takes a PROVEN standstill (both sides' last Pokemon frozen, nothing acting on them, different speeds) to its last
+    turn-step in one go; the oracle plays every turn.  Same bytes: by step cap, by the 1,000-turn tie, from late turns, with volatiles
+    that do and do not satisfy the proof, and with equal speeds (no skip: a tie is drawn every turn)."""
+    gpu_ctx.set_playouts_per_lane(2)
+    for seed0, cap, turn in ((0xF0F0_0001, 1000, None), (0xF0F0_0002, 137, None), (0xF0F0_0003, 1000, 960), (0xF0F0_0004, 50, 998)):
+        b, d, p, r = _frozen_standstills(3000, seed0, turn=turn)
+        if seed0 == 0xF0F0_0001:                      # a tenth of the lanes: equal speeds (bytes 6-7 of the active's stats)
+            for k in range(0, len(b), 10):
+                b[k, 184 + 144 + 6:184 + 144 + 8] = b[k, 144 + 6:144 + 8]
+        assert len(b) > 1000
+        ob, od, op = b.copy(), d.copy(), p.copy()
+        oout, osteps = O.rollout_batch(ob, od, r, op, max_steps=cap, threads=8)
+        got = gpu_ctx.rollout(b, d, r, p, max_steps=cap, return_state=True)
+        assert (((oout & 15) == 3) | (osteps >= cap)).mean() > 0.9, "the fixture no longer produces standstills"
+        for key, exp in (("results", oout), ("steps", osteps), ("battles", ob), ("durations", od), ("prng", op)):
+            assert (got[key] == exp).all(), (hex(seed0), cap, turn, key, int((got[key] != exp).sum()))

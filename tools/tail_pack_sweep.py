@@ -1,6 +1,7 @@
 """Manual GPU tool: ONE group launch of 20 x 65,536 playouts (the driver's --steps 20 shape) for a sweep of tail-pack
 settings (oakgpu_set_tail_pack: below, waves, lanes).  Prints ms per launch and G turn-steps/s per setting."""
 import ctypes as C
+import os
 import sys
 
 import torch
@@ -21,7 +22,7 @@ steps, values = T(G, n, dt=torch.int32), T(G, n, dt=torch.float32)
 P = lambda t: C.c_void_p(t.data_ptr())
 descs = (_lib.RolloutBatch * G)()
 for k in range(G):
-    _lib.check(lib.oakgpu_random_ou_battles_dev(h, C.c_uint64(0x0A4B00000000 + k * n), n, P(battles[k]), P(durations[k]), P(prng0[k]), P(rin[k])))
+    _lib.check(lib.oakgpu_random_ou_battles_dev(h, C.c_uint64(0x0A4B00000000 + int(os.environ.get('SEED_OFF', '0')) + k * n), n, P(battles[k]), P(durations[k]), P(prng0[k]), P(rin[k])))
     descs[k] = _lib.RolloutBatch(battles[k].data_ptr(), durations[k].data_ptr(), rin[k].data_ptr(), prng[k].data_ptr(), n, rout[k].data_ptr(),
                                  steps[k].data_ptr(), values[k].data_ptr(), None, None)
 torch.cuda.synchronize()
@@ -68,8 +69,10 @@ if len(sys.argv) > 1 and sys.argv[1] == "window":     # standstill-window donati
         out = np.zeros(64, dtype=np.uint32)
         _lib.check(lib.oakgpu_get_queue_counters(h, out.ctypes.data_as(C.c_void_p)))
         return out
-    for win, ls, ad in ((0, 300, 0), (64, 300, 0), (48, 300, 0), (40, 300, 0), (32, 300, 0), (24, 300, 0), (16, 300, 0), (40, 300, 192), (32, 300, 256), (24, 300, 256),
-                        (32, 250, 0), (40, 1000, 0), (0, 300, 0), (40, 300, 0)):
+    full = ((0, 300, 0), (64, 300, 0), (48, 300, 0), (40, 300, 0), (32, 300, 0), (24, 300, 0), (16, 300, 0), (40, 300, 192), (32, 300, 256), (24, 300, 256),
+            (32, 250, 0), (40, 1000, 0), (0, 300, 0), (40, 300, 0))
+    short = ((0, 300, 0), (64, 300, 0), (48, 300, 0), (32, 300, 0), (24, 300, 0), (16, 300, 0), (32, 200, 0), (48, 250, 0))
+    for win, ls, ad in (short if os.environ.get("SHORT") else full):
         _lib.check(lib.oakgpu_set_migration(h, 1, ls, ad))
         _lib.check(lib.oakgpu_set_migration_window(h, win))
         print("window %3d long_steps %4d adopters %3d" % (win, ls, ad), end="  ")

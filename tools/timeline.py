@@ -27,7 +27,7 @@ T = lambda *s, dt=torch.uint8: torch.empty(s, dtype=dt, device=dev)
 battles, durations, prng, prng0, rin, rout = T(n, 384), T(n, 8), T(n, 8), T(n, 8), T(n), T(n)
 steps, values = T(n, dt=torch.int32), T(n, dt=torch.float32)
 P = lambda t: C.c_void_p(t.data_ptr())
-_lib.check(lib.oakgpu_random_ou_battles_dev(h, C.c_uint64(0x0A4B00000000), n, P(battles), P(durations), P(prng0), P(rin)))
+_lib.check(lib.oakgpu_random_ou_battles_dev(h, C.c_uint64(0x0A4B00000000 + int(os.environ.get('SEED_OFF', '0'))), n, P(battles), P(durations), P(prng0), P(rin)))
 for rep in range(2):
     prng.copy_(prng0)
     torch.cuda.synchronize()
@@ -53,5 +53,7 @@ na = int(os.environ.get("TL_ADOPTERS", "0"))
 if na:   # the first `na` waves are the migration's adopters (oakgpu_set_migration)
     print("adopters    us: exit min %.0f med %.0f max %.0f; steps per adopter wave: med %.0f max %.0f" % (end[:na].min(), np.median(end[:na]), end[:na].max(), np.median(tl[:na, 4]), tl[:na, 4].max()))
     print("bulk waves  us: exit med %.0f p99 %.0f max %.0f" % (np.median(end[na:]), np.percentile(end[na:], 99), end[na:].max()))
+order_ = np.argsort(end)[-8:]
+print("last waves   : " + "  ".join("w%d%s exit %.0f us steps %d" % (w, "(adopter)" if w < na else "", end[w], tl[w, 4]) for w in order_))
 for t in range(0, min(int(end.max()) + 1000, 60000), 1000):
     print("  t=%5d us: waves still running %5d" % (t, int((end > t).sum())))
