@@ -1321,18 +1321,21 @@ struct EngineR {
     return a;
   }
   // Is this position a frozen-versus-frozen standstill whose every further turn-step is the same turn-step?  (k_rollout_queue
-  // skips all but the last of them.)  Both sides: request Move, exactly the active alive, status exactly FRZ, none of the
-  // volatiles that act without a move or change what select_move / before_move do in front of the freeze check (recharging,
-  // Rage, thrashing, charging, Bide, binding, Leech Seed), and speeds that differ (no tie draw).  Then update_frame does:
-  // select_move x 2 (clears the flinch bit, writes last selected move and last move index from the choice), an order decision
-  // that draws nothing, before_move x 2 -> `status & FRZ`: last used move = 0, done; no residual damage (FRZ excludes PSN / BRN,
-  // no Leech Seed), nobody faints; turn + 1, tie at 1,000.  Everything it writes is either the same every time or overwritten
-  // by the next turn-step before it is read.
+  // skips all but the last of them.)  Both sides: request Move, status exactly FRZ, hp > 0, no Leech Seed and no binding volatile
+  // (the first drains a Pokemon that cannot move, the second is cleared by the turn's epilogue and would free the side's choices),
+  // and NO WAY OUT: either the active is the side's last Pokemon, or it is locked into its move (recharging, Rage, thrashing,
+  // charging, Bide: `legal` offers the forced move only, and none of these counters runs while before_move returns at the freeze
+  // check in front of them, so the lock never ends).  And speeds that differ (no tie draw).  Then update_frame does: select_move
+  // x 2 (a locked side: nothing; else clears the flinch bit and writes last selected move and last move index from the choice),
+  // an order decision that draws nothing, before_move x 2 -> `status & FRZ`: last used move = 0, done; no residual damage (FRZ
+  // excludes PSN / BRN, no Leech Seed), nobody faints; turn + 1, tie at 1,000.  Everything it writes is either the same every
+  // time or overwritten by the next turn-step before it is read.
   __device__ __forceinline__ bool frozen_standstill(uint32_t result) const {
-    constexpr uint32_t busy = V_RECHARGING | V_RAGE | V_THRASHING | V_CHARGING | V_BIDE | V_BINDING | V_LEECHSEED | V_MULTIHIT;
+    constexpr uint32_t locked = V_RECHARGING | V_RAGE | V_THRASHING | V_CHARGING | V_BIDE;
+    const bool stuckS = (S.misc & 63) == 1 || (S.vlo & locked) != 0, stuckF = (F.misc & 63) == 1 || (F.vlo & locked) != 0;
     return result == mk_result(0, C_MOVE, C_MOVE) && turn >= 1 && turn < 1000 &&
-           status(S) == ST_FRZ && status(F) == ST_FRZ && (S.misc & 63) == 1 && (F.misc & 63) == 1 &&
-           ((S.vlo | F.vlo) & busy) == 0 && spe(S) != spe(F) && hp(S) > 0 && hp(F) > 0;
+           status(S) == ST_FRZ && status(F) == ST_FRZ && stuckS && stuckF && (S.misc & 1) && (F.misc & 1) &&
+           ((S.vlo | F.vlo) & (V_BINDING | V_LEECHSEED)) == 0 && spe(S) != spe(F) && hp(S) > 0 && hp(F) > 0;
   }
   // one random-policy turn-step of the rollout (choices x2 + update), frame-agnostic
   __device__ __forceinline__ uint32_t random_step(uint32_t result, uint32_t hi, uint32_t lo) {

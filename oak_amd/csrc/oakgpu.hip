@@ -728,8 +728,8 @@ __global__ __launch_bounds__(BLK, WPS) void k_rollout_queue(GroupArgs g_in, Roun
 #ifdef OAKGPU_TIMELINE
     tl_steps += (unsigned long long)__popcll(__ballot(playing));
 #endif
-    // A standstill that can be PROVEN: both sides down to one Pokemon, both FROZEN (gen 1 never thaws by itself), nothing that acts
-    // on a Pokemon that cannot move (Leech Seed, a binding or multi-turn volatile) and different speeds.  Such a turn-step draws
+    // A standstill that can be PROVEN: both actives FROZEN (gen 1 never thaws by itself), neither side able to leave (its last
+    // Pokemon, or locked into a move), nothing that acts on a Pokemon that cannot move (Leech Seed, binding) and different speeds.  Such a turn-step draws
     // nothing from battle.rng (no speed tie), executes no move (before_move returns at the freeze check) and leaves every byte as
     // it was except the turn counter and the fields the NEXT turn-step overwrites unconditionally -- last selected move, last
     // move index, last used move = 0, the flinch bit -- see EngineR::frozen_standstill.  So all but the last of the remaining

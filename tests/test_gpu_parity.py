@@ -637,17 +637,21 @@ def _frozen_standstills(n, seed0, clear_volatiles_every=2, turn=None):
         for s in range(2):
             so = s * 184
             act = int(b[k, so + 176]) - 1      # order[0]: the active's party slot
+            locked = k % 8 in (1, 5) and s == (k % 8 == 5)   # a side that keeps its bench but is LOCKED into a move (Rage / recharging)
             for q in range(6):
                 o = so + q * 24
                 if q != act:
-                    b[k, o + 18] = b[k, o + 19] = 0     # hp 0: fainted
-                    b[k, o + 20] = 0
+                    if not locked:
+                        b[k, o + 18] = b[k, o + 19] = 0     # hp 0: fainted
+                        b[k, o + 20] = 0
                 else:
                     b[k, o + 20] = 0x20                 # FRZ
                     if b[k, o + 18] == 0 and b[k, o + 19] == 0:
                         b[k, o + 18] = 1
-            if k % clear_volatiles_every == 0:
+            if k % clear_volatiles_every == 0 or locked:
                 b[k, so + 144 + 16:so + 144 + 24] = 0   # the active's volatiles
+            if locked:
+                b[k, so + 144 + 17] = 0x10 if k % 8 == 1 else 0x08   # V_RAGE (bit 12) / V_RECHARGING (bit 11)
         if turn is not None:
             b[k, 368], b[k, 369] = turn & 0xFF, turn >> 8
     d[:] = 0

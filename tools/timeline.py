@@ -28,7 +28,19 @@ battles, durations, prng, prng0, rin, rout = T(n, 384), T(n, 8), T(n, 8), T(n, 8
 steps, values = T(n, dt=torch.int32), T(n, dt=torch.float32)
 P = lambda t: C.c_void_p(t.data_ptr())
 _lib.check(lib.oakgpu_random_ou_battles_dev(h, C.c_uint64(0x0A4B00000000 + int(os.environ.get('SEED_OFF', '0'))), n, P(battles), P(durations), P(prng0), P(rin)))
-for rep in range(2):
+REPS = int(os.environ.get("REPS", "2"))
+for rep in range(REPS):
+    if rep >= 2:   # (REPS > 2: one line per earlier repetition -- the run-to-run spread of the same launch)
+        wv = min(((n + 63) // 64 + ppl - 1) // ppl, 16384)
+        t_ = np.zeros((wv, 5), dtype=np.uint64)
+        lib.oakgpu_timeline.argtypes = [C.c_void_p, C.c_int]
+        lib.oakgpu_timeline(t_.ctypes.data_as(C.c_void_p), wv)
+        t_ = t_[t_[:, 0] != 0]
+        e_ = (t_[:, 2].astype(np.int64) - np.int64(t_[:, 0].min())) / 100.0
+        na_ = int(os.environ.get("TL_ADOPTERS", "0"))
+        last_ = int(np.argmax(e_))
+        print("rep %d: launch %.3f ms  bulk max exit %.0f us  adopters max exit %.0f us  last wave w%d steps %d  adopters still running 300 us before the end: %d" % (
+            rep - 1, a.elapsed_time(b), e_[na_:].max(), e_[:na_].max() if na_ else 0, last_, t_[last_, 4], int((e_[:na_] > e_.max() - 300).sum()) if na_ else 0))
     prng.copy_(prng0)
     torch.cuda.synchronize()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
