@@ -112,7 +112,12 @@ class RootGroups:
     battles / durations / results_in / prng: device tensors over ALL this rank's lanes (roots x reps, root-major); a group
     works on its contiguous slice in place (prng advances from step to step).  exchange(means, out) -- nullable -- gathers a
     group's padded means [per] into out [world * per] on the current stream; ordered=True launches in a fixed (step, group)
-    order so that every rank issues its collectives in the same order (required whenever exchange is a collective)."""
+    order so that every rank issues its collectives in the same order (required whenever exchange is a collective).
+
+    Stream ordering: the groups' streams are the contexts' own NON-BLOCKING streams, unordered with torch's current stream.  The
+    inputs (and the zero fills of this object's own buffers) are produced on the caller's current stream, so the constructor and
+    every run() first make each group stream wait for it (`wait_stream`); inputs must be complete ON THE CALLER'S CURRENT STREAM
+    when run() is called."""
 
     def __init__(self, make_context, device, battles, durations, results_in, prng, roots, reps, groups, world=1, exchange=None,
                  max_steps=1000, per=None, owns_contexts=True):
@@ -140,6 +145,13 @@ class RootGroups:
                 allm=torch.empty((world * max(self.per, 1),), dtype=torch.float32, device=device),
                 host=torch.empty((world * max(self.per, 1),), dtype=torch.float32).pin_memory(),
                 event=torch.cuda.Event(), done=0, inflight=False, history=[]))
+        self._order_after_caller()
+
+    def _order_after_caller(self):
+        """Every group stream waits for what the caller's current stream has queued so far (input tensors, zero fills)."""
+        cur = self.torch.cuda.current_stream(self.dev)
+        for G in self.groups:
+            G["stream"].wait_stream(cur)
 
     def _p(self, t):
         return self.C.c_void_p(t.data_ptr())
@@ -176,6 +188,7 @@ class RootGroups:
         ranks); else work-conserving: whichever group's means have arrived is relaunched first."""
         for G in self.groups:
             G["done"], G["inflight"], G["history"] = 0, False, []
+        self._order_after_caller()
         if ordered:
             for k in range(steps):
                 for g in range(len(self.groups)):

@@ -9,6 +9,7 @@ integer constants torch.py reads (values from cpp/src/pyoak.cc:586-600 /
 cpp/include/nn/default-hyperparameters.h).  Outputs (data only):
   tests/golden/net_default.battle.net   seeded default-dim network file (reference writer)
   tests/golden/net_tiny.battle.net      small-dim network (generic-dimension coverage)
+  tests/golden/net_256.battle.net       hidden = value_hidden = 256: BASELINE configs[2]'s "3x256 MLP" 
   tests/golden/nn_goldens.npz           inputs + reference outputs of pokemon_net, active_net,
                                         main_net.forward_value_only and main_net.forward (policy logits)
 """
@@ -54,8 +55,9 @@ def main():
     out = {}
     rng = np.random.default_rng(20260101)
     for tag, kw, act in (("default", {}, T.Activation.relu),
-                         ("tiny", dict(phd=16, ahd=24, pod=8, aod=12, hd=32, vhd=16, pohd=8), T.Activation.clamp)):
-        torch.manual_seed(1234 if tag == "default" else 99)
+                         ("tiny", dict(phd=16, ahd=24, pod=8, aod=12, hd=32, vhd=16, pohd=8), T.Activation.clamp),
+                         ("256", dict(hd=256, vhd=256), T.Activation.relu)):
+        torch.manual_seed({"default": 1234, "tiny": 99, "256": 256}[tag])
         net = T.BattleNetwork(activation=act, **kw)
         with torch.no_grad():   # widen the default init so relu/clamp both saturate and pass
             for p in net.parameters():

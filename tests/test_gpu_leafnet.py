@@ -13,6 +13,9 @@ import oracle_lib as O  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-5
+# hidden = value_hidden = 256 (BASELINE configs[2]'s "3x256 MLP"), written by the reference's torch mirror
+# (tests/golden/make_nn_goldens.py); the numpy oracle is held to the mirror's outputs for this file in tests/test_nn_oracle.py
+NET256 = os.path.join(ROOT, "tests", "golden", "net_256.battle.net")
 
 
 def _midgame_states(n, steps, seed0):
@@ -23,7 +26,7 @@ def _midgame_states(n, steps, seed0):
     return b, d
 
 
-@pytest.mark.parametrize("tag", ["default", "tiny"])
+@pytest.mark.parametrize("tag", ["default", "tiny", "256"])
 def test_value_inference_matches_oracle(gpu_ctx, tag):
     from oak_amd.engine import Network
     path = os.path.join(ROOT, "tests", "golden", "net_%s.battle.net" % tag)
@@ -46,8 +49,7 @@ def test_value_inference_matches_oracle(gpu_ctx, tag):
 def test_config3_net_256(gpu_ctx, tmp_path):
     """BASELINE config 3: 768 -> 256 -> 256 -> 256 -> 1 value path, seeded synthetic weights."""
     from oak_amd.engine import Network
-    path = str(tmp_path / "c3.battle.net")
-    NN.write_random_net(path, hidden=256, value_hidden=256, seed=7)
+    path = NET256
     net = Network(gpu_ctx, path=path)
     onet = NN.Net(path)
     b, d = _midgame_states(130, 25, 777)   # ragged: not a multiple of the 64-row tile
@@ -76,8 +78,7 @@ def test_bf16_triple_main_net_is_an_fp32_result(gpu_ctx, tmp_path, kind):
     1e-6; and the mode switch really switches (the two results are not bit-identical everywhere)."""
     from oak_amd.engine import Network
     if kind == "config3":
-        path = str(tmp_path / "c3.battle.net")
-        NN.write_random_net(path, hidden=256, value_hidden=256, seed=7)
+        path = NET256
     else:
         path = os.path.join(ROOT, "tests", "golden", "net_%s.battle.net" % kind)
     net = Network(gpu_ctx, path=path)
@@ -128,8 +129,7 @@ def test_bf16_triple_main_net_at_the_edges_of_the_exponent_range(gpu_ctx, tmp_pa
       * fc0 x 2^+100 alone: fp32 MFMA, values saturate exactly like the float64 evaluation;
       * a net whose fc1 holds weights down to 1e-38 (normal and subnormal fp32) next to ordinary ones: bf16 pipe."""
     from oak_amd.engine import Network
-    src = str(tmp_path / "c3.battle.net")
-    NN.write_random_net(src, hidden=256, value_hidden=256, seed=11)
+    src = NET256
     dst = str(tmp_path / "edge.battle.net")
     dn = {"down20_up20": -20, "down100_up100": -100, "down120_up120": -120, "down100": -100, "down120": -120, "up100": 100}.get(case, 0)
     up = -dn if "_up" in case else 0
@@ -214,8 +214,7 @@ def test_layer_widths(gpu_ctx, tmp_path, dims):
 def test_ragged_batch_sizes(gpu_ctx, tmp_path, n):
     """Batches around the kernels' 32-item mini-tiles (1 leaf = 10 party items + 2 actives; 33 leaves = a second main-net tile of one row)."""
     from oak_amd.engine import Network
-    path = str(tmp_path / "c3.battle.net")
-    NN.write_random_net(path, hidden=256, value_hidden=256, seed=9)
+    path = NET256
     net = Network(gpu_ctx, path=path)
     onet = NN.Net(path)
     b, d = _midgame_states(n, 40, 900 + n)
@@ -241,8 +240,7 @@ def test_tile_form_of_the_embedding_passes_agrees(gpu_ctx, tmp_path):
     import subprocess
     import sys
     from oak_amd.engine import Network
-    path = str(tmp_path / "c3.battle.net")
-    NN.write_random_net(path, hidden=256, value_hidden=256, seed=21)
+    path = NET256
     b, d = _midgame_states(257, 35, 31337)
     np.save(str(tmp_path / "b.npy"), b)
     np.save(str(tmp_path / "d.npy"), d)
@@ -264,8 +262,7 @@ def test_full_size_batch_properties(gpu_ctx, tmp_path):
     (every 32nd leaf) against the C oracle."""
     from oak_amd.engine import Network
     n = 65536
-    path = str(tmp_path / "c3.battle.net")
-    NN.write_random_net(path, hidden=256, value_hidden=256, seed=13)
+    path = NET256
     net = Network(gpu_ctx, path=path)
     b, d, p, r = O.make_random_ou_batch(n, seed0=0xF0115123)
     O.rollout_batch(b, d, r, p, max_steps=25, threads=8)
@@ -298,8 +295,7 @@ def test_config3_rollout_with_leaf_eval_every_turn(gpu_ctx, tmp_path):
     """BASELINE config 3 at test size: after EVERY turn-step run value_inference on the new state.
     GPU: rollout(max_steps=1) + leaf eval per turn; oracle: update + numpy network per turn."""
     from oak_amd.engine import Network
-    path = str(tmp_path / "c3.battle.net")
-    NN.write_random_net(path, hidden=256, value_hidden=256, seed=11)
+    path = NET256
     net = Network(gpu_ctx, path=path)
     onet = NN.Net(path)
     n, turns = 96, 30
@@ -363,8 +359,7 @@ def test_value_policy_inference_config3_net(gpu_ctx, tmp_path):
     budget (two activation tiles next to the staged weight chunk) is only exercised at this width."""
     import oracle_lib as O
     from oak_amd.engine import Network
-    path = str(tmp_path / "c3p.battle.net")
-    NN.write_random_net(path, hidden=256, value_hidden=256, policy_hidden=64, seed=5)
+    path = NET256
     net = Network(gpu_ctx, path=path)
     onet = NN.Net(path)
     b, d = _midgame_states(96, 15, 31337)
@@ -450,8 +445,7 @@ def test_cached_leaf_eval_equals_plain_eval_over_a_resident_batch(gpu_ctx, tmp_p
     from hipmem import Dev
     from oak_amd import _lib
     from oak_amd.engine import Network
-    path = str(tmp_path / "c3.battle.net")
-    NN.write_random_net(path, hidden=256, value_hidden=256, seed=7)
+    path = NET256
     net = Network(gpu_ctx, path=path)
     lib, h = gpu_ctx.lib, gpu_ctx.handle
     n = 3001

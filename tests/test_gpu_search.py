@@ -443,3 +443,78 @@ def test_tutorial_vs_known_answer_small_sample():
     assert rec["games"] == 16 and rec["W"] + rec["D"] + rec["L"] == 16
     assert rec["W"] + 0.5 * rec["D"] >= 10, rec
     assert 30 <= rec["mean_updates"] <= 200, rec
+
+
+# ---- BASELINE configs[4] at bench.py's size (search_workload: 8 roots at once, 2^18 iterations, 768-256-256-256-1 net) --------------
+def _nash_certificate(out, tol=1e-9):
+    """The minimax certificate of MCTS::Search::process_output's solve (mcts.h:620-659): the matrix it solved is the empirical root
+    matrix x 256 truncated to integers; (p1, p2, v) is an equilibrium of it iff no pure reply beats v -- checked in exact rationals from
+    the floats the output carries (the solver's strategies are k / denominator, so the tolerance only has to cover their float form)."""
+    from fractions import Fraction
+    v, n = out["value_matrix"], out["visit_matrix"]
+    M = (v / np.where(n == 0, 1, n) * 256).astype(np.int64)
+    p1 = [Fraction(float(x)) for x in out["p1_nash"]]
+    p2 = [Fraction(float(x)) for x in out["p2_nash"]]
+    assert all(x >= 0 for x in p1) and all(x >= 0 for x in p2)
+    assert abs(sum(p1) - 1) < tol and abs(sum(p2) - 1) < tol
+    val = Fraction(float(out["nash_value"])) * 256
+    rows = [sum(int(M[i, j]) * p2[j] for j in range(M.shape[1])) for i in range(M.shape[0])]     # P1's pure replies to p2
+    cols = [sum(int(M[i, j]) * p1[i] for i in range(M.shape[0])) for j in range(M.shape[1])]     # P2's pure replies to p1
+    assert max(rows) <= val + tol * 256 and min(cols) >= val - tol * 256, (float(max(rows)), float(min(cols)), float(val))
+    return M
+
+
+def test_full_size_config5_search_properties(gpu_ctx):
+    """BASELINE configs[4] at the size bench.py times it (search_workload / the `config5` record): oakgpu_search_many, 8 random OU turn-1
+    roots searched AT ONCE, 2^18 iterations each in batches of 16,384 descents, joint UCB (c = 2), the 768-256-256-256-1 network
+    (tests/golden/net_256.battle.net, the reference torch mirror's file) as leaf evaluator, exact Nash of the root matrix.  No oracle
+    exists for a search (the reference's is seeded from std::random_device, search-test.cc:20-21), so everything is held by
+    properties (MCTS::Search::run, mcts.h:154-248; process_output, mcts.h:498-566, 620-659):
+      * bookkeeping: every iteration is one root visit (visit sum = iterations = 2^18), 0 <= value sum <= visits per cell, every legal
+        joint action is visited, nodes <= iterations + 1, the tree is deeper than one ply;
+      * the Nash solution is an exact equilibrium of the matrix process_output solved (rational best-response certificate), both
+        strategies are distributions, the value is inside the matrix's range;
+      * same seeds -> the same eight outputs, byte for byte (the many-roots schedule is deterministic);
+      * each of the eight equals the search run ALONE on another context with all host threads (visit / value matrices, nodes, depth,
+        Nash value): concurrency changes nothing;
+      * the empirical value and strategies are the matrices' own sums; eight different positions give eight different values."""
+    import oracle_lib as O
+    from oak_amd.engine import Context, Network
+    from oak_amd.search import tree_search, tree_search_many
+    R, iters, batch = 8, 1 << 18, 16384
+    b, d, p, r = O.make_random_ou_batch(R, seed0=0x0A4B00000000 + 4096)      # bench.py's roots (SEED0 + 4096)
+    net = Network(gpu_ctx, path=os.path.join(ROOT, "tests", "golden", "net_256.battle.net"))
+    assert net.shape()[:3] == (768, 256, 256)
+    ctxs = [Context(0) for _ in range(R)]
+    try:
+        seeds = list(range(R))
+        many = tree_search_many(ctxs, b, d, r, seeds, iterations=iters, batch=batch, evaluator=net, threads_per_search=2)
+        again = tree_search_many(ctxs, b, d, r, seeds, iterations=iters, batch=batch, evaluator=net, threads_per_search=2)
+        values = []
+        for i in range(R):
+            o = many[i]
+            assert o["iterations"] == iters and int(o["visit_matrix"].sum()) == iters
+            assert o["m"] >= 1 and o["n"] >= 1 and o["visit_matrix"].shape == (o["m"], o["n"])
+            assert (o["visit_matrix"] > 0).all()                                   # 2^18 iterations over <= 81 cells: none unvisited
+            assert (o["value_matrix"] >= 0).all() and (o["value_matrix"] <= o["visit_matrix"] + 1e-6).all()
+            assert 81 < o["nodes"] <= iters + 1 and 1.0 < o["mean_depth"] <= 100.0
+            M = _nash_certificate(o)
+            assert M.min() / 256 - 1e-9 <= o["nash_value"] <= M.max() / 256 + 1e-9
+            emp = o["value_matrix"].sum() / iters
+            assert abs(emp - o["empirical_value"]) < 1e-9 and 0.0 < emp < 1.0
+            assert abs(o["p1_empirical"].sum() - 1) < 1e-9 and abs(o["p2_empirical"].sum() - 1) < 1e-9
+            assert np.allclose(o["p1_empirical"], o["visit_matrix"].sum(axis=1) / iters, atol=1e-12)
+            assert np.allclose(o["p2_empirical"], o["visit_matrix"].sum(axis=0) / iters, atol=1e-12)
+            values.append(emp)
+            for key in ("visit_matrix", "value_matrix", "p1_nash", "p2_nash"):
+                assert (o[key] == again[i][key]).all(), (i, key)
+            assert o["nodes"] == again[i]["nodes"] and o["nash_value"] == again[i]["nash_value"]
+            alone = tree_search(gpu_ctx, b[i], d[i], int(r[i]), iterations=iters, batch=batch, seed=seeds[i], evaluator=net)
+            for key in ("visit_matrix", "value_matrix", "p1_nash", "p2_nash"):
+                assert (o[key] == alone[key]).all(), (i, key)
+            assert o["nodes"] == alone["nodes"] and o["nash_value"] == alone["nash_value"] and o["mean_depth"] == alone["mean_depth"]
+        assert len(set(round(v, 6) for v in values)) == R                          # eight different positions, eight different answers
+    finally:
+        net.close()
+        for c in ctxs:
+            c.close()

@@ -12,10 +12,12 @@ import nn_oracle as NN  # noqa: E402
 G = np.load(os.path.join(ROOT, "tests", "golden", "nn_goldens.npz"))
 
 
-@pytest.mark.parametrize("tag", ["default", "tiny"])
+@pytest.mark.parametrize("tag", ["default", "tiny", "256"])
 def test_subnetworks_match_reference_torch(tag):
     net = NN.Net(os.path.join(ROOT, "tests", "golden", "net_%s.battle.net" % tag))
-    assert net.activation == (1 if tag == "default" else 2)
+    assert net.activation == (2 if tag == "tiny" else 1)
+    if tag == "256":   # BASELINE configs[2]'s net: 768 -> 256 -> 256 -> 256 -> 1
+        assert (net.fc0.in_dim, net.fc0.out_dim, net.fc1.out_dim, net.v2.out_dim) == (768, 256, 256, 256)
     for x, y in zip(G[tag + "_xp"], G[tag + "_yp"]):
         nz = np.nonzero(x)[0]
         got = net.embed(net.p0, net.p1, nz, x[nz])
@@ -86,8 +88,7 @@ def test_c_port_matches_numpy_oracle(tmp_path):
     b, d, p, r = O.make_random_ou_batch(160, seed0=0xC0DE)
     O.rollout_batch(b[:80], d[:80], r[:80], p[:80], max_steps=25, threads=2)
     O.rollout_batch(b[80:], d[80:], r[80:], p[80:], max_steps=70, threads=2)
-    wide = str(tmp_path / "c3.battle.net")
-    NN.write_random_net(wide, hidden=256, value_hidden=256, seed=7)
+    wide = os.path.join(ROOT, "tests", "golden", "net_256.battle.net")
     for path in (os.path.join(ROOT, "tests", "golden", "net_default.battle.net"),
                  os.path.join(ROOT, "tests", "golden", "net_tiny.battle.net"), wide):
         net, cnet = NN.Net(path), O.CNet(path)
