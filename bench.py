@@ -55,6 +55,10 @@ def main():
                          "the library's own ncclAllGather call site (oakgpu_all_gather_dev)")
     ap.add_argument("--root-groups", type=int, default=4,
                     help="config4: independent groups a rank cuts its roots into (oak_amd.dist.RootGroups); 1 = one launch per step")
+    ap.add_argument("--root-slice", type=int, default=64,
+                    help="config4: turn-steps a launch advances each playout in flight by (oak_amd.dist.RootSteps: a playout is credited to "
+                         "step k + (len - 1) // slice of its root, stragglers travel on a carry list); a power of two; 0 = round 4's grouped "
+                         "form (every step waits for its longest playout, --root-groups)")
     ap.add_argument("--workload", choices=["all", "rollout", "leaf", "config3", "config4", "search"], default="all",
                     help="all (default) = the configs[1] headline line + `leaf` and `config3` sub-records; rollout = configs[1] "
                          "only; leaf = leaf-evals/s of the 768-256-256-256-1 net; config3 = configs[2]: one turn-step of the "
@@ -770,11 +774,61 @@ def config4_workload(args, torch, dev, rank, local_rank, world, dist):
         del battles, durations, rin, prng
         return dt, my_steps, G, blocks
 
+    def run_sliced(lo, hi, K, W, w, r, exchange_on):
+        """K timed search steps of roots [lo, hi) in slices (oak_amd.dist.RootSteps) as rank r of w: a step's launch advances every playout
+        in flight by <= --root-slice turn-steps, credits the ones that finished to this step and carries the rest; the step is over when
+        its per-root aggregates (of every rank) are on the host, and only then is the next step launched.  Returns (seconds, turn-steps
+        executed by the timed launches, last step's gathered record, carried playouts after the last step)."""
+        mine = hi - lo
+        n = mine * reps
+        prng = torch.empty((n, 8), dtype=u8, device=dev)
+        tb, tdur, tr = torch.empty((n, 384), dtype=u8, device=dev), torch.empty((n, 8), dtype=u8, device=dev), torch.empty((n,), dtype=u8, device=dev)
+        # one fast_prng stream per (root, replica), seeded by its GLOBAL lane index (results do not depend on the number of ranks)
+        _lib.check(lib.oakgpu_random_ou_battles_dev(h, C.c_uint64(0xC40000000000 + lo * reps), n, P(tb), P(tdur), P(prng), P(tr)))
+        ctx.synchronize()
+        del tb, tdur, tr
+        per = -(-n_roots // w) if exchange_on else mine
+
+        def exchange(send, recv):     # on the context's stream: `per` int64 per rank
+            if rccl:
+                _lib.check(lib.oakgpu_all_gather_dev(h, comm[0], P(send), P(recv), 2 * per))      # (counted in floats: 2 per int64)
+            else:
+                dist.all_gather_into_tensor(recv, send)
+        ex = exchange if (exchange_on and (w > 1 or rccl)) else None
+        rs = oakdist.RootSteps(ctx, dev, rb[lo:hi].contiguous(), rd[lo:hi].contiguous(), rr[lo:hi].contiguous(), prng, mine, reps,
+                               slice=args.root_slice, max_steps=MAX_STEPS, world=(w if exchange_on else 1), exchange=ex, per=per)
+        # warm-up: the carry lists reach their steady population after ~250 / slice steps (99.5 % of the playouts end before 250 turn-steps)
+        for _ in range(max(W, 2 + 256 // max(args.root_slice, 1))):
+            rs.step()
+            rs.finish()
+        torch.cuda.synchronize(dev)
+        if exchange_on and w > 1:
+            dist.barrier()
+        t0 = time.perf_counter()
+        steps_done = 0
+        for _ in range(K):
+            rs.step()
+            rec = rs.finish()        # the aggregates of every rank are on the host: the step is over
+            steps_done += rec["turn_steps"]
+        torch.cuda.synchronize(dev)
+        if exchange_on and w > 1:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        carried = rec["carried"]
+        rs.close()
+        del prng
+        return dt, steps_done, rec, carried
+
+    sliced = args.root_slice > 0
     if rccl:
         args.root_groups = 1
     lo, hi = oakdist.root_shard(n_roots, rank, world)
     K = args.steps
-    elapsed, my_steps, G, blocks = run(lo, hi, args.root_groups, K, args.warmup, world, rank, True)
+    if sliced:
+        elapsed, my_steps, last, carried = run_sliced(lo, hi, K, args.warmup, world, rank, True)
+        G, blocks = 1, None
+    else:
+        elapsed, my_steps, G, blocks = run(lo, hi, args.root_groups, K, args.warmup, world, rank, True)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -784,7 +838,14 @@ def config4_workload(args, torch, dev, rank, local_rank, world, dist):
         all_steps = int(s_.item())
     else:
         all_steps = my_steps
-    got = oakdist.assemble_group_means(n_roots, world, G, blocks)
+    if sliced:
+        per_ = -(-n_roots // world)
+        cnt = oakdist.assemble_rank_blocks(n_roots, world, per_, last["count"])
+        got = oakdist.credited_means(cnt, oakdist.assemble_rank_blocks(n_roots, world, per_, last["sum2"]))
+        # in the steady state a step is credited as many playouts as it starts (they are other steps' stragglers, not its own)
+        assert abs(int(cnt.sum()) - n_roots * reps) <= n_roots * reps // 50, "a step's credited playouts are not ~ roots x playouts"
+    else:
+        got = oakdist.assemble_group_means(n_roots, world, G, blocks)
     assert got.shape == (n_roots,) and ((got >= 0) & (got <= 1)).all(), "the gathered per-root means are not the 256 roots' means"
     rec = None
     if rank == 0:
@@ -795,39 +856,55 @@ def config4_workload(args, torch, dev, rank, local_rank, world, dist):
             "n_gpus": world, "ranks_seen": (dist.get_world_size() if dist is not None else 1),
             "steps": K, "warmup": args.warmup, "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "u16", "data": "synthetic",
-            "config": {"workload": "configs[3]: root-parallel MCTS, 256 roots x 4096 playouts per search step and root, roots sharded contiguous-by-root over "
-                                   "the ranks and cut into independent groups per rank (no barrier across roots: a group's next step starts when ITS "
-                                   "means are on the host); per-root means reduced on the device, ONE all-gather per group and step; every root performs "
-                                   "exactly `steps` steps", "roots": n_roots, "playouts_per_root": reps, "roots_per_gpu": hi - lo, "root_groups_per_gpu": G,
+            "config": {"workload": (
+                           "configs[3]: root-parallel MCTS, 256 roots x 4096 fresh playouts per search step and root (root prep + rollout), roots sharded "
+                           "contiguous-by-root over the ranks; a step's launch advances every playout in flight by at most %d turn-steps "
+                           "(oakgpu_root_steps / k_root_step): a playout of len turn-steps started in step k is credited to step k + (len - 1) // %d of "
+                           "its root -- a function of its own length, never of the schedule -- and travels between launches as a bit-exact state image "
+                           "(the reference's workers never wait for each other either, generate.cc:527-536); per-root aggregates (count, 2 x value sum: "
+                           "integers) folded into the kernel's retire path, ONE all-gather of them per step, the next step is launched only when they "
+                           "are on the host; `value` counts the turn-steps the timed launches EXECUTED (steady state: as many playouts credited as "
+                           "started per step)" % (args.root_slice, args.root_slice)) if sliced else (
+                           "configs[3], round 4's form (--root-slice 0): every step runs its playouts to terminal; the rank's roots cut into independent "
+                           "groups (no barrier across roots: a group's next step starts when ITS means are on the host); per-root means reduced on the "
+                           "device, ONE all-gather per group and step"),
+                       "roots": n_roots, "playouts_per_root": reps, "roots_per_gpu": hi - lo, "root_groups_per_gpu": G,
+                       "slice_turn_steps": args.root_slice if sliced else None, "pipelined": bool(sliced or G > 1),
+                       "carried_playouts_after_last_step": (carried if sliced else None),
                        "playouts_per_s": n_roots * reps * K / elapsed,
-                       "exchange": ("oakgpu_all_gather_dev (ncclAllGather)" if comm[0] is not None else "torch.distributed all_gather_into_tensor, one per group and step"
+                       "exchange": ("oakgpu_all_gather_dev (ncclAllGather)" if comm[0] is not None else "torch.distributed all_gather_into_tensor, one per step"
                                     if world > 1 else "none (one rank)"),
                        "mean_root_value": float(got.mean())},
-            "roofline": {"bound": "hbm", "kernel": "oak::k_rollout_regs (one launch = one search step of one group's roots, root prep included)" if G > 1 else
-                                                   "oak::k_rollout_queue (one launch = one search step of this rank's roots, root prep included)",
+            "roofline": {"bound": "hbm", "kernel": ("oak::k_root_step (one launch = one search step of this rank's roots: carried playouts resumed, fresh ones "
+                                                    "prepared, everything advanced one slice)") if sliced else
+                                                   ("oak::k_rollout_regs (one launch = one search step of one group's roots, root prep included)" if G > 1 else
+                                                    "oak::k_rollout_queue (one launch = one search step of this rank's roots, root prep included)"),
                          "achieved": my_steps * ALGO_BYTES_PER_STEP / elapsed / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": my_steps * ALGO_BYTES_PER_STEP / elapsed / 1e9 / HBM_PEAK_GBPS,
                          "traffic": (per_step * my_steps / K if per_step else None),
                          "traffic_source": (PROFILE_SOURCE + ": config4_hbm_bytes_per_turn_step (2 x FETCH_SIZE + WRITE_SIZE of a profiled step) x this run's "
                                             "turn-steps per step; not measured in this run") if per_step else None,
                          "algorithmic_bytes_per_turn_step": ALGO_BYTES_PER_STEP,
-                         "note": "whole-job clock over all groups (launches + segment means + gathers + host copies), per rank; notional like the headline's: "
-                                 "the kernels are VALU-issue bound"},
+                         "note": "whole-job clock (launches + gathers + host copies + the host's wait for every step's aggregates), per rank; notional like the "
+                                 "headline's: the kernel is VALU-issue bound"},
         }
     if world == 1 and not rccl and not os.environ.get("BENCH_NO_RANK_SHARE"):
         # one rank's share at 8 GPUs (32 roots x 4096), same pipelined code, on this one GPU: what bounds the strong-scaling curve
         share = n_roots // 8
-        e8, s8, g8, _ = run(0, share, min(args.root_groups, 2), K, max(args.warmup, 2), 1, 0, False)
+        if sliced:
+            e8, s8, _, _ = run_sliced(0, share, K, max(args.warmup, 2), 1, 0, False)
+            g8 = 1
+        else:
+            e8, s8, g8, _ = run(0, share, min(args.root_groups, 2), K, max(args.warmup, 2), 1, 0, False)
         rec["rank_share"] = {
-            "what": "ONE rank's share of configs[3] at 8 GPUs (%d roots x %d playouts per step) through the same grouped code on this one GPU" % (share, reps),
-            "rank_share_ms": e8 / K * 1e3, "root_groups": g8, "turn_steps_per_s": s8 / e8,
+            "what": "ONE rank's share of configs[3] at 8 GPUs (%d roots x %d playouts per step) through the same code on this one GPU" % (share, reps),
+            "rank_share_ms": e8 / K * 1e3, "root_groups": g8, "slice_turn_steps": args.root_slice if sliced else None, "turn_steps_per_s": s8 / e8,
             "frac_of_full_job_rate": (s8 / e8) / (all_steps / elapsed),
             "projected_8gpu_speedup": (elapsed / K) / (e8 / K),
-            "note": "projection from a one-GPU measurement, NOT a hardware curve: 8 ranks each take rank_share_ms per step (the all-gather of 256 floats "
-                    "is microseconds), so 8 GPUs would run the job full-job-ms / rank_share_ms times faster than one.  The share does not fill a GPU: "
-                    "its step cannot end before its longest playout, and 98% of the roots' 4096-playout batches hold a playout that runs to the "
-                    "1,000-step cap -- 1,000 DEPENDENT turn-steps at a lone lane's ~6.5 us each (DESIGN 6).  More roots per GPU, not more GPUs per "
-                    "root, is what fills a node (profiles/r04_config4_pipeline.json: turn-steps/s by roots in flight).",
+            "note": "projection from a one-GPU measurement, NOT a hardware curve: 8 ranks each take rank_share_ms per step (the all-gather of 256 "
+                    "aggregates is microseconds), so 8 GPUs would run the job full-job-ms / rank_share_ms times faster than one."
+                    + ("" if sliced else "  In this form the share's step cannot end before its longest playout -- 1,000 DEPENDENT turn-steps at a lone "
+                                         "lane's ~6.5 us each."),
         }
     torch.cuda.synchronize(dev)
     if comm[0] is not None:

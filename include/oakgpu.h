@@ -358,6 +358,28 @@ int oakgpu_comm_create(oakgpu_ctx *ctx, const uint8_t *id128, int rank, int worl
 void oakgpu_comm_destroy(oakgpu_comm *comm);
 int oakgpu_all_gather_dev(oakgpu_ctx *ctx, oakgpu_comm *comm, const float *send, float *recv, size_t count);
 
+/* ---- root-parallel search steps that do not wait for their longest playout (BASELINE configs[3]).
+ * One search step of root-parallel MCTS = `reps` fresh playouts per root (run_root_iteration's prep, mcts.h:250-263, then the
+ * rollout loop of mcts.h:448-496) -> one aggregate per root.  The reference's workers never wait for each other
+ * (generate.cc:527-536); a step here does not wait for its stragglers either: every launch advances each playout in flight by at
+ * most `slice` turn-steps (a power of two; 0 = run to terminal inside the step, the plain rollout's behaviour).  A playout of
+ * `len` turn-steps started in step k is credited to step k + (len - 1) / slice (len = 0: step k) -- a function of its own length,
+ * not of the schedule -- and travels between launches as a bit-exact state image on a carry list owned by this object.  Values
+ * never change, only the step they are credited to.
+ *   Streams: lane_prng (n_roots * reps x 8 bytes, device) holds one fast_prng stream per (root, replica), advanced by ONE
+ * uniform_64 per step; that draw is the 8-byte state of the fresh playout's own stream (all-zero -> s1 = 1), which supplies
+ * battle.rng for the prep and then the choices.
+ *   report (device, n_roots + 2 u64, written by the launch): [r] = playouts credited to this step for root r: count | (sum of
+ * 2 x value) << 32 -- integers, so independent of the order playouts finish in; [n_roots] = turn-steps this launch executed;
+ * [n_roots + 1] = playouts carried into the next step | error word << 32 (bit 0: the carry list overflowed -- playouts were
+ * lost; sticky).  fresh = 0 launches a DRAIN step: no new playouts, the carried ones advance one more slice.
+ * Everything is asynchronous on the context's stream; consecutive launches need no host round trip. */
+typedef struct oakgpu_root_steps oakgpu_root_steps;
+int oakgpu_root_steps_create(oakgpu_ctx *ctx, uint32_t n_roots, uint32_t reps, uint32_t slice, uint32_t max_steps, oakgpu_root_steps **out);
+void oakgpu_root_steps_destroy(oakgpu_root_steps *rs);
+int oakgpu_root_steps_launch_dev(oakgpu_root_steps *rs, const uint8_t *root_battles, const uint8_t *root_durations,
+                                 const uint8_t *root_results, uint8_t *lane_prng, int fresh, unsigned long long *report);
+
 /* ---- `.battle.data` training frames + self-play on the GPU path.
  * oakgpu_frames_write / _read = Train::Battle::CompressedFrames::write / read (train/battle/compressed-frame.h:37-243):
  * one game = u32 record length, u16 frame count, the 384-byte battle after the opening update, the final result byte,

@@ -829,6 +829,147 @@ __global__ __launch_bounds__(BLK, WPS) void k_rollout_queue(GroupArgs g_in, Roun
 #undef IS_ADOPTING
 #undef ANY_PLAYING
 
+// ---- root-parallel search steps in SLICES (BASELINE configs[3]: 256 roots x 4,096 playouts per search step) -----------------
+// A search step of root-parallel MCTS hands every root `reps` fresh playouts (run_root_iteration's prep, mcts.h:250-263, then the
+// rollout loop of mcts.h:448-496) and consumes one aggregate per root.  Run to terminal inside the step, a step lasts as long
+// as its LONGEST playout -- 98 % of the 4,096-playout batches hold one that runs into the 1,000-step cap: a chain of 1,000 dependent
+// turn-steps (6 ms) however little work the step holds, which is what bound a rank's share at 8 GPUs (round 4: 6.5 ms, 1.8x
+// projected).  The reference's workers never wait for each other (generate.cc:527-536), and neither does a step here: a launch
+// advances every playout in flight by at most `slice` turn-steps (a power of two).  A playout that ends inside its slice is
+// CREDITED TO THE STEP WHOSE LAUNCH FINISHED IT -- step k + (len - 1) / slice for a playout of len turn-steps started in step k,
+// a function of the playout's own length only, never of the schedule; one that does not is CARRIED: its bit-exact state image
+// (the 384-byte battle, durations, result, step count, its own choice stream, its root) goes to the carry list and the NEXT
+// step's launch resumes it beside that step's fresh playouts.  Values never change, only the step they are credited to.
+// The per-root aggregate is folded into the retire path: one 64-bit atomic per finished playout, count | (2 x value) << 32
+// -- integers, so a root's aggregate does not depend on the order its playouts finish in (byte-identical to the oracle's).
+//   Streams: lane (root r, replica i) owns one fast_prng stream that advances by exactly ONE uniform_64 per step; that draw IS
+// the 8-byte state of the step's fresh playout's own stream (an all-zero draw -- the generator's fixed point -- becomes s1 = 1),
+// from which the playout takes battle.rng (prep) and its choices.  So a carried playout and the lane's next fresh one never
+// share draws, and nothing depends on which launch, wave or rank runs a playout.
+struct RootStepArgs {
+  const uint8_t *root_battles, *root_durations, *root_results; // n_roots x {384, 8, 1}
+  uint8_t *lane_prng;              // n_fresh x 8
+  const uint8_t *cin_state;        // carried playouts: cap x 384-byte battle images ...
+  const uint32_t *cin_meta;        // ... and cap x 8 dwords {dur0, dur1, prng s0, prng s1, steps, root, result, 0}
+  const uint32_t *cin_count;
+  uint8_t *cout_state;
+  uint32_t *cout_meta;
+  uint32_t *cout_count;
+  unsigned long long *acc;         // n_roots: finished playouts credited to this step, count | (2 x value) << 32
+  unsigned long long *turn_steps;  // += the turn-steps this launch executed
+  uint32_t *queue;                 // queue head, zeroed before the launch
+  uint32_t *err;                   // sticky: bit 0 = the carry list overflowed (playouts lost)
+  uint32_t n_fresh, reps, cap, slice_mask, max_steps, pad;
+};
+constexpr int ROOT_STEP_COLD_BYTES = (sizeof(RootStepArgs) + 15) & ~15;
+constexpr int ROOT_STEP_LDS_BYTES = 24 * 64 * 4 + TABLE_LDS_PAD + ROOT_STEP_COLD_BYTES;
+template <int WPS>
+__global__ __launch_bounds__(64, WPS) void k_root_step(RootStepArgs a_in) {
+  extern __shared__ __align__(16) uint8_t smem[];
+  lds_u32 *party = (lds_u32 *)smem;
+  using ER = EngineR<64, false>;
+  Tables T = stage_default_tables((lds_u8 *)smem + ER::PARTY_WORDS * 64 * 4);
+  // the cold arguments are parked in LDS, like k_rollout_queue's: as kernel arguments they would hold ~34 SGPRs across the turn loop
+  lds_u32 *cold = (lds_u32 *)((lds_u8 *)smem + ER::PARTY_WORDS * 64 * 4 + TABLE_LDS_PAD);
+  if (threadIdx.x == 0) {
+    const uint32_t *src = (const uint32_t *)&a_in;
+#pragma unroll
+    for (uint32_t i = 0; i < sizeof(RootStepArgs) / 4; ++i) cold[i] = src[i];
+  }
+  __syncthreads();
+#define RS_PTR(field, type) cold_ptr<type>(cold, offsetof(RootStepArgs, field))
+#define RS_U32(field) ((uint32_t)__builtin_amdgcn_readfirstlane((int)cold[offsetof(RootStepArgs, field) / 4]))
+  const uint32_t wl = threadIdx.x;
+  constexpr uint32_t NONE = 0xFFFFFFFFu, DONE = 0xFFFFFFFEu;
+  const uint32_t cap = RS_U32(cap), max_steps = RS_U32(max_steps), slice_mask = RS_U32(slice_mask);
+  uint32_t n_carry = (uint32_t)__builtin_amdgcn_readfirstlane((int)*RS_PTR(cin_count, const uint32_t *));
+  if (n_carry > cap) n_carry = cap; // (an overflowing launch lost the playouts beyond the cap and said so in *err)
+  const uint32_t total = n_carry + RS_U32(n_fresh);
+  ER e;
+  e.m = party + wl;
+  e.T = T;
+  FastPrng g;
+  g.s0 = g.s1 = 0;
+  uint32_t root = NONE, result = 0, steps = 0, executed = 0;
+  bool dry = false;
+  for (;;) {
+    bool load = false;
+    uint32_t my = 0;
+    const uint64_t mask = __ballot(root == NONE);
+    if (mask && !dry) { // wave-uniform: free lanes take the next playouts of the queue -- the carried ones first (they are the oldest)
+      uint32_t base = 0;
+      if (wl == 0) base = atomicAdd(RS_PTR(queue, uint32_t *), (uint32_t)__popcll(mask));
+      base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+      if (base + (uint32_t)__popcll(mask) >= total) dry = true;
+      if (root == NONE) {
+        my = base + (uint32_t)__popcll(mask & ((1ull << wl) - 1));
+        if (my < total) load = true; else root = DONE;
+      }
+    } else if (mask && root == NONE) root = DONE;
+    if (__ballot(load)) {
+      if (load && my < n_carry) { // resume a carried playout from its image
+        const uint4 *mt = (const uint4 *)(RS_PTR(cin_meta, const uint32_t *) + 8 * (size_t)my);
+        const uint4 m0 = mt[0], m1 = mt[1];
+        g.s0 = m0.z; g.s1 = m0.w;
+        steps = m1.x; root = m1.y; result = m1.z;
+        e.load_battle_global(RS_PTR(cin_state, const uint8_t *) + (size_t)my * 384, m0.x, m0.y);
+      } else if (load) {          // a fresh playout of lane `ln` = (root, replica): mcts.h:250-263
+        const uint32_t ln = my - n_carry;
+        root = ln / RS_U32(reps);
+        uint32_t *ps = (uint32_t *)RS_PTR(lane_prng, uint8_t *) + 2 * (size_t)ln;
+        FastPrng lane;
+        lane.s0 = ps[0]; lane.s1 = ps[1];
+        const uint32_t hi = lane.next32(), lo = lane.next32(); // the lane's uniform_64 of this step = the playout's own stream
+        ps[0] = lane.s0; ps[1] = lane.s1;
+        g.s0 = hi; g.s1 = (hi | lo) ? lo : 1u;
+        const uint32_t *dsrc = (const uint32_t *)RS_PTR(root_durations, const uint8_t *) + 2 * (size_t)root;
+        e.load_battle_global(RS_PTR(root_battles, const uint8_t *) + (size_t)root * 384, dsrc[0], dsrc[1]);
+        const uint32_t bh = g.next32(), bl = g.next32();
+        e.rng = ((uint64_t)bh << 32) | bl;
+        e.randomize_hidden();
+        result = RS_PTR(root_results, const uint8_t *)[root];
+        steps = 0;
+      }
+    }
+    if (__ballot(root != DONE) == 0) break;
+    bool playing = root < DONE && (result & 15) == 0 && steps < max_steps;
+    bool sliced = false;
+    executed += (uint32_t)__popcll(__ballot(playing));
+    if (playing) {
+      const uint32_t hi = g.next32(), lo = g.next32(); // uniform_64 = hi << 32 | lo
+      result = e.random_step(result, hi, lo);
+      ++steps;
+      playing = (result & 15) == 0 && steps < max_steps;
+      sliced = playing && (steps & slice_mask) == 0;
+    }
+    const uint64_t cm = __ballot(sliced);
+    uint32_t slot = 0;
+    if (cm) { // wave-uniform: one ticket range per wave for the playouts whose slice is over
+      const uint32_t leader = (uint32_t)__ffsll((unsigned long long)cm) - 1;
+      uint32_t base = 0;
+      if (wl == leader) base = atomicAdd(RS_PTR(cout_count, uint32_t *), (uint32_t)__popcll(cm));
+      slot = (uint32_t)__builtin_amdgcn_readlane((int)base, (int)leader) + (uint32_t)__popcll(cm & ((1ull << wl) - 1));
+    }
+    if (root < DONE && (!playing || sliced)) { // retire the lane: credit a finished playout to this step / carry an unfinished one
+      if (!sliced) {
+        const uint32_t t = result & 15;
+        const unsigned long long v2 = t == R_WIN ? 2ull : t == R_LOSE ? 0ull : 1ull; // 2 x {1, 0, 0.5}: mcts.h:481-495
+        atomicAdd(RS_PTR(acc, unsigned long long *) + root, 1ull | (v2 << 32));
+      } else if (slot < cap) {
+        e.normalize();
+        uint4 *mt = (uint4 *)(RS_PTR(cout_meta, uint32_t *) + 8 * (size_t)slot);
+        mt[0] = make_uint4(e.S.dur, e.F.dur, g.s0, g.s1);
+        mt[1] = make_uint4(steps, root, result, 0u);
+        e.store_battle_global(RS_PTR(cout_state, uint8_t *) + (size_t)slot * 384);
+      } else atomicOr(RS_PTR(err, uint32_t *), 1u);
+      root = NONE;
+    }
+  }
+  if (wl == 0 && executed) atomicAdd(RS_PTR(turn_steps, unsigned long long *), (unsigned long long)executed);
+#undef RS_PTR
+#undef RS_U32
+}
+
 // ---- K1 with per-turn ACTION-CLASS COMPACTION across the waves of a workgroup (north_star: "wavefront ballot / prefix-sum
 // for per-turn branch compaction").  In k_rollout_queue every wave runs the move pipeline and the switch code twice per
 // turn with ~30 of its 64 lanes in each (PMC: 17 active lanes per VALU instruction on average).  Here 256 lanes step in
@@ -1888,6 +2029,84 @@ int oakgpu_rollout_dev(oakgpu_ctx *c, const uint8_t *battles, const uint8_t *dur
                        uint32_t *steps_out, float *values_out, uint8_t *battles_out, uint8_t *durations_out) {
   const oakgpu_rollout_batch b{battles, durations, results_in, prng_state, n, results_out, steps_out, values_out, battles_out, durations_out};
   return oakgpu_rollout_group_dev(c, &b, 1, max_steps, prep);
+}
+
+// ---- root-parallel search steps in slices (k_root_step; include/oakgpu.h) -----------------------------------------------------
+struct oakgpu_root_steps {
+  oakgpu_ctx *ctx;
+  uint32_t n_roots, reps, slice, max_steps, cap;
+  uint8_t *state[2];   // carry lists, ping-pong: cap x 384
+  uint32_t *meta[2];   // cap x 8 dwords
+  uint32_t *ctl;       // [0], [1]: the two lists' counts; [2]: queue head; [3]: sticky error word; [4..5]: turn-steps (u64)
+  int cur;             // the list the NEXT launch reads
+};
+
+int oakgpu_root_steps_create(oakgpu_ctx *c, uint32_t n_roots, uint32_t reps, uint32_t slice, uint32_t max_steps, oakgpu_root_steps **out) {
+  if (!c || !out) return bad("oakgpu_root_steps_create: null argument");
+  if (n_roots == 0 || reps == 0 || max_steps == 0) return bad("oakgpu_root_steps_create: roots, replicas and max_steps must be positive");
+  if (slice & (slice - 1)) return bad("oakgpu_root_steps_create: slice must be a power of two (0 = playouts run to terminal inside their step)");
+  if ((uint64_t)n_roots * reps >= 0x40000000ull) return bad("oakgpu_root_steps_create: more than 2^30 playouts per step");
+  HIPCHK(hipSetDevice(c->device));
+  oakgpu_root_steps *rs = new oakgpu_root_steps{};
+  rs->ctx = c; rs->n_roots = n_roots; rs->reps = reps; rs->slice = slice; rs->max_steps = max_steps;
+  // every playout in flight is in at most one list: a step adds n_roots * reps and a playout lives ceil(max_steps / slice) launches
+  const uint64_t lives = slice ? (max_steps + slice - 1) / slice : 1;
+  const uint64_t worst = (uint64_t)n_roots * reps * (lives > 1 ? lives - 1 : 0);
+  // ... but the length distribution decays fast (99.5 % of random OU playouts end before 250 turn-steps): three steps' worth is ~2x the
+  // steady state at slice 64; an overflow is reported (sticky error), never silent
+  const uint64_t want = (uint64_t)n_roots * reps * 3;
+  rs->cap = (uint32_t)(worst < want ? worst : want);
+  if (rs->cap == 0) rs->cap = 1;
+  hipError_t e = hipSuccess;
+  for (int k = 0; k < 2 && e == hipSuccess; ++k) {
+    e = hipMalloc((void **)&rs->state[k], (size_t)rs->cap * 384);
+    if (e == hipSuccess) e = hipMalloc((void **)&rs->meta[k], (size_t)rs->cap * 32);
+  }
+  if (e == hipSuccess) e = hipMalloc((void **)&rs->ctl, 64);
+  if (e == hipSuccess) e = hipMemsetAsync(rs->ctl, 0, 64, c->stream);
+  if (e != hipSuccess) { oakgpu_root_steps_destroy(rs); return fail(e, "oakgpu_root_steps_create"); }
+  *out = rs;
+  return 0;
+}
+
+void oakgpu_root_steps_destroy(oakgpu_root_steps *rs) {
+  if (!rs) return;
+  (void)hipSetDevice(rs->ctx->device);
+  (void)hipStreamSynchronize(rs->ctx->stream);
+  for (int k = 0; k < 2; ++k) { if (rs->state[k]) (void)hipFree(rs->state[k]); if (rs->meta[k]) (void)hipFree(rs->meta[k]); }
+  if (rs->ctl) (void)hipFree(rs->ctl);
+  delete rs;
+}
+
+int oakgpu_root_steps_launch_dev(oakgpu_root_steps *rs, const uint8_t *root_battles, const uint8_t *root_durations,
+                                 const uint8_t *root_results, uint8_t *lane_prng, int fresh, unsigned long long *report) {
+  if (!rs || !report) return bad("oakgpu_root_steps_launch_dev: null argument");
+  if (fresh && (!root_battles || !root_durations || !root_results || !lane_prng)) return bad("oakgpu_root_steps_launch_dev: null root / stream pointer");
+  oakgpu_ctx *c = rs->ctx;
+  HIPCHK(hipSetDevice(c->device));
+  const int in = rs->cur, outl = in ^ 1;
+  HIPCHK(hipMemsetAsync(report, 0, ((size_t)rs->n_roots + 2) * 8, c->stream));
+  HIPCHK(hipMemsetAsync(rs->ctl + outl, 0, 4, c->stream)); // the list this launch fills
+  HIPCHK(hipMemsetAsync(rs->ctl + 2, 0, 4, c->stream));    // queue head
+  oak::RootStepArgs a{};
+  a.root_battles = root_battles; a.root_durations = root_durations; a.root_results = root_results; a.lane_prng = lane_prng;
+  a.cin_state = rs->state[in]; a.cin_meta = rs->meta[in]; a.cin_count = rs->ctl + in;
+  a.cout_state = rs->state[outl]; a.cout_meta = rs->meta[outl]; a.cout_count = rs->ctl + outl;
+  a.acc = report; a.turn_steps = report + rs->n_roots; a.queue = rs->ctl + 2; a.err = rs->ctl + 3;
+  a.n_fresh = fresh ? rs->n_roots * rs->reps : 0u; a.reps = rs->reps; a.cap = rs->cap;
+  a.slice_mask = rs->slice ? rs->slice - 1 : 0xFFFFFFFFu; // (0xFFFFFFFF: steps & mask is never 0 after a step -- no slicing)
+  a.max_steps = rs->max_steps;
+  // a persistent grid of the resident waves: the number of carried playouts is only known on the device
+  const uint64_t upper = (uint64_t)a.n_fresh + rs->cap;
+  const uint32_t resident = (uint32_t)c->n_cu * 4u * 4u;
+  const uint32_t waves = (uint32_t)std::min<uint64_t>(resident, (upper + 63) / 64);
+  hipLaunchKernelGGL(oak::k_root_step<4>, dim3(waves), dim3(64), oak::ROOT_STEP_LDS_BYTES, c->stream, a);
+  HIPCHK(hipGetLastError());
+  // report[n_roots + 1] = playouts carried into the next step | error word << 32 (ctl[outl] and ctl[3] are not adjacent: two copies)
+  HIPCHK(hipMemcpyAsync((uint32_t *)(report + rs->n_roots + 1), rs->ctl + outl, 4, hipMemcpyDeviceToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync((uint32_t *)(report + rs->n_roots + 1) + 1, rs->ctl + 3, 4, hipMemcpyDeviceToDevice, c->stream));
+  rs->cur = outl;
+  return 0;
 }
 
 int oakgpu_rollout_draws_dev(oakgpu_ctx *c, const uint8_t *battles, uint32_t battle_stride, const uint8_t *durations,

@@ -231,3 +231,103 @@ class RootGroups:
         if self.owns:
             for c in ctxs:
                 c.close()
+
+
+class RootSteps:
+    """BASELINE configs[3] as search steps that do not wait for their longest playout (include/oakgpu.h: oakgpu_root_steps_*;
+    csrc/oakgpu.hip: k_root_step).  A step hands every root `reps` fresh playouts (root prep + rollout, mcts.h:250-263, 448-496);
+    every launch advances each playout in flight by at most `slice` turn-steps; a playout of `len` turn-steps started in step k is
+    credited to step k + (len - 1) // slice -- a function of its own length -- and travels between launches on a carry list.  The
+    reference's workers never wait for each other either (cpp/src/generate.cc:527-536).  Values never change, only the step they
+    are credited to; per-root aggregates are integer (count, sum of 2 x value), so they do not depend on any order.
+
+    root_battles / root_durations / root_results: device tensors of this rank's `roots` roots; lane_prng [roots * reps, 8]: one
+    fast_prng stream per (root, replica), advanced by one uniform_64 per step (the seeds are the caller's: by GLOBAL lane index, so
+    results do not depend on the number of ranks).  exchange(send, recv) -- nullable -- all-gathers this rank's padded aggregates
+    (`per` int64 per rank) on the current stream: the path's ONE collective.  step() is asynchronous; finish() returns the step's
+    record once its aggregates are on the host."""
+
+    def __init__(self, ctx, device, root_battles, root_durations, root_results, lane_prng, roots, reps, slice=64, max_steps=1000,
+                 world=1, exchange=None, per=None):
+        import ctypes as C
+        from . import _lib
+        self.C, self.lib, self.ctx, self.dev = C, ctx.lib, ctx, device
+        self.roots, self.reps, self.slice, self.world, self.exchange = roots, reps, slice, world, exchange
+        self.per = int(per) if per else roots
+        self.handle = C.c_void_p()
+        _lib.check(self.lib.oakgpu_root_steps_create(ctx.handle, roots, reps, slice, max_steps, C.byref(self.handle)))
+        self.rb, self.rd, self.rr, self.prng = root_battles, root_durations, root_results, lane_prng
+        self.stream = torch.cuda.ExternalStream(ctx.stream_ptr(), device=device)
+        n = max(self.per, roots) + 2
+        self.report = torch.zeros((n,), dtype=torch.int64, device=device)       # [r] count | sum2 << 32, [roots] turn-steps, [roots + 1] carried | err << 32
+        self.send = torch.zeros((self.per,), dtype=torch.int64, device=device)
+        self.recv = torch.zeros((world * self.per,), dtype=torch.int64, device=device)
+        self.host = torch.zeros((world * self.per + 2,), dtype=torch.int64).pin_memory()
+        self.event = torch.cuda.Event()
+        self.stream.wait_stream(torch.cuda.current_stream(device))               # inputs and zero fills come from the caller's stream
+        self.turn_steps = 0
+        self.inflight = False
+
+    def _p(self, t):
+        return self.C.c_void_p(t.data_ptr()) if t is not None else None
+
+    def step(self, fresh=True):
+        """Launch one search step (fresh=False: a drain step -- no new playouts, the carried ones advance one more slice)."""
+        from . import _lib
+        assert not self.inflight, "finish() the previous step first (its record lives in one pinned buffer)"
+        _lib.check(self.lib.oakgpu_root_steps_launch_dev(self.handle, self._p(self.rb), self._p(self.rd), self._p(self.rr), self._p(self.prng),
+                                                         1 if fresh else 0, self._p(self.report)))
+        with torch.cuda.stream(self.stream):
+            self.send.zero_()
+            self.send[:self.roots] = self.report[:self.roots]
+            if self.exchange is not None:
+                self.exchange(self.send, self.recv)
+            else:
+                self.recv[:self.per] = self.send
+            self.host[:self.world * self.per].copy_(self.recv, non_blocking=True)
+            self.host[self.world * self.per:].copy_(self.report[self.roots:self.roots + 2], non_blocking=True)
+            self.event.record(self.stream)
+        self.inflight = True
+
+    def finish(self):
+        """Wait for the step's aggregates: {"count": [world * per], "sum2": [world * per] (rank-major, padded), "turn_steps", "carried"}."""
+        import numpy as np
+        self.event.synchronize()
+        self.inflight = False
+        h = self.host.numpy()
+        k = self.world * self.per
+        acc = h[:k].view(np.uint64)
+        tail = h[k:].view(np.uint64)
+        err = int(tail[1] >> np.uint64(32))
+        if err:
+            raise RuntimeError("oakgpu_root_steps: the carry list overflowed (error word %d): playouts were lost" % err)
+        self.turn_steps += int(tail[0])
+        return {"count": (acc & np.uint64(0xFFFFFFFF)).astype(np.int64), "sum2": (acc >> np.uint64(32)).astype(np.int64),
+                "turn_steps": int(tail[0]), "carried": int(tail[1] & np.uint64(0xFFFFFFFF))}
+
+    def close(self):
+        torch.cuda.synchronize(self.dev)
+        if self.handle:
+            self.lib.oakgpu_root_steps_destroy(self.handle)
+            self.handle = None
+        self.report = self.send = self.recv = None
+        torch.cuda.empty_cache()
+
+
+def assemble_rank_blocks(n_roots, world, per, flat):
+    """flat = a gathered [world * per] array (rank-major, each rank's roots first, then padding) -> the n_roots entries in global
+    root order: rank r holds root_shard(n_roots, r, world)."""
+    import numpy as np
+    flat = np.asarray(flat)
+    out = np.zeros(n_roots, dtype=flat.dtype)
+    for r in range(world):
+        lo, hi = root_shard(n_roots, r, world)
+        out[lo:hi] = flat[r * per:r * per + (hi - lo)]
+    return out
+
+
+def credited_means(count, sum2):
+    """Per-root mean leaf value of one step's credited playouts (0.5 where a root was credited nothing)."""
+    import numpy as np
+    c = np.asarray(count, dtype=np.float64)
+    return np.where(c > 0, np.asarray(sum2, dtype=np.float64) / (2.0 * np.maximum(c, 1.0)), 0.5).astype(np.float32)

@@ -160,3 +160,45 @@ class CNet:
         if self.h:
             LIB.oracle_nn_free(self.h)
             self.h = None
+
+
+def root_steps_reference(root_b, root_d, root_r, lane_prng, reps, steps, slice, max_steps=1000, threads=4):
+    """The oracle of oakgpu_root_steps (BASELINE configs[3] in slices): `steps` search steps over the given roots on the CPU, every
+    playout run to terminal at once (mcts.h:250-263 prep + mcts.h:448-496 loop, oracle_rollout_batch) and credited by the rule the
+    product documents -- a playout of len turn-steps started in step k belongs to step k + (len - 1) // slice (len = 0 or slice = 0:
+    step k).  Lane (root, replica) owns a fast_prng stream that advances by ONE uniform_64 per step; that draw is the 8-byte state of
+    the fresh playout's own stream (all-zero -> s1 = 1).  lane_prng [roots * reps, 8] is advanced in place.
+    Returns (count, sum2, turn_steps): int64 [steps + tail, roots] each for the first two (tail = the drain steps the longest playout
+    needs), and the list of turn-steps EXECUTED per step (what the launches of a sliced run execute, drain steps included)."""
+    roots = root_b.shape[0]
+    n = roots * reps
+    lives = (max_steps + slice - 1) // slice if slice else 1
+    total_steps = steps + lives
+    count = np.zeros((total_steps, roots), dtype=np.int64)
+    sum2 = np.zeros((total_steps, roots), dtype=np.int64)
+    executed = np.zeros(total_steps, dtype=np.int64)
+    rid = np.repeat(np.arange(roots), reps)
+    for k in range(steps):
+        pp = np.zeros((n, 8), dtype=np.uint8)
+        for i in range(n):
+            hi = LIB.oracle_fast_prng_next32(ptr(lane_prng[i]))
+            lo = LIB.oracle_fast_prng_next32(ptr(lane_prng[i]))
+            if hi == 0 and lo == 0:
+                lo = 1
+            pp[i].view(np.uint32)[:] = (hi, lo)
+        b = np.ascontiguousarray(np.repeat(root_b, reps, axis=0))
+        d = np.ascontiguousarray(np.repeat(root_d, reps, axis=0))
+        r = np.ascontiguousarray(np.repeat(root_r, reps))
+        out, ln = rollout_batch(b, d, r, pp, max_steps=max_steps, prep=True, threads=threads)
+        t = out & 15
+        v2 = np.where(t == 1, 2, np.where(t == 2, 0, 1)).astype(np.int64)
+        ln = ln.astype(np.int64)
+        when = k + (np.where(ln > 0, (ln - 1) // slice, 0) if slice else 0)
+        np.add.at(count, (when, rid), 1)
+        np.add.at(sum2, (when, rid), v2)
+        if slice:
+            for j in range(lives):      # slice j of a playout executes min(len - j * slice, slice) turn-steps in launch k + j
+                executed[k + j] += int(np.clip(ln - j * slice, 0, slice).sum())
+        else:
+            executed[k] += int(ln.sum())
+    return count, sum2, executed

@@ -211,3 +211,62 @@ def test_config4_root_groups_exchange_reassembles_the_global_root_order():
         p.join(timeout=180)
         assert p.exitcode == 0
     assert got.shape == (n_roots,) and (got == _config4_means(n_roots, reps, 0, n_roots)).all()
+
+
+# ---- configs[3] in slices (oak_amd.dist.RootSteps' exchange): per-step credited aggregates, int64, one all-gather per step -----------
+def _credited(n_roots, reps, steps, slice_, lo, hi):
+    """The oracle's credited aggregates of roots [lo, hi) packed the way the kernel reports them (count | sum2 << 32): lane streams are
+    seeded by GLOBAL lane index, so a rank's roots give the same numbers wherever they run."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import ctypes as C
+    import oracle_lib as O
+    rb, rd, rp, rr = O.make_random_ou_batch(n_roots, seed0=4000)
+    lane = np.zeros(((hi - lo) * reps, 8), dtype=np.uint8)
+    for i in range((hi - lo) * reps):
+        O.LIB.oracle_fast_prng_seed(O.ptr(lane[i]), C.c_uint64(0xC40000000000 + lo * reps + i))
+    cnt, s2, _ = O.root_steps_reference(rb[lo:hi], rd[lo:hi], rr[lo:hi], lane, reps, steps, slice_, max_steps=200)
+    return (cnt | (s2 << 32)).astype(np.int64)          # [steps + tail, hi - lo]
+
+
+def _root_steps_worker(rank, world, port, n_roots, reps, steps, slice_, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oak_amd import dist as D
+    lo, hi = D.root_shard(n_roots, rank, world)
+    per = -(-n_roots // world)
+    mine = _credited(n_roots, reps, steps, slice_, lo, hi)
+    got = []
+    for k in range(mine.shape[0]):               # one collective per step, the same count on every rank (padded)
+        send = torch.zeros(per, dtype=torch.int64)
+        send[:hi - lo] = torch.from_numpy(mine[k])
+        recv = torch.empty(world * per, dtype=torch.int64)
+        dist.all_gather_into_tensor(recv, send)
+        got.append(D.assemble_rank_blocks(n_roots, world, per, recv.numpy()))
+    if rank == world - 1:
+        q.put(np.stack(got))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_config4_sliced_steps_gather_the_credited_aggregates_in_global_root_order():
+    """13 roots ragged over 2 ranks (7 + 6), 3 search steps in slices of 16 turn-steps: every step's gathered (count, 2 x value sum) per
+    root -- late credits and drain steps included -- equals the single-process oracle's, and every playout is credited exactly once."""
+    n_roots, reps, steps, slice_, world = 13, 6, 3, 16, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_root_steps_worker, args=(r, world, port, n_roots, reps, steps, slice_, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=180)
+    for p in procs:
+        p.join(timeout=180)
+        assert p.exitcode == 0
+    want = _credited(n_roots, reps, steps, slice_, 0, n_roots)
+    assert got.shape == want.shape and (got == want).all()
+    assert int((got & 0xFFFFFFFF).sum()) == n_roots * reps * steps
+    from oak_amd import dist as D
+    m = D.credited_means(got[0] & 0xFFFFFFFF, got[0] >> 32)
+    assert m.shape == (n_roots,) and ((m >= 0) & (m <= 1)).all()

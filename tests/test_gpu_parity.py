@@ -683,3 +683,131 @@ def test_frozen_standstill_skip_is_exact(gpu_ctx):
         assert (((oout & 15) == 3) | (osteps >= cap)).mean() > (0.3 if seed0 == 0xF0F0_0005 else 0.9), "the fixture no longer produces standstills"
         for key, exp in (("results", oout), ("steps", osteps), ("battles", ob), ("durations", od), ("prng", op)):
             assert (got[key] == exp).all(), (hex(seed0), cap, turn, key, int((got[key] != exp).sum()))
+
+
+# ---- BASELINE configs[3] in slices: oakgpu_root_steps (k_root_step) against the oracle that applies the same crediting rule ----------
+def _root_step_inputs(n_roots, seed0):
+    """Roots at different depths of their game: turn-1 positions, mid-game positions with live durations (so that root prep -- the
+    hidden-variable resampling of durations.h:25-97 -- matters), and one finished game (a playout of length 0)."""
+    b, d, p, r = O.make_random_ou_batch(n_roots, seed0=seed0)
+    for i in range(n_roots):
+        k = (0, 0, 7, 19, 33, 60)[i % 6]
+        if k:
+            out, _ = O.rollout_batch(b[i:i + 1], d[i:i + 1], r[i:i + 1], p[i:i + 1], max_steps=k)
+            r[i] = out[0]
+    out, _ = O.rollout_batch(b[-1:], d[-1:], r[-1:], p[-1:], max_steps=1000)     # the last root: a terminal position
+    r[-1] = out[0]
+    assert (r[-1] & 15) != 0
+    return b, d, r
+
+
+class _RootSteps:
+    """The C ABI of the sliced search steps driven with raw device buffers (no torch in this process: tests/hipmem.py)."""
+
+    def __init__(self, ctx, b, d, r, lane, reps, slice_, max_steps=1000):
+        from hipmem import Dev
+        from oak_amd import _lib
+        self.ctx, self.lib, self.n = ctx, ctx.lib, b.shape[0]
+        self.bufs = [Dev(np.ascontiguousarray(x)) for x in (b, d, r, lane)]
+        self.report = Dev(np.zeros(self.n + 2, dtype=np.uint64))
+        self.h = C.c_void_p()
+        _lib.check(self.lib.oakgpu_root_steps_create(ctx.handle, self.n, reps, slice_, max_steps, C.byref(self.h)))
+
+    def step(self, fresh=True):
+        from oak_amd import _lib
+        tb, td, tr, tp = self.bufs
+        _lib.check(self.lib.oakgpu_root_steps_launch_dev(self.h, tb.p, td.p, tr.p, tp.p, 1 if fresh else 0, self.report.p))
+        self.ctx.synchronize()
+        rep = self.report.host()
+        acc = rep[:self.n]
+        return {"count": (acc & np.uint64(0xFFFFFFFF)).astype(np.int64), "sum2": (acc >> np.uint64(32)).astype(np.int64),
+                "turn_steps": int(rep[self.n]), "carried": int(rep[self.n + 1] & np.uint64(0xFFFFFFFF)), "err": int(rep[self.n + 1] >> np.uint64(32))}
+
+    def lane_streams(self):
+        return self.bufs[3].host()
+
+    def close(self):
+        self.lib.oakgpu_root_steps_destroy(self.h)
+        for x in self.bufs + [self.report]:
+            x.free()
+
+
+@pytest.mark.parametrize("slice_,reps,steps", [(64, 96, 5), (16, 64, 4), (256, 64, 3), (0, 64, 2)])
+def test_root_steps_credit_each_playout_by_its_own_length(gpu_ctx, slice_, reps, steps):
+    """Every step's per-root aggregate (count, 2 x value sum) of the sliced search steps equals the oracle's, which plays every playout to
+    terminal at once and applies the documented rule (step k + (len - 1) // slice); so do the turn-steps each launch executes, the
+    drain steps' aggregates, the lane streams afterwards, and -- after the drain -- nothing is left in flight."""
+    n_roots = 13
+    b, d, r = _root_step_inputs(n_roots, 0xC0FFEE00 + slice_)
+    lane = _seed_prng(n_roots * reps, 0xC40000000000)
+    ref_lane = lane.copy()
+    cnt, s2, ex = O.root_steps_reference(b, d, r, ref_lane, reps, steps, slice_, threads=8)
+    rs = _RootSteps(gpu_ctx, b, d, r, lane, reps, slice_)
+    try:
+        k = 0
+        while True:
+            rec = rs.step(fresh=k < steps)
+            assert rec["err"] == 0
+            assert (rec["count"] == cnt[k]).all(), (k, rec["count"], cnt[k])
+            assert (rec["sum2"] == s2[k]).all(), k
+            assert rec["turn_steps"] == ex[k], (k, rec["turn_steps"], ex[k])
+            k += 1
+            if k >= steps and rec["carried"] == 0:
+                break
+            assert k < cnt.shape[0], "playouts still in flight after the longest possible life"
+        assert cnt[k:].sum() == 0 and cnt[:k].sum() == n_roots * reps * steps      # every playout credited exactly once
+        assert (rs.lane_streams() == ref_lane).all()                                 # one uniform_64 per lane and step
+        if slice_ == 0:
+            assert k == steps
+    finally:
+        rs.close()
+
+
+def test_root_steps_do_not_depend_on_the_partition_of_the_roots(gpu_ctx):
+    """Two objects over disjoint parts of the roots (what two ranks hold: lane streams seeded by GLOBAL lane index) credit exactly what
+    one object over all roots credits -- nothing depends on which launch, wave or rank runs a playout."""
+    from oak_amd.engine import Context
+    n_roots, reps, steps, slice_ = 12, 64, 4, 32
+    b, d, r = _root_step_inputs(n_roots, 0xD15C0)
+    lane = _seed_prng(n_roots * reps, 0xC40000000000)
+
+    def run(ctx, lo, hi):
+        rs = _RootSteps(ctx, b[lo:hi], d[lo:hi], r[lo:hi], lane[lo * reps:hi * reps], reps, slice_)
+        out = []
+        for k in range(steps + 1000 // slice_ + 1):
+            rec = rs.step(fresh=k < steps)
+            out.append(np.stack([rec["count"], rec["sum2"]]))
+        assert rec["carried"] == 0 and rec["err"] == 0
+        rs.close()
+        return np.stack(out)            # [step, 2, roots]
+    whole = run(gpu_ctx, 0, n_roots)
+    other = Context(0)
+    try:
+        parts = np.concatenate([run(gpu_ctx, 0, 5), run(other, 5, n_roots)], axis=2)
+    finally:
+        other.close()
+    assert (whole == parts).all()
+
+
+def test_root_steps_report_a_carry_list_overflow(gpu_ctx):
+    """slice = 2 keeps ~50 steps' worth of playouts in flight, far beyond the carry list's three steps' worth: the launch that overflows
+    says so (sticky error word), it never loses playouts silently."""
+    n_roots, reps = 4, 256
+    b, d, p, r = O.make_random_ou_batch(n_roots, seed0=0xBEEF)
+    rs = _RootSteps(gpu_ctx, b, d, r, _seed_prng(n_roots * reps, 77), reps, 2)
+    try:
+        errs = [rs.step()["err"] for _ in range(12)]
+        assert errs[0] == 0 and errs[-1] == 1 and errs == sorted(errs)      # sticky once set
+    finally:
+        rs.close()
+
+
+def test_root_steps_host_class_in_a_torch_process():
+    """oak_amd.dist.RootSteps (torch tensors, the exchange hook, pinned host record) through tests/root_steps_check.py in a child
+    process -- torch must initialise the GPU before the library does."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tests", "root_steps_check.py")], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "root steps ok" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
