@@ -849,19 +849,33 @@ __global__ __launch_bounds__(BLK, WPS) void k_rollout_queue(GroupArgs g_in, Roun
 struct RootStepArgs {
   const uint8_t *root_battles, *root_durations, *root_results; // n_roots x {384, 8, 1}
   uint8_t *lane_prng;              // n_fresh x 8
-  const uint8_t *cin_state;        // carried playouts: cap x 384-byte battle images ...
-  const uint32_t *cin_meta;        // ... and cap x 8 dwords {dur0, dur1, prng s0, prng s1, steps, root, result, 0}
-  const uint32_t *cin_count;
-  uint8_t *cout_state;
-  uint32_t *cout_meta;
+  const uint4 *cin_state;          // carried playouts: ROOT_SHARDS segments of `seg` records of CARRY_VEC uint4 (below)
+  const uint32_t *cin_count;       // ROOT_SHARDS counters, CTL_STRIDE words apart (one 256-byte line each)
+  uint4 *cout_state;
   uint32_t *cout_count;
   unsigned long long *acc;         // n_roots: finished playouts credited to this step, count | (2 x value) << 32
   unsigned long long *turn_steps;  // += the turn-steps this launch executed
-  uint32_t *queue;                 // queue head, zeroed before the launch
-  uint32_t *err;                   // sticky: bit 0 = the carry list overflowed (playouts lost)
-  uint32_t n_fresh, reps, cap, slice_mask, max_steps, pad;
+  uint32_t *queue;                 // ROOT_SHARDS queue heads (CTL_STRIDE words apart), zeroed before the launch
+  uint32_t *err;                   // sticky: bit 0 = a carry segment overflowed (playouts lost)
+  uint32_t n_fresh, reps, seg, slice_mask, max_steps, fper; // fper: fresh lanes per shard (the last shard takes what is left)
 };
-constexpr int ROOT_STEP_COLD_BYTES = (sizeof(RootStepArgs) + 15) & ~15;
+// The queue and the carry list are cut into 8 SHARDS, each with a head and a counter on a 256-byte line of its own: one device-scope
+// counter saturates at ~88 returning atomics per microsecond on this chip (MI355X_MICROARCH.md, "dequeue"), and a step in slices
+// of 64 turn-steps needs ~110 dequeues + ~60 carry tickets per microsecond -- with ONE head and ONE ticket counter the kernel ran at
+// exactly that rate whatever else it did (256 roots: 20 ms per step at slice 64, 30 ms at 32, against 11 ms of turn-steps).  Shard
+// s = {segment s of the carry list, fresh lanes [s * fper, (s + 1) * fper)}; a wave starts at shard blockIdx % 8 (the dispatcher
+// deals workgroups round-robin over the XCDs) and moves on to the next shard when its own is exhausted, so every playout is taken
+// whoever is left; it carries into its home shard's segment of the outgoing list.
+constexpr int ROOT_SHARDS = 8;
+constexpr int CTL_STRIDE = 64; // words between two counters
+// A carried playout travels as the engine's own MUTABLE state, raw: both sides' register sets (2 x 18 dwords, in whatever frame the
+// turn left them), the battle scalars, the 24 party dwords of its LDS column, its choice stream, step count, root and result --
+// 72 dwords = 18 uint4, stored and loaded as whole vectors with no load in the store path.  (First form: the 384-byte battle
+// image through store_battle_global / load_battle_global, whose stores each wait for a load of the immutable fields behind the
+// previous store -- stores count in vmcnt on gfx950 -- ~37 us of wave time per carried playout: 256 roots in slices of 64 ran at
+// 5.2 G turn-steps/s against 9.4 G without slices.)  The immutable party data is the ROOT's (`gin`), shared by the root's playouts.
+constexpr int CARRY_VEC = 18;
+constexpr int ROOT_STEP_COLD_BYTES = ((sizeof(RootStepArgs) + 15) & ~15) + ROOT_SHARDS * 4;
 constexpr int ROOT_STEP_LDS_BYTES = 24 * 64 * 4 + TABLE_LDS_PAD + ROOT_STEP_COLD_BYTES;
 template <int WPS>
 __global__ __launch_bounds__(64, WPS) void k_root_step(RootStepArgs a_in) {
@@ -876,15 +890,19 @@ __global__ __launch_bounds__(64, WPS) void k_root_step(RootStepArgs a_in) {
 #pragma unroll
     for (uint32_t i = 0; i < sizeof(RootStepArgs) / 4; ++i) cold[i] = src[i];
   }
+  lds_u32 *sh_carry = cold + ((sizeof(RootStepArgs) + 15) & ~15) / 4; // carried playouts per shard (clamped to the segment size)
+  if (threadIdx.x < ROOT_SHARDS) {
+    const uint32_t c = a_in.cin_count[threadIdx.x * CTL_STRIDE];
+    sh_carry[threadIdx.x] = c < a_in.seg ? c : a_in.seg; // (an overflowing launch lost the playouts beyond the segment and said so in *err)
+  }
   __syncthreads();
 #define RS_PTR(field, type) cold_ptr<type>(cold, offsetof(RootStepArgs, field))
 #define RS_U32(field) ((uint32_t)__builtin_amdgcn_readfirstlane((int)cold[offsetof(RootStepArgs, field) / 4]))
   const uint32_t wl = threadIdx.x;
   constexpr uint32_t NONE = 0xFFFFFFFFu, DONE = 0xFFFFFFFEu;
-  const uint32_t cap = RS_U32(cap), max_steps = RS_U32(max_steps), slice_mask = RS_U32(slice_mask);
-  uint32_t n_carry = (uint32_t)__builtin_amdgcn_readfirstlane((int)*RS_PTR(cin_count, const uint32_t *));
-  if (n_carry > cap) n_carry = cap; // (an overflowing launch lost the playouts beyond the cap and said so in *err)
-  const uint32_t total = n_carry + RS_U32(n_fresh);
+  const uint32_t seg = RS_U32(seg), max_steps = RS_U32(max_steps), slice_mask = RS_U32(slice_mask);
+  const uint32_t home = blockIdx.x & (ROOT_SHARDS - 1);
+  uint32_t shard = home, exhausted = 0;
   ER e;
   e.m = party + wl;
   e.T = T;
@@ -894,27 +912,53 @@ __global__ __launch_bounds__(64, WPS) void k_root_step(RootStepArgs a_in) {
   bool dry = false;
   for (;;) {
     bool load = false;
-    uint32_t my = 0;
+    uint32_t my = 0, my_carry = 0, my_shard = 0;
     const uint64_t mask = __ballot(root == NONE);
-    if (mask && !dry) { // wave-uniform: free lanes take the next playouts of the queue -- the carried ones first (they are the oldest)
-      uint32_t base = 0;
-      if (wl == 0) base = atomicAdd(RS_PTR(queue, uint32_t *), (uint32_t)__popcll(mask));
-      base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-      if (base + (uint32_t)__popcll(mask) >= total) dry = true;
-      if (root == NONE) {
-        my = base + (uint32_t)__popcll(mask & ((1ull << wl) - 1));
-        if (my < total) load = true; else root = DONE;
+    if (mask && !dry) { // wave-uniform: free lanes take the next playouts of the wave's current shard -- its carried ones first (the oldest)
+      uint64_t rem = mask;
+      while (rem) {
+        const uint32_t need = (uint32_t)__popcll(rem);
+        const uint32_t carry_s = (uint32_t)__builtin_amdgcn_readfirstlane((int)sh_carry[shard]);
+        const uint32_t n_fresh = RS_U32(n_fresh), fper = RS_U32(fper), flo = shard * fper;
+        const uint32_t fresh_s = flo < n_fresh ? (n_fresh - flo < fper ? n_fresh - flo : fper) : 0u;
+        const uint32_t tot = carry_s + fresh_s;
+        uint32_t base = 0;
+        if (wl == 0) base = atomicAdd(RS_PTR(queue, uint32_t *) + shard * CTL_STRIDE, need);
+        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+        const uint32_t avail = base < tot ? (tot - base < need ? tot - base : need) : 0u;
+        const uint32_t rank = (uint32_t)__popcll(rem & ((1ull << wl) - 1));
+        if (((rem >> wl) & 1) && rank < avail) { my = base + rank; my_carry = carry_s; my_shard = shard; load = true; }
+        if (avail == need) break;
+        rem = __ballot(root == NONE && !load);           // the shard is exhausted: the lanes it could not serve try the next one
+        shard = (shard + 1) & (ROOT_SHARDS - 1);
+        if (++exhausted >= (uint32_t)ROOT_SHARDS) { dry = true; break; }
       }
-    } else if (mask && root == NONE) root = DONE;
+    }
+    if (dry && root == NONE && !load) root = DONE;
     if (__ballot(load)) {
-      if (load && my < n_carry) { // resume a carried playout from its image
-        const uint4 *mt = (const uint4 *)(RS_PTR(cin_meta, const uint32_t *) + 8 * (size_t)my);
-        const uint4 m0 = mt[0], m1 = mt[1];
-        g.s0 = m0.z; g.s1 = m0.w;
-        steps = m1.x; root = m1.y; result = m1.z;
-        e.load_battle_global(RS_PTR(cin_state, const uint8_t *) + (size_t)my * 384, m0.x, m0.y);
+      if (load && my < my_carry) { // resume a carried playout from its record
+        const uint4 *rec = RS_PTR(cin_state, const uint4 *) + (size_t)CARRY_VEC * ((size_t)my_shard * seg + my);
+        uint4 v[CARRY_VEC];
+#pragma unroll
+        for (int q = 0; q < CARRY_VEC; ++q) v[q] = rec[q];
+        // (component i of the record by CONSTANT index: no pointer into the register array, which would put it in scratch)
+        auto w = [&](int i) -> uint32_t { const uint4 &q = v[i >> 2]; return (i & 3) == 0 ? q.x : (i & 3) == 1 ? q.y : (i & 3) == 2 ? q.z : q.w; };
+        int o = 0;
+#define X(f) e.S.f = w(o++);
+        OAK_FOR_SIDE_FIELDS(X)
+#undef X
+#define X(f) e.F.f = w(o++);
+        OAK_FOR_SIDE_FIELDS(X)
+#undef X
+        e.rng = (uint64_t)w(36) | ((uint64_t)w(37) << 32);
+        e.turn = w(38) & 0xFFFF; e.last_damage = w(38) >> 16; e.lm = w(39);
+#pragma unroll
+        for (int q = 0; q < 24; ++q) e.m[q * 64] = w(40 + q);
+        g.s0 = w(64); g.s1 = w(65); steps = w(66); root = w(67); result = w(68);
+        e.actS = e.actF = 0;
+        e.gin = (const uint32_t *)(RS_PTR(root_battles, const uint8_t *) + (size_t)root * 384);
       } else if (load) {          // a fresh playout of lane `ln` = (root, replica): mcts.h:250-263
-        const uint32_t ln = my - n_carry;
+        const uint32_t ln = my_shard * RS_U32(fper) + (my - my_carry);
         root = ln / RS_U32(reps);
         uint32_t *ps = (uint32_t *)RS_PTR(lane_prng, uint8_t *) + 2 * (size_t)ln;
         FastPrng lane;
@@ -947,7 +991,7 @@ __global__ __launch_bounds__(64, WPS) void k_root_step(RootStepArgs a_in) {
     if (cm) { // wave-uniform: one ticket range per wave for the playouts whose slice is over
       const uint32_t leader = (uint32_t)__ffsll((unsigned long long)cm) - 1;
       uint32_t base = 0;
-      if (wl == leader) base = atomicAdd(RS_PTR(cout_count, uint32_t *), (uint32_t)__popcll(cm));
+      if (wl == leader) base = atomicAdd(RS_PTR(cout_count, uint32_t *) + home * CTL_STRIDE, (uint32_t)__popcll(cm));
       slot = (uint32_t)__builtin_amdgcn_readlane((int)base, (int)leader) + (uint32_t)__popcll(cm & ((1ull << wl) - 1));
     }
     if (root < DONE && (!playing || sliced)) { // retire the lane: credit a finished playout to this step / carry an unfinished one
@@ -955,12 +999,22 @@ __global__ __launch_bounds__(64, WPS) void k_root_step(RootStepArgs a_in) {
         const uint32_t t = result & 15;
         const unsigned long long v2 = t == R_WIN ? 2ull : t == R_LOSE ? 0ull : 1ull; // 2 x {1, 0, 0.5}: mcts.h:481-495
         atomicAdd(RS_PTR(acc, unsigned long long *) + root, 1ull | (v2 << 32));
-      } else if (slot < cap) {
-        e.normalize();
-        uint4 *mt = (uint4 *)(RS_PTR(cout_meta, uint32_t *) + 8 * (size_t)slot);
-        mt[0] = make_uint4(e.S.dur, e.F.dur, g.s0, g.s1);
-        mt[1] = make_uint4(steps, root, result, 0u);
-        e.store_battle_global(RS_PTR(cout_state, uint8_t *) + (size_t)slot * 384);
+      } else if (slot < seg) {
+        uint32_t w[CARRY_VEC * 4];
+        int o = 0;
+#define X(f) w[o++] = e.S.f;
+        OAK_FOR_SIDE_FIELDS(X)
+#undef X
+#define X(f) w[o++] = e.F.f;
+        OAK_FOR_SIDE_FIELDS(X)
+#undef X
+        w[36] = (uint32_t)e.rng; w[37] = (uint32_t)(e.rng >> 32); w[38] = e.turn | (e.last_damage << 16); w[39] = e.lm;
+#pragma unroll
+        for (int q = 0; q < 24; ++q) w[40 + q] = e.m[q * 64];
+        w[64] = g.s0; w[65] = g.s1; w[66] = steps; w[67] = root; w[68] = result; w[69] = w[70] = w[71] = 0;
+        uint4 *rec = RS_PTR(cout_state, uint4 *) + (size_t)CARRY_VEC * ((size_t)home * seg + slot);
+#pragma unroll
+        for (int q = 0; q < CARRY_VEC; ++q) rec[q] = make_uint4(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
       } else atomicOr(RS_PTR(err, uint32_t *), 1u);
       root = NONE;
     }
@@ -968,6 +1022,14 @@ __global__ __launch_bounds__(64, WPS) void k_root_step(RootStepArgs a_in) {
   if (wl == 0 && executed) atomicAdd(RS_PTR(turn_steps, unsigned long long *), (unsigned long long)executed);
 #undef RS_PTR
 #undef RS_U32
+}
+// report[0] = playouts carried into the next step (sum over the shards, each clamped to its segment) | error word << 32
+__global__ __launch_bounds__(64) void k_root_step_report(const uint32_t *cout_count, const uint32_t *err, uint32_t seg, unsigned long long *report) {
+  uint32_t c = threadIdx.x < ROOT_SHARDS ? cout_count[threadIdx.x * CTL_STRIDE] : 0u;
+  if (c > seg) c = seg;
+#pragma unroll
+  for (int o = 4; o > 0; o >>= 1) c += __shfl_down(c, o);
+  if (threadIdx.x == 0) *report = (unsigned long long)c | ((unsigned long long)*err << 32);
 }
 
 // ---- K1 with per-turn ACTION-CLASS COMPACTION across the waves of a workgroup (north_star: "wavefront ballot / prefix-sum
@@ -2035,9 +2097,8 @@ int oakgpu_rollout_dev(oakgpu_ctx *c, const uint8_t *battles, const uint8_t *dur
 struct oakgpu_root_steps {
   oakgpu_ctx *ctx;
   uint32_t n_roots, reps, slice, max_steps, cap;
-  uint8_t *state[2];   // carry lists, ping-pong: cap x 384
-  uint32_t *meta[2];   // cap x 8 dwords
-  uint32_t *ctl;       // [0], [1]: the two lists' counts; [2]: queue head; [3]: sticky error word; [4..5]: turn-steps (u64)
+  uint4 *state[2];     // carry lists, ping-pong: cap records of oak::CARRY_VEC uint4
+  uint32_t *ctl;       // counters on 256-byte lines of their own: lines [0, 8) / [8, 16) the two lists' per-shard counts, [16, 24) the queue heads, 24 the sticky error word
   int cur;             // the list the NEXT launch reads
 };
 
@@ -2052,18 +2113,18 @@ int oakgpu_root_steps_create(oakgpu_ctx *c, uint32_t n_roots, uint32_t reps, uin
   // every playout in flight is in at most one list: a step adds n_roots * reps and a playout lives ceil(max_steps / slice) launches
   const uint64_t lives = slice ? (max_steps + slice - 1) / slice : 1;
   const uint64_t worst = (uint64_t)n_roots * reps * (lives > 1 ? lives - 1 : 0);
-  // ... but the length distribution decays fast (99.5 % of random OU playouts end before 250 turn-steps): three steps' worth is ~2x the
-  // steady state at slice 64; an overflow is reported (sticky error), never silent
-  const uint64_t want = (uint64_t)n_roots * reps * 3;
+  // ... but the length distribution decays fast (random OU playouts: mean ~100 turn-steps, 99.5 % end before 250): the steady population
+  // is ~(mean length / slice - 0.4) steps' worth (measured: 0.17 / 1.14 / 2.66 steps' worth at slice 128 / 64 / 32); 1 + 256 / slice steps'
+  // worth leaves 3-4x of that, shard imbalance included; an overflow is reported (sticky error), never silent
+  const uint64_t want = (uint64_t)n_roots * reps * (1 + (slice ? 256 / slice : 0));
   rs->cap = (uint32_t)(worst < want ? worst : want);
-  if (rs->cap == 0) rs->cap = 1;
+  rs->cap = (rs->cap + oak::ROOT_SHARDS - 1) / oak::ROOT_SHARDS * oak::ROOT_SHARDS; // (segments of cap / 8 records)
+  if (rs->cap == 0) rs->cap = oak::ROOT_SHARDS;
   hipError_t e = hipSuccess;
-  for (int k = 0; k < 2 && e == hipSuccess; ++k) {
-    e = hipMalloc((void **)&rs->state[k], (size_t)rs->cap * 384);
-    if (e == hipSuccess) e = hipMalloc((void **)&rs->meta[k], (size_t)rs->cap * 32);
-  }
-  if (e == hipSuccess) e = hipMalloc((void **)&rs->ctl, 64);
-  if (e == hipSuccess) e = hipMemsetAsync(rs->ctl, 0, 64, c->stream);
+  for (int k = 0; k < 2 && e == hipSuccess; ++k) e = hipMalloc((void **)&rs->state[k], (size_t)rs->cap * oak::CARRY_VEC * 16);
+  constexpr size_t CTL_BYTES = (size_t)25 * oak::CTL_STRIDE * 4;
+  if (e == hipSuccess) e = hipMalloc((void **)&rs->ctl, CTL_BYTES);
+  if (e == hipSuccess) e = hipMemsetAsync(rs->ctl, 0, CTL_BYTES, c->stream);
   if (e != hipSuccess) { oakgpu_root_steps_destroy(rs); return fail(e, "oakgpu_root_steps_create"); }
   *out = rs;
   return 0;
@@ -2073,7 +2134,7 @@ void oakgpu_root_steps_destroy(oakgpu_root_steps *rs) {
   if (!rs) return;
   (void)hipSetDevice(rs->ctx->device);
   (void)hipStreamSynchronize(rs->ctx->stream);
-  for (int k = 0; k < 2; ++k) { if (rs->state[k]) (void)hipFree(rs->state[k]); if (rs->meta[k]) (void)hipFree(rs->meta[k]); }
+  for (int k = 0; k < 2; ++k) if (rs->state[k]) (void)hipFree(rs->state[k]);
   if (rs->ctl) (void)hipFree(rs->ctl);
   delete rs;
 }
@@ -2086,14 +2147,17 @@ int oakgpu_root_steps_launch_dev(oakgpu_root_steps *rs, const uint8_t *root_batt
   HIPCHK(hipSetDevice(c->device));
   const int in = rs->cur, outl = in ^ 1;
   HIPCHK(hipMemsetAsync(report, 0, ((size_t)rs->n_roots + 2) * 8, c->stream));
-  HIPCHK(hipMemsetAsync(rs->ctl + outl, 0, 4, c->stream)); // the list this launch fills
-  HIPCHK(hipMemsetAsync(rs->ctl + 2, 0, 4, c->stream));    // queue head
+  constexpr size_t LINES8 = (size_t)oak::ROOT_SHARDS * oak::CTL_STRIDE; // words of eight counters
+  uint32_t *cnt_in = rs->ctl + in * LINES8, *cnt_out = rs->ctl + outl * LINES8, *heads = rs->ctl + 2 * LINES8, *errw = rs->ctl + 3 * LINES8;
+  HIPCHK(hipMemsetAsync(cnt_out, 0, LINES8 * 4, c->stream)); // the list this launch fills
+  HIPCHK(hipMemsetAsync(heads, 0, LINES8 * 4, c->stream));   // queue heads
   oak::RootStepArgs a{};
   a.root_battles = root_battles; a.root_durations = root_durations; a.root_results = root_results; a.lane_prng = lane_prng;
-  a.cin_state = rs->state[in]; a.cin_meta = rs->meta[in]; a.cin_count = rs->ctl + in;
-  a.cout_state = rs->state[outl]; a.cout_meta = rs->meta[outl]; a.cout_count = rs->ctl + outl;
-  a.acc = report; a.turn_steps = report + rs->n_roots; a.queue = rs->ctl + 2; a.err = rs->ctl + 3;
-  a.n_fresh = fresh ? rs->n_roots * rs->reps : 0u; a.reps = rs->reps; a.cap = rs->cap;
+  a.cin_state = rs->state[in]; a.cin_count = cnt_in;
+  a.cout_state = rs->state[outl]; a.cout_count = cnt_out;
+  a.acc = report; a.turn_steps = report + rs->n_roots; a.queue = heads; a.err = errw;
+  a.n_fresh = fresh ? rs->n_roots * rs->reps : 0u; a.reps = rs->reps; a.seg = rs->cap / oak::ROOT_SHARDS;
+  a.fper = (a.n_fresh + oak::ROOT_SHARDS - 1) / oak::ROOT_SHARDS;
   a.slice_mask = rs->slice ? rs->slice - 1 : 0xFFFFFFFFu; // (0xFFFFFFFF: steps & mask is never 0 after a step -- no slicing)
   a.max_steps = rs->max_steps;
   // a persistent grid of the resident waves: the number of carried playouts is only known on the device
@@ -2102,9 +2166,8 @@ int oakgpu_root_steps_launch_dev(oakgpu_root_steps *rs, const uint8_t *root_batt
   const uint32_t waves = (uint32_t)std::min<uint64_t>(resident, (upper + 63) / 64);
   hipLaunchKernelGGL(oak::k_root_step<4>, dim3(waves), dim3(64), oak::ROOT_STEP_LDS_BYTES, c->stream, a);
   HIPCHK(hipGetLastError());
-  // report[n_roots + 1] = playouts carried into the next step | error word << 32 (ctl[outl] and ctl[3] are not adjacent: two copies)
-  HIPCHK(hipMemcpyAsync((uint32_t *)(report + rs->n_roots + 1), rs->ctl + outl, 4, hipMemcpyDeviceToDevice, c->stream));
-  HIPCHK(hipMemcpyAsync((uint32_t *)(report + rs->n_roots + 1) + 1, rs->ctl + 3, 4, hipMemcpyDeviceToDevice, c->stream));
+  hipLaunchKernelGGL(oak::k_root_step_report, dim3(1), dim3(64), 0, c->stream, cnt_out, errw, a.seg, report + rs->n_roots + 1);
+  HIPCHK(hipGetLastError());
   rs->cur = outl;
   return 0;
 }

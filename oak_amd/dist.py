@@ -310,8 +310,12 @@ class RootSteps:
         if self.handle:
             self.lib.oakgpu_root_steps_destroy(self.handle)
             self.handle = None
-        self.report = self.send = self.recv = None
+        # the stream belongs to the context: torch must hold nothing that refers to it when the context is destroyed (the caching
+        # allocators -- device and pinned host -- keep blocks used on a stream tied to that stream)
+        self.report = self.send = self.recv = self.host = self.event = self.stream = None
         torch.cuda.empty_cache()
+        if hasattr(torch._C, "_host_emptyCache"):
+            torch._C._host_emptyCache()
 
 
 def assemble_rank_blocks(n_roots, world, per, flat):

@@ -790,13 +790,15 @@ def test_root_steps_do_not_depend_on_the_partition_of_the_roots(gpu_ctx):
 
 
 def test_root_steps_report_a_carry_list_overflow(gpu_ctx):
-    """slice = 2 keeps ~50 steps' worth of playouts in flight, far beyond the carry list's three steps' worth: the launch that overflows
+    """With slices of 256 turn-steps the carry list holds two steps' worth of playouts (1 + 256 / slice); standstills (a lone frozen
+    Pokemon on either side: every playout runs to the 1,000-turn tie, ~4 slices) pile up three steps' worth: the launch that overflows
     says so (sticky error word), it never loses playouts silently."""
+    b, d, p, r = _frozen_standstills(64, 0x5EED0)
     n_roots, reps = 4, 256
-    b, d, p, r = O.make_random_ou_batch(n_roots, seed0=0xBEEF)
-    rs = _RootSteps(gpu_ctx, b, d, r, _seed_prng(n_roots * reps, 77), reps, 2)
+    b, d, r = b[:n_roots], d[:n_roots], r[:n_roots]
+    rs = _RootSteps(gpu_ctx, b, d, r, _seed_prng(n_roots * reps, 77), reps, 256, max_steps=6000)
     try:
-        errs = [rs.step()["err"] for _ in range(12)]
+        errs = [rs.step()["err"] for _ in range(8)]
         assert errs[0] == 0 and errs[-1] == 1 and errs == sorted(errs)      # sticky once set
     finally:
         rs.close()
