@@ -445,7 +445,7 @@ struct RoundArgs {
   uint8_t *sd;              // scratch: total x 8 durations
   uint8_t *sres;            // scratch: total results
   uint32_t suspend_below;
-  uint32_t *queue;          // this round's queue head
+  uint32_t *queue;          // this round's queue heads: QUEUE_HEADS counters, QUEUE_HEAD_STRIDE words apart (k_rollout_bins: one head)
   uint32_t lanes;           // lanes of a wave that take playouts (0 / 64: all); a tail round runs a few playouts per wave
   const uint32_t *order;    // round 0, nullable: queue position -> playout (k_queue_order: the likely-long playouts first)
   // long-playout migration (below): control words {tail, head, bulk waves exited, error}, one list entry per donation
@@ -567,6 +567,14 @@ constexpr uint32_t LONG_STEPS = OAK_LONG_STEPS;
 #define OAK_PRIO_STILL 24
 #endif
 constexpr uint32_t PRIO_STILL = OAK_PRIO_STILL;
+#ifndef OAK_REFILL_EVERY
+#define OAK_REFILL_EVERY 8
+#endif
+#ifndef OAK_REFILL_LANES
+#define OAK_REFILL_LANES 16
+#endif
+constexpr uint32_t REFILL_EVERY = OAK_REFILL_EVERY, REFILL_LANES = OAK_REFILL_LANES; // free lanes refill every n-th iteration (a power of two), or at once when this many are free
+constexpr uint32_t QUEUE_HEADS = 8, QUEUE_HEAD_STRIDE = 64; // eight queue heads per round, 64 words (one 256-byte line) apart
 template <int BLK, int WPS>
 __global__ __launch_bounds__(BLK, WPS) void k_rollout_queue(GroupArgs g_in, RoundArgs q_in) {
   extern __shared__ __align__(16) uint8_t smem[];
@@ -600,6 +608,7 @@ __global__ __launch_bounds__(BLK, WPS) void k_rollout_queue(GroupArgs g_in, Roun
   const uint32_t total = IS_RESUME ? (uint32_t)__builtin_amdgcn_readfirstlane((int)*COLD_Q(n_in, const uint32_t *)) : COLD_GU(total);
   const uint32_t max_steps = COLD_GU(max_steps), suspend_below = COLD_QU(suspend_below);
   if (!IS_RESUME && COLD_GU(prep) != 0) ust |= U_PREP;
+  ust |= (blockIdx.x & 7u) << 8; // the queue head this wave starts at
   ER e;
   e.m = party + tid;
   e.T = T;
@@ -685,23 +694,50 @@ __global__ __launch_bounds__(BLK, WPS) void k_rollout_queue(GroupArgs g_in, Roun
     // (an adopter's free lanes stay NONE after the queue has run dry -- they wait for donations -- and must not keep asking the
     // dry queue: ~150 waves adding to one L2 word on every iteration, and in a long launch the 32-bit head could wrap and hand
     // playouts out twice; round-3 advice)
-    if (mask && !(IS_DRY && IS_ADOPTER)) { // wave-uniform
+    // (refills in batches, OAK_REFILL_EVERY > 1: a refill is a wave-wide stall -- a returning atomic, then the dependent loads of the
+    // queue order, the batch descriptor and the 384-byte battle -- for the sake of the one or two lanes that finished in this
+    // iteration; free lanes cost no issue slots, so they wait for company: every 8th iteration, or at once when 16 lanes are free.
+    // Measured, tools/refill_variants.sh: driver command 8.53-8.59 -> 8.91-8.96 G, 160 steps 9.24-9.30 -> 9.76-9.79 G; every 4th / 16th
+    // iteration and thresholds of 8 / 64 lanes are within 2 % of it)
+    ust = (ust & ~0xFF0000u) | ((ust + 0x10000u) & 0xFF0000u);
+    if (mask && !IS_DRY && (REFILL_EVERY <= 1 || ((ust >> 16) & (REFILL_EVERY - 1)) == 0 || (uint32_t)__popcll(mask) >= REFILL_LANES || !ANY_PLAYING)) { // wave-uniform
       OAK_SCOPE(PS_REFILL);
-      uint32_t base = 0;
-      if (wl == 0) base = atomicAdd(COLD_Q(queue, uint32_t *), (uint32_t)__popcll(mask));
-      base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base); // (lane 0 is active: whole waves run this loop)
-      if (base + (uint32_t)__popcll(mask) >= total) ust |= U_DRY; else ust &= ~U_DRY;
+      // The queue has EIGHT heads, each on a 256-byte line of its own (round 5): one device-scope counter saturates at ~88 returning
+      // atomics per microsecond on this chip (MI355X_MICROARCH.md, "dequeue"), and 4,096 waves refilling 0.5 times per ~28 us
+      // iteration ask for 70-90 -- the single head of rounds 1-4 ran at its limit.  Head s hands out the queue positions s, s + 8,
+      // s + 16, ... (so every head's sequence starts with the likely-long playouts of k_queue_order); a wave starts at head
+      // blockIdx % 8 (workgroups are dealt round-robin over the XCDs) and moves to the next head when its own is exhausted; the
+      // queue is dry for a wave when it has seen all eight exhausted.  `ust` bits 8-10: the current head, bits 12-15: heads seen dry.
+      uint64_t rem = mask;
+      bool got = false;
+      uint32_t my = 0;
+      for (;;) {
+        const uint32_t shard = (ust >> 8) & 7u, need_n = (uint32_t)__popcll(rem);
+        const uint32_t lim = total > shard ? (total - shard + 7u) >> 3 : 0u; // positions of this head
+        uint32_t base = 0;
+        if (wl == 0) base = atomicAdd(COLD_Q(queue, uint32_t *) + shard * QUEUE_HEAD_STRIDE, need_n);
+        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base); // (lane 0 is active: whole waves run this loop)
+        const uint32_t avail = base < lim ? (lim - base < need_n ? lim - base : need_n) : 0u;
+        const uint32_t rank = (uint32_t)__popcll(rem & ((1ull << wl) - 1));
+        if (((rem >> wl) & 1) && rank < avail) { my = shard + ((base + rank) << 3); got = true; }
+        if (avail == need_n) break;
+        rem = __ballot(need && !got);
+        ust = (ust & ~(7u << 8)) | (((shard + 1u) & 7u) << 8);
+        ust += 1u << 12;
+        if (((ust >> 12) & 15u) >= 8u) { ust |= U_DRY; break; }
+      }
 #ifdef OAKGPU_TIMELINE
       if (IS_DRY && !tl_dry) { tl_dry = true; OAK_TL(1, wall_clock64()); }
 #endif
       if (need) {
-        const uint32_t my = base + (uint32_t)__popcll(mask & ((1ull << wl) - 1));
-        if (my < total) {
+        if (got) {
           const uint32_t *order = COLD_Q(order, const uint32_t *);
           idx = IS_RESUME ? COLD_Q(list_in, const uint32_t *)[my] : order ? order[my] : my;
           load = true;
-        } else idx = IS_ADOPTER ? NONE : DONE; // (an adopter's free lanes wait for donations until adoption is over)
+        } else idx = IS_ADOPTER ? NONE : DONE; // (the queue is dry; an adopter's free lanes wait for donations until adoption is over)
       }
+    } else if (mask && IS_DRY && !IS_ADOPTER) { // the queue is dry: a bulk wave's free lanes are done (an adopter's wait for donations)
+      if (need) idx = DONE;
     }
     if (__ballot(load)) { // wave-uniform: (re)fill the lanes that got a playout -- from its batch, or from its parked image
       OAK_SCOPE(PS_REFILL);
@@ -866,6 +902,13 @@ struct RootStepArgs {
 // s = {segment s of the carry list, fresh lanes [s * fper, (s + 1) * fper)}; a wave starts at shard blockIdx % 8 (the dispatcher
 // deals workgroups round-robin over the XCDs) and moves on to the next shard when its own is exhausted, so every playout is taken
 // whoever is left; it carries into its home shard's segment of the outgoing list.
+#ifndef OAK_ROOT_REFILL_EVERY
+#define OAK_ROOT_REFILL_EVERY 8
+#endif
+#ifndef OAK_ROOT_REFILL_LANES
+#define OAK_ROOT_REFILL_LANES 16
+#endif
+constexpr uint32_t ROOT_REFILL_EVERY = OAK_ROOT_REFILL_EVERY, ROOT_REFILL_LANES = OAK_ROOT_REFILL_LANES;
 constexpr int ROOT_SHARDS = 8;
 constexpr int CTL_STRIDE = 64; // words between two counters
 // A carried playout travels as the engine's own MUTABLE state, raw: both sides' register sets (2 x 18 dwords, in whatever frame the
@@ -902,7 +945,8 @@ __global__ __launch_bounds__(64, WPS) void k_root_step(RootStepArgs a_in) {
   constexpr uint32_t NONE = 0xFFFFFFFFu, DONE = 0xFFFFFFFEu;
   const uint32_t seg = RS_U32(seg), max_steps = RS_U32(max_steps), slice_mask = RS_U32(slice_mask);
   const uint32_t home = blockIdx.x & (ROOT_SHARDS - 1);
-  uint32_t shard = home, exhausted = 0;
+  uint32_t shard = home, exhausted = 0, iter = 0xFFFFFFFFu;
+  bool any_playing = false;
   ER e;
   e.m = party + wl;
   e.T = T;
@@ -914,7 +958,8 @@ __global__ __launch_bounds__(64, WPS) void k_root_step(RootStepArgs a_in) {
     bool load = false;
     uint32_t my = 0, my_carry = 0, my_shard = 0;
     const uint64_t mask = __ballot(root == NONE);
-    if (mask && !dry) { // wave-uniform: free lanes take the next playouts of the wave's current shard -- its carried ones first (the oldest)
+    ++iter;
+    if (mask && !dry && (ROOT_REFILL_EVERY <= 1 || (iter & (ROOT_REFILL_EVERY - 1)) == 0 || (uint32_t)__popcll(mask) >= ROOT_REFILL_LANES || !any_playing)) { // wave-uniform: free lanes take the next playouts of the wave's current shard -- its carried ones first (the oldest)
       uint64_t rem = mask;
       while (rem) {
         const uint32_t need = (uint32_t)__popcll(rem);
@@ -984,8 +1029,11 @@ __global__ __launch_bounds__(64, WPS) void k_root_step(RootStepArgs a_in) {
       result = e.random_step(result, hi, lo);
       ++steps;
       playing = (result & 15) == 0 && steps < max_steps;
-      sliced = playing && (steps & slice_mask) == 0;
+      sliced = playing && (steps & slice_mask) == 0; // the slice is over: the playout is carried
     }
+    any_playing = __ballot(playing && !sliced) != 0;
+    // (retiring in batches as well -- finished and sliced lanes waiting for the iteration in front of a refill -- was measured and
+    // dropped: nothing at 256 roots, 1.53 -> 1.60 ms for a rank's 32 roots; same for the queue kernel's publishing)
     const uint64_t cm = __ballot(sliced);
     uint32_t slot = 0;
     if (cm) { // wave-uniform: one ticket range per wave for the playouts whose slice is over
@@ -1541,7 +1589,8 @@ struct oakgpu_ctx {
   int bins_wps;       // engine 3: workgroups per CU (= waves per SIMD)
   int playouts_per_lane; // > 1: persistent grid of n / this lanes with queue refill (k_rollout_queue)
   int waves_per_simd;    // register budget of the queue kernel: 2, 3 or 4 waves per SIMD
-  uint32_t *d_queue;      // 64 counters: queue heads and suspended-playout counts of the regrouping rounds
+  uint32_t *d_queue;      // 64 counters: suspended-playout counts of the regrouping rounds, queue-order counters, migration control block
+  uint32_t *d_heads;      // the queue kernel's heads: MAX_ROUNDS rounds x 8 heads, each on a 256-byte line of its own
   int rounds;             // regrouping rounds of the queue kernel (1 = none)
   int suspend_below;      // a dry wave with fewer live lanes than this hands them to the next round
   int round_shrink;       // each round launches 1/round_shrink of the previous round's waves
@@ -1704,6 +1753,7 @@ int oakgpu_create(oakgpu_ctx **out, int device) {
   c->playouts_per_lane = 2;
   if (const char *env = getenv("OAKGPU_PLAYOUTS_PER_LANE")) c->playouts_per_lane = atoi(env) > 0 ? atoi(env) : 1;
   c->d_queue = nullptr;
+  c->d_heads = nullptr;
   c->d_scratch = nullptr;
   c->scratch_n = 0;
   c->h_table = c->d_table = nullptr;
@@ -1770,6 +1820,7 @@ void oakgpu_destroy(oakgpu_ctx *c) {
   if (c->d_pools) (void)hipFree(c->d_pools);
   if (c->d_sizes) (void)hipFree(c->d_sizes);
   if (c->d_queue) (void)hipFree(c->d_queue);
+  if (c->d_heads) (void)hipFree(c->d_heads);
   if (c->d_scratch) (void)hipFree(c->d_scratch);
   if (c->d_order) (void)hipFree(c->d_order);
   for (auto &b : c->stage) if (b.p) (void)hipFree(b.p);
@@ -1919,6 +1970,9 @@ static int launch_group(oakgpu_ctx *c, const oak::BatchDesc *descs, uint32_t cou
   // (the first clearing covers the sticky word too, ON THE CONTEXT'S STREAM: a hipMemset on the NULL stream is not ordered with a
   // non-blocking stream and could land in the middle of the first launch -- queue heads zeroed under a running kernel)
   if (!c->d_queue) { HIPCHK(hipMalloc((void **)&c->d_queue, 256)); HIPCHK(hipMemsetAsync(c->d_queue, 0, 256, c->stream)); }
+  constexpr int MAX_ROUNDS = 16;
+  constexpr size_t HEADS_BYTES = (size_t)MAX_ROUNDS * oak::QUEUE_HEADS * oak::QUEUE_HEAD_STRIDE * 4;
+  if (!c->d_heads) HIPCHK(hipMalloc((void **)&c->d_heads, HEADS_BYTES));
   if (!c->h_table) {
     HIPCHK(hipHostMalloc((void **)&c->h_table, sizeof(oak::BatchDesc) * oak::MAX_GROUP * oakgpu_ctx::TABLE_SLOTS, hipHostMallocDefault));
     HIPCHK(hipMalloc((void **)&c->d_table, sizeof(oak::BatchDesc) * oak::MAX_GROUP * oakgpu_ctx::TABLE_SLOTS));
@@ -1931,6 +1985,7 @@ static int launch_group(oakgpu_ctx *c, const oak::BatchDesc *descs, uint32_t cou
   HIPCHK(hipMemcpyAsync(dt, ht, sizeof(oak::BatchDesc) * count, hipMemcpyHostToDevice, c->stream));
   HIPCHK(hipEventRecord(c->table_ev[slot], c->stream));
   HIPCHK(hipMemsetAsync(c->d_queue, 0, 252, c->stream)); // (word 63 is the sticky migration error word: never cleared here)
+  HIPCHK(hipMemsetAsync(c->d_heads, 0, HEADS_BYTES, c->stream));
   if (c->rollout_engine == 3 && max_steps < (1u << 24)) { // per-turn action-class compaction (k_rollout_bins): 256-lane workgroups
     const int wps = c->bins_wps;
     uint32_t blocks = ((total + oak::BINS_BLK - 1) / oak::BINS_BLK + c->playouts_per_lane - 1) / c->playouts_per_lane;
@@ -2021,7 +2076,7 @@ static int launch_group(oakgpu_ctx *c, const oak::BatchDesc *descs, uint32_t cou
     q.count_out = c->d_queue + 2 * r + 1;
     q.sb = sb; q.sd = sd; q.sres = sres;
     q.suspend_below = r + 1 < rounds ? (uint32_t)(tail_pack ? c->tail_below : c->suspend_below) : 0u;
-    q.queue = c->d_queue + 2 * r;
+    q.queue = c->d_heads + (size_t)r * oak::QUEUE_HEADS * oak::QUEUE_HEAD_STRIDE;
     q.lanes = (tail_pack && r > 0) ? (uint32_t)c->tail_lanes : (r == 0 ? spread : 0u);
 #define OAK_LAUNCH_Q(W) hipLaunchKernelGGL((oak::k_rollout_queue<64, W>), dim3(waves), dim3(64), lq, c->stream, g, q)
     if (c->waves_per_simd >= 4) OAK_LAUNCH_Q(4); else if (c->waves_per_simd == 3) OAK_LAUNCH_Q(3); else OAK_LAUNCH_Q(2);

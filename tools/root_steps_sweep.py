@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """configs[3] in slices: ms per search step and turn-steps/s of oakgpu_root_steps by roots in flight and slice length (raw C ABI,
-device buffers through tests/hipmem.py).  usage: tools/root_steps_sweep.py [roots,roots,...] [slice,slice,...] [steps]"""
+device buffers through tests/hipmem.py).  usage: tools/root_steps_sweep.py [roots,roots,...] [slice,slice,...] [steps] [replicas per root]
+(replicas = 1 with 2^20 roots: the headline's heterogeneous workload -- every playout another team pair -- through this kernel)"""
 import ctypes as C
 import json
 import os
@@ -19,7 +20,8 @@ from oak_amd.engine import Context  # noqa: E402
 roots_list = [int(x) for x in (sys.argv[1] if len(sys.argv) > 1 else "32,256").split(",")]
 slices = [int(x) for x in (sys.argv[2] if len(sys.argv) > 2 else "64,128").split(",")]
 K = int(sys.argv[3]) if len(sys.argv) > 3 else 10
-reps = 4096
+reps = int(sys.argv[4]) if len(sys.argv) > 4 else 4096
+MAX_STEPS = int(os.environ.get("SWEEP_MAX_STEPS", "1000"))       # (a cap of 250 leaves no tail: the steady rate of a launch without slices)
 ctx = Context(0)
 ctx.ensure_ou_pools()
 lib, h = ctx.lib, ctx.handle
@@ -35,7 +37,7 @@ for roots in roots_list:
         for x in (tb, tdur, tr):
             x.free()
         rs = C.c_void_p()
-        _lib.check(lib.oakgpu_root_steps_create(h, roots, reps, slice_, 1000, C.byref(rs)))
+        _lib.check(lib.oakgpu_root_steps_create(h, roots, reps, slice_, MAX_STEPS, C.byref(rs)))
         report = Dev(np.zeros(roots + 2, dtype=np.uint64))
         warm = 2 + (256 // slice_ if slice_ else 0)
         for _ in range(warm):
