@@ -331,6 +331,12 @@ def rollout_workload(args, torch, dev, rank, local_rank, world, dist, force_dist
     total_steps = sum(sl.total for sl in slots)
     my_steps = int(total_steps.item())
     kern_ms = [a.elapsed_time(b) for a, b in ev]
+    # the queue kernel's control words after the timed region (outside it: the call synchronises): [40] donations, [41] adoptions of the
+    # last launch of each context; [63] the STICKY error word of the in-launch migration (a bounded wait that ran out) -- must be 0
+    qc = [sl.ctx.queue_counters() for sl in slots]
+    queue_counters = {"error_word_63": [int(c[63]) for c in qc], "donations_last_launch": [int(c[40]) for c in qc],
+                      "adoptions_last_launch": [int(c[41]) for c in qc]}
+    assert not any(queue_counters["error_word_63"]), "k_rollout_queue: a bounded wait of the in-launch migration ran out"
     if exchange and world > 1:       # one-off check of the exchange: rank r's rows of the last full gather are rank r's values
         sl = slots[0]
         mine = sl.values.clone()
@@ -384,6 +390,10 @@ def rollout_workload(args, torch, dev, rank, local_rank, world, dist, force_dist
                            "steps submitted as %d group launch(es) of up to %d batches over %d HIP stream(s)" % (len(timed), G, S),
             "group": G, "groups": len(timed), "streams": S,
             "playouts_per_lane": args.playouts_per_lane,
+            "queue_counters": queue_counters,
+            "fast_forward": "a PROVEN frozen standstill (both actives frozen, nobody able to act) is taken to its last turn-step in one go and its "
+                            "skipped turn-steps are counted in `value` (exact: tests/test_gpu_parity.py::test_frozen_standstill_skip_is_exact; <= 0.004 % "
+                            "of the count)",
             "parity": "bit-exact vs this repo's CPU oracle (libpkmn parity unpinned, see DESIGN.md)",
         },
         "roofline": {

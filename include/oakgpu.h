@@ -75,14 +75,18 @@ int oakgpu_set_spread(oakgpu_ctx *ctx, int lanes);
  * tests): a wave hands a playout that is still running after `long_steps` turn-steps (default 300; 99.5% end before 250) to
  * `adopters` dedicated waves (0 = one per two compute units), which from the first donation on hold only such playouts -- a dozen
  * per wave at the top priority of their SIMD -- so the 1,000-step chains that end a launch advance at a sparse wave's pace
- * long before the device drains.  State travels as the regrouping rounds' bit-exact image; results never depend on it. */
+ * long before the device drains.  State travels as the regrouping rounds' bit-exact image; results never depend on it.
+ * Co-residency of the launch's waves is NOT required (other launches may share the device, e.g. a second context's group launch):
+ * a bulk wave never waits for anybody, so it always runs to its end and counts itself out; an adopter waits only for bulk waves
+ * (bounded: ~10 s of polls, then the sticky error word and a failed oakgpu_synchronize) and holds nothing a bulk wave needs --
+ * tests/test_gpu_parity.py::test_two_contexts_migrate_concurrently_on_one_device. */
 int oakgpu_set_migration(oakgpu_ctx *ctx, int mode, int long_steps, int adopters);
 /* ... and, earlier than that, a playout whose two active Pokemon have stood still -- same slots, same hp -- for `window`
  * consecutive turn-steps (default 48; 0 = off; at most 255): the playouts that run into the 1,000-step cap are stalemates whose
  * hp stop changing at a median of turn-step 85, so they leave their full wave at ~step 135 instead of 300.  A heuristic about
  * WHO finishes a playout only; results never depend on it. */
 int oakgpu_set_migration_window(oakgpu_ctx *ctx, int window);
-/* Diagnostic (synchronises the stream): the 64 control words of the last queue launch -- [0] playouts handed out, [32] / [33]
+/* Diagnostic (synchronises the stream): the 64 control words of the last queue launch -- [32] / [33]
  * the queue order's two counters, [40] donations, [41] adoptions, [42] bulk waves that left, [63] error bits (0 = none:
  * 1 a ticket never arrived, 2 an adopter gave up waiting) -- STICKY: no launch clears them; oakgpu_synchronize reports a
  * non-zero word as a failed call and clears it, so the error of any launch since the last synchronize is seen, not only the

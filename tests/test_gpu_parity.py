@@ -260,6 +260,60 @@ def test_long_playout_migration_does_not_change_results(gpu_ctx):
         gpu_ctx.set_migration_window(48)
 
 
+def test_two_contexts_migrate_concurrently_on_one_device(gpu_ctx):
+    """Co-residency is not a correctness requirement of k_rollout_queue's migration: a bulk wave never waits for anyone,
+    so it always finishes and counts itself out; adopters only ever wait for bulk waves (bounded) and hold nothing a bulk wave needs.
+    Two contexts launch saturating group launches AT THE SAME TIME on their own streams -- each grid alone would fill the device's wave
+    slots, so neither is fully resident while the other runs -- with migration forced on and thresholds that donate thousands of playouts:
+    every output byte of both launches equals the oracle's, donations == adoptions, and both sticky error words are 0."""
+    from hipmem import Dev
+    from oak_amd import _lib
+    from oak_amd.engine import Context
+    nb, n = 5, 65536                      # 5 batches x 65,536 playouts per context: 327,680 > the 262,144 resident lanes
+    other = Context(0)
+    ctxs = [gpu_ctx, other]
+    runs = []
+    try:
+        for k, ctx in enumerate(ctxs):
+            ctx.set_playouts_per_lane(2)
+            ctx.set_migration(2, 120, 0)          # forced on; donate everything still running after 120 turn-steps
+            ctx.set_migration_window(24)
+            b, d, p, r = O.make_random_ou_batch(nb * n, seed0=0xC0DE0000 + k * nb * n)
+            dev = {"b": Dev(b), "d": Dev(d), "p": Dev(p), "r": Dev(r), "ro": Dev(r, fill=0), "st": Dev(np.zeros(nb * n, dtype=np.uint32)),
+                   "va": Dev(np.zeros(nb * n, dtype=np.float32)), "bo": Dev(b, fill=0), "do": Dev(d, fill=0)}
+            batches = (_lib.RolloutBatch * nb)()
+            for j in range(nb):
+                o = j * n
+                at = lambda key, stride: C.c_void_p(dev[key].p.value + o * stride)
+                batches[j] = _lib.RolloutBatch(at("b", 384), at("d", 8), at("r", 1), at("p", 8), n, at("ro", 1), at("st", 4), at("va", 4), at("bo", 384), at("do", 8))
+            runs.append((ctx, dev, batches, (b, d, p, r)))
+        for rep in range(2):                       # both launches in flight together, twice
+            for ctx, dev, batches, _ in runs:
+                _lib.check(ctx.lib.oakgpu_rollout_group_dev(ctx.handle, batches, nb, 1000, 0))
+        for ctx, dev, batches, (b, d, p, r) in runs:
+            c = ctx.queue_counters()              # synchronises the context's stream
+            assert c[63] == 0, ("bounded wait ran out", int(c[63]))
+            assert c[40] == c[41] and c[40] > 1000, ("donations / adoptions", int(c[40]), int(c[41]))
+            # the second launch started from the first one's choice streams (prng advances in place): replay both on the oracle
+            ob, od, op = b.copy(), d.copy(), p.copy()
+            O.rollout_batch(ob, od, r, op, max_steps=1000, threads=16)
+            ob, od = b.copy(), d.copy()
+            oout, osteps = O.rollout_batch(ob, od, r, op, max_steps=1000, threads=16)
+            assert (dev["ro"].host() == oout).all() and (dev["st"].host() == osteps).all()
+            assert (dev["bo"].host() == ob).all() and (dev["do"].host() == od).all() and (dev["p"].host() == op).all()
+    finally:
+        for ctx, dev, _, _ in runs:
+            try:
+                ctx.synchronize()
+            except Exception:
+                pass
+            for x in dev.values():
+                x.free()
+        gpu_ctx.set_migration(1, 300, 0)
+        gpu_ctx.set_migration_window(48)
+        other.close()
+
+
 def test_rollout_in_place_on_device_buffers(gpu_ctx):
     """oakgpu_rollout_dev with battles_out == battles, durations_out == durations, results_out == results_in
     (how bench.py --workload config3 steps a resident batch one turn at a time): same bytes as out of place.
