@@ -889,11 +889,13 @@ struct RootStepArgs {
   const uint32_t *cin_count;       // ROOT_SHARDS counters, CTL_STRIDE words apart (one 256-byte line each)
   uint4 *cout_state;
   uint32_t *cout_count;
-  unsigned long long *acc;         // n_roots: finished playouts credited to this step, count | (2 x value) << 32
+  unsigned long long *acc;         // ROOT_SHARDS x acc_stride: finished playouts credited to this step per root, count | (2 x value) << 32, one copy per
+                                   // shard (a rank's 32 roots are ONE 256-byte line: 131,072 credits per 1.4 ms on it ran at the ~90 atomics/us a line takes)
   unsigned long long *turn_steps;  // += the turn-steps this launch executed
   uint32_t *queue;                 // ROOT_SHARDS queue heads (CTL_STRIDE words apart), zeroed before the launch
   uint32_t *err;                   // sticky: bit 0 = a carry segment overflowed (playouts lost)
   uint32_t n_fresh, reps, seg, slice_mask, max_steps, fper; // fper: fresh lanes per shard (the last shard takes what is left)
+  uint32_t acc_stride, pad;        // u64 entries between two shards' accumulators
 };
 // The queue and the carry list are cut into 8 SHARDS, each with a head and a counter on a 256-byte line of its own: one device-scope
 // counter saturates at ~88 returning atomics per microsecond on this chip (MI355X_MICROARCH.md, "dequeue"), and a step in slices
@@ -1046,7 +1048,7 @@ __global__ __launch_bounds__(64, WPS) void k_root_step(RootStepArgs a_in) {
       if (!sliced) {
         const uint32_t t = result & 15;
         const unsigned long long v2 = t == R_WIN ? 2ull : t == R_LOSE ? 0ull : 1ull; // 2 x {1, 0, 0.5}: mcts.h:481-495
-        atomicAdd(RS_PTR(acc, unsigned long long *) + root, 1ull | (v2 << 32));
+        atomicAdd(RS_PTR(acc, unsigned long long *) + (size_t)home * RS_U32(acc_stride) + root, 1ull | (v2 << 32));
       } else if (slot < seg) {
         uint32_t w[CARRY_VEC * 4];
         int o = 0;
@@ -1071,13 +1073,24 @@ __global__ __launch_bounds__(64, WPS) void k_root_step(RootStepArgs a_in) {
 #undef RS_PTR
 #undef RS_U32
 }
-// report[0] = playouts carried into the next step (sum over the shards, each clamped to its segment) | error word << 32
-__global__ __launch_bounds__(64) void k_root_step_report(const uint32_t *cout_count, const uint32_t *err, uint32_t seg, unsigned long long *report) {
-  uint32_t c = threadIdx.x < ROOT_SHARDS ? cout_count[threadIdx.x * CTL_STRIDE] : 0u;
-  if (c > seg) c = seg;
+// The launch's report: report[r] = the shards' accumulators of root r added up; report[n_roots + 1] = playouts carried into the next
+// step (sum over the shards, each clamped to its segment) | error word << 32.  (report[n_roots], the turn-steps, is written by the waves.)
+__global__ __launch_bounds__(256) void k_root_step_report(const unsigned long long *acc, uint32_t acc_stride, uint32_t n_roots, const uint32_t *cout_count,
+                                                          const uint32_t *err, uint32_t seg, unsigned long long *report) {
+  const uint32_t r = blockIdx.x * 256 + threadIdx.x;
+  if (r < n_roots) {
+    unsigned long long a = 0;
 #pragma unroll
-  for (int o = 4; o > 0; o >>= 1) c += __shfl_down(c, o);
-  if (threadIdx.x == 0) *report = (unsigned long long)c | ((unsigned long long)*err << 32);
+    for (int s = 0; s < ROOT_SHARDS; ++s) a += acc[(size_t)s * acc_stride + r];
+    report[r] = a;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < 64) {
+    uint32_t c = threadIdx.x < ROOT_SHARDS ? cout_count[threadIdx.x * CTL_STRIDE] : 0u;
+    if (c > seg) c = seg;
+#pragma unroll
+    for (int o = 4; o > 0; o >>= 1) c += __shfl_down(c, o);
+    if (threadIdx.x == 0) report[n_roots + 1] = (unsigned long long)c | ((unsigned long long)*err << 32);
+  }
 }
 
 // ---- K1 with per-turn ACTION-CLASS COMPACTION across the waves of a workgroup (north_star: "wavefront ballot / prefix-sum
@@ -2153,6 +2166,8 @@ struct oakgpu_root_steps {
   oakgpu_ctx *ctx;
   uint32_t n_roots, reps, slice, max_steps, cap;
   uint4 *state[2];     // carry lists, ping-pong: cap records of oak::CARRY_VEC uint4
+  unsigned long long *acc; // ROOT_SHARDS x acc_stride per-root accumulators of the launch in flight
+  uint32_t acc_stride;
   uint32_t *ctl;       // counters on 256-byte lines of their own: lines [0, 8) / [8, 16) the two lists' per-shard counts, [16, 24) the queue heads, 24 the sticky error word
   int cur;             // the list the NEXT launch reads
 };
@@ -2177,6 +2192,8 @@ int oakgpu_root_steps_create(oakgpu_ctx *c, uint32_t n_roots, uint32_t reps, uin
   if (rs->cap == 0) rs->cap = oak::ROOT_SHARDS;
   hipError_t e = hipSuccess;
   for (int k = 0; k < 2 && e == hipSuccess; ++k) e = hipMalloc((void **)&rs->state[k], (size_t)rs->cap * oak::CARRY_VEC * 16);
+  rs->acc_stride = (n_roots + 31u) & ~31u; // (whole 256-byte lines per shard)
+  if (e == hipSuccess) e = hipMalloc((void **)&rs->acc, (size_t)oak::ROOT_SHARDS * rs->acc_stride * 8);
   constexpr size_t CTL_BYTES = (size_t)25 * oak::CTL_STRIDE * 4;
   if (e == hipSuccess) e = hipMalloc((void **)&rs->ctl, CTL_BYTES);
   if (e == hipSuccess) e = hipMemsetAsync(rs->ctl, 0, CTL_BYTES, c->stream);
@@ -2191,6 +2208,7 @@ void oakgpu_root_steps_destroy(oakgpu_root_steps *rs) {
   (void)hipStreamSynchronize(rs->ctx->stream);
   for (int k = 0; k < 2; ++k) if (rs->state[k]) (void)hipFree(rs->state[k]);
   if (rs->ctl) (void)hipFree(rs->ctl);
+  if (rs->acc) (void)hipFree(rs->acc);
   delete rs;
 }
 
@@ -2202,6 +2220,7 @@ int oakgpu_root_steps_launch_dev(oakgpu_root_steps *rs, const uint8_t *root_batt
   HIPCHK(hipSetDevice(c->device));
   const int in = rs->cur, outl = in ^ 1;
   HIPCHK(hipMemsetAsync(report, 0, ((size_t)rs->n_roots + 2) * 8, c->stream));
+  HIPCHK(hipMemsetAsync(rs->acc, 0, (size_t)oak::ROOT_SHARDS * rs->acc_stride * 8, c->stream));
   constexpr size_t LINES8 = (size_t)oak::ROOT_SHARDS * oak::CTL_STRIDE; // words of eight counters
   uint32_t *cnt_in = rs->ctl + in * LINES8, *cnt_out = rs->ctl + outl * LINES8, *heads = rs->ctl + 2 * LINES8, *errw = rs->ctl + 3 * LINES8;
   HIPCHK(hipMemsetAsync(cnt_out, 0, LINES8 * 4, c->stream)); // the list this launch fills
@@ -2210,7 +2229,7 @@ int oakgpu_root_steps_launch_dev(oakgpu_root_steps *rs, const uint8_t *root_batt
   a.root_battles = root_battles; a.root_durations = root_durations; a.root_results = root_results; a.lane_prng = lane_prng;
   a.cin_state = rs->state[in]; a.cin_count = cnt_in;
   a.cout_state = rs->state[outl]; a.cout_count = cnt_out;
-  a.acc = report; a.turn_steps = report + rs->n_roots; a.queue = heads; a.err = errw;
+  a.acc = rs->acc; a.acc_stride = rs->acc_stride; a.turn_steps = report + rs->n_roots; a.queue = heads; a.err = errw;
   a.n_fresh = fresh ? rs->n_roots * rs->reps : 0u; a.reps = rs->reps; a.seg = rs->cap / oak::ROOT_SHARDS;
   a.fper = (a.n_fresh + oak::ROOT_SHARDS - 1) / oak::ROOT_SHARDS;
   a.slice_mask = rs->slice ? rs->slice - 1 : 0xFFFFFFFFu; // (0xFFFFFFFF: steps & mask is never 0 after a step -- no slicing)
@@ -2221,7 +2240,8 @@ int oakgpu_root_steps_launch_dev(oakgpu_root_steps *rs, const uint8_t *root_batt
   const uint32_t waves = (uint32_t)std::min<uint64_t>(resident, (upper + 63) / 64);
   hipLaunchKernelGGL(oak::k_root_step<4>, dim3(waves), dim3(64), oak::ROOT_STEP_LDS_BYTES, c->stream, a);
   HIPCHK(hipGetLastError());
-  hipLaunchKernelGGL(oak::k_root_step_report, dim3(1), dim3(64), 0, c->stream, cnt_out, errw, a.seg, report + rs->n_roots + 1);
+  hipLaunchKernelGGL(oak::k_root_step_report, dim3((rs->n_roots + 255) / 256), dim3(256), 0, c->stream, rs->acc, rs->acc_stride, rs->n_roots, cnt_out, errw,
+                     a.seg, report);
   HIPCHK(hipGetLastError());
   rs->cur = outl;
   return 0;
