@@ -419,6 +419,10 @@ typedef struct {
                                 * indices and the observation after every turn (the subtree is searched on); 0 = a fresh heap per turn */
   uint32_t nodes_kept;         /* out: how many of the game's updates found their child (RuntimeData::update_with_node_counter) */
 } oakgpu_selfplay_params;
+/* endless_battle_check (cpp/src/generate.cc:127-152): 1 when every pairing of the two teams (2 x 6 x {species, 4 moves}) is a Ghost against a
+ * Ghost with no move on either side that can hit a Ghost (type Normal / Fighting or base power 0) -- with ebc=false such a game runs to turn
+ * 1,000; the generator draws other teams, and oakgpu_selfplay_game(s) refuse the pair with "EBC check failed". */
+int oakgpu_endless_battle_check(const uint8_t *teams);
 int oakgpu_selfplay_game(oakgpu_ctx *ctx, oakgpu_net *net /* nullable for eval != 1 */, const uint8_t *teams /* 60 */,
                          uint64_t battle_seed, oakgpu_selfplay_params *params, uint8_t *buffer, size_t capacity,
                          size_t *written, uint32_t *n_frames, uint8_t *result);

@@ -20,7 +20,7 @@ SYMBOLS = [
     "oakgpu_tree_step_dev", "oakgpu_search", "oakgpu_search_many", "oakgpu_search_agent", "oakgpu_agent_networks_clear", "oakgpu_bandit_replay", "oakgpu_bandit_select_run", "oakgpu_solve_matrix",
     "oakgpu_segment_mean_dev", "oakgpu_comm_unique_id", "oakgpu_comm_create", "oakgpu_comm_destroy", "oakgpu_all_gather_dev",
     "oakgpu_root_steps_create", "oakgpu_root_steps_destroy", "oakgpu_root_steps_launch_dev",
-    "oakgpu_frames_size", "oakgpu_frames_write", "oakgpu_frames_read", "oakgpu_selfplay_game", "oakgpu_selfplay_games", "oakgpu_poke_engine_eval_dev", "oakgpu_poke_engine_eval",
+    "oakgpu_endless_battle_check", "oakgpu_frames_size", "oakgpu_frames_write", "oakgpu_frames_read", "oakgpu_selfplay_game", "oakgpu_selfplay_games", "oakgpu_poke_engine_eval_dev", "oakgpu_poke_engine_eval",
 ]
 
 
@@ -142,6 +142,7 @@ def load():
     lib.oakgpu_comm_destroy.argtypes = [vp]
     lib.oakgpu_comm_destroy.restype = None
     lib.oakgpu_all_gather_dev.argtypes = [vp, vp, vp, vp, C.c_size_t]
+    lib.oakgpu_endless_battle_check.argtypes = [vp]
     lib.oakgpu_frames_size.restype = C.c_size_t
     lib.oakgpu_frames_size.argtypes = [C.POINTER(FrameUpdate), u32]
     lib.oakgpu_frames_write.argtypes = [vp, C.c_uint8, C.POINTER(FrameUpdate), u32, vp, C.c_size_t, C.POINTER(C.c_size_t)]

@@ -32,6 +32,19 @@ namespace oak {
 #ifndef OAK_PSYWAVE_SHOWDOWN
 #define OAK_PSYWAVE_SHOWDOWN 1
 #endif
+//   OAK_COUNTER_SHOWDOWN     (round 5, default 0) Counter hits iff the target side's last USED and last SELECTED move are both counterable
+//                            (bp > 0, Normal / Fighting, not Counter) and last_damage > 0 -- Showdown's gen-1 damageCallback; 0: the
+//                            `counterable` byte of last_moves[]
+//   OAK_ACCURACY_LAST        (round 5, default 0) cartridge roll order of ordinary damaging moves: crit, damage roll, THEN accuracy
+#ifndef OAK_COUNTER_SHOWDOWN
+#define OAK_COUNTER_SHOWDOWN 0
+#endif
+#ifndef OAK_ACCURACY_LAST
+#define OAK_ACCURACY_LAST 0
+#endif
+#if OAK_ACCURACY_LAST && OAK_MULTIHIT_ROLL_FIRST
+#error "OAK_ACCURACY_LAST needs -DOAK_MULTIHIT_ROLL_FIRST=0 (the count is rolled behind the accuracy check)"
+#endif
 
 // ---- result / choice encodings (cpp/include/libpkmn/pkmn.h:108-133,214-233) ------------
 enum : uint32_t { R_NONE = 0, R_WIN = 1, R_LOSE = 2, R_TIE = 3, R_ERROR = 4 };
@@ -890,9 +903,20 @@ struct Engine {
     if (!fixed) immune = chart(mv.type(), ft & 15) == 0 || chart(mv.type(), ft >> 4) == 0;
     if (eff == E_DreamEater && !(r8(fp + P_STATUS) & ST_SLP)) immune = true;
     if (ohko && r16(so + O_ACTIVE + P_SPE) < r16(fo + O_ACTIVE + P_SPE)) immune = true;
+#if OAK_COUNTER_SHOWDOWN
+    if (move_id == M_Counter) {
+      const uint32_t lu = r8(fo + O_LAST_USED), ls = r8(fo + O_LAST_SEL);
+      const Move mu = move_data(lu), ms = move_data(ls);
+      const bool cu = lu != 0 && lu != M_Counter && mu.bp() > 0 && (mu.type() == T_Normal || mu.type() == T_Fighting);
+      const bool cs = ls != 0 && ls != M_Counter && ms.bp() > 0 && (ms.type() == T_Normal || ms.type() == T_Fighting);
+      if (!(cu && cs) || r16(B_LAST_DAMAGE) == 0) immune = true;
+    }
+#else
     if (move_id == M_Counter && (!r8(B_LAST_MOVES + 2 * (p ^ 1) + 1) || r16(B_LAST_DAMAGE) == 0)) immune = true;
+#endif
     bool hit = false;
-    if (!immune) hit = move_hit(p, mv);
+    const bool late_hit = OAK_ACCURACY_LAST && !fixed && !ohko; // cartridge order: crit and damage roll in front of the accuracy roll
+    if (!immune) hit = late_hit ? true : move_hit(p, mv);
     if (immune || !hit) {
       w16(B_LAST_DAMAGE, 0);
       clear_binding(p);
@@ -934,6 +958,15 @@ struct Engine {
       adjust_damage(p, mv);
       randomize_damage(p);
       if (r16(B_LAST_DAMAGE) == 0) { clear_binding(p); return; }
+#if OAK_ACCURACY_LAST
+      if (!move_hit(p, mv)) {
+        w16(B_LAST_DAMAGE, 0);
+        clear_binding(p);
+        if (eff == E_Explode) { w16(sp + P_HP, 0); w8(sp + P_STATUS, 0); }
+        if (eff == E_JumpKick) { uint32_t hp = r16(sp + P_HP); if (hp > 0) w16(sp + P_HP, hp - 1); }
+        return;
+      }
+#endif
     }
 
     if (eff == E_DoubleHit || eff == E_Twineedle) hits = 2;

@@ -753,9 +753,19 @@ struct EngineR {
       bool immune = !fixed && type_immune;
       if (eff == E_DreamEater && !(fs & ST_SLP)) immune = true;
       if (ohko && spe(S) < spe(F)) immune = true;
+#if OAK_COUNTER_SHOWDOWN
+      if (move_id == M_Counter) {
+        const uint32_t lu = last_used(F), ls = last_sel(F);
+        const Move mu = move_data(lu), ms = move_data(ls);
+        const bool cu = lu != 0 && lu != M_Counter && mu.bp() > 0 && (mu.type() == T_Normal || mu.type() == T_Fighting);
+        const bool cs = ls != 0 && ls != M_Counter && ms.bp() > 0 && (ms.type() == T_Normal || ms.type() == T_Fighting);
+        if (!(cu && cs) || last_damage == 0) immune = true;
+      }
+#else
       if (move_id == M_Counter && (!lm_counterable(fap) || last_damage == 0)) immune = true;
+#endif
       go = !immune;
-      need_hit = true;
+      need_hit = !(OAK_ACCURACY_LAST && !fixed && !ohko); // (cartridge order: the accuracy roll behind crit and damage roll, stage 4)
     }
     // -- stage 2: THE accuracy check ------------------------------------------------------------------
     bool hit = true;
@@ -929,6 +939,15 @@ struct EngineR {
         adjust_damage(mv);
         randomize_damage();
         if (last_damage == 0) { clear_binding(S); return; } // rounded down to nothing
+#if OAK_ACCURACY_LAST
+        if (!move_hit(mv)) {
+          last_damage = 0;
+          clear_binding(S);
+          if (eff == E_Explode) { set_hp(S, 0); set_status(S, 0); }
+          if (eff == E_JumpKick) { const uint32_t h = hp(S); if (h > 0) set_hp(S, h - 1); }
+          return;
+        }
+#endif
       }
       uint32_t hits = 1;
       if (eff == E_DoubleHit || eff == E_Twineedle) hits = 2;

@@ -85,9 +85,31 @@ int sample_pdf(const double *p, int k, uint64_t &rng) { // device.sample_pdf (ut
   return 0;
 }
 
+// endless_battle_check (generate.cc:127-152): with ebc=false a battle of Ghosts that cannot hurt each other never ends before turn 1,000.
+// Moves that cannot hit a Ghost: type Normal or Fighting, or base power 0 (the reference's own test) -- one bit per move id, from
+// oak_amd/data/gen1_data.json (tests/test_frames.py recomputes the mask from that file).
+const uint64_t CANT_HIT_GHOST[3] = {0x8047f8ffffb5fc7full, 0x03ffffdf9442e67cull, 0x0000003fd6dd5bfeull};
+bool set_is_ghost(const uint8_t *set) { return set[0] == 92 || set[0] == 93 || set[0] == 94; } // Gastly, Haunter, Gengar
+bool set_cant_hit_ghosts(const uint8_t *set) {
+  for (int k = 1; k <= 4; ++k) { const uint32_t m = set[k]; if (m > 165 || !((CANT_HIT_GHOST[m >> 6] >> (m & 63)) & 1)) return false; }
+  return true;
+}
+
 } // namespace
 
 extern "C" {
+
+// 1 when EVERY pairing of the two teams is Ghost against Ghost with no move on either side that can hit a Ghost -- the match-ups the
+// reference's generator rejects up front (generate.cc:127-152, 222-225): teams = 2 x 6 x {species, 4 moves}.
+int oakgpu_endless_battle_check(const uint8_t *teams) {
+  if (!teams) return 0;
+  for (int i = 0; i < 6; ++i)
+    for (int j = 0; j < 6; ++j) {
+      const uint8_t *a = teams + 5 * i, *b = teams + 30 + 5 * j;
+      if (!(set_is_ghost(a) && set_cant_hit_ghosts(b) && set_is_ghost(b) && set_cant_hit_ghosts(a))) return 0;
+    }
+  return 1;
+}
 
 size_t oakgpu_frames_size(const oakgpu_frame_update *updates, uint32_t count) { // CompressedFrames::n_bytes (:180-187)
   size_t n = 4 + 2 + 384 + 1;
@@ -167,6 +189,9 @@ int oakgpu_frames_read(const uint8_t *buffer, size_t size, uint8_t *battle, uint
 int oakgpu_selfplay_game(oakgpu_ctx *ctx, oakgpu_net *net, const uint8_t *teams, uint64_t battle_seed, oakgpu_selfplay_params *prm,
                          uint8_t *buffer, size_t capacity, size_t *written, uint32_t *n_frames, uint8_t *result_out) {
   if (!ctx || !teams || !prm || !buffer) return oakgpu_fail_msg("oakgpu_selfplay_game: null argument");
+  // generate.cc:222-225: such a pair is not played (the reference prints "EBC check failed. Continuing." and draws other teams; the teams
+  // are the caller's here, so the caller is told)
+  if (oakgpu_endless_battle_check(teams)) return oakgpu_fail_msg("oakgpu_selfplay_game: EBC check failed (every match-up is Ghost against Ghost with no move that can hit a Ghost, generate.cc:127-152)");
   // PKMN::battle(p1, p2, seed) + the opening update(0, 0) (generate.cc:238-240), on the device
   uint8_t battle[384], durations[8] = {}, result = 0;
   if (int rc = oakgpu_init_battles(ctx, teams, &battle_seed, 1, 1, battle, durations, &result)) return rc;

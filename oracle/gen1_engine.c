@@ -62,6 +62,23 @@
 #ifndef OAK_PSYWAVE_SHOWDOWN
 #define OAK_PSYWAVE_SHOWDOWN 1
 #endif
+/* ... and the other two (round 5), default = what rounds 1-4 did, alternatives for a future libpkmn fixture to select:
+ *   OAK_COUNTER_SHOWDOWN     Counter gated like Pokemon Showdown's gen-1 Counter (data/mods/gen1/moves.ts counter.damageCallback): it
+ *                            hits iff the target side's last USED move and its last SELECTED move are both counterable -- base power
+ *                            > 0, Normal or Fighting, not Counter -- and last_damage > 0 ("Desync Clause Mod" fails the mixed case);
+ *                            0: gated by the `counterable` byte the target's last damaging HIT left in last_moves[];
+ *   OAK_ACCURACY_LAST        the cartridge's roll order for ordinary damaging moves: critical hit, damage roll, THEN accuracy (a miss
+ *                            has consumed two more draws), multi-hit count behind it; 0: accuracy first (Showdown's order).  Needs
+ *                            OAK_MULTIHIT_ROLL_FIRST = 0. */
+#ifndef OAK_COUNTER_SHOWDOWN
+#define OAK_COUNTER_SHOWDOWN 0
+#endif
+#ifndef OAK_ACCURACY_LAST
+#define OAK_ACCURACY_LAST 0
+#endif
+#if OAK_ACCURACY_LAST && OAK_MULTIHIT_ROLL_FIRST
+#error "OAK_ACCURACY_LAST rolls the multi-hit count behind the accuracy check, i.e. behind crit / damage: build with -DOAK_MULTIHIT_ROLL_FIRST=0"
+#endif
 
 #pragma pack(push, 1)
 typedef struct { uint16_t hp, atk, def, spe, spc; } Stats;
@@ -804,10 +821,19 @@ static void do_move(Ctx *c, int player, uint8_t mslot) {
   if (mv->effect == EFF_DreamEater && !(fp->status & ST_SLP_MASK)) immune = 1;
   if (ohko && s->active.stats.spe < f->active.stats.spe) immune = 1;
   if (move_id == MV_Counter) {
+#if OAK_COUNTER_SHOWDOWN
+    const uint8_t lu = f->last_used_move, ls = f->last_selected_move;
+    const oracle_move_t *mu = &ORACLE_MOVES[lu], *ms = &ORACLE_MOVES[ls];
+    int cu = lu != 0 && lu != MV_Counter && mu->bp > 0 && (mu->type == TY_Normal || mu->type == TY_Fighting);
+    int cs = ls != 0 && ls != MV_Counter && ms->bp > 0 && (ms->type == TY_Normal || ms->type == TY_Fighting);
+    if (!(cu && cs) || b->last_damage == 0) immune = 1;
+#else
     if (!b->last_moves[player ^ 1].counterable || b->last_damage == 0) immune = 1;
+#endif
   }
   int hit = 0;
-  if (!immune) hit = move_hit(c, player, mv, move_id);
+  const int late_hit = OAK_ACCURACY_LAST && !fixed && !ohko; /* cartridge order: crit and damage roll in front of the accuracy roll */
+  if (!immune) hit = late_hit ? 1 : move_hit(c, player, mv, move_id);
   if (immune || !hit) {
     b->last_damage = 0;
     clear_binding(c, player);
@@ -851,6 +877,13 @@ static void do_move(Ctx *c, int player, uint8_t mslot) {
     (void)adjust_damage(b, player, mv);
     randomize_damage(c, player);
     if (b->last_damage == 0) { clear_binding(c, player); return; } /* rounded down to nothing */
+#if OAK_ACCURACY_LAST
+    if (!move_hit(c, player, mv, move_id)) { /* (move_hit zeroes last_damage and clears the binding on a miss) */
+      if (mv->effect == EFF_Explode) { sp->hp = 0; sp->status = 0; }
+      if (mv->effect == EFF_JumpKick && sp->hp > 0) sp->hp -= 1;
+      return;
+    }
+#endif
   }
 
   if (mv->effect == EFF_DoubleHit || mv->effect == EFF_Twineedle) hits = 2;

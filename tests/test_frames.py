@@ -67,3 +67,43 @@ def test_malformed_records_are_refused():
     with pytest.raises(RuntimeError):
         write_frames(np.zeros(384, np.uint8), 1, [{"m": 10, "n": 1, "c1": 0, "c2": 0, "iterations": 1, "empirical_value": 0.5, "nash_value": 0.5,
                                                      "p1_empirical": [0.1] * 9, "p1_nash": [0.1] * 9, "p2_empirical": [1.0], "p2_nash": [1.0]}])
+
+
+def test_endless_battle_check_follows_the_generators_rule():
+    """oakgpu_endless_battle_check = generate.cc:127-152: every pairing Ghost against Ghost, neither with a move that can hit a Ghost
+    (type Normal / Fighting or base power 0).  The library's move mask is recomputed here from the data file; the 16 sample teams never
+    trigger it (which is why the TUTORIAL's frames-per-game statistic cannot depend on it)."""
+    import ctypes as C
+    import json
+    import os
+    from oak_amd import _lib, gamedata as G
+    lib = _lib.load()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    data = json.load(open(os.path.join(root, "oak_amd", "data", "gen1_data.json")))
+    cant = {0} | {i + 1 for i, m in enumerate(data["moves"]) if m[2] in (0, 1) or m[1] == 0}
+
+    def check(teams):
+        t = np.ascontiguousarray(np.array(teams, dtype=np.uint8).reshape(60))
+        return lib.oakgpu_endless_battle_check(t.ctypes.data_as(C.c_void_p))
+
+    def rule(teams):
+        t = np.array(teams).reshape(2, 6, 5)
+        ghost = lambda s: s[0] in (92, 93, 94)
+        blunt = lambda s: all(int(m) in cant for m in s[1:])
+        return int(all(ghost(a) and blunt(b) and ghost(b) and blunt(a) for a in t[0] for b in t[1]))
+    rng = np.random.default_rng(7)
+    gengar_blunt = [94, G.match_move("hypnosis"), G.match_move("bodyslam"), G.match_move("confuseray"), G.match_move("explosion")]
+    gengar_sharp = [94, G.match_move("hypnosis"), G.match_move("nightshade"), G.match_move("thunderbolt"), G.match_move("explosion")]
+    assert check([[gengar_blunt] * 6, [gengar_blunt] * 6]) == 1
+    assert check([[gengar_blunt] * 6, [gengar_blunt] * 5 + [gengar_sharp]]) == 0
+    assert check([[gengar_blunt] * 5 + [[0, 0, 0, 0, 0]], [gengar_blunt] * 6]) == 0        # an empty slot is not a Ghost
+    for _ in range(300):                                                                    # every move id against the mask
+        teams = [[[int(rng.choice([92, 93, 94, 113])), *[int(x) for x in rng.integers(0, 166, 4)]] for _ in range(6)] for _ in range(2)]
+        if rng.random() < 0.7:
+            teams = [[[94, *[int(rng.choice(sorted(cant))) for _ in range(4)]] for _ in range(6)] for _ in range(2)]
+            if rng.random() < 0.5:
+                teams[int(rng.integers(0, 2))][int(rng.integers(0, 6))][int(rng.integers(1, 5))] = int(rng.integers(0, 166))
+        assert check(teams) == rule(teams)
+    sample = json.load(open(os.path.join(root, "tests", "golden", "ou_sample_teams.json")))["teams"]
+    tb = [[[G.match_species(s[0])] + [G.match_move(m) for m in s[1:]] for s in t] for t in sample]
+    assert not any(check([a, b]) for a in tb for b in tb)

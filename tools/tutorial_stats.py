@@ -66,7 +66,9 @@ if mode == "length":
            "percentiles_50_75_90_95_99": [float(x) for x in np.percentile(L, [50, 75, 90, 95, 99])],
            "games_of_300_frames_or_more": int((L >= 300).sum()), "games_of_1000_frames_or_more": int((L >= 1000).sum()),
            "mean_of_games_under_300_frames": float(L[L < 300].mean()),
-           "results_win_lose_tie": [int(np.sum(np.array(results) == k)) for k in (1, 2, 3)], "seconds": time.time() - t0}
+           "results_win_lose_tie": [int(np.sum(np.array(results) == k)) for k in (1, 2, 3)], "seconds": time.time() - t0,
+           "library": os.environ.get("OAKGPU_LIB", "product"), "seed": int(os.environ.get("SEED", "20261004")),
+           "lengths": [int(x) for x in lengths], "results": [int(x) for x in results]}
 else:
     P = int(sys.argv[2]) if len(sys.argv) > 2 else 109          # 109 pairs = 218 games, the TUTORIAL's count
     batch = int(sys.argv[3]) if len(sys.argv) > 3 else 256
