@@ -730,6 +730,13 @@ def test_frozen_standstill_skip_is_exact(gpu_ctx):
                     m = int(rs.randint(0, 1 << 17)) if k % 3 else int(1 << rs.randint(0, 17))
                     b[k, so + 144 + 16:so + 144 + 24] = 0
                     b[k, so + 144 + 16], b[k, so + 144 + 17], b[k, so + 144 + 18] = m & 0xFF, (m >> 8) & 0xFF, (m >> 16) & 1
+                    # a lock goes with the move that causes it: a side "thrashing" in Toxic is a state no game reaches, and once a Haze
+                    # thaws it the engines are free to differ there (the checker resolves status moves before the lock check, the
+                    # register engine behind it -- seen in a variant build, round 5)
+                    for bit, move in ((1, 37), (4, 76), (0, 117), (12, 99)):      # Thrash, SolarBeam, Bide, Rage
+                        if m >> bit & 1:
+                            b[k, so + 182] = move
+                            break
         assert len(b) > 1000
         ob, od, op = b.copy(), d.copy(), p.copy()
         oout, osteps = O.rollout_batch(ob, od, r, op, max_steps=cap, threads=8)
