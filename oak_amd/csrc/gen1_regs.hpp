@@ -102,7 +102,9 @@ __device__ __forceinline__ void cswap_sides(bool c, SideR &a, SideR &b) {
 #undef X
 }
 
-template <int STRIDE, bool TRACK_ACTIONS>
+// GIN_LDS: the lane's input battle lives in LDS (k_rollout_staged's staged copy) -- `gin` is then an LDS pointer and the immutable party
+// data is read with ds_read; as a generic pointer (flat loads that resolve to LDS) the staged kernel carried 44-54 spilled SGPRs.
+template <int STRIDE, bool TRACK_ACTIONS, bool GIN_LDS = false>
 struct EngineR {
   lds_u32 *m; // party storage (lane-interleaved LDS, same addressing as Engine)
   Tables T;
@@ -118,7 +120,15 @@ struct EngineR {
   // battle in global memory (`gin`, L2-resident) on the rare occasions it is needed (switch-in,
   // Transform bookkeeping, final write-back).  6 KB of LDS per wave leaves occupancy to the VGPR budget.
   static constexpr int PARTY_WORDS = 24;
-  const uint32_t *gin; // this lane's input battle: 96 dwords
+  template <bool L, class Dummy = void> struct GinPtr { typedef const uint32_t *type; };
+  template <class Dummy> struct GinPtr<true, Dummy> { typedef const lds_u32 *type; };
+  typedef typename GinPtr<GIN_LDS>::type gin_t;
+  gin_t gin; // this lane's input battle: 96 dwords
+  __device__ __forceinline__ uint4 gin4(int off) const { // 16 aligned bytes of it
+    typedef uint32_t v4 __attribute__((ext_vector_type(4)));
+    if constexpr (GIN_LDS) { const v4 t = *(const OAK_LDS v4 *)(gin + off); return make_uint4(t.x, t.y, t.z, t.w); }
+    else return *(const uint4 *)(gin + off);
+  }
   __device__ __forceinline__ uint32_t pw(uint32_t side, uint32_t i, int k) const { return m[((side * 6 + i) * 2 + k) * STRIDE]; }
   __device__ __forceinline__ void set_pw(uint32_t side, uint32_t i, int k, uint32_t v) { m[((side * 6 + i) * 2 + k) * STRIDE] = v; }
   __device__ __forceinline__ uint32_t gdw(uint32_t side, uint32_t i, int k) const { return gin[side * 46 + i * 6 + k]; }
@@ -287,7 +297,7 @@ struct EngineR {
     x.p5 = ((gdw(sd, pi, 5) & 0xFFFFFF00u) | ((hs >> 16) & 0xFF)) & keep;
   }
   __device__ __forceinline__ void load_battle_global(const uint8_t *battle384, uint32_t dur0, uint32_t dur1) {
-    gin = (const uint32_t *)battle384;
+    gin = (gin_t)battle384;
 #pragma unroll
     for (uint32_t sd = 0; sd < 2; ++sd)
 #pragma unroll
@@ -296,13 +306,13 @@ struct EngineR {
         set_pw(sd, i, 0, pack_pp(d2, d3, d4));
         set_pw(sd, i, 1, (d4 >> 16) | ((d5 & 0xFF) << 16));
       }
-    { const uint4 v = *(const uint4 *)(gin + 36); S.a0 = v.x; S.a1 = v.y; S.a2 = v.z; S.bo = v.w; }
-    { const uint4 v = *(const uint4 *)(gin + 40); S.vlo = v.x; S.vhi = v.y; S.m01 = v.z; S.m23 = v.w; }
+    { const uint4 v = gin4(36); S.a0 = v.x; S.a1 = v.y; S.a2 = v.z; S.bo = v.w; }
+    { const uint4 v = gin4(40); S.vlo = v.x; S.vhi = v.y; S.m01 = v.z; S.m23 = v.w; }
     S.o0 = gin[44]; S.o1 = gin[45];
     F.a0 = gin[82]; F.a1 = gin[83];
-    { const uint4 v = *(const uint4 *)(gin + 84); F.a2 = v.x; F.bo = v.y; F.vlo = v.z; F.vhi = v.w; }
-    { const uint4 v = *(const uint4 *)(gin + 88); F.m01 = v.x; F.m23 = v.y; F.o0 = v.z; F.o1 = v.w; }
-    { const uint4 v = *(const uint4 *)(gin + 92); turn = v.x & 0xFFFF; last_damage = v.x >> 16; lm = v.y; rng = (uint64_t)v.z | ((uint64_t)v.w << 32); }
+    { const uint4 v = gin4(84); F.a2 = v.x; F.bo = v.y; F.vlo = v.z; F.vhi = v.w; }
+    { const uint4 v = gin4(88); F.m01 = v.x; F.m23 = v.y; F.o0 = v.z; F.o1 = v.w; }
+    { const uint4 v = gin4(92); turn = v.x & 0xFFFF; last_damage = v.x >> 16; lm = v.y; rng = (uint64_t)v.z | ((uint64_t)v.w << 32); }
     S.dur = dur0; F.dur = dur1;
     S.misc = 0; F.misc = 1u << 8;
     actS = actF = 0;

@@ -707,6 +707,10 @@ __device__ __forceinline__ void embed_scatter(float *emb, uint32_t doff, float h
       o[nb][4 * g + 2] = acc[nb][4 * g + 2] + b[nb][g].z; o[nb][4 * g + 3] = acc[nb][4 * g + 3] + b[nb][g].w;
     }
   act_blocks<NBMAX>(o, activation);
+  // (opaque per call: the width tests below depend on the lane's half only, so the compiler hoisted all 48 of them -- 64-bit lane
+  // masks, two SGPRs each -- out of the mini-tile loop and kept them alive across it: 93 of the actives pass's 93 spilled SGPRs,
+  // a v_readlane pair per mask and mini-tile; recomputed here they are 48 compares per mini-tile)
+  asm volatile("" : "+v"(out_dim));
   if (doff != 0xFFFFFFFFu) {
     float *dst = emb + (size_t)doff + 1;
 #pragma unroll

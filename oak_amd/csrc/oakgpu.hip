@@ -291,16 +291,28 @@ __global__ __launch_bounds__(BLK, 2) void k_rollout_regs(RolloutArgs a) {
 // launch with ZERO steps; the HBM traffic is worth 12).  Here the wave moves its 64 battles (24 KB, contiguous) between
 // global memory and LDS with fully coalesced 1 KB accesses, and the engine reads / writes the LDS copy through `gin`
 // (a generic pointer: the flat loads resolve to LDS).
+template <class P>
+__device__ __forceinline__ P cold_ptr_at(const lds_u32 *cold, size_t byte_off) { // a 64-bit pointer parked in LDS
+  return (P)((uint64_t)cold[byte_off / 4] | ((uint64_t)cold[byte_off / 4 + 1] << 32));
+}
 constexpr int STAGE_STRIDE = 100; // words per staged battle: 96 + 4 (16-byte aligned rows that spread over the banks)
-constexpr int STAGED_LDS_BYTES = 24 * 64 * 4 + TABLE_LDS_PAD + 64 * STAGE_STRIDE * 4;
+constexpr int STAGED_COLD_BYTES = 128; // the kernel arguments, parked (below)
+constexpr int STAGED_LDS_BYTES = 24 * 64 * 4 + TABLE_LDS_PAD + 64 * STAGE_STRIDE * 4 + STAGED_COLD_BYTES;
 __global__ __launch_bounds__(64, 2) void k_rollout_staged(RolloutArgs a) {
   extern __shared__ __align__(16) uint8_t smem[];
   lds_u32 *party = (lds_u32 *)smem;
-  using ER = EngineR<64, false>;
+  using ER = EngineR<64, false, true>;
   Tables T = stage_default_tables((lds_u8 *)smem + ER::PARTY_WORDS * 64 * 4);
   typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
   typedef OAK_LDS u32x4 lds_u128;
   lds_u32 *stage = (lds_u32 *)((lds_u8 *)smem + ER::PARTY_WORDS * 64 * 4 + TABLE_LDS_PAD);
+  // the output pointers are parked in LDS across the turn loop, like k_rollout_queue's cold arguments: as kernel arguments they held
+  // ~20 SGPRs the loop's nested exec masks need (54 spilled SGPRs, a v_writelane / v_readlane pair each, in a kernel that runs ONE
+  // turn-step per launch in BASELINE configs[2])
+  static_assert(sizeof(RolloutArgs) <= STAGED_COLD_BYTES, "parked arguments fit");
+  lds_u32 *cold = stage + 64 * STAGE_STRIDE;
+  if (threadIdx.x < sizeof(RolloutArgs) / 4) cold[threadIdx.x] = ((const uint32_t *)&a)[threadIdx.x];
+#define SA_PTR(field, type) cold_ptr_at<type>(cold, offsetof(RolloutArgs, field))
   const uint32_t tid = threadIdx.x, base = blockIdx.x * 64, lane = base + tid;
   const uint32_t cnt = a.n - base < 64 ? a.n - base : 64; // battles of this wave
   {
@@ -318,46 +330,55 @@ __global__ __launch_bounds__(64, 2) void k_rollout_staged(RolloutArgs a) {
   ER e;
   e.m = party + tid;
   e.T = T;
-  if (lane < a.n) {
-    const uint32_t *dsrc = (const uint32_t *)a.durations + 2 * (size_t)lane;
-    const uint32_t *psrc = (const uint32_t *)a.prng + 2 * (size_t)lane;
+  const uint32_t n_all = (uint32_t)__builtin_amdgcn_readfirstlane((int)cold[offsetof(RolloutArgs, n) / 4]);
+  const uint32_t max_steps = (uint32_t)__builtin_amdgcn_readfirstlane((int)cold[offsetof(RolloutArgs, max_steps) / 4]);
+  if (lane < n_all) {
+    const uint32_t *dsrc = SA_PTR(durations, const uint32_t *) + 2 * (size_t)lane;
+    const uint32_t *psrc = SA_PTR(prng, const uint32_t *) + 2 * (size_t)lane;
     g.s0 = psrc[0];
     g.s1 = psrc[1];
-    e.load_battle_global((const uint8_t *)(stage + tid * STAGE_STRIDE), dsrc[0], dsrc[1]);
-    if (a.prep) { // mcts.h:254-259
+    e.load_battle_global((const uint8_t *)(stage + tid * STAGE_STRIDE), dsrc[0], dsrc[1]);   // (the address space comes back inside: gin_t)
+    if (cold[offsetof(RolloutArgs, prep) / 4]) { // mcts.h:254-259
       const uint32_t hi = g.next32(), lo = g.next32();
       e.rng = ((uint64_t)hi << 32) | lo;
       e.randomize_hidden();
     }
-    result = a.results_in[lane];
-    while ((result & 15) == 0 && steps < a.max_steps) {
+    result = SA_PTR(results_in, const uint8_t *)[lane];
+    while ((result & 15) == 0 && steps < max_steps) {
       const uint32_t hi = g.next32(), lo = g.next32(); // uniform_64 = hi << 32 | lo
       result = e.random_step(result, hi, lo);
       ++steps;
     }
     e.normalize();
-    a.results_out[lane] = (uint8_t)result;
-    a.steps_out[lane] = steps;
+    SA_PTR(results_out, uint8_t *)[lane] = (uint8_t)result;
+    SA_PTR(steps_out, uint32_t *)[lane] = steps;
     const uint32_t t = result & 15;
-    a.values_out[lane] = t == R_WIN ? 1.0f : t == R_LOSE ? 0.0f : 0.5f;
-    uint32_t *pdst = (uint32_t *)a.prng + 2 * (size_t)lane;
+    SA_PTR(values_out, float *)[lane] = t == R_WIN ? 1.0f : t == R_LOSE ? 0.0f : 0.5f;
+    uint32_t *pdst = SA_PTR(prng, uint32_t *) + 2 * (size_t)lane;
     pdst[0] = g.s0;
     pdst[1] = g.s1;
-    if (a.durations_out) {
-      uint32_t *ddst = (uint32_t *)a.durations_out + 2 * (size_t)lane;
+    uint32_t *dout = SA_PTR(durations_out, uint32_t *);
+    if (dout) {
+      uint32_t *ddst = dout + 2 * (size_t)lane;
       ddst[0] = e.S.dur;
       ddst[1] = e.F.dur;
     }
-    if (a.battles_out) e.store_battle_global((uint8_t *)(stage + tid * STAGE_STRIDE));
+    if (SA_PTR(battles_out, uint8_t *)) e.store_battle_global((uint8_t *)(stage + tid * STAGE_STRIDE));
   }
-  if (!a.battles_out) return;
+  uint8_t *bout = SA_PTR(battles_out, uint8_t *);
+  if (!bout) return;
   __syncthreads();
-  u32x4 *dst = (u32x4 *)(a.battles_out + (size_t)base * 384);
+  u32x4 *dst = (u32x4 *)(bout + (size_t)base * 384);
+  // (opaque: the 24 bounds tests here are the ones of the staging loop at the top, and the compiler kept their 24 lane masks -- 48
+  // SGPRs -- alive across the whole turn loop to reuse them: 44 of the kernel's 46 spilled SGPRs)
+  uint32_t cnt_out = cnt;
+  asm volatile("" : "+s"(cnt_out));
 #pragma unroll
   for (int k = 0; k < 24; ++k) {
     const uint32_t i = k * 64 + tid, b = i / 24, w = i - b * 24;
-    if (i < cnt * 24) dst[i] = *(const lds_u128 *)(stage + b * STAGE_STRIDE + 4 * w);
+    if (i < cnt_out * 24) dst[i] = *(const lds_u128 *)(stage + b * STAGE_STRIDE + 4 * w);
   }
+#undef SA_PTR
 }
 
 // ---- K1 driven by a caller-supplied DRAW STREAM instead of per-lane fast_prng: lane i consumes
