@@ -86,6 +86,11 @@ int oakgpu_set_migration(oakgpu_ctx *ctx, int mode, int long_steps, int adopters
  * hp stop changing at a median of turn-step 85, so they leave their full wave at ~step 135 instead of 300.  A heuristic about
  * WHO finishes a playout only; results never depend on it. */
 int oakgpu_set_migration_window(oakgpu_ctx *ctx, int window);
+/* The queue kernel takes a PROVEN frozen standstill -- both actives frozen (gen 1 never thaws by itself), neither side able to leave or
+ * act, different speeds: a turn-step then draws nothing and changes nothing but the turn counter -- to its last turn-step in one go
+ * (exact; tests/test_gpu_parity.py::test_frozen_standstill_skip_is_exact).  on = 0 plays every turn-step instead (A / B; also
+ * OAKGPU_STANDSTILL_SKIP=0 at context creation).  Default 1.  The one-lane-per-playout kernels (k_rollout_regs, k_root_step) never skip. */
+int oakgpu_set_standstill_skip(oakgpu_ctx *ctx, int on);
 /* Diagnostic (synchronises the stream): the 64 control words of the last queue launch -- [32] / [33]
  * the queue order's two counters, [40] donations, [41] adoptions, [42] bulk waves that left, [63] error bits (0 = none:
  * 1 a ticket never arrived, 2 an adopter gave up waiting) -- STICKY: no launch clears them; oakgpu_synchronize reports a
@@ -233,6 +238,10 @@ typedef struct {
   uint64_t duration_us;  /* time budget (search.cc:300-306): when non-zero, `iterations` is ignored and whole batches are
                           * started until this much time has elapsed; output.iterations tells how many ran */
 } oakgpu_search_params;
+/* Return code of oakgpu_search_heap / oakgpu_search_agent_heap (every other failure is -1 or a HIP error code): the heap's root was
+ * initialised with other action counts than the position passed in -- Heap::update was not called with the move that was played, or
+ * (--keep-node self-play) the kept child was expanded under other resampled hidden variables than the game really reached. */
+#define OAKGPU_E_ROOT_MISMATCH (-2)
 #define OAKGPU_EXP3_ALPHA_DEFAULT (-1.0f)
 /* the reference's defaults where a zero is not one: UCB c = 2 is the caller's business (agent strings carry it), root / other
  * rolls = default_search {3, 1} (mcts.h:131), Exp3 mixing = the default of an absent field */
@@ -482,7 +491,9 @@ int oakgpu_net_set_main_precision(oakgpu_net *net, int mode);
  * triple carries a value to fp32 accuracy only while its low parts are normal bf16 numbers (|x| >= ~2^-102); what a flushed
  * part loses is at most 2^-126 per factor, harmless unless later layers multiply it back up.  So a network with a main-net
  * weight (fc0 / fc1 / value_fc2) above 2^20 in magnitude runs its main net on fp32 MFMA, and a request for OAKGPU_MAIN_SPLIT
- * is not honoured for it (tests/test_gpu_leafnet.py: layers scaled by 2^-100 / 2^-120 / 2^+100, alone and compensated).  Returns the mode in effect (-1: null net); *split_allowed (nullable) = 0 for such
+ * is not honoured for it (tests/test_gpu_leafnet.py: layers scaled by 2^-100 / 2^-120 / 2^+100, alone and compensated).  The
+ * embedding nets' passes multiply as bf16 triples as well; a weight above 2^20 in their second layers or in the main net sends them
+ * through the fp32-MFMA form (k_embed_lds) instead.  Returns the mode in effect (-1: null net); *split_allowed (nullable) = 0 for such
  * a network. */
 int oakgpu_net_main_precision(const oakgpu_net *net, int *split_allowed);
 int oakgpu_leaf_eval_dev(oakgpu_ctx *ctx, oakgpu_net *net, const uint8_t *battles, const uint8_t *durations,

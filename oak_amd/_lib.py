@@ -8,7 +8,7 @@ LIB_PATH = os.environ.get("OAKGPU_LIB") or os.path.join(_HERE, "liboakgpu.so")  
 
 # every symbol include/oakgpu.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
-    "oakgpu_create", "oakgpu_destroy", "oakgpu_last_error", "oakgpu_set_stream", "oakgpu_get_stream", "oakgpu_synchronize", "oakgpu_set_kernel_timing", "oakgpu_get_leaf_kernel_ms", "oakgpu_set_playouts_per_lane", "oakgpu_set_regroup", "oakgpu_set_tail_pack", "oakgpu_set_queue_order", "oakgpu_set_spread", "oakgpu_set_migration", "oakgpu_set_migration_window", "oakgpu_get_queue_counters", "oakgpu_set_rollout_engine",
+    "oakgpu_create", "oakgpu_destroy", "oakgpu_last_error", "oakgpu_set_stream", "oakgpu_get_stream", "oakgpu_synchronize", "oakgpu_set_kernel_timing", "oakgpu_get_leaf_kernel_ms", "oakgpu_set_playouts_per_lane", "oakgpu_set_regroup", "oakgpu_set_tail_pack", "oakgpu_set_queue_order", "oakgpu_set_spread", "oakgpu_set_migration", "oakgpu_set_migration_window", "oakgpu_set_standstill_skip", "oakgpu_get_queue_counters", "oakgpu_set_rollout_engine",
     "oakgpu_device_count", "oakgpu_rollout_dev", "oakgpu_rollout", "oakgpu_rollout_group_dev", "oakgpu_rollout_group",
     "oakgpu_mt19937_fill", "oakgpu_rollout_draws_dev", "oakgpu_rollout_shared_device", "oakgpu_update_dev", "oakgpu_update",
     "oakgpu_choices_dev", "oakgpu_choices", "oakgpu_init_battles_dev", "oakgpu_init_battles",
@@ -101,6 +101,7 @@ def load():
     lib.oakgpu_set_spread.argtypes = [vp, i32]
     lib.oakgpu_set_migration.argtypes = [vp, i32, i32, i32]
     lib.oakgpu_set_migration_window.argtypes = [vp, i32]
+    lib.oakgpu_set_standstill_skip.argtypes = [vp, i32]
     lib.oakgpu_get_queue_counters.argtypes = [vp, vp]
     lib.oakgpu_set_rollout_engine.argtypes = [vp, i32, i32]
     lib.oakgpu_rollout_dev.argtypes = [vp, vp, vp, vp, vp, u32, u32, i32, vp, vp, vp, vp, vp]

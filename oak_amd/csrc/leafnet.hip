@@ -2111,6 +2111,7 @@ struct oakgpu_net {
   int device;        // the device the weights live on
   int main_mode;     // which kernel runs the main net: 0 = k_mainnet_wave (fp32 MFMA), 1 = k_mainnet_split (bf16 triples)
   bool split_safe;   // no main-net weight above 2^20 in magnitude: what a flushed low bf16 part loses cannot be amplified back (else fp32 MFMA only)
+  bool embed_safe;   // ... and none in the embedding nets' second layers either: the embedding passes' triples are safe (else k_embed_lds: fp32 MFMA)
 };
 
 namespace {
@@ -2484,6 +2485,14 @@ int oakgpu_net_load_memory(oakgpu_ctx *ctx, const void *bytes, size_t size, oakg
     for (const HostAffine *a : {&fc0, &fc1, &v2})
       for (float v : a->w) safe = safe && std::fabs(v) <= 0x1p20f;
     net->split_safe = safe;
+    // The embedding passes (k_embed_prows / k_embed_arows) multiply as bf16 triples too (round 4).  What a flushed part loses there is
+    // amplified by whatever comes BEHIND it -- the embedding nets' own second layers (L[1], L[3]) and the main net -- so a network
+    // with a weight above 2^20 in any of those runs its embedding nets through k_embed_lds (fp32 MFMA), whatever the main net's mode
+    // (round-4 advice: a layer scaled by 2^-110 in front of one scaled by 2^+110 is the same function in fp32).
+    bool esafe = safe;
+    for (const HostAffine *a : {&L[1], &L[3]})
+      for (float v : a->w) esafe = esafe && std::fabs(v) <= 0x1p20f;
+    net->embed_safe = esafe;
     const char *env = getenv("OAKGPU_MAIN_NET");
     net->main_mode = !safe ? 0 : env ? (strcmp(env, "fp32") == 0 ? 0 : 1) : 1;
   }
@@ -2615,7 +2624,8 @@ static int leaf_eval_impl(oakgpu_ctx *ctx, oakgpu_net *net, const uint8_t *battl
   // and active outputs up to 128; anything wider goes to k_embed_lds (the 64-item tile form).  OAKGPU_EMBED_TILE=1 forces
   // the tile form (A/B and a second implementation for the tests).
   static const bool force_tile = getenv("OAKGPU_EMBED_TILE") != nullptr;
-  const bool prow_ok = !force_tile && D.p_hidden <= 128 && D.p_out <= 64, arow_ok = !force_tile && D.a_hidden <= 128 && D.a_out <= 32 * oak::AR_MAX_NBO;
+  const bool rows = !force_tile && net->embed_safe; // (the row kernels multiply as bf16 triples: see embed_safe)
+  const bool prow_ok = rows && D.p_hidden <= 128 && D.p_out <= 64, arow_ok = rows && D.a_hidden <= 128 && D.a_out <= 32 * oak::AR_MAX_NBO;
   hipEvent_t *tev = (hipEvent_t *)oakgpu_ctx_timing_events(ctx); // diagnostic only (oakgpu_set_kernel_timing)
   static const int kinds = getenv("OAKGPU_EMBED_KINDS") ? atoi(getenv("OAKGPU_EMBED_KINDS")) : 3; // diagnostics: 1 party, 2 actives
   static const bool split = getenv("OAKGPU_EMBED_SPLIT") != nullptr; // A/B: the two passes as two launches

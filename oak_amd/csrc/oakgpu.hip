@@ -475,6 +475,7 @@ struct RoundArgs {
   uint32_t n_adopters;      // 0 = off; waves [0, n_adopters) adopt
   uint32_t long_steps;      // bits 0-15: a bulk wave donates a playout that is still running after this many turn-steps;
                             // bits 16-24: ... or whose actives' {slot, hp} have not changed for this many turn-steps (256: never)
+  uint32_t no_skip;         // 1: a proven frozen standstill is played turn by turn like everything else (oakgpu_set_standstill_skip: A/B)
 };
 
 // One launch drains a GROUP of independent batches (oakgpu_rollout_group_dev): the queue hands out GLOBAL playout
@@ -622,7 +623,7 @@ __global__ __launch_bounds__(BLK, WPS) void k_rollout_queue(GroupArgs g_in, Roun
 #define COLD_GU(field) COLD_U32(offsetof(ColdArgs, g) + offsetof(GroupArgs, field))
   // (wave-uniform booleans live as BITS of one scalar word: as `bool`s each is a 64-bit lane mask, two SGPRs, and the turn loop
   // has none to spare)
-  constexpr uint32_t U_RESUME = 1, U_PREP = 2, U_ADOPTER = 4, U_DRY = 8, U_ADOPTING = 16, U_ANY_PLAYING = 32;
+  constexpr uint32_t U_RESUME = 1, U_PREP = 2, U_ADOPTER = 4, U_DRY = 8, U_ADOPTING = 16, U_ANY_PLAYING = 32, U_NO_SKIP = 64;
   uint32_t ust = (COLD_QU(list_in) | COLD_U32(offsetof(ColdArgs, q) + offsetof(RoundArgs, list_in) + 4)) != 0 ? U_RESUME : 0u; // a later round: playouts come from the previous round's suspended list
 #define IS_RESUME ((ust & U_RESUME) != 0)
 #define IS_PREP ((ust & U_PREP) != 0)
@@ -630,6 +631,7 @@ __global__ __launch_bounds__(BLK, WPS) void k_rollout_queue(GroupArgs g_in, Roun
   const uint32_t max_steps = COLD_GU(max_steps), suspend_below = COLD_QU(suspend_below);
   if (!IS_RESUME && COLD_GU(prep) != 0) ust |= U_PREP;
   ust |= (blockIdx.x & 7u) << 8; // the queue head this wave starts at
+  if (COLD_QU(no_skip) != 0) ust |= U_NO_SKIP;
   ER e;
   e.m = party + tid;
   e.T = T;
@@ -795,7 +797,7 @@ __global__ __launch_bounds__(BLK, WPS) void k_rollout_queue(GroupArgs g_in, Roun
     // order cannot see in the teams (round 4: 1-5 per 1.31 M playouts, started anywhere in the queue, each ~950 dependent
     // turn-steps at a lone lane's 4.7 us: the launches they ended took 16.4-16.6 ms instead of 14.7-14.9).  Exact, not a
     // heuristic: tests/test_gpu_parity.py holds it to the oracle, which plays every turn.
-    if (playing && stale >= (8u << 24) && e.frozen_standstill(result)) {
+    if (playing && stale >= (8u << 24) && !(ust & U_NO_SKIP) && e.frozen_standstill(result)) {
       const uint32_t by_steps = max_steps - steps, by_turn = 1000u - e.turn;
       const uint32_t skip = (by_steps < by_turn ? by_steps : by_turn) - 1u; // (both >= 1 while playing)
       for (uint32_t k = 0; k < skip; ++k) { (void)g.next32(); (void)g.next32(); }
@@ -1642,6 +1644,7 @@ struct oakgpu_ctx {
   int migrate_used;       //   the last queue launch ran with migration: oakgpu_synchronize reports its error word
   int spread_lanes;       // launches that do not fill the device: lanes per wave that take playouts (-1 automatic, 0 / 64 = all)
   int queue_order;        // 1 (default): a saturated launch hands its playouts out likely-longest first (k_queue_order)
+  int standstill_skip;    // 1 (default): the queue kernel takes a PROVEN frozen standstill to its last turn-step in one go (exact); 0: plays every turn
   uint32_t *d_order;      // total entries
   size_t order_n;
   int n_cu;               // compute units of the device
@@ -1816,6 +1819,8 @@ int oakgpu_create(oakgpu_ctx **out, int device) {
   if (const char *env = getenv("OAKGPU_SPREAD_LANES")) c->spread_lanes = atoi(env) < -1 ? -1 : atoi(env) > 64 ? 64 : atoi(env);
   c->queue_order = 1;
   if (const char *env = getenv("OAKGPU_QUEUE_ORDER")) c->queue_order = atoi(env) != 0;
+  c->standstill_skip = 1;
+  if (const char *env = getenv("OAKGPU_STANDSTILL_SKIP")) c->standstill_skip = atoi(env) != 0;
   c->migrate = 1;
   c->migrate_steps = 300;
   c->migrate_adopters = 0;
@@ -1925,6 +1930,12 @@ int oakgpu_get_queue_counters(oakgpu_ctx *c, uint32_t *out64) { // diagnostic: s
 int oakgpu_set_spread(oakgpu_ctx *c, int lanes) {
   if (!c || lanes < -1 || lanes > 64) return bad("oakgpu_set_spread: lanes must be -1 (automatic) or 0..64");
   c->spread_lanes = lanes;
+  return 0;
+}
+
+int oakgpu_set_standstill_skip(oakgpu_ctx *c, int on) {
+  if (!c) return bad("null ctx");
+  c->standstill_skip = on != 0;
   return 0;
 }
 
@@ -2103,6 +2114,7 @@ static int launch_group(oakgpu_ctx *c, const oak::BatchDesc *descs, uint32_t cou
     oak::RoundArgs q{};
     q.order = r == 0 ? order : nullptr;
     q.long_steps = (uint32_t)(c->migrate_steps > 0xFFFF ? 0xFFFF : c->migrate_steps) | (uint32_t)(c->migrate_window > 0 ? c->migrate_window : 256) << 16;
+    q.no_skip = c->standstill_skip ? 0u : 1u;
     if (migrate) { q.adopt_ctl = c->d_queue + 40; q.adopt_list = lists[0]; q.n_adopters = adopters; }
     q.list_in = r ? lists[(r - 1) & 1] : nullptr;
     q.n_in = r ? c->d_queue + 2 * r - 1 : nullptr; // = count_out of round r - 1

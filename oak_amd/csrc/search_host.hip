@@ -712,7 +712,10 @@ int oakgpu_search_heap(oakgpu_ctx *ctx, oakgpu_net *net, oakgpu_heap *heap, cons
   }
   const uint32_t root = H.root;
   if (tree.node(root).is_init() && (tree.node(root).p1.k != m || tree.node(root).p2.k != n))
-    return oakgpu_fail_msg("oakgpu_search: the heap's root has other action counts than this position (Heap::update was not called with the move that was played?)");
+  {
+    (void)oakgpu_fail_msg("oakgpu_search: the heap's root has other action counts than this position (Heap::update was not called with the move that was played?)");
+    return OAKGPU_E_ROOT_MISMATCH;
+  }
   if (!tree.node(root).is_init()) { // stats.init(k1, k2) + priors (mcts.h:177-210)
     tree.node(root).p1.init(m, BP.kind);
     tree.node(root).p2.init(n, BP.kind);

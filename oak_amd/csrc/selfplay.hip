@@ -211,7 +211,7 @@ int oakgpu_selfplay_game(oakgpu_ctx *ctx, oakgpu_net *net, const uint8_t *teams,
     oakgpu_search_output out;
     sp.seed = splitmix64(rng);
     int src = oakgpu_search_heap(ctx, net, heap.h, battle, durations, result, &sp, nullptr, &out);
-    if (src && heap.h && strstr(oakgpu_last_error(), "other action counts")) {
+    if (src == OAKGPU_E_ROOT_MISMATCH && heap.h) {
       // --keep-node: the kept child was expanded by a playout whose RESAMPLED hidden variables (mcts.h:254-259) gave it other
       // legal choices than the position the game really reached (a thrash / bide counter that ran out in one and not in the
       // other).  Its statistics are about another decision: start this position's tree afresh, like an update that found no child.

@@ -77,6 +77,10 @@ class Context:
         """Donate a playout whose actives stood still for `window` turn-steps (oakgpu_set_migration_window; 0 = off)."""
         _lib.check(self.lib.oakgpu_set_migration_window(self.handle, int(window)))
 
+    def set_standstill_skip(self, on=True):
+        """The queue kernel's exact fast-forward of proven frozen standstills (oakgpu_set_standstill_skip); results never change."""
+        _lib.check(self.lib.oakgpu_set_standstill_skip(self.handle, 1 if on else 0))
+
     def queue_counters(self):
         """The 64 control words of the last queue launch (oakgpu_get_queue_counters): [40] donations, [41] adoptions, [63] sticky error bits."""
         out = np.zeros(64, dtype=np.uint32)

@@ -166,6 +166,36 @@ def test_bf16_triple_main_net_at_the_edges_of_the_exponent_range(gpu_ctx, tmp_pa
     net.close()
 
 
+@pytest.mark.parametrize("case", ["down20_up20", "down110_up110"])
+def test_bf16_triple_embedding_nets_at_the_edges_of_the_exponent_range(gpu_ctx, tmp_path, case):
+    """The embedding passes multiply as bf16 triples too (round 4); round-4 advice: an embedding first layer scaled by 2^-s in front of
+    a second layer scaled by 2^+s is the same function in fp32 (ReLU commutes with a positive scale), but for s ~ 110 the triples'
+    low parts flush in the first layer and the second multiplies the loss back up.  A second-layer weight above 2^20 therefore sends
+    the embedding nets through the fp32-MFMA form (k_embed_lds); s = 20 stays on the bf16 pipe.  Either way the embedding equals the
+    unscaled net's to 2e-5 and the value to 1e-5 of the oracle."""
+    from oak_amd.engine import Network
+    dst = str(tmp_path / "edge_emb.battle.net")
+    s_ = 20 if case == "down20_up20" else 110
+
+    def edit(i, b, W):
+        if i in (0, 2):
+            return b * np.float32(2.0 ** -s_), W * np.float32(2.0 ** -s_)
+        if i in (1, 3):
+            return b, W * np.float32(2.0 ** s_)
+        return b, W
+    _rewrite_net(NET256, dst, edit)
+    net, plain = Network(gpu_ctx, path=dst), Network(gpu_ctx, path=NET256)
+    onet = NN.Net(NET256)
+    b, d = _midgame_states(200, 30, 777)
+    v, emb = net.value_inference(b, d, return_embedding=True)
+    pv, pemb = plain.value_inference(b, d, return_embedding=True)
+    assert np.isfinite(emb).all() and np.abs(emb - pemb).max() <= 2e-5, (case, np.abs(emb - pemb).max())
+    exp = np.array([float(NN.value_inference(onet, b[i], d[i])) for i in range(b.shape[0])])
+    assert np.abs(v - exp).max() <= TOL and np.abs(pv - exp).max() <= TOL
+    net.close()
+    plain.close()
+
+
 def test_non_finite_parameters_are_refused_by_the_loader(gpu_ctx, tmp_path):
     """oakgpu_net_load refuses a parameter file that holds a NaN or an infinity, naming the layer (the reference would load
     it and propagate NaN through every inference; on the bf16 pipe an infinite weight would split into inf + NaN)."""

@@ -744,6 +744,14 @@ def test_frozen_standstill_skip_is_exact(gpu_ctx):
         assert (((oout & 15) == 3) | (osteps >= cap)).mean() > (0.3 if seed0 == 0xF0F0_0005 else 0.9), "the fixture no longer produces standstills"
         for key, exp in (("results", oout), ("steps", osteps), ("battles", ob), ("durations", od), ("prng", op)):
             assert (got[key] == exp).all(), (hex(seed0), cap, turn, key, int((got[key] != exp).sum()))
+        if seed0 == 0xF0F0_0002:                      # the runtime switch: every turn-step played, same bytes (round-4 advice: an A/B handle)
+            gpu_ctx.set_standstill_skip(False)
+            try:
+                slow = gpu_ctx.rollout(b, d, r, p, max_steps=cap, return_state=True)
+            finally:
+                gpu_ctx.set_standstill_skip(True)
+            for key in ("results", "steps", "battles", "durations", "prng"):
+                assert (slow[key] == got[key]).all(), key
 
 
 # ---- BASELINE configs[3] in slices: oakgpu_root_steps (k_root_step) against the oracle that applies the same crediting rule ----------

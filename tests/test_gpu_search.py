@@ -294,6 +294,25 @@ def test_heap_update_promotes_the_played_child(gpu_ctx):
     h.close()
 
 
+def test_a_heap_searched_from_another_position_is_refused_with_its_own_code(gpu_ctx):
+    """A heap whose root was initialised for one position and is then searched from a position with other legal-choice counts (the
+    caller forgot Heap::update, or a --keep-node game reached a position its kept child was not expanded for): refused with
+    OAKGPU_E_ROOT_MISMATCH (-2) -- the code oakgpu_selfplay_game recovers from by starting the position's tree afresh -- not with a
+    message that has to be parsed."""
+    from oak_amd._lib import OakGpuError
+    from oak_amd.search import Heap, tree_search
+    full, d9 = parse_battle("starmie surf recover thunderwave psychic; alakazam psychic; chansey icebeam | snorlax bodyslam rest; tauros bodyslam; exeggutor psychic")
+    single, d1 = parse_battle("starmie seismictoss 101hp slp3 | snorlax seismictoss 1hp")
+    h = Heap()
+    a = tree_search(gpu_ctx, full, d9, result_from_state(full), iterations=2048, batch=512, seed=1, heap=h)
+    assert a["m"] > 1
+    with pytest.raises(OakGpuError, match=r"other action counts.*code -2"):
+        tree_search(gpu_ctx, single, d1, result_from_state(single), iterations=512, batch=128, seed=2, heap=h)
+    b = tree_search(gpu_ctx, full, d9, result_from_state(full), iterations=2048, batch=512, seed=3, heap=h)     # the heap is still good for ITS position
+    assert b["iterations"] == 2048 and b["nodes"] >= a["nodes"]
+    h.close()
+
+
 def test_time_budget_on_a_cold_context_runs_at_least_one_batch():
     """Round-2 advice: with the clock started before the set-up a 1 ms budget on a fresh context ran zero batches and
     returned NaN strategies.  The clock now covers the iteration loop only and a time budget always runs once
