@@ -895,9 +895,21 @@ def config4_workload(args, torch, dev, rank, local_rank, world, dist):
                          "traffic_source": (PROFILE_SOURCE + ": config4_hbm_bytes_per_turn_step (2 x FETCH_SIZE + WRITE_SIZE of a profiled step) x this run's "
                                             "turn-steps per step; not measured in this run") if per_step else None,
                          "algorithmic_bytes_per_turn_step": ALGO_BYTES_PER_STEP,
-                         "note": "whole-job clock (launches + gathers + host copies + the host's wait for every step's aggregates), per rank; notional like the "
-                                 "headline's: the kernel is VALU-issue bound"},
+                         "note": "whole-job clock (launches + gathers + host copies + the host's wait for every step's aggregates), per rank.  NOTIONAL, and "
+                                 "above 1 by construction: SURVEY 8d's 802 algorithmic bytes per turn-step describe a step-per-launch design; this kernel keeps "
+                                 "a playout on chip for a whole slice and moves `traffic` bytes.  The bound that applies is `valu_issue`."},
         }
+    if rank == 0 and sliced and tj.get("config4_valu_wave_insts_per_turn_step"):
+        peak, peak_src = valu_issue_peak()
+        vpt = tj["config4_valu_wave_insts_per_turn_step"]
+        ach = vpt * my_steps / elapsed
+        rec["roofline"]["valu_issue"] = {
+            "wave_insts_per_turn_step": vpt, "achieved_ginst_s": ach / 1e9, "peak_ginst_s": peak / 1e9, "peak_source": peak_src, "frac": ach / peak,
+            "active_lanes_per_wave_inst": tj.get("config4_valu_active_lanes_per_wave_inst"),
+            "source": PROFILE_SOURCE + ": " + tj.get("config4_valu_source", ""),
+            "note": "the peak is the best MIXED integer stream of the issue microbenchmark (4 cycles per wave64 instruction); homogeneous v_add / v_and / v_mov "
+                    "runs issue at 2 cycles (1,000-1,160 G/s), and a kernel whose stream holds such runs can pass the mixed figure -- read a fraction near "
+                    "or above 1 as `at the issue roof`, not as a measurement error"}
     if world == 1 and not rccl and not os.environ.get("BENCH_NO_RANK_SHARE"):
         # one rank's share at 8 GPUs (32 roots x 4096), same pipelined code, on this one GPU: what bounds the strong-scaling curve
         share = n_roots // 8
