@@ -312,9 +312,41 @@ public:
     check(oakgpu_all_gather_dev(ctx_.get(), comm_, means, all, roots));
   }
 
+  // the sliced search steps' exchange: `count` 64-bit aggregates (count | 2 x value sum << 32, OakGPU::RootSteps) per rank
+  void aggregates_all_gather_dev(const unsigned long long *mine, unsigned long long *all, size_t count) {
+    check(oakgpu_all_gather_dev(ctx_.get(), comm_, reinterpret_cast<const float *>(mine), reinterpret_cast<float *>(all), 2 * count));
+  }
+
 private:
   Context &ctx_;
   oakgpu_comm *comm_{};
+};
+
+// BASELINE configs[3] as search steps that do not wait for their longest playout (oakgpu_root_steps_*, include/oakgpu.h): every launch
+// advances each playout in flight by at most `slice` turn-steps; a playout of len turn-steps started in step k is credited to step
+// k + (len - 1) / slice of its root and travels between launches on a carry list.  The reference's analogue: the generator's workers never
+// wait for each other (cpp/src/generate.cc:527-536); per-playout prep = mcts.h:250-263, the playout = mcts.h:448-496.
+class RootSteps {
+public:
+  RootSteps(Context &ctx, uint32_t roots, uint32_t replicas, uint32_t slice = 32, uint32_t max_steps = 1000) : roots_{roots} {
+    check(oakgpu_root_steps_create(ctx.get(), roots, replicas, slice, max_steps, &rs_));
+  }
+  ~RootSteps() { oakgpu_root_steps_destroy(rs_); }
+  RootSteps(const RootSteps &) = delete;
+  RootSteps &operator=(const RootSteps &) = delete;
+  // device pointers, asynchronous on the context's stream.  report: roots + 2 u64 -- [r] count | (2 x value sum) << 32 of the playouts
+  // credited to this step, [roots] turn-steps executed, [roots + 1] carried playouts | error word << 32.  fresh = false: a drain step.
+  void launch_dev(const uint8_t *root_battles, const uint8_t *root_durations, const uint8_t *root_results, uint8_t *lane_prng,
+                  unsigned long long *report, bool fresh = true) {
+    check(oakgpu_root_steps_launch_dev(rs_, root_battles, root_durations, root_results, lane_prng, fresh ? 1 : 0, report));
+  }
+  static uint32_t credited(unsigned long long a) { return static_cast<uint32_t>(a); }
+  static double mean_value(unsigned long long a) { return credited(a) ? static_cast<double>(a >> 32) / (2.0 * credited(a)) : 0.5; }
+  uint32_t roots() const { return roots_; }
+
+private:
+  oakgpu_root_steps *rs_{};
+  uint32_t roots_;
 };
 
 } // namespace OakGPU

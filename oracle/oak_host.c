@@ -167,6 +167,20 @@ uint32_t oracle_fast_prng_next32(uint8_t state8[8]) {
   memcpy(state8 + 4, &s1, 4);
   return result;
 }
+/* batch helpers of the tests (plain loops over the two functions above) */
+void oracle_fast_prng_seed_batch(uint8_t *states8, uint32_t n, uint64_t seed0) {
+  for (uint32_t i = 0; i < n; ++i) oracle_fast_prng_seed(states8 + (size_t)i * 8, seed0 + i);
+}
+/* oakgpu_root_steps' stream rule: lane i's stream advances by ONE uniform_64 (hi, lo); that draw is the 8-byte state {s0 = hi, s1 = lo} of
+ * the step's fresh playout's own stream (all-zero -- the generator's fixed point -- becomes s1 = 1). */
+void oracle_fast_prng_spawn_batch(uint8_t *lane_states8, uint32_t n, uint8_t *playout_states8) {
+  for (uint32_t i = 0; i < n; ++i) {
+    uint32_t hi = oracle_fast_prng_next32(lane_states8 + (size_t)i * 8), lo = oracle_fast_prng_next32(lane_states8 + (size_t)i * 8);
+    if (hi == 0 && lo == 0) lo = 1;
+    memcpy(playout_states8 + (size_t)i * 8, &hi, 4);
+    memcpy(playout_states8 + (size_t)i * 8 + 4, &lo, 4);
+  }
+}
 uint64_t oracle_fast_prng_uniform_64(uint8_t state8[8]) {
   uint64_t hi = oracle_fast_prng_next32(state8);
   uint64_t lo = oracle_fast_prng_next32(state8);

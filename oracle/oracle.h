@@ -68,6 +68,8 @@ uint64_t oracle_mt19937_uniform_64(oracle_mt19937 *g);
 void oracle_fast_prng_seed(uint8_t state8[8], uint64_t seed); /* std::seed_seq{lo,hi} */
 uint32_t oracle_fast_prng_next32(uint8_t state8[8]);
 uint64_t oracle_fast_prng_uniform_64(uint8_t state8[8]);
+void oracle_fast_prng_seed_batch(uint8_t *states8, uint32_t n, uint64_t seed0);               /* lane i seeded with seed0 + i */
+void oracle_fast_prng_spawn_batch(uint8_t *lane_states8, uint32_t n, uint8_t *playout_states8); /* oakgpu_root_steps' stream rule */
 
 /* MCTS::Search::init_stats_and_rollout (search/mcts.h:448-496) with a fast_prng device
  * whose 8-byte state is `prng8`; stops at a terminal result or after max_steps

@@ -34,6 +34,8 @@ def _load():
     lib.oracle_fast_prng_next32.argtypes = [C.c_void_p]
     lib.oracle_fast_prng_uniform_64.restype = C.c_uint64
     lib.oracle_fast_prng_uniform_64.argtypes = [C.c_void_p]
+    lib.oracle_fast_prng_seed_batch.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64]
+    lib.oracle_fast_prng_spawn_batch.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
     lib.oracle_rollout_fast.restype = C.c_uint8
     lib.oracle_rollout_fast.argtypes = [C.c_void_p, C.c_void_p, C.c_uint8, C.c_void_p, C.c_uint32, C.c_void_p]
     lib.oracle_rollout_mt.restype = C.c_uint8
@@ -180,12 +182,8 @@ def root_steps_reference(root_b, root_d, root_r, lane_prng, reps, steps, slice, 
     rid = np.repeat(np.arange(roots), reps)
     for k in range(steps):
         pp = np.zeros((n, 8), dtype=np.uint8)
-        for i in range(n):
-            hi = LIB.oracle_fast_prng_next32(ptr(lane_prng[i]))
-            lo = LIB.oracle_fast_prng_next32(ptr(lane_prng[i]))
-            if hi == 0 and lo == 0:
-                lo = 1
-            pp[i].view(np.uint32)[:] = (hi, lo)
+        assert lane_prng.flags["C_CONTIGUOUS"] and lane_prng.shape == (n, 8)
+        LIB.oracle_fast_prng_spawn_batch(ptr(lane_prng), n, ptr(pp))
         b = np.ascontiguousarray(np.repeat(root_b, reps, axis=0))
         d = np.ascontiguousarray(np.repeat(root_d, reps, axis=0))
         r = np.ascontiguousarray(np.repeat(root_r, reps))

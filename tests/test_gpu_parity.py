@@ -12,8 +12,7 @@ pytestmark = pytest.mark.gpu
 
 def _seed_prng(n, seed0):
     prng = np.zeros((n, 8), dtype=np.uint8)
-    for i in range(n):
-        O.LIB.oracle_fast_prng_seed(O.ptr(prng[i]), C.c_uint64(seed0 + i))
+    O.LIB.oracle_fast_prng_seed_batch(O.ptr(prng), n, C.c_uint64(seed0))
     return prng
 
 
@@ -882,3 +881,31 @@ def test_root_steps_host_class_in_a_torch_process():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, os.path.join(root, "tests", "root_steps_check.py")], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "root steps ok" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
+
+
+def test_full_size_config4_sliced_steps_bit_exact(gpu_ctx):
+    """BASELINE configs[3] at full size through the sliced search steps: 256 roots x 4,096 fresh playouts per step (the first 256 lanes of
+    config 2), slices of 32 turn-steps, two search steps and the drain.  EVERY step's per-root aggregate (count, 2 x value sum)
+    and the turn-steps each launch executes equal the oracle's -- 2.1 M playouts, ~210 M turn-steps, every one credited exactly once --
+    and the lane streams afterwards are the oracle's."""
+    n_roots, reps, steps, slice_ = 256, 4096, 2, 32
+    b, d, p, r = O.make_random_ou_batch(n_roots, seed0=0x0A4B00000000)
+    lane = _seed_prng(n_roots * reps, 0xC40000000000)
+    ref_lane = lane.copy()
+    cnt, s2, ex = O.root_steps_reference(b, d, r, ref_lane, reps, steps, slice_, threads=16)
+    rs = _RootSteps(gpu_ctx, b, d, r, lane, reps, slice_)
+    try:
+        k = 0
+        while True:
+            rec = rs.step(fresh=k < steps)
+            assert rec["err"] == 0
+            assert (rec["count"] == cnt[k]).all() and (rec["sum2"] == s2[k]).all(), k
+            assert rec["turn_steps"] == ex[k], (k, rec["turn_steps"], ex[k])
+            k += 1
+            if k >= steps and rec["carried"] == 0:
+                break
+            assert k < cnt.shape[0]
+        assert int(cnt[:k].sum()) == n_roots * reps * steps and int(ex.sum()) > 150_000_000
+        assert (rs.lane_streams() == ref_lane).all()
+    finally:
+        rs.close()
