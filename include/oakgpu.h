@@ -347,7 +347,7 @@ int oakgpu_search_heap(oakgpu_ctx *ctx, oakgpu_net *net, oakgpu_heap *heap, cons
  * threads that never wait for each other, generate.cc:527-536), search i on ctxs[i] -- every search needs a context of its own (its
  * stream and batch slots) and, when heaps != NULL, a heap of its own -- with battles n x 384, durations n x 8, results n, params n
  * entries (seeds!), outs n entries.  Each search is exactly oakgpu_search_heap(ctxs[i], net, heaps[i], ..., NULL, &outs[i]): same output,
- * same heap, whatever runs beside it.  threads_per_search: host threads of each tree walk (1, 2, 4, 8); 0 = the usable cores shared
+ * same heap, whatever runs beside it.  threads_per_search: host threads of each tree walk (1, 2, 4, 8, 16); 0 = the usable cores shared
  * evenly (OAKGPU_SEARCH_CORES overrides the affinity mask's count, e.g. under a cgroup quota). */
 int oakgpu_search_many(oakgpu_ctx *const *ctxs, oakgpu_net *net, oakgpu_heap *const *heaps, const uint8_t *battles, const uint8_t *durations,
                        const uint8_t *results, const oakgpu_search_params *params, uint32_t n, int threads_per_search,
@@ -439,7 +439,7 @@ int oakgpu_selfplay_game(oakgpu_ctx *ctx, oakgpu_net *net /* nullable for eval !
 /* n self-play games at once on one GPU (the generator's N worker threads, generate.cc:527-536): game g on ctxs[g] -- a context of its own
  * each -- with teams + 60 g, battle_seeds[g], params[g]; its record goes to buffers + g * capacity_each, written[g] / n_frames[g] /
  * results[g] as oakgpu_selfplay_game returns them.  Every game is byte for byte the game it would be alone.  threads_per_game: host
- * threads of each game's tree walks (1, 2, 4, 8); 0 = the usable cores shared evenly. */
+ * threads of each game's tree walks (1, 2, 4, 8, 16); 0 = the usable cores shared evenly. */
 int oakgpu_selfplay_games(oakgpu_ctx *const *ctxs, oakgpu_net *net, const uint8_t *teams, const uint64_t *battle_seeds, oakgpu_selfplay_params *params,
                           uint32_t n, int threads_per_game, uint8_t *buffers, size_t capacity_each, size_t *written, uint32_t *n_frames,
                           uint8_t *results);

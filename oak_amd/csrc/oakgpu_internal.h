@@ -37,3 +37,5 @@ int oakgpu_ctx_set_concurrent_hint(oakgpu_ctx *ctx, int on);
 // Host threads of the tree walks started by the CALLING thread (0 = the default rule): callers that run several searches side
 // by side -- oakgpu_search_many, oakgpu_selfplay_games -- give each its share of the cores.
 void oakgpu_set_thread_search_threads(int threads);
+// Cores the process may really use (affinity mask capped by the cgroup CPU quota; OAKGPU_SEARCH_CORES overrides): search_host.hip.
+unsigned oakgpu_usable_cores();

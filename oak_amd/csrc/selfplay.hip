@@ -257,14 +257,8 @@ int oakgpu_selfplay_games(oakgpu_ctx *const *ctxs, oakgpu_net *net, const uint8_
     for (uint32_t k = 0; k < g; ++k) if (ctxs[k] == ctxs[g]) return oakgpu_fail_msg("oakgpu_selfplay_games: every game needs a context of its own");
   }
   int W = threads_per_game;
-  if (W <= 0) {
-    unsigned hc = std::thread::hardware_concurrency();
-    cpu_set_t set;
-    if (sched_getaffinity(0, sizeof set, &set) == 0) hc = (unsigned)CPU_COUNT(&set);
-    if (const char *e = getenv("OAKGPU_SEARCH_CORES")) hc = (unsigned)atoi(e);
-    W = (int)(hc / n);
-  }
-  W = W >= 8 ? 8 : W >= 4 ? 4 : W >= 2 ? 2 : 1;
+  if (W <= 0) W = (int)(oakgpu_usable_cores() / n);
+  W = W >= 16 ? 16 : W >= 8 ? 8 : W >= 4 ? 4 : W >= 2 ? 2 : 1;
   std::vector<int> rc(n, 0);
   std::vector<std::string> err(n);
   std::vector<std::thread> th;

@@ -354,14 +354,14 @@ def test_contextual_root_priors_and_zero_budget(gpu_ctx):
 
 
 def test_host_thread_count_does_not_change_the_search(gpu_ctx):
-    """The tree is cut into 8 shards served by 1, 2, 4 or 8 host threads (search_host.hip): any count walks the same tree."""
+    """The tree is cut into 16 shards served by 1, 2, 4, 8 or 16 host threads (search_host.hip): any count walks the same tree."""
     import oracle_lib as O
     from oak_amd.search import tree_search
     b, d, p, r = O.make_random_ou_batch(1, seed0=999)
     outs = []
     old = os.environ.get("OAKGPU_SEARCH_THREADS")
     try:
-        for w in ("1", "2", "4", "8"):
+        for w in ("1", "2", "4", "8", "16"):
             os.environ["OAKGPU_SEARCH_THREADS"] = w
             outs.append(tree_search(gpu_ctx, b[0], d[0], int(r[0]), iterations=1 << 15, batch=4096, seed=13, bandit="exp3", c=0.3))
             outs.append(tree_search(gpu_ctx, b[0], d[0], int(r[0]), iterations=1 << 15, batch=4096, seed=13))
@@ -370,7 +370,7 @@ def test_host_thread_count_does_not_change_the_search(gpu_ctx):
             os.environ.pop("OAKGPU_SEARCH_THREADS", None)
         else:
             os.environ["OAKGPU_SEARCH_THREADS"] = old
-    for k in (2, 4, 6):
+    for k in (2, 4, 6, 8):
         for base in (0, 1):
             assert (outs[k + base]["visit_matrix"] == outs[base]["visit_matrix"]).all()
             assert outs[k + base]["value_matrix"].tobytes() == outs[base]["value_matrix"].tobytes()

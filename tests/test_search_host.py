@@ -180,7 +180,7 @@ def test_root_select_run_equals_the_plain_select_visit_loop():
             assert int(vr.sum()) == int(visits.sum()) + (count if k > 1 else 0) or k == 1
 
 
-@pytest.mark.parametrize("threads", [1, 4, 8])
+@pytest.mark.parametrize("threads", [1, 4, 8, 16])
 def test_promoted_heap_keeps_the_shard_invariant_of_the_threaded_walk(threads):
     """Round-3 advice (data race after Heap::update): Tree::keep_subtree kept a node's OLD creator shard while its edge
     re-hashed into another table, so the thread of that table read arena[owner][creator'] while thread creator' could append

@@ -1,7 +1,7 @@
 """ThreadSanitizer over the tree search's threaded host walk (round-3 advice: the race after Heap::update).  The host side of
 oak_amd/csrc/search_host.hip is rebuilt with -fsanitize=thread (device code untouched; every other symbol comes from the product
 library) and oakgpu_heap_selftest -- grow a random tree with the search's own threaded resolve phase, promote a child, grow on --
-runs under it on 1 / 2 / 4 / 8 threads.  CPU only: no kernel is launched."""
+runs under it on 1 / 2 / 4 / 8 / 16 threads.  CPU only: no kernel is launched."""
 import os
 import shutil
 import subprocess
@@ -18,7 +18,7 @@ int oakgpu_heap_selftest(uint32_t rounds, uint32_t lanes, uint64_t seed, int thr
 const char *oakgpu_last_error(void);
 int main(void) {
   int bad = 0;
-  for (int threads = 1; threads <= 8; threads *= 2)
+  for (int threads = 1; threads <= 16; threads *= 2)
     for (uint64_t seed = 1; seed <= 2; ++seed) {
       uint64_t out[4] = {0, 0, 0, 0};
       const int rc = oakgpu_heap_selftest(16, 2048, seed, threads, out);
@@ -50,4 +50,4 @@ def test_threaded_tree_walk_is_clean_under_thread_sanitizer(tmp_path):
     out = r.stdout + r.stderr
     assert "ThreadSanitizer" not in out, out[-4000:]
     assert r.returncode == 0, out[-2000:]
-    assert out.count("violations 0") == 8, out
+    assert out.count("violations 0") == 10, out

@@ -20,6 +20,8 @@ b, d, p, r = O.make_random_ou_batch(1, seed0=0x0A4B00000000)
 net = Network(ctx, path=os.path.join("tests", "golden", "net_256.battle.net"))
 tree_search(ctx, b[0], d[0], int(r[0]), iterations=2 * batch, batch=batch, evaluator=net)
 for k in range(reps):
+    if len(sys.argv) > 4:                         # thread counts to compare, e.g. 8,16
+        os.environ["OAKGPU_SEARCH_THREADS"] = sys.argv[4].split(",")[k % len(sys.argv[4].split(","))]
     t0 = time.perf_counter()
     out = tree_search(ctx, b[0], d[0], int(r[0]), iterations=it, batch=batch, evaluator=net, seed=k)
     dt = time.perf_counter() - t0
