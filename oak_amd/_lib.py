@@ -19,7 +19,7 @@ SYMBOLS = [
     "oakgpu_heap_root_stats", "oakgpu_heap_child_stats", "oakgpu_search_heap", "oakgpu_search_agent_heap", "oakgpu_heap_check_shards", "oakgpu_heap_selftest",
     "oakgpu_tree_step_dev", "oakgpu_search", "oakgpu_search_many", "oakgpu_search_agent", "oakgpu_agent_networks_clear", "oakgpu_bandit_replay", "oakgpu_bandit_select_run", "oakgpu_solve_matrix",
     "oakgpu_segment_mean_dev", "oakgpu_comm_unique_id", "oakgpu_comm_create", "oakgpu_comm_destroy", "oakgpu_all_gather_dev",
-    "oakgpu_root_steps_create", "oakgpu_root_steps_destroy", "oakgpu_root_steps_launch_dev",
+    "oakgpu_root_steps_create", "oakgpu_root_steps_destroy", "oakgpu_root_steps_launch_dev", "oakgpu_root_steps_capacity", "oakgpu_root_steps_reserve",
     "oakgpu_endless_battle_check", "oakgpu_frames_size", "oakgpu_frames_write", "oakgpu_frames_read", "oakgpu_selfplay_game", "oakgpu_selfplay_games", "oakgpu_poke_engine_eval_dev", "oakgpu_poke_engine_eval",
 ]
 
@@ -138,6 +138,8 @@ def load():
     lib.oakgpu_root_steps_destroy.argtypes = [vp]
     lib.oakgpu_root_steps_destroy.restype = None
     lib.oakgpu_root_steps_launch_dev.argtypes = [vp, vp, vp, vp, vp, C.c_int, vp]
+    lib.oakgpu_root_steps_capacity.argtypes = [vp, C.POINTER(u32)]
+    lib.oakgpu_root_steps_reserve.argtypes = [vp, u64]
     lib.oakgpu_comm_unique_id.argtypes = [vp]
     lib.oakgpu_comm_create.argtypes = [vp, vp, i32, i32, C.POINTER(vp)]
     lib.oakgpu_comm_destroy.argtypes = [vp]

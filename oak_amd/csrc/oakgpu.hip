@@ -2245,6 +2245,41 @@ void oakgpu_root_steps_destroy(oakgpu_root_steps *rs) {
   delete rs;
 }
 
+// Grow the carry lists to hold at least `playouts` carried playouts (never shrinks).  Synchronises the context's stream; the playouts
+// in flight keep their places (each shard's segment is copied to its new base).  The default capacity (1 + 256 / slice steps' worth)
+// is 3-4x what random OU roots need; roots whose playouts mostly run into the step cap (stalemates) need up to
+// ceil(max_steps / slice) - 1 steps' worth -- a caller that sees `carried` approach the capacity reserves more BEFORE the next launch.
+int oakgpu_root_steps_reserve(oakgpu_root_steps *rs, uint64_t playouts) {
+  if (!rs) return bad("oakgpu_root_steps_reserve: null argument");
+  oakgpu_ctx *c = rs->ctx;
+  HIPCHK(hipSetDevice(c->device));
+  uint64_t want = (playouts + oak::ROOT_SHARDS - 1) / oak::ROOT_SHARDS * oak::ROOT_SHARDS;
+  if (want <= rs->cap) return 0;
+  if (want >= 0xFFFFFFF0ull) return bad("oakgpu_root_steps_reserve: more than 2^32 carried playouts");
+  HIPCHK(hipStreamSynchronize(c->stream));
+  constexpr size_t LINES8 = (size_t)oak::ROOT_SHARDS * oak::CTL_STRIDE;
+  uint32_t counts[oak::ROOT_SHARDS];
+  for (int sh = 0; sh < oak::ROOT_SHARDS; ++sh) HIPCHK(hipMemcpy(&counts[sh], rs->ctl + rs->cur * LINES8 + (size_t)sh * oak::CTL_STRIDE, 4, hipMemcpyDeviceToHost));
+  const size_t old_seg = rs->cap / oak::ROOT_SHARDS, new_seg = want / oak::ROOT_SHARDS, rec = (size_t)oak::CARRY_VEC * 16;
+  uint4 *fresh[2] = {nullptr, nullptr};
+  for (int k = 0; k < 2; ++k) {
+    hipError_t e = hipMalloc((void **)&fresh[k], (size_t)want * rec);
+    if (e != hipSuccess) { if (fresh[0]) (void)hipFree(fresh[0]); return fail(e, "oakgpu_root_steps_reserve"); }
+  }
+  for (int sh = 0; sh < oak::ROOT_SHARDS; ++sh) { // the list the next launch reads; the other one is scratch
+    const size_t n = counts[sh] < old_seg ? counts[sh] : old_seg;
+    if (n) HIPCHK(hipMemcpy((uint8_t *)fresh[rs->cur] + (size_t)sh * new_seg * rec, (const uint8_t *)rs->state[rs->cur] + (size_t)sh * old_seg * rec, n * rec, hipMemcpyDeviceToDevice));
+  }
+  for (int k = 0; k < 2; ++k) { (void)hipFree(rs->state[k]); rs->state[k] = fresh[k]; }
+  rs->cap = (uint32_t)want;
+  return 0;
+}
+int oakgpu_root_steps_capacity(const oakgpu_root_steps *rs, uint32_t *capacity) {
+  if (!rs || !capacity) return bad("oakgpu_root_steps_capacity: null argument");
+  *capacity = rs->cap;
+  return 0;
+}
+
 int oakgpu_root_steps_launch_dev(oakgpu_root_steps *rs, const uint8_t *root_battles, const uint8_t *root_durations,
                                  const uint8_t *root_results, uint8_t *lane_prng, int fresh, unsigned long long *report) {
   if (!rs || !report) return bad("oakgpu_root_steps_launch_dev: null argument");

@@ -302,6 +302,12 @@ class RootSteps:
         if err:
             raise RuntimeError("oakgpu_root_steps: the carry list overflowed (error word %d): playouts were lost" % err)
         self.turn_steps += int(tail[0])
+        carried = int(tail[1] & np.uint64(0xFFFFFFFF))
+        cap = self.C.c_uint32()
+        self.lib.oakgpu_root_steps_capacity(self.handle, self.C.byref(cap))
+        if carried * 2 > cap.value:      # stalemate-heavy roots: make room before the next launch (keeps the playouts in flight)
+            from . import _lib
+            _lib.check(self.lib.oakgpu_root_steps_reserve(self.handle, 4 * carried))
         return {"count": (acc & np.uint64(0xFFFFFFFF)).astype(np.int64), "sum2": (acc >> np.uint64(32)).astype(np.int64),
                 "turn_steps": int(tail[0]), "carried": int(tail[1] & np.uint64(0xFFFFFFFF))}
 

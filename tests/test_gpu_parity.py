@@ -870,6 +870,28 @@ def test_root_steps_report_a_carry_list_overflow(gpu_ctx):
         assert errs[0] == 0 and errs[-1] == 1 and errs == sorted(errs)      # sticky once set
     finally:
         rs.close()
+    # ... and a caller that reserves room when `carried` approaches the capacity (what oak_amd.dist.RootSteps.finish does) loses nothing:
+    # every playout is credited exactly once, to the step the rule names
+    from oak_amd import _lib
+    lane = _seed_prng(n_roots * reps, 77)
+    ref_lane = lane.copy()
+    cnt, s2, ex = O.root_steps_reference(b, d, r, ref_lane, reps, 6, 256, max_steps=6000, threads=8)
+    rs = _RootSteps(gpu_ctx, b, d, r, lane, reps, 256, max_steps=6000)
+    try:
+        cap = C.c_uint32()
+        k = 0
+        while True:
+            rec = rs.step(fresh=k < 6)
+            assert rec["err"] == 0 and (rec["count"] == cnt[k]).all() and (rec["sum2"] == s2[k]).all() and rec["turn_steps"] == ex[k], k
+            _lib.check(rs.lib.oakgpu_root_steps_capacity(rs.h, C.byref(cap)))
+            if rec["carried"] * 2 > cap.value:
+                _lib.check(rs.lib.oakgpu_root_steps_reserve(rs.h, 4 * rec["carried"]))
+            k += 1
+            if k >= 6 and rec["carried"] == 0:
+                break
+        assert cap.value > 2 * n_roots * reps and int(cnt[:k].sum()) == 6 * n_roots * reps
+    finally:
+        rs.close()
 
 
 def test_root_steps_host_class_in_a_torch_process():
