@@ -393,8 +393,9 @@ void oakgpu_root_steps_destroy(oakgpu_root_steps *rs);
 int oakgpu_root_steps_launch_dev(oakgpu_root_steps *rs, const uint8_t *root_battles, const uint8_t *root_durations,
                                  const uint8_t *root_results, uint8_t *lane_prng, int fresh, unsigned long long *report);
 /* The carry lists hold 1 + 256 / slice steps' worth of playouts by default (3-4x what random OU roots keep in flight).  Roots whose
- * playouts mostly run into the step cap need up to ceil(max_steps / slice) - 1 steps' worth: a caller that sees `carried` approach
- * the capacity reserves more BEFORE its next launch (synchronises the stream, keeps the playouts in flight).  An overflow is never
+ * playouts mostly run into the step cap need up to ceil(max_steps / slice) - 1 steps' worth: a caller whose capacity is below
+ * 2 x (carried + n_roots x reps) -- what the next launch may carry, doubled for the shards' imbalance -- reserves more BEFORE that launch
+ * (synchronises the stream, keeps the playouts in flight; oak_amd.dist.RootSteps does).  An overflow is never
  * silent either way (sticky error word in the report). */
 int oakgpu_root_steps_capacity(const oakgpu_root_steps *rs, uint32_t *capacity);
 int oakgpu_root_steps_reserve(oakgpu_root_steps *rs, uint64_t playouts);

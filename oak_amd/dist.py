@@ -305,9 +305,10 @@ class RootSteps:
         carried = int(tail[1] & np.uint64(0xFFFFFFFF))
         cap = self.C.c_uint32()
         self.lib.oakgpu_root_steps_capacity(self.handle, self.C.byref(cap))
-        if carried * 2 > cap.value:      # stalemate-heavy roots: make room before the next launch (keeps the playouts in flight)
+        need = 2 * (carried + self.roots * self.reps)      # the next launch can carry what is in flight + a whole step's worth; x 2 for the shards' imbalance
+        if need > cap.value:             # stalemate-heavy roots: make room before the next launch (keeps the playouts in flight)
             from . import _lib
-            _lib.check(self.lib.oakgpu_root_steps_reserve(self.handle, 4 * carried))
+            _lib.check(self.lib.oakgpu_root_steps_reserve(self.handle, 2 * need))
         return {"count": (acc & np.uint64(0xFFFFFFFF)).astype(np.int64), "sum2": (acc >> np.uint64(32)).astype(np.int64),
                 "turn_steps": int(tail[0]), "carried": int(tail[1] & np.uint64(0xFFFFFFFF))}
 
