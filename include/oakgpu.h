@@ -385,7 +385,8 @@ int oakgpu_all_gather_dev(oakgpu_ctx *ctx, oakgpu_comm *comm, const float *send,
  *   report (device, n_roots + 2 u64, written by the launch): [r] = playouts credited to this step for root r: count | (sum of
  * 2 x value) << 32 -- integers, so independent of the order playouts finish in; [n_roots] = turn-steps this launch executed;
  * [n_roots + 1] = playouts carried into the next step | error word << 32 (bit 0: the carry list overflowed -- playouts were
- * lost; sticky).  fresh = 0 launches a DRAIN step: no new playouts, the carried ones advance one more slice.
+ * lost; sticky).  fresh = 0 launches a DRAIN step: no new playouts, the carried ones advance one more slice (root_battles must still
+ * be the roots' battles, unchanged since the playouts started: a carried playout reads its Pokemon's immutable data from there).
  * Everything is asynchronous on the context's stream; consecutive launches need no host round trip. */
 typedef struct oakgpu_root_steps oakgpu_root_steps;
 int oakgpu_root_steps_create(oakgpu_ctx *ctx, uint32_t n_roots, uint32_t reps, uint32_t slice, uint32_t max_steps, oakgpu_root_steps **out);

@@ -2283,7 +2283,9 @@ int oakgpu_root_steps_capacity(const oakgpu_root_steps *rs, uint32_t *capacity) 
 int oakgpu_root_steps_launch_dev(oakgpu_root_steps *rs, const uint8_t *root_battles, const uint8_t *root_durations,
                                  const uint8_t *root_results, uint8_t *lane_prng, int fresh, unsigned long long *report) {
   if (!rs || !report) return bad("oakgpu_root_steps_launch_dev: null argument");
-  if (fresh && (!root_battles || !root_durations || !root_results || !lane_prng)) return bad("oakgpu_root_steps_launch_dev: null root / stream pointer");
+  // (root_battles also in a drain step: a carried playout reads its Pokemon's immutable data -- stats, move ids, species, types -- from its ROOT's battle)
+  if (!root_battles) return bad("oakgpu_root_steps_launch_dev: null root_battles (carried playouts read their root's immutable data: drain steps need it too)");
+  if (fresh && (!root_durations || !root_results || !lane_prng)) return bad("oakgpu_root_steps_launch_dev: null root / stream pointer");
   oakgpu_ctx *c = rs->ctx;
   HIPCHK(hipSetDevice(c->device));
   const int in = rs->cur, outl = in ^ 1;
