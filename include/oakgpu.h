@@ -387,6 +387,8 @@ int oakgpu_all_gather_dev(oakgpu_ctx *ctx, oakgpu_comm *comm, const float *send,
  * [n_roots + 1] = playouts carried into the next step | error word << 32 (bit 0: the carry list overflowed -- playouts were
  * lost; sticky).  fresh = 0 launches a DRAIN step: no new playouts, the carried ones advance one more slice (root_battles must still
  * be the roots' battles, unchanged since the playouts started: a carried playout reads its Pokemon's immutable data from there).
+ * When the roots themselves change (the games move on to new positions), drain first -- fresh = 0 until `carried` is 0, at most
+ * ceil(max_steps / slice) launches -- or the old roots' stragglers are credited to the new roots' steps.
  * Everything is asynchronous on the context's stream; consecutive launches need no host round trip. */
 typedef struct oakgpu_root_steps oakgpu_root_steps;
 int oakgpu_root_steps_create(oakgpu_ctx *ctx, uint32_t n_roots, uint32_t reps, uint32_t slice, uint32_t max_steps, oakgpu_root_steps **out);
