@@ -55,7 +55,7 @@ def main():
                          "the library's own ncclAllGather call site (oakgpu_all_gather_dev)")
     ap.add_argument("--root-groups", type=int, default=4,
                     help="config4: independent groups a rank cuts its roots into (oak_amd.dist.RootGroups); 1 = one launch per step")
-    ap.add_argument("--root-slice", type=int, default=32,
+    ap.add_argument("--root-slice", type=int, default=16,
                     help="config4: turn-steps a launch advances each playout in flight by (oak_amd.dist.RootSteps: a playout is credited to "
                          "step k + (len - 1) // slice of its root, stragglers travel on a carry list); a power of two; 0 = round 4's grouped "
                          "form (every step waits for its longest playout, --root-groups)")
