@@ -97,12 +97,13 @@ int oakgpu_set_standstill_skip(oakgpu_ctx *ctx, int on);
  * non-zero word as a failed call and clears it, so the error of any launch since the last synchronize is seen, not only the
  * last launch's. */
 int oakgpu_get_queue_counters(oakgpu_ctx *ctx, uint32_t *out64);
-/* Rollout engine (results never depend on it; all three are bit-identical): 2 = register-resident engine, one wave per
- * workgroup, queue refill (default); 1 = LDS-resident engine (first implementation, kept as a second opinion); 3 =
- * register-resident engine in 256-lane workgroups that re-bin their playouts by action class {move, switch / pass,
- * nothing} before each of a turn's two action slots (per-turn branch compaction through LDS), `workgroups_per_cu` of
- * them per CU (2..4, 0 = keep). */
-int oakgpu_set_rollout_engine(oakgpu_ctx *ctx, int engine, int workgroups_per_cu);
+/* Rollout engine (results never depend on it; both are bit-identical): 2 = register-resident engine, one wave per
+ * workgroup, queue refill (default); 1 = LDS-resident engine (first implementation, kept as a second opinion on the
+ * transcription: it is what oakgpu_update* / _choices* / the tree step run, and tests/test_gpu_parity.py holds its
+ * rollouts to the oracle too), one launch per batch.  (Round 2-4's engine 3, 256-lane workgroups that re-binned
+ * their playouts by action class through LDS before each action slot, lost to engine 2 by 8-12 % and was removed in round 5:
+ * DESIGN_HISTORY.md.) */
+int oakgpu_set_rollout_engine(oakgpu_ctx *ctx, int engine);
 int oakgpu_device_count(void);
 
 /* ---- rollout: replaces MCTS::Search::init_stats_and_rollout (search/mcts.h:448-496) and,

@@ -103,7 +103,7 @@ def load():
     lib.oakgpu_set_migration_window.argtypes = [vp, i32]
     lib.oakgpu_set_standstill_skip.argtypes = [vp, i32]
     lib.oakgpu_get_queue_counters.argtypes = [vp, vp]
-    lib.oakgpu_set_rollout_engine.argtypes = [vp, i32, i32]
+    lib.oakgpu_set_rollout_engine.argtypes = [vp, i32]
     lib.oakgpu_rollout_dev.argtypes = [vp, vp, vp, vp, vp, u32, u32, i32, vp, vp, vp, vp, vp]
     lib.oakgpu_rollout.argtypes = [vp, vp, vp, vp, vp, u32, u32, i32, vp, vp, vp, vp, vp]
     lib.oakgpu_rollout_group_dev.argtypes = [vp, C.POINTER(RolloutBatch), u32, u32, i32]

@@ -466,7 +466,7 @@ struct RoundArgs {
   uint8_t *sd;              // scratch: total x 8 durations
   uint8_t *sres;            // scratch: total results
   uint32_t suspend_below;
-  uint32_t *queue;          // this round's queue heads: QUEUE_HEADS counters, QUEUE_HEAD_STRIDE words apart (k_rollout_bins: one head)
+  uint32_t *queue;          // this round's queue heads: QUEUE_HEADS counters, QUEUE_HEAD_STRIDE words apart
   uint32_t lanes;           // lanes of a wave that take playouts (0 / 64: all); a tail round runs a few playouts per wave
   const uint32_t *order;    // round 0, nullable: queue position -> playout (k_queue_order: the likely-long playouts first)
   // long-playout migration (below): control words {tail, head, bulk waves exited, error}, one list entry per donation
@@ -1116,208 +1116,6 @@ __global__ __launch_bounds__(256) void k_root_step_report(const unsigned long lo
   }
 }
 
-// ---- K1 with per-turn ACTION-CLASS COMPACTION across the waves of a workgroup (north_star: "wavefront ballot / prefix-sum
-// for per-turn branch compaction").  In k_rollout_queue every wave runs the move pipeline and the switch code twice per
-// turn with ~30 of its 64 lanes in each (PMC: 17 active lanes per VALU instruction on average).  Here 256 lanes step in
-// lock-step and before EACH of a turn's two action slots the playouts are re-binned by what they are about to do --
-// {move, switch / pass, nothing} -- with wave ballots + a prefix sum over the four waves' counts, and every playout's
-// whole travelling state (both SideR register sets, battle scalars, choice RNG, playout index, party-LDS home: 48 dwords)
-// moves to its new lane through LDS, 12 dwords per round.  Waves then hold one kind of action each: a wave of switches
-// skips the ~1,550 instructions of the move pipeline, a wave of moves the switch code, a wave of finished lanes both.
-// Per-playout RNG order is untouched, so results stay bit-identical to k_rollout_queue and the oracle.  A playout never
-// needs to return to the lane it started on: whichever lane holds it publishes it and refills from the queue; only its
-// party slots stay put in LDS, addressed by the `home` index that travels with it.
-constexpr int BINS_BLK = 256, BINS_NW = 48, BINS_ROUND = 12;
-constexpr int BINS_LDS_BYTES = 24 * BINS_BLK * 4 + TABLE_LDS_PAD + COLD_LDS_BYTES + BINS_ROUND * BINS_BLK * 4 + 64;
-static_assert(4 * 3 * 4 <= 64, "class counters fit the tail of the exchange area");
-template <int WPS, bool ONE_EXCHANGE = false>
-__global__ __launch_bounds__(BINS_BLK, WPS) void k_rollout_bins(GroupArgs g_in, RoundArgs q_in) {
-  extern __shared__ __align__(16) uint8_t smem[];
-  lds_u32 *party = (lds_u32 *)smem;
-  using ER = EngineR<BINS_BLK, false>;
-  Tables T = stage_default_tables((lds_u8 *)smem + ER::PARTY_WORDS * BINS_BLK * 4);
-  lds_u32 *cold = (lds_u32 *)((lds_u8 *)smem + ER::PARTY_WORDS * BINS_BLK * 4 + TABLE_LDS_PAD);
-  lds_u32 *xch = (lds_u32 *)((lds_u8 *)cold + COLD_LDS_BYTES);          // BINS_ROUND x 256 dwords
-  lds_u32 *counts = xch + BINS_ROUND * BINS_BLK;                         // 4 waves x 3 class counts (the fourth is the rest)
-  if (threadIdx.x == 0) {
-    struct { GroupArgs g; RoundArgs q; } c{g_in, q_in};
-    const uint32_t *src = (const uint32_t *)&c;
-#pragma unroll
-    for (uint32_t i = 0; i < offsetof(ColdArgs, starts) / 4; ++i) cold[i] = src[i];
-  }
-  for (uint32_t i = threadIdx.x; i < g_in.count; i += BINS_BLK) cold[offsetof(ColdArgs, starts) / 4 + i] = g_in.table[i].start;
-  __syncthreads();
-  const uint32_t tid = threadIdx.x, wl = tid & 63, wib = tid >> 6;
-  constexpr uint32_t NONE = 0xFFFFFFFFu, DONE = 0xFFFFFFFEu;
-  const uint32_t total = g_in.total, max_steps = g_in.max_steps;
-  const bool prep = g_in.prep;
-  ER e;
-  e.T = T;
-  uint32_t home = tid; // the party-LDS slot of the playout this lane currently holds
-  e.m = party + home;
-  FastPrng g;
-  g.s0 = g.s1 = 0;
-  uint32_t idx = NONE, result = 0, steps = 0;
-#define COLD_Q(field, type) cold_ptr<type>(cold, offsetof(ColdArgs, q) + offsetof(RoundArgs, field))
-  // all 48 travelling dwords of a lane <-> an array (constant indices only: stays in registers)
-  auto pack = [&](uint32_t (&st)[BINS_NW], uint32_t pc, uint32_t qc, uint32_t flags) {
-    int k = 0;
-#define X(f) st[k++] = e.S.f;
-    OAK_FOR_SIDE_FIELDS(X)
-#undef X
-#define X(f) st[k++] = e.F.f;
-    OAK_FOR_SIDE_FIELDS(X)
-#undef X
-    st[k++] = (uint32_t)e.rng; st[k++] = (uint32_t)(e.rng >> 32);
-    st[k++] = e.turn | (e.last_damage << 16);
-    st[k++] = e.lm;
-    st[k++] = (uint32_t)(uintptr_t)e.gin; st[k++] = (uint32_t)((uintptr_t)e.gin >> 32);
-    st[k++] = idx;
-    st[k++] = steps | (result << 24);
-    st[k++] = g.s0; st[k++] = g.s1;
-    st[k++] = pc | (qc << 8) | (flags << 16);
-    st[k++] = home;
-  };
-  auto unpack = [&](const uint32_t (&st)[BINS_NW], uint32_t &pc, uint32_t &qc, uint32_t &flags) {
-    int k = 0;
-#define X(f) e.S.f = st[k++];
-    OAK_FOR_SIDE_FIELDS(X)
-#undef X
-#define X(f) e.F.f = st[k++];
-    OAK_FOR_SIDE_FIELDS(X)
-#undef X
-    e.rng = (uint64_t)st[k] | ((uint64_t)st[k + 1] << 32); k += 2;
-    e.turn = st[k] & 0xFFFF; e.last_damage = st[k] >> 16; ++k;
-    e.lm = st[k++];
-    e.gin = (const uint32_t *)(uintptr_t)((uint64_t)st[k] | ((uint64_t)st[k + 1] << 32)); k += 2;
-    idx = st[k++];
-    steps = st[k] & 0xFFFFFF; result = st[k] >> 24; ++k;
-    g.s0 = st[k++]; g.s1 = st[k++];
-    pc = st[k] & 0xFF; qc = (st[k] >> 8) & 0xFF; flags = st[k] >> 16; ++k;
-    home = st[k++];
-    e.m = party + home;
-  };
-  // re-bin the workgroup's 256 playouts by class 0..3 (classes are a scheduling hint only: any permutation is correct)
-  auto exchange = [&](uint32_t cls, uint32_t &pc, uint32_t &qc, uint32_t &flags) {
-    const uint64_t mA = __ballot(cls == 0), mB = __ballot(cls == 1), mC = __ballot(cls == 2);
-    if (wl == 0) { counts[3 * wib] = (uint32_t)__popcll(mA); counts[3 * wib + 1] = (uint32_t)__popcll(mB); counts[3 * wib + 2] = (uint32_t)__popcll(mC); }
-    __syncthreads();
-    uint32_t totA = 0, totB = 0, totC = 0, preA = 0, preB = 0, preC = 0, preD = 0;
-#pragma unroll
-    for (uint32_t w = 0; w < 4; ++w) {
-      const uint32_t a = counts[3 * w], b = counts[3 * w + 1], cc = counts[3 * w + 2];
-      preA += w < wib ? a : 0; preB += w < wib ? b : 0; preC += w < wib ? cc : 0; preD += w < wib ? 64 - a - b - cc : 0;
-      totA += a; totB += b; totC += cc;
-    }
-    const uint64_t below = (1ull << wl) - 1, mD = ~(mA | mB | mC);
-    const uint32_t dest = cls == 0 ? preA + (uint32_t)__popcll(mA & below)
-                        : cls == 1 ? totA + preB + (uint32_t)__popcll(mB & below)
-                        : cls == 2 ? totA + totB + preC + (uint32_t)__popcll(mC & below)
-                                   : totA + totB + totC + preD + (uint32_t)__popcll(mD & below);
-    uint32_t st[BINS_NW];
-    pack(st, pc, qc, flags);
-#pragma unroll
-    for (int r = 0; r < BINS_NW / BINS_ROUND; ++r) {
-#pragma unroll
-      for (int k = 0; k < BINS_ROUND; ++k) xch[k * BINS_BLK + dest] = st[r * BINS_ROUND + k];
-      __syncthreads();
-#pragma unroll
-      for (int k = 0; k < BINS_ROUND; ++k) st[r * BINS_ROUND + k] = xch[k * BINS_BLK + tid];
-      __syncthreads();
-    }
-    unpack(st, pc, qc, flags);
-  };
-  for (;;) {
-    // ---- refill from the queue, per wave (as k_rollout_queue) ----
-    const bool need = idx == NONE;
-    const uint64_t mask = __ballot(need);
-    if (mask) {
-      uint32_t base = 0;
-      if (wl == 0) base = atomicAdd(COLD_Q(queue, uint32_t *), (uint32_t)__popcll(mask));
-      base = __shfl(base, 0, 64);
-      if (need) {
-        const uint32_t my = base + (uint32_t)__popcll(mask & ((1ull << wl) - 1));
-        if (my < total) {
-          idx = my;
-          const BatchDesc *bd = find_batch(cold, idx);
-          const uint32_t k = idx - bd->start;
-          const uint32_t *dsrc = (const uint32_t *)bd->durations + 2 * (size_t)k;
-          const uint32_t *psrc = (const uint32_t *)bd->prng + 2 * (size_t)k;
-          g.s0 = psrc[0];
-          g.s1 = psrc[1];
-          e.load_battle_global(bd->battles + (size_t)k * 384, dsrc[0], dsrc[1]);
-          if (prep) { // mcts.h:254-259
-            const uint32_t hi = g.next32(), lo = g.next32();
-            e.rng = ((uint64_t)hi << 32) | lo;
-            e.randomize_hidden();
-          }
-          result = bd->results_in[k];
-          steps = 0;
-        } else idx = DONE;
-      }
-    }
-    if (!__syncthreads_or(idx != DONE)) break; // every lane of the workgroup has drained the queue and retired its playout
-    // ---- one turn: prologue, slot 1, slot 2, epilogue; the playouts are re-binned before each slot ----
-    const bool playing = idx != DONE && (result & 15) == 0 && steps < max_steps;
-    uint32_t pc = 0, qc = 0, r = 0;
-    if (playing) {
-      const uint32_t hi = g.next32(), lo = g.next32(); // uniform_64 = hi << 32 | lo
-      const bool s_p1 = ER::absp(e.S) == 0;
-      const uint32_t req1 = (result >> 4) & 3, req2 = (result >> 6) & 3;
-      const typename ER::Legal LS = e.legal(e.S, s_p1 ? req1 : req2), LF = e.legal(e.F, s_p1 ? req2 : req1);
-      const uint32_t cS = e.nth_choice(LS, e.draw_index(s_p1, hi, lo, LS.n));
-      const uint32_t cF = e.nth_choice(LF, e.draw_index(!s_p1, hi, lo, LF.n));
-      r = e.turn_prologue(cS, cF, pc, qc);
-    }
-    // flags: bit 0 playing this turn, bit 1 an action is pending in the coming slot, bits 8-15 the turn's result so far
-    uint32_t flags = (playing ? 1u : 0u) | ((playing && r == 0) ? 2u : 0u) | (r << 8);
-    if constexpr (ONE_EXCHANGE) { // bin once per turn by the PAIR of pending actions: {move first, switch then move, switches only, nothing}
-      const bool act = (flags & 2) != 0;
-      exchange(!act ? 3u : (pc & 3) == C_MOVE ? 0u : (qc & 3) == C_MOVE ? 1u : 2u, pc, qc, flags);
-    }
-#pragma unroll 1
-    for (int slot = 0; slot < 2; ++slot) {
-      if constexpr (!ONE_EXCHANGE) {
-        const bool act = (flags & 2) != 0;
-        exchange(!act ? 3u : (pc & 3) == C_MOVE ? 0u : 1u, pc, qc, flags);
-      }
-      if (flags & 2) {
-        r = (pc & 3) == C_MOVE ? e.act_move(pc) : e.act_cheap(pc);
-        const bool last = r != 0 || (qc & 3) == C_PASS;
-        e.next_actor();
-        const uint32_t t = pc; pc = qc; qc = t;
-        flags = (flags & 1u) | ((last || slot == 1) ? 0u : 2u) | (r << 8);
-      }
-    }
-    if (flags & 1) {
-      r = flags >> 8;
-      result = r ? r : e.turn_epilogue();
-      ++steps;
-    }
-    // ---- retire finished playouts from whichever lane holds them ----
-    if (idx != DONE && idx != NONE && ((result & 15) != 0 || steps >= max_steps)) {
-      e.normalize();
-      const BatchDesc *bd = find_batch(cold, idx);
-      const uint32_t k = idx - bd->start;
-      bd->results_out[k] = (uint8_t)result;
-      bd->steps_out[k] = steps;
-      const uint32_t t = result & 15;
-      bd->values_out[k] = t == R_WIN ? 1.0f : t == R_LOSE ? 0.0f : 0.5f;
-      uint32_t *pdst = (uint32_t *)bd->prng + 2 * (size_t)k;
-      pdst[0] = g.s0;
-      pdst[1] = g.s1;
-      if (bd->durations_out) {
-        uint32_t *ddst = (uint32_t *)bd->durations_out + 2 * (size_t)k;
-        ddst[0] = e.S.dur;
-        ddst[1] = e.F.dur;
-      }
-      if (bd->battles_out) e.store_battle_global(bd->battles_out + (size_t)k * 384);
-      idx = NONE;
-    }
-  }
-#undef COLD_Q
-}
-
 // ---- batched single update -------------------------------------------------------------------
 __global__ __launch_bounds__(BLOCK) void k_update(uint8_t *battles, const uint8_t *c1, const uint8_t *c2,
                                                   uint8_t *durations, uint8_t *actions, const uint8_t *overrides,
@@ -1620,11 +1418,8 @@ struct oakgpu_ctx {
   bool own_stream;
   uint8_t *d_legal, *d_pools, *d_sizes;
   int n_legal;
-  int rollout_block;  // threads per workgroup of the rollout kernel (64 or 256)
-  int rollout_engine; // 2 = register-resident (default), 1 = LDS-resident, 3 = register-resident with per-turn action-class compaction
-  int bins_wps;       // engine 3: workgroups per CU (= waves per SIMD)
+  int rollout_engine; // 2 = register-resident (default), 1 = LDS-resident (a second implementation of the same engine: A/B)
   int playouts_per_lane; // > 1: persistent grid of n / this lanes with queue refill (k_rollout_queue)
-  int waves_per_simd;    // register budget of the queue kernel: 2, 3 or 4 waves per SIMD
   uint32_t *d_queue;      // 64 counters: suspended-playout counts of the regrouping rounds, queue-order counters, migration control block
   uint32_t *d_heads;      // the queue kernel's heads: MAX_ROUNDS rounds x 8 heads, each on a 256-byte line of its own
   int rounds;             // regrouping rounds of the queue kernel (1 = none)
@@ -1731,19 +1526,11 @@ int oakgpu_device_count(void) {
 }
 
 static int set_lds_limits() {
-  HIPCHK(hipFuncSetAttribute((const void *)oak::k_rollout<256>, hipFuncAttributeMaxDynamicSharedMemorySize, oak::ENGINE_LDS_BYTES));
   HIPCHK(hipFuncSetAttribute((const void *)oak::k_rollout<64>, hipFuncAttributeMaxDynamicSharedMemorySize, oak::STATE_WORDS * 64 * 4 + oak::TABLE_LDS_PAD));
-  HIPCHK(hipFuncSetAttribute((const void *)oak::k_rollout_regs<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 24 * 128 * 4 + oak::TABLE_LDS_PAD));
   HIPCHK(hipFuncSetAttribute((const void *)oak::k_rollout_regs<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 24 * 64 * 4 + oak::TABLE_LDS_PAD));
   HIPCHK(hipFuncSetAttribute((const void *)oak::k_rollout_staged, hipFuncAttributeMaxDynamicSharedMemorySize, oak::STAGED_LDS_BYTES));
   HIPCHK(hipFuncSetAttribute((const void *)oak::k_rollout_draws<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 24 * 64 * 4 + oak::TABLE_LDS_PAD));
-  HIPCHK(hipFuncSetAttribute((const void *)oak::k_rollout_bins<2>, hipFuncAttributeMaxDynamicSharedMemorySize, oak::BINS_LDS_BYTES));
-  HIPCHK(hipFuncSetAttribute((const void *)oak::k_rollout_bins<3>, hipFuncAttributeMaxDynamicSharedMemorySize, oak::BINS_LDS_BYTES));
-  HIPCHK(hipFuncSetAttribute((const void *)oak::k_rollout_bins<4>, hipFuncAttributeMaxDynamicSharedMemorySize, oak::BINS_LDS_BYTES));
-  HIPCHK(hipFuncSetAttribute((const void *)(oak::k_rollout_bins<3, true>), hipFuncAttributeMaxDynamicSharedMemorySize, oak::BINS_LDS_BYTES));
-#define OAK_LIM_Q(W) HIPCHK(hipFuncSetAttribute((const void *)oak::k_rollout_queue<64, W>, hipFuncAttributeMaxDynamicSharedMemorySize, 24 * 64 * 4 + oak::TABLE_LDS_PAD + oak::COLD_LDS_BYTES))
-  OAK_LIM_Q(2); OAK_LIM_Q(3); OAK_LIM_Q(4);
-#undef OAK_LIM_Q
+  HIPCHK(hipFuncSetAttribute((const void *)oak::k_rollout_queue<64, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 24 * 64 * 4 + oak::TABLE_LDS_PAD + oak::COLD_LDS_BYTES));
   HIPCHK(hipFuncSetAttribute((const void *)oak::k_update, hipFuncAttributeMaxDynamicSharedMemorySize, oak::ENGINE_LDS_BYTES));
   HIPCHK(hipFuncSetAttribute((const void *)oak::k_choices, hipFuncAttributeMaxDynamicSharedMemorySize, oak::ENGINE_LDS_BYTES));
   HIPCHK(hipFuncSetAttribute((const void *)oak::k_tree_step, hipFuncAttributeMaxDynamicSharedMemorySize, oak::ENGINE_LDS_BYTES));
@@ -1785,8 +1572,6 @@ int oakgpu_create(oakgpu_ctx **out, int device) {
   c->own_stream = true;
   c->d_legal = c->d_pools = c->d_sizes = nullptr;
   c->n_legal = 0;
-  c->rollout_block = 64; // register engine: 64 (default: single-wave workgroups spread evenly over SIMDs) or 128; LDS engine: 64 or 256
-  if (const char *env = getenv("OAKGPU_ROLLOUT_BLOCK")) c->rollout_block = atoi(env);
   c->playouts_per_lane = 2;
   if (const char *env = getenv("OAKGPU_PLAYOUTS_PER_LANE")) c->playouts_per_lane = atoi(env) > 0 ? atoi(env) : 1;
   c->d_queue = nullptr;
@@ -1837,12 +1622,8 @@ int oakgpu_create(oakgpu_ctx **out, int device) {
   if (const char *env = getenv("OAKGPU_ROUNDS")) c->rounds = atoi(env) < 1 ? 1 : atoi(env) > 8 ? 8 : atoi(env);
   if (const char *env = getenv("OAKGPU_SUSPEND_BELOW")) c->suspend_below = atoi(env) < 0 ? 0 : atoi(env) > 64 ? 64 : atoi(env);
   if (const char *env = getenv("OAKGPU_ROUND_SHRINK")) c->round_shrink = atoi(env) < 1 ? 1 : atoi(env);
-  c->waves_per_simd = 4; // measured best on MI355X: the staged run_move fits 128 VGPRs without scratch
-  if (const char *env = getenv("OAKGPU_WAVES_PER_SIMD")) c->waves_per_simd = atoi(env);
   c->rollout_engine = 2;
-  if (const char *env = getenv("OAKGPU_ROLLOUT_ENGINE")) c->rollout_engine = atoi(env) == 1 ? 1 : atoi(env) == 3 ? 3 : 2;
-  c->bins_wps = 3;
-  if (const char *env = getenv("OAKGPU_BINS_WPS")) c->bins_wps = atoi(env) < 2 ? 2 : atoi(env) > 4 ? 4 : atoi(env);
+  if (const char *env = getenv("OAKGPU_ROLLOUT_ENGINE")) c->rollout_engine = atoi(env) == 1 ? 1 : 2;
   hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
   if (e != hipSuccess) { delete c; return fail(e, "hipStreamCreate"); }
   *out = c;
@@ -1887,10 +1668,9 @@ int oakgpu_set_playouts_per_lane(oakgpu_ctx *c, int k) {
   return 0;
 }
 
-int oakgpu_set_rollout_engine(oakgpu_ctx *c, int engine, int workgroups_per_cu) {
-  if (!c || engine < 1 || engine > 3) return bad("oakgpu_set_rollout_engine: engine must be 1, 2 or 3");
+int oakgpu_set_rollout_engine(oakgpu_ctx *c, int engine) {
+  if (!c || engine < 1 || engine > 2) return bad("oakgpu_set_rollout_engine: engine must be 1 (LDS-resident) or 2 (register-resident)");
   c->rollout_engine = engine;
-  if (workgroups_per_cu) c->bins_wps = workgroups_per_cu < 2 ? 2 : workgroups_per_cu > 4 ? 4 : workgroups_per_cu;
   return 0;
 }
 
@@ -2031,28 +1811,11 @@ static int launch_group(oakgpu_ctx *c, const oak::BatchDesc *descs, uint32_t cou
   HIPCHK(hipEventRecord(c->table_ev[slot], c->stream));
   HIPCHK(hipMemsetAsync(c->d_queue, 0, 252, c->stream)); // (word 63 is the sticky migration error word: never cleared here)
   HIPCHK(hipMemsetAsync(c->d_heads, 0, HEADS_BYTES, c->stream));
-  if (c->rollout_engine == 3 && max_steps < (1u << 24)) { // per-turn action-class compaction (k_rollout_bins): 256-lane workgroups
-    const int wps = c->bins_wps;
-    uint32_t blocks = ((total + oak::BINS_BLK - 1) / oak::BINS_BLK + c->playouts_per_lane - 1) / c->playouts_per_lane;
-    const uint32_t resident_blocks = (uint32_t)c->n_cu * (uint32_t)wps; // wps workgroups of 4 waves per CU = wps waves per SIMD
-    if (blocks > resident_blocks) blocks = resident_blocks;
-    if (blocks < 1) blocks = 1;
-    const oak::GroupArgs gb{dt, count, total, max_steps, prep};
-    oak::RoundArgs qb{};
-    qb.queue = c->d_queue;
-    static const bool one = getenv("OAKGPU_BINS_ONE") && atoi(getenv("OAKGPU_BINS_ONE")); // A/B: one exchange per turn (by action pair)
-    if (one) hipLaunchKernelGGL((oak::k_rollout_bins<3, true>), dim3(blocks), dim3(oak::BINS_BLK), oak::BINS_LDS_BYTES, c->stream, gb, qb);
-    else if (wps >= 4) hipLaunchKernelGGL(oak::k_rollout_bins<4>, dim3(blocks), dim3(oak::BINS_BLK), oak::BINS_LDS_BYTES, c->stream, gb, qb);
-    else if (wps == 3) hipLaunchKernelGGL(oak::k_rollout_bins<3>, dim3(blocks), dim3(oak::BINS_BLK), oak::BINS_LDS_BYTES, c->stream, gb, qb);
-    else hipLaunchKernelGGL(oak::k_rollout_bins<2>, dim3(blocks), dim3(oak::BINS_BLK), oak::BINS_LDS_BYTES, c->stream, gb, qb);
-    HIPCHK(hipGetLastError());
-    return 0;
-  }
   // grid: at least `playouts_per_lane` playouts per lane, and never more waves than the device keeps resident
   const uint32_t n64 = (total + 63) / 64;
   uint32_t waves = (n64 + c->playouts_per_lane - 1) / c->playouts_per_lane;
   if (waves < 1) waves = 1;
-  const uint32_t resident = (uint32_t)c->n_cu * 4u * (uint32_t)(c->waves_per_simd >= 4 ? 4 : c->waves_per_simd == 3 ? 3 : 2);
+  const uint32_t resident = (uint32_t)c->n_cu * 4u * 4u; // four waves per SIMD (k_rollout_queue<64, 4>: 128 VGPRs, measured best; 2 and 3 were removed in round 5)
   bool saturated = waves >= resident;
   if (saturated) waves = resident;
   // A launch that leaves wave slots empty uses them: the same playouts in flight on MORE waves, each taking only a few at a
@@ -2124,9 +1887,7 @@ static int launch_group(oakgpu_ctx *c, const oak::BatchDesc *descs, uint32_t cou
     q.suspend_below = r + 1 < rounds ? (uint32_t)(tail_pack ? c->tail_below : c->suspend_below) : 0u;
     q.queue = c->d_heads + (size_t)r * oak::QUEUE_HEADS * oak::QUEUE_HEAD_STRIDE;
     q.lanes = (tail_pack && r > 0) ? (uint32_t)c->tail_lanes : (r == 0 ? spread : 0u);
-#define OAK_LAUNCH_Q(W) hipLaunchKernelGGL((oak::k_rollout_queue<64, W>), dim3(waves), dim3(64), lq, c->stream, g, q)
-    if (c->waves_per_simd >= 4) OAK_LAUNCH_Q(4); else if (c->waves_per_simd == 3) OAK_LAUNCH_Q(3); else OAK_LAUNCH_Q(2);
-#undef OAK_LAUNCH_Q
+    hipLaunchKernelGGL((oak::k_rollout_queue<64, 4>), dim3(waves), dim3(64), lq, c->stream, g, q);
     waves = tail_pack ? (uint32_t)(c->tail_waves > 0 ? c->tail_waves : c->n_cu) : (waves + c->round_shrink - 1) / c->round_shrink;
     if (waves < 1) waves = 1;
   }
@@ -2138,16 +1899,13 @@ static int launch_single(oakgpu_ctx *c, const oak::RolloutArgs &a) { // one lane
   const uint32_t n = a.n;
   const size_t lds64 = oak::STATE_WORDS * 64 * 4 + oak::TABLE_LDS_PAD;
   if (c->rollout_engine == 1) { // LDS-resident engine (gen1_device.hpp), kept for A/B and as a second implementation
-    if (c->rollout_block <= 64) hipLaunchKernelGGL(oak::k_rollout<64>, dim3((n + 63) / 64), dim3(64), lds64, c->stream, a);
-    else hipLaunchKernelGGL(oak::k_rollout<256>, dim3(grid_for(n)), dim3(256), oak::ENGINE_LDS_BYTES, c->stream, a);
+    hipLaunchKernelGGL(oak::k_rollout<64>, dim3((n + 63) / 64), dim3(64), lds64, c->stream, a);
   } else {                      // register-resident engine (gen1_regs.hpp)
     static const bool no_staged = getenv("OAKGPU_NO_STAGED") != nullptr; // (A/B)
     if (a.max_steps <= 16 && !no_staged && ((uintptr_t)a.battles & 15) == 0 && (!a.battles_out || ((uintptr_t)a.battles_out & 15) == 0))
       hipLaunchKernelGGL(oak::k_rollout_staged, dim3((n + 63) / 64), dim3(64), oak::STAGED_LDS_BYTES, c->stream, a);
-    else if (c->rollout_block == 64)
-      hipLaunchKernelGGL(oak::k_rollout_regs<64>, dim3((n + 63) / 64), dim3(64), 24 * 64 * 4 + oak::TABLE_LDS_PAD, c->stream, a);
     else
-      hipLaunchKernelGGL(oak::k_rollout_regs<128>, dim3((n + 127) / 128), dim3(128), 24 * 128 * 4 + oak::TABLE_LDS_PAD, c->stream, a);
+      hipLaunchKernelGGL(oak::k_rollout_regs<64>, dim3((n + 63) / 64), dim3(64), 24 * 64 * 4 + oak::TABLE_LDS_PAD, c->stream, a);
   }
   HIPCHK(hipGetLastError());
   return 0;

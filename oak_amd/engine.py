@@ -87,9 +87,9 @@ class Context:
         _lib.check(self.lib.oakgpu_get_queue_counters(self.handle, out.ctypes.data_as(C.c_void_p)))
         return out
 
-    def set_rollout_engine(self, engine=2, workgroups_per_cu=0):
-        """2: register engine + queue (default); 1: LDS engine; 3: register engine with per-turn action-class compaction."""
-        _lib.check(self.lib.oakgpu_set_rollout_engine(self.handle, int(engine), int(workgroups_per_cu)))
+    def set_rollout_engine(self, engine=2):
+        """2: register-resident engine + queue (default); 1: LDS-resident engine, one launch per batch (the second implementation)."""
+        _lib.check(self.lib.oakgpu_set_rollout_engine(self.handle, int(engine)))
 
     def stream_ptr(self):
         """hipStream_t of this context (wrap with torch.cuda.ExternalStream to share it with torch)."""

@@ -616,14 +616,13 @@ def test_segment_mean_and_direct_rccl_all_gather(gpu_ctx):
     hip.hipFree(dr)
 
 
-def test_action_class_compaction_engine_is_bit_identical(gpu_ctx):
-    """Engine 3 (k_rollout_bins: 256-lane workgroups that re-bin their playouts by action class before each action slot,
-    the whole playout state travelling between lanes through LDS) against the oracle: every output byte, with and without
-    root prep, capped, ragged, and as a group launch."""
+def test_lds_resident_engine_rollouts_are_bit_identical(gpu_ctx):
+    """Engine 1 (k_rollout<64>: gen1_device.hpp's LDS-resident engine, written first and kept as a second implementation
+    of the same turn resolution) against the oracle: every output byte, with and without root prep, capped, ragged, and as
+    a group launch.  (The register-resident engine is what every other rollout test runs.)"""
     try:
-        gpu_ctx.set_rollout_engine(3, 3)
-        for n, ppl, max_steps, seed0 in ((3000, 2, 1000, 0xB1A50000), (700, 1, 23, 0xB1A51000), (9000, 5, 1000, 0xB1A52000), (1, 2, 1000, 0xB1A53000)):
-            gpu_ctx.set_playouts_per_lane(ppl)
+        gpu_ctx.set_rollout_engine(1)
+        for n, max_steps, seed0 in ((3000, 1000, 0xB1A50000), (700, 23, 0xB1A51000), (9000, 1000, 0xB1A52000), (1, 1000, 0xB1A53000)):
             b, d, p, r = O.make_random_ou_batch(n, seed0=seed0)
             for prep in (False, True):
                 got = gpu_ctx.rollout(b, d, r, p, max_steps=max_steps, prep=prep, return_state=True)
@@ -633,16 +632,16 @@ def test_action_class_compaction_engine_is_bit_identical(gpu_ctx):
                 bad = np.nonzero((got["battles"] != ob).any(axis=1))[0]
                 assert bad.size == 0, (n, prep, int(bad[0]))
                 assert (got["durations"] == od).all() and (got["prng"] == op).all()
-        gpu_ctx.set_playouts_per_lane(3)
         batches = [O.make_random_ou_batch(n, seed0=0xB1A60000 + 1000 * k) for k, n in enumerate((1200, 77, 2500))]
         got = gpu_ctx.rollout_group([(b, d, r, p) for b, d, p, r in batches], return_state=True)
         for (b, d, p, r), g in zip(batches, got):
             ob, od, op = b.copy(), d.copy(), p.copy()
             oout, osteps = O.rollout_batch(ob, od, r, op, max_steps=1000, threads=8)
             assert (g["steps"] == osteps).all() and (g["results"] == oout).all() and (g["battles"] == ob).all() and (g["prng"] == op).all()
+        with pytest.raises(RuntimeError, match="engine must be 1"):
+            gpu_ctx.set_rollout_engine(3)
     finally:
         gpu_ctx.set_rollout_engine(2)
-        gpu_ctx.set_playouts_per_lane(2)
 
 
 def test_group_launch_limits(gpu_ctx):

@@ -1,6 +1,6 @@
 """Manual GPU tool: large randomized GPU-vs-oracle parity soak (bit-exact final states) beyond the test suite's sizes.
 usage: parity_soak.py [batches] [playouts per batch] [engine].  Batches alternate between single launches and group
-launches of four (oakgpu_rollout_group), with and without root prep; engine 2 (default) or 3 (action-class compaction).
+launches of four (oakgpu_rollout_group), with and without root prep; engine 2 (register-resident, default) or 1 (LDS-resident).
 Uses the CPU oracle as the checker, like the tests do."""
 import sys
 import time
@@ -16,7 +16,7 @@ batches = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 262144
 ctx = Context(0)
 if len(sys.argv) > 3:
-    ctx.set_rollout_engine(int(sys.argv[3]), 3)
+    ctx.set_rollout_engine(int(sys.argv[3]))
 bad = 0
 total_steps = 0
 t0 = time.time()
