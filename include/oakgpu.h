@@ -490,12 +490,15 @@ void oakgpu_net_free(oakgpu_ctx *ctx, oakgpu_net *net);
 /* MainNet::shape() (main-net.h:32-34): fc0.in, fc0.out, value_fc2.out, p1_policy_fc2.out */
 int oakgpu_net_shape(const oakgpu_net *net, int *in_dim, int *hidden, int *value_hidden, int *policy_hidden);
 /* How the main net's three dense layers are multiplied (results are fp32 either way, held to the same 1e-5 against the
- * oracle): OAKGPU_MAIN_SPLIT (default) = every fp32 value as an exact sum of three bf16 parts, six bf16 MFMAs per fp32
- * multiply-add block, fp32 accumulation (k_mainnet_split: 187 us per 65,536 leaves); OAKGPU_MAIN_FP32 = fp32 MFMA
- * (k_mainnet_wave: 336 us).  The environment variable OAKGPU_MAIN_NET=fp32 makes the latter the default of networks loaded
- * after it is set.  Returns the previous mode, -1 on a bad argument. */
+ * oracle and to 1e-6 against a float64 evaluation): OAKGPU_MAIN_PAIR (default since round 5) = every fp32 value times an exact
+ * power of two (one per layer for the weights, one per batch row for the activations) as the sum of two round-to-nearest fp16
+ * parts, three fp16 MFMAs per multiply-add block, fp32 accumulation (k_mainnet_pair); OAKGPU_MAIN_SPLIT = every fp32 value as
+ * an exact sum of three bf16 parts, six bf16 MFMAs per block (k_mainnet_split: 190-200 us per 65,536 leaves); OAKGPU_MAIN_FP32 =
+ * fp32 MFMA (k_mainnet_wave: 336 us).  The environment variable OAKGPU_MAIN_NET=fp32 / bf16x3 makes one of the latter the
+ * default of networks loaded after it is set.  Returns the previous mode, -1 on a bad argument. */
 #define OAKGPU_MAIN_FP32 0
 #define OAKGPU_MAIN_SPLIT 1
+#define OAKGPU_MAIN_PAIR 2
 int oakgpu_net_set_main_precision(oakgpu_net *net, int mode);
 /* Edges of the bf16-triple form.  (1) A parameter file with a NaN / inf anywhere is REFUSED by oakgpu_net_load* ("non-finite
  * parameter ... in <layer>"); the reference loads it and propagates NaN (nn/affine.h:72-85 is a plain fp32 W x + b).  (2) A
@@ -504,8 +507,13 @@ int oakgpu_net_set_main_precision(oakgpu_net *net, int mode);
  * weight (fc0 / fc1 / value_fc2) above 2^20 in magnitude runs its main net on fp32 MFMA, and a request for OAKGPU_MAIN_SPLIT
  * is not honoured for it (tests/test_gpu_leafnet.py: layers scaled by 2^-100 / 2^-120 / 2^+100, alone and compensated).  The
  * embedding nets' passes multiply as bf16 triples as well; a weight above 2^20 in their second layers or in the main net sends them
- * through the fp32-MFMA form (k_embed_lds) instead.  Returns the mode in effect (-1: null net); *split_allowed (nullable) = 0 for such
- * a network. */
+ * through the fp32-MFMA form (k_embed_lds) instead.  (3) The fp16 pairs are scaled per layer and per batch row, so no absolute
+ * magnitude matters to them; what must hold is that every weight ROW survives the pairing to fp32 accuracy (the sum of what its
+ * pairs miss within 2^-23 of the sum of its magnitudes: a row of tiny weights in a layer with one huge weight elsewhere fails) and
+ * that no non-zero weight COLUMN lies more than 2^14 below the layer's largest weight (a network that compensates tiny weights
+ * with huge inputs is the same function in fp32 but not in a 5-bit exponent) -- a network that fails either runs on the triples, or
+ * on fp32 MFMA by (2).  Returns the mode in effect (-1: null net); *split_allowed
+ * (nullable) = 0 for a network of case (2). */
 int oakgpu_net_main_precision(const oakgpu_net *net, int *split_allowed);
 int oakgpu_leaf_eval_dev(oakgpu_ctx *ctx, oakgpu_net *net, const uint8_t *battles, const uint8_t *durations,
                          uint32_t n, float *values, float *embedding_out);

@@ -43,6 +43,9 @@ struct NetDev {
   // of fc0 (ws_T0, a multiple of 4), the block count both widths are padded to (ws_NB: 1, 2, 4, 8)
   const uint16_t *ws;
   int ws_T0, ws_NB;
+  // k_mainnet_pair: the same stream as scaled fp16 pairs (pair_stream), and 1 / the scale of each of the three layers
+  const uint16_t *wp;
+  float wp_inv[3];
   // policy heads (main-net.h:67-107): fc2 [PHp][H] (rows padded to 32), fc3 [315][PHp] (+ biases)
   const float *q1a, *q1a_b, *q1b, *q1b_b, *q2a, *q2a_b, *q2b, *q2b_b;
   const float *q1a_f, *q2a_f; // fc2 of the two heads as k_policy_rows' A operand (policy_frag_order)
@@ -1882,6 +1885,324 @@ __global__ __launch_bounds__(MN_BLOCK) void k_mainnet_split(MainArgs a) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
+// ---- K3'': the main net on the fp16 matrix pipe, fp32 values carried as scaled fp16 PAIRS (round 5) ------------------------
+// k_mainnet_split pays six bf16 MFMAs per fp32 multiply-add block because a bf16 part holds 8 significant bits.  An fp16 part
+// holds 11, so TWO round-to-nearest parts carry an fp32 value to 2^-24: x s = h + l + e with h = fp16(x s), l = fp16(x s - h) (that
+// remainder is exact in fp32) and |e| <= 2^-12 |l| <= 2^-24 |x s|.  A product is then h.h + h.l + l.h (three MFMAs of the same
+// rate, each product exact in the fp32 accumulator) and drops l.l <= 2^-24 |x w| -- the error class of the triple form at half
+// the matrix work.  What fp16 lacks is RANGE (5 exponent bits), so every operand is multiplied by an exact power of two first:
+//   * weights: one scale per layer, chosen on the host so that the layer's largest weight lands in [2^14, 2^15) (pair_stream);
+//   * activations: one scale PER BATCH ROW (= per lane: the row's values of a layer sit in that lane's registers and its partner
+//     lane's), so that the row's largest value lands in [2^14, 2^15).  For fc1 / value_fc2 the row maximum is read off the
+//     accumulators; for fc0 the row arrives from memory 64 columns at a time, the scale is set from the first chunk and LOWERED
+//     when a later chunk holds a larger value -- the accumulators are then multiplied by the (exact) ratio, like an online softmax.
+// Accumulators are scaled back (two exact power-of-two factors) in front of the bias.  A part below 2^-14 of the scaled unit is an
+// fp16 SUBNORMAL, which both v_cvt_f16_f32 and the fp16 MFMA honour on gfx950 (tools/experiments/mfma_f16_denorm.hip, run on the
+// chip), so a value's absolute error is at most max(2^-24 |x|, 2^-39 x the row's / the layer's largest): the product is accurate
+// normwise like the fp32 multiply-add it replaces whenever a row's sum is not 2^13 times smaller than its largest term --
+// oakgpu_net_load* CHECKS the weight side of that (pair_layer_ok: rows and columns) and keeps a network that fails it on the bf16 triples.
+// Everything else -- orientation, the LDS-DMA ring, the software pipeline -- is k_mainnet_split's; a phase is MPair::G k-steps of
+// NB x 2 KB.
+using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
+#ifndef OAK_MP_G
+#define OAK_MP_G 4
+#endif
+template <int NB> struct MPair {
+  static constexpr int G = NB >= 2 ? OAK_MP_G : 2;                // k-steps per phase: even, divides 4 (a chunk of fc0) and 2 NB (a register layer)
+  static_assert(G % 2 == 0 && 4 % G == 0 && (2 * NB) % G == 0, "k-steps alternate two weight buffers; chunks and layers are whole phases");
+  static constexpr int PHASE_BYTES = G * NB * 2048;               // [k-step][block][h l][lane] x 16 B
+  static constexpr int PT = (PHASE_BYTES + 4095) / 4096;          // 1-KB DMA pieces per wave per phase, at most
+  static constexpr size_t LDS = 2 * (size_t)PHASE_BYTES + 4 * MAXH * 4;
+};
+template <int NB>
+__device__ __forceinline__ void mp_dma_phase(const uint8_t *src, uint8_t *dst, int tid) {
+  using M = MPair<NB>;
+  const int wave = tid >> 6;
+#pragma unroll
+  for (int i = 0; i < M::PT; ++i) {
+    const int piece = (i * MN_BLOCK + wave * 64) * 16; // wave-uniform; PHASE_BYTES is a multiple of 1 KB
+    if (M::PHASE_BYTES % 4096 == 0 || piece < M::PHASE_BYTES)
+      __builtin_amdgcn_global_load_lds((ms_glb_void *)(src + (i * MN_BLOCK + tid) * 16), (ms_lds_void *)(dst + piece), 16, 0, 0);
+  }
+}
+#ifndef OAK_MP_EXP
+#define OAK_MP_EXP 0 // experiments (WRONG results): 1 no DMA after the prologue, 2 no phase barrier, 4 no LDS reads of the weights, 8 no row loads after the first chunk
+#endif
+template <int NB>
+__device__ __forceinline__ void mp_next_phase(MSRing &R, int tid) { // (see ms_next_phase for the written-out wait)
+  using M = MPair<NB>;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (!(OAK_MP_EXP & 2)) __syncthreads();
+  const int done = R.cur;
+  R.cur ^= 1;
+  R.phase = R.phase + 1 == R.n_phases ? 0 : R.phase + 1;
+  const int nx = R.phase + 1 == R.n_phases ? 0 : R.phase + 1;
+  if (!(OAK_MP_EXP & 1)) mp_dma_phase<NB>(R.stream + (size_t)nx * M::PHASE_BYTES, R.lds + done * M::PHASE_BYTES, tid);
+}
+template <int OFF>
+__device__ __forceinline__ void mp_load_a(f16x8 (&A)[2], uint32_t addr) {
+  static_assert(OFF >= 0 && OFF + 1024 < 65536, "ds_read offset field");
+  if (OAK_MP_EXP & 4) { asm volatile("" : "=v"(A[0]), "=v"(A[1]) : "v"(addr)); return; }
+  asm volatile("ds_read_b128 %0, %2 offset:%3\n\tds_read_b128 %1, %2 offset:%4" : "=&v"(A[0]), "=&v"(A[1]) : "v"(addr), "n"(OFF), "n"(OFF + 1024));
+}
+template <int YOUNGER> // wait for a pair with YOUNGER LDS reads (0 or 2) issued behind it
+__device__ __forceinline__ void mp_wait_a(f16x8 (&A)[2]) {
+  if (YOUNGER == 2) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(A[0]), "+v"(A[1]));
+  else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(A[0]), "+v"(A[1]));
+}
+// the power of two that takes m (> 0: callers floor it) into [2^14, 2^15), and the exact ratio of two such scales
+__device__ __forceinline__ float mp_scale_of(float m) { return __uint_as_float((268u - (__float_as_uint(m) >> 23)) << 23); }
+__device__ __forceinline__ float mp_ratio(float to, float from) { // (a ratio below 2^-126 is 0: the sums it would multiply are then zeros or nothing)
+  const int e = 127 + (int)(__float_as_uint(to) >> 23) - (int)(__float_as_uint(from) >> 23);
+  return __uint_as_float((uint32_t)(e > 0 ? e : 0) << 23);
+}
+__device__ __forceinline__ float mp_inverse(float s) { return __uint_as_float((254u - (__float_as_uint(s) >> 23)) << 23); }
+constexpr float MP_FLOOR = 0x1p-110f; // a row of zeros (or of values below this): scale 2^124, every part 0 (or a subnormal's worth)
+// elements [e0, e1) of a k-step's 8 activation values, times the row's scale, as their pairs
+#ifndef OAK_MP_SPLIT
+#define OAK_MP_SPLIT 0 // 0: both parts rounded to nearest; 1 (experiment): the high part by truncation, two values per instruction (v_cvt_pkrtz_f16_f32); 2 (experiment, WRONG results): no split at all
+#endif
+#ifndef OAK_MP_VALU
+#define OAK_MP_VALU 3  // vector instructions the scheduler may place behind each MFMA of a block
+#endif
+__device__ __forceinline__ void mp_split_part(const float (&v)[8], float scale, f16x8 (&B)[2], int e0, int e1) {
+#if OAK_MP_SPLIT == 2
+  if (e0 == 0) { B[0] = __builtin_bit_cast(f16x8, *(const float4 *)&v[0]); B[1] = __builtin_bit_cast(f16x8, *(const float4 *)&v[4]); }
+  (void)scale; (void)e1;
+#elif OAK_MP_SPLIT == 1
+  typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
+#pragma unroll
+  for (int i = 0; i < 8; i += 2)
+    if (i >= e0 && i < e1) { // (e0, e1 even or the whole k-step: NB <= 4 or one call)
+      const float x0 = v[i] * scale, x1 = v[i + 1] * scale;
+      const f16x2 hi = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(x0, x1));
+      B[0][i] = hi[0]; B[0][i + 1] = hi[1];
+      B[1][i] = (_Float16)(x0 - (float)hi[0]);
+      B[1][i + 1] = (_Float16)(x1 - (float)hi[1]);
+    }
+#else
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+    if (i >= e0 && i < e1) {
+      const float x = v[i] * scale;
+      const _Float16 hi = (_Float16)x;
+      B[0][i] = hi;
+      B[1][i] = (_Float16)(x - (float)hi);
+    }
+#endif
+}
+template <int NB, bool SAME_PHASE>
+__device__ __forceinline__ void mp_kstep(f32x16 (&acc)[NB], const f16x8 (&B)[2], const float (&vn)[8], float scale_n, f16x8 (&Bn)[2], f16x8 (&Afirst)[2],
+                                         f16x8 (&Anext)[2], uint32_t base) {
+  f16x8 A[2][2];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+    f16x8 (&W)[2] = nb == 0 ? Afirst : A[nb & 1];
+#define MP_LOAD_NEXT(NBV)                                                                   \
+  if (nb == NBV) {                                                                          \
+    if (NBV + 1 < NB) mp_load_a<(NBV + 1) * 2048>(A[(NBV + 1) & 1], base);                   \
+    else if (SAME_PHASE) mp_load_a<NB * 2048>(Anext, base);                                  \
+  }
+    MP_LOAD_NEXT(0) MP_LOAD_NEXT(1) MP_LOAD_NEXT(2) MP_LOAD_NEXT(3) MP_LOAD_NEXT(4) MP_LOAD_NEXT(5) MP_LOAD_NEXT(6) MP_LOAD_NEXT(7)
+#undef MP_LOAD_NEXT
+    if (nb + 1 < NB || SAME_PHASE) mp_wait_a<2>(W); else mp_wait_a<0>(W);
+    if (OAK_MP_SPLIT == 1 && NB == 8) { if ((nb & 1) == 0) mp_split_part(vn, scale_n, Bn, nb, nb + 2); } // (two values per conversion)
+    else mp_split_part(vn, scale_n, Bn, nb * 8 / NB, (nb + 1) * 8 / NB);
+    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(W[1], B[0], acc[nb], 0, 0, 0); // l . h   (small terms first)
+    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(W[0], B[1], acc[nb], 0, 0, 0); // h . l
+    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(W[0], B[0], acc[nb], 0, 0, 0); // h . h
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, OAK_MP_VALU, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+// the accumulators back to the layer's real values (x 1 / row scale x 1 / layer scale: two exact factors), bias, activation
+template <int NB>
+__device__ __forceinline__ void mp_bias_act(f32x16 (&acc)[NB], float inv_row, float inv_layer, const float *bias, int h, int activation) {
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const float4 b = *(const float4 *)(bias + 32 * nb + 8 * g + 4 * h);
+      acc[nb][4 * g + 0] = act_fn(acc[nb][4 * g + 0] * inv_row * inv_layer + b.x, activation);
+      acc[nb][4 * g + 1] = act_fn(acc[nb][4 * g + 1] * inv_row * inv_layer + b.y, activation);
+      acc[nb][4 * g + 2] = act_fn(acc[nb][4 * g + 2] * inv_row * inv_layer + b.z, activation);
+      acc[nb][4 * g + 3] = act_fn(acc[nb][4 * g + 3] * inv_row * inv_layer + b.w, activation);
+    }
+}
+// a layer whose input is the previous layer's activations in registers; returns the row's scale (the caller scales back)
+template <int NB>
+__device__ __forceinline__ float mp_reg_layer(f32x16 (&acc)[NB], const f32x16 (&in)[NB], MSRing &R, int tid) {
+  using M = MPair<NB>;
+  const int lane16 = (tid & 63) * 16;
+  float m = MP_FLOOR;
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) { m = fmaxf(m, fabsf(in[nb][q])); acc[nb][q] = 0.0f; }
+  m = fmaxf(m, __shfl_xor(m, 32, 64)); // the other half of the row's features
+  const float scale = mp_scale_of(m);
+  f16x8 B[2], Bn[2], A0[2], A1[2]; // A0 / A1: block 0's weights of the even / odd k-steps
+  {
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = in[0][j];
+    mp_split_part(v, scale, B, 0, 8);
+  }
+  mp_load_a<0>(A0, ms_lds_addr(R.lds + R.cur * M::PHASE_BYTES + lane16));
+#pragma unroll
+  for (int t = 0; t < 2 * NB; ++t) {
+    float vn[8];
+    const int tn = t + 1 < 2 * NB ? t + 1 : t;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) vn[j] = in[tn >> 1][8 * (tn & 1) + j];
+    constexpr int G = M::G;
+    const uint32_t base = ms_lds_addr(R.lds + R.cur * M::PHASE_BYTES + (t % G) * NB * 2048 + lane16);
+    const bool last = t % G == G - 1;
+    if ((t & 1) == 0) { if (!last) mp_kstep<NB, true>(acc, B, vn, scale, Bn, A0, A1, base); else mp_kstep<NB, false>(acc, B, vn, scale, Bn, A0, A1, base); }
+    else { if (!last) mp_kstep<NB, true>(acc, B, vn, scale, Bn, A1, A0, base); else mp_kstep<NB, false>(acc, B, vn, scale, Bn, A1, A0, base); }
+    B[0] = Bn[0]; B[1] = Bn[1];
+    if (last) {
+      mp_next_phase<NB>(R, tid);
+      if ((t & 1) == 0) mp_load_a<0>(A1, ms_lds_addr(R.lds + R.cur * M::PHASE_BYTES + lane16));
+      else mp_load_a<0>(A0, ms_lds_addr(R.lds + R.cur * M::PHASE_BYTES + lane16));
+    }
+  }
+  mp_wait_a<0>(A0); // nothing of this layer's reads stays in flight past it (the next layer reads A0 again)
+  return scale;
+}
+
+template <int NB>
+__global__ __launch_bounds__(MN_BLOCK) void k_mainnet_pair(MainArgs a) {
+  extern __shared__ __align__(16) uint8_t lds_b[];
+  using M = MPair<NB>;
+  const NetDev &N = a.net;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+  float *vec = (float *)(lds_b + 2 * M::PHASE_BYTES); // [b0 | b1 | b2 | w3], MAXH each
+  for (int i = tid; i < MAXH; i += MN_BLOCK) {
+    vec[i] = i < N.H ? N.b0[i] : 0.0f; vec[MAXH + i] = i < N.H ? N.b1[i] : 0.0f;
+    vec[2 * MAXH + i] = i < N.VH ? N.b2[i] : 0.0f; vec[3 * MAXH + i] = i < N.VH ? N.w3[i] : 0.0f;
+  }
+  const int T0 = N.ws_T0, K = N.emb_dim;
+  MSRing R{0, 0, (T0 + 4 * NB) / M::G, (const uint8_t *)N.wp, lds_b}; // fc0: T0 k-steps, fc1 and value_fc2: 2 NB each
+  mp_dma_phase<NB>(R.stream, lds_b, tid);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads(); // (also publishes vec)
+  mp_dma_phase<NB>(R.stream + (size_t)M::PHASE_BYTES, lds_b + M::PHASE_BYTES, tid);
+
+  f32x16 X[NB], Y[NB];
+  const uint32_t ngroups = (a.n + 127) / 128;
+  for (uint32_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+    const uint32_t row0 = grp * 128 + wave * 32;
+    const uint32_t n_rows = row0 < a.n ? min(32u, a.n - row0) : 0u;
+    const uint32_t grow = n_rows ? row0 + ((uint32_t)r < n_rows ? (uint32_t)r : n_rows - 1) : a.n - 1;
+    const float *arow = a.emb + (size_t)grow * K;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) X[nb][q] = 0.0f;
+    float4 aC[8], aN[8];
+#define MP_LOAD_ROW(av, c)                                                                                       \
+  _Pragma("unroll") for (int u_ = 0; u_ < 4; ++u_) _Pragma("unroll") for (int qq_ = 0; qq_ < 2; ++qq_) {          \
+    const int col_ = 64 * (c) + 16 * u_ + 8 * h + 4 * qq_;                                                       \
+    av[2 * u_ + qq_] = *(const float4 *)(arow + (col_ < K ? col_ : 0));                                          \
+  }
+    // the largest magnitude of a chunk's 64 columns of this row (both half-waves)
+    auto chunk_max = [](const float4 (&av)[8]) {
+      float m = MP_FLOOR;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) m = fmaxf(fmaxf(m, fmaxf(fabsf(av[q].x), fabsf(av[q].y))), fmaxf(fabsf(av[q].z), fabsf(av[q].w)));
+      return fmaxf(m, __shfl_xor(m, 32, 64));
+    };
+    const int nch = T0 / 4;
+    MS_T0();
+    MP_LOAD_ROW(aC, 0);
+    float scale = mp_scale_of(chunk_max(aC)); // the row's scale so far
+    f16x8 B[2], Bn[2], A0[2], A1[2];
+    {
+      const float v[8] = {aC[0].x, aC[0].y, aC[0].z, aC[0].w, aC[1].x, aC[1].y, aC[1].z, aC[1].w};
+      mp_split_part(v, scale, B, 0, 8);
+    }
+    mp_load_a<0>(A0, ms_lds_addr(R.lds + R.cur * M::PHASE_BYTES + lane * 16));
+#pragma unroll 1
+    for (int c = 0; c < nch; ++c) {
+      const int cn = c + 1 < nch ? c + 1 : c;
+      if (!(OAK_MP_EXP & 8)) { MP_LOAD_ROW(aN, cn); }
+      float scale_n = scale;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float4 n0 = u < 3 ? aC[2 * (u < 3 ? u + 1 : 0)] : aN[0], n1 = u < 3 ? aC[2 * (u < 3 ? u + 1 : 0) + 1] : aN[1];
+        const float vn[8] = {n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, n1.z, n1.w};
+        if (u == 3) scale_n = fminf(scale, mp_scale_of(chunk_max(aN))); // the next chunk may need a smaller scale: its first k-step is split with it
+        const int ph = u % M::G; // (a chunk is one or two whole phases)
+        const uint32_t base = ms_lds_addr(R.lds + R.cur * M::PHASE_BYTES + ph * NB * 2048 + lane * 16);
+        const bool last = ph == M::G - 1;
+        const float sn = u == 3 ? scale_n : scale;
+        if ((u & 1) == 0) { if (!last) mp_kstep<NB, true>(X, B, vn, sn, Bn, A0, A1, base); else mp_kstep<NB, false>(X, B, vn, sn, Bn, A0, A1, base); }
+        else { if (!last) mp_kstep<NB, true>(X, B, vn, sn, Bn, A1, A0, base); else mp_kstep<NB, false>(X, B, vn, sn, Bn, A1, A0, base); }
+        B[0] = Bn[0]; B[1] = Bn[1];
+        if (last) {
+          mp_next_phase<NB>(R, tid);
+          if ((u & 1) == 0) mp_load_a<0>(A1, ms_lds_addr(R.lds + R.cur * M::PHASE_BYTES + lane * 16));
+          else mp_load_a<0>(A0, ms_lds_addr(R.lds + R.cur * M::PHASE_BYTES + lane * 16));
+        }
+      }
+      if (scale_n != scale) { // (per lane, rare: a later chunk raised the row's maximum) the sums so far move to the new scale
+        const float f = mp_ratio(scale_n, scale);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+          for (int q = 0; q < 16; ++q) X[nb][q] *= f;
+        scale = scale_n;
+      }
+#pragma unroll
+      for (int q = 0; q < 8; ++q) aC[q] = aN[q];
+    }
+#undef MP_LOAD_ROW
+    mp_wait_a<0>(A0); // (four k-steps per chunk: the buffer in flight behind the last one is A0)
+    MS_MARK(0);
+    mp_bias_act<NB>(X, mp_inverse(scale), N.wp_inv[0], vec, h, N.activation);
+    MS_MARK(1);
+    // ---- fc1 ----
+    const float s1 = mp_reg_layer<NB>(Y, X, R, tid);
+    MS_MARK(2);
+    mp_bias_act<NB>(Y, mp_inverse(s1), N.wp_inv[1], vec + MAXH, h, N.activation);
+    if (a.h1_out && n_rows && (uint32_t)r < n_rows) { // keep fc1's activations for the policy heads (row-major n x H)
+      float *dst = a.h1_out + (size_t)(row0 + r) * N.H;
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          if (32 * nb + 8 * g + 4 * h < N.H) *(float4 *)(dst + 32 * nb + 8 * g + 4 * h) = make_float4(Y[nb][4 * g], Y[nb][4 * g + 1], Y[nb][4 * g + 2], Y[nb][4 * g + 3]);
+    }
+    // ---- value_fc2, then value_fc3 + sigmoid straight from the accumulators (network.h:14,75) ----
+    MS_MARK(3);
+    const float s2 = mp_reg_layer<NB>(X, Y, R, tid);
+    MS_MARK(4);
+    const float i2 = mp_inverse(s2), il2 = N.wp_inv[2];
+    float part = 0.0f;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float4 b = *(const float4 *)(vec + 2 * MAXH + 32 * nb + 8 * g + 4 * h);
+        const float4 w = *(const float4 *)(vec + 3 * MAXH + 32 * nb + 8 * g + 4 * h);
+        part = fmaf(act_fn(X[nb][4 * g + 0] * i2 * il2 + b.x, N.activation), w.x, part);
+        part = fmaf(act_fn(X[nb][4 * g + 1] * i2 * il2 + b.y, N.activation), w.y, part);
+        part = fmaf(act_fn(X[nb][4 * g + 2] * i2 * il2 + b.z, N.activation), w.z, part);
+        part = fmaf(act_fn(X[nb][4 * g + 3] * i2 * il2 + b.w, N.activation), w.w, part);
+      }
+    part += __shfl_xor(part, 32, 64);
+    if (h == 0 && (uint32_t)r < n_rows) a.values[row0 + r] = 1.0f / (1.0f + expf(-(part + N.b3)));
+    MS_MARK(5);
+    MS_FLUSH();
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // (the ring's last phase must have landed before the wave ends: k_mainnet_split)
+}
+
 // ---- policy heads: value_policy_inference's logits (network.h:102-123, main-net.h:67-107) ----------
 // Encode::Battle::Policy::get_index (encode/battle/policy.h:29-58) on the raw battle bytes
 __device__ __forceinline__ uint32_t policy_index(const uint8_t *side, uint32_t choice) {
@@ -2109,7 +2430,8 @@ struct oakgpu_net {
   std::vector<void *> allocs;
   int in_dim, hidden, value_hidden, policy_hidden; // unpadded, as in the file
   int device;        // the device the weights live on
-  int main_mode;     // which kernel runs the main net: 0 = k_mainnet_wave (fp32 MFMA), 1 = k_mainnet_split (bf16 triples)
+  int main_mode;     // which kernel runs the main net: 0 = k_mainnet_wave (fp32 MFMA), 1 = k_mainnet_split (bf16 triples), 2 = k_mainnet_pair (fp16 pairs)
+  bool pair_safe;    // every main-net layer passes pair_layer_ok (rows keep fp32 accuracy as scaled fp16 pairs, no dwarfed column): k_mainnet_pair may run
   bool split_safe;   // no main-net weight above 2^20 in magnitude: what a flushed low bf16 part loses cannot be amplified back (else fp32 MFMA only)
   bool embed_safe;   // ... and none in the embedding nets' second layers either: the embedding passes' triples are safe (else k_embed_lds: fp32 MFMA)
 };
@@ -2217,6 +2539,81 @@ std::vector<uint16_t> split_stream(const HostAffine &fc0, const HostAffine &fc1,
         }
       }
   return w;
+}
+
+// k_mainnet_pair's weight stream: the same order with TWO parts per weight, (h, l) = the fp16 pair of w x scale, scale = the power
+// of two that takes the layer's largest |w| into [2^14, 2^15) (1 for an all-zero layer): byte (((t * NB + nb) * 2 + part) * 64 +
+// lane) * 16 + 2 j.  inv[layer] = 1 / scale.
+uint16_t f16_bits(_Float16 v) { uint16_t b; memcpy(&b, &v, 2); return b; }
+float layer_pair_scale(const HostAffine &a) {
+  float m = 0.0f;
+  for (float v : a.w) m = std::fmax(m, std::fabs(v));
+  if (!(m > 0.0f) || !std::isfinite(m)) return 1.0f;
+  int e;
+  std::frexp(m, &e); // m = f x 2^e, f in [0.5, 1): m in [2^(e-1), 2^e)
+  e = 15 - e;        // (kept inside 2^+-100: the scale, its inverse and their products with a row's scale stay normal fp32 numbers;
+  return std::ldexp(1.0f, e > 100 ? 100 : e < -100 ? -100 : e); // a layer beyond that fails pair_layer_ok or saturates like fp32 does)
+}
+std::vector<uint16_t> pair_stream(const HostAffine &fc0, const HostAffine &fc1, const HostAffine &v2, uint32_t NB, uint32_t T0, float (&inv)[3]) {
+  const uint32_t steps = T0 + 4 * NB;
+  std::vector<uint16_t> w((size_t)steps * NB * 2 * 64 * 8, 0);
+  const float sc[3] = {layer_pair_scale(fc0), layer_pair_scale(fc1), layer_pair_scale(v2)};
+  for (int l = 0; l < 3; ++l) inv[l] = 1.0f / sc[l];
+  auto put = [&](uint32_t t_flat, const HostAffine &a, float scale, uint32_t nb, uint32_t lane, uint32_t j, uint32_t k) {
+    const uint32_t n = 32 * nb + (lane & 31);
+    if (n >= a.out || k >= a.in) return;
+    const float x = a.w[(size_t)n * a.in + k] * scale;
+    const _Float16 hi = (_Float16)x;
+    const _Float16 lo = (_Float16)(x - (float)hi);
+    const size_t base = ((size_t)t_flat * NB + nb) * 2;
+    w[((base + 0) * 64 + lane) * 8 + j] = f16_bits(hi);
+    w[((base + 1) * 64 + lane) * 8 + j] = f16_bits(lo);
+  };
+  for (uint32_t nb = 0; nb < NB; ++nb)
+    for (uint32_t lane = 0; lane < 64; ++lane)
+      for (uint32_t j = 0; j < 8; ++j) {
+        const uint32_t hb = lane >> 5;
+        for (uint32_t t = 0; t < T0; ++t) put(t, fc0, sc[0], nb, lane, j, 16 * t + 8 * hb + j);
+        for (uint32_t t = 0; t < 2 * NB; ++t) {
+          const uint32_t reg = 8 * (t & 1) + j, k = 32 * (t >> 1) + (reg & 3) + 8 * (reg >> 2) + 4 * hb;
+          put(T0 + t, fc1, sc[1], nb, lane, j, k);
+          put(T0 + 2 * NB + t, v2, sc[2], nb, lane, j, k);
+        }
+      }
+  return w;
+}
+// May this layer run as pairs?  Two checks on its weights, both relative to the layer's own scale:
+//   rows    -- the pair of w x scale misses w by at most 2^-24 |w| while its low part is a normal fp16 number and by up to 2^-25 /
+//              scale (= 2^-39 x the layer's largest weight) when it is a subnormal; a row passes when the sum of what its pairs miss
+//              stays within 2^-23 of the sum of its magnitudes -- the normwise error of ONE fp32 rounding per weight (a row of tiny
+//              weights in a layer with one huge weight elsewhere fails);
+//   columns -- a column whose largest weight is more than 2^16 below the layer's largest is carried with fewer bits, which is
+//              harmless while its input is no larger than the others' and wrong when the network compensates small weights with
+//              large inputs (an embedding net scaled up by 2^60 in front of fc0 columns scaled down by 2^60 is the same function in
+//              fp32).  The loader cannot see the inputs, so every non-zero column must reach 2^-14 of the layer's largest weight.
+// With both, a layer's outputs are accurate to ~2^-23 of (the row's largest input) x (the row's weight magnitudes) -- the fp32
+// multiply-add's own normwise error -- for any input whose values of consequence lie within 2^15 of the row's largest.  A network that
+// fails stays on the bf16 triples, which have fp32's exponent range.
+bool pair_layer_ok(const HostAffine &a) {
+  const float scale = layer_pair_scale(a);
+  float layer_max = 0.0f;
+  std::vector<float> col_max(a.in, 0.0f);
+  for (uint32_t n = 0; n < a.out; ++n) {
+    double miss = 0.0, mag = 0.0;
+    for (uint32_t k = 0; k < a.in; ++k) {
+      const float wv = a.w[(size_t)n * a.in + k], x = wv * scale;
+      const _Float16 hi = (_Float16)x;
+      const _Float16 lo = (_Float16)(x - (float)hi);
+      miss += std::fabs((double)x - ((double)(float)hi + (double)(float)lo));
+      mag += std::fabs((double)x);
+      col_max[k] = std::fmax(col_max[k], std::fabs(wv));
+      layer_max = std::fmax(layer_max, std::fabs(wv));
+    }
+    if (miss > mag * 0x1p-23) return false;
+  }
+  for (uint32_t k = 0; k < a.in; ++k)
+    if (col_max[k] != 0.0f && col_max[k] < layer_max * 0x1p-14f) return false;
+  return true;
 }
 
 // k_policy_rows' A operand of a policy head's fc2 (H -> PH): float4 ((u * PB + b) * 64 + lane) = W[32 b + (lane & 31)][8 u + 4 (lane >> 5) .. + 3]
@@ -2475,6 +2872,20 @@ int oakgpu_net_load_memory(oakgpu_ctx *ctx, const void *bytes, size_t size, oakg
       }
     }
     D.ws = (const uint16_t *)dptr; D.ws_T0 = (int)T0; D.ws_NB = (int)NB;
+    {
+      const std::vector<uint16_t> wp = pair_stream(fc0, fc1, v2, NB, T0, D.wp_inv);
+      void *pptr = nullptr;
+      if (!rc) {
+        he = hipMalloc(&pptr, wp.size() * 2);
+        if (he != hipSuccess) rc = oakgpu_fail_hip((int)he, "hipMalloc(pair stream)");
+        else {
+          net->allocs.push_back(pptr);
+          he = hipMemcpy(pptr, wp.data(), wp.size() * 2, hipMemcpyHostToDevice);
+          if (he != hipSuccess) rc = oakgpu_fail_hip((int)he, "hipMemcpy(pair stream)");
+        }
+      }
+      D.wp = (const uint16_t *)pptr;
+    }
     // The bf16 triple (h, m, l) of a value x is exact to 2^-24 |x| only while its low parts are normal bf16 numbers (|x| >= ~2^-102);
     // below that a part that flushes loses at most 2^-126 per factor -- an ABSOLUTE error of at most 2^-126 |other factor| per
     // product.  That is harmless unless later layers amplify it: a layer scaled by 2^-120 feeding one scaled by 2^+120 computes an
@@ -2493,8 +2904,12 @@ int oakgpu_net_load_memory(oakgpu_ctx *ctx, const void *bytes, size_t size, oakg
     for (const HostAffine *a : {&L[1], &L[3]})
       for (float v : a->w) esafe = esafe && std::fabs(v) <= 0x1p20f;
     net->embed_safe = esafe;
+    // fp16 pairs (k_mainnet_pair, the default since round 5): scaled per layer and per batch row, so no absolute magnitude matters;
+    // what must hold is that every weight row survives the pairing to fp32 accuracy and no column is dwarfed (pair_layer_ok)
+    net->pair_safe = pair_layer_ok(fc0) && pair_layer_ok(fc1) && pair_layer_ok(v2);
     const char *env = getenv("OAKGPU_MAIN_NET");
-    net->main_mode = !safe ? 0 : env ? (strcmp(env, "fp32") == 0 ? 0 : 1) : 1;
+    const int want = env ? (strcmp(env, "fp32") == 0 ? 0 : strcmp(env, "bf16x3") == 0 ? 1 : 2) : 2;
+    net->main_mode = want == 2 && net->pair_safe ? 2 : want >= 1 && safe ? 1 : 0;
   }
   {
     const HostAffine &q1a = L[8], &q1b = L[9], &q2a = L[10], &q2b = L[11];
@@ -2545,10 +2960,11 @@ int oakgpu_net_load(oakgpu_ctx *ctx, const char *path, oakgpu_net **out) {
 }
 
 int oakgpu_net_set_main_precision(oakgpu_net *net, int mode) {
-  if (!net || (mode != OAKGPU_MAIN_FP32 && mode != OAKGPU_MAIN_SPLIT)) { oakgpu_fail_msg("oakgpu_net_set_main_precision: bad argument"); return -1; }
+  if (!net || (mode != OAKGPU_MAIN_FP32 && mode != OAKGPU_MAIN_SPLIT && mode != OAKGPU_MAIN_PAIR)) { oakgpu_fail_msg("oakgpu_net_set_main_precision: bad argument"); return -1; }
   const int prev = net->main_mode;
-  // (a network with a main-net weight above 2^20 in magnitude stays on fp32 MFMA: the request for bf16 triples is not honoured --
-  // the returned previous mode and oakgpu_net_main_precision say what runs)
+  // (a request the network's weights do not allow is not honoured: fp16 pairs fall back to bf16 triples, those -- a main-net weight
+  // above 2^20 in magnitude -- to fp32 MFMA; the returned previous mode and oakgpu_net_main_precision say what runs)
+  if (mode == OAKGPU_MAIN_PAIR && !net->pair_safe) mode = OAKGPU_MAIN_SPLIT;
   net->main_mode = (mode == OAKGPU_MAIN_SPLIT && !net->split_safe) ? OAKGPU_MAIN_FP32 : mode;
   return prev;
 }
@@ -2603,6 +3019,11 @@ int oakgpu_leaf_set_lds_limits(void) { // per DEVICE (hipFuncSetAttribute applie
   if (e == hipSuccess) e = hipFuncSetAttribute((const void *)oak::k_mainnet_split<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)oak::MSplit<2>::LDS);
   if (e == hipSuccess) e = hipFuncSetAttribute((const void *)oak::k_mainnet_split<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)oak::MSplit<1>::LDS);
   if (e != hipSuccess) return oakgpu_fail_hip((int)e, "hipFuncSetAttribute(k_mainnet_split)");
+  e = hipFuncSetAttribute((const void *)oak::k_mainnet_pair<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)oak::MPair<8>::LDS);
+  if (e == hipSuccess) e = hipFuncSetAttribute((const void *)oak::k_mainnet_pair<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)oak::MPair<4>::LDS);
+  if (e == hipSuccess) e = hipFuncSetAttribute((const void *)oak::k_mainnet_pair<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)oak::MPair<2>::LDS);
+  if (e == hipSuccess) e = hipFuncSetAttribute((const void *)oak::k_mainnet_pair<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)oak::MPair<1>::LDS);
+  if (e != hipSuccess) return oakgpu_fail_hip((int)e, "hipFuncSetAttribute(k_mainnet_pair)");
   return 0;
 }
 
@@ -2678,6 +3099,10 @@ static int leaf_eval_impl(oakgpu_ctx *ctx, oakgpu_net *net, const uint8_t *battl
   {
     const uint32_t wgs = ((n + 31) / 32 + 3) / 4, grid = wgs < 256 ? wgs : 256;
     if (net->main_mode == 0) hipLaunchKernelGGL(oak::k_mainnet_wave, dim3(grid), dim3(oak::MN_BLOCK), oak::MW_BYTES, stream, ma);
+    else if (net->main_mode == 2 && D.ws_NB == 8) hipLaunchKernelGGL(oak::k_mainnet_pair<8>, dim3(grid), dim3(oak::MN_BLOCK), oak::MPair<8>::LDS, stream, ma);
+    else if (net->main_mode == 2 && D.ws_NB == 4) hipLaunchKernelGGL(oak::k_mainnet_pair<4>, dim3(grid), dim3(oak::MN_BLOCK), oak::MPair<4>::LDS, stream, ma);
+    else if (net->main_mode == 2 && D.ws_NB == 2) hipLaunchKernelGGL(oak::k_mainnet_pair<2>, dim3(grid), dim3(oak::MN_BLOCK), oak::MPair<2>::LDS, stream, ma);
+    else if (net->main_mode == 2) hipLaunchKernelGGL(oak::k_mainnet_pair<1>, dim3(grid), dim3(oak::MN_BLOCK), oak::MPair<1>::LDS, stream, ma);
     else if (D.ws_NB == 8) hipLaunchKernelGGL(oak::k_mainnet_split<8>, dim3(grid), dim3(oak::MN_BLOCK), oak::MSplit<8>::LDS, stream, ma);
     else if (D.ws_NB == 4) hipLaunchKernelGGL(oak::k_mainnet_split<4>, dim3(grid), dim3(oak::MN_BLOCK), oak::MSplit<4>::LDS, stream, ma);
     else if (D.ws_NB == 2) hipLaunchKernelGGL(oak::k_mainnet_split<2>, dim3(grid), dim3(oak::MN_BLOCK), oak::MSplit<2>::LDS, stream, ma);
@@ -2691,7 +3116,7 @@ static int leaf_eval_impl(oakgpu_ctx *ctx, oakgpu_net *net, const uint8_t *battl
     const uint32_t ptiles = (n + 31) / 32;
     auto pgrid = [&](uint32_t waves) { const uint32_t wgs = (ptiles + waves - 1) / waves; return dim3(wgs < 256 ? wgs : 256); };
     // fc2 as bf16 triples when the main net runs that way and no fc2 weight forbids it (q1a_t), else on fp32 MFMA
-    const bool triple = net->main_mode == OAKGPU_MAIN_SPLIT && D.q1a_t != nullptr && D.q2a_t != nullptr;
+    const bool triple = net->main_mode != OAKGPU_MAIN_FP32 && D.q1a_t != nullptr && D.q2a_t != nullptr; // (the heads stay on bf16 triples beside a main net on fp16 pairs)
 #define OAK_POLICY_LAUNCH(PBV)                                                                                                                            \
   do {                                                                                                                                                    \
     if (triple) hipLaunchKernelGGL((oak::k_policy_rows<PBV, true>), pgrid(oak::PolicyRows<PBV>::WAVES), dim3(oak::PolicyRows<PBV>::BLOCK), oak::PolicyRows<PBV>::LDS, stream, pa);  \

@@ -227,20 +227,20 @@ class Network:
         return tuple(x.value for x in v)
 
     def main_precision(self):
-        """(mode in effect: "fp32" | "split", whether the bf16-triple form is allowed for this network): oakgpu_net_main_precision."""
+        """(mode in effect: "fp32" | "split" | "pair", whether the bf16-triple form is allowed for this network): oakgpu_net_main_precision."""
         allowed = C.c_int(0)
         mode = self.ctx.lib.oakgpu_net_main_precision(self.handle, C.byref(allowed))
         if mode < 0:
             raise _lib.OakGpuError("oakgpu_net_main_precision failed")
-        return ("fp32", "split")[mode], bool(allowed.value)
+        return ("fp32", "split", "pair")[mode], bool(allowed.value)
 
     def set_main_precision(self, mode):
-        """"split" (default: fp32 values as bf16 triples on the bf16 matrix pipe, fp32 accumulation) or "fp32" (fp32 MFMA);
-        include/oakgpu.h: oakgpu_net_set_main_precision.  Returns the previous mode."""
-        prev = self.ctx.lib.oakgpu_net_set_main_precision(self.handle, {"fp32": 0, "split": 1}[mode])
+        """"pair" (default: fp32 values as scaled fp16 pairs on the fp16 matrix pipe, fp32 accumulation), "split" (bf16 triples) or
+        "fp32" (fp32 MFMA); include/oakgpu.h: oakgpu_net_set_main_precision.  Returns the previous mode."""
+        prev = self.ctx.lib.oakgpu_net_set_main_precision(self.handle, {"fp32": 0, "split": 1, "pair": 2}[mode])
         if prev < 0:
             raise _lib.OakGpuError("oakgpu_net_set_main_precision failed")
-        return ("fp32", "split")[prev]
+        return ("fp32", "split", "pair")[prev]
 
     def value_inference(self, battles, durations, return_embedding=False):
         battles = _u8(battles)

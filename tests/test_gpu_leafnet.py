@@ -71,11 +71,12 @@ def _main_value_f64(onet, emb):
 
 
 @pytest.mark.parametrize("kind", ["config3", "default", "tiny"])
-def test_bf16_triple_main_net_is_an_fp32_result(gpu_ctx, tmp_path, kind):
-    """k_mainnet_split multiplies fp32 values as exact sums of three bf16 parts (six bf16 MFMAs per block, fp32 accumulation)
-    and drops only terms below 2^-24 of a product.  Held here to what that claims: against a FLOAT64 evaluation of the same
-    embedding its error is of the size of k_mainnet_wave's (fp32 MFMA) and far inside the 1e-5 bar; the two kernels agree to
-    1e-6; and the mode switch really switches (the two results are not bit-identical everywhere)."""
+def test_pair_and_triple_main_nets_are_fp32_results(gpu_ctx, tmp_path, kind):
+    """k_mainnet_pair (the default) multiplies fp32 values as scaled fp16 pairs -- three fp16 MFMAs per block, one power-of-two
+    scale per layer and per batch row -- and k_mainnet_split as exact sums of three bf16 parts (six bf16 MFMAs); both accumulate
+    in fp32 and drop only terms below 2^-24 of a product.  Held here to what that claims: against a FLOAT64 evaluation of the
+    same embedding their errors are of the size of k_mainnet_wave's (fp32 MFMA) and far inside the 1e-5 bar; the three kernels
+    agree to 1e-6; and the mode switch really switches (the results are not bit-identical everywhere)."""
     from oak_amd.engine import Network
     if kind == "config3":
         path = NET256
@@ -84,17 +85,19 @@ def test_bf16_triple_main_net_is_an_fp32_result(gpu_ctx, tmp_path, kind):
     net = Network(gpu_ctx, path=path)
     onet = NN.Net(path)
     b, d = _midgame_states(700, 30, 4242)          # 5 full 128-row groups + a ragged one
-    assert net.set_main_precision("split") == "split"   # the default
-    v_split, emb = net.value_inference(b, d, return_embedding=True)
+    assert net.main_precision() == ("pair", True)       # the default
+    v_pair, emb = net.value_inference(b, d, return_embedding=True)
+    assert net.set_main_precision("split") == "pair"
+    v_split = net.value_inference(b, d)
     assert net.set_main_precision("fp32") == "split"
     v_fp32 = net.value_inference(b, d)
-    net.set_main_precision("split")
+    assert net.set_main_precision("pair") == "fp32"
     ref = np.array([_main_value_f64(onet, emb[i]) for i in range(b.shape[0])])
-    e_split, e_fp32 = np.abs(v_split - ref).max(), np.abs(v_fp32 - ref).max()
-    assert e_split <= 1e-6 and e_fp32 <= 1e-6, (e_split, e_fp32)
-    assert e_split <= 4 * e_fp32 + 2e-7, (e_split, e_fp32)
-    assert np.abs(v_split - v_fp32).max() <= 1e-6
-    assert (v_split != v_fp32).any() or kind != "config3"
+    e_pair, e_split, e_fp32 = np.abs(v_pair - ref).max(), np.abs(v_split - ref).max(), np.abs(v_fp32 - ref).max()
+    assert e_pair <= 1e-6 and e_split <= 1e-6 and e_fp32 <= 1e-6, (e_pair, e_split, e_fp32)
+    assert e_pair <= 4 * e_fp32 + 2e-7 and e_split <= 4 * e_fp32 + 2e-7, (e_pair, e_split, e_fp32)
+    assert np.abs(v_split - v_fp32).max() <= 1e-6 and np.abs(v_pair - v_fp32).max() <= 1e-6
+    assert ((v_split != v_fp32).any() and (v_pair != v_split).any()) or kind != "config3"
     net.close()
 
 
@@ -115,6 +118,52 @@ def _rewrite_net(src, dst, edit):
         out += [struct.pack("<II", n_in, n_out), b.astype("<f4").tobytes(), W.astype("<f4").tobytes()]
     assert off == len(raw)
     open(dst, "wb").write(b"".join(out))
+
+
+@pytest.mark.parametrize("case", ["late_columns_large", "late_columns_huge", "one_huge_weight", "zero_rows"])
+def test_fp16_pair_main_net_scales(gpu_ctx, tmp_path, case):
+    """k_mainnet_pair's power-of-two scales.  fc0 reads a row 64 columns at a time and sets the row's scale from the FIRST chunk (the
+    active's block), lowering it -- and rescaling its sums -- when a later chunk holds a larger value: `late_columns_large` multiplies the
+    bench Pokemon's embedding net by 2^12 (its blocks come later in the row) and fc0's columns for those blocks by 2^-12 -- the same
+    function, and every row rescales.  `late_columns_huge` does the same with 2^60: beyond what a 5-bit exponent carries, the loader's
+    column check refuses the pairs and the network runs on the bf16 triples.  `one_huge_weight` plants a 2^19 in fc1: the other rows'
+    low parts fall into fp16 subnormals, the row check refuses the pairs.  `zero_rows`: an fc0 bias so negative that every hidden value
+    of fc0 is zero -- fc1 sees all-zero rows (the scale's floor).  Each against a float64 evaluation of the edited net from the
+    kernel's own embedding."""
+    from oak_amd.engine import Network
+    dst = str(tmp_path / "pair_edge.battle.net")
+    base = NN.Net(NET256)
+    bench_cols = np.array([s_ * base.side_dim + (1 + base.aod) + q * (1 + base.pod) + 1 + o for s_ in range(2) for q in range(5) for o in range(base.pod)])
+    shift = 12 if case == "late_columns_large" else 60
+
+    def edit(i, b, W):
+        if i == 1 and case.startswith("late_columns"):
+            return b * np.float32(2.0 ** shift), W * np.float32(2.0 ** shift)
+        if i == 4 and case.startswith("late_columns"):
+            W = W.copy()
+            W[:, bench_cols] *= np.float32(2.0 ** -shift)
+        if i == 5 and case == "one_huge_weight":
+            W = W.copy()
+            W[0, 0] = np.float32(2.0 ** 19)
+        if i == 4 and case == "zero_rows":
+            return b - np.float32(1e6), W
+        return b, W
+    _rewrite_net(NET256, dst, edit)
+    net, onet = Network(gpu_ctx, path=dst), NN.Net(dst)
+    refused = case in ("one_huge_weight", "late_columns_huge")
+    assert net.main_precision() == (("split", True) if refused else ("pair", True))
+    net.set_main_precision("pair")                        # not honoured where the loader refused it
+    assert net.main_precision()[0] == ("split" if refused else "pair")
+    b, d = _midgame_states(300, 30, 999)
+    v, emb = net.value_inference(b, d, return_embedding=True)
+    if case.startswith("late_columns"):                   # the premise: the row's largest value is not in its first 64 columns
+        assert (np.abs(emb[:, 64:]).max(axis=1) > 1000 * np.abs(emb[:, :64]).max(axis=1)).mean() > 0.9
+    with np.errstate(over="ignore"):
+        ref = np.array([_main_value_f64(onet, emb[i]) for i in range(b.shape[0])])
+    assert np.isfinite(v).all() and np.abs(v - ref).max() <= 1e-6, (case, np.abs(v - ref).max())
+    net.set_main_precision("fp32")
+    assert np.abs(net.value_inference(b, d) - v).max() <= 1e-6
+    net.close()
 
 
 @pytest.mark.parametrize("case", ["down20_up20", "down100_up100", "down120_up120", "down100", "down120", "up100", "tiny_weights"])
@@ -148,13 +197,19 @@ def test_bf16_triple_main_net_at_the_edges_of_the_exponent_range(gpu_ctx, tmp_pa
     net = Network(gpu_ctx, path=dst)
     onet = NN.Net(dst)
     expect_split = case in ("down20_up20", "down100", "down120", "tiny_weights")
-    assert net.main_precision() == (("split", True) if expect_split else ("fp32", False))
-    net.set_main_precision("split")                       # not honoured where the loader refused it
-    assert net.main_precision()[0] == ("split" if expect_split else "fp32")
+    # the fp16 pairs (the default) are scaled per layer and per batch row, so a layer scaled UP, or down by 2^-20, stays on them; a
+    # layer scaled down by 2^-100 is beyond the layer scale's range (2^+-100): its low parts are fp16 subnormals, the loader's row
+    # check refuses the pairs and the network runs on the triples -- or on fp32 MFMA where those are refused too
+    default = "pair" if case in ("down20_up20", "up100", "tiny_weights") else "split" if expect_split else "fp32"
+    assert net.main_precision() == (default, expect_split)
     b, d = _midgame_states(300, 30, 555)
-    v, emb = net.value_inference(b, d, return_embedding=True)
+    v_pair, emb = net.value_inference(b, d, return_embedding=True)
     with np.errstate(over="ignore"):
         ref = np.array([_main_value_f64(onet, emb[i]) for i in range(b.shape[0])])
+    assert np.isfinite(v_pair).all() and np.abs(v_pair - ref).max() <= 1e-6, (case, np.abs(v_pair - ref).max())
+    net.set_main_precision("split")                       # not honoured where the loader refused it
+    assert net.main_precision()[0] == ("split" if expect_split else "fp32")
+    v = net.value_inference(b, d)
     assert np.isfinite(v).all() and np.abs(v - ref).max() <= 1e-6, (case, np.abs(v - ref).max())
     if expect_split:                                       # and the fp32-MFMA kernel agrees with it
         net.set_main_precision("fp32")
@@ -423,7 +478,7 @@ def test_policy_head_widths(gpu_ctx, tmp_path, ph):
     c1, n1 = gpu_ctx.choices(b, r, 0)
     c2, n2 = gpu_ctx.choices(b, r, 1)
     # both forms of fc2: bf16 triples (the default, with the main net) and fp32 MFMA (what "fp32" selects for the whole net)
-    for mode in ("split", "fp32"):
+    for mode in ("pair", "split", "fp32"):
         net.set_main_precision(mode)
         assert net.main_precision()[0] == mode
         vals, l1, l2 = net.value_policy_inference(b, d, c1, n1, c2, n2)
