@@ -536,15 +536,22 @@ def leaf_records(args, torch, dev, rank, local_rank, world, dist, which=("leaf",
         _lib.check(lib.oakgpu_set_kernel_timing(h, 0))
         return {"k_embed_prows (party slots)": acc[0] / 5 * 1e3, "k_embed_arows (actives)": acc[1] / 5 * 1e3, MAIN_KERNEL: acc[2] / 5 * 1e3}
 
-    # the main net's kernel: fp32 values as exact bf16 triples on the bf16 matrix pipe unless OAKGPU_MAIN_NET=fp32 (include/oakgpu.h)
-    split = os.environ.get("OAKGPU_MAIN_NET", "") != "fp32"
-    MAIN_KERNEL = "k_mainnet_split<8>" if split else "k_mainnet_wave"
-    ARITH = ("fp32 results throughout.  Embedding nets: one-hot rows summed in fp32 on the vector ALUs; dense features, the move of the sums into the item "
-             "lanes and the second layers as exact bf16 triples on the bf16 pipe.  Main net: every "
-             "fp32 value is the exact sum of three bf16 parts and every product runs as its six largest bf16 x bf16 partial products (exact in the "
-             "fp32 accumulator; dropped: < 2^-24 of the product) on v_mfma_f32_32x32x16_bf16, fp32 accumulation; error vs float64 at the fp32-MFMA "
-             "kernel's level (tests/test_gpu_leafnet.py::test_bf16_triple_main_net_is_an_fp32_result)") if split else \
-            "embedding nets: first layers fp32 MFMA, second layers bf16 triples; main net fp32 MFMA"
+    # the main net's kernel: fp32 values as scaled fp16 pairs on the fp16 matrix pipe (k_mainnet_pair, the default since round 5) unless
+    # OAKGPU_MAIN_NET=bf16x3 (bf16 triples, k_mainnet_split) or =fp32 (fp32 MFMA, k_mainnet_wave); include/oakgpu.h
+    main_env = os.environ.get("OAKGPU_MAIN_NET", "")
+    main_mode = "fp32" if main_env == "fp32" else "split" if main_env == "bf16x3" else "pair"
+    split = main_mode != "fp32"
+    MAIN_KERNEL = {"pair": "k_mainnet_pair<8>", "split": "k_mainnet_split<8>", "fp32": "k_mainnet_wave"}[main_mode]
+    MAIN_PRODUCTS = {"pair": 3, "split": 6, "fp32": 1}[main_mode]   # matrix-pipe products executed per algorithmic multiply-add
+    EMB = ("fp32 results throughout.  Embedding nets: one-hot rows summed in fp32 on the vector ALUs; dense features, the move of the sums into the item "
+           "lanes and the second layers as exact bf16 triples on the bf16 pipe.  ")
+    ARITH = {"pair": EMB + "Main net: every fp32 value times an exact power of two (one per layer for the weights, one per batch row for the activations) is the sum of "
+                           "two round-to-nearest fp16 parts (to 2^-24), and every product runs as its three largest fp16 x fp16 partial products (exact in the fp32 "
+                           "accumulator; dropped: < 2^-24 of the product) on v_mfma_f32_32x32x16_f16, fp32 accumulation; error vs float64 at the fp32-MFMA "
+                           "kernel's level (tests/test_gpu_leafnet.py::test_pair_and_triple_main_nets_are_fp32_results)",
+             "split": EMB + "Main net: every fp32 value is the exact sum of three bf16 parts and every product runs as its six largest bf16 x bf16 partial products "
+                            "(exact in the fp32 accumulator; dropped: < 2^-24 of the product) on v_mfma_f32_32x32x16_bf16, fp32 accumulation",
+             "fp32": "embedding nets: first layers fp32 vector ALUs, second layers bf16 triples; main net fp32 MFMA"}[main_mode]
 
     def policy_note(value_call_s):   # SURVEY 8 row f3, untimed diagnostic pass: value_policy_inference (network.h:102-123) over the same states
         c1, c2 = (torch.empty((n, 9), dtype=u8, device=dev) for _ in range(2))
@@ -584,8 +591,10 @@ def leaf_records(args, torch, dev, rank, local_rank, world, dist, which=("leaf",
                "parts": [("first layer (6 dense + 7 one-hot rows per item)", "fp32 vector ALUs (157.3 TFLOP/s, = the fp32 MFMA peak)", p1 * n, F), ("second layer 128 -> 59 as bf16 triples", "bf16 MFMA x 6", 6 * p2 * n, B)]},
               {"name": "oak::k_embed_arows (actives; the other half)", "us": kus["k_embed_arows (actives)"],
                "parts": [("first layer (36 dense + 17 one-hot / move rows per item)", "fp32 vector ALUs (157.3 TFLOP/s, = the fp32 MFMA peak)", a1 * n, F), ("second layer 128 -> 83 as bf16 triples", "bf16 MFMA x 6", 6 * a2 * n, B)]}]
-        if split:
-            ks.append({"name": "oak::" + MAIN_KERNEL, "us": kus[MAIN_KERNEL], "parts": [("768 -> 256 -> 256 -> 256 as bf16 triples", "bf16 MFMA x 6", 6 * mainf * n, B)]})
+        if split:   # (the fp16 and the bf16 matrix pipes have the same dense peak)
+            ks.append({"name": "oak::" + MAIN_KERNEL, "us": kus[MAIN_KERNEL],
+                       "parts": [("768 -> 256 -> 256 -> 256 as " + ("scaled fp16 pairs" if main_mode == "pair" else "bf16 triples"),
+                                  "%s MFMA x %d" % ("fp16" if main_mode == "pair" else "bf16", MAIN_PRODUCTS), MAIN_PRODUCTS * mainf * n, B)]})
         else:
             ks.append({"name": "oak::" + MAIN_KERNEL, "us": kus[MAIN_KERNEL], "parts": [("768 -> 256 -> 256 -> 256", "fp32 MFMA", mainf * n, F)]})
         return ks
@@ -614,8 +623,8 @@ def leaf_records(args, torch, dev, rank, local_rank, world, dist, which=("leaf",
             # layer at the peak of the pipe it runs on (time-weighted over the call's kernels) -- frac = achieved / peak <= 1
             "roofline": {"bound": "mfma", "kernel": "oak::k_embed_both (k_embed_prows + k_embed_arows in one launch) + oak::%s (one value_inference call)" % MAIN_KERNEL,
                          "achieved": achieved, "peak": achieved / (tmin / avg_s), "unit": "TFLOP/s", "frac": tmin / avg_s,
-                         "frac_note": "sum over the call's layers of (algorithmic work on its pipe / that pipe's dense peak: fp32 (vector ALUs = fp32 MFMA) 157.3 TFLOP/s, bf16 MFMA "
-                                      "2,500 TFLOP/s with 6 partial products per multiply-add) / the call's measured time; `kernels` has it per kernel "
+                         "frac_note": "sum over the call's layers of (algorithmic work on its pipe / that pipe's dense peak: fp32 (vector ALUs = fp32 MFMA) 157.3 TFLOP/s, bf16 / fp16 MFMA "
+                                      "2,500 TFLOP/s with 6 (bf16 triples) or 3 (fp16 pairs) partial products per multiply-add) / the call's measured time; `kernels` has it per kernel "
                                       "(durations from HIP events around each launch, a diagnostic pass outside the timed region: "
                                       "time-weighted %.3f over those)" % frac,
                          "kernels": rows,

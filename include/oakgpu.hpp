@@ -98,7 +98,7 @@ public:
     check(oakgpu_net_shape(net_, &a, &b, &c, &d));
     return {a, b, c, d};
   }
-  // how the main net's dense layers are multiplied: OAKGPU_MAIN_SPLIT (default, bf16 triples, fp32 results) or OAKGPU_MAIN_FP32
+  // how the main net's dense layers are multiplied: OAKGPU_MAIN_PAIR (default: scaled fp16 pairs, fp32 results), OAKGPU_MAIN_SPLIT (bf16 triples) or OAKGPU_MAIN_FP32
   int set_main_precision(int mode) { return oakgpu_net_set_main_precision(net_, mode); }
   // value_inference(battle, durations) for every leaf (network.h:72-79)
   std::vector<float> value_inference(const std::vector<Leaf> &leaves) {
