@@ -32,6 +32,7 @@ struct NetDev {
   const float *a_w0d, *a_img; // k_embed_arows: padded W0^T (move rows), and the image of its LDS weights (arows_image)
   const float *p_img;         // k_embed_prows: the image of its LDS weights (prows_image)
   int p_hidden, p_out, a_hidden, a_out;
+  float p_l2_inv, a_l2_inv;   // 1 / the scale of the second layers' fp16 pairs in p_img / a_img (embed_pair_order)
   int side_dim, emb_dim;
   int activation; // 1 relu, 2 clamp
   // main net (value path), rows padded to multiples of 32 with zeros
@@ -527,6 +528,50 @@ constexpr int ER_ITEMS = 32, ER_RS = 128; // items per wave mini-tile; LDS weigh
 //                  parts of four k-steps' row sums into the item lanes).  A first attempt with the round-to-nearest split cost
 //                  ~1,000 more vector instructions per mini-tile and lost; with the truncation split it is 352, and the fp32
 //                  MFMAs it replaces turned out to hold the vector issue for their whole 64 cycles.
+// ---- fp32 values as SCALED fp16 PAIRS (round 5; the full argument is at k_mainnet_pair): x s = h + l to 2^-24 with h = fp16(x s), l =
+// fp16(x s - h), s a power of two that takes the largest value of the row (weights: of the layer) into [2^14, 2^15) ----
+using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
+// the power of two that takes m (> 0: callers floor it) into [2^14, 2^15), and the exact ratio of two such scales
+__device__ __forceinline__ float mp_scale_of(float m) { return __uint_as_float((268u - (__float_as_uint(m) >> 23)) << 23); }
+__device__ __forceinline__ float mp_ratio(float to, float from) { // (a ratio below 2^-126 is 0: the sums it would multiply are then zeros or nothing)
+  const int e = 127 + (int)(__float_as_uint(to) >> 23) - (int)(__float_as_uint(from) >> 23);
+  return __uint_as_float((uint32_t)(e > 0 ? e : 0) << 23);
+}
+__device__ __forceinline__ float mp_inverse(float s) { return __uint_as_float((254u - (__float_as_uint(s) >> 23)) << 23); }
+constexpr float MP_FLOOR = 0x1p-110f; // a row of zeros (or of values below this): scale 2^124, every part 0 (or a subnormal's worth)
+// elements [e0, e1) of a k-step's 8 activation values, times the row's scale, as their pairs
+#ifndef OAK_MP_SPLIT
+#define OAK_MP_SPLIT 0 // 0: both parts rounded to nearest; 1 (experiment): the high part by truncation, two values per instruction (v_cvt_pkrtz_f16_f32); 2 (experiment, WRONG results): no split at all
+#endif
+#ifndef OAK_MP_VALU
+#define OAK_MP_VALU 3  // vector instructions the scheduler may place behind each MFMA of a block
+#endif
+__device__ __forceinline__ void mp_split_part(const float (&v)[8], float scale, f16x8 (&B)[2], int e0, int e1) {
+#if OAK_MP_SPLIT == 2
+  if (e0 == 0) { B[0] = __builtin_bit_cast(f16x8, *(const float4 *)&v[0]); B[1] = __builtin_bit_cast(f16x8, *(const float4 *)&v[4]); }
+  (void)scale; (void)e1;
+#elif OAK_MP_SPLIT == 1
+  typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
+#pragma unroll
+  for (int i = 0; i < 8; i += 2)
+    if (i >= e0 && i < e1) { // (e0, e1 even or the whole k-step: NB <= 4 or one call)
+      const float x0 = v[i] * scale, x1 = v[i + 1] * scale;
+      const f16x2 hi = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(x0, x1));
+      B[0][i] = hi[0]; B[0][i + 1] = hi[1];
+      B[1][i] = (_Float16)(x0 - (float)hi[0]);
+      B[1][i + 1] = (_Float16)(x1 - (float)hi[1]);
+    }
+#else
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+    if (i >= e0 && i < e1) {
+      const float x = v[i] * scale;
+      const _Float16 hi = (_Float16)x;
+      B[0][i] = hi;
+      B[1][i] = (_Float16)(x - (float)hi);
+    }
+#endif
+}
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 constexpr int E2_BLOCK_BYTES = 8 * 3 * 1024; // W1's triples of one 32-wide output block: [k-step T][h m l][lane] x 16 B
 // v[0..7] as their bf16 triples, by TRUNCATION: h = the top 16 bits of x (its 8 leading significant bits), m = the top 16 bits of
@@ -656,14 +701,25 @@ __device__ __forceinline__ void dense_layer_bf16(const uint8_t *wd_lane, const u
 }
 // Second layer: hb = the item's 128 activated hidden channels (lane (item r, hh): register s of block b = channel ar_channel),
 // w1t = this lane's 16 bytes of W1's triple image in LDS.  Orientation Out^T = W1 . H^T: the weights are the A operand (lane
-// (o, h) element j = W1[32 nb + o][ar_channel(8 T + j, h)], prebuilt on the host: embed_triple_order), the activations the B
+// (o, h) element j = W1[32 nb + o][ar_channel(8 T + j, h)], prebuilt on the host: embed_pair_order), the activations the B
 // operand (lane (item r, h) element j = that channel = its own registers 8 T .. 8 T + 7) -- so acc[nb] holds, on lane (item r,
 // h), the item's outputs 32 nb + 8 (q >> 2) + 4 h + (q & 3): every lane scatters ITS OWN item, four consecutive outputs per
 // 16-byte store (embed_scatter), with the destination offset in a register.  (Rounds 2-3 had the outputs on the lanes and the
 // items in the registers: 16 four-byte stores per block, each behind an LDS read of the item's offset, a branch and -- stores
 // count in vmcnt -- the completion of the store before it: 11.8 k of a party mini-tile's 35 k cycles.)
+// Round 5: as scaled fp16 PAIRS instead of bf16 triples -- three MFMAs per block and k-step instead of six (the phase was bound by its
+// chain of dependent MFMAs: 8 k-steps x 6 x NBo x 32 cycles against ~350 vector instructions).  The item's scale comes from the largest of
+// its 128 hidden activations (64 registers of this lane, 64 of its partner); W1's pairs carry the layer's scale (embed_pair_order).
+// Returns 1 / the item's scale: embed_scatter multiplies the sums back (x N.*_l2_inv, the layer's).
 template <int NBMAX>
-__device__ __forceinline__ void embed_layer2(const f32x16 (&hb)[4], const uint8_t *w1t, int NBo, f32x16 (&acc)[NBMAX]) {
+__device__ __forceinline__ float embed_layer2(const f32x16 (&hb)[4], const uint8_t *w1t, int NBo, f32x16 (&acc)[NBMAX]) {
+  float m = MP_FLOOR;
+#pragma unroll
+  for (int b = 0; b < 4; ++b)
+#pragma unroll
+    for (int q = 0; q < 16; q += 2) m = fmaxf(m, fmaxf(fabsf(hb[b][q]), fabsf(hb[b][q + 1])));
+  m = fmaxf(m, __shfl_xor(m, 32, 64));
+  const float scale = mp_scale_of(m);
 #pragma unroll
   for (int nb = 0; nb < NBMAX; ++nb)
 #pragma unroll
@@ -673,21 +729,19 @@ __device__ __forceinline__ void embed_layer2(const f32x16 (&hb)[4], const uint8_
     float v[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) v[j] = hb[T >> 1][8 * (T & 1) + j];
-    bf16x8 A[3];
-    e_split(v, A);
+    f16x8 A[2];
+    mp_split_part(v, scale, A, 0, 8);
 #pragma unroll
     for (int nb = 0; nb < NBMAX; ++nb)
       if (nb < NBo) { // wave-uniform
-        const uint8_t *p = w1t + nb * E2_BLOCK_BYTES + T * 3072;
-        const bf16x8 W0 = *(const bf16x8 *)p, W1 = *(const bf16x8 *)(p + 1024), W2 = *(const bf16x8 *)(p + 2048);
-        acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W0, A[2], acc[nb], 0, 0, 0); // l . h   (small terms first)
-        acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W2, A[0], acc[nb], 0, 0, 0); // h . l
-        acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W1, A[1], acc[nb], 0, 0, 0); // m . m
-        acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W0, A[1], acc[nb], 0, 0, 0); // m . h
-        acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W1, A[0], acc[nb], 0, 0, 0); // h . m
-        acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W0, A[0], acc[nb], 0, 0, 0); // h . h
+        const uint8_t *p = w1t + nb * E2_BLOCK_BYTES + T * 3072; // (the image keeps the triples' 3 x 1 KB per k-step; the third is unused)
+        const f16x8 W0 = *(const f16x8 *)p, W1 = *(const f16x8 *)(p + 1024);
+        acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(W1, A[0], acc[nb], 0, 0, 0); // l . h   (small terms first)
+        acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(W0, A[1], acc[nb], 0, 0, 0); // h . l
+        acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(W0, A[0], acc[nb], 0, 0, 0); // h . h
       }
   }
+  return mp_inverse(scale);
 }
 // The item's outputs to its block of the battle embedding: bias + activation, four consecutive outputs per store (the block
 // starts one float behind a 16-byte boundary -- the hp ratio comes first -- so the stores are 4-byte aligned dwordx4's), all
@@ -695,7 +749,7 @@ __device__ __forceinline__ void embed_layer2(const f32x16 (&hb)[4], const uint8_
 struct __attribute__((packed, aligned(4))) f4u { float x, y, z, w; };
 template <int NBMAX>
 __device__ __forceinline__ void embed_scatter(float *emb, uint32_t doff, float hpr, uint32_t hh, const f32x16 (&acc)[NBMAX], int NBo, int out_dim,
-                                              const float *bias, int activation) {
+                                              const float *bias, int activation, float inv) { // inv: 1 / (the item's scale x the layer's), exact
   float4 b[NBMAX][4];
 #pragma unroll
   for (int nb = 0; nb < NBMAX; ++nb)
@@ -706,8 +760,8 @@ __device__ __forceinline__ void embed_scatter(float *emb, uint32_t doff, float h
   for (int nb = 0; nb < NBMAX; ++nb)
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      o[nb][4 * g + 0] = acc[nb][4 * g + 0] + b[nb][g].x; o[nb][4 * g + 1] = acc[nb][4 * g + 1] + b[nb][g].y;
-      o[nb][4 * g + 2] = acc[nb][4 * g + 2] + b[nb][g].z; o[nb][4 * g + 3] = acc[nb][4 * g + 3] + b[nb][g].w;
+      o[nb][4 * g + 0] = acc[nb][4 * g + 0] * inv + b[nb][g].x; o[nb][4 * g + 1] = acc[nb][4 * g + 1] * inv + b[nb][g].y;
+      o[nb][4 * g + 2] = acc[nb][4 * g + 2] * inv + b[nb][g].z; o[nb][4 * g + 3] = acc[nb][4 * g + 3] * inv + b[nb][g].w;
     }
   act_blocks<NBMAX>(o, activation);
   // (opaque per call: the width tests below depend on the lane's half only, so the compiler hoisted all 48 of them -- 64-bit lane
@@ -1020,7 +1074,7 @@ __device__ __forceinline__ void embed_arows_body(const EmbedTileArgs &a, float *
     // wave priority: second layer 3 > first layer 2 > encode / scatter 0 -- whoever can feed the matrix pipe issues first
     __builtin_amdgcn_s_setprio(3);
     f32x16 acc[NBO];
-    embed_layer2<NBO>(hb, W1t + lane * 16, NBO, acc);
+    const float inv_item = embed_layer2<NBO>(hb, W1t + lane * 16, NBO, acc);
     EL_MARK(6);
     __builtin_amdgcn_s_setprio(0);
     const uint32_t cur_doff = my_doff;
@@ -1030,7 +1084,7 @@ __device__ __forceinline__ void embed_arows_body(const EmbedTileArgs &a, float *
     // wait for them does not wait for the stores (vmcnt retires in order)
     if (next < nmt) encode_compute(next);
     EL_MARK(7);
-    embed_scatter<NBO>(a.emb, cur_doff, cur_hpr, hh, acc, NBO, out_dim, b1s, N.activation);
+    embed_scatter<NBO>(a.emb, cur_doff, cur_hpr, hh, acc, NBO, out_dim, b1s, N.activation, inv_item * N.a_l2_inv);
     EL_MARK(5);
     mt = next;
   }
@@ -1237,7 +1291,7 @@ __device__ __forceinline__ void embed_prows_body(const EmbedTileArgs &a, float *
     // wave priority: second layer 3 > first layer 2 > encode / scatter 0 -- whoever can feed the matrix pipe issues first
     __builtin_amdgcn_s_setprio(3);
     f32x16 acc[NBO];
-    embed_layer2<NBO>(hb, W1t + lane * 16, NBO, acc);
+    const float inv_item = embed_layer2<NBO>(hb, W1t + lane * 16, NBO, acc);
     EL_MARK(6);
     __builtin_amdgcn_s_setprio(0);
     const uint32_t cur_doff = my_doff;
@@ -1247,7 +1301,7 @@ __device__ __forceinline__ void embed_prows_body(const EmbedTileArgs &a, float *
     // wait for them does not wait for the stores (vmcnt retires in order)
     if (next < nmt) encode_compute(next);
     EL_MARK(7);
-    embed_scatter<NBO>(a.emb, cur_doff, cur_hpr, hh, acc, NBO, out_dim, b1s, N.activation);
+    embed_scatter<NBO>(a.emb, cur_doff, cur_hpr, hh, acc, NBO, out_dim, b1s, N.activation, inv_item * N.p_l2_inv);
     EL_MARK(5);
     mt = next;
   }
@@ -1903,7 +1957,6 @@ __global__ __launch_bounds__(MN_BLOCK) void k_mainnet_split(MainArgs a) {
 // oakgpu_net_load* CHECKS the weight side of that (pair_layer_ok: rows and columns) and keeps a network that fails it on the bf16 triples.
 // Everything else -- orientation, the LDS-DMA ring, the software pipeline -- is k_mainnet_split's; a phase is MPair::G k-steps of
 // NB x 2 KB.
-using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
 #ifndef OAK_MP_G
 #define OAK_MP_G 4
 #endif
@@ -1949,47 +2002,6 @@ template <int YOUNGER> // wait for a pair with YOUNGER LDS reads (0 or 2) issued
 __device__ __forceinline__ void mp_wait_a(f16x8 (&A)[2]) {
   if (YOUNGER == 2) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(A[0]), "+v"(A[1]));
   else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(A[0]), "+v"(A[1]));
-}
-// the power of two that takes m (> 0: callers floor it) into [2^14, 2^15), and the exact ratio of two such scales
-__device__ __forceinline__ float mp_scale_of(float m) { return __uint_as_float((268u - (__float_as_uint(m) >> 23)) << 23); }
-__device__ __forceinline__ float mp_ratio(float to, float from) { // (a ratio below 2^-126 is 0: the sums it would multiply are then zeros or nothing)
-  const int e = 127 + (int)(__float_as_uint(to) >> 23) - (int)(__float_as_uint(from) >> 23);
-  return __uint_as_float((uint32_t)(e > 0 ? e : 0) << 23);
-}
-__device__ __forceinline__ float mp_inverse(float s) { return __uint_as_float((254u - (__float_as_uint(s) >> 23)) << 23); }
-constexpr float MP_FLOOR = 0x1p-110f; // a row of zeros (or of values below this): scale 2^124, every part 0 (or a subnormal's worth)
-// elements [e0, e1) of a k-step's 8 activation values, times the row's scale, as their pairs
-#ifndef OAK_MP_SPLIT
-#define OAK_MP_SPLIT 0 // 0: both parts rounded to nearest; 1 (experiment): the high part by truncation, two values per instruction (v_cvt_pkrtz_f16_f32); 2 (experiment, WRONG results): no split at all
-#endif
-#ifndef OAK_MP_VALU
-#define OAK_MP_VALU 3  // vector instructions the scheduler may place behind each MFMA of a block
-#endif
-__device__ __forceinline__ void mp_split_part(const float (&v)[8], float scale, f16x8 (&B)[2], int e0, int e1) {
-#if OAK_MP_SPLIT == 2
-  if (e0 == 0) { B[0] = __builtin_bit_cast(f16x8, *(const float4 *)&v[0]); B[1] = __builtin_bit_cast(f16x8, *(const float4 *)&v[4]); }
-  (void)scale; (void)e1;
-#elif OAK_MP_SPLIT == 1
-  typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
-#pragma unroll
-  for (int i = 0; i < 8; i += 2)
-    if (i >= e0 && i < e1) { // (e0, e1 even or the whole k-step: NB <= 4 or one call)
-      const float x0 = v[i] * scale, x1 = v[i + 1] * scale;
-      const f16x2 hi = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(x0, x1));
-      B[0][i] = hi[0]; B[0][i + 1] = hi[1];
-      B[1][i] = (_Float16)(x0 - (float)hi[0]);
-      B[1][i + 1] = (_Float16)(x1 - (float)hi[1]);
-    }
-#else
-#pragma unroll
-  for (int i = 0; i < 8; ++i)
-    if (i >= e0 && i < e1) {
-      const float x = v[i] * scale;
-      const _Float16 hi = (_Float16)x;
-      B[0][i] = hi;
-      B[1][i] = (_Float16)(x - (float)hi);
-    }
-#endif
 }
 template <int NB, bool SAME_PHASE>
 __device__ __forceinline__ void mp_kstep(f32x16 (&acc)[NB], const f16x8 (&B)[2], const float (&vn)[8], float scale_n, f16x8 (&Bn)[2], f16x8 (&Afirst)[2],
@@ -2731,37 +2743,37 @@ std::vector<float> pad_vec(const std::vector<float> &v, uint32_t n) {
 }
 uint32_t up32(uint32_t x) { return (x + 31) & ~31u; }
 
-// W1 of an embedding net as bf16 triples in embed_layer2's order: 16-bit word ((((nb * 8 + T) * 3 + part) * 64 + lane) * 8 + j) = part of
-// W1[32 nb + (lane & 31)][ar_channel(8 T + j, lane >> 5)]; absent rows / channels are zeros.  Returned as floats (the LDS image's unit).
-std::vector<float> embed_triple_order(const HostAffine &a, uint32_t NB) {
+// W1 of an embedding net as scaled fp16 PAIRS in embed_layer2's order (round 5; rounds 3-4: bf16 triples -- the image keeps their three
+// 1-KB parts per k-step, the third is zeros): 16-bit word ((((nb * 8 + T) * 3 + part) * 64 + lane) * 8 + j) = part (0: h, 1: l) of
+// W1[32 nb + (lane & 31)][ar_channel(8 T + j, lane >> 5)] x layer_pair_scale(W1); absent rows / channels are zeros.  Returned as floats
+// (the LDS image's unit).
+std::vector<float> embed_pair_order(const HostAffine &a, uint32_t NB) {
   std::vector<uint16_t> w((size_t)NB * 8 * 3 * 64 * 8, 0);
+  const float scale = layer_pair_scale(a);
   for (uint32_t nb = 0; nb < NB; ++nb)
     for (uint32_t T = 0; T < 8; ++T)
       for (uint32_t lane = 0; lane < 64; ++lane)
         for (uint32_t j = 0; j < 8; ++j) {
           const uint32_t o = nb * 32 + (lane & 31), c = (uint32_t)oak::ar_channel((int)(8 * T + j), (int)(lane >> 5));
           if (o >= a.out || c >= a.in) continue;
-          const float x = a.w[(size_t)o * a.in + c];
-          const uint16_t hh = f32_to_bf16(x);
-          const float r1 = x - bf16_to_f32(hh);
-          const uint16_t mm = f32_to_bf16(r1);
-          const uint16_t ll = f32_to_bf16(r1 - bf16_to_f32(mm));
+          const float x = a.w[(size_t)o * a.in + c] * scale;
+          const _Float16 hi = (_Float16)x;
+          const _Float16 lo = (_Float16)(x - (float)hi);
           const size_t base = ((size_t)nb * 8 + T) * 3;
-          w[((base + 0) * 64 + lane) * 8 + j] = hh;
-          w[((base + 1) * 64 + lane) * 8 + j] = mm;
-          w[((base + 2) * 64 + lane) * 8 + j] = ll;
+          w[((base + 0) * 64 + lane) * 8 + j] = f16_bits(hi);
+          w[((base + 1) * 64 + lane) * 8 + j] = f16_bits(lo);
         }
   std::vector<float> f(w.size() / 2);
   memcpy(f.data(), w.data(), w.size() * 2);
   return f;
 }
 
-// the images of the two kernels' LDS weights: [one-hot rows (stride ER_RS) + a zero row | dense fragment | W1's bf16 triples]
+// the images of the two kernels' LDS weights: [one-hot rows (stride ER_RS) + a zero row | dense fragment | W1's fp16 pairs]
 std::vector<float> arows_image(const HostAffine &a0, const HostAffine &a1) {
   std::vector<float> img((size_t)(oak::AR_SPARSE + 1) * oak::ER_RS, 0.0f);
   for (int sl = 0; sl < oak::AR_SPARSE; ++sl)
     for (uint32_t c = 0; c < a0.out && c < 128; ++c) img[(size_t)sl * oak::ER_RS + c] = a0.w[(size_t)c * a0.in + (uint32_t)oak::ar_sparse_row(sl)];
-  const std::vector<float> d = arows_dense_frag(a0), f = embed_triple_order(a1, (a1.out + 31) / 32), bp = pad_vec(a1.b, up32(a1.out));
+  const std::vector<float> d = arows_dense_frag(a0), f = embed_pair_order(a1, (a1.out + 31) / 32), bp = pad_vec(a1.b, up32(a1.out));
   img.insert(img.end(), d.begin(), d.end());
   img.insert(img.end(), f.begin(), f.end());
   img.insert(img.end(), bp.begin(), bp.end());
@@ -2771,7 +2783,7 @@ std::vector<float> prows_image(const HostAffine &p0, const HostAffine &p1) {
   std::vector<float> img((size_t)(oak::PR_SPARSE + 1) * oak::ER_RS, 0.0f);
   for (int sl = 0; sl < oak::PR_SPARSE; ++sl)
     for (uint32_t c = 0; c < p0.out && c < 128; ++c) img[(size_t)sl * oak::ER_RS + c] = p0.w[(size_t)c * p0.in + (uint32_t)(sl + 5)];
-  const std::vector<float> d = prows_dense_frag(p0), f = embed_triple_order(p1, (p1.out + 31) / 32), bp = pad_vec(p1.b, up32(p1.out));
+  const std::vector<float> d = prows_dense_frag(p0), f = embed_pair_order(p1, (p1.out + 31) / 32), bp = pad_vec(p1.b, up32(p1.out));
   img.insert(img.end(), d.begin(), d.end());
   img.insert(img.end(), f.begin(), f.end());
   img.insert(img.end(), bp.begin(), bp.end());
@@ -2903,7 +2915,11 @@ int oakgpu_net_load_memory(oakgpu_ctx *ctx, const void *bytes, size_t size, oakg
     bool esafe = safe;
     for (const HostAffine *a : {&L[1], &L[3]})
       for (float v : a->w) esafe = esafe && std::fabs(v) <= 0x1p20f;
+    // (round 5) ... and their second layers multiply as scaled fp16 pairs, which both must survive (pair_layer_ok: rows and columns)
+    esafe = esafe && pair_layer_ok(L[1]) && pair_layer_ok(L[3]);
     net->embed_safe = esafe;
+    D.p_l2_inv = 1.0f / layer_pair_scale(L[1]);
+    D.a_l2_inv = 1.0f / layer_pair_scale(L[3]);
     // fp16 pairs (k_mainnet_pair, the default since round 5): scaled per layer and per batch row, so no absolute magnitude matters;
     // what must hold is that every weight row survives the pairing to fp32 accuracy and no column is dwarfed (pair_layer_ok)
     net->pair_safe = pair_layer_ok(fc0) && pair_layer_ok(fc1) && pair_layer_ok(v2);
