@@ -32,7 +32,7 @@ for k in range(configs):
     res = np.array([O.LIB.oracle_result_from_state(O.ptr(b[i])) for i in range(n)], dtype=np.uint8)
     c1, n1 = ctx.choices(b, res, 0)
     c2, n2 = ctx.choices(b, res, 1)
-    for mode in ("split", "fp32"):
+    for mode in ("pair", "split", "fp32"):
         net.set_main_precision(mode)
         plain = net.value_inference(b, d)
         vals, l1, l2 = net.value_policy_inference(b, d, c1, n1, c2, n2)
@@ -50,4 +50,4 @@ for k in range(configs):
         worst_v, worst_l = max(worst_v, ev), max(worst_l, el)
     print("config %2d  hidden %3d value_hidden %3d policy_hidden %3d act %d  n %3d steps %2d  ok" % (k, hid, vh, ph, act, n, steps), flush=True)
     net.close()
-print("leaf fuzz: %d random shapes x 2 main-net modes, worst |value - oracle| %.2e, worst |logit - oracle| %.2e" % (configs, worst_v, worst_l))
+print("leaf fuzz: %d random shapes x 3 main-net modes, worst |value - oracle| %.2e, worst |logit - oracle| %.2e" % (configs, worst_v, worst_l))
