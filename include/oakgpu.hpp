@@ -328,7 +328,7 @@ private:
 // wait for each other (cpp/src/generate.cc:527-536); per-playout prep = mcts.h:250-263, the playout = mcts.h:448-496.
 class RootSteps {
 public:
-  RootSteps(Context &ctx, uint32_t roots, uint32_t replicas, uint32_t slice = 32, uint32_t max_steps = 1000) : roots_{roots} {
+  RootSteps(Context &ctx, uint32_t roots, uint32_t replicas, uint32_t slice = 16, uint32_t max_steps = 1000) : roots_{roots} {
     check(oakgpu_root_steps_create(ctx.get(), roots, replicas, slice, max_steps, &rs_));
   }
   ~RootSteps() { oakgpu_root_steps_destroy(rs_); }

@@ -247,7 +247,7 @@ class RootSteps:
     (`per` int64 per rank) on the current stream: the path's ONE collective.  step() is asynchronous; finish() returns the step's
     record once its aggregates are on the host."""
 
-    def __init__(self, ctx, device, root_battles, root_durations, root_results, lane_prng, roots, reps, slice=64, max_steps=1000,
+    def __init__(self, ctx, device, root_battles, root_durations, root_results, lane_prng, roots, reps, slice=16, max_steps=1000,
                  world=1, exchange=None, per=None):
         import ctypes as C
         from . import _lib
