@@ -1220,6 +1220,85 @@ __global__ __launch_bounds__(BLOCK) void k_tree_step(uint8_t *battles, uint8_t *
   store_state(state, battles, base, count);
 }
 
+// Round 5: the same tree level on the REGISTER-resident engine, staged like k_rollout_staged -- one wave per workgroup, its 64
+// battles moved between global memory and LDS with coalesced 1-KB accesses, 35 KB of LDS (four workgroups per CU) instead of
+// k_tree_step's 100 KB workgroup of four waves whose every field access is an LDS round trip.  A search level is a launch of
+// 4-32 k lanes that does not fill the device: its time is the latency of ONE wave's turn-step, which is what the register engine
+// halves (6.4 us for a dense lone wave).  Chance actions (EngineR<.., TRACK_ACTIONS>) and the damage-roll clamp (the override byte
+// in SideR::misc) are the register engine's own; outputs are byte for byte k_tree_step's (tests/test_gpu_parity.py:
+// test_tree_step_levels_match_the_oracle runs both against the oracle).
+struct TreeStepArgs {
+  uint8_t *battles, *durations, *results;
+  const uint8_t *c1, *c2;
+  uint8_t *actions, *ch1, *cnt1, *ch2, *cnt2;
+  uint32_t n, rolls;
+};
+__global__ __launch_bounds__(64, 2) void k_tree_step_staged(TreeStepArgs a) {
+  extern __shared__ __align__(16) uint8_t smem[];
+  lds_u32 *party = (lds_u32 *)smem;
+  using ER = EngineR<64, true, true>;
+  Tables T = stage_default_tables((lds_u8 *)smem + ER::PARTY_WORDS * 64 * 4);
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  typedef OAK_LDS u32x4 lds_u128;
+  lds_u32 *stage = (lds_u32 *)((lds_u8 *)smem + ER::PARTY_WORDS * 64 * 4 + TABLE_LDS_PAD);
+  static_assert(sizeof(TreeStepArgs) <= STAGED_COLD_BYTES, "parked arguments fit");
+  lds_u32 *cold = stage + 64 * STAGE_STRIDE; // the pointers are parked in LDS across the turn-step (k_rollout_staged: the SGPRs they would hold are needed for exec masks)
+  if (threadIdx.x < sizeof(TreeStepArgs) / 4) cold[threadIdx.x] = ((const uint32_t *)&a)[threadIdx.x];
+#define TS_PTR(field, type) cold_ptr_at<type>(cold, offsetof(TreeStepArgs, field))
+  const uint32_t tid = threadIdx.x, base = blockIdx.x * 64, lane = base + tid;
+  const uint32_t cnt = a.n - base < 64 ? a.n - base : 64; // battles of this wave
+  {
+    const u32x4 *src = (const u32x4 *)(a.battles + (size_t)base * 384);
+    u32x4 t[24];
+#pragma unroll
+    for (int k = 0; k < 24; ++k) { const uint32_t i = k * 64 + tid; t[k] = src[i < cnt * 24 ? i : 0]; }
+#pragma unroll
+    for (int k = 0; k < 24; ++k) { const uint32_t i = k * 64 + tid, b = i / 24, w = i - b * 24; *(lds_u128 *)(stage + b * STAGE_STRIDE + 4 * w) = t[k]; }
+  }
+  __syncthreads();
+  const uint32_t n_all = (uint32_t)__builtin_amdgcn_readfirstlane((int)cold[offsetof(TreeStepArgs, n) / 4]);
+  const uint32_t rolls = (uint32_t)__builtin_amdgcn_readfirstlane((int)cold[offsetof(TreeStepArgs, rolls) / 4]);
+  const uint32_t pc1 = lane < n_all ? TS_PTR(c1, const uint8_t *)[lane] : 0xFFu;
+  if (pc1 != 0xFF) {
+    ER e;
+    e.m = party + tid;
+    e.T = T;
+    uint32_t *d = TS_PTR(durations, uint32_t *) + 2 * (size_t)lane;
+    e.load_battle_global((const uint8_t *)(stage + tid * STAGE_STRIDE), d[0], d[1]);
+    if (rolls != 39) { // battle_options_set's clamp (mcts.h:569-604): override bytes from the last two bytes of battle.rng
+      const uint32_t hi = (uint32_t)(e.rng >> 32);
+      e.S.misc |= roll_byte(rolls, (hi >> 16) & 0xFF) << 16;
+      e.F.misc |= roll_byte(rolls, hi >> 24) << 16;
+    }
+    e.actS = e.actF = 0;
+    const uint32_t r = e.update(pc1, TS_PTR(c2, const uint8_t *)[lane]);
+    TS_PTR(results, uint8_t *)[lane] = (uint8_t)r;
+    d[0] = e.S.dur;
+    d[1] = e.F.dur;
+    uint64_t *ad = TS_PTR(actions, uint64_t *) + 2 * (size_t)lane;
+    ad[0] = e.actS;
+    ad[1] = e.actF;
+#pragma unroll 1
+    for (int pl = 0; pl < 2; ++pl) {
+      const auto c = e.choices(pl ? e.F : e.S, pl == 0 ? (r >> 4) & 3 : (r >> 6) & 3);
+      uint8_t *out = (pl ? TS_PTR(ch2, uint8_t *) : TS_PTR(ch1, uint8_t *)) + (size_t)lane * OAKGPU_MAX_CHOICES;
+      (pl ? TS_PTR(cnt2, uint8_t *) : TS_PTR(cnt1, uint8_t *))[lane] = (r & 15) ? 0 : (uint8_t)c.n;
+      for (uint32_t i = 0; i < OAKGPU_MAX_CHOICES; ++i) out[i] = i < c.n ? (uint8_t)c.get(i) : 0;
+    }
+    e.store_battle_global((uint8_t *)(stage + tid * STAGE_STRIDE));
+  }
+  __syncthreads();
+  u32x4 *dst = (u32x4 *)(TS_PTR(battles, uint8_t *) + (size_t)base * 384);
+  uint32_t cnt_out = cnt;
+  asm volatile("" : "+s"(cnt_out)); // (opaque: k_rollout_staged -- the bounds tests' lane masks would otherwise live across the turn-step)
+#pragma unroll
+  for (int k = 0; k < 24; ++k) {
+    const uint32_t i = k * 64 + tid, b = i / 24, w = i - b * 24;
+    if (i < cnt_out * 24) dst[i] = *(const lds_u128 *)(stage + b * STAGE_STRIDE + 4 * w);
+  }
+#undef TS_PTR
+}
+
 // ---- PokeEngine::Eval (cpp/include/search/poke-engine-evaluate.h:9-204): the hand-written fp32 position score the
 // reference uses as its default data-generation evaluator.  One lane per battle, straight from the AoS bytes.
 __device__ __forceinline__ float pe_boost(uint32_t nib) { // get_boost_multiplier (:52-85) of a 4-bit two's-complement stage
@@ -1534,6 +1613,7 @@ static int set_lds_limits() {
   HIPCHK(hipFuncSetAttribute((const void *)oak::k_update, hipFuncAttributeMaxDynamicSharedMemorySize, oak::ENGINE_LDS_BYTES));
   HIPCHK(hipFuncSetAttribute((const void *)oak::k_choices, hipFuncAttributeMaxDynamicSharedMemorySize, oak::ENGINE_LDS_BYTES));
   HIPCHK(hipFuncSetAttribute((const void *)oak::k_tree_step, hipFuncAttributeMaxDynamicSharedMemorySize, oak::ENGINE_LDS_BYTES));
+  HIPCHK(hipFuncSetAttribute((const void *)oak::k_tree_step_staged, hipFuncAttributeMaxDynamicSharedMemorySize, oak::STAGED_LDS_BYTES));
   HIPCHK(hipFuncSetAttribute((const void *)oak::k_init, hipFuncAttributeMaxDynamicSharedMemorySize, oak::ENGINE_LDS_BYTES));
   HIPCHK(hipFuncSetAttribute((const void *)oak::k_random_ou, hipFuncAttributeMaxDynamicSharedMemorySize, oak::ENGINE_LDS_BYTES));
   return 0;
@@ -2212,8 +2292,13 @@ int oakgpu_tree_step_dev(oakgpu_ctx *c, uint8_t *battles, uint8_t *durations, ui
     return bad("oakgpu_tree_step_dev: null required pointer");
   if (!(rolls == 1 || rolls == 2 || rolls == 3 || rolls == 20 || rolls == 39)) return bad("oakgpu_tree_step_dev: rolls must be 1, 2, 3, 20 or 39");
   HIPCHK(hipSetDevice(c->device));
-  hipLaunchKernelGGL(oak::k_tree_step, dim3(grid_for(n)), dim3(oak::BLOCK), oak::ENGINE_LDS_BYTES, c->stream, battles, durations,
-                     results, c1, c2, n, rolls, actions, p1_choices, p1_counts, p2_choices, p2_counts);
+  static const bool lds_engine = getenv("OAKGPU_TREE_STEP") && strcmp(getenv("OAKGPU_TREE_STEP"), "lds") == 0; // (A/B: the LDS-resident engine's kernel)
+  if (!lds_engine && ((uintptr_t)battles & 15) == 0 && ((uintptr_t)durations & 3) == 0 && ((uintptr_t)actions & 7) == 0) {
+    const oak::TreeStepArgs ta{battles, durations, results, c1, c2, actions, p1_choices, p1_counts, p2_choices, p2_counts, n, rolls};
+    hipLaunchKernelGGL(oak::k_tree_step_staged, dim3((n + 63) / 64), dim3(64), oak::STAGED_LDS_BYTES, c->stream, ta);
+  } else
+    hipLaunchKernelGGL(oak::k_tree_step, dim3(grid_for(n)), dim3(oak::BLOCK), oak::ENGINE_LDS_BYTES, c->stream, battles, durations,
+                       results, c1, c2, n, rolls, actions, p1_choices, p1_counts, p2_choices, p2_counts);
   HIPCHK(hipGetLastError());
   return 0;
 }

@@ -1,5 +1,7 @@
 """GPU parity tests proper: HIP path (through the C ABI) vs the CPU oracle, bit-exact."""
 import ctypes as C
+import os
+import sys
 
 import numpy as np
 import pytest
@@ -108,6 +110,19 @@ def test_stepwise_update_choices_actions(gpu_ctx):
         gd[~live] = d[~live]
         gr = np.where(live, gres, gr).astype(np.uint8)
         r = gr.copy()
+
+
+def test_tree_step_levels_match_the_oracle(gpu_ctx):
+    """oakgpu_tree_step_dev (one search level: joint action, result, chance-action key, both players' next choices) over random
+    walks, finished lanes and every damage-roll clamp, every output byte against the oracle -- the default kernel (round 5: the
+    register-resident engine, staged) in this process, the LDS-resident engine's kernel in a child with OAKGPU_TREE_STEP=lds."""
+    import subprocess
+    import tree_step_check
+    assert tree_step_check.run(gpu_ctx) > 20000
+    assert tree_step_check.run(gpu_ctx, n=64 * 5 + 1, levels=12, seed0=0x7EE51000) > 1000      # a ragged last wave of one lane
+    env = dict(os.environ, OAKGPU_TREE_STEP="lds")
+    p = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tree_step_check.py"), "700", "25"], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "kernel: lds" in p.stdout, (p.stdout[-1000:], p.stderr[-3000:])
 
 
 def test_init_battle_matches_oracle_and_golden(gpu_ctx):
