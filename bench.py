@@ -545,7 +545,7 @@ def leaf_records(args, torch, dev, rank, local_rank, world, dist, which=("leaf",
     MAIN_PRODUCTS = {"pair": 3, "split": 6, "fp32": 1}[main_mode]   # matrix-pipe products executed per algorithmic multiply-add
     EMB = ("fp32 results throughout.  Embedding nets: one-hot rows summed in fp32 on the vector ALUs; dense features, the move of the sums into the item "
            "lanes and the second layers as exact bf16 triples on the bf16 pipe.  ")
-    ARITH = {"pair": EMB + "Main net: every fp32 value times an exact power of two (one per layer for the weights, one per batch row for the activations) is the sum of "
+    ARITH = {"pair": EMB + "Main net: every fp32 value times an exact power of two (one per weight row = output feature, one per batch row for the activations) is the sum of "
                            "two round-to-nearest fp16 parts (to 2^-24), and every product runs as its three largest fp16 x fp16 partial products (exact in the fp32 "
                            "accumulator; dropped: < 2^-24 of the product) on v_mfma_f32_32x32x16_f16, fp32 accumulation; error vs float64 at the fp32-MFMA "
                            "kernel's level (tests/test_gpu_leafnet.py::test_pair_and_triple_main_nets_are_fp32_results)",

@@ -491,7 +491,7 @@ void oakgpu_net_free(oakgpu_ctx *ctx, oakgpu_net *net);
 int oakgpu_net_shape(const oakgpu_net *net, int *in_dim, int *hidden, int *value_hidden, int *policy_hidden);
 /* How the main net's three dense layers are multiplied (results are fp32 either way, held to the same 1e-5 against the
  * oracle and to 1e-6 against a float64 evaluation): OAKGPU_MAIN_PAIR (default since round 5) = every fp32 value times an exact
- * power of two (one per layer for the weights, one per batch row for the activations) as the sum of two round-to-nearest fp16
+ * power of two (one per weight row = output feature, one per batch row for the activations) as the sum of two round-to-nearest fp16
  * parts, three fp16 MFMAs per multiply-add block, fp32 accumulation (k_mainnet_pair); OAKGPU_MAIN_SPLIT = every fp32 value as
  * an exact sum of three bf16 parts, six bf16 MFMAs per block (k_mainnet_split: 190-200 us per 65,536 leaves); OAKGPU_MAIN_FP32 =
  * fp32 MFMA (k_mainnet_wave: 336 us).  The environment variable OAKGPU_MAIN_NET=fp32 / bf16x3 makes one of the latter the
@@ -507,9 +507,9 @@ int oakgpu_net_set_main_precision(oakgpu_net *net, int mode);
  * weight (fc0 / fc1 / value_fc2) above 2^20 in magnitude runs its main net on fp32 MFMA, and a request for OAKGPU_MAIN_SPLIT
  * is not honoured for it (tests/test_gpu_leafnet.py: layers scaled by 2^-100 / 2^-120 / 2^+100, alone and compensated).  The
  * embedding nets' passes multiply as bf16 triples as well; a weight above 2^20 in their second layers or in the main net sends them
- * through the fp32-MFMA form (k_embed_lds) instead.  (3) The fp16 pairs are scaled per layer and per batch row, so no absolute
- * magnitude matters to them; what must hold is that every weight ROW survives the pairing to fp32 accuracy (the sum of what its
- * pairs miss within 2^-23 of the sum of its magnitudes: a row of tiny weights in a layer with one huge weight elsewhere fails) and
+ * through the fp32-MFMA form (k_embed_lds) instead.  (3) The fp16 pairs are scaled per weight row and per batch row, so no absolute
+ * magnitude matters to them; what must hold is that every weight ROW survives the pairing to fp32 accuracy under its own scale (the
+ * sum of what its pairs miss within 2^-23 of the sum of its magnitudes: only rows beyond 2^+-100 fail) and
  * that no non-zero weight COLUMN lies more than 2^14 below the layer's largest weight (a network that compensates tiny weights
  * with huge inputs is the same function in fp32 but not in a 5-bit exponent) -- a network that fails either runs on the triples, or
  * on fp32 MFMA by (2).  Returns the mode in effect (-1: null net); *split_allowed

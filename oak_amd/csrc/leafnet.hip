@@ -32,7 +32,6 @@ struct NetDev {
   const float *a_w0d, *a_img; // k_embed_arows: padded W0^T (move rows), and the image of its LDS weights (arows_image)
   const float *p_img;         // k_embed_prows: the image of its LDS weights (prows_image)
   int p_hidden, p_out, a_hidden, a_out;
-  float p_l2_inv, a_l2_inv;   // 1 / the scale of the second layers' fp16 pairs in p_img / a_img (embed_pair_order)
   int side_dim, emb_dim;
   int activation; // 1 relu, 2 clamp
   // main net (value path), rows padded to multiples of 32 with zeros
@@ -46,7 +45,7 @@ struct NetDev {
   int ws_T0, ws_NB;
   // k_mainnet_pair: the same stream as scaled fp16 pairs (pair_stream), and 1 / the scale of each of the three layers
   const uint16_t *wp;
-  float wp_inv[3];
+  const float *wp_inv;        // 1 / the scale of every output row: [fc0: H | fc1: H | value_fc2: VH] (padded rows: 0)
   // policy heads (main-net.h:67-107): fc2 [PHp][H] (rows padded to 32), fc3 [315][PHp] (+ biases)
   const float *q1a, *q1a_b, *q1b, *q1b_b, *q2a, *q2a_b, *q2b, *q2b_b;
   const float *q1a_f, *q2a_f; // fc2 of the two heads as k_policy_rows' A operand (policy_frag_order)
@@ -749,7 +748,7 @@ __device__ __forceinline__ float embed_layer2(const f32x16 (&hb)[4], const uint8
 struct __attribute__((packed, aligned(4))) f4u { float x, y, z, w; };
 template <int NBMAX>
 __device__ __forceinline__ void embed_scatter(float *emb, uint32_t doff, float hpr, uint32_t hh, const f32x16 (&acc)[NBMAX], int NBo, int out_dim,
-                                              const float *bias, int activation, float inv) { // inv: 1 / (the item's scale x the layer's), exact
+                                              const float *bias, int activation, float inv) { // inv: 1 / the item's scale; bias + 32 NBo: 1 / the scales of W1's rows (embed_pair_order)
   float4 b[NBMAX][4];
 #pragma unroll
   for (int nb = 0; nb < NBMAX; ++nb)
@@ -760,8 +759,9 @@ __device__ __forceinline__ void embed_scatter(float *emb, uint32_t doff, float h
   for (int nb = 0; nb < NBMAX; ++nb)
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      o[nb][4 * g + 0] = acc[nb][4 * g + 0] * inv + b[nb][g].x; o[nb][4 * g + 1] = acc[nb][4 * g + 1] * inv + b[nb][g].y;
-      o[nb][4 * g + 2] = acc[nb][4 * g + 2] * inv + b[nb][g].z; o[nb][4 * g + 3] = acc[nb][4 * g + 3] * inv + b[nb][g].w;
+      const float4 sc = nb < NBo ? *(const float4 *)(bias + 32 * NBo + 32 * nb + 8 * g + 4 * hh) : make_float4(0.f, 0.f, 0.f, 0.f);
+      o[nb][4 * g + 0] = acc[nb][4 * g + 0] * inv * sc.x + b[nb][g].x; o[nb][4 * g + 1] = acc[nb][4 * g + 1] * inv * sc.y + b[nb][g].y;
+      o[nb][4 * g + 2] = acc[nb][4 * g + 2] * inv * sc.z + b[nb][g].z; o[nb][4 * g + 3] = acc[nb][4 * g + 3] * inv * sc.w + b[nb][g].w;
     }
   act_blocks<NBMAX>(o, activation);
   // (opaque per call: the width tests below depend on the lane's half only, so the compiler hoisted all 48 of them -- 64-bit lane
@@ -853,7 +853,7 @@ constexpr int AR_WAVES = OAK_EMBED_WAVES, AR_BLOCK = 64 * AR_WAVES;
 constexpr int AR_DENSE_WORDS = AR_KT * 4 * 3 * 64 * 2; // the dense weights' triples: [k-step][channel block][h m l][lane] x 8 B (dense_layer_bf16)
 constexpr int AR_COMBINED = 428; // first precombined (active + stored) move row of a_w0d: behind W0^T's 427 rows and the zero row
 constexpr int AR_MAX_NBO = 3; // W1 as bf16 triples: 24 KB per 32-wide output block; four blocks (outputs above 96) do not fit beside the rest
-constexpr size_t ar_bytes(int nbo) { return (size_t)((AR_SPARSE + 1) * ER_RS + AR_DENSE_WORDS + AR_WAVES * AR_WAVE_WORDS + 32 * nbo) * 4 + (size_t)nbo * E2_BLOCK_BYTES; }
+constexpr size_t ar_bytes(int nbo) { return (size_t)((AR_SPARSE + 1) * ER_RS + AR_DENSE_WORDS + AR_WAVES * AR_WAVE_WORDS + 64 * nbo) * 4 + (size_t)nbo * E2_BLOCK_BYTES; }
 // channel held by register s (0..63) of a lane in half hh: the C layout of four 32x32 MFMA blocks, block b's row i being
 // channel 4 i + b (so that a lane's float4 of a weight row feeds the four blocks)
 __host__ __device__ constexpr int ar_channel(int s, int hh) { return 4 * ((s & 3) + 8 * ((s & 15) >> 2) + 4 * hh) + (s >> 4); }
@@ -863,7 +863,7 @@ __host__ __device__ constexpr int ar_dense_row(int d) { return d < 6 ? d - 1 : d
 __device__ __forceinline__ uint32_t ar_sparse_slot(uint32_t row) { return row < 20 ? row - 5 : row < 229 ? row - 209 + 15 : row - 398 + 35; }
 __host__ __device__ constexpr int ar_sparse_row(int slot) { return slot < 15 ? slot + 5 : slot < 35 ? slot - 15 + 209 : slot - 35 + 398; }
 // bias (padded to 32 NBo floats) behind W1's triples in both images: embed_scatter reads it from LDS
-constexpr int ar_img_words(int nbo) { return (AR_SPARSE + 1) * ER_RS + AR_DENSE_WORDS + nbo * (E2_BLOCK_BYTES / 4) + 32 * nbo; }
+constexpr int ar_img_words(int nbo) { return (AR_SPARSE + 1) * ER_RS + AR_DENSE_WORDS + nbo * (E2_BLOCK_BYTES / 4) + 64 * nbo; } // (... + b1 + 1 / W1's row scales)
 template <int WAVES, int NBO>
 __device__ __forceinline__ void embed_arows_body(const EmbedTileArgs &a, float *lds_f, const uint32_t bid, const uint32_t nblocks) {
   constexpr int BLOCK = WAVES * 64;
@@ -1084,7 +1084,7 @@ __device__ __forceinline__ void embed_arows_body(const EmbedTileArgs &a, float *
     // wait for them does not wait for the stores (vmcnt retires in order)
     if (next < nmt) encode_compute(next);
     EL_MARK(7);
-    embed_scatter<NBO>(a.emb, cur_doff, cur_hpr, hh, acc, NBO, out_dim, b1s, N.activation, inv_item * N.a_l2_inv);
+    embed_scatter<NBO>(a.emb, cur_doff, cur_hpr, hh, acc, NBO, out_dim, b1s, N.activation, inv_item);
     EL_MARK(5);
     mt = next;
   }
@@ -1120,7 +1120,7 @@ constexpr int PR_WAVE_WORDS = ER_ITEMS * PR_ITEM_WORDS;
 constexpr int PR_WAVES = OAK_EMBED_WAVES, PR_BLOCK = 64 * PR_WAVES;
 constexpr int PR_DENSE_WORDS = PR_KT * 4 * 3 * 64 * 2;
 constexpr int PR_MAX_NBO = 2;
-constexpr int pr_img_words(int nbo) { return (PR_SPARSE + 1) * ER_RS + PR_DENSE_WORDS + nbo * (E2_BLOCK_BYTES / 4) + 32 * nbo; }
+constexpr int pr_img_words(int nbo) { return (PR_SPARSE + 1) * ER_RS + PR_DENSE_WORDS + nbo * (E2_BLOCK_BYTES / 4) + 64 * nbo; } // (... + b1 + 1 / W1's row scales)
 constexpr size_t PR_BYTES = (size_t)(pr_img_words(PR_MAX_NBO) + PR_WAVES * PR_WAVE_WORDS) * 4;
 static_assert(PR_BYTES <= 160 * 1024, "the party pass's LDS image fits one CU");
 template <bool LIST, int NBO>
@@ -1301,7 +1301,7 @@ __device__ __forceinline__ void embed_prows_body(const EmbedTileArgs &a, float *
     // wait for them does not wait for the stores (vmcnt retires in order)
     if (next < nmt) encode_compute(next);
     EL_MARK(7);
-    embed_scatter<NBO>(a.emb, cur_doff, cur_hpr, hh, acc, NBO, out_dim, b1s, N.activation, inv_item * N.p_l2_inv);
+    embed_scatter<NBO>(a.emb, cur_doff, cur_hpr, hh, acc, NBO, out_dim, b1s, N.activation, inv_item);
     EL_MARK(5);
     mt = next;
   }
@@ -1945,7 +1945,8 @@ __global__ __launch_bounds__(MN_BLOCK) void k_mainnet_split(MainArgs a) {
 // remainder is exact in fp32) and |e| <= 2^-12 |l| <= 2^-24 |x s|.  A product is then h.h + h.l + l.h (three MFMAs of the same
 // rate, each product exact in the fp32 accumulator) and drops l.l <= 2^-24 |x w| -- the error class of the triple form at half
 // the matrix work.  What fp16 lacks is RANGE (5 exponent bits), so every operand is multiplied by an exact power of two first:
-//   * weights: one scale per layer, chosen on the host so that the layer's largest weight lands in [2^14, 2^15) (pair_stream);
+//   * weights: one scale per ROW (= output feature), chosen on the host so that the row's largest weight lands in [2^14, 2^15)
+//     (pair_stream); the accumulators are scaled back per feature, next to the bias;
 //   * activations: one scale PER BATCH ROW (= per lane: the row's values of a layer sit in that lane's registers and its partner
 //     lane's), so that the row's largest value lands in [2^14, 2^15).  For fc1 / value_fc2 the row maximum is read off the
 //     accumulators; for fc0 the row arrives from memory 64 columns at a time, the scale is set from the first chunk and LOWERED
@@ -1965,7 +1966,7 @@ template <int NB> struct MPair {
   static_assert(G % 2 == 0 && 4 % G == 0 && (2 * NB) % G == 0, "k-steps alternate two weight buffers; chunks and layers are whole phases");
   static constexpr int PHASE_BYTES = G * NB * 2048;               // [k-step][block][h l][lane] x 16 B
   static constexpr int PT = (PHASE_BYTES + 4095) / 4096;          // 1-KB DMA pieces per wave per phase, at most
-  static constexpr size_t LDS = 2 * (size_t)PHASE_BYTES + 4 * MAXH * 4;
+  static constexpr size_t LDS = 2 * (size_t)PHASE_BYTES + 7 * MAXH * 4; // + [b0 | b1 | b2 | w3 | 1 / the rows' scales of fc0, fc1, value_fc2]
 };
 template <int NB>
 __device__ __forceinline__ void mp_dma_phase(const uint8_t *src, uint8_t *dst, int tid) {
@@ -2031,18 +2032,19 @@ __device__ __forceinline__ void mp_kstep(f32x16 (&acc)[NB], const f16x8 (&B)[2],
     __builtin_amdgcn_sched_barrier(0);
   }
 }
-// the accumulators back to the layer's real values (x 1 / row scale x 1 / layer scale: two exact factors), bias, activation
+// the accumulators back to the layer's real values (x 1 / the batch row's scale x 1 / the weight row's: two exact factors), bias, activation
 template <int NB>
-__device__ __forceinline__ void mp_bias_act(f32x16 (&acc)[NB], float inv_row, float inv_layer, const float *bias, int h, int activation) {
+__device__ __forceinline__ void mp_bias_act(f32x16 (&acc)[NB], float inv_row, const float *inv_out, const float *bias, int h, int activation) {
 #pragma unroll
   for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const float4 b = *(const float4 *)(bias + 32 * nb + 8 * g + 4 * h);
-      acc[nb][4 * g + 0] = act_fn(acc[nb][4 * g + 0] * inv_row * inv_layer + b.x, activation);
-      acc[nb][4 * g + 1] = act_fn(acc[nb][4 * g + 1] * inv_row * inv_layer + b.y, activation);
-      acc[nb][4 * g + 2] = act_fn(acc[nb][4 * g + 2] * inv_row * inv_layer + b.z, activation);
-      acc[nb][4 * g + 3] = act_fn(acc[nb][4 * g + 3] * inv_row * inv_layer + b.w, activation);
+      const float4 s = *(const float4 *)(inv_out + 32 * nb + 8 * g + 4 * h); // 1 / the scale of the weights' row = output feature
+      acc[nb][4 * g + 0] = act_fn(acc[nb][4 * g + 0] * inv_row * s.x + b.x, activation);
+      acc[nb][4 * g + 1] = act_fn(acc[nb][4 * g + 1] * inv_row * s.y + b.y, activation);
+      acc[nb][4 * g + 2] = act_fn(acc[nb][4 * g + 2] * inv_row * s.z + b.z, activation);
+      acc[nb][4 * g + 3] = act_fn(acc[nb][4 * g + 3] * inv_row * s.w + b.w, activation);
     }
 }
 // a layer whose input is the previous layer's activations in registers; returns the row's scale (the caller scales back)
@@ -2093,10 +2095,12 @@ __global__ __launch_bounds__(MN_BLOCK) void k_mainnet_pair(MainArgs a) {
   using M = MPair<NB>;
   const NetDev &N = a.net;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
-  float *vec = (float *)(lds_b + 2 * M::PHASE_BYTES); // [b0 | b1 | b2 | w3], MAXH each
+  float *vec = (float *)(lds_b + 2 * M::PHASE_BYTES); // [b0 | b1 | b2 | w3 | 1 / row scales of fc0 | fc1 | value_fc2], MAXH each
   for (int i = tid; i < MAXH; i += MN_BLOCK) {
     vec[i] = i < N.H ? N.b0[i] : 0.0f; vec[MAXH + i] = i < N.H ? N.b1[i] : 0.0f;
     vec[2 * MAXH + i] = i < N.VH ? N.b2[i] : 0.0f; vec[3 * MAXH + i] = i < N.VH ? N.w3[i] : 0.0f;
+    vec[4 * MAXH + i] = i < N.H ? N.wp_inv[i] : 0.0f; vec[5 * MAXH + i] = i < N.H ? N.wp_inv[N.H + i] : 0.0f;
+    vec[6 * MAXH + i] = i < N.VH ? N.wp_inv[2 * N.H + i] : 0.0f;
   }
   const int T0 = N.ws_T0, K = N.emb_dim;
   MSRing R{0, 0, (T0 + 4 * NB) / M::G, (const uint8_t *)N.wp, lds_b}; // fc0: T0 k-steps, fc1 and value_fc2: 2 NB each
@@ -2176,12 +2180,12 @@ __global__ __launch_bounds__(MN_BLOCK) void k_mainnet_pair(MainArgs a) {
 #undef MP_LOAD_ROW
     mp_wait_a<0>(A0); // (four k-steps per chunk: the buffer in flight behind the last one is A0)
     MS_MARK(0);
-    mp_bias_act<NB>(X, mp_inverse(scale), N.wp_inv[0], vec, h, N.activation);
+    mp_bias_act<NB>(X, mp_inverse(scale), vec + 4 * MAXH, vec, h, N.activation);
     MS_MARK(1);
     // ---- fc1 ----
     const float s1 = mp_reg_layer<NB>(Y, X, R, tid);
     MS_MARK(2);
-    mp_bias_act<NB>(Y, mp_inverse(s1), N.wp_inv[1], vec + MAXH, h, N.activation);
+    mp_bias_act<NB>(Y, mp_inverse(s1), vec + 5 * MAXH, vec + MAXH, h, N.activation);
     if (a.h1_out && n_rows && (uint32_t)r < n_rows) { // keep fc1's activations for the policy heads (row-major n x H)
       float *dst = a.h1_out + (size_t)(row0 + r) * N.H;
 #pragma unroll
@@ -2194,7 +2198,7 @@ __global__ __launch_bounds__(MN_BLOCK) void k_mainnet_pair(MainArgs a) {
     MS_MARK(3);
     const float s2 = mp_reg_layer<NB>(X, Y, R, tid);
     MS_MARK(4);
-    const float i2 = mp_inverse(s2), il2 = N.wp_inv[2];
+    const float i2 = mp_inverse(s2);
     float part = 0.0f;
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb)
@@ -2202,10 +2206,11 @@ __global__ __launch_bounds__(MN_BLOCK) void k_mainnet_pair(MainArgs a) {
       for (int g = 0; g < 4; ++g) {
         const float4 b = *(const float4 *)(vec + 2 * MAXH + 32 * nb + 8 * g + 4 * h);
         const float4 w = *(const float4 *)(vec + 3 * MAXH + 32 * nb + 8 * g + 4 * h);
-        part = fmaf(act_fn(X[nb][4 * g + 0] * i2 * il2 + b.x, N.activation), w.x, part);
-        part = fmaf(act_fn(X[nb][4 * g + 1] * i2 * il2 + b.y, N.activation), w.y, part);
-        part = fmaf(act_fn(X[nb][4 * g + 2] * i2 * il2 + b.z, N.activation), w.z, part);
-        part = fmaf(act_fn(X[nb][4 * g + 3] * i2 * il2 + b.w, N.activation), w.w, part);
+        const float4 s = *(const float4 *)(vec + 6 * MAXH + 32 * nb + 8 * g + 4 * h);
+        part = fmaf(act_fn(X[nb][4 * g + 0] * i2 * s.x + b.x, N.activation), w.x, part);
+        part = fmaf(act_fn(X[nb][4 * g + 1] * i2 * s.y + b.y, N.activation), w.y, part);
+        part = fmaf(act_fn(X[nb][4 * g + 2] * i2 * s.z + b.z, N.activation), w.z, part);
+        part = fmaf(act_fn(X[nb][4 * g + 3] * i2 * s.w + b.w, N.activation), w.w, part);
       }
     part += __shfl_xor(part, 32, 64);
     if (h == 0 && (uint32_t)r < n_rows) a.values[row0 + r] = 1.0f / (1.0f + expf(-(part + N.b3)));
@@ -2554,27 +2559,34 @@ std::vector<uint16_t> split_stream(const HostAffine &fc0, const HostAffine &fc1,
 }
 
 // k_mainnet_pair's weight stream: the same order with TWO parts per weight, (h, l) = the fp16 pair of w x scale, scale = the power
-// of two that takes the layer's largest |w| into [2^14, 2^15) (1 for an all-zero layer): byte (((t * NB + nb) * 2 + part) * 64 +
-// lane) * 16 + 2 j.  inv[layer] = 1 / scale.
+// of two that takes the largest |w| of the weight's ROW (= output feature) into [2^14, 2^15) (1 for an all-zero row): byte
+// (((t * NB + nb) * 2 + part) * 64 + lane) * 16 + 2 j.  inv = 1 / scale of every row: [fc0: Hp | fc1: Hp | value_fc2: VHp] (padded rows: 0).
 uint16_t f16_bits(_Float16 v) { uint16_t b; memcpy(&b, &v, 2); return b; }
-float layer_pair_scale(const HostAffine &a) {
-  float m = 0.0f;
-  for (float v : a.w) m = std::fmax(m, std::fabs(v));
+float pair_scale_of(float m) { // the power of two that takes m into [2^14, 2^15); 1 for m = 0
   if (!(m > 0.0f) || !std::isfinite(m)) return 1.0f;
   int e;
   std::frexp(m, &e); // m = f x 2^e, f in [0.5, 1): m in [2^(e-1), 2^e)
-  e = 15 - e;        // (kept inside 2^+-100: the scale, its inverse and their products with a row's scale stay normal fp32 numbers;
-  return std::ldexp(1.0f, e > 100 ? 100 : e < -100 ? -100 : e); // a layer beyond that fails pair_layer_ok or saturates like fp32 does)
+  e = 15 - e;        // (kept inside 2^+-100: the scale, its inverse and their products with a batch row's scale stay normal fp32 numbers;
+  return std::ldexp(1.0f, e > 100 ? 100 : e < -100 ? -100 : e); // a row beyond that fails pair_layer_ok or saturates like fp32 does)
 }
-std::vector<uint16_t> pair_stream(const HostAffine &fc0, const HostAffine &fc1, const HostAffine &v2, uint32_t NB, uint32_t T0, float (&inv)[3]) {
+float row_pair_scale(const HostAffine &a, uint32_t n) {
+  float m = 0.0f;
+  for (uint32_t k = 0; k < a.in; ++k) m = std::fmax(m, std::fabs(a.w[(size_t)n * a.in + k]));
+  return pair_scale_of(m);
+}
+std::vector<uint16_t> pair_stream(const HostAffine &fc0, const HostAffine &fc1, const HostAffine &v2, uint32_t NB, uint32_t T0, uint32_t Hp, uint32_t VHp,
+                                  std::vector<float> &inv) {
   const uint32_t steps = T0 + 4 * NB;
   std::vector<uint16_t> w((size_t)steps * NB * 2 * 64 * 8, 0);
-  const float sc[3] = {layer_pair_scale(fc0), layer_pair_scale(fc1), layer_pair_scale(v2)};
-  for (int l = 0; l < 3; ++l) inv[l] = 1.0f / sc[l];
-  auto put = [&](uint32_t t_flat, const HostAffine &a, float scale, uint32_t nb, uint32_t lane, uint32_t j, uint32_t k) {
+  inv.assign((size_t)2 * Hp + VHp, 0.0f);
+  std::vector<float> sc0(fc0.out), sc1(fc1.out), sc2(v2.out);
+  for (uint32_t n = 0; n < fc0.out; ++n) { sc0[n] = row_pair_scale(fc0, n); inv[n] = 1.0f / sc0[n]; }
+  for (uint32_t n = 0; n < fc1.out; ++n) { sc1[n] = row_pair_scale(fc1, n); inv[Hp + n] = 1.0f / sc1[n]; }
+  for (uint32_t n = 0; n < v2.out; ++n) { sc2[n] = row_pair_scale(v2, n); inv[2 * (size_t)Hp + n] = 1.0f / sc2[n]; }
+  auto put = [&](uint32_t t_flat, const HostAffine &a, const std::vector<float> &sc, uint32_t nb, uint32_t lane, uint32_t j, uint32_t k) {
     const uint32_t n = 32 * nb + (lane & 31);
     if (n >= a.out || k >= a.in) return;
-    const float x = a.w[(size_t)n * a.in + k] * scale;
+    const float x = a.w[(size_t)n * a.in + k] * sc[n];
     const _Float16 hi = (_Float16)x;
     const _Float16 lo = (_Float16)(x - (float)hi);
     const size_t base = ((size_t)t_flat * NB + nb) * 2;
@@ -2585,32 +2597,32 @@ std::vector<uint16_t> pair_stream(const HostAffine &fc0, const HostAffine &fc1, 
     for (uint32_t lane = 0; lane < 64; ++lane)
       for (uint32_t j = 0; j < 8; ++j) {
         const uint32_t hb = lane >> 5;
-        for (uint32_t t = 0; t < T0; ++t) put(t, fc0, sc[0], nb, lane, j, 16 * t + 8 * hb + j);
+        for (uint32_t t = 0; t < T0; ++t) put(t, fc0, sc0, nb, lane, j, 16 * t + 8 * hb + j);
         for (uint32_t t = 0; t < 2 * NB; ++t) {
           const uint32_t reg = 8 * (t & 1) + j, k = 32 * (t >> 1) + (reg & 3) + 8 * (reg >> 2) + 4 * hb;
-          put(T0 + t, fc1, sc[1], nb, lane, j, k);
-          put(T0 + 2 * NB + t, v2, sc[2], nb, lane, j, k);
+          put(T0 + t, fc1, sc1, nb, lane, j, k);
+          put(T0 + 2 * NB + t, v2, sc2, nb, lane, j, k);
         }
       }
   return w;
 }
-// May this layer run as pairs?  Two checks on its weights, both relative to the layer's own scale:
-//   rows    -- the pair of w x scale misses w by at most 2^-24 |w| while its low part is a normal fp16 number and by up to 2^-25 /
-//              scale (= 2^-39 x the layer's largest weight) when it is a subnormal; a row passes when the sum of what its pairs miss
-//              stays within 2^-23 of the sum of its magnitudes -- the normwise error of ONE fp32 rounding per weight (a row of tiny
-//              weights in a layer with one huge weight elsewhere fails);
+// May this layer run as pairs?  Two checks on its weights:
+//   rows    -- every row (= output feature) carries its own scale, so a row of small weights next to rows of large ones loses nothing.
+//              Within a row the pair of w x scale misses w by at most 2^-24 |w| while its low part is a normal fp16 number and by up to
+//              2^-25 / scale (= 2^-39 x the row's largest weight) when it is a subnormal; the row passes when the sum of what its pairs
+//              miss stays within 2^-23 of the sum of its magnitudes -- the normwise error of ONE fp32 rounding per weight;
 //   columns -- a column whose largest weight is more than 2^16 below the layer's largest is carried with fewer bits, which is
 //              harmless while its input is no larger than the others' and wrong when the network compensates small weights with
 //              large inputs (an embedding net scaled up by 2^60 in front of fc0 columns scaled down by 2^60 is the same function in
 //              fp32).  The loader cannot see the inputs, so every non-zero column must reach 2^-14 of the layer's largest weight.
-// With both, a layer's outputs are accurate to ~2^-23 of (the row's largest input) x (the row's weight magnitudes) -- the fp32
+// With both, a layer's outputs are accurate to ~2^-23 of (the batch row's largest input) x (the weight row's magnitudes) -- the fp32
 // multiply-add's own normwise error -- for any input whose values of consequence lie within 2^15 of the row's largest.  A network that
 // fails stays on the bf16 triples, which have fp32's exponent range.
 bool pair_layer_ok(const HostAffine &a) {
-  const float scale = layer_pair_scale(a);
   float layer_max = 0.0f;
   std::vector<float> col_max(a.in, 0.0f);
   for (uint32_t n = 0; n < a.out; ++n) {
+    const float scale = row_pair_scale(a, n);
     double miss = 0.0, mag = 0.0;
     for (uint32_t k = 0; k < a.in; ++k) {
       const float wv = a.w[(size_t)n * a.in + k], x = wv * scale;
@@ -2621,7 +2633,7 @@ bool pair_layer_ok(const HostAffine &a) {
       col_max[k] = std::fmax(col_max[k], std::fabs(wv));
       layer_max = std::fmax(layer_max, std::fabs(wv));
     }
-    if (miss > mag * 0x1p-23) return false;
+    if (miss > mag * 0x1p-23 || !std::isfinite(mag)) return false;
   }
   for (uint32_t k = 0; k < a.in; ++k)
     if (col_max[k] != 0.0f && col_max[k] < layer_max * 0x1p-14f) return false;
@@ -2745,18 +2757,17 @@ uint32_t up32(uint32_t x) { return (x + 31) & ~31u; }
 
 // W1 of an embedding net as scaled fp16 PAIRS in embed_layer2's order (round 5; rounds 3-4: bf16 triples -- the image keeps their three
 // 1-KB parts per k-step, the third is zeros): 16-bit word ((((nb * 8 + T) * 3 + part) * 64 + lane) * 8 + j) = part (0: h, 1: l) of
-// W1[32 nb + (lane & 31)][ar_channel(8 T + j, lane >> 5)] x layer_pair_scale(W1); absent rows / channels are zeros.  Returned as floats
+// W1[32 nb + (lane & 31)][ar_channel(8 T + j, lane >> 5)] x row_pair_scale(W1, that row); absent rows / channels are zeros.  Returned as floats
 // (the LDS image's unit).
 std::vector<float> embed_pair_order(const HostAffine &a, uint32_t NB) {
   std::vector<uint16_t> w((size_t)NB * 8 * 3 * 64 * 8, 0);
-  const float scale = layer_pair_scale(a);
   for (uint32_t nb = 0; nb < NB; ++nb)
     for (uint32_t T = 0; T < 8; ++T)
       for (uint32_t lane = 0; lane < 64; ++lane)
         for (uint32_t j = 0; j < 8; ++j) {
           const uint32_t o = nb * 32 + (lane & 31), c = (uint32_t)oak::ar_channel((int)(8 * T + j), (int)(lane >> 5));
           if (o >= a.out || c >= a.in) continue;
-          const float x = a.w[(size_t)o * a.in + c] * scale;
+          const float x = a.w[(size_t)o * a.in + c] * row_pair_scale(a, o);
           const _Float16 hi = (_Float16)x;
           const _Float16 lo = (_Float16)(x - (float)hi);
           const size_t base = ((size_t)nb * 8 + T) * 3;
@@ -2767,26 +2778,33 @@ std::vector<float> embed_pair_order(const HostAffine &a, uint32_t NB) {
   memcpy(f.data(), w.data(), w.size() * 2);
   return f;
 }
+std::vector<float> row_scale_inverses(const HostAffine &a, uint32_t padded) { // 1 / row_pair_scale of every output row (padded rows: 0)
+  std::vector<float> v(padded, 0.0f);
+  for (uint32_t o = 0; o < a.out; ++o) v[o] = 1.0f / row_pair_scale(a, o);
+  return v;
+}
 
-// the images of the two kernels' LDS weights: [one-hot rows (stride ER_RS) + a zero row | dense fragment | W1's fp16 pairs]
+// the images of the two kernels' LDS weights: [one-hot rows (stride ER_RS) + a zero row | dense fragment | W1's fp16 pairs | b1 | 1 / W1's row scales]
 std::vector<float> arows_image(const HostAffine &a0, const HostAffine &a1) {
   std::vector<float> img((size_t)(oak::AR_SPARSE + 1) * oak::ER_RS, 0.0f);
   for (int sl = 0; sl < oak::AR_SPARSE; ++sl)
     for (uint32_t c = 0; c < a0.out && c < 128; ++c) img[(size_t)sl * oak::ER_RS + c] = a0.w[(size_t)c * a0.in + (uint32_t)oak::ar_sparse_row(sl)];
-  const std::vector<float> d = arows_dense_frag(a0), f = embed_pair_order(a1, (a1.out + 31) / 32), bp = pad_vec(a1.b, up32(a1.out));
+  const std::vector<float> d = arows_dense_frag(a0), f = embed_pair_order(a1, (a1.out + 31) / 32), bp = pad_vec(a1.b, up32(a1.out)), iv = row_scale_inverses(a1, up32(a1.out));
   img.insert(img.end(), d.begin(), d.end());
   img.insert(img.end(), f.begin(), f.end());
   img.insert(img.end(), bp.begin(), bp.end());
+  img.insert(img.end(), iv.begin(), iv.end());
   return img;
 }
 std::vector<float> prows_image(const HostAffine &p0, const HostAffine &p1) {
   std::vector<float> img((size_t)(oak::PR_SPARSE + 1) * oak::ER_RS, 0.0f);
   for (int sl = 0; sl < oak::PR_SPARSE; ++sl)
     for (uint32_t c = 0; c < p0.out && c < 128; ++c) img[(size_t)sl * oak::ER_RS + c] = p0.w[(size_t)c * p0.in + (uint32_t)(sl + 5)];
-  const std::vector<float> d = prows_dense_frag(p0), f = embed_pair_order(p1, (p1.out + 31) / 32), bp = pad_vec(p1.b, up32(p1.out));
+  const std::vector<float> d = prows_dense_frag(p0), f = embed_pair_order(p1, (p1.out + 31) / 32), bp = pad_vec(p1.b, up32(p1.out)), iv = row_scale_inverses(p1, up32(p1.out));
   img.insert(img.end(), d.begin(), d.end());
   img.insert(img.end(), f.begin(), f.end());
   img.insert(img.end(), bp.begin(), bp.end());
+  img.insert(img.end(), iv.begin(), iv.end());
   return img;
 }
 
@@ -2885,7 +2903,9 @@ int oakgpu_net_load_memory(oakgpu_ctx *ctx, const void *bytes, size_t size, oakg
     }
     D.ws = (const uint16_t *)dptr; D.ws_T0 = (int)T0; D.ws_NB = (int)NB;
     {
-      const std::vector<uint16_t> wp = pair_stream(fc0, fc1, v2, NB, T0, D.wp_inv);
+      std::vector<float> wp_inv;
+      const std::vector<uint16_t> wp = pair_stream(fc0, fc1, v2, NB, T0, (uint32_t)H, (uint32_t)VH, wp_inv);
+      rc = rc ? rc : upload(net, wp_inv, &D.wp_inv);
       void *pptr = nullptr;
       if (!rc) {
         he = hipMalloc(&pptr, wp.size() * 2);
@@ -2918,9 +2938,7 @@ int oakgpu_net_load_memory(oakgpu_ctx *ctx, const void *bytes, size_t size, oakg
     // (round 5) ... and their second layers multiply as scaled fp16 pairs, which both must survive (pair_layer_ok: rows and columns)
     esafe = esafe && pair_layer_ok(L[1]) && pair_layer_ok(L[3]);
     net->embed_safe = esafe;
-    D.p_l2_inv = 1.0f / layer_pair_scale(L[1]);
-    D.a_l2_inv = 1.0f / layer_pair_scale(L[3]);
-    // fp16 pairs (k_mainnet_pair, the default since round 5): scaled per layer and per batch row, so no absolute magnitude matters;
+    // fp16 pairs (k_mainnet_pair, the default since round 5): scaled per weight row and per batch row, so no absolute magnitude matters;
     // what must hold is that every weight row survives the pairing to fp32 accuracy and no column is dwarfed (pair_layer_ok)
     net->pair_safe = pair_layer_ok(fc0) && pair_layer_ok(fc1) && pair_layer_ok(v2);
     const char *env = getenv("OAKGPU_MAIN_NET");

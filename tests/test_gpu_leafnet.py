@@ -120,16 +120,17 @@ def _rewrite_net(src, dst, edit):
     open(dst, "wb").write(b"".join(out))
 
 
-@pytest.mark.parametrize("case", ["late_columns_large", "late_columns_huge", "one_huge_weight", "zero_rows"])
+@pytest.mark.parametrize("case", ["late_columns_large", "late_columns_huge", "one_huge_weight", "zero_rows", "small_rows"])
 def test_fp16_pair_main_net_scales(gpu_ctx, tmp_path, case):
     """k_mainnet_pair's power-of-two scales.  fc0 reads a row 64 columns at a time and sets the row's scale from the FIRST chunk (the
     active's block), lowering it -- and rescaling its sums -- when a later chunk holds a larger value: `late_columns_large` multiplies the
     bench Pokemon's embedding net by 2^12 (its blocks come later in the row) and fc0's columns for those blocks by 2^-12 -- the same
     function, and every row rescales.  `late_columns_huge` does the same with 2^60: beyond what a 5-bit exponent carries, the loader's
     column check refuses the pairs and the network runs on the bf16 triples.  `one_huge_weight` plants a 2^19 in fc1: the other rows'
-    low parts fall into fp16 subnormals, the row check refuses the pairs.  `zero_rows`: an fc0 bias so negative that every hidden value
-    of fc0 is zero -- fc1 sees all-zero rows (the scale's floor).  Each against a float64 evaluation of the edited net from the
-    kernel's own embedding."""
+    columns are dwarfed by it, the column check refuses the pairs.  `zero_rows`: an fc0 bias so negative that every hidden value
+    of fc0 is zero -- fc1 sees all-zero rows (the scale's floor).  `small_rows`: every fourth output unit of fc1 and of the bench
+    Pokemon's embedding net scaled by 2^-20 (nearly dead units, as training leaves them): every weight ROW carries its own scale, so
+    the pairs stay and lose nothing.  Each against a float64 evaluation of the edited net from the kernel's own embedding."""
     from oak_amd.engine import Network
     dst = str(tmp_path / "pair_edge.battle.net")
     base = NN.Net(NET256)
@@ -147,6 +148,10 @@ def test_fp16_pair_main_net_scales(gpu_ctx, tmp_path, case):
             W[0, 0] = np.float32(2.0 ** 19)
         if i == 4 and case == "zero_rows":
             return b - np.float32(1e6), W
+        if i in (1, 5) and case == "small_rows":
+            b, W = b.copy(), W.copy()
+            b[::4] *= np.float32(2.0 ** -20)
+            W[::4] *= np.float32(2.0 ** -20)
         return b, W
     _rewrite_net(NET256, dst, edit)
     net, onet = Network(gpu_ctx, path=dst), NN.Net(dst)
@@ -161,6 +166,12 @@ def test_fp16_pair_main_net_scales(gpu_ctx, tmp_path, case):
     with np.errstate(over="ignore"):
         ref = np.array([_main_value_f64(onet, emb[i]) for i in range(b.shape[0])])
     assert np.isfinite(v).all() and np.abs(v - ref).max() <= 1e-6, (case, np.abs(v - ref).max())
+    if case == "small_rows":                              # the embedding's small rows too, held to THEIR size (2^-20 of the others')
+        oemb = np.stack([NN.battle_embedding(onet, b[i], d[i]) for i in range(0, b.shape[0], 7)])
+        small = np.array([s_ * base.side_dim + (1 + base.aod) + q * (1 + base.pod) + 1 + o for s_ in range(2) for q in range(5) for o in range(0, base.pod, 4)])
+        diff = np.abs(emb[::7] - oemb)
+        assert diff.max() <= 2e-5 and diff[:, small].max() <= 2e-5 * 2.0 ** -20, (diff.max(), diff[:, small].max())
+        assert np.abs(oemb[:, small]).max() > 0           # (they are not all clipped away)
     net.set_main_precision("fp32")
     assert np.abs(net.value_inference(b, d) - v).max() <= 1e-6
     net.close()
