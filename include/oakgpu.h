@@ -510,7 +510,7 @@ int oakgpu_net_set_main_precision(oakgpu_net *net, int mode);
  * through the fp32-MFMA form (k_embed_lds) instead.  (3) The fp16 pairs are scaled per weight row and per batch row, so no absolute
  * magnitude matters to them; what must hold is that every weight ROW survives the pairing to fp32 accuracy under its own scale (the
  * sum of what its pairs miss within 2^-23 of the sum of its magnitudes: only rows beyond 2^+-100 fail) and
- * that no non-zero weight COLUMN lies more than 2^14 below the layer's largest weight (a network that compensates tiny weights
+ * that no non-zero weight COLUMN lies more than 2^18 below the layer's largest weight (a network that compensates tiny weights
  * with huge inputs is the same function in fp32 but not in a 5-bit exponent) -- a network that fails either runs on the triples, or
  * on fp32 MFMA by (2).  Returns the mode in effect (-1: null net); *split_allowed
  * (nullable) = 0 for a network of case (2). */

@@ -2614,7 +2614,9 @@ std::vector<uint16_t> pair_stream(const HostAffine &fc0, const HostAffine &fc1, 
 //   columns -- a column whose largest weight is more than 2^16 below the layer's largest is carried with fewer bits, which is
 //              harmless while its input is no larger than the others' and wrong when the network compensates small weights with
 //              large inputs (an embedding net scaled up by 2^60 in front of fc0 columns scaled down by 2^60 is the same function in
-//              fp32).  The loader cannot see the inputs, so every non-zero column must reach 2^-14 of the layer's largest weight.
+//              fp32).  The loader cannot see the inputs, so every non-zero column must reach 2^-18 of the layer's largest weight: a column
+//              that small matters only through inputs 2^18 times the others', and is then still carried to 2^-21 (the bound a
+//              nearly dead input unit of a trained network passes, a rescaled one does not).
 // With both, a layer's outputs are accurate to ~2^-23 of (the batch row's largest input) x (the weight row's magnitudes) -- the fp32
 // multiply-add's own normwise error -- for any input whose values of consequence lie within 2^15 of the row's largest.  A network that
 // fails stays on the bf16 triples, which have fp32's exponent range.
@@ -2636,7 +2638,7 @@ bool pair_layer_ok(const HostAffine &a) {
     if (miss > mag * 0x1p-23 || !std::isfinite(mag)) return false;
   }
   for (uint32_t k = 0; k < a.in; ++k)
-    if (col_max[k] != 0.0f && col_max[k] < layer_max * 0x1p-14f) return false;
+    if (col_max[k] != 0.0f && col_max[k] < layer_max * 0x1p-18f) return false;
   return true;
 }
 

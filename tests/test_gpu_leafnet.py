@@ -120,7 +120,7 @@ def _rewrite_net(src, dst, edit):
     open(dst, "wb").write(b"".join(out))
 
 
-@pytest.mark.parametrize("case", ["late_columns_large", "late_columns_huge", "one_huge_weight", "zero_rows", "small_rows"])
+@pytest.mark.parametrize("case", ["late_columns_large", "late_columns_huge", "one_huge_weight", "zero_rows", "small_rows", "dead_columns"])
 def test_fp16_pair_main_net_scales(gpu_ctx, tmp_path, case):
     """k_mainnet_pair's power-of-two scales.  fc0 reads a row 64 columns at a time and sets the row's scale from the FIRST chunk (the
     active's block), lowering it -- and rescaling its sums -- when a later chunk holds a larger value: `late_columns_large` multiplies the
@@ -130,7 +130,8 @@ def test_fp16_pair_main_net_scales(gpu_ctx, tmp_path, case):
     columns are dwarfed by it, the column check refuses the pairs.  `zero_rows`: an fc0 bias so negative that every hidden value
     of fc0 is zero -- fc1 sees all-zero rows (the scale's floor).  `small_rows`: every fourth output unit of fc1 and of the bench
     Pokemon's embedding net scaled by 2^-20 (nearly dead units, as training leaves them): every weight ROW carries its own scale, so
-    the pairs stay and lose nothing.  Each against a float64 evaluation of the edited net from the kernel's own embedding."""
+    the pairs stay and lose nothing; `dead_columns`: input columns at 2^-16 of the layer's largest weight pass the column check (its
+    bound is 2^-18).  Each against a float64 evaluation of the edited net from the kernel's own embedding."""
     from oak_amd.engine import Network
     dst = str(tmp_path / "pair_edge.battle.net")
     base = NN.Net(NET256)
@@ -148,6 +149,9 @@ def test_fp16_pair_main_net_scales(gpu_ctx, tmp_path, case):
             W[0, 0] = np.float32(2.0 ** 19)
         if i == 4 and case == "zero_rows":
             return b - np.float32(1e6), W
+        if i in (4, 5) and case == "dead_columns":        # input units whose weights have decayed to 2^-16 of the others': harmless, the pairs stay
+            W = W.copy()
+            W[:, 3::17] *= np.float32(2.0 ** -16)
         if i in (1, 5) and case == "small_rows":
             b, W = b.copy(), W.copy()
             b[::4] *= np.float32(2.0 ** -20)
