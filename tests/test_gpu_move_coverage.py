@@ -94,3 +94,63 @@ def test_every_move_rollout_bit_exact(gpu_ctx):
     oout, osteps = O.rollout_batch(ob, od, gr, op, max_steps=1000, threads=8)
     assert (got["steps"] == osteps).all() and (got["results"] == oout).all()
     assert (got["battles"] == ob).all() and (got["durations"] == od).all() and (got["prng"] == op).all()
+
+
+def test_every_move_through_the_tree_step_bit_exact(gpu_ctx):
+    """The same move-by-move walks through oakgpu_tree_step_dev -- since round 5 the REGISTER-resident engine with its own chance-action
+    tracking (k_tree_step_staged): every battle / durations / result / action-key byte and both players' next choices against the
+    oracle, every move used at least once, with a damage-roll clamp on every third level."""
+    from hipmem import Dev
+    teams, forced = _teams()
+    n = teams.shape[0]
+    seeds = (np.arange(n, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15) + np.uint64(4242))
+    b = np.stack([O.init_battle(teams[i], int(seeds[i])) for i in range(n)])
+    opts = [O.Options() for _ in range(n)]
+    r = np.array([O.update(b[i], 0, 0, opts[i]) for i in range(n)], dtype=np.uint8)
+    d = np.stack([o.durations for o in opts])
+    lib, h = gpu_ctx.lib, gpu_ctx.handle
+    db, dd, dr = Dev(b), Dev(d), Dev(r)
+    dc1, dc2, dact = Dev(np.zeros(n, np.uint8)), Dev(np.zeros(n, np.uint8)), Dev(np.zeros((n, 16), np.uint8))
+    dch1, dch2, dn1, dn2 = Dev(np.zeros((n, 9), np.uint8)), Dev(np.zeros((n, 9), np.uint8)), Dev(np.zeros(n, np.uint8)), Dev(np.zeros(n, np.uint8))
+    rng = np.random.default_rng(199)
+    used = np.zeros(166, dtype=np.int64)
+    roll_byte = lambda rolls, seed: 236 if rolls == 1 else 217 + (38 // (rolls - 1)) * (seed % rolls)
+    for step in range(36):
+        rolls = 3 if step % 3 == 2 else 39
+        c1, c2 = np.full(n, 0xFF, np.uint8), np.full(n, 0xFF, np.uint8)
+        live = (r & 15) == 0
+        for i in np.nonzero(live)[0]:
+            side, move = forced[i]
+            picks = []
+            for pl in (0, 1):
+                ch = O.choices(b[i], pl, (int(r[i]) >> (4 + 2 * pl)) & 3)
+                pick = int(ch[rng.integers(len(ch))])
+                if pl == side:
+                    for c in ch:
+                        if (int(c) & 3) == 1 and (int(c) >> 2) >= 1 and b[i][184 * pl + 144 + 24 + 2 * ((int(c) >> 2) - 1)] == move:
+                            pick = int(c)
+                            used[move] += 1
+                picks.append(pick)
+            c1[i], c2[i] = picks
+        dc1.put(c1)
+        dc2.put(c2)
+        assert lib.oakgpu_tree_step_dev(h, db.p, dd.p, dr.p, dc1.p, dc2.p, n, rolls, dact.p, dch1.p, dn1.p, dch2.p, dn2.p) == 0
+        gpu_ctx.synchronize()
+        gb, gd, gr, gact, gch1, gch2, gn1, gn2 = db.host(), dd.host(), dr.host(), dact.host(), dch1.host(), dch2.host(), dn1.host(), dn2.host()
+        for i in np.nonzero(live)[0]:
+            over = np.zeros(16, np.uint8)
+            if rolls != 39:
+                over[0], over[8] = roll_byte(rolls, int(b[i][376 + 6])), roll_byte(rolls, int(b[i][376 + 7]))
+            opts[i].set(None, over if rolls != 39 else None)
+            r[i] = O.update(b[i], int(c1[i]), int(c2[i]), opts[i])
+            d[i] = opts[i].durations
+            name = G.MOVE_NAMES[forced[i][1]]
+            assert (gact[i] == opts[i].actions).all(), (step, i, name, "actions")
+            if (int(r[i]) & 15) == 0:
+                o1, o2 = O.choices(b[i], 0, (int(r[i]) >> 4) & 3), O.choices(b[i], 1, (int(r[i]) >> 6) & 3)
+                assert gn1[i] == len(o1) and (gch1[i, :len(o1)] == o1).all() and gn2[i] == len(o2) and (gch2[i, :len(o2)] == o2).all(), (step, i, name)
+        bad = np.nonzero((gb != b).any(axis=1) | (gr != r) | (gd != d).any(axis=1))[0]
+        assert bad.size == 0, "step %d lane %d move %s" % (step, bad[0], G.MOVE_NAMES[forced[bad[0]][1]])
+    assert (used[1:165] > 0).all(), [G.MOVE_NAMES[m] for m in range(1, 165) if used[m] == 0]
+    for x in (db, dd, dr, dc1, dc2, dact, dch1, dch2, dn1, dn2):
+        x.free()
