@@ -199,7 +199,9 @@ int oakgpu_poke_engine_eval(oakgpu_ctx *ctx, const uint8_t *battles, uint32_t n,
  * report result, the 16-byte observation key (pkmn_gen1_battle_options_chance_actions; tree edge key,
  * mcts.h:93-98,359) and BOTH players' legal choices in the new state (n x 9 + n counts each; counts are 0
  * for terminal results).  rolls in {1, 2, 3, 20, 39}: damage-roll clamping of battle_options_set
- * (mcts.h:569-604; 39 = off), override bytes derived from the last two bytes of battle.rng. */
+ * (mcts.h:569-604; 39 = off), override bytes derived from the last two bytes of battle.rng.  Since round 5 the level runs on the
+ * register-resident engine (k_tree_step_staged; 16-byte aligned battles, else -- or with OAKGPU_TREE_STEP=lds in the environment -- on the
+ * LDS-resident engine's k_tree_step); both are held to the oracle byte for byte (tests/tree_step_check.py, test_gpu_move_coverage.py). */
 int oakgpu_tree_step_dev(oakgpu_ctx *ctx, uint8_t *battles, uint8_t *durations, uint8_t *results, const uint8_t *c1,
                          const uint8_t *c2, uint32_t n, uint32_t rolls, uint8_t *actions, uint8_t *p1_choices,
                          uint8_t *p1_counts, uint8_t *p2_choices, uint8_t *p2_counts);
